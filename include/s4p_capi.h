@@ -1,0 +1,165 @@
+/*
+ * s4p_capi.h -- C ABI of the MI355X-native Super4PCS hot path (libsuper4pcs_amd.so).
+ *
+ * Plain pointers and sizes only; no C++/torch/Eigen types.  Every entry point names
+ * the reference interface (file:line under nmellado/Super4PCS v1.1.3) it replaces.
+ * The reference is a single-process C++ library with no FFI of its own; the "binding"
+ * a maintainer adds is the facade in include/super4pcs/ (see INTEGRATION.md), whose
+ * Match4PCSBase/MatchSuper4PCS bodies call exactly these functions.
+ *
+ * Conventions
+ *   - all point arrays are SoA float32 host pointers (x[], y[], z[]), caller-owned;
+ *   - 4x4 matrices are row-major float[16];
+ *   - every function returns S4P_OK (0) or a negative s4p_status; s4p_last_error()
+ *     gives the message.  Nothing throws across the ABI and nothing allocated
+ *     inside is handed to the caller.
+ *   - one s4p_ctx = one matcher = one host thread = one GPU.
+ *   - there is NO CPU fallback: s4p_create fails if no gfx950 device is present.
+ */
+#ifndef S4P_CAPI_H_
+#define S4P_CAPI_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct s4p_ctx s4p_ctx;
+
+typedef enum {
+  S4P_OK = 0,
+  S4P_ERR_BAD_ARG = -1,
+  S4P_ERR_NO_DEVICE = -2,
+  S4P_ERR_HIP = -3,
+  S4P_ERR_OOM = -4,
+  S4P_ERR_CAPACITY = -5,     /* an on-device pair/quad buffer overflowed; raise s4p_limits */
+  S4P_ERR_UNSUPPORTED = -6,  /* option not supported on the device path */
+  S4P_ERR_STATE = -7
+} s4p_status;
+
+/* Mirrors GlobalRegistration::Match4PCSOptions, src/super4pcs/shared4pcs.h:148-190. */
+typedef struct {
+  float delta;
+  float max_normal_difference;
+  float max_translation_distance;
+  float max_angle;
+  float max_color_distance;
+  uint64_t sample_size;
+  int32_t max_time_seconds;
+  uint32_t random_seed;
+  float terminate_threshold;
+  float overlap_estimation;
+} s4p_options;
+
+/* Device buffer capacities (entries).  0 = library default. */
+typedef struct {
+  uint64_t max_pairs;   /* ordered pairs per ExtractPairs call           */
+  uint64_t max_quads;   /* congruent quads per base                      */
+  uint64_t max_grid_cells; /* cap on the LCP grid size (cells)           */
+} s4p_limits;
+
+/* Result of one RANSAC base (one TryOneBase after base selection),
+ * src/super4pcs/algorithms/match4pcsBase.hpp:328-351. */
+typedef struct {
+  uint64_t n_pairs1;      /* |pairs1|  (ExtractPairs #1)                                  */
+  uint64_t n_pairs2;      /* |pairs2|  (ExtractPairs #2)                                  */
+  uint64_t n_quads;       /* congruent quads found (FindCongruentQuadrilaterals)          */
+  uint64_t n_verified;    /* candidates that passed the rms gate and were LCP-scored      */
+  uint32_t best_count;    /* max inlier count over verified candidates (0 if none)        */
+  int32_t  has_best;      /* 1 if n_verified > 0                                          */
+  uint64_t best_rank;     /* rank of the winner in reference candidate order, or ~0       */
+  int32_t  best_quad[4];  /* indices into sampled Q of the winning congruent quad         */
+  float    best_transform[16];  /* row-major, centred frame (transform_)                  */
+  float    best_centroid2[3];   /* qcentroid2_                                            */
+  float    centroid1[3];        /* qcentroid1_                                            */
+} s4p_base_result;
+
+/* ---- lifecycle ------------------------------------------------------------ */
+int32_t s4p_create(const s4p_options* opt, const s4p_limits* limits /*nullable*/, int32_t device, s4p_ctx** out);
+void    s4p_destroy(s4p_ctx* ctx);
+const char* s4p_last_error(const s4p_ctx* ctx);   /* ctx may be NULL: last create error */
+int32_t s4p_device_name(const s4p_ctx* ctx, char* buf, int32_t buflen);
+
+/* ---- state ---------------------------------------------------------------- */
+/* Uploads the sampled, centred clouds and builds the device structures.
+ * Replaces Match4PCSBase::initKdTree (match4pcsBase.cc:353-363; the kd-tree becomes
+ * a uniform grid with the same inlier predicate, kdtree.h:417-421) and
+ * PairCreationFunctor::synch3DContent (pairCreationFunctor.h:90-122).
+ * Q normals / rgb may be NULL (treated as zero normals / rgb=-1 as Point3D does). */
+int32_t s4p_set_clouds(s4p_ctx* ctx,
+                       const float* px, const float* py, const float* pz, int64_t n_p,
+                       const float* qx, const float* qy, const float* qz,
+                       const float* qnx, const float* qny, const float* qnz,
+                       const float* qr, const float* qg, const float* qb, int64_t n_q);
+
+/* base_3D_ of the current RANSAC base (4 points, ordered as TryQuadrilateral left them):
+ * positions, normals, rgb as float[12] each (normals/rgb nullable).
+ * Replaces PairCreationFunctor::setBase (pairCreationFunctor.h:135-143). */
+int32_t s4p_set_base(s4p_ctx* ctx, const float* base_xyz, const float* base_nrm, const float* base_rgb);
+
+/* ---- hot loop A: MatchSuper4PCS::ExtractPairs (super4pcs.cc:183-224) ------- */
+/* Writes ordered pairs (first,second) in the reference's emission order
+ *  to out_pairs (2 ints per pair, capacity cap pairs); *n_out = m. */
+int32_t s4p_extract_pairs(s4p_ctx* ctx, float pair_distance, float pair_normals_angle,
+                          float pair_distance_epsilon, int32_t base_point1, int32_t base_point2,
+                          int32_t* out_pairs, int64_t cap, int64_t* n_out);
+
+/* ---- hot loop B: MatchSuper4PCS::FindCongruentQuadrilaterals (super4pcs.cc:80-177) */
+/* pairs1/pairs2: 2 ints per pair; out_quads: 4 ints per quad in std::set (id,i) order. */
+int32_t s4p_find_congruent(s4p_ctx* ctx, float invariant1, float invariant2,
+                           float distance_threshold1, float distance_threshold2,
+                           const int32_t* pairs1, int64_t m1, const int32_t* pairs2, int64_t m2,
+                           int32_t* out_quads, int64_t cap, int64_t* n_out);
+
+/* ---- hot loop C: Match4PCSBase::TryCongruentSet (match4pcsBase.hpp:363-497)
+ *      = ComputeRigidTransformation (match4pcsBase.cc:365-500) + Verify (:508-567) */
+/* base_ids: the 4 sampled-P indices of the base; quads: 4 ints each.
+ * per_candidate (nullable, K entries): -1 if the rms gate rejected the quad, else the
+ * integer inlier count of Verify (no early exit).  result: best of this set only. */
+int32_t s4p_try_congruent_set(s4p_ctx* ctx, const int32_t* base_ids, const int32_t* quads, int64_t K,
+                              int32_t* per_candidate, s4p_base_result* result);
+
+/* Match4PCSBase::Verify (match4pcsBase.cc:508-567) for B explicit row-major 4x4
+ * transforms: counts[b] = number of sampled-Q points with a sampled-P point within delta. */
+int32_t s4p_verify_transforms(s4p_ctx* ctx, const float* transforms, int64_t B, uint32_t* counts);
+
+/* ---- fused, device-resident A -> B -> C for one base -------------------------
+ * Equivalent to the body of Match4PCSBase::TryOneBase after SelectQuadrilateral
+ * (match4pcsBase.hpp:313-351): two ExtractPairs, FindCongruentQuadrilaterals,
+ * TryCongruentSet; nothing but the s4p_base_result leaves the GPU.
+ * base_ids: sampled-P indices (ordered); base3D via s4p_set_base beforehand. */
+int32_t s4p_try_base(s4p_ctx* ctx, const int32_t* base_ids, float invariant1, float invariant2,
+                     s4p_base_result* result);
+
+/* Debug/parity access to the last s4p_try_base: per-candidate records in reference order.
+ * quads (4 ints), counts (-1 = gate failed); returns K via n_out. */
+int32_t s4p_last_candidates(s4p_ctx* ctx, int32_t* quads, int32_t* counts, int64_t cap, int64_t* n_out);
+
+/* ---- final apply: Match4PCSBase::Perform_N_steps tail (match4pcsBase.hpp:265-267) */
+/* xyz SoA in place: p <- (M * [p;1]).head<3>() for n points. */
+int32_t s4p_transform_points(s4p_ctx* ctx, const float* M, float* x, float* y, float* z, int64_t n);
+
+/* ---- instrumentation ------------------------------------------------------- */
+typedef struct {
+  uint64_t verify_launches;      /* number of LCP-verify kernel launches timed          */
+  double   verify_ms_total;      /* HIP-event time of those launches (ms)               */
+  uint64_t verify_candidates;    /* candidates LCP-scored in those launches             */
+  uint64_t verify_quads;         /* quads read by those launches (gate evaluated)       */
+  uint64_t verify_point_tests;   /* P-point distance tests (k-bar numerator), if enabled */
+  uint64_t verify_queries;       /* point queries (candidates * n_Q)                    */
+  double   pairs_ms_total, quads_ms_total;
+  uint64_t pairs_launches, quads_launches;
+} s4p_profile;
+int32_t s4p_profile_enable(s4p_ctx* ctx, int32_t enable_events, int32_t count_point_tests);
+int32_t s4p_profile_get(s4p_ctx* ctx, s4p_profile* out, int32_t reset);
+
+/* IEEE self-test of the device float path (sqrt, divide, no-FMA mul/add) against the
+ * values the host computed for the same inputs; returns number of mismatches in *n_bad. */
+int32_t s4p_selftest_ieee(s4p_ctx* ctx, const float* a, const float* b, int64_t n,
+                          float* out_sqrt, float* out_div, float* out_muladd);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* S4P_CAPI_H_ */

@@ -1,0 +1,251 @@
+"""ctypes binding of the C ABI in include/s4p_capi.h (libsuper4pcs_amd.so).
+
+This is plumbing for tests, bench.py and the Python mirror of the reference's
+matcher interface (super4pcs_amd/matcher.py).  There is no CPU fallback: if the
+shared library is missing or no gfx950 device is visible, calls raise S4PError.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsuper4pcs_amd.so")
+
+S4P_OK = 0
+ERR_NAMES = {0: "OK", -1: "BAD_ARG", -2: "NO_DEVICE", -3: "HIP", -4: "OOM", -5: "CAPACITY", -6: "UNSUPPORTED", -7: "STATE"}
+
+EXPORTED_SYMBOLS = [
+    "s4p_create", "s4p_destroy", "s4p_last_error", "s4p_device_name", "s4p_set_clouds", "s4p_set_base",
+    "s4p_extract_pairs", "s4p_find_congruent", "s4p_try_congruent_set", "s4p_verify_transforms",
+    "s4p_try_base", "s4p_last_candidates", "s4p_transform_points", "s4p_profile_enable", "s4p_profile_get",
+    "s4p_selftest_ieee",
+]
+
+
+class S4PError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("s4p error %s (%d): %s" % (ERR_NAMES.get(code, "?"), code, msg))
+        self.code = code
+
+
+class Options(C.Structure):
+    _fields_ = [
+        ("delta", C.c_float), ("max_normal_difference", C.c_float),
+        ("max_translation_distance", C.c_float), ("max_angle", C.c_float),
+        ("max_color_distance", C.c_float), ("sample_size", C.c_uint64),
+        ("max_time_seconds", C.c_int32), ("random_seed", C.c_uint32),
+        ("terminate_threshold", C.c_float), ("overlap_estimation", C.c_float),
+    ]
+
+
+class Limits(C.Structure):
+    _fields_ = [("max_pairs", C.c_uint64), ("max_quads", C.c_uint64), ("max_grid_cells", C.c_uint64)]
+
+
+class BaseResult(C.Structure):
+    _fields_ = [
+        ("n_pairs1", C.c_uint64), ("n_pairs2", C.c_uint64), ("n_quads", C.c_uint64), ("n_verified", C.c_uint64),
+        ("best_count", C.c_uint32), ("has_best", C.c_int32), ("best_rank", C.c_uint64),
+        ("best_quad", C.c_int32 * 4), ("best_transform", C.c_float * 16),
+        ("best_centroid2", C.c_float * 3), ("centroid1", C.c_float * 3),
+    ]
+
+
+class Profile(C.Structure):
+    _fields_ = [
+        ("verify_launches", C.c_uint64), ("verify_ms_total", C.c_double), ("verify_candidates", C.c_uint64),
+        ("verify_quads", C.c_uint64), ("verify_point_tests", C.c_uint64), ("verify_queries", C.c_uint64),
+        ("pairs_ms_total", C.c_double), ("quads_ms_total", C.c_double),
+        ("pairs_launches", C.c_uint64), ("quads_launches", C.c_uint64),
+    ]
+
+
+_LIB = None
+
+
+def load_library():
+    """Loads libsuper4pcs_amd.so (no device needed) and declares the prototypes."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise S4PError(-7, "libsuper4pcs_amd.so not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    L = C.CDLL(LIB_PATH)
+    fp = C.POINTER(C.c_float)
+    ip = C.POINTER(C.c_int32)
+    vp = C.c_void_p
+    L.s4p_create.restype = C.c_int32
+    L.s4p_create.argtypes = [C.POINTER(Options), C.POINTER(Limits), C.c_int32, C.POINTER(vp)]
+    L.s4p_destroy.argtypes = [vp]
+    L.s4p_last_error.restype = C.c_char_p
+    L.s4p_last_error.argtypes = [vp]
+    L.s4p_device_name.argtypes = [vp, C.c_char_p, C.c_int32]
+    L.s4p_set_clouds.restype = C.c_int32
+    L.s4p_set_clouds.argtypes = [vp, fp, fp, fp, C.c_int64, fp, fp, fp, fp, fp, fp, fp, fp, fp, C.c_int64]
+    L.s4p_set_base.restype = C.c_int32
+    L.s4p_set_base.argtypes = [vp, fp, fp, fp]
+    L.s4p_extract_pairs.restype = C.c_int32
+    L.s4p_extract_pairs.argtypes = [vp, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_int32, ip, C.c_int64, C.POINTER(C.c_int64)]
+    L.s4p_find_congruent.restype = C.c_int32
+    L.s4p_find_congruent.argtypes = [vp, C.c_float, C.c_float, C.c_float, C.c_float, ip, C.c_int64, ip, C.c_int64, ip, C.c_int64, C.POINTER(C.c_int64)]
+    L.s4p_try_congruent_set.restype = C.c_int32
+    L.s4p_try_congruent_set.argtypes = [vp, ip, ip, C.c_int64, ip, C.POINTER(BaseResult)]
+    L.s4p_verify_transforms.restype = C.c_int32
+    L.s4p_verify_transforms.argtypes = [vp, fp, C.c_int64, C.POINTER(C.c_uint32)]
+    L.s4p_try_base.restype = C.c_int32
+    L.s4p_try_base.argtypes = [vp, ip, C.c_float, C.c_float, C.POINTER(BaseResult)]
+    L.s4p_last_candidates.restype = C.c_int32
+    L.s4p_last_candidates.argtypes = [vp, ip, ip, C.c_int64, C.POINTER(C.c_int64)]
+    L.s4p_transform_points.restype = C.c_int32
+    L.s4p_transform_points.argtypes = [vp, fp, fp, fp, fp, C.c_int64]
+    L.s4p_profile_enable.restype = C.c_int32
+    L.s4p_profile_enable.argtypes = [vp, C.c_int32, C.c_int32]
+    L.s4p_profile_get.restype = C.c_int32
+    L.s4p_profile_get.argtypes = [vp, C.POINTER(Profile), C.c_int32]
+    L.s4p_selftest_ieee.restype = C.c_int32
+    L.s4p_selftest_ieee.argtypes = [vp, fp, fp, C.c_int64, fp, fp, fp]
+    _LIB = L
+    return L
+
+
+def _f(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _i(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def _col(a, k):
+    return np.ascontiguousarray(a[:, k], dtype=np.float32)
+
+
+def make_options(delta, overlap, sample_size, seed=5489, max_time_seconds=10 ** 6, terminate_threshold=1.0,
+                 max_normal_difference=-1.0, max_translation_distance=-1.0, max_angle=-1.0, max_color_distance=-1.0):
+    o = Options()
+    o.delta = delta
+    o.max_normal_difference = max_normal_difference
+    o.max_translation_distance = max_translation_distance
+    o.max_angle = max_angle
+    o.max_color_distance = max_color_distance
+    o.sample_size = sample_size
+    o.max_time_seconds = max_time_seconds
+    o.random_seed = seed
+    o.terminate_threshold = terminate_threshold
+    o.overlap_estimation = overlap
+    return o
+
+
+class Context:
+    """One s4p_ctx (one matcher, one GPU)."""
+
+    def __init__(self, options, device=0, max_pairs=0, max_quads=0, max_grid_cells=0):
+        self.L = load_library()
+        lim = Limits(max_pairs, max_quads, max_grid_cells)
+        h = C.c_void_p()
+        rc = self.L.s4p_create(C.byref(options), C.byref(lim), device, C.byref(h))
+        if rc != S4P_OK:
+            raise S4PError(rc, self.L.s4p_last_error(None).decode())
+        self.h = h
+        self.opt = options
+        self._keep = []
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.s4p_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != S4P_OK:
+            raise S4PError(rc, self.L.s4p_last_error(self.h).decode())
+
+    def device_name(self):
+        b = C.create_string_buffer(256)
+        self._chk(self.L.s4p_device_name(self.h, b, 256))
+        return b.value.decode()
+
+    def set_clouds(self, P, Q, Qn=None, Qrgb=None):
+        """P, Q: (n,3) float32 sampled + centred clouds."""
+        P = np.ascontiguousarray(P, np.float32); Q = np.ascontiguousarray(Q, np.float32)
+        cols = [_col(P, 0), _col(P, 1), _col(P, 2), _col(Q, 0), _col(Q, 1), _col(Q, 2)]
+        n = [None] * 3 if Qn is None else [_col(np.asarray(Qn, np.float32), k) for k in range(3)]
+        c = [None] * 3 if Qrgb is None else [_col(np.asarray(Qrgb, np.float32), k) for k in range(3)]
+        self.n_p, self.n_q = P.shape[0], Q.shape[0]
+        self._chk(self.L.s4p_set_clouds(self.h, _f(cols[0]), _f(cols[1]), _f(cols[2]), P.shape[0],
+                                        _f(cols[3]), _f(cols[4]), _f(cols[5]),
+                                        _f(n[0]), _f(n[1]), _f(n[2]), _f(c[0]), _f(c[1]), _f(c[2]), Q.shape[0]))
+
+    def set_base(self, xyz, nrm=None, rgb=None):
+        xyz = np.ascontiguousarray(xyz, np.float32).reshape(12)
+        nrm = None if nrm is None else np.ascontiguousarray(nrm, np.float32).reshape(12)
+        rgb = None if rgb is None else np.ascontiguousarray(rgb, np.float32).reshape(12)
+        self._chk(self.L.s4p_set_base(self.h, _f(xyz), _f(nrm), _f(rgb)))
+
+    def extract_pairs(self, d, normal_angle, eps, bp1, bp2, cap=None):
+        cap = cap or max(self.n_q * self.n_q, 16)
+        out = np.empty((cap, 2), np.int32)
+        m = C.c_int64()
+        self._chk(self.L.s4p_extract_pairs(self.h, d, normal_angle, eps, bp1, bp2, _i(out), cap, C.byref(m)))
+        return out[:m.value].copy()
+
+    def find_congruent(self, inv1, inv2, thr, pairs1, pairs2, cap=1 << 22):
+        p1 = np.ascontiguousarray(pairs1, np.int32); p2 = np.ascontiguousarray(pairs2, np.int32)
+        out = np.empty((cap, 4), np.int32)
+        K = C.c_int64()
+        self._chk(self.L.s4p_find_congruent(self.h, inv1, inv2, thr, thr, _i(p1), p1.shape[0], _i(p2), p2.shape[0],
+                                            _i(out), cap, C.byref(K)))
+        return out[:K.value].copy()
+
+    def try_congruent_set(self, base_ids, quads, want_counts=True):
+        base_ids = np.ascontiguousarray(base_ids, np.int32); quads = np.ascontiguousarray(quads, np.int32).reshape(-1, 4)
+        K = quads.shape[0]
+        per = np.empty(max(K, 1), np.int32) if want_counts else None
+        r = BaseResult()
+        self._chk(self.L.s4p_try_congruent_set(self.h, _i(base_ids), _i(quads), K, _i(per), C.byref(r)))
+        return r, (per[:K].copy() if want_counts else None)
+
+    def verify_transforms(self, T):
+        T = np.ascontiguousarray(T, np.float32).reshape(-1, 16)
+        out = np.empty(T.shape[0], np.uint32)
+        self._chk(self.L.s4p_verify_transforms(self.h, _f(T), T.shape[0], out.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return out
+
+    def try_base(self, base_ids, inv1, inv2):
+        base_ids = np.ascontiguousarray(base_ids, np.int32)
+        r = BaseResult()
+        self._chk(self.L.s4p_try_base(self.h, _i(base_ids), inv1, inv2, C.byref(r)))
+        return r
+
+    def last_candidates(self, cap):
+        cap = max(int(cap), 1)
+        quads = np.empty((cap, 4), np.int32); counts = np.empty(cap, np.int32)
+        K = C.c_int64()
+        self._chk(self.L.s4p_last_candidates(self.h, _i(quads), _i(counts), cap, C.byref(K)))
+        return quads[:K.value].copy(), counts[:K.value].copy()
+
+    def transform_points(self, M, xyz):
+        M = np.ascontiguousarray(M, np.float32).reshape(16)
+        x, y, z = _col(xyz, 0).copy(), _col(xyz, 1).copy(), _col(xyz, 2).copy()
+        self._chk(self.L.s4p_transform_points(self.h, _f(M), _f(x), _f(y), _f(z), x.shape[0]))
+        return np.stack([x, y, z], axis=1)
+
+    def profile_enable(self, events=True, point_tests=False):
+        self._chk(self.L.s4p_profile_enable(self.h, int(events), int(point_tests)))
+
+    def profile_get(self, reset=False):
+        p = Profile()
+        self._chk(self.L.s4p_profile_get(self.h, C.byref(p), int(reset)))
+        return p
+
+    def selftest_ieee(self, a, b):
+        a = np.ascontiguousarray(a, np.float32); b = np.ascontiguousarray(b, np.float32)
+        o1 = np.empty_like(a); o2 = np.empty_like(a); o3 = np.empty_like(a)
+        self._chk(self.L.s4p_selftest_ieee(self.h, _f(a), _f(b), a.shape[0], _f(o1), _f(o2), _f(o3)))
+        return o1, o2, o3

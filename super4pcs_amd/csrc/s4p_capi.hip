@@ -1,0 +1,620 @@
+// s4p_capi.hip -- context + C ABI (include/s4p_capi.h) over the gfx950 kernels.
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared (see super4pcs_amd/build.py)
+#include "s4p_capi.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "s4p_host_structs.hpp"
+#include "s4p_kernels.hip.hpp"
+
+using namespace s4p;
+
+namespace {
+std::string g_create_error;
+
+template <class T>
+struct DevBuf {
+  T* p = nullptr; size_t n = 0;
+  hipError_t alloc(size_t count) { free(); n = count; return count ? hipMalloc((void**)&p, count * sizeof(T)) : hipSuccess; }
+  void free() { if (p) { (void)hipFree(p); p = nullptr; } n = 0; }
+};
+template <class T>
+struct PinBuf {
+  T* p = nullptr; size_t n = 0;
+  hipError_t alloc(size_t count) { free(); n = count; return count ? hipHostMalloc((void**)&p, count * sizeof(T), hipHostMallocDefault) : hipSuccess; }
+  void free() { if (p) { (void)hipHostFree(p); p = nullptr; } n = 0; }
+};
+uint32_t next_pow2(uint64_t v) { uint64_t p = 1; while (p < v) p <<= 1; return uint32_t(p); }
+}  // namespace
+
+struct s4p_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  s4p_options opt{};
+  uint64_t max_pairs = 0, max_quads = 0, max_grid_cells = 0;
+  char devname[256] = {0};
+
+  // host mirrors
+  std::vector<float> hpx, hpy, hpz;          // sampled P, original order (for base lookups)
+  std::vector<float> hqx, hqy, hqz, hux, huy, huz;
+  bool has_normals = false, has_rgb = false;
+  uint32_t n_p = 0, n_q = 0;
+  UnitFrame frame;
+  PairOctree tree;
+  LcpGridHost hgrid;
+  float base_xyz[12] = {0}, base_nrm[12] = {0}, base_rgb[12];
+  bool clouds_set = false;
+
+  // device state
+  DevBuf<float> gpx, gpy, gpz; DevBuf<uint32_t> gcell_start, gbitmap;
+  DevBuf<float> qx, qy, qz, ux, uy, uz, qnx, qny, qnz, qcr, qcg, qcb;
+  // pair sets
+  DevBuf<int2> ab1, ab2; DevBuf<uint32_t> okey1, okey2, cell1, cell2, bucket1, next1, mask2; DevBuf<float4> ew1, ew2;
+  DevBuf<int4> quads; DevBuf<unsigned long long> tags; DevBuf<uint32_t> counts;
+  DevBuf<unsigned long long> ht_keys, ht_heads; uint32_t ht_mask = 0, epoch = 0;
+  DevBuf<DevCounters> ctr; PinBuf<DevCounters> hctr;
+  DevBuf<uint32_t> seq_id[2], seq_leaf[2]; DevBuf<float4> leaves[2];
+  PinBuf<uint32_t> hseq_id[2], hseq_leaf[2]; PinBuf<float4> hleaves[2];
+  DevBuf<float> tbuf; size_t tbuf_cap = 0;
+
+  // profiling
+  bool prof_events = false, prof_points = false;
+  hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  s4p_profile prof{};
+  uint64_t last_K = 0;
+
+  LcpGrid dev_grid() const {
+    LcpGrid g;
+    g.px = gpx.p; g.py = gpy.p; g.pz = gpz.p; g.cell_start = gcell_start.p; g.bitmap = gbitmap.p;
+    g.ox = hgrid.ox; g.oy = hgrid.oy; g.oz = hgrid.oz; g.inv_h = hgrid.inv_h;
+    g.nx = hgrid.nx; g.ny = hgrid.ny; g.nz = hgrid.nz;
+    g.sq_eps = opt.delta * opt.delta;     // match4pcsBase.cc:517,522
+    return g;
+  }
+};
+
+#define S4P_FAIL(ctx, code, msg) do { (ctx)->err = (msg); return (code); } while (0)
+#define HIPCHK(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
+    (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_); \
+    return (e_ == hipErrorOutOfMemory) ? S4P_ERR_OOM : S4P_ERR_HIP; } } while (0)
+
+namespace {
+
+int32_t check_overflow(s4p_ctx* c, uint32_t ov) {
+  if (!ov) return S4P_OK;
+  char b[160];
+  snprintf(b, sizeof b, "device buffer overflow (bits=%u: 1=pairs1 2=pairs2 4=quads); raise s4p_limits (max_pairs=%llu max_quads=%llu)",
+           ov, (unsigned long long)c->max_pairs, (unsigned long long)c->max_quads);
+  c->err = b;
+  return S4P_ERR_CAPACITY;
+}
+
+// Host side of ExtractPairs (super4pcs.cc:193-217): functor state, octree loop 1, upload, launch.
+int32_t launch_pairs(s4p_ctx* c, int set, float pair_distance, float pair_normals_angle, float pair_distance_epsilon,
+                     int bp1, int bp2) {
+  const float nRadius = pair_distance / c->frame.ratio;                         // setRadius, pairCreationFunctor.h:124-129
+  const float eps_n = pair_distance_epsilon / c->frame.ratio;                  // getNormalizedEpsilon, :131-133
+  c->tree.build(c->hux.data(), c->huy.data(), c->huz.data(), c->n_q, nRadius, eps_n, 50);
+  const uint32_t n_seq = uint32_t(c->tree.seq_id.size());
+  const uint32_t n_leaf = uint32_t(c->tree.leaves.size());
+  DevBuf<int2>& ab = set == 0 ? c->ab1 : c->ab2;
+  DevBuf<uint32_t>& okey = set == 0 ? c->okey1 : c->okey2;
+  if (n_seq == 0) return S4P_OK;
+  std::memcpy(c->hseq_id[set].p, c->tree.seq_id.data(), n_seq * sizeof(uint32_t));
+  std::memcpy(c->hseq_leaf[set].p, c->tree.seq_leaf.data(), n_seq * sizeof(uint32_t));
+  std::memcpy(c->hleaves[set].p, c->tree.leaves.data(), n_leaf * sizeof(float4));
+  HIPCHK(c, hipMemcpyAsync(c->seq_id[set].p, c->hseq_id[set].p, n_seq * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->seq_leaf[set].p, c->hseq_leaf[set].p, n_seq * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->leaves[set].p, c->hleaves[set].p, n_leaf * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+  PairParams P{};
+  P.ux = c->ux.p; P.uy = c->uy.p; P.uz = c->uz.p; P.qx = c->qx.p; P.qy = c->qy.p; P.qz = c->qz.p;
+  P.nx = c->has_normals ? c->qnx.p : nullptr; P.ny = c->qny.p; P.nz = c->qnz.p;
+  P.cr = c->has_rgb ? c->qcr.p : nullptr; P.cg = c->qcg.p; P.cb = c->qcb.p;
+  P.seq_id = c->seq_id[set].p; P.seq_leaf = c->seq_leaf[set].p; P.n_seq = n_seq; P.leaves = c->leaves[set].p;
+  P.n_q = c->n_q; P.nRadius = nRadius; P.eps_unit = c->tree.eps_unit;
+  P.pair_distance = pair_distance; P.pair_distance_eps = pair_distance_epsilon; P.pair_normals_angle = pair_normals_angle;
+  P.max_normal_difference = c->opt.max_normal_difference; P.max_color_distance = c->opt.max_color_distance;
+  P.max_translation_distance = c->opt.max_translation_distance;
+  P.norm_threshold = float(0.5 * double(c->opt.max_normal_difference) * M_PI / 180.0);   // pairCreationFunctor.h:169-170
+  for (int k = 0; k < 3; ++k) {
+    P.b1pos[k] = c->base_xyz[3 * bp1 + k]; P.b2pos[k] = c->base_xyz[3 * bp2 + k];
+    P.b1rgb[k] = c->base_rgb[3 * bp1 + k]; P.b2rgb[k] = c->base_rgb[3 * bp2 + k];
+  }
+  P.ab = ab.p; P.okey = okey.p; P.counter = set == 0 ? &c->ctr.p->m1 : &c->ctr.p->m2;
+  P.cap = uint32_t(c->max_pairs); P.overflow = &c->ctr.p->overflow; P.overflow_bit = set == 0 ? 1u : 2u;
+  dim3 grid((n_seq + 255) / 256, c->n_q);
+  hipLaunchKernelGGL(k_pairs, grid, dim3(256), 0, c->stream, P);
+  HIPCHK(c, hipGetLastError());
+  return S4P_OK;
+}
+
+// IndexedNormalSet ctor (normalset.h:114-124) + getNeighbors constants (normalset.hpp:174-191)
+void quad_setup(const s4p_ctx* c, float distance_threshold2, QuadGrid& qg, ConeTable& cone) {
+  const float eps = distance_threshold2 / c->frame.ratio;                       // super4pcs.cc:114
+  const int gridDepth = int(-std::log2(eps));
+  qg.egSize = int(std::pow(2, gridDepth));
+  qg.gepsilon = 1.f / float(qg.egSize);
+  qg.nepsilon = float(double(1.f / 7.f) + 0.00001);
+  // cos(alpha) of the two base segments, super4pcs.cc:109-111
+  float a[3], b[3];
+  for (int k = 0; k < 3; ++k) { a[k] = c->base_xyz[3 + k] - c->base_xyz[k]; b[k] = c->base_xyz[9 + k] - c->base_xyz[6 + k]; }
+  auto nrm = [](float* v) { float s2 = v[0] * v[0] + (v[1] * v[1] + v[2] * v[2]); if (s2 > 0.f) { float s = std::sqrt(s2); v[0] /= s; v[1] /= s; v[2] /= s; } };
+  nrm(a); nrm(b);
+  const float cosAlpha = a[0] * b[0] + (a[1] * b[1] + a[2] * b[2]);
+  const float alpha = std::acos(cosAlpha);
+  const float perimeter = float(double(2.f) * M_PI * double(std::atan(alpha)));
+  const float fnb = 2.f * std::ceil(perimeter * 7.f / 2.f);
+  unsigned nb = (fnb == fnb && fnb > 0.f) ? unsigned(fnb) : 0u;                 // NaN (|cos|>1) -> no samples
+  if (nb > unsigned(kMaxConeSamples)) nb = unsigned(kMaxConeSamples);           // cannot exceed 56 for alpha in [0,pi]
+  const float angleStep = float(double(2.f) * M_PI / double(float(nb)));
+  const float sinAlpha = std::sin(alpha);
+  cone.nb = int(nb);
+  for (unsigned s = 0; s < nb; ++s) {
+    const float theta = float(s) * angleStep;
+    cone.v[s][0] = sinAlpha * std::cos(theta);
+    cone.v[s][1] = sinAlpha * std::sin(theta);
+    cone.v[s][2] = cosAlpha;
+  }
+}
+
+int32_t launch_quads(s4p_ctx* c, float inv1, float inv2, float thr2) {
+  QuadGrid qg; ConeTable cone;
+  quad_setup(c, thr2, qg, cone);
+  if (qg.egSize > 1024) S4P_FAIL(c, S4P_ERR_UNSUPPORTED, "FindCongruentQuadrilaterals grid finer than 1024^3 cells (delta/extent too small)");
+  c->epoch++;
+  if (c->epoch == 0xFFFFFFFFu) {   // wrap: clear the table once every 4e9 bases
+    HIPCHK(c, hipMemsetAsync(c->ht_keys.p, 0, c->ht_keys.n * 8, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->ht_heads.p, 0, c->ht_heads.n * 8, c->stream));
+    c->epoch = 1;
+  }
+  HashTable ht{c->ht_keys.p, c->ht_heads.p, c->ht_mask, c->epoch};
+  PrepParams P1{};
+  P1.ux = c->ux.p; P1.uy = c->uy.p; P1.uz = c->uz.p; P1.qx = c->qx.p; P1.qy = c->qy.p; P1.qz = c->qz.p;
+  P1.ab = c->ab1.p; P1.m_dev = &c->ctr.p->m1; P1.cap = uint32_t(c->max_pairs); P1.invariant = inv1; P1.qg = qg;
+  P1.cell = c->cell1.p; P1.bucket = c->bucket1.p; P1.ew = c->ew1.p; P1.next = c->next1.p; P1.mask = nullptr; P1.ht = ht;
+  P1.cone.nb = 0;
+  hipLaunchKernelGGL(k_prep1, dim3(1024), dim3(256), 0, c->stream, P1);
+  PrepParams P2{};
+  P2.ux = c->ux.p; P2.uy = c->uy.p; P2.uz = c->uz.p; P2.qx = c->qx.p; P2.qy = c->qy.p; P2.qz = c->qz.p;
+  P2.ab = c->ab2.p; P2.m_dev = &c->ctr.p->m2; P2.cap = uint32_t(c->max_pairs); P2.invariant = inv2; P2.qg = qg;
+  P2.cell = c->cell2.p; P2.bucket = nullptr; P2.ew = c->ew2.p; P2.next = nullptr; P2.mask = c->mask2.p; P2.ht = ht;
+  P2.cone = cone;
+  hipLaunchKernelGGL(k_prep2, dim3(1024), dim3(256), 0, c->stream, P2);
+  QuadParams Q{};
+  Q.ab1 = c->ab1.p; Q.okey1 = c->okey1.p; Q.bucket1 = c->bucket1.p; Q.ew1 = c->ew1.p; Q.next1 = c->next1.p;
+  Q.ab2 = c->ab2.p; Q.okey2 = c->okey2.p; Q.cell2 = c->cell2.p; Q.ew2 = c->ew2.p; Q.mask2 = c->mask2.p;
+  Q.m2_dev = &c->ctr.p->m2; Q.cap2 = uint32_t(c->max_pairs); Q.ht = ht; Q.thr = thr2;
+  Q.quads = c->quads.p; Q.tags = c->tags.p; Q.K_dev = &c->ctr.p->K; Q.K_cap = uint32_t(c->max_quads); Q.overflow = &c->ctr.p->overflow;
+  hipLaunchKernelGGL(k_quads, dim3(2048), dim3(256), 0, c->stream, Q);
+  HIPCHK(c, hipGetLastError());
+  return S4P_OK;
+}
+
+BaseFrame make_base_frame(const s4p_ctx* c, const int32_t* base_ids) {
+  BaseFrame b{};
+  for (int i = 0; i < 3; ++i) { b.p[i][0] = c->hpx[base_ids[i]]; b.p[i][1] = c->hpy[base_ids[i]]; b.p[i][2] = c->hpz[base_ids[i]]; }
+  for (int k = 0; k < 3; ++k) b.c1[k] = ((b.p[0][k] + b.p[1][k]) + b.p[2][k]) / 3.f;   // match4pcsBase.hpp:385
+  b.gate = 2.0f * c->opt.delta;                                                        // distance_factor * delta
+  return b;
+}
+
+int32_t launch_verify(s4p_ctx* c, const BaseFrame& bf) {
+  VerifyParams V{};
+  V.grid = c->dev_grid(); V.qx = c->qx.p; V.qy = c->qy.p; V.qz = c->qz.p; V.n_q = c->n_q; V.base = bf;
+  V.quads = c->quads.p; V.tags = c->tags.p; V.counts = c->counts.p; V.K_dev = &c->ctr.p->K; V.K_cap = uint32_t(c->max_quads);
+  V.ctr = c->ctr.p;
+  if (c->prof_events) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+  if (c->prof_points) hipLaunchKernelGGL(k_verify<true>, dim3(2048), dim3(256), 0, c->stream, V);
+  else hipLaunchKernelGGL(k_verify<false>, dim3(2048), dim3(256), 0, c->stream, V);
+  if (c->prof_events) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+  SelectParams S{};
+  S.tags = c->tags.p; S.counts = c->counts.p; S.quads = c->quads.p; S.K_dev = &c->ctr.p->K; S.K_cap = uint32_t(c->max_quads);
+  S.ctr = c->ctr.p; S.qx = c->qx.p; S.qy = c->qy.p; S.qz = c->qz.p; S.base = bf;
+  hipLaunchKernelGGL(k_select, dim3(512), dim3(256), 0, c->stream, S);
+  hipLaunchKernelGGL(k_winner, dim3(512), dim3(256), 0, c->stream, S);
+  HIPCHK(c, hipGetLastError());
+  return S4P_OK;
+}
+
+int32_t fetch_result(s4p_ctx* c, const BaseFrame& bf, s4p_base_result* r) {
+  HIPCHK(c, hipMemcpyAsync(c->hctr.p, c->ctr.p, sizeof(DevCounters), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const DevCounters& d = *c->hctr.p;
+  if (int32_t rc = check_overflow(c, d.overflow)) return rc;
+  std::memset(r, 0, sizeof(*r));
+  r->n_pairs1 = d.m1; r->n_pairs2 = d.m2; r->n_quads = d.K; r->n_verified = d.C;
+  r->best_count = d.C ? d.best_count : 0u; r->has_best = d.C ? 1 : 0;
+  r->best_rank = d.C ? d.best_tag : ~0ull;
+  for (int i = 0; i < 4; ++i) r->best_quad[i] = d.C ? d.best_quad[i] : 0;
+  for (int i = 0; i < 16; ++i) r->best_transform[i] = d.C ? d.best_T[i] : ((i % 5 == 0) ? 1.f : 0.f);
+  for (int k = 0; k < 3; ++k) { r->best_centroid2[k] = d.C ? d.best_c2[k] : 0.f; r->centroid1[k] = bf.c1[k]; }
+  c->last_K = d.K;
+  if (c->prof_events) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) {
+      c->prof.verify_launches++; c->prof.verify_ms_total += ms;
+      c->prof.verify_candidates += d.C; c->prof.verify_quads += d.K; c->prof.verify_queries += uint64_t(d.C) * c->n_q;
+    }
+  }
+  if (c->prof_points) c->prof.verify_point_tests += d.point_tests;
+  return S4P_OK;
+}
+
+int32_t reset_counters(s4p_ctx* c) {
+  hipLaunchKernelGGL(k_reset_counters, dim3(1), dim3(1), 0, c->stream, c->ctr.p);
+  if (c->prof_points) HIPCHK(c, hipMemsetAsync(&c->ctr.p->point_tests, 0, 8, c->stream));
+  return S4P_OK;
+}
+
+}  // namespace
+
+// ============================================================================
+extern "C" {
+
+const char* s4p_last_error(const s4p_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int32_t s4p_create(const s4p_options* opt, const s4p_limits* lim, int32_t device, s4p_ctx** out) {
+  if (!opt || !out) { g_create_error = "null argument"; return S4P_ERR_BAD_ARG; }
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    g_create_error = "no HIP device visible: the MI355X path has no CPU fallback";
+    return S4P_ERR_NO_DEVICE;
+  }
+  if (device < 0 || device >= ndev) { g_create_error = "bad device index"; return S4P_ERR_BAD_ARG; }
+  if (!(opt->delta > 0.f)) { g_create_error = "delta must be > 0"; return S4P_ERR_BAD_ARG; }
+  if (opt->max_angle >= 0.f) {
+    g_create_error = "max_angle >= 0 (Euler-angle gate / segment-angle pair filter use libm acos/atan2 and are not "
+                     "bit-reproducible on device): unsupported on the device path";
+    return S4P_ERR_UNSUPPORTED;
+  }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) { g_create_error = "hipGetDeviceProperties failed"; return S4P_ERR_HIP; }
+  if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos) {
+    g_create_error = std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only";
+    return S4P_ERR_NO_DEVICE;
+  }
+  s4p_ctx* c = new s4p_ctx();
+  c->device = device; c->opt = *opt;
+  snprintf(c->devname, sizeof c->devname, "%s (%s)", prop.name, prop.gcnArchName);
+  c->max_pairs = (lim && lim->max_pairs) ? lim->max_pairs : (4ull << 20);
+  c->max_quads = (lim && lim->max_quads) ? lim->max_quads : (16ull << 20);
+  c->max_grid_cells = (lim && lim->max_grid_cells) ? lim->max_grid_cells : (1ull << 27);
+  if (c->max_pairs > 0x7FFFFFFFull || c->max_quads > 0x7FFFFFFFull) { g_create_error = "limits exceed 2^31 entries"; delete c; return S4P_ERR_BAD_ARG; }
+  for (int k = 0; k < 12; ++k) c->base_rgb[k] = -1.f;
+  auto fail = [&](hipError_t e, const char* what) { g_create_error = std::string(what) + ": " + hipGetErrorString(e); s4p_destroy(c); return e == hipErrorOutOfMemory ? S4P_ERR_OOM : S4P_ERR_HIP; };
+  hipError_t e;
+  if ((e = hipSetDevice(device)) != hipSuccess) return fail(e, "hipSetDevice");
+  if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
+  const size_t mp = c->max_pairs, mq = c->max_quads;
+#define A(buf, cnt) if ((e = (buf).alloc(cnt)) != hipSuccess) return fail(e, "hipMalloc " #buf)
+  A(c->ab1, mp); A(c->ab2, mp); A(c->okey1, mp); A(c->okey2, mp); A(c->cell1, mp); A(c->cell2, mp);
+  A(c->bucket1, mp); A(c->next1, mp); A(c->mask2, mp * kMaskWords); A(c->ew1, mp); A(c->ew2, mp);
+  A(c->quads, mq); A(c->tags, mq); A(c->counts, mq);
+  const uint32_t hts = next_pow2(2 * mp);
+  A(c->ht_keys, hts); A(c->ht_heads, hts); c->ht_mask = hts - 1;
+  A(c->ctr, 1);
+#undef A
+  if ((e = c->hctr.alloc(1)) != hipSuccess) return fail(e, "hipHostMalloc");
+  if ((e = hipMemset(c->ht_keys.p, 0, size_t(hts) * 8)) != hipSuccess) return fail(e, "hipMemset");
+  if ((e = hipMemset(c->ht_heads.p, 0, size_t(hts) * 8)) != hipSuccess) return fail(e, "hipMemset");
+  if ((e = hipMemset(c->ctr.p, 0, sizeof(DevCounters))) != hipSuccess) return fail(e, "hipMemset");
+  c->epoch = 0;
+  for (auto& ev : c->ev) if ((e = hipEventCreate(&ev)) != hipSuccess) return fail(e, "hipEventCreate");
+  *out = c;
+  return S4P_OK;
+}
+
+void s4p_destroy(s4p_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  c->gpx.free(); c->gpy.free(); c->gpz.free(); c->gcell_start.free(); c->gbitmap.free();
+  c->qx.free(); c->qy.free(); c->qz.free(); c->ux.free(); c->uy.free(); c->uz.free();
+  c->qnx.free(); c->qny.free(); c->qnz.free(); c->qcr.free(); c->qcg.free(); c->qcb.free();
+  c->ab1.free(); c->ab2.free(); c->okey1.free(); c->okey2.free(); c->cell1.free(); c->cell2.free();
+  c->bucket1.free(); c->next1.free(); c->mask2.free(); c->ew1.free(); c->ew2.free();
+  c->quads.free(); c->tags.free(); c->counts.free(); c->ht_keys.free(); c->ht_heads.free(); c->ctr.free(); c->hctr.free();
+  for (int s = 0; s < 2; ++s) { c->seq_id[s].free(); c->seq_leaf[s].free(); c->leaves[s].free(); c->hseq_id[s].free(); c->hseq_leaf[s].free(); c->hleaves[s].free(); }
+  c->tbuf.free();
+  for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int32_t s4p_device_name(const s4p_ctx* c, char* buf, int32_t buflen) {
+  if (!c || !buf || buflen <= 0) return S4P_ERR_BAD_ARG;
+  snprintf(buf, size_t(buflen), "%s", c->devname);
+  return S4P_OK;
+}
+
+int32_t s4p_set_clouds(s4p_ctx* c, const float* px, const float* py, const float* pz, int64_t n_p,
+                       const float* qx, const float* qy, const float* qz,
+                       const float* qnx, const float* qny, const float* qnz,
+                       const float* qr, const float* qg, const float* qb, int64_t n_q) {
+  if (!c) return S4P_ERR_BAD_ARG;
+  if (!px || !py || !pz || !qx || !qy || !qz || n_p <= 0 || n_q <= 0) S4P_FAIL(c, S4P_ERR_BAD_ARG, "s4p_set_clouds: null or empty cloud");
+  if (n_q > 46340) S4P_FAIL(c, S4P_ERR_UNSUPPORTED, "sampled Q larger than 46340 points: 32-bit pair order keys would overflow");
+  if (n_p > 0x7FFFFFF0ll) S4P_FAIL(c, S4P_ERR_UNSUPPORTED, "sampled P too large");
+  HIPCHK(c, hipSetDevice(c->device));
+  c->clouds_set = false;
+  c->n_p = uint32_t(n_p); c->n_q = uint32_t(n_q);
+  c->hpx.assign(px, px + n_p); c->hpy.assign(py, py + n_p); c->hpz.assign(pz, pz + n_p);
+  c->hqx.assign(qx, qx + n_q); c->hqy.assign(qy, qy + n_q); c->hqz.assign(qz, qz + n_q);
+  c->frame.build(c->hqx, c->hqy, c->hqz, c->hux, c->huy, c->huz);
+  c->tree.reset(c->n_q);
+  if (!c->hgrid.build(c->hpx, c->hpy, c->hpz, c->opt.delta, c->max_grid_cells)) S4P_FAIL(c, S4P_ERR_STATE, "LCP grid build failed");
+  const size_t nc = c->hgrid.ncell();
+  HIPCHK(c, c->gpx.alloc(n_p)); HIPCHK(c, c->gpy.alloc(n_p)); HIPCHK(c, c->gpz.alloc(n_p));
+  HIPCHK(c, c->gcell_start.alloc(nc + 1)); HIPCHK(c, c->gbitmap.alloc(c->hgrid.bitmap.size()));
+  HIPCHK(c, hipMemcpy(c->gpx.p, c->hgrid.sx.data(), n_p * 4, hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(c->gpy.p, c->hgrid.sy.data(), n_p * 4, hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(c->gpz.p, c->hgrid.sz.data(), n_p * 4, hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(c->gcell_start.p, c->hgrid.cell_start.data(), (nc + 1) * 4, hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(c->gbitmap.p, c->hgrid.bitmap.data(), c->hgrid.bitmap.size() * 4, hipMemcpyHostToDevice));
+  // free the big host mirrors of the grid (keep parameters)
+  std::vector<uint32_t>().swap(c->hgrid.cell_start); std::vector<uint32_t>().swap(c->hgrid.bitmap);
+  auto up = [&](DevBuf<float>& d, const float* src) -> hipError_t {
+    hipError_t e = d.alloc(n_q); if (e != hipSuccess) return e;
+    return hipMemcpy(d.p, src, n_q * 4, hipMemcpyHostToDevice);
+  };
+  HIPCHK(c, up(c->qx, qx)); HIPCHK(c, up(c->qy, qy)); HIPCHK(c, up(c->qz, qz));
+  HIPCHK(c, up(c->ux, c->hux.data())); HIPCHK(c, up(c->uy, c->huy.data())); HIPCHK(c, up(c->uz, c->huz.data()));
+  c->has_normals = (qnx && qny && qnz); c->has_rgb = (qr && qg && qb);
+  if (c->has_normals) { HIPCHK(c, up(c->qnx, qnx)); HIPCHK(c, up(c->qny, qny)); HIPCHK(c, up(c->qnz, qnz)); }
+  if (c->has_rgb) { HIPCHK(c, up(c->qcr, qr)); HIPCHK(c, up(c->qcg, qg)); HIPCHK(c, up(c->qcb, qb)); }
+  for (int s = 0; s < 2; ++s) {
+    HIPCHK(c, c->seq_id[s].alloc(n_q)); HIPCHK(c, c->seq_leaf[s].alloc(n_q)); HIPCHK(c, c->leaves[s].alloc(n_q));
+    HIPCHK(c, c->hseq_id[s].alloc(n_q)); HIPCHK(c, c->hseq_leaf[s].alloc(n_q)); HIPCHK(c, c->hleaves[s].alloc(n_q));
+  }
+  c->clouds_set = true;
+  return S4P_OK;
+}
+
+int32_t s4p_set_base(s4p_ctx* c, const float* xyz, const float* nrm, const float* rgb) {
+  if (!c || !xyz) return S4P_ERR_BAD_ARG;
+  std::memcpy(c->base_xyz, xyz, sizeof c->base_xyz);
+  if (nrm) std::memcpy(c->base_nrm, nrm, sizeof c->base_nrm); else std::memset(c->base_nrm, 0, sizeof c->base_nrm);
+  if (rgb) std::memcpy(c->base_rgb, rgb, sizeof c->base_rgb); else for (int k = 0; k < 12; ++k) c->base_rgb[k] = -1.f;
+  return S4P_OK;
+}
+
+int32_t s4p_extract_pairs(s4p_ctx* c, float pair_distance, float pair_normals_angle, float pair_distance_epsilon,
+                          int32_t bp1, int32_t bp2, int32_t* out_pairs, int64_t cap, int64_t* n_out) {
+  if (!c || !n_out) return S4P_ERR_BAD_ARG;
+  if (!c->clouds_set) S4P_FAIL(c, S4P_ERR_STATE, "s4p_set_clouds not called");
+  if (bp1 < 0 || bp1 > 3 || bp2 < 0 || bp2 > 3) S4P_FAIL(c, S4P_ERR_BAD_ARG, "base_point index out of [0,3]");
+  HIPCHK(c, hipSetDevice(c->device));
+  if (int32_t rc = reset_counters(c)) return rc;
+  if (int32_t rc = launch_pairs(c, 0, pair_distance, pair_normals_angle, pair_distance_epsilon, bp1, bp2)) return rc;
+  HIPCHK(c, hipMemcpyAsync(c->hctr.p, c->ctr.p, sizeof(DevCounters), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (int32_t rc = check_overflow(c, c->hctr.p->overflow)) return rc;
+  const uint32_t m = c->hctr.p->m1;
+  *n_out = m;
+  if (m == 0) return S4P_OK;
+  if (!out_pairs || cap < int64_t(m)) S4P_FAIL(c, S4P_ERR_CAPACITY, "s4p_extract_pairs: output buffer too small");
+  std::vector<int2> ab(m); std::vector<uint32_t> ok(m);
+  HIPCHK(c, hipMemcpy(ab.data(), c->ab1.p, size_t(m) * sizeof(int2), hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(ok.data(), c->okey1.p, size_t(m) * 4, hipMemcpyDeviceToHost));
+  std::vector<uint32_t> order(m);
+  std::iota(order.begin(), order.end(), 0u);
+  std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return ok[a] < ok[b]; });
+  for (uint32_t i = 0; i < m; ++i) { out_pairs[2 * i] = ab[order[i]].x; out_pairs[2 * i + 1] = ab[order[i]].y; }
+  return S4P_OK;
+}
+
+int32_t s4p_find_congruent(s4p_ctx* c, float inv1, float inv2, float /*thr1*/, float thr2,
+                           const int32_t* pairs1, int64_t m1, const int32_t* pairs2, int64_t m2,
+                           int32_t* out_quads, int64_t cap, int64_t* n_out) {
+  if (!c || !n_out) return S4P_ERR_BAD_ARG;
+  if (!c->clouds_set) S4P_FAIL(c, S4P_ERR_STATE, "s4p_set_clouds not called");
+  *n_out = 0;
+  if (m1 <= 0 || m2 <= 0) return S4P_OK;
+  if (!pairs1 || !pairs2) S4P_FAIL(c, S4P_ERR_BAD_ARG, "null pair list");
+  if (uint64_t(m1) > c->max_pairs || uint64_t(m2) > c->max_pairs) S4P_FAIL(c, S4P_ERR_CAPACITY, "pair list longer than max_pairs");
+  for (int64_t i = 0; i < 2 * m1; ++i) if (pairs1[i] < 0 || uint32_t(pairs1[i]) >= c->n_q) S4P_FAIL(c, S4P_ERR_BAD_ARG, "pair index out of range");
+  for (int64_t i = 0; i < 2 * m2; ++i) if (pairs2[i] < 0 || uint32_t(pairs2[i]) >= c->n_q) S4P_FAIL(c, S4P_ERR_BAD_ARG, "pair index out of range");
+  HIPCHK(c, hipSetDevice(c->device));
+  if (int32_t rc = reset_counters(c)) return rc;
+  std::vector<uint32_t> idx((size_t)std::max(m1, m2));
+  std::iota(idx.begin(), idx.end(), 0u);
+  HIPCHK(c, hipMemcpyAsync(c->ab1.p, pairs1, size_t(m1) * 8, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->ab2.p, pairs2, size_t(m2) * 8, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->okey1.p, idx.data(), size_t(m1) * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->okey2.p, idx.data(), size_t(m2) * 4, hipMemcpyHostToDevice, c->stream));
+  const uint32_t mm[2] = {uint32_t(m1), uint32_t(m2)};
+  HIPCHK(c, hipMemcpyAsync(&c->ctr.p->m1, mm, 8, hipMemcpyHostToDevice, c->stream));
+  if (int32_t rc = launch_quads(c, inv1, inv2, thr2)) return rc;
+  HIPCHK(c, hipMemcpyAsync(c->hctr.p, c->ctr.p, sizeof(DevCounters), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (int32_t rc = check_overflow(c, c->hctr.p->overflow)) return rc;
+  const uint32_t K = c->hctr.p->K;
+  *n_out = K;
+  if (K == 0) return S4P_OK;
+  if (!out_quads || cap < int64_t(K)) S4P_FAIL(c, S4P_ERR_CAPACITY, "s4p_find_congruent: output buffer too small");
+  std::vector<int4> q(K); std::vector<unsigned long long> t(K);
+  HIPCHK(c, hipMemcpy(q.data(), c->quads.p, size_t(K) * 16, hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(t.data(), c->tags.p, size_t(K) * 8, hipMemcpyDeviceToHost));
+  std::vector<uint32_t> order(K);
+  std::iota(order.begin(), order.end(), 0u);
+  std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return t[a] < t[b]; });   // std::set<(id,i)> order
+  for (uint32_t i = 0; i < K; ++i) {
+    const int4 v = q[order[i]];
+    out_quads[4 * i] = v.x; out_quads[4 * i + 1] = v.y; out_quads[4 * i + 2] = v.z; out_quads[4 * i + 3] = v.w;
+  }
+  return S4P_OK;
+}
+
+int32_t s4p_try_congruent_set(s4p_ctx* c, const int32_t* base_ids, const int32_t* quads, int64_t K,
+                              int32_t* per_candidate, s4p_base_result* result) {
+  if (!c || !base_ids || !result) return S4P_ERR_BAD_ARG;
+  if (!c->clouds_set) S4P_FAIL(c, S4P_ERR_STATE, "s4p_set_clouds not called");
+  for (int i = 0; i < 4; ++i) if (base_ids[i] < 0 || uint32_t(base_ids[i]) >= c->n_p) S4P_FAIL(c, S4P_ERR_BAD_ARG, "base id out of range");
+  if (K < 0 || uint64_t(K) > c->max_quads) S4P_FAIL(c, S4P_ERR_CAPACITY, "more quads than max_quads");
+  if (K > 0 && !quads) S4P_FAIL(c, S4P_ERR_BAD_ARG, "null quads");
+  for (int64_t i = 0; i < 4 * K; ++i) if (quads[i] < 0 || uint32_t(quads[i]) >= c->n_q) S4P_FAIL(c, S4P_ERR_BAD_ARG, "quad index out of range");
+  HIPCHK(c, hipSetDevice(c->device));
+  if (int32_t rc = reset_counters(c)) return rc;
+  const BaseFrame bf = make_base_frame(c, base_ids);
+  std::vector<unsigned long long> tg((size_t)K);
+  std::iota(tg.begin(), tg.end(), 0ull);
+  if (K > 0) {
+    HIPCHK(c, hipMemcpyAsync(c->quads.p, quads, size_t(K) * 16, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->tags.p, tg.data(), size_t(K) * 8, hipMemcpyHostToDevice, c->stream));
+  }
+  const uint32_t k32 = uint32_t(K);
+  HIPCHK(c, hipMemcpyAsync(&c->ctr.p->K, &k32, 4, hipMemcpyHostToDevice, c->stream));
+  if (int32_t rc = launch_verify(c, bf)) return rc;
+  if (int32_t rc = fetch_result(c, bf, result)) return rc;
+  if (per_candidate && K > 0) {
+    std::vector<uint32_t> cnt((size_t)K);
+    HIPCHK(c, hipMemcpy(cnt.data(), c->counts.p, size_t(K) * 4, hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < K; ++i) per_candidate[i] = cnt[i] == kGateFailed ? -1 : int32_t(cnt[i]);
+  }
+  return S4P_OK;
+}
+
+int32_t s4p_verify_transforms(s4p_ctx* c, const float* T, int64_t B, uint32_t* counts) {
+  if (!c || (B > 0 && (!T || !counts))) return S4P_ERR_BAD_ARG;
+  if (!c->clouds_set) S4P_FAIL(c, S4P_ERR_STATE, "s4p_set_clouds not called");
+  if (B <= 0) return S4P_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  DevBuf<float> dT; DevBuf<uint32_t> dC;
+  HIPCHK(c, dT.alloc(size_t(B) * 16));
+  hipError_t e = dC.alloc(size_t(B));
+  if (e != hipSuccess) { dT.free(); HIPCHK(c, e); }
+  int32_t rc = S4P_OK;
+  do {
+    if ((e = hipMemcpyAsync(dT.p, T, size_t(B) * 64, hipMemcpyHostToDevice, c->stream)) != hipSuccess) break;
+    VerifyTParams V{};
+    V.grid = c->dev_grid(); V.qx = c->qx.p; V.qy = c->qy.p; V.qz = c->qz.p; V.n_q = c->n_q; V.T = dT.p; V.B = uint32_t(B);
+    V.counts = dC.p; V.ctr = c->ctr.p;
+    const uint32_t blocks = uint32_t(std::min<int64_t>((B + 3) / 4, 4096));
+    hipLaunchKernelGGL(k_verify_T, dim3(blocks), dim3(256), 0, c->stream, V);
+    if ((e = hipGetLastError()) != hipSuccess) break;
+    if ((e = hipMemcpyAsync(counts, dC.p, size_t(B) * 4, hipMemcpyDeviceToHost, c->stream)) != hipSuccess) break;
+    e = hipStreamSynchronize(c->stream);
+  } while (0);
+  dT.free(); dC.free();
+  if (e != hipSuccess) { c->err = std::string("s4p_verify_transforms: ") + hipGetErrorString(e); rc = S4P_ERR_HIP; }
+  return rc;
+}
+
+int32_t s4p_try_base(s4p_ctx* c, const int32_t* base_ids, float inv1, float inv2, s4p_base_result* result) {
+  if (!c || !base_ids || !result) return S4P_ERR_BAD_ARG;
+  if (!c->clouds_set) S4P_FAIL(c, S4P_ERR_STATE, "s4p_set_clouds not called");
+  for (int i = 0; i < 4; ++i) if (base_ids[i] < 0 || uint32_t(base_ids[i]) >= c->n_p) S4P_FAIL(c, S4P_ERR_BAD_ARG, "base id out of range");
+  HIPCHK(c, hipSetDevice(c->device));
+  if (int32_t rc = reset_counters(c)) return rc;
+  // match4pcsBase.hpp:313-331: segment lengths / normal "angles" of the ordered base, two ExtractPairs
+  auto seg = [&](const float* v, int a, int b) {
+    const float d0 = v[3 * a] - v[3 * b], d1 = v[3 * a + 1] - v[3 * b + 1], d2 = v[3 * a + 2] - v[3 * b + 2];
+    return std::sqrt(d0 * d0 + (d1 * d1 + d2 * d2));
+  };
+  const float distance1 = seg(c->base_xyz, 0, 1), distance2 = seg(c->base_xyz, 2, 3);
+  const float normal_angle1 = seg(c->base_nrm, 0, 1), normal_angle2 = seg(c->base_nrm, 2, 3);
+  const float eps = 2.0f * c->opt.delta;                                          // distance_factor * delta
+  if (c->prof_events) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+  if (int32_t rc = launch_pairs(c, 0, distance1, normal_angle1, eps, 0, 1)) return rc;
+  if (int32_t rc = launch_pairs(c, 1, distance2, normal_angle2, eps, 2, 3)) return rc;
+  if (c->prof_events) HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+  if (int32_t rc = launch_quads(c, inv1, inv2, eps)) return rc;
+  if (c->prof_events) HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
+  const BaseFrame bf = make_base_frame(c, base_ids);
+  if (int32_t rc = launch_verify(c, bf)) return rc;
+  if (int32_t rc = fetch_result(c, bf, result)) return rc;
+  if (c->prof_events) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) { c->prof.pairs_ms_total += ms; c->prof.pairs_launches += 2; }
+    if (hipEventElapsedTime(&ms, c->ev[3], c->ev[4]) == hipSuccess) { c->prof.quads_ms_total += ms; c->prof.quads_launches += 1; }
+  }
+  return S4P_OK;
+}
+
+int32_t s4p_last_candidates(s4p_ctx* c, int32_t* quads, int32_t* counts, int64_t cap, int64_t* n_out) {
+  if (!c || !n_out) return S4P_ERR_BAD_ARG;
+  const uint64_t K = c->last_K;
+  *n_out = int64_t(K);
+  if (K == 0) return S4P_OK;
+  if (cap < int64_t(K) || !quads || !counts) S4P_FAIL(c, S4P_ERR_CAPACITY, "s4p_last_candidates: output buffer too small");
+  HIPCHK(c, hipSetDevice(c->device));
+  std::vector<int4> q(K); std::vector<unsigned long long> t(K); std::vector<uint32_t> cn(K);
+  HIPCHK(c, hipMemcpy(q.data(), c->quads.p, K * 16, hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(t.data(), c->tags.p, K * 8, hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(cn.data(), c->counts.p, K * 4, hipMemcpyDeviceToHost));
+  std::vector<uint32_t> order(K);
+  std::iota(order.begin(), order.end(), 0u);
+  std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return t[a] < t[b]; });
+  for (uint64_t i = 0; i < K; ++i) {
+    const int4 v = q[order[i]];
+    quads[4 * i] = v.x; quads[4 * i + 1] = v.y; quads[4 * i + 2] = v.z; quads[4 * i + 3] = v.w;
+    counts[i] = cn[order[i]] == kGateFailed ? -1 : int32_t(cn[order[i]]);
+  }
+  return S4P_OK;
+}
+
+int32_t s4p_transform_points(s4p_ctx* c, const float* M, float* x, float* y, float* z, int64_t n) {
+  if (!c || !M || (n > 0 && (!x || !y || !z))) return S4P_ERR_BAD_ARG;
+  if (n <= 0) return S4P_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  if (c->tbuf_cap < size_t(n) * 3) { HIPCHK(c, c->tbuf.alloc(size_t(n) * 3)); c->tbuf_cap = size_t(n) * 3; }
+  float* dx = c->tbuf.p; float* dy = dx + n; float* dz = dy + n;
+  HIPCHK(c, hipMemcpyAsync(dx, x, size_t(n) * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(dy, y, size_t(n) * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(dz, z, size_t(n) * 4, hipMemcpyHostToDevice, c->stream));
+  ApplyParams A{};
+  for (int i = 0; i < 12; ++i) A.M[i] = M[i];
+  A.x = dx; A.y = dy; A.z = dz; A.n = uint64_t(n);
+  const uint32_t blocks = uint32_t(std::min<uint64_t>((uint64_t(n) + 255) / 256, 4096));
+  hipLaunchKernelGGL(k_apply, dim3(blocks), dim3(256), 0, c->stream, A);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(x, dx, size_t(n) * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(y, dy, size_t(n) * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(z, dz, size_t(n) * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return S4P_OK;
+}
+
+int32_t s4p_profile_enable(s4p_ctx* c, int32_t enable_events, int32_t count_point_tests) {
+  if (!c) return S4P_ERR_BAD_ARG;
+  c->prof_events = enable_events != 0; c->prof_points = count_point_tests != 0;
+  return S4P_OK;
+}
+int32_t s4p_profile_get(s4p_ctx* c, s4p_profile* out, int32_t reset) {
+  if (!c || !out) return S4P_ERR_BAD_ARG;
+  *out = c->prof;
+  if (reset) c->prof = s4p_profile{};
+  return S4P_OK;
+}
+
+int32_t s4p_selftest_ieee(s4p_ctx* c, const float* a, const float* b, int64_t n, float* o_sqrt, float* o_div, float* o_ma) {
+  if (!c || !a || !b || !o_sqrt || !o_div || !o_ma || n <= 0) return S4P_ERR_BAD_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  DevBuf<float> d;
+  HIPCHK(c, d.alloc(size_t(n) * 5));
+  hipError_t e;
+  do {
+    if ((e = hipMemcpy(d.p, a, size_t(n) * 4, hipMemcpyHostToDevice)) != hipSuccess) break;
+    if ((e = hipMemcpy(d.p + n, b, size_t(n) * 4, hipMemcpyHostToDevice)) != hipSuccess) break;
+    hipLaunchKernelGGL(k_selftest, dim3(256), dim3(256), 0, c->stream, d.p, d.p + n, uint64_t(n), d.p + 2 * n, d.p + 3 * n, d.p + 4 * n);
+    if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) break;
+    if ((e = hipMemcpy(o_sqrt, d.p + 2 * n, size_t(n) * 4, hipMemcpyDeviceToHost)) != hipSuccess) break;
+    if ((e = hipMemcpy(o_div, d.p + 3 * n, size_t(n) * 4, hipMemcpyDeviceToHost)) != hipSuccess) break;
+    e = hipMemcpy(o_ma, d.p + 4 * n, size_t(n) * 4, hipMemcpyDeviceToHost);
+  } while (0);
+  d.free();
+  HIPCHK(c, e);
+  return S4P_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,609 @@
+// s4p_kernels.cuh -- gfx950 device code of the Super4PCS hot path (HIP, wave64).
+//
+// Compiled ONLY for gfx950 with -ffp-contract=off: every float expression below is
+// evaluated as separate IEEE mul/add (no FMA), with correctly rounded sqrtf and '/',
+// in the exact association order the reference's Eigen 3.3 fixed-size expressions
+// use (see DESIGN.md "Numerics contract").  That is what makes integer inlier counts
+// bit-exact against the CPU path.
+//
+// Reference functions restated here (paths under /root/reference/src/super4pcs/):
+//   k_pairs        accelerators/pairExtraction/intersectionFunctor.h:197-233 (loop 2),
+//                  intersectionPrimitive.h:117-157, algorithms/pairCreationFunctor.h:151-218
+//   k_prep1/2      algorithms/super4pcs.cc:118-146, accelerators/normalset.hpp:110-127,162-203
+//   k_quads        algorithms/super4pcs.cc:151-163
+//   k_verify       algorithms/match4pcsBase.cc:365-500 (ComputeRigidTransformation),
+//                  match4pcsBase.cc:508-567 (Verify), accelerators/kdtree.h:417-421 (predicate)
+//   k_apply        algorithms/match4pcsBase.hpp:265-267
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace s4p {
+
+constexpr uint32_t kNil = 0xFFFFFFFFu;
+constexpr uint32_t kGateFailed = 0xFFFFFFFFu;
+constexpr int kMaskWords = 11;   // 343 direction buckets (7^3) -> 11 x 32 bit
+constexpr int kMaxConeSamples = 56;
+
+// ---------------------------------------------------------------------------
+// exact-order float helpers (Eigen 3-vector reductions: x + (y + z))
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz) {
+  return ax * bx + (ay * by + az * bz);
+}
+__device__ __forceinline__ float sqn3(float x, float y, float z) { return x * x + (y * y + z * z); }
+__device__ __forceinline__ void normalize3(float& x, float& y, float& z) {
+  const float s2 = sqn3(x, y, z);
+  if (s2 > 0.f) { const float s = sqrtf(s2); x /= s; y /= s; z /= s; }
+}
+__device__ __forceinline__ void cross3(float ax, float ay, float az, float bx, float by, float bz,
+                                       float& ox, float& oy, float& oz) {
+  ox = ay * bz - az * by;
+  oy = az * bx - ax * bz;
+  oz = ax * by - ay * bx;
+}
+
+// ---------------------------------------------------------------------------
+// device-resident per-base counters / result
+// ---------------------------------------------------------------------------
+struct DevCounters {
+  uint32_t m1, m2, K, C;            // appended pairs1 / pairs2 / quads, verified candidates
+  uint32_t best_count;              // max inlier count (verified candidates only)
+  uint32_t overflow;                // bit0 pairs1, bit1 pairs2, bit2 quads
+  unsigned long long best_tag;      // min tag among candidates with best_count
+  unsigned long long point_tests;   // optional instrumentation
+  // winner record
+  int32_t best_quad[4];
+  float best_T[16];
+  float best_c2[3];
+  uint32_t has_best;
+};
+
+// ---------------------------------------------------------------------------
+// LCP grid over sampled P  (replaces kd_tree_, match4pcsBase.cc:353-363)
+// ---------------------------------------------------------------------------
+struct LcpGrid {
+  const float* px; const float* py; const float* pz;   // P points sorted by cell
+  const uint32_t* cell_start;                           // ncell + 1
+  const uint32_t* bitmap;                               // dilated occupancy, 1 bit per cell
+  float ox, oy, oz, inv_h;
+  int nx, ny, nz;
+  float sq_eps;                                         // fl(delta*delta)
+};
+
+template <bool COUNT>
+__device__ __forceinline__ bool lcp_probe(const LcpGrid& g, float tx, float ty, float tz,
+                                          unsigned long long* point_tests) {
+  const float fx = floorf((tx - g.ox) * g.inv_h);
+  const float fy = floorf((ty - g.oy) * g.inv_h);
+  const float fz = floorf((tz - g.oz) * g.inv_h);
+  if (!(fx >= 0.f && fx < float(g.nx) && fy >= 0.f && fy < float(g.ny) && fz >= 0.f && fz < float(g.nz))) return false;
+  const int ix = int(fx), iy = int(fy), iz = int(fz);
+  const uint32_t c = (uint32_t(iz) * uint32_t(g.ny) + uint32_t(iy)) * uint32_t(g.nx) + uint32_t(ix);
+  if (!((g.bitmap[c >> 5] >> (c & 31u)) & 1u)) return false;
+  const int x0 = max(ix - 1, 0), x1 = min(ix + 1, g.nx - 1);
+  const int y0 = max(iy - 1, 0), y1 = min(iy + 1, g.ny - 1);
+  const int z0 = max(iz - 1, 0), z1 = min(iz + 1, g.nz - 1);
+  for (int z = z0; z <= z1; ++z) {
+    for (int y = y0; y <= y1; ++y) {
+      const uint32_t row = (uint32_t(z) * uint32_t(g.ny) + uint32_t(y)) * uint32_t(g.nx);
+      const uint32_t s = g.cell_start[row + x0];
+      const uint32_t e = g.cell_start[row + x1 + 1];
+      for (uint32_t p = s; p < e; ++p) {
+        const float dx = tx - g.px[p], dy = ty - g.py[p], dz = tz - g.pz[p];
+        if (COUNT) atomicAdd(point_tests, 1ull);
+        if (sqn3(dx, dy, dz) <= g.sq_eps) return true;    // kdtree.h:417-421  sqdist <= cl_dist
+      }
+    }
+  }
+  return false;
+}
+
+// ---------------------------------------------------------------------------
+// ComputeRigidTransformation (match4pcsBase.cc:365-500), computeScale == false,
+// max_angle < 0 (the Euler-angle gate is rejected at s4p_create).
+// Returns true iff "ok && rms >= 0 && rms < 2*delta" (match4pcsBase.hpp:436-439).
+// T is row-major 3x4 (R | t).
+// ---------------------------------------------------------------------------
+struct BaseFrame {          // per-base constants, computed once on the host side of the ABI
+  float p[3][3];            // first three base points (sampled P, centred)
+  float c1[3];              // centroid1 = ((b1+b2)+b3)/3
+  float gate;               // distance_factor * delta = 2*delta
+};
+
+__device__ __forceinline__ bool gs_frame(const float* a0, const float* a1, const float* a2, float e[3][3]) {
+  e[0][0] = a1[0] - a0[0]; e[0][1] = a1[1] - a0[1]; e[0][2] = a1[2] - a0[2];
+  if (sqn3(e[0][0], e[0][1], e[0][2]) == 0.f) return false;
+  normalize3(e[0][0], e[0][1], e[0][2]);
+  const float tx = a2[0] - a0[0], ty = a2[1] - a0[1], tz = a2[2] - a0[2];
+  const float dd = dot3(tx, ty, tz, e[0][0], e[0][1], e[0][2]);
+  e[1][0] = tx - dd * e[0][0]; e[1][1] = ty - dd * e[0][1]; e[1][2] = tz - dd * e[0][2];
+  if (sqn3(e[1][0], e[1][1], e[1][2]) == 0.f) return false;
+  normalize3(e[1][0], e[1][1], e[1][2]);
+  cross3(e[0][0], e[0][1], e[0][2], e[1][0], e[1][1], e[1][2], e[2][0], e[2][1], e[2][2]);
+  if (sqn3(e[2][0], e[2][1], e[2][2]) == 0.f) return false;
+  normalize3(e[2][0], e[2][1], e[2][2]);
+  return true;
+}
+
+__device__ __forceinline__ bool rigid_gate(const BaseFrame& b, const float q[3][3], float T[12], float c2[3]) {
+  for (int k = 0; k < 3; ++k) c2[k] = ((q[0][k] + q[1][k]) + q[2][k]) / 3.f;    // match4pcsBase.hpp:415-417
+  float vp[3][3], vq[3][3];
+  if (!gs_frame(b.p[0], b.p[1], b.p[2], vp)) return false;   // rms = 1e9 -> gate fails (quirk .cc:417-433)
+  if (!gs_frame(q[0], q[1], q[2], vq)) return false;
+  float R[3][3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) R[r][c] = vp[0][r] * vq[0][c] + (vp[1][r] * vq[1][c] + vp[2][r] * vq[2][c]);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const float dg = R[i][0] * R[0][i] + (R[i][1] * R[1][i] + R[i][2] * R[2][i]);   // (R*R).diagonal() .cc:453
+    if (dg - 1.f > 1e-6f) return false;
+  }
+  float rms = 0.f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const float f0 = 1.f * q[i][0] - c2[0], f1 = 1.f * q[i][1] - c2[1], f2 = 1.f * q[i][2] - c2[2];
+    float d[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const float tr = R[r][0] * f0 + (R[r][1] * f1 + R[r][2] * f2);
+      d[r] = (tr - b.p[i][r]) + b.c1[r];
+    }
+    rms += sqrtf(sqn3(d[0], d[1], d[2]));
+  }
+  rms /= 4.f;                                                                      // .cc:489 (quirk: /4 over 3 terms)
+  if (!(rms >= 0.f && rms < b.gate)) return false;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const float rc = R[r][0] * (-c2[0]) + (R[r][1] * (-c2[1]) + R[r][2] * (-c2[2]));
+    T[r * 4 + 0] = R[r][0]; T[r * 4 + 1] = R[r][1]; T[r * 4 + 2] = R[r][2];
+    T[r * 4 + 3] = b.c1[r] + rc;
+  }
+  return true;
+}
+
+// ---------------------------------------------------------------------------
+// k_verify: one wave64 per candidate quad; lanes stride over the sampled Q points.
+// ---------------------------------------------------------------------------
+struct VerifyParams {
+  LcpGrid grid;
+  const float* qx; const float* qy; const float* qz;   // sampled Q (centred)
+  uint32_t n_q;
+  BaseFrame base;
+  const int4* quads; const unsigned long long* tags; uint32_t* counts;
+  const uint32_t* K_dev; uint32_t K_cap;
+  DevCounters* ctr;
+};
+
+template <bool COUNT>
+__global__ __launch_bounds__(256) void k_verify(VerifyParams P) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+  const uint32_t K = min(*P.K_dev, P.K_cap);
+  uint32_t local_best = 0, local_C = 0;
+  bool any = false;
+  for (uint32_t k = wave; k < K; k += nwaves) {
+    const int4 qd = P.quads[k];
+    float q[3][3];
+    q[0][0] = P.qx[qd.x]; q[0][1] = P.qy[qd.x]; q[0][2] = P.qz[qd.x];
+    q[1][0] = P.qx[qd.y]; q[1][1] = P.qy[qd.y]; q[1][2] = P.qz[qd.y];
+    q[2][0] = P.qx[qd.z]; q[2][1] = P.qy[qd.z]; q[2][2] = P.qz[qd.z];
+    float T[12], c2[3];
+    const bool ok = rigid_gate(P.base, q, T, c2);
+    if (!ok) { if (lane == 0) P.counts[k] = kGateFailed; continue; }
+    uint32_t cnt = 0;
+    for (uint32_t i = lane; i < P.n_q; i += 64) {
+      const float x = P.qx[i], y = P.qy[i], z = P.qz[i];
+      // (mat * q.homogeneous()).head<3>() : ((m0*x + m1*y) + m2*z) + m3   (match4pcsBase.cc:532)
+      const float tx = ((T[0] * x + T[1] * y) + T[2] * z) + T[3];
+      const float ty = ((T[4] * x + T[5] * y) + T[6] * z) + T[7];
+      const float tz = ((T[8] * x + T[9] * y) + T[10] * z) + T[11];
+      cnt += lcp_probe<COUNT>(P.grid, tx, ty, tz, &P.ctr->point_tests) ? 1u : 0u;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    if (lane == 0) P.counts[k] = cnt;
+    local_C++;
+    local_best = max(local_best, cnt);
+    any = true;
+  }
+  if (lane == 0 && any) {
+    atomicAdd(&P.ctr->C, local_C);
+    atomicMax(&P.ctr->best_count, local_best);
+  }
+}
+
+// k_select: best_tag = min tag among candidates whose count == best_count (first in
+// reference order wins: match4pcsBase.hpp:468 strict '>').
+struct SelectParams {
+  const unsigned long long* tags; const uint32_t* counts; const int4* quads;
+  const uint32_t* K_dev; uint32_t K_cap; DevCounters* ctr;
+  const float* qx; const float* qy; const float* qz; BaseFrame base;
+};
+__global__ __launch_bounds__(256) void k_select(SelectParams P) {
+  const uint32_t K = min(*P.K_dev, P.K_cap);
+  if (P.ctr->C == 0) return;
+  const uint32_t best = P.ctr->best_count;
+  for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < K; k += gridDim.x * blockDim.x)
+    if (P.counts[k] == best) atomicMin(&P.ctr->best_tag, P.tags[k]);
+}
+__global__ __launch_bounds__(256) void k_winner(SelectParams P) {
+  const uint32_t K = min(*P.K_dev, P.K_cap);
+  if (P.ctr->C == 0) return;
+  const unsigned long long bt = P.ctr->best_tag;
+  const uint32_t best = P.ctr->best_count;
+  for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < K; k += gridDim.x * blockDim.x) {
+    if (P.tags[k] == bt && P.counts[k] == best) {
+      const int4 qd = P.quads[k];
+      float q[3][3];
+      q[0][0] = P.qx[qd.x]; q[0][1] = P.qy[qd.x]; q[0][2] = P.qz[qd.x];
+      q[1][0] = P.qx[qd.y]; q[1][1] = P.qy[qd.y]; q[1][2] = P.qz[qd.y];
+      q[2][0] = P.qx[qd.z]; q[2][1] = P.qy[qd.z]; q[2][2] = P.qz[qd.z];
+      float T[12], c2[3];
+      rigid_gate(P.base, q, T, c2);
+      for (int i = 0; i < 12; ++i) P.ctr->best_T[i] = T[i];
+      P.ctr->best_T[12] = 0.f; P.ctr->best_T[13] = 0.f; P.ctr->best_T[14] = 0.f; P.ctr->best_T[15] = 1.f;
+      for (int i = 0; i < 3; ++i) P.ctr->best_c2[i] = c2[i];
+      P.ctr->best_quad[0] = qd.x; P.ctr->best_quad[1] = qd.y; P.ctr->best_quad[2] = qd.z; P.ctr->best_quad[3] = qd.w;
+      P.ctr->has_best = 1u;
+    }
+  }
+}
+
+// k_verify_T: Verify() for explicit transforms (one wave per transform).
+struct VerifyTParams {
+  LcpGrid grid; const float* qx; const float* qy; const float* qz; uint32_t n_q;
+  const float* T; uint32_t B; uint32_t* counts; DevCounters* ctr;
+};
+__global__ __launch_bounds__(256) void k_verify_T(VerifyTParams P) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+  for (uint32_t k = wave; k < P.B; k += nwaves) {
+    const float* T = P.T + 16 * size_t(k);
+    uint32_t cnt = 0;
+    for (uint32_t i = lane; i < P.n_q; i += 64) {
+      const float x = P.qx[i], y = P.qy[i], z = P.qz[i];
+      const float tx = ((T[0] * x + T[1] * y) + T[2] * z) + T[3];
+      const float ty = ((T[4] * x + T[5] * y) + T[6] * z) + T[7];
+      const float tz = ((T[8] * x + T[9] * y) + T[10] * z) + T[11];
+      cnt += lcp_probe<false>(P.grid, tx, ty, tz, nullptr) ? 1u : 0u;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    if (lane == 0) P.counts[k] = cnt;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// k_pairs: loop 2 of IntersectionFunctor::process + PairCreationFunctor::process.
+// One thread per (primitive pId, sequence slot s); the sequence is the concatenation
+// of the leaf ranges of the host-built octree, so (pId, s) order == reference order.
+// Accepted (i=pId, j) appends (j,i) then (i,j) with order keys 2*(pId*n_seq+s)+{0,1}.
+// ---------------------------------------------------------------------------
+struct PairParams {
+  const float* ux; const float* uy; const float* uz;     // unit-cube coordinates of sampled Q
+  const float* qx; const float* qy; const float* qz;     // world (centred) coordinates
+  const float* nx; const float* ny; const float* nz;     // normals or nullptr
+  const float* cr; const float* cg; const float* cb;     // rgb or nullptr
+  const uint32_t* seq_id; const uint32_t* seq_leaf; uint32_t n_seq;
+  const float4* leaves;                                    // (cx, cy, cz, halfEdge argument)
+  uint32_t n_q;
+  float nRadius, eps_unit;
+  double pair_distance, pair_distance_eps, pair_normals_angle;
+  float max_normal_difference, max_color_distance, max_translation_distance, norm_threshold;
+  float b1pos[3], b2pos[3], b1rgb[3], b2rgb[3];
+  int2* ab; uint32_t* okey; uint32_t* counter; uint32_t cap; uint32_t* overflow; uint32_t overflow_bit;
+};
+
+__device__ __forceinline__ bool sphere_box(float cx, float cy, float cz, float r, float4 leaf) {
+  const float h = leaf.w;
+  float dmin[3], dmax[3];
+  const float c[3] = {cx, cy, cz};
+  const float nc[3] = {leaf.x, leaf.y, leaf.z};
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float mn = nc[k] - h, mx = nc[k] + h;
+    const float sqmin = (c[k] - mn) * (c[k] - mn);
+    const float sqmax = (c[k] - mx) * (c[k] - mx);
+    dmin[k] = (c[k] < mn) ? sqmin : ((c[k] > mx) ? sqmax : 0.f);
+    dmax[k] = (sqmin < sqmax) ? sqmax : sqmin;
+  }
+  const float r2 = r * r;
+  return (dmin[0] + (dmin[1] + dmin[2])) < r2 && r2 < (dmax[0] + (dmax[1] + dmax[2]));
+}
+
+__global__ __launch_bounds__(256) void k_pairs(PairParams P) {
+  const uint32_t pId = blockIdx.y;
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  bool acc = false;
+  uint32_t j = 0;
+  if (s < P.n_seq) {
+    j = P.seq_id[s];
+    if (pId > j) {
+      const float cx = P.ux[pId], cy = P.uy[pId], cz = P.uz[pId];
+      const float dx = P.ux[j] - cx, dy = P.uy[j] - cy, dz = P.uz[j] - cz;
+      const float t = sqrtf(sqn3(dx, dy, dz)) - P.nRadius;
+      if (t * t < P.eps_unit * P.eps_unit) {                               // intersectPoint, intersectionPrimitive.h:154-157
+        if (sphere_box(cx, cy, cz, P.nRadius, P.leaves[P.seq_leaf[s]])) {   // intersect, :117-142
+          // PairCreationFunctor::process(i = pId, j): p = Q[j], q = Q[i]
+          const float wx = P.qx[pId] - P.qx[j], wy = P.qy[pId] - P.qy[j], wz = P.qz[pId] - P.qz[j];
+          const float distance = sqrtf(sqn3(wx, wy, wz));
+          acc = !(fabs(double(distance) - P.pair_distance) > P.pair_distance_eps);   // :162
+          if (acc && P.max_normal_difference > 0.f && P.nx != nullptr) {              // :166-180
+            const float qn0 = P.nx[pId], qn1 = P.ny[pId], qn2 = P.nz[pId];
+            const float pn0 = P.nx[j], pn1 = P.ny[j], pn2 = P.nz[j];
+            if (sqn3(qn0, qn1, qn2) > 0.f && sqn3(pn0, pn1, pn2) > 0.f) {
+              const double a1 = double(sqrtf(sqn3(qn0 - pn0, qn1 - pn1, qn2 - pn2)));
+              const double a2 = double(sqrtf(sqn3(qn0 + pn0, qn1 + pn1, qn2 + pn2)));
+              const float fnd = float(fmin(fabs(a1 - P.pair_normals_angle), fabs(a2 - P.pair_normals_angle)));
+              if (fnd > P.norm_threshold) acc = false;
+            }
+          }
+          if (acc && P.max_color_distance > 0.f) {                                    // :182-192
+            float pr0 = -1.f, pr1 = -1.f, pr2 = -1.f, qr0 = -1.f, qr1 = -1.f, qr2 = -1.f;
+            if (P.cr != nullptr) { pr0 = P.cr[j]; pr1 = P.cg[j]; pr2 = P.cb[j]; qr0 = P.cr[pId]; qr1 = P.cg[pId]; qr2 = P.cb[pId]; }
+            const bool use_rgb = (pr0 >= 0.f && qr0 >= 0.f && P.b1rgb[0] >= 0.f && P.b2rgb[0] >= 0.f);
+            const bool good = sqrtf(sqn3(pr0 - P.b1rgb[0], pr1 - P.b1rgb[1], pr2 - P.b1rgb[2])) < P.max_color_distance &&
+                              sqrtf(sqn3(qr0 - P.b2rgb[0], qr1 - P.b2rgb[1], qr2 - P.b2rgb[2])) < P.max_color_distance;
+            if (use_rgb && !good) acc = false;
+          }
+          if (acc && P.max_translation_distance > 0.f) {                              // :194-200
+            const bool good =
+                sqrtf(sqn3(P.qx[j] - P.b1pos[0], P.qy[j] - P.b1pos[1], P.qz[j] - P.b1pos[2])) < P.max_translation_distance &&
+                sqrtf(sqn3(P.qx[pId] - P.b2pos[0], P.qy[pId] - P.b2pos[1], P.qz[pId] - P.b2pos[2])) < P.max_translation_distance;
+            if (!good) acc = false;
+          }
+        }
+      }
+    }
+  }
+  // wave-aggregated, order-free append (order is carried by okey)
+  const unsigned long long m = __ballot(acc);
+  if (m == 0ull) return;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t leader = __ffsll((long long)m) - 1;
+  uint32_t base = 0;
+  if (lane == leader) base = atomicAdd(P.counter, 2u * uint32_t(__popcll(m)));
+  base = __shfl(base, leader);
+  if (acc) {
+    const uint32_t at = base + 2u * uint32_t(__popcll(m & ((1ull << lane) - 1ull)));
+    if (at + 1u < P.cap) {
+      const uint32_t ok = 2u * (pId * P.n_seq + s);
+      P.ab[at] = make_int2(int(j), int(pId));     P.okey[at] = ok;          // pairs->emplace_back(j, i)  :214
+      P.ab[at + 1] = make_int2(int(pId), int(j)); P.okey[at + 1] = ok + 1u; // pairs->emplace_back(i, j)  :215
+    } else {
+      atomicOr(P.overflow, P.overflow_bit);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Congruent-quad enumeration (FindCongruentQuadrilaterals, super4pcs.cc:80-177).
+// set 1 entries are chained per euclidean cell in an epoch-tagged hash table
+// (no per-base clearing); set 2 entries carry a 343-bit cone mask of direction buckets.
+// ---------------------------------------------------------------------------
+struct QuadGrid {             // IndexedNormalSet parameters (normalset.h:114-124)
+  float gepsilon;             // 1.f / egSize
+  float nepsilon;             // 1/7 + 1e-5
+  int egSize;
+};
+struct ConeTable {            // getNeighbors constants (normalset.hpp:174-191), host-computed with libm
+  int nb;
+  float v[kMaxConeSamples][3];   // (sinA*cos(theta_a), sinA*sin(theta_a), cosA)
+};
+
+__device__ __forceinline__ uint32_t index_normal(float x, float y, float z, float neps) {
+  const int c0 = int((x / 2.f + 0.5f) / neps);
+  const int c1 = int((y / 2.f + 0.5f) / neps);
+  const int c2 = int((z / 2.f + 0.5f) / neps);
+  return uint32_t(c2 * 49 + c1 * 7 + c0);
+}
+__device__ __forceinline__ uint32_t index_pos(float x, float y, float z, const QuadGrid& g) {
+  const int c0 = int(x / g.gepsilon), c1 = int(y / g.gepsilon), c2 = int(z / g.gepsilon);
+  return (uint32_t(c2) * uint32_t(g.egSize) + uint32_t(c1)) * uint32_t(g.egSize) + uint32_t(c0);
+}
+__device__ __forceinline__ uint32_t hash_cell(uint32_t c) {
+  c ^= c >> 16; c *= 0x7feb352du; c ^= c >> 15; c *= 0x846ca68bu; c ^= c >> 16;
+  return c;
+}
+
+struct HashTable {
+  unsigned long long* keys;    // (epoch << 32) | cell
+  unsigned long long* heads;   // (epoch << 32) | entry index
+  uint32_t mask;               // size - 1 (power of two)
+  uint32_t epoch;
+};
+
+struct PrepParams {
+  const float* ux; const float* uy; const float* uz;
+  const float* qx; const float* qy; const float* qz;
+  const int2* ab; const uint32_t* m_dev; uint32_t cap;
+  float invariant;
+  QuadGrid qg;
+  uint32_t* cell; uint32_t* bucket; float4* ew; uint32_t* next;   // set 1: bucket,next used; set 2: unused
+  uint32_t* mask;                                                  // set 2: kMaskWords per entry
+  HashTable ht;
+  ConeTable cone;
+};
+
+__global__ __launch_bounds__(256) void k_prep1(PrepParams P) {
+  const uint32_t m = min(*P.m_dev, P.cap);
+  for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < m; e += gridDim.x * blockDim.x) {
+    const int2 ab = P.ab[e];
+    const float p1x = P.ux[ab.x], p1y = P.uy[ab.x], p1z = P.uz[ab.x];
+    const float p2x = P.ux[ab.y], p2y = P.uy[ab.y], p2z = P.uz[ab.y];
+    float nx = p2x - p1x, ny = p2y - p1y, nz = p2z - p1z;
+    const float posx = p1x + P.invariant * nx, posy = p1y + P.invariant * ny, posz = p1z + P.invariant * nz;  // super4pcs.cc:123
+    normalize3(nx, ny, nz);                                                                                  // :121
+    const uint32_t cell = index_pos(posx, posy, posz, P.qg);
+    P.cell[e] = cell;
+    P.bucket[e] = index_normal(nx, ny, nz, P.qg.nepsilon);
+    const float w1x = P.qx[ab.x], w1y = P.qy[ab.x], w1z = P.qz[ab.x];
+    const float w2x = P.qx[ab.y], w2y = P.qy[ab.y], w2z = P.qz[ab.y];
+    P.ew[e] = make_float4(w1x + (w2x - w1x) * P.invariant, w1y + (w2y - w1y) * P.invariant,
+                          w1z + (w2z - w1z) * P.invariant, 0.f);                                            // :157
+    // insert into the cell hash (find-or-claim slot, then push on the chain)
+    const unsigned long long mykey = ((unsigned long long)P.ht.epoch << 32) | cell;
+    uint32_t h = hash_cell(cell) & P.ht.mask;
+    while (true) {
+      const unsigned long long k = __hip_atomic_load(&P.ht.keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (k == mykey) break;
+      if (uint32_t(k >> 32) != P.ht.epoch) {
+        const unsigned long long old = atomicCAS(&P.ht.keys[h], k, mykey);
+        if (old == k || old == mykey) break;
+        continue;   // somebody claimed it for another cell: re-read the same slot
+      }
+      h = (h + 1u) & P.ht.mask;
+    }
+    const unsigned long long prev = atomicExch(&P.ht.heads[h], ((unsigned long long)P.ht.epoch << 32) | e);
+    P.next[e] = (uint32_t(prev >> 32) == P.ht.epoch) ? uint32_t(prev) : kNil;
+  }
+}
+
+// Quaternion::setFromTwoVectors(zhat, n) (Eigen/Geometry) + closed-form replacement of
+// its JacobiSVD branch (deviation D1, identical in the oracle).  q = (w, x, y, z).
+__device__ __forceinline__ void quat_from_z_to(float nx, float ny, float nz, float q[4]) {
+  normalize3(nx, ny, nz);
+  float c = 0.f * nx + (0.f * ny + 1.f * nz);
+  float ax, ay, az;
+  cross3(0.f, 0.f, 1.f, nx, ny, nz, ax, ay, az);
+  if (c < -1.f + 1e-5f) {
+    c = fmaxf(c, -1.f);
+    const float s = sqn3(ax, ay, az);
+    if (s > 0.f) { const float r = sqrtf(s); ax /= r; ay /= r; az /= r; }
+    else { ax = 1.f; ay = 0.f; az = 0.f; }
+    const float w2 = (1.f + c) * 0.5f;
+    q[0] = sqrtf(w2);
+    const float sv = sqrtf(1.f - w2);
+    q[1] = ax * sv; q[2] = ay * sv; q[3] = az * sv;
+    return;
+  }
+  const float s = sqrtf((1.f + c) * 2.f);
+  const float invs = 1.f / s;
+  q[1] = ax * invs; q[2] = ay * invs; q[3] = az * invs;
+  q[0] = s * 0.5f;
+}
+
+__global__ __launch_bounds__(256) void k_prep2(PrepParams P) {
+  __shared__ uint32_t smask[256 * kMaskWords];
+  const uint32_t m = min(*P.m_dev, P.cap);
+  const uint32_t nthreads = gridDim.x * blockDim.x;
+  uint32_t* my = smask + threadIdx.x * kMaskWords;
+  for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < m; e += nthreads) {
+    const int2 ab = P.ab[e];
+    const float p1x = P.ux[ab.x], p1y = P.uy[ab.x], p1z = P.uz[ab.x];
+    const float p2x = P.ux[ab.y], p2y = P.uy[ab.y], p2z = P.uz[ab.y];
+    const float nx = p2x - p1x, ny = p2y - p1y, nz = p2z - p1z;
+    const float qx_ = p1x + P.invariant * nx, qy_ = p1y + P.invariant * ny, qz_ = p1z + P.invariant * nz;   // super4pcs.cc:141
+    P.cell[e] = index_pos(qx_, qy_, qz_, P.qg);
+    const float w1x = P.qx[ab.x], w1y = P.qy[ab.x], w1z = P.qz[ab.x];
+    const float w2x = P.qx[ab.y], w2y = P.qy[ab.y], w2z = P.qz[ab.y];
+    P.ew[e] = make_float4(w1x + P.invariant * (w2x - w1x), w1y + P.invariant * (w2y - w1y),
+                          w1z + P.invariant * (w2z - w1z), 0.f);                                          // :142
+    float q[4];
+    float qnx = nx, qny = ny, qnz = nz;
+    normalize3(qnx, qny, qnz);                          // queryn = (p2-p1).normalized()            super4pcs.cc:144
+    quat_from_z_to(qnx, qny, qnz, q);                   // setFromTwoVectors normalises it again    normalset.hpp:181
+#pragma unroll
+    for (int w = 0; w < kMaskWords; ++w) my[w] = 0u;
+    for (int a = 0; a < P.cone.nb; ++a) {               // normalset.hpp:186-196
+      const float vx = P.cone.v[a][0], vy = P.cone.v[a][1], vz = P.cone.v[a][2];
+      float ux_, uy_, uz_;
+      cross3(q[1], q[2], q[3], vx, vy, vz, ux_, uy_, uz_);            // QuaternionBase::_transformVector
+      ux_ += ux_; uy_ += uy_; uz_ += uz_;
+      float cx, cy, cz;
+      cross3(q[1], q[2], q[3], ux_, uy_, uz_, cx, cy, cz);
+      float dx = (vx + q[0] * ux_) + cx, dy = (vy + q[0] * uy_) + cy, dz = (vz + q[0] * uz_) + cz;
+      normalize3(dx, dy, dz);
+      const uint32_t id = index_normal(dx, dy, dz, P.qg.nepsilon);
+      if (id < 343u) my[id >> 5] |= (1u << (id & 31u));
+    }
+#pragma unroll
+    for (int w = 0; w < kMaskWords; ++w) P.mask[size_t(e) * kMaskWords + w] = my[w];
+  }
+}
+
+struct QuadParams {
+  // set 1
+  const int2* ab1; const uint32_t* okey1; const uint32_t* bucket1; const float4* ew1; const uint32_t* next1;
+  // set 2
+  const int2* ab2; const uint32_t* okey2; const uint32_t* cell2; const float4* ew2; const uint32_t* mask2;
+  const uint32_t* m2_dev; uint32_t cap2;
+  HashTable ht;
+  float thr;                   // distance_threshold2 (compared against a SQUARED norm: quirk super4pcs.cc:160)
+  int4* quads; unsigned long long* tags; uint32_t* K_dev; uint32_t K_cap; uint32_t* overflow;
+};
+
+__global__ __launch_bounds__(256) void k_quads(QuadParams P) {
+  const uint32_t m2 = min(*P.m2_dev, P.cap2);
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < m2; i += gridDim.x * blockDim.x) {
+    const uint32_t cell = P.cell2[i];
+    const unsigned long long mykey = ((unsigned long long)P.ht.epoch << 32) | cell;
+    uint32_t h = hash_cell(cell) & P.ht.mask;
+    uint32_t e = kNil;
+    while (true) {
+      const unsigned long long k = P.ht.keys[h];
+      if (k == mykey) { const unsigned long long hd = P.ht.heads[h]; e = (uint32_t(hd >> 32) == P.ht.epoch) ? uint32_t(hd) : kNil; break; }
+      if (uint32_t(k >> 32) != P.ht.epoch) break;
+      h = (h + 1u) & P.ht.mask;
+    }
+    if (e == kNil) continue;
+    const float4 eq = P.ew2[i];
+    const uint32_t* mk = P.mask2 + size_t(i) * kMaskWords;
+    const int2 ab2 = P.ab2[i];
+    const uint32_t ok2 = P.okey2[i];
+    while (e != kNil) {
+      const uint32_t b = P.bucket1[e];
+      if ((mk[b >> 5] >> (b & 31u)) & 1u) {
+        const float4 ep = P.ew1[e];
+        const float dx = eq.x - ep.x, dy = eq.y - ep.y, dz = eq.z - ep.z;
+        if (sqn3(dx, dy, dz) <= P.thr) {                                           // super4pcs.cc:160
+          const uint32_t at = atomicAdd(P.K_dev, 1u);
+          if (at < P.K_cap) {
+            const int2 ab1 = P.ab1[e];
+            P.quads[at] = make_int4(ab1.x, ab1.y, ab2.x, ab2.y);                   // :171-172
+            P.tags[at] = ((unsigned long long)P.okey1[e] << 32) | ok2;
+          } else {
+            atomicOr(P.overflow, 4u);
+          }
+        }
+      }
+      e = P.next1[e];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// k_apply: final rigid apply on the full-resolution cloud (match4pcsBase.hpp:265-267).
+// 24 B/point of HBM traffic for 18 flop: bandwidth-bound; plain VALU keeps the
+// reference's (non-fused) rounding, which an MFMA fma-chain would not.
+// ---------------------------------------------------------------------------
+struct ApplyParams { float M[12]; float* x; float* y; float* z; uint64_t n; };
+__global__ __launch_bounds__(256) void k_apply(ApplyParams P) {
+  for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < P.n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const float x = P.x[i], y = P.y[i], z = P.z[i];
+    P.x[i] = ((P.M[0] * x + P.M[1] * y) + P.M[2] * z) + P.M[3];
+    P.y[i] = ((P.M[4] * x + P.M[5] * y) + P.M[6] * z) + P.M[7];
+    P.z[i] = ((P.M[8] * x + P.M[9] * y) + P.M[10] * z) + P.M[11];
+  }
+}
+
+__global__ void k_selftest(const float* a, const float* b, uint64_t n, float* o_sqrt, float* o_div, float* o_ma) {
+  for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const float x = a[i], y = b[i];
+    o_sqrt[i] = sqrtf(fabsf(x));
+    o_div[i] = x / y;
+    o_ma[i] = x * y + (x * x + y * y);
+  }
+}
+
+__global__ void k_reset_counters(DevCounters* c) {
+  c->m1 = 0; c->m2 = 0; c->K = 0; c->C = 0; c->best_count = 0; c->overflow = 0;
+  c->best_tag = ~0ull; c->has_best = 0;
+}
+
+}  // namespace s4p

@@ -1,0 +1,77 @@
+"""Synthetic point-cloud pairs for the BASELINE.json configs.
+
+All generators are seeded numpy, float32 output, and jitter coordinates so that no two
+points are lattice-aligned (exact delta^2 distances must be measure-zero).
+"""
+import numpy as np
+
+
+def _bumpy_radius(dirs, rng_params):
+    a, f, g, al, be = rng_params
+    theta = np.arccos(np.clip(dirs[:, 2], -1.0, 1.0))
+    phi = np.arctan2(dirs[:, 1], dirs[:, 0])
+    r = np.ones(dirs.shape[0])
+    for k in range(len(a)):
+        r += a[k] * np.sin(f[k] * theta + al[k]) * np.sin(g[k] * phi + be[k])
+    return r
+
+
+def _random_rotation(rng):
+    q = rng.normal(size=4)
+    q /= np.linalg.norm(q)
+    w, x, y, z = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def bumpy_pair(n_points, overlap=0.5, delta=0.004, noise_sigma=None, seed=20140814):
+    """Config-3 style pair: a closed bumpy surface r(theta,phi) = 1 + sum a_k sin(f_k theta + al_k) sin(g_k phi + be_k),
+    scaled to unit bounding-box diagonal.  P and Q are independent draws; P keeps directions with
+    z >= -c, Q keeps z <= c, with c chosen so the shared band is `overlap` of each cloud.
+    Q is then moved by a random rigid motion and perturbed by Gaussian noise (sigma = delta by default).
+
+    Returns (P, Q, T_gt) with T_gt the 4x4 that maps the *moved* Q back onto P.
+    """
+    rng = np.random.default_rng(seed)
+    K = 8
+    params = (rng.uniform(0.02, 0.08, K), rng.integers(1, 7, K), rng.integers(1, 7, K),
+              rng.uniform(0, 2 * np.pi, K), rng.uniform(0, 2 * np.pi, K))
+    # each cloud covers a fraction (1+c)/2 of the sphere; the shared band covers c: c/((1+c)/2) = overlap
+    c = overlap / (2.0 - overlap)
+
+    def draw(n, keep):
+        out = []
+        got = 0
+        while got < n:
+            d = rng.normal(size=(int((n - got) * 2.2) + 16, 3))
+            d /= np.linalg.norm(d, axis=1, keepdims=True)
+            d = d[keep(d[:, 2])]
+            out.append(d)
+            got += d.shape[0]
+        d = np.concatenate(out)[:n]
+        return d * _bumpy_radius(d, params)[:, None]
+
+    P = draw(n_points, lambda z: z >= -c)
+    Q = draw(n_points, lambda z: z <= c)
+    both = np.concatenate([P, Q])
+    diag = np.linalg.norm(both.max(0) - both.min(0))
+    P /= diag
+    Q /= diag
+    R = _random_rotation(rng)
+    t = rng.uniform(-0.5, 0.5, 3)
+    sigma = delta if noise_sigma is None else noise_sigma
+    Qm = Q @ R.T + t + rng.normal(scale=sigma, size=Q.shape)
+    Qm = Qm[rng.permutation(Qm.shape[0])]
+    T = np.eye(4)
+    T[:3, :3] = R.T
+    T[:3, 3] = -R.T @ t
+    return P.astype(np.float32), Qm.astype(np.float32), T
+
+
+def sphere_cloud(n, seed):
+    """tests/testing.h:157-168 generateSphereCloud analogue (random points on the unit sphere)."""
+    rng = np.random.default_rng(seed)
+    d = rng.uniform(-1, 1, size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    return d.astype(np.float32)

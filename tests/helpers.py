@@ -1,0 +1,28 @@
+"""Shared helpers of the parity tests."""
+import numpy as np
+
+from super4pcs_amd import datasets as D
+
+
+def small_pair(n_points=30000, delta=0.01, seed=7, overlap=0.6):
+    P, Q, T = D.bumpy_pair(n_points, overlap=overlap, delta=delta, noise_sigma=0.3 * delta, seed=seed)
+    return P, Q, T
+
+
+def init_oracle(O, P, Q, delta, overlap, sample_size, seed=5489, **kw):
+    opt = O.make_options(delta, overlap, sample_size, seed=seed, **kw)
+    m = O.Matcher(opt, full_counts=True, use_kdtree=True, keep_trace=True)
+    m.init(P, Q)
+    return m
+
+
+def random_rigid(rng, scale_t=0.2):
+    q = rng.normal(size=4); q /= np.linalg.norm(q)
+    w, x, y, z = q
+    R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                  [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                  [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+    T = np.eye(4, dtype=np.float32)
+    T[:3, :3] = R
+    T[:3, 3] = rng.uniform(-scale_t, scale_t, 3)
+    return T
