@@ -132,6 +132,12 @@ int32_t s4p_verify_transforms(s4p_ctx* ctx, const float* transforms, int64_t B, 
 int32_t s4p_try_base(s4p_ctx* ctx, const int32_t* base_ids, float invariant1, float invariant2,
                      s4p_base_result* result);
 
+/* Multi-GPU sharding by base: a rank that does NOT own the current base still has to
+ * advance the persistent pair-octree permutation exactly as the two ExtractPairs calls of that base
+ * would (intersectionNode.h:156-176 partitions functor.ids in place), so that later bases emit pairs in
+ * the reference order on every rank.  Host-only; launches nothing. */
+int32_t s4p_skip_base(s4p_ctx* ctx);
+
 /* Debug/parity access to the last s4p_try_base: per-candidate records in reference order.
  * quads (4 ints), counts (-1 = gate failed); returns K via n_out. */
 int32_t s4p_last_candidates(s4p_ctx* ctx, int32_t* quads, int32_t* counts, int64_t cap, int64_t* n_out);

@@ -54,6 +54,9 @@ def lib():
         L.s4po_create.argtypes = [C.POINTER(Options)]
         L.s4po_destroy.argtypes = [C.c_void_p]
         L.s4po_set_mode.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.s4po_set_budget.argtypes = [C.c_void_p, C.c_double]
+        L.s4po_budget_hit.restype = C.c_int32
+        L.s4po_budget_hit.argtypes = [C.c_void_p]
         L.s4po_sample.restype = C.c_uint64
         L.s4po_sample.argtypes = [fp, C.c_uint64, C.c_float, fp]
         L.s4po_init.argtypes = [C.c_void_p, fp, fp, fp, C.c_uint64, fp, fp, fp, C.c_uint64]
@@ -143,6 +146,12 @@ class Matcher:
 
     def set_mode(self, full_counts, use_kdtree=True, keep_trace=False):
         self.L.s4po_set_mode(self.h, int(full_counts), int(use_kdtree), int(keep_trace))
+
+    def set_budget(self, seconds):
+        self.L.s4po_set_budget(self.h, float(seconds))
+
+    def budget_hit(self):
+        return bool(self.L.s4po_budget_hit(self.h))
 
     def init(self, P, Q, Pn=None, Prgb=None, Qn=None, Qrgb=None):
         P = _c32(P); Q = _c32(Q)

@@ -325,6 +325,9 @@ struct Matcher {
   uint64_t n_verified = 0;          // visitor calls with fraction == -1
   uint64_t n_quads = 0, n_pairs = 0, n_verify_queries = 0;
   double t_pairs = 0, t_quads = 0, t_verify = 0, t_select = 0;
+  double budget_seconds = 0;        // >0: TryCongruentSet stops once this much wall time was spent (bench sample)
+  std::chrono::steady_clock::time_point budget_t0;
+  bool budget_hit = false;
   bool full_counts = false;         // if true Verify never exits early (parity mode)
   bool use_kdtree = true;           // false: brute-force predicate
   std::vector<Trace> trace;
@@ -880,6 +883,11 @@ struct Matcher {
     size_t nb = 0;
     if (per_cand) per_cand->assign(quads.size(), -1);
     for (int i = 0; i < int(quads.size()); ++i) {
+      if (budget_seconds > 0 && (i & 15) == 0 &&
+          std::chrono::duration<double>(std::chrono::steady_clock::now() - budget_t0).count() > budget_seconds) {
+        budget_hit = true;   // bounded cpu_baseline sample: not a reference behaviour
+        break;
+      }
       const int a = quads[i][0], b = quads[i][1], c = quads[i][2], d = quads[i][3];
       const P3 cc[4] = {Qs[a], Qs[b], Qs[c], Qs[d]};
       float centroid2[3];
@@ -1047,6 +1055,12 @@ void* s4po_create(const s4po_options* o) {
   return new Matcher(opt);
 }
 void s4po_destroy(void* h) { delete static_cast<Matcher*>(h); }
+// bench-only: bound the CPU sample; the clock starts now.  Returns nothing; s4po_budget_hit() tells if it tripped.
+void s4po_set_budget(void* h, double seconds) {
+  Matcher* m = static_cast<Matcher*>(h);
+  m->budget_seconds = seconds; m->budget_t0 = std::chrono::steady_clock::now(); m->budget_hit = false;
+}
+int32_t s4po_budget_hit(void* h) { return static_cast<Matcher*>(h)->budget_hit ? 1 : 0; }
 void s4po_set_mode(void* h, int full_counts, int use_kdtree, int keep_trace) {
   Matcher* m = static_cast<Matcher*>(h);
   m->full_counts = full_counts != 0; m->use_kdtree = use_kdtree != 0; m->keep_trace = keep_trace != 0;

@@ -18,7 +18,7 @@ ERR_NAMES = {0: "OK", -1: "BAD_ARG", -2: "NO_DEVICE", -3: "HIP", -4: "OOM", -5: 
 EXPORTED_SYMBOLS = [
     "s4p_create", "s4p_destroy", "s4p_last_error", "s4p_device_name", "s4p_set_clouds", "s4p_set_base",
     "s4p_extract_pairs", "s4p_find_congruent", "s4p_try_congruent_set", "s4p_verify_transforms",
-    "s4p_try_base", "s4p_last_candidates", "s4p_transform_points", "s4p_profile_enable", "s4p_profile_get",
+    "s4p_try_base", "s4p_skip_base", "s4p_last_candidates", "s4p_transform_points", "s4p_profile_enable", "s4p_profile_get",
     "s4p_selftest_ieee",
 ]
 
@@ -95,6 +95,8 @@ def load_library():
     L.s4p_verify_transforms.argtypes = [vp, fp, C.c_int64, C.POINTER(C.c_uint32)]
     L.s4p_try_base.restype = C.c_int32
     L.s4p_try_base.argtypes = [vp, ip, C.c_float, C.c_float, C.POINTER(BaseResult)]
+    L.s4p_skip_base.restype = C.c_int32
+    L.s4p_skip_base.argtypes = [vp]
     L.s4p_last_candidates.restype = C.c_int32
     L.s4p_last_candidates.argtypes = [vp, ip, ip, C.c_int64, C.POINTER(C.c_int64)]
     L.s4p_transform_points.restype = C.c_int32
@@ -249,3 +251,208 @@ class Context:
         o1 = np.empty_like(a); o2 = np.empty_like(a); o3 = np.empty_like(a)
         self._chk(self.L.s4p_selftest_ieee(self.h, _f(a), _f(b), a.shape[0], _f(o1), _f(o2), _f(o3)))
         return o1, o2, o3
+
+
+# ----------------------------------------------------------------------------------------------
+# include/s4p_matcher.h : host RANSAC driver (C++ engine) behind Match4PCSBase::ComputeTransformation
+# ----------------------------------------------------------------------------------------------
+class CloudView(C.Structure):
+    _fields_ = [(n, C.POINTER(C.c_float)) for n in ("x", "y", "z", "nx", "ny", "nz", "r", "g", "b")] + [("n", C.c_int64)]
+
+
+class MatcherInfo(C.Structure):
+    _fields_ = [
+        ("number_of_trials", C.c_int32), ("current_trial", C.c_int32), ("n_sampled_p", C.c_int32), ("n_sampled_q", C.c_int32),
+        ("best_lcp", C.c_float), ("best_count", C.c_uint32), ("p_diameter", C.c_float),
+        ("centroid_p", C.c_float * 3), ("centroid_q", C.c_float * 3), ("transform", C.c_float * 16),
+        ("qcentroid1", C.c_float * 3), ("qcentroid2", C.c_float * 3), ("base", C.c_int32 * 4), ("congruent", C.c_int32 * 4),
+        ("candidates_verified", C.c_uint64), ("quads_total", C.c_uint64), ("pairs_total", C.c_uint64), ("bases_tried", C.c_uint64),
+        ("seconds_select", C.c_double), ("seconds_device", C.c_double),
+    ]
+
+
+MATCHER_SYMBOLS = [
+    "s4p_matcher_create", "s4p_matcher_destroy", "s4p_matcher_last_error", "s4p_matcher_ctx", "s4p_uniform_dist_sample",
+    "s4p_matcher_init", "s4p_matcher_init_full", "s4p_matcher_get_info", "s4p_matcher_get_sampled",
+    "s4p_matcher_select_quadrilateral", "s4p_matcher_try_one_base", "s4p_matcher_next_base", "s4p_matcher_commit", "s4p_matcher_perform_n_steps",
+    "s4p_matcher_global_transform", "s4p_matcher_compute_transformation",
+]
+VISITOR_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_float, C.c_float, C.POINTER(C.c_float))
+_MATCHER_DECLARED = False
+
+
+def _declare_matcher(L):
+    global _MATCHER_DECLARED
+    if _MATCHER_DECLARED:
+        return
+    fp = C.POINTER(C.c_float); ip = C.POINTER(C.c_int32); vp = C.c_void_p; cv = C.POINTER(CloudView)
+    L.s4p_matcher_create.restype = C.c_int32
+    L.s4p_matcher_create.argtypes = [C.POINTER(Options), C.POINTER(Limits), C.c_int32, C.POINTER(vp)]
+    L.s4p_matcher_destroy.argtypes = [vp]
+    L.s4p_matcher_last_error.restype = C.c_char_p
+    L.s4p_matcher_last_error.argtypes = [vp]
+    L.s4p_matcher_ctx.restype = vp
+    L.s4p_matcher_ctx.argtypes = [vp]
+    L.s4p_uniform_dist_sample.restype = C.c_int64
+    L.s4p_uniform_dist_sample.argtypes = [fp, fp, fp, C.c_int64, C.c_float, C.POINTER(C.c_int64)]
+    L.s4p_matcher_init.restype = C.c_int32
+    L.s4p_matcher_init.argtypes = [vp, cv, cv, C.c_int32]
+    L.s4p_matcher_init_full.restype = C.c_int32
+    L.s4p_matcher_init_full.argtypes = [vp, cv, cv]
+    L.s4p_matcher_get_info.restype = C.c_int32
+    L.s4p_matcher_get_info.argtypes = [vp, C.POINTER(MatcherInfo)]
+    L.s4p_matcher_get_sampled.restype = C.c_int32
+    L.s4p_matcher_get_sampled.argtypes = [vp, C.c_int32, fp, fp, fp]
+    L.s4p_matcher_select_quadrilateral.restype = C.c_int32
+    L.s4p_matcher_select_quadrilateral.argtypes = [vp, ip, fp, fp, ip, fp]
+    L.s4p_matcher_try_one_base.restype = C.c_int32
+    L.s4p_matcher_try_one_base.argtypes = [vp, ip, C.POINTER(BaseResult)]
+    L.s4p_matcher_next_base.restype = C.c_int32
+    L.s4p_matcher_next_base.argtypes = [vp, C.c_int32, ip, ip, C.POINTER(BaseResult)]
+    L.s4p_matcher_commit.restype = C.c_int32
+    L.s4p_matcher_commit.argtypes = [vp, C.c_int32, ip, C.POINTER(BaseResult), ip]
+    L.s4p_matcher_perform_n_steps.restype = C.c_int32
+    L.s4p_matcher_perform_n_steps.argtypes = [vp, C.c_int32, VISITOR_FN, vp, C.c_int32, fp, ip, ip]
+    L.s4p_matcher_global_transform.restype = C.c_int32
+    L.s4p_matcher_global_transform.argtypes = [vp, fp]
+    L.s4p_matcher_compute_transformation.restype = C.c_int32
+    L.s4p_matcher_compute_transformation.argtypes = [vp, cv, cv, fp, fp, fp, fp, fp]
+    _MATCHER_DECLARED = True
+
+
+def uniform_dist_sample(xyz, delta):
+    """UniformDistSampler (sampling.h:104-121): indices of the kept points."""
+    L = load_library(); _declare_matcher(L)
+    xyz = np.ascontiguousarray(xyz, np.float32)
+    x, y, z = _col(xyz, 0), _col(xyz, 1), _col(xyz, 2)
+    out = np.empty(xyz.shape[0], np.int64)
+    k = L.s4p_uniform_dist_sample(_f(x), _f(y), _f(z), xyz.shape[0], delta, out.ctypes.data_as(C.POINTER(C.c_int64)))
+    return out[:k].copy()
+
+
+class _View:
+    """Keeps the SoA columns of an (n,3) cloud (+ optional normals / rgb) alive for a CloudView."""
+
+    def __init__(self, xyz, nrm=None, rgb=None):
+        xyz = np.ascontiguousarray(xyz, np.float32)
+        self.cols = [_col(xyz, k).copy() for k in range(3)]
+        self.ncols = None if nrm is None else [_col(np.asarray(nrm, np.float32), k).copy() for k in range(3)]
+        self.ccols = None if rgb is None else [_col(np.asarray(rgb, np.float32), k).copy() for k in range(3)]
+        v = CloudView()
+        v.x, v.y, v.z = (_f(c) for c in self.cols)
+        if self.ncols is not None:
+            v.nx, v.ny, v.nz = (_f(c) for c in self.ncols)
+        if self.ccols is not None:
+            v.r, v.g, v.b = (_f(c) for c in self.ccols)
+        v.n = xyz.shape[0]
+        self.view = v
+
+
+class Matcher:
+    """One s4p_matcher: the engine behind MatchSuper4PCS (reference: algorithms/super4pcs.h:56-130)."""
+
+    def __init__(self, options, device=0, max_pairs=0, max_quads=0, max_grid_cells=0):
+        self.L = load_library(); _declare_matcher(self.L)
+        lim = Limits(max_pairs, max_quads, max_grid_cells)
+        h = C.c_void_p()
+        rc = self.L.s4p_matcher_create(C.byref(options), C.byref(lim), device, C.byref(h))
+        if rc != S4P_OK:
+            raise S4PError(rc, self.L.s4p_last_error(None).decode())
+        self.h = h
+        self.opt = options
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.s4p_matcher_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != S4P_OK:
+            raise S4PError(rc, self.L.s4p_matcher_last_error(self.h).decode())
+
+    def ctx_handle(self):
+        return C.c_void_p(self.L.s4p_matcher_ctx(self.h))
+
+    def profile_enable(self, events=True, point_tests=False):
+        self._chk(self.L.s4p_profile_enable(self.ctx_handle(), int(events), int(point_tests)))
+
+    def profile_get(self, reset=False):
+        p = Profile()
+        self._chk(self.L.s4p_profile_get(self.ctx_handle(), C.byref(p), int(reset)))
+        return p
+
+    def init_full(self, P, Q, Pn=None, Prgb=None, Qn=None, Qrgb=None):
+        vp, vq = _View(P, Pn, Prgb), _View(Q, Qn, Qrgb)
+        self._chk(self.L.s4p_matcher_init_full(self.h, C.byref(vp.view), C.byref(vq.view)))
+
+    def init_sampled(self, Ps, Qu, q_needs_shuffle):
+        vp, vq = _View(Ps), _View(Qu)
+        self._chk(self.L.s4p_matcher_init(self.h, C.byref(vp.view), C.byref(vq.view), int(q_needs_shuffle)))
+
+    def info(self):
+        i = MatcherInfo()
+        self._chk(self.L.s4p_matcher_get_info(self.h, C.byref(i)))
+        return i
+
+    def sampled(self, which):
+        i = self.info()
+        n = i.n_sampled_p if which == 0 else i.n_sampled_q
+        x = np.empty(n, np.float32); y = np.empty(n, np.float32); z = np.empty(n, np.float32)
+        self._chk(self.L.s4p_matcher_get_sampled(self.h, which, _f(x), _f(y), _f(z)))
+        return np.stack([x, y, z], axis=1)
+
+    def select_quadrilateral(self):
+        found = C.c_int32(); i1 = C.c_float(); i2 = C.c_float()
+        base = np.empty(4, np.int32); bx = np.zeros(12, np.float32)
+        self._chk(self.L.s4p_matcher_select_quadrilateral(self.h, C.byref(found), C.byref(i1), C.byref(i2), _i(base), _f(bx)))
+        return bool(found.value), i1.value, i2.value, base, bx.reshape(4, 3)
+
+    def try_one_base(self):
+        ok = C.c_int32(); r = BaseResult()
+        self._chk(self.L.s4p_matcher_try_one_base(self.h, C.byref(ok), C.byref(r)))
+        return bool(ok.value), r
+
+    def next_base(self, run_device=True):
+        found = C.c_int32(); base = np.empty(4, np.int32); r = BaseResult()
+        self._chk(self.L.s4p_matcher_next_base(self.h, int(run_device), C.byref(found), _i(base), C.byref(r)))
+        return bool(found.value), base, r
+
+    def commit(self, found, base, r):
+        ok = C.c_int32()
+        base = np.ascontiguousarray(base, np.int32)
+        self._chk(self.L.s4p_matcher_commit(self.h, int(found), _i(base), C.byref(r), C.byref(ok)))
+        return bool(ok.value)
+
+    def perform_n_steps(self, n, visitor=None, needs_global=False):
+        M = np.eye(4, dtype=np.float32).reshape(16)
+        imp = C.c_int32(); done = C.c_int32()
+        if visitor is None:
+            cb = C.cast(None, VISITOR_FN)
+        else:
+            def tramp(user, fraction, lcp, Tp):
+                visitor(fraction, lcp, np.ctypeslib.as_array(Tp, shape=(16,)).reshape(4, 4))
+            cb = VISITOR_FN(tramp)
+        self._chk(self.L.s4p_matcher_perform_n_steps(self.h, n, cb, None, int(needs_global), _f(M), C.byref(imp), C.byref(done)))
+        return M.reshape(4, 4), bool(imp.value), bool(done.value)
+
+    def global_transform(self):
+        M = np.empty(16, np.float32)
+        self._chk(self.L.s4p_matcher_global_transform(self.h, _f(M)))
+        return M.reshape(4, 4)
+
+    def compute_transformation(self, P, Q, Pn=None, Prgb=None, Qn=None, Qrgb=None):
+        """Returns (lcp, M 4x4 row-major, transformed Q) like Match4PCSBase::ComputeTransformation."""
+        vp, vq = _View(P, Pn, Prgb), _View(Q, Qn, Qrgb)
+        n = vq.view.n
+        qx = np.empty(n, np.float32); qy = np.empty(n, np.float32); qz = np.empty(n, np.float32)
+        qx[:] = vq.cols[0]; qy[:] = vq.cols[1]; qz[:] = vq.cols[2]
+        M = np.eye(4, dtype=np.float32).reshape(16)
+        lcp = C.c_float()
+        self._chk(self.L.s4p_matcher_compute_transformation(self.h, C.byref(vp.view), C.byref(vq.view), _f(qx), _f(qy), _f(qz), _f(M), C.byref(lcp)))
+        return lcp.value, M.reshape(4, 4), np.stack([qx, qy, qz], axis=1)

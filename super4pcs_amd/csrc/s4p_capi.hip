@@ -541,6 +541,19 @@ int32_t s4p_try_base(s4p_ctx* c, const int32_t* base_ids, float inv1, float inv2
   return S4P_OK;
 }
 
+int32_t s4p_skip_base(s4p_ctx* c) {
+  if (!c) return S4P_ERR_BAD_ARG;
+  if (!c->clouds_set) S4P_FAIL(c, S4P_ERR_STATE, "s4p_set_clouds not called");
+  auto seg = [&](const float* v, int a, int b) {
+    const float d0 = v[3 * a] - v[3 * b], d1 = v[3 * a + 1] - v[3 * b + 1], d2 = v[3 * a + 2] - v[3 * b + 2];
+    return std::sqrt(d0 * d0 + (d1 * d1 + d2 * d2));
+  };
+  const float eps_n = (2.0f * c->opt.delta) / c->frame.ratio;
+  c->tree.build(c->hux.data(), c->huy.data(), c->huz.data(), c->n_q, seg(c->base_xyz, 0, 1) / c->frame.ratio, eps_n, 50);
+  c->tree.build(c->hux.data(), c->huy.data(), c->huz.data(), c->n_q, seg(c->base_xyz, 2, 3) / c->frame.ratio, eps_n, 50);
+  return S4P_OK;
+}
+
 int32_t s4p_last_candidates(s4p_ctx* c, int32_t* quads, int32_t* counts, int64_t cap, int64_t* n_out) {
   if (!c || !n_out) return S4P_ERR_BAD_ARG;
   const uint64_t K = c->last_K;

@@ -1,0 +1,513 @@
+// s4p_engine.cpp -- host RANSAC driver behind include/s4p_matcher.h.
+//
+// Host-side parts of the reference that fix the RNG stream and the inputs of the hot
+// path and therefore have to be reproduced exactly:
+//   UniformDistSampler                    src/super4pcs/sampling.h:59-122
+//   Match4PCSBase::init                   src/super4pcs/algorithms/match4pcsBase.hpp:90-203
+//   SelectRandomTriangle / TryQuadrilateral / SelectQuadrilateral / distSegmentToSegment
+//                                         src/super4pcs/algorithms/match4pcsBase.cc:64-131,185-351
+//   TryOneBase / Perform_N_steps          match4pcsBase.hpp:208-360
+// Everything data-parallel (pairs, quads, rigid transform, LCP, final apply) is delegated to
+// the gfx950 kernels through the C ABI of s4p_capi.h.  No CPU fallback exists for those.
+#include <algorithm>
+#include <array>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <random>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "s4p_matcher.h"
+
+namespace {
+
+struct Cloud {
+  std::vector<float> x, y, z, nx, ny, nz, r, g, b;
+  bool has_n = false, has_c = false;
+  size_t size() const { return x.size(); }
+  void reserve(size_t n) { x.reserve(n); y.reserve(n); z.reserve(n); }
+  void push_from(const s4p_cloud_view& v, int64_t i) {
+    x.push_back(v.x[i]); y.push_back(v.y[i]); z.push_back(v.z[i]);
+    if (has_n) { nx.push_back(v.nx[i]); ny.push_back(v.ny[i]); nz.push_back(v.nz[i]); }
+    if (has_c) { r.push_back(v.r[i]); g.push_back(v.g[i]); b.push_back(v.b[i]); }
+  }
+  void init_flags(const s4p_cloud_view& v) { has_n = v.nx && v.ny && v.nz; has_c = v.r && v.g && v.b; }
+};
+
+struct V3 { float x, y, z; };
+inline V3 sub(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline float dot(V3 a, V3 b) { return a.x * b.x + (a.y * b.y + a.z * b.z); }      // Eigen: x + (y + z)
+inline float sqn(V3 a) { return dot(a, a); }
+inline float len(V3 a) { return std::sqrt(sqn(a)); }
+inline V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+
+struct VoxelKey { int32_t a, b, c; bool operator==(const VoxelKey& o) const { return a == o.a && b == o.b && c == o.c; } };
+struct VoxelHash {
+  size_t operator()(const VoxelKey& k) const {
+    uint64_t h = uint64_t(uint32_t(k.a)) * 0x9E3779B97F4A7C15ull;
+    h ^= (uint64_t(uint32_t(k.b)) + 0x7F4A7C15ull + (h << 6) + (h >> 2));
+    h ^= (uint64_t(uint32_t(k.c)) * 0xC2B2AE3D27D4EB4Full + (h << 7) + (h >> 3));
+    return size_t(h);
+  }
+};
+
+// sampling.h:104-121: first point per delta-voxel, voxel = int(floor(coord * (1.0f / delta))).
+int64_t voxel_first_hits(const float* x, const float* y, const float* z, int64_t n, float delta, int64_t* out) {
+  const float scale = 1.0f / delta;
+  std::unordered_map<VoxelKey, char, VoxelHash> seen;
+  seen.reserve(size_t(n / 4 + 16));
+  int64_t kept = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    VoxelKey k{int32_t(std::floor(x[i] * scale)), int32_t(std::floor(y[i] * scale)), int32_t(std::floor(z[i] * scale))};
+    if (seen.emplace(k, 1).second) out[kept++] = i;
+  }
+  return kept;
+}
+
+}  // namespace
+
+struct s4p_matcher {
+  s4p_options opt{};
+  s4p_ctx* ctx = nullptr;
+  std::string err;
+  std::mt19937 rng;
+  Cloud Ps, Qs;
+  float centroid_p[3] = {0, 0, 0}, centroid_q[3] = {0, 0, 0};
+  float p_diameter = 0.f, max_base_diameter = -1.f;
+  int number_of_trials = 0, current_trial = 0;
+  float best_lcp = 0.f; uint32_t best_count = 0;
+  float transform[16];
+  float qc1[3] = {0, 0, 0}, qc2[3] = {0, 0, 0};
+  int base[4] = {0, 0, 0, 0}, congruent[4] = {0, 0, 0, 0};
+  // base_3D_
+  int b3_id[4] = {0, 0, 0, 0};
+  uint64_t candidates_verified = 0, quads_total = 0, pairs_total = 0, bases_tried = 0;
+  double seconds_select = 0, seconds_device = 0;
+  bool ready = false;
+
+  void set_identity() { for (int i = 0; i < 16; ++i) transform[i] = (i % 5 == 0) ? 1.f : 0.f; }
+  V3 P(int i) const { return {Ps.x[i], Ps.y[i], Ps.z[i]}; }
+  int32_t fail(int32_t code, const std::string& m) { err = m; return code; }
+  int32_t ctx_fail(int32_t code) { err = s4p_last_error(ctx); return code; }
+};
+
+namespace {
+
+void centre_cloud(Cloud& c, float* cen) {               // match4pcsBase.hpp:142-149
+  cen[0] = cen[1] = cen[2] = 0.f;
+  const size_t n = c.size();
+  for (size_t i = 0; i < n; ++i) { cen[0] += c.x[i]; cen[1] += c.y[i]; cen[2] += c.z[i]; }
+  const float fn = float(n);
+  cen[0] /= fn; cen[1] /= fn; cen[2] /= fn;
+  for (size_t i = 0; i < n; ++i) { c.x[i] -= cen[0]; c.y[i] -= cen[1]; c.z[i] -= cen[2]; }
+}
+
+// match4pcsBase.cc:64-131 with Scalar = double and float vectors (double * Vector3f promotes to float).
+double segment_segment(V3 p1, V3 p2, V3 q1, V3 q2, double& inv1, double& inv2) {
+  const double tiny = 0.0001;
+  const V3 u = sub(p2, p1), v = sub(q2, q1), w = sub(p1, q1);
+  const double a = dot(u, u), b = dot(u, v), c = dot(v, v), d = dot(u, w), e = dot(v, w);
+  const double f = a * c - b * b;
+  double s1 = 0.0, s2 = f, t1 = 0.0, t2 = f;
+  if (f < tiny) { s1 = 0.0; s2 = 1.0; t1 = e; t2 = c; }
+  else {
+    s1 = b * e - c * d;
+    t1 = a * e - b * d;
+    if (s1 < 0.0) { s1 = 0.0; t1 = e; t2 = c; }
+    else if (s1 > s2) { s1 = s2; t1 = e + b; t2 = c; }
+  }
+  if (t1 < 0.0) {
+    t1 = 0.0;
+    if (-d < 0.0) s1 = 0.0;
+    else if (-d > a) s1 = s2;
+    else { s1 = -d; s2 = a; }
+  } else if (t1 > t2) {
+    t1 = t2;
+    if ((-d + b) < 0.0) s1 = 0;
+    else if ((-d + b) > a) s1 = s2;
+    else { s1 = (-d + b); s2 = a; }
+  }
+  inv1 = (std::abs(s1) < tiny ? 0.0 : s1 / s2);
+  inv2 = (std::abs(t1) < tiny ? 0.0 : t1 / t2);
+  const float f1 = float(inv1), f2 = float(inv2);
+  const V3 r{(w.x + f1 * u.x) - f2 * v.x, (w.y + f1 * u.y) - f2 * v.y, (w.z + f1 * u.z) - f2 * v.z};
+  return double(len(r));
+}
+
+// match4pcsBase.cc:185-218
+bool pick_triangle(s4p_matcher* m, int& b1, int& b2, int& b3) {
+  const int n = int(m->Ps.size());
+  b1 = b2 = b3 = -1;
+  const int first = int(m->rng() % (unsigned long)n);
+  const float limit = m->max_base_diameter * m->max_base_diameter;
+  float widest = 0.f;
+  const V3 o = m->P(first);
+  for (int t = 0; t < 1000; ++t) {
+    const int second = int(m->rng() % (unsigned long)n);
+    const int third = int(m->rng() % (unsigned long)n);
+    const V3 u = sub(m->P(second), o), w = sub(m->P(third), o);
+    const float wide = len(cross(u, w));
+    if (wide > widest && sqn(u) < limit && sqn(w) < limit) { widest = wide; b1 = first; b2 = second; b3 = third; }
+  }
+  return b1 != -1 && b2 != -1 && b3 != -1;
+}
+
+// match4pcsBase.cc:225-274: best of the 12 segment pairings; reorders ids.
+bool order_quadrilateral(s4p_matcher* m, int ids[4], float& inv1, float& inv2) {
+  float best = std::numeric_limits<float>::max();
+  int pick[4] = {-1, -1, -1, -1};
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) {
+      if (i == j) continue;
+      int k = 0; while (k == i || k == j) k++;
+      int l = 0; while (l == i || l == j || l == k) l++;
+      double a, b;
+      const float dist = float(segment_segment(m->P(ids[i]), m->P(ids[j]), m->P(ids[k]), m->P(ids[l]), a, b));
+      if (dist < best) { best = dist; pick[0] = i; pick[1] = j; pick[2] = k; pick[3] = l; inv1 = float(a); inv2 = float(b); }
+    }
+  if (pick[0] < 0 || pick[1] < 0 || pick[2] < 0 || pick[3] < 0) return false;
+  const int old[4] = {ids[0], ids[1], ids[2], ids[3]};
+  for (int t = 0; t < 4; ++t) ids[t] = old[pick[t]];
+  return true;
+}
+
+// match4pcsBase.cc:279-351
+bool select_quadrilateral(s4p_matcher* m, float& inv1, float& inv2, int ids[4]) {
+  const float kBaseTooSmall = 0.2f;
+  const size_t n = m->Ps.size();
+  for (int attempt = 0; attempt < 1000; ++attempt) {
+    int b1, b2, b3;
+    if (!pick_triangle(m, b1, b2, b3)) return false;
+    const V3 A = m->P(b1), B = m->P(b2), C = m->P(b3);
+    const double x1 = A.x, y1 = A.y, z1 = A.z, x2 = B.x, y2 = B.y, z2 = B.z, x3 = C.x, y3 = C.y, z3 = C.z;
+    const float denom = float(-x3 * y2 * z1 + x2 * y3 * z1 + x3 * y1 * z2 - x1 * y3 * z2 - x2 * y1 * z3 + x1 * y2 * z3);
+    if (denom != 0) {
+      const float pa = float((-y2 * z1 + y3 * z1 + y1 * z2 - y3 * z2 - y1 * z3 + y2 * z3) / denom);
+      const float pb = float((x2 * z1 - x3 * z1 - x1 * z2 + x3 * z2 + x1 * z3 - x2 * z3) / denom);
+      const float pc = float((-x2 * y1 + x3 * y1 + x1 * y2 - x3 * y2 - x1 * y3 + x2 * y3) / denom);
+      int b4 = -1;
+      float best = std::numeric_limits<float>::max();
+      const float too_small = float(std::pow(double(m->max_base_diameter * kBaseTooSmall), 2));
+      const float* X = m->Ps.x.data(); const float* Y = m->Ps.y.data(); const float* Z = m->Ps.z.data();
+      for (size_t i = 0; i < n; ++i) {
+        const V3 p{X[i], Y[i], Z[i]};
+        if (sqn(sub(p, A)) >= too_small && sqn(sub(p, B)) >= too_small && sqn(sub(p, C)) >= too_small) {
+          const float dist = float(std::abs(double(pa * p.x + pb * p.y + pc * p.z) - 1.0));
+          if (dist < best) { best = dist; b4 = int(i); }
+        }
+      }
+      if (b4 != -1) {
+        ids[0] = b1; ids[1] = b2; ids[2] = b3; ids[3] = b4;
+        if (order_quadrilateral(m, ids, inv1, inv2)) return true;
+      }
+    }
+  }
+  return false;
+}
+
+void fill_base_arrays(const s4p_matcher* m, const int ids[4], float* xyz, float* nrm, float* rgb) {
+  for (int t = 0; t < 4; ++t) {
+    const int i = ids[t];
+    xyz[3 * t] = m->Ps.x[i]; xyz[3 * t + 1] = m->Ps.y[i]; xyz[3 * t + 2] = m->Ps.z[i];
+    if (m->Ps.has_n) { nrm[3 * t] = m->Ps.nx[i]; nrm[3 * t + 1] = m->Ps.ny[i]; nrm[3 * t + 2] = m->Ps.nz[i]; }
+    else { nrm[3 * t] = nrm[3 * t + 1] = nrm[3 * t + 2] = 0.f; }
+    if (m->Ps.has_c) { rgb[3 * t] = m->Ps.r[i]; rgb[3 * t + 1] = m->Ps.g[i]; rgb[3 * t + 2] = m->Ps.b[i]; }
+    else { rgb[3 * t] = rgb[3 * t + 1] = rgb[3 * t + 2] = -1.f; }
+  }
+}
+
+// match4pcsBase.hpp:224-229.  computeRotationScaling(rot, scale) of a rigid [R|t] returns
+// rot*scale == R up to SVD round-off; the linear part is used directly (DESIGN.md deviation D4).
+void global_transform(const s4p_matcher* m, float* M) {
+  std::memcpy(M, m->transform, sizeof(float) * 16);
+  const float a[3] = {m->qc2[0] + m->centroid_q[0], m->qc2[1] + m->centroid_q[1], m->qc2[2] + m->centroid_q[2]};
+  for (int r = 0; r < 3; ++r) {
+    const float ra = m->transform[4 * r] * a[0] + (m->transform[4 * r + 1] * a[1] + m->transform[4 * r + 2] * a[2]);
+    M[4 * r + 3] = (m->qc1[r] + m->centroid_p[r]) - ra;
+  }
+  M[12] = M[13] = M[14] = 0.f; M[15] = 1.f;
+}
+
+// first half of TryOneBase (match4pcsBase.hpp:281-351): base selection + device pass (or state advance only)
+int32_t next_base(s4p_matcher* m, bool run_device, bool& found, int ids[4], s4p_base_result& r) {
+  using clk = std::chrono::steady_clock;
+  float inv1 = 0, inv2 = 0;
+  std::memset(&r, 0, sizeof(r));
+  auto t0 = clk::now();
+  found = select_quadrilateral(m, inv1, inv2, ids);
+  m->seconds_select += std::chrono::duration<double>(clk::now() - t0).count();
+  if (!found) return S4P_OK;                                     // :313-316
+  float bx[12], bn[12], bc[12];
+  fill_base_arrays(m, ids, bx, bn, bc);
+  if (int32_t rc = s4p_set_base(m->ctx, bx, bn, bc)) return m->ctx_fail(rc);
+  t0 = clk::now();
+  if (run_device) {
+    if (int32_t rc = s4p_try_base(m->ctx, ids, inv1, inv2, &r)) return m->ctx_fail(rc);
+    m->bases_tried++;
+    m->pairs_total += r.n_pairs1 + r.n_pairs2; m->quads_total += r.n_quads; m->candidates_verified += r.n_verified;
+  } else {
+    if (int32_t rc = s4p_skip_base(m->ctx)) return m->ctx_fail(rc);
+  }
+  m->seconds_device += std::chrono::duration<double>(clk::now() - t0).count();
+  return S4P_OK;
+}
+
+// second half: best update + TryOneBase's return value
+bool commit_base(s4p_matcher* m, bool found, const int ids[4], const s4p_base_result& r) {
+  if (!found) return false;
+  if (r.n_pairs1 == 0 || r.n_pairs2 == 0) return false;         // :335-337
+  if (r.n_quads == 0) return false;                              // :340-347
+  if (r.has_best) {
+    const float lcp = float(r.best_count) / float(m->Qs.size()); // Verify's return value, .cc:566
+    if (lcp > m->best_lcp) {                                     // :467-484 (first strictly greater wins)
+      for (int t = 0; t < 4; ++t) { m->base[t] = ids[t]; m->congruent[t] = r.best_quad[t]; }
+      m->best_lcp = lcp; m->best_count = r.best_count;
+      std::memcpy(m->transform, r.best_transform, sizeof(float) * 16);
+      for (int k = 0; k < 3; ++k) { m->qc1[k] = r.centroid1[k]; m->qc2[k] = r.best_centroid2[k]; }
+    }
+  }
+  return m->best_lcp > m->opt.terminate_threshold;               // :496
+}
+
+int32_t try_one_base(s4p_matcher* m, bool& ok, s4p_base_result* last) {
+  ok = false;
+  bool found = false; int ids[4] = {0, 0, 0, 0}; s4p_base_result r;
+  if (int32_t rc = next_base(m, true, found, ids, r)) return rc;
+  if (last) *last = r;
+  ok = commit_base(m, found, ids, r);
+  return S4P_OK;
+}
+
+bool view_ok(const s4p_cloud_view* v) { return v && v->x && v->y && v->z && v->n >= 0; }
+
+}  // namespace
+
+extern "C" {
+
+int32_t s4p_matcher_create(const s4p_options* opt, const s4p_limits* lim, int32_t device, s4p_matcher** out) {
+  if (!opt || !out) return S4P_ERR_BAD_ARG;
+  *out = nullptr;
+  s4p_ctx* ctx = nullptr;
+  if (int32_t rc = s4p_create(opt, lim, device, &ctx)) return rc;
+  s4p_matcher* m = new s4p_matcher();
+  m->opt = *opt; m->ctx = ctx; m->rng.seed(opt->random_seed);
+  m->set_identity();
+  *out = m;
+  return S4P_OK;
+}
+
+void s4p_matcher_destroy(s4p_matcher* m) {
+  if (!m) return;
+  s4p_destroy(m->ctx);
+  delete m;
+}
+
+const char* s4p_matcher_last_error(const s4p_matcher* m) { return m ? m->err.c_str() : s4p_last_error(nullptr); }
+s4p_ctx* s4p_matcher_ctx(s4p_matcher* m) { return m ? m->ctx : nullptr; }
+
+int64_t s4p_uniform_dist_sample(const float* x, const float* y, const float* z, int64_t n, float delta, int64_t* out) {
+  if (!x || !y || !z || !out || n <= 0 || !(delta > 0.f)) return 0;
+  return voxel_first_hits(x, y, z, n, delta, out);
+}
+
+int32_t s4p_matcher_init(s4p_matcher* m, const s4p_cloud_view* p, const s4p_cloud_view* q, int32_t q_needs_shuffle) {
+  if (!m) return S4P_ERR_BAD_ARG;
+  if (!view_ok(p) || !view_ok(q) || p->n == 0 || q->n == 0) return m->fail(S4P_ERR_BAD_ARG, "s4p_matcher_init: empty or null cloud");
+  m->ready = false;
+  Cloud& Ps = m->Ps; Cloud& Qs = m->Qs;
+  Ps = Cloud(); Qs = Cloud();
+  Ps.init_flags(*p); Qs.init_flags(*q);
+  Ps.reserve(size_t(p->n));
+  for (int64_t i = 0; i < p->n; ++i) Ps.push_from(*p, i);
+  if (q_needs_shuffle) {                                           // match4pcsBase.hpp:129-133
+    std::vector<uint32_t> perm(size_t(q->n));
+    for (size_t i = 0; i < perm.size(); ++i) perm[i] = uint32_t(i);
+    std::shuffle(perm.begin(), perm.end(), m->rng);                // identical swap sequence to shuffling the points
+    const size_t keep = std::min<size_t>(perm.size(), size_t(m->opt.sample_size));
+    Qs.reserve(keep);
+    for (size_t i = 0; i < keep; ++i) Qs.push_from(*q, int64_t(perm[i]));
+  } else {
+    Qs.reserve(size_t(q->n));
+    for (int64_t i = 0; i < q->n; ++i) Qs.push_from(*q, i);
+  }
+  centre_cloud(Ps, m->centroid_p);
+  centre_cloud(Qs, m->centroid_q);
+  // P_diameter_: 1000 random pair distances in the sampled Q (quirk), match4pcsBase.hpp:155-164
+  m->p_diameter = 0.f;
+  const unsigned long nq = (unsigned long)Qs.size();
+  for (int t = 0; t < 1000; ++t) {
+    const int at = int(m->rng() % nq);
+    const int bt = int(m->rng() % nq);
+    const float l = len(sub(V3{Qs.x[bt], Qs.y[bt], Qs.z[bt]}, V3{Qs.x[at], Qs.y[at], Qs.z[at]}));
+    if (l > m->p_diameter) m->p_diameter = l;
+  }
+  // MeanDistance() (match4pcsBase.cc:158-182) only fills P_mean_distance_, which nothing reads; it draws
+  // no random numbers, so it is skipped here.
+  m->max_base_diameter = m->p_diameter;                            // :172
+  const float kSmallError = 0.00001f;                               // :175-185
+  const float first_estimation = float(std::log(kSmallError) /
+      std::log(1.0 - std::pow(double(m->opt.overlap_estimation), double(4.0f))));
+  m->number_of_trials = int(first_estimation * (m->p_diameter / 0.3f) / m->max_base_diameter);
+  if (m->number_of_trials < 4) m->number_of_trials = 4;
+  m->current_trial = 0;
+  m->best_lcp = 0.f; m->best_count = 0;
+  for (int t = 0; t < 4; ++t) { m->base[t] = 0; m->congruent[t] = 0; }
+  m->set_identity();
+  // Initialize() -> device structures; then best_LCP_ = Verify(identity)   (:199-201)
+  if (int32_t rc = s4p_set_clouds(m->ctx, Ps.x.data(), Ps.y.data(), Ps.z.data(), int64_t(Ps.size()),
+                                  Qs.x.data(), Qs.y.data(), Qs.z.data(),
+                                  Qs.has_n ? Qs.nx.data() : nullptr, Qs.has_n ? Qs.ny.data() : nullptr, Qs.has_n ? Qs.nz.data() : nullptr,
+                                  Qs.has_c ? Qs.r.data() : nullptr, Qs.has_c ? Qs.g.data() : nullptr, Qs.has_c ? Qs.b.data() : nullptr,
+                                  int64_t(Qs.size())))
+    return m->ctx_fail(rc);
+  uint32_t c0 = 0;
+  if (int32_t rc = s4p_verify_transforms(m->ctx, m->transform, 1, &c0)) return m->ctx_fail(rc);
+  m->best_count = c0;
+  m->best_lcp = float(c0) / float(Qs.size());
+  m->ready = true;
+  return S4P_OK;
+}
+
+int32_t s4p_matcher_init_full(s4p_matcher* m, const s4p_cloud_view* P, const s4p_cloud_view* Q) {
+  if (!m) return S4P_ERR_BAD_ARG;
+  if (!view_ok(P) || !view_ok(Q) || P->n == 0 || Q->n == 0) return m->fail(S4P_ERR_BAD_ARG, "empty or null cloud");
+  auto subset = [&](const s4p_cloud_view& v, bool sample, std::vector<std::vector<float>>& store) -> s4p_cloud_view {
+    if (!sample) return v;                                          // "use whole cloud", match4pcsBase.hpp:115-119
+    std::vector<int64_t> idx(size_t(v.n));
+    const int64_t k = voxel_first_hits(v.x, v.y, v.z, v.n, m->opt.delta, idx.data());
+    const float* src[9] = {v.x, v.y, v.z, v.nx, v.ny, v.nz, v.r, v.g, v.b};
+    store.assign(9, {});
+    const float* dst[9];
+    for (int a = 0; a < 9; ++a) {
+      if (!src[a]) { dst[a] = nullptr; continue; }
+      store[a].resize(size_t(k));
+      for (int64_t i = 0; i < k; ++i) store[a][size_t(i)] = src[a][idx[size_t(i)]];
+      dst[a] = store[a].data();
+    }
+    return s4p_cloud_view{dst[0], dst[1], dst[2], dst[3], dst[4], dst[5], dst[6], dst[7], dst[8], k};
+  };
+  std::vector<std::vector<float>> sp, sq;
+  const bool sample_p = uint64_t(P->n) > m->opt.sample_size;
+  const bool sample_q = uint64_t(Q->n) > m->opt.sample_size;
+  const s4p_cloud_view pv = subset(*P, sample_p, sp);
+  const s4p_cloud_view qv = subset(*Q, sample_q, sq);
+  return s4p_matcher_init(m, &pv, &qv, sample_q ? 1 : 0);
+}
+
+int32_t s4p_matcher_get_info(s4p_matcher* m, s4p_matcher_info* o) {
+  if (!m || !o) return S4P_ERR_BAD_ARG;
+  std::memset(o, 0, sizeof(*o));
+  o->number_of_trials = m->number_of_trials; o->current_trial = m->current_trial;
+  o->n_sampled_p = int32_t(m->Ps.size()); o->n_sampled_q = int32_t(m->Qs.size());
+  o->best_lcp = m->best_lcp; o->best_count = m->best_count; o->p_diameter = m->p_diameter;
+  for (int k = 0; k < 3; ++k) { o->centroid_p[k] = m->centroid_p[k]; o->centroid_q[k] = m->centroid_q[k]; o->qcentroid1[k] = m->qc1[k]; o->qcentroid2[k] = m->qc2[k]; }
+  std::memcpy(o->transform, m->transform, sizeof(float) * 16);
+  for (int t = 0; t < 4; ++t) { o->base[t] = m->base[t]; o->congruent[t] = m->congruent[t]; }
+  o->candidates_verified = m->candidates_verified; o->quads_total = m->quads_total; o->pairs_total = m->pairs_total;
+  o->bases_tried = m->bases_tried; o->seconds_select = m->seconds_select; o->seconds_device = m->seconds_device;
+  return S4P_OK;
+}
+
+int32_t s4p_matcher_get_sampled(s4p_matcher* m, int32_t which, float* x, float* y, float* z) {
+  if (!m || !x || !y || !z) return S4P_ERR_BAD_ARG;
+  const Cloud& c = which == 0 ? m->Ps : m->Qs;
+  std::memcpy(x, c.x.data(), c.size() * 4); std::memcpy(y, c.y.data(), c.size() * 4); std::memcpy(z, c.z.data(), c.size() * 4);
+  return S4P_OK;
+}
+
+int32_t s4p_matcher_select_quadrilateral(s4p_matcher* m, int32_t* found, float* inv1, float* inv2, int32_t* base_ids, float* base_xyz) {
+  if (!m || !found || !inv1 || !inv2 || !base_ids) return S4P_ERR_BAD_ARG;
+  if (!m->ready) return m->fail(S4P_ERR_STATE, "matcher not initialised");
+  int ids[4] = {0, 0, 0, 0};
+  *found = select_quadrilateral(m, *inv1, *inv2, ids) ? 1 : 0;
+  for (int t = 0; t < 4; ++t) base_ids[t] = ids[t];
+  if (base_xyz && *found) { float bn[12], bc[12]; fill_base_arrays(m, ids, base_xyz, bn, bc); }
+  return S4P_OK;
+}
+
+int32_t s4p_matcher_try_one_base(s4p_matcher* m, int32_t* ok, s4p_base_result* last) {
+  if (!m || !ok) return S4P_ERR_BAD_ARG;
+  if (!m->ready) return m->fail(S4P_ERR_STATE, "matcher not initialised");
+  bool b = false;
+  const int32_t rc = try_one_base(m, b, last);
+  *ok = b ? 1 : 0;
+  return rc;
+}
+
+int32_t s4p_matcher_next_base(s4p_matcher* m, int32_t run_device, int32_t* found, int32_t* base_ids, s4p_base_result* result) {
+  if (!m || !found || !base_ids || !result) return S4P_ERR_BAD_ARG;
+  if (!m->ready) return m->fail(S4P_ERR_STATE, "matcher not initialised");
+  bool f = false; int ids[4] = {0, 0, 0, 0};
+  const int32_t rc = next_base(m, run_device != 0, f, ids, *result);
+  *found = f ? 1 : 0;
+  for (int t = 0; t < 4; ++t) base_ids[t] = ids[t];
+  return rc;
+}
+
+int32_t s4p_matcher_commit(s4p_matcher* m, int32_t found, const int32_t* base_ids, const s4p_base_result* result, int32_t* ok) {
+  if (!m || !base_ids || !result || !ok) return S4P_ERR_BAD_ARG;
+  if (!m->ready) return m->fail(S4P_ERR_STATE, "matcher not initialised");
+  const int ids[4] = {base_ids[0], base_ids[1], base_ids[2], base_ids[3]};
+  *ok = commit_base(m, found != 0, ids, *result) ? 1 : 0;
+  return S4P_OK;
+}
+
+int32_t s4p_matcher_global_transform(s4p_matcher* m, float* M) {
+  if (!m || !M) return S4P_ERR_BAD_ARG;
+  global_transform(m, M);
+  return S4P_OK;
+}
+
+int32_t s4p_matcher_perform_n_steps(s4p_matcher* m, int32_t n, s4p_visitor_fn visitor, void* user, int32_t needs_global,
+                                    float* transformation, int32_t* improved, int32_t* done) {
+  if (!m || !transformation || !improved || !done) return S4P_ERR_BAD_ARG;
+  if (!m->ready) return m->fail(S4P_ERR_STATE, "matcher not initialised");
+  using sclock = std::chrono::system_clock;
+  const float last_best = m->best_lcp;
+  if (visitor) visitor(user, 0.f, m->best_lcp, transformation);          // match4pcsBase.hpp:232
+  bool ok = false;
+  const auto t0 = sclock::now();
+  for (int i = m->current_trial; i < m->current_trial + n; ++i) {
+    if (int32_t rc = try_one_base(m, ok, nullptr)) return rc;
+    const float fraction_try = float(i) / float(m->number_of_trials);
+    // integer seconds / integer max_time_seconds: reference quirk, :240-243
+    const float fraction_time = float(std::chrono::duration_cast<std::chrono::seconds>(sclock::now() - t0).count() /
+                                      (long)m->opt.max_time_seconds);
+    const float fraction = std::max(fraction_time, fraction_try);
+    if (needs_global) global_transform(m, transformation);
+    else std::memcpy(transformation, m->transform, sizeof(float) * 16);
+    if (visitor) visitor(user, fraction, m->best_lcp, transformation);
+    if (ok || i > m->number_of_trials || fraction >= 0.99 || m->best_lcp == 1.0) break;
+  }
+  m->current_trial += n;
+  *improved = m->best_lcp > last_best ? 1 : 0;
+  if (*improved) global_transform(m, transformation);
+  *done = (ok || m->current_trial >= m->number_of_trials) ? 1 : 0;
+  return S4P_OK;
+}
+
+int32_t s4p_matcher_compute_transformation(s4p_matcher* m, const s4p_cloud_view* P, const s4p_cloud_view* Q,
+                                           float* qx, float* qy, float* qz, float* M, float* lcp) {
+  if (!m || !M || !lcp) return S4P_ERR_BAD_ARG;
+  *lcp = 1e9f;                                                     // kLargeNumber, match4pcsBase.hpp:69-70
+  if (!Q || !P) return S4P_OK;
+  if (!view_ok(P) || !view_ok(Q)) return m->fail(S4P_ERR_BAD_ARG, "null coordinate arrays");
+  if (P->n == 0 || Q->n == 0) return S4P_OK;
+  if (int32_t rc = s4p_matcher_init_full(m, P, Q)) return rc;
+  int32_t improved = 0, done = 0;
+  if (m->best_lcp != 1.f)
+    if (int32_t rc = s4p_matcher_perform_n_steps(m, m->number_of_trials, nullptr, nullptr, 0, M, &improved, &done)) return rc;
+  *lcp = m->best_lcp;
+  if (improved && qx && qy && qz) {                                // match4pcsBase.hpp:259-268
+    if (qx != Q->x) std::memcpy(qx, Q->x, size_t(Q->n) * 4);
+    if (qy != Q->y) std::memcpy(qy, Q->y, size_t(Q->n) * 4);
+    if (qz != Q->z) std::memcpy(qz, Q->z, size_t(Q->n) * 4);
+    if (int32_t rc = s4p_transform_points(m->ctx, M, qx, qy, qz, Q->n)) return m->ctx_fail(rc);
+  }
+  return S4P_OK;
+}
+
+}  // extern "C"
