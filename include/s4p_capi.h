@@ -154,6 +154,8 @@ typedef struct {
   uint64_t verify_quads;         /* quads read by those launches (gate evaluated)       */
   uint64_t verify_point_tests;   /* P-point distance tests (k-bar numerator), if enabled */
   uint64_t verify_queries;       /* point queries (candidates * n_Q)                    */
+  uint64_t verify_l0_pass;       /* queries that passed the LDS coarse bitmap, if enabled */
+  uint64_t verify_l1_pass;       /* queries that passed the dilated fine bitmap, if enabled */
   double   pairs_ms_total, quads_ms_total;
   uint64_t pairs_launches, quads_launches;
 } s4p_profile;

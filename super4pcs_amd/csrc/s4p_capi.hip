@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <string>
@@ -55,11 +56,11 @@ struct s4p_ctx {
   bool clouds_set = false;
 
   // device state
-  DevBuf<float> gpx, gpy, gpz; DevBuf<uint32_t> gcell_start, gbitmap;
+  DevBuf<uint2> greach; DevBuf<uint32_t> glist_start, gcoarse; DevBuf<float4> gnbr; DevBuf<float4> q4;
   DevBuf<float> qx, qy, qz, ux, uy, uz, qnx, qny, qnz, qcr, qcg, qcb;
   // pair sets
   DevBuf<int2> ab1, ab2; DevBuf<uint32_t> okey1, okey2, cell1, cell2, bucket1, next1, mask2; DevBuf<float4> ew1, ew2;
-  DevBuf<int4> quads; DevBuf<unsigned long long> tags; DevBuf<uint32_t> counts;
+  DevBuf<int4> quads; DevBuf<unsigned long long> tags; DevBuf<uint32_t> counts, cand_idx; DevBuf<float4> cand_T;
   DevBuf<unsigned long long> ht_keys, ht_heads; uint32_t ht_mask = 0, epoch = 0;
   DevBuf<DevCounters> ctr; PinBuf<DevCounters> hctr;
   DevBuf<uint32_t> seq_id[2], seq_leaf[2]; DevBuf<float4> leaves[2];
@@ -71,10 +72,14 @@ struct s4p_ctx {
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   s4p_profile prof{};
   uint64_t last_K = 0;
+  uint32_t verify_blocks = 512;
 
+  size_t verify_lds_bytes() const { return gcoarse.n * 4 + size_t(kVerifyThreads / 64) * 3 * kQueueEntries * 4; }
   LcpGrid dev_grid() const {
     LcpGrid g;
-    g.px = gpx.p; g.py = gpy.p; g.pz = gpz.p; g.cell_start = gcell_start.p; g.bitmap = gbitmap.p;
+    g.reach = greach.p; g.list_start = glist_start.p; g.nbr = gnbr.p;
+    g.coarse = gcoarse.p; g.coarse_words = uint32_t(gcoarse.n);
+    g.cshift = hgrid.cshift; g.cnx = hgrid.cnx; g.cny = hgrid.cny;
     g.ox = hgrid.ox; g.oy = hgrid.oy; g.oz = hgrid.oz; g.inv_h = hgrid.inv_h;
     g.nx = hgrid.nx; g.ny = hgrid.ny; g.nz = hgrid.nz;
     g.sq_eps = opt.delta * opt.delta;     // match4pcsBase.cc:517,522
@@ -209,16 +214,19 @@ BaseFrame make_base_frame(const s4p_ctx* c, const int32_t* base_ids) {
 
 int32_t launch_verify(s4p_ctx* c, const BaseFrame& bf) {
   VerifyParams V{};
-  V.grid = c->dev_grid(); V.qx = c->qx.p; V.qy = c->qy.p; V.qz = c->qz.p; V.n_q = c->n_q; V.base = bf;
+  V.grid = c->dev_grid(); V.q4 = c->q4.p; V.n_q = c->n_q; V.base = bf;
   V.quads = c->quads.p; V.tags = c->tags.p; V.counts = c->counts.p; V.K_dev = &c->ctr.p->K; V.K_cap = uint32_t(c->max_quads);
-  V.ctr = c->ctr.p;
+  V.ctr = c->ctr.p; V.cand_idx = c->cand_idx.p; V.cand_T = c->cand_T.p;
+  { const char* ab = getenv("S4P_ABLATE"); V.ablate = ab ? atoi(ab) : 0; }   // debugging aid, results are wrong when set
+  hipLaunchKernelGGL(k_gate, dim3(1024), dim3(256), 0, c->stream, V);
   if (c->prof_events) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
-  if (c->prof_points) hipLaunchKernelGGL(k_verify<true>, dim3(2048), dim3(256), 0, c->stream, V);
-  else hipLaunchKernelGGL(k_verify<false>, dim3(2048), dim3(256), 0, c->stream, V);
+  const size_t lds = c->verify_lds_bytes();
+  if (c->prof_points) hipLaunchKernelGGL(k_verify<true>, dim3(c->verify_blocks), dim3(kVerifyThreads), lds, c->stream, V);
+  else hipLaunchKernelGGL(k_verify<false>, dim3(c->verify_blocks), dim3(kVerifyThreads), lds, c->stream, V);
   if (c->prof_events) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
   SelectParams S{};
   S.tags = c->tags.p; S.counts = c->counts.p; S.quads = c->quads.p; S.K_dev = &c->ctr.p->K; S.K_cap = uint32_t(c->max_quads);
-  S.ctr = c->ctr.p; S.qx = c->qx.p; S.qy = c->qy.p; S.qz = c->qz.p; S.base = bf;
+  S.ctr = c->ctr.p; S.q4 = c->q4.p; S.base = bf;
   hipLaunchKernelGGL(k_select, dim3(512), dim3(256), 0, c->stream, S);
   hipLaunchKernelGGL(k_winner, dim3(512), dim3(256), 0, c->stream, S);
   HIPCHK(c, hipGetLastError());
@@ -245,13 +253,13 @@ int32_t fetch_result(s4p_ctx* c, const BaseFrame& bf, s4p_base_result* r) {
       c->prof.verify_candidates += d.C; c->prof.verify_quads += d.K; c->prof.verify_queries += uint64_t(d.C) * c->n_q;
     }
   }
-  if (c->prof_points) c->prof.verify_point_tests += d.point_tests;
+  if (c->prof_points) { c->prof.verify_point_tests += d.point_tests; c->prof.verify_l0_pass += d.l0_pass; c->prof.verify_l1_pass += d.l1_pass; }
   return S4P_OK;
 }
 
 int32_t reset_counters(s4p_ctx* c) {
   hipLaunchKernelGGL(k_reset_counters, dim3(1), dim3(1), 0, c->stream, c->ctr.p);
-  if (c->prof_points) HIPCHK(c, hipMemsetAsync(&c->ctr.p->point_tests, 0, 8, c->stream));
+  if (c->prof_points) HIPCHK(c, hipMemsetAsync(&c->ctr.p->point_tests, 0, 24, c->stream));
   return S4P_OK;
 }
 
@@ -299,7 +307,7 @@ int32_t s4p_create(const s4p_options* opt, const s4p_limits* lim, int32_t device
 #define A(buf, cnt) if ((e = (buf).alloc(cnt)) != hipSuccess) return fail(e, "hipMalloc " #buf)
   A(c->ab1, mp); A(c->ab2, mp); A(c->okey1, mp); A(c->okey2, mp); A(c->cell1, mp); A(c->cell2, mp);
   A(c->bucket1, mp); A(c->next1, mp); A(c->mask2, mp * kMaskWords); A(c->ew1, mp); A(c->ew2, mp);
-  A(c->quads, mq); A(c->tags, mq); A(c->counts, mq);
+  A(c->quads, mq); A(c->tags, mq); A(c->counts, mq); A(c->cand_idx, mq); A(c->cand_T, mq * 3);
   const uint32_t hts = next_pow2(2 * mp);
   A(c->ht_keys, hts); A(c->ht_heads, hts); c->ht_mask = hts - 1;
   A(c->ctr, 1);
@@ -309,6 +317,12 @@ int32_t s4p_create(const s4p_options* opt, const s4p_limits* lim, int32_t device
   if ((e = hipMemset(c->ht_heads.p, 0, size_t(hts) * 8)) != hipSuccess) return fail(e, "hipMemset");
   if ((e = hipMemset(c->ctr.p, 0, sizeof(DevCounters))) != hipSuccess) return fail(e, "hipMemset");
   c->epoch = 0;
+  {  // allow the verify kernels their dynamic LDS (coarse bitmap + survivor queues)
+    const int max_lds = int(kCoarseMaxWords * 4 + (kVerifyThreads / 64) * 3 * kQueueEntries * 4);
+    if ((e = hipFuncSetAttribute((const void*)k_verify<false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds)) != hipSuccess) return fail(e, "hipFuncSetAttribute");
+    if ((e = hipFuncSetAttribute((const void*)k_verify<true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds)) != hipSuccess) return fail(e, "hipFuncSetAttribute");
+    if ((e = hipFuncSetAttribute((const void*)k_verify_T, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds)) != hipSuccess) return fail(e, "hipFuncSetAttribute");
+  }
   for (auto& ev : c->ev) if ((e = hipEventCreate(&ev)) != hipSuccess) return fail(e, "hipEventCreate");
   *out = c;
   return S4P_OK;
@@ -318,12 +332,13 @@ void s4p_destroy(s4p_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  c->gpx.free(); c->gpy.free(); c->gpz.free(); c->gcell_start.free(); c->gbitmap.free();
+  c->greach.free(); c->glist_start.free(); c->gnbr.free();
+  c->gcoarse.free(); c->q4.free();
   c->qx.free(); c->qy.free(); c->qz.free(); c->ux.free(); c->uy.free(); c->uz.free();
   c->qnx.free(); c->qny.free(); c->qnz.free(); c->qcr.free(); c->qcg.free(); c->qcb.free();
   c->ab1.free(); c->ab2.free(); c->okey1.free(); c->okey2.free(); c->cell1.free(); c->cell2.free();
   c->bucket1.free(); c->next1.free(); c->mask2.free(); c->ew1.free(); c->ew2.free();
-  c->quads.free(); c->tags.free(); c->counts.free(); c->ht_keys.free(); c->ht_heads.free(); c->ctr.free(); c->hctr.free();
+  c->quads.free(); c->tags.free(); c->counts.free(); c->cand_idx.free(); c->cand_T.free(); c->ht_keys.free(); c->ht_heads.free(); c->ctr.free(); c->hctr.free();
   for (int s = 0; s < 2; ++s) { c->seq_id[s].free(); c->seq_leaf[s].free(); c->leaves[s].free(); c->hseq_id[s].free(); c->hseq_leaf[s].free(); c->hleaves[s].free(); }
   c->tbuf.free();
   for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
@@ -352,17 +367,31 @@ int32_t s4p_set_clouds(s4p_ctx* c, const float* px, const float* py, const float
   c->hqx.assign(qx, qx + n_q); c->hqy.assign(qy, qy + n_q); c->hqz.assign(qz, qz + n_q);
   c->frame.build(c->hqx, c->hqy, c->hqz, c->hux, c->huy, c->huz);
   c->tree.reset(c->n_q);
-  if (!c->hgrid.build(c->hpx, c->hpy, c->hpz, c->opt.delta, c->max_grid_cells)) S4P_FAIL(c, S4P_ERR_STATE, "LCP grid build failed");
-  const size_t nc = c->hgrid.ncell();
-  HIPCHK(c, c->gpx.alloc(n_p)); HIPCHK(c, c->gpy.alloc(n_p)); HIPCHK(c, c->gpz.alloc(n_p));
-  HIPCHK(c, c->gcell_start.alloc(nc + 1)); HIPCHK(c, c->gbitmap.alloc(c->hgrid.bitmap.size()));
-  HIPCHK(c, hipMemcpy(c->gpx.p, c->hgrid.sx.data(), n_p * 4, hipMemcpyHostToDevice));
-  HIPCHK(c, hipMemcpy(c->gpy.p, c->hgrid.sy.data(), n_p * 4, hipMemcpyHostToDevice));
-  HIPCHK(c, hipMemcpy(c->gpz.p, c->hgrid.sz.data(), n_p * 4, hipMemcpyHostToDevice));
-  HIPCHK(c, hipMemcpy(c->gcell_start.p, c->hgrid.cell_start.data(), (nc + 1) * 4, hipMemcpyHostToDevice));
-  HIPCHK(c, hipMemcpy(c->gbitmap.p, c->hgrid.bitmap.data(), c->hgrid.bitmap.size() * 4, hipMemcpyHostToDevice));
-  // free the big host mirrors of the grid (keep parameters)
-  std::vector<uint32_t>().swap(c->hgrid.cell_start); std::vector<uint32_t>().swap(c->hgrid.bitmap);
+  if (!c->hgrid.build(c->hpx, c->hpy, c->hpz, c->opt.delta, c->max_grid_cells, kCoarseMaxWords)) S4P_FAIL(c, S4P_ERR_STATE, "LCP grid build failed");
+  {
+    std::vector<uint2> rw(c->hgrid.reach_bits.size());
+    for (size_t w = 0; w < rw.size(); ++w) rw[w] = make_uint2(c->hgrid.reach_bits[w], c->hgrid.reach_prefix[w]);
+    HIPCHK(c, c->greach.alloc(rw.size()));
+    HIPCHK(c, hipMemcpy(c->greach.p, rw.data(), rw.size() * sizeof(uint2), hipMemcpyHostToDevice));
+    HIPCHK(c, c->gnbr.alloc(c->hgrid.nbr.size() / 4));
+    HIPCHK(c, hipMemcpy(c->gnbr.p, c->hgrid.nbr.data(), c->hgrid.nbr.size() * 4, hipMemcpyHostToDevice));
+    std::vector<uint32_t>().swap(c->hgrid.reach_bits); std::vector<uint32_t>().swap(c->hgrid.reach_prefix);
+    std::vector<float>().swap(c->hgrid.nbr);
+  }
+  auto upu = [&](DevBuf<uint32_t>& d, std::vector<uint32_t>& src) -> hipError_t {
+    hipError_t e = d.alloc(src.size()); if (e != hipSuccess) return e;
+    e = hipMemcpy(d.p, src.data(), src.size() * 4, hipMemcpyHostToDevice);
+    std::vector<uint32_t>().swap(src);          // the host mirror is not needed afterwards
+    return e;
+  };
+  HIPCHK(c, upu(c->glist_start, c->hgrid.list_start));
+  HIPCHK(c, upu(c->gcoarse, c->hgrid.coarse));
+  {
+    std::vector<float4> q4((size_t)n_q);
+    for (int64_t i = 0; i < n_q; ++i) q4[size_t(i)] = make_float4(qx[i], qy[i], qz[i], 0.f);
+    HIPCHK(c, c->q4.alloc(size_t(n_q)));
+    HIPCHK(c, hipMemcpy(c->q4.p, q4.data(), size_t(n_q) * sizeof(float4), hipMemcpyHostToDevice));
+  }
   auto up = [&](DevBuf<float>& d, const float* src) -> hipError_t {
     hipError_t e = d.alloc(n_q); if (e != hipSuccess) return e;
     return hipMemcpy(d.p, src, n_q * 4, hipMemcpyHostToDevice);
@@ -497,10 +526,11 @@ int32_t s4p_verify_transforms(s4p_ctx* c, const float* T, int64_t B, uint32_t* c
   do {
     if ((e = hipMemcpyAsync(dT.p, T, size_t(B) * 64, hipMemcpyHostToDevice, c->stream)) != hipSuccess) break;
     VerifyTParams V{};
-    V.grid = c->dev_grid(); V.qx = c->qx.p; V.qy = c->qy.p; V.qz = c->qz.p; V.n_q = c->n_q; V.T = dT.p; V.B = uint32_t(B);
+    V.grid = c->dev_grid(); V.q4 = c->q4.p; V.n_q = c->n_q; V.T = dT.p; V.B = uint32_t(B);
     V.counts = dC.p; V.ctr = c->ctr.p;
-    const uint32_t blocks = uint32_t(std::min<int64_t>((B + 3) / 4, 4096));
-    hipLaunchKernelGGL(k_verify_T, dim3(blocks), dim3(256), 0, c->stream, V);
+    const uint32_t wpb = kVerifyThreads / 64;
+    const uint32_t blocks = uint32_t(std::min<int64_t>((B + wpb - 1) / wpb, 512));
+    hipLaunchKernelGGL(k_verify_T, dim3(blocks), dim3(kVerifyThreads), c->verify_lds_bytes(), c->stream, V);
     if ((e = hipGetLastError()) != hipSuccess) break;
     if ((e = hipMemcpyAsync(counts, dC.p, size_t(B) * 4, hipMemcpyDeviceToHost, c->stream)) != hipSuccess) break;
     e = hipStreamSynchronize(c->stream);

@@ -51,7 +51,9 @@ struct DevCounters {
   uint32_t best_count;              // max inlier count (verified candidates only)
   uint32_t overflow;                // bit0 pairs1, bit1 pairs2, bit2 quads
   unsigned long long best_tag;      // min tag among candidates with best_count
-  unsigned long long point_tests;   // optional instrumentation
+  unsigned long long point_tests;   // optional instrumentation (COUNT kernels only)
+  unsigned long long l0_pass, l1_pass;
+  uint32_t cursor;                  // k_verify work cursor
   // winner record
   int32_t best_quad[4];
   float best_T[16];
@@ -60,43 +62,123 @@ struct DevCounters {
 };
 
 // ---------------------------------------------------------------------------
-// LCP grid over sampled P  (replaces kd_tree_, match4pcsBase.cc:353-363)
+// LCP structure over sampled P  (replaces kd_tree_, match4pcsBase.cc:353-363).
+// Uniform grid of edge h >= 1.002*delta, three levels, all conservative supersets of the
+// exact predicate "some P point with fl(dx^2+(dy^2+dz^2)) <= fl(delta^2)" (kdtree.h:417-421):
+//   L0  coarse bitmap (OR of 2^s-cubes of the reach bitmap), <= 48 KB, staged in LDS;
+//   L1  reach bitmap: bit(c) = some P point lies within 1.01*delta of the box of cell c,
+//       stored as {bits, rank-prefix} records (one 8 B load gives the bit and the rank);
+//   L2  per reachable cell, the contiguous list of exactly those P points (float4 copies):
+//       one range load, then one 16 B load per exact distance test -- no neighbour-cell walk.
+// The reach records and range table (~2 MB per 10^5 points) are L2-cache resident; the
+// point lists (~400 B per P point) stream from Infinity Cache / HBM.
 // ---------------------------------------------------------------------------
 struct LcpGrid {
-  const float* px; const float* py; const float* pz;   // P points sorted by cell
-  const uint32_t* cell_start;                           // ncell + 1
-  const uint32_t* bitmap;                               // dilated occupancy, 1 bit per cell
+  const uint2* reach;           // per 32-cell word: {reach bits, number of reachable cells before this word}
+  const uint32_t* list_start;   // n_reach + 1 offsets into nbr
+  const float4* nbr;            // P points (x,y,z,0) grouped by reachable cell
+  const uint32_t* coarse;       // coarse bitmap (global copy, staged to LDS by the kernels)
+  uint32_t coarse_words;
+  int cshift, cnx, cny;
   float ox, oy, oz, inv_h;
   int nx, ny, nz;
-  float sq_eps;                                         // fl(delta*delta)
+  float sq_eps;                 // fl(delta*delta)
 };
 
-template <bool COUNT>
-__device__ __forceinline__ bool lcp_probe(const LcpGrid& g, float tx, float ty, float tz,
-                                          unsigned long long* point_tests) {
+constexpr int kQueueEntries = 128;                 // per-wave survivor queue (3 floats per entry)
+constexpr int kCoarseMaxWords = 12288;             // 48 KB
+
+__device__ __forceinline__ bool cell_coords(const LcpGrid& g, float tx, float ty, float tz, int& ix, int& iy, int& iz) {
   const float fx = floorf((tx - g.ox) * g.inv_h);
   const float fy = floorf((ty - g.oy) * g.inv_h);
   const float fz = floorf((tz - g.oz) * g.inv_h);
   if (!(fx >= 0.f && fx < float(g.nx) && fy >= 0.f && fy < float(g.ny) && fz >= 0.f && fz < float(g.nz))) return false;
-  const int ix = int(fx), iy = int(fy), iz = int(fz);
+  ix = int(fx); iy = int(fy); iz = int(fz);
+  return true;
+}
+
+// L1 + L2 + exact point tests for one transformed query point.
+template <bool COUNT>
+__device__ __forceinline__ bool fine_test(const LcpGrid& g, float tx, float ty, float tz, unsigned long long* point_tests) {
+  int ix, iy, iz;
+  if (!cell_coords(g, tx, ty, tz, ix, iy, iz)) return false;
   const uint32_t c = (uint32_t(iz) * uint32_t(g.ny) + uint32_t(iy)) * uint32_t(g.nx) + uint32_t(ix);
-  if (!((g.bitmap[c >> 5] >> (c & 31u)) & 1u)) return false;
-  const int x0 = max(ix - 1, 0), x1 = min(ix + 1, g.nx - 1);
-  const int y0 = max(iy - 1, 0), y1 = min(iy + 1, g.ny - 1);
-  const int z0 = max(iz - 1, 0), z1 = min(iz + 1, g.nz - 1);
-  for (int z = z0; z <= z1; ++z) {
-    for (int y = y0; y <= y1; ++y) {
-      const uint32_t row = (uint32_t(z) * uint32_t(g.ny) + uint32_t(y)) * uint32_t(g.nx);
-      const uint32_t s = g.cell_start[row + x0];
-      const uint32_t e = g.cell_start[row + x1 + 1];
-      for (uint32_t p = s; p < e; ++p) {
-        const float dx = tx - g.px[p], dy = ty - g.py[p], dz = tz - g.pz[p];
-        if (COUNT) atomicAdd(point_tests, 1ull);
-        if (sqn3(dx, dy, dz) <= g.sq_eps) return true;    // kdtree.h:417-421  sqdist <= cl_dist
-      }
-    }
+  const uint2 w = g.reach[c >> 5];
+  const uint32_t sh = c & 31u;
+  if (!((w.x >> sh) & 1u)) return false;
+  if (COUNT) atomicAdd(point_tests + 2, 1ull);     // l1_pass
+  const uint32_t rank = w.y + uint32_t(__popc(w.x & ((1u << sh) - 1u)));
+  const uint32_t s = g.list_start[rank], e = g.list_start[rank + 1];
+  for (uint32_t p = s; p < e; ++p) {
+    const float4 pp = g.nbr[p];
+    const float dx = tx - pp.x, dy = ty - pp.y, dz = tz - pp.z;
+    if (COUNT) atomicAdd(point_tests, 1ull);
+    if (sqn3(dx, dy, dz) <= g.sq_eps) return true;          // kdtree.h:417-421  sqdist <= cl_dist
   }
   return false;
+}
+
+// Number of sampled-Q points that T brings within delta of a sampled-P point: Verify()
+// (match4pcsBase.cc:508-567) without the early exit, for one wave64.
+//   s_coarse : LDS copy of the coarse bitmap (workgroup-shared)
+//   s_queue  : this wave's private LDS queue (3 * kQueueEntries floats)
+// Phase 1 (every query): transform + L0 test out of LDS; survivors are compacted into the
+// queue with a ballot/prefix.  Phase 2 (64 survivors at a time, one per lane): L1/L2 + points.
+template <bool COUNT, bool SKIP_FINE = false>
+__device__ __forceinline__ uint32_t wave_lcp_count(const LcpGrid& g, const uint32_t* s_coarse, float* s_queue,
+                                                   const float4* q4, uint32_t n_q, const float* T,
+                                                   unsigned long long* point_tests) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  uint32_t cnt = 0, qn = 0;
+  for (uint32_t base = 0; base < n_q; base += 64) {
+    const uint32_t i = base + lane;
+    bool surv = false;
+    float tx = 0.f, ty = 0.f, tz = 0.f;
+    if (i < n_q) {
+      const float4 q = q4[i];
+      // (mat * q.homogeneous()).head<3>() : ((m0*x + m1*y) + m2*z) + m3   (match4pcsBase.cc:532)
+      tx = ((T[0] * q.x + T[1] * q.y) + T[2] * q.z) + T[3];
+      ty = ((T[4] * q.x + T[5] * q.y) + T[6] * q.z) + T[7];
+      tz = ((T[8] * q.x + T[9] * q.y) + T[10] * q.z) + T[11];
+      int ix, iy, iz;
+      if (cell_coords(g, tx, ty, tz, ix, iy, iz)) {
+        const uint32_t cc = (uint32_t(iz >> g.cshift) * uint32_t(g.cny) + uint32_t(iy >> g.cshift)) * uint32_t(g.cnx) +
+                            uint32_t(ix >> g.cshift);
+        surv = (s_coarse[cc >> 5] >> (cc & 31u)) & 1u;
+      }
+    }
+    const unsigned long long m = __ballot(surv);
+    if (COUNT && lane == 0) atomicAdd(point_tests + 1, (unsigned long long)__popcll(m));   // l0_pass
+    if (surv) {
+      const uint32_t at = qn + uint32_t(__popcll(m & lt_mask));
+      s_queue[3 * at] = tx; s_queue[3 * at + 1] = ty; s_queue[3 * at + 2] = tz;
+    }
+    qn += uint32_t(__popcll(m));
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (qn >= 64u) {
+      const uint32_t at = qn - 64u + lane;
+      const float x = s_queue[3 * at], y = s_queue[3 * at + 1], z = s_queue[3 * at + 2];
+      cnt += SKIP_FINE ? uint32_t(x > 1e30f) : (fine_test<COUNT>(g, x, y, z, point_tests) ? 1u : 0u);
+      qn -= 64u;
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  if (lane < qn) {
+    const float x = s_queue[3 * lane], y = s_queue[3 * lane + 1], z = s_queue[3 * lane + 2];
+    cnt += SKIP_FINE ? uint32_t(x > 1e30f) : (fine_test<COUNT>(g, x, y, z, point_tests) ? 1u : 0u);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+  __builtin_amdgcn_wave_barrier();
+  return cnt;
+}
+
+__device__ __forceinline__ void stage_coarse(const LcpGrid& g, uint32_t* s_coarse) {
+  for (uint32_t w = threadIdx.x; w < g.coarse_words; w += blockDim.x) s_coarse[w] = g.coarse[w];
+  __syncthreads();
 }
 
 // ---------------------------------------------------------------------------
@@ -165,55 +247,90 @@ __device__ __forceinline__ bool rigid_gate(const BaseFrame& b, const float q[3][
 }
 
 // ---------------------------------------------------------------------------
-// k_verify: one wave64 per candidate quad; lanes stride over the sampled Q points.
+// k_verify: persistent workgroups of 8 waves; one wave64 per candidate quad, striding over
+// the quad list whose length lives in device memory (no host round trip).
+// LDS: coarse bitmap (<= 48 KB) + 8 private survivor queues (1.5 KB each).
 // ---------------------------------------------------------------------------
+constexpr int kVerifyThreads = 512;
 struct VerifyParams {
   LcpGrid grid;
-  const float* qx; const float* qy; const float* qz;   // sampled Q (centred)
+  const float4* q4;                                     // sampled Q (centred), packed (x,y,z,0)
   uint32_t n_q;
   BaseFrame base;
   const int4* quads; const unsigned long long* tags; uint32_t* counts;
   const uint32_t* K_dev; uint32_t K_cap;
+  uint32_t* cand_idx; float4* cand_T;                   // gated candidates: quad index + 3x4 transform
   DevCounters* ctr;
+  int ablate;                                           // S4P_ABLATE debugging only (0 = full kernel)
 };
 
-template <bool COUNT>
-__global__ __launch_bounds__(256) void k_verify(VerifyParams P) {
+// k_gate: one thread per congruent quad: ComputeRigidTransformation + rms gate
+// (match4pcsBase.cc:365-500, match4pcsBase.hpp:436-439).  Passing candidates are compacted
+// (wave-aggregated append) into cand_idx / cand_T so that the scoring kernel sees a dense,
+// perfectly balanceable list; failing ones get counts[k] = kGateFailed.
+__global__ __launch_bounds__(256) void k_gate(VerifyParams P) {
+  const uint32_t K = min(*P.K_dev, P.K_cap);
   const uint32_t lane = threadIdx.x & 63u;
+  for (uint32_t k0 = (blockIdx.x * blockDim.x + threadIdx.x) & ~63u; k0 < K; k0 += gridDim.x * blockDim.x) {
+    const uint32_t k = k0 + lane;
+    float T[12]; float c2[3];
+    bool ok = false;
+    if (k < K) {
+      const int4 qd = P.quads[k];
+      const float4 a = P.q4[qd.x], b = P.q4[qd.y], c = P.q4[qd.z];
+      float q[3][3] = {{a.x, a.y, a.z}, {b.x, b.y, b.z}, {c.x, c.y, c.z}};
+      ok = rigid_gate(P.base, q, T, c2);
+      if (!ok) P.counts[k] = kGateFailed;
+    }
+    const unsigned long long pass = __ballot(ok);
+    if (pass == 0ull) continue;
+    const uint32_t leader = __ffsll((long long)pass) - 1;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(&P.ctr->C, uint32_t(__popcll(pass)));
+    base = __shfl(base, leader);
+    if (ok) {
+      const uint32_t at = base + uint32_t(__popcll(pass & ((1ull << lane) - 1ull)));
+      P.cand_idx[at] = k;
+      float4* dst = P.cand_T + 3 * size_t(at);
+      dst[0] = make_float4(T[0], T[1], T[2], T[3]);
+      dst[1] = make_float4(T[4], T[5], T[6], T[7]);
+      dst[2] = make_float4(T[8], T[9], T[10], T[11]);
+    }
+  }
+}
+
+// k_verify: Verify() (match4pcsBase.cc:508-567, no early exit) of every gated candidate.
+// Persistent workgroups of 8 waves striding over the gated candidate list (its length lives in
+// device memory: no host round trip).
+// LDS: coarse bitmap (<= 48 KB) + 8 private survivor queues (1.5 KB each).
+template <bool COUNT>
+__global__ __launch_bounds__(kVerifyThreads) void k_verify(VerifyParams P) {
+  extern __shared__ uint32_t s_mem[];
+  uint32_t* s_coarse = s_mem;
+  float* s_queue = reinterpret_cast<float*>(s_mem + P.grid.coarse_words) + (threadIdx.x >> 6) * (3 * kQueueEntries);
+  const uint32_t C = P.ctr->C;
+  if (blockIdx.x * (kVerifyThreads / 64) >= C) return;   // more workgroups than candidates
+  stage_coarse(P.grid, s_coarse);
+  const uint32_t lane = threadIdx.x & 63u;
+  uint32_t local_best = 0;
+  bool any = false;
+  // After k_gate every candidate costs about the same (n_Q queries), so a static stride balances
+  // well; a single-address atomic cursor would cap at ~90 dequeues/us (MI355X_MICROARCH "dequeue").
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
-  const uint32_t K = min(*P.K_dev, P.K_cap);
-  uint32_t local_best = 0, local_C = 0;
-  bool any = false;
-  for (uint32_t k = wave; k < K; k += nwaves) {
-    const int4 qd = P.quads[k];
-    float q[3][3];
-    q[0][0] = P.qx[qd.x]; q[0][1] = P.qy[qd.x]; q[0][2] = P.qz[qd.x];
-    q[1][0] = P.qx[qd.y]; q[1][1] = P.qy[qd.y]; q[1][2] = P.qz[qd.y];
-    q[2][0] = P.qx[qd.z]; q[2][1] = P.qy[qd.z]; q[2][2] = P.qz[qd.z];
-    float T[12], c2[3];
-    const bool ok = rigid_gate(P.base, q, T, c2);
-    if (!ok) { if (lane == 0) P.counts[k] = kGateFailed; continue; }
+  for (uint32_t i = wave; i < C; i += nwaves) {
+    const float4* src = P.cand_T + 3 * size_t(i);
+    const float4 r0 = src[0], r1 = src[1], r2 = src[2];
+    const float T[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
     uint32_t cnt = 0;
-    for (uint32_t i = lane; i < P.n_q; i += 64) {
-      const float x = P.qx[i], y = P.qy[i], z = P.qz[i];
-      // (mat * q.homogeneous()).head<3>() : ((m0*x + m1*y) + m2*z) + m3   (match4pcsBase.cc:532)
-      const float tx = ((T[0] * x + T[1] * y) + T[2] * z) + T[3];
-      const float ty = ((T[4] * x + T[5] * y) + T[6] * z) + T[7];
-      const float tz = ((T[8] * x + T[9] * y) + T[10] * z) + T[11];
-      cnt += lcp_probe<COUNT>(P.grid, tx, ty, tz, &P.ctr->point_tests) ? 1u : 0u;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
-    if (lane == 0) P.counts[k] = cnt;
-    local_C++;
+    if (P.ablate == 2) cnt = uint32_t(T[3] > 1e30f);
+    else if (P.ablate == 1) cnt = wave_lcp_count<COUNT, true>(P.grid, s_coarse, s_queue, P.q4, P.n_q, T, &P.ctr->point_tests);
+    else cnt = wave_lcp_count<COUNT, false>(P.grid, s_coarse, s_queue, P.q4, P.n_q, T, &P.ctr->point_tests);
+    if (lane == 0) P.counts[P.cand_idx[i]] = cnt;
     local_best = max(local_best, cnt);
     any = true;
   }
-  if (lane == 0 && any) {
-    atomicAdd(&P.ctr->C, local_C);
-    atomicMax(&P.ctr->best_count, local_best);
-  }
+  if (lane == 0 && any) atomicMax(&P.ctr->best_count, local_best);
 }
 
 // k_select: best_tag = min tag among candidates whose count == best_count (first in
@@ -221,7 +338,7 @@ __global__ __launch_bounds__(256) void k_verify(VerifyParams P) {
 struct SelectParams {
   const unsigned long long* tags; const uint32_t* counts; const int4* quads;
   const uint32_t* K_dev; uint32_t K_cap; DevCounters* ctr;
-  const float* qx; const float* qy; const float* qz; BaseFrame base;
+  const float4* q4; BaseFrame base;
 };
 __global__ __launch_bounds__(256) void k_select(SelectParams P) {
   const uint32_t K = min(*P.K_dev, P.K_cap);
@@ -238,10 +355,8 @@ __global__ __launch_bounds__(256) void k_winner(SelectParams P) {
   for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < K; k += gridDim.x * blockDim.x) {
     if (P.tags[k] == bt && P.counts[k] == best) {
       const int4 qd = P.quads[k];
-      float q[3][3];
-      q[0][0] = P.qx[qd.x]; q[0][1] = P.qy[qd.x]; q[0][2] = P.qz[qd.x];
-      q[1][0] = P.qx[qd.y]; q[1][1] = P.qy[qd.y]; q[1][2] = P.qz[qd.y];
-      q[2][0] = P.qx[qd.z]; q[2][1] = P.qy[qd.z]; q[2][2] = P.qz[qd.z];
+      const float4 a = P.q4[qd.x], b = P.q4[qd.y], c = P.q4[qd.z];
+      float q[3][3] = {{a.x, a.y, a.z}, {b.x, b.y, b.z}, {c.x, c.y, c.z}};
       float T[12], c2[3];
       rigid_gate(P.base, q, T, c2);
       for (int i = 0; i < 12; ++i) P.ctr->best_T[i] = T[i];
@@ -255,25 +370,22 @@ __global__ __launch_bounds__(256) void k_winner(SelectParams P) {
 
 // k_verify_T: Verify() for explicit transforms (one wave per transform).
 struct VerifyTParams {
-  LcpGrid grid; const float* qx; const float* qy; const float* qz; uint32_t n_q;
+  LcpGrid grid; const float4* q4; uint32_t n_q;
   const float* T; uint32_t B; uint32_t* counts; DevCounters* ctr;
 };
-__global__ __launch_bounds__(256) void k_verify_T(VerifyTParams P) {
+__global__ __launch_bounds__(kVerifyThreads) void k_verify_T(VerifyTParams P) {
+  extern __shared__ uint32_t s_mem[];
+  uint32_t* s_coarse = s_mem;
+  float* s_queue = reinterpret_cast<float*>(s_mem + P.grid.coarse_words) + (threadIdx.x >> 6) * (3 * kQueueEntries);
+  stage_coarse(P.grid, s_coarse);
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
   for (uint32_t k = wave; k < P.B; k += nwaves) {
-    const float* T = P.T + 16 * size_t(k);
-    uint32_t cnt = 0;
-    for (uint32_t i = lane; i < P.n_q; i += 64) {
-      const float x = P.qx[i], y = P.qy[i], z = P.qz[i];
-      const float tx = ((T[0] * x + T[1] * y) + T[2] * z) + T[3];
-      const float ty = ((T[4] * x + T[5] * y) + T[6] * z) + T[7];
-      const float tz = ((T[8] * x + T[9] * y) + T[10] * z) + T[11];
-      cnt += lcp_probe<false>(P.grid, tx, ty, tz, nullptr) ? 1u : 0u;
-    }
+    float T[12];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    for (int i = 0; i < 12; ++i) T[i] = P.T[16 * size_t(k) + i];
+    const uint32_t cnt = wave_lcp_count<false, false>(P.grid, s_coarse, s_queue, P.q4, P.n_q, T, nullptr);
     if (lane == 0) P.counts[k] = cnt;
   }
 }
@@ -603,7 +715,7 @@ __global__ void k_selftest(const float* a, const float* b, uint64_t n, float* o_
 
 __global__ void k_reset_counters(DevCounters* c) {
   c->m1 = 0; c->m2 = 0; c->K = 0; c->C = 0; c->best_count = 0; c->overflow = 0;
-  c->best_tag = ~0ull; c->has_best = 0;
+  c->best_tag = ~0ull; c->has_best = 0; c->cursor = 0;
 }
 
 }  // namespace s4p
