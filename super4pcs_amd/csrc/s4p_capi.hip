@@ -136,8 +136,7 @@ int32_t launch_pairs(s4p_ctx* c, int set, float pair_distance, float pair_normal
   }
   P.ab = ab.p; P.okey = okey.p; P.counter = set == 0 ? &c->ctr.p->m1 : &c->ctr.p->m2;
   P.cap = uint32_t(c->max_pairs); P.overflow = &c->ctr.p->overflow; P.overflow_bit = set == 0 ? 1u : 2u;
-  dim3 grid((n_seq + 255) / 256, c->n_q);
-  hipLaunchKernelGGL(k_pairs, grid, dim3(256), 0, c->stream, P);
+  hipLaunchKernelGGL(k_pairs, dim3(c->n_q), dim3(256), 0, c->stream, P);
   HIPCHK(c, hipGetLastError());
   return S4P_OK;
 }

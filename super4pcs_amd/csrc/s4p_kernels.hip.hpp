@@ -428,69 +428,92 @@ __device__ __forceinline__ bool sphere_box(float cx, float cy, float cz, float r
   return (dmin[0] + (dmin[1] + dmin[2])) < r2 && r2 < (dmax[0] + (dmax[1] + dmax[2]));
 }
 
+constexpr int kPairStage = 1024;   // accepted (pId, j) per workgroup between two flushes
+
+// One workgroup per primitive pId; threads sweep the sequence in chunks of 256.  Accepted slots are
+// staged in LDS and flushed with ONE global atomic per workgroup (a per-wave atomic on the single
+// output cursor serialises at ~90 ops/us and dominated the first version of this kernel).
 __global__ __launch_bounds__(256) void k_pairs(PairParams P) {
-  const uint32_t pId = blockIdx.y;
-  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-  bool acc = false;
-  uint32_t j = 0;
-  if (s < P.n_seq) {
-    j = P.seq_id[s];
-    if (pId > j) {
-      const float cx = P.ux[pId], cy = P.uy[pId], cz = P.uz[pId];
-      const float dx = P.ux[j] - cx, dy = P.uy[j] - cy, dz = P.uz[j] - cz;
-      const float t = sqrtf(sqn3(dx, dy, dz)) - P.nRadius;
-      if (t * t < P.eps_unit * P.eps_unit) {                               // intersectPoint, intersectionPrimitive.h:154-157
-        if (sphere_box(cx, cy, cz, P.nRadius, P.leaves[P.seq_leaf[s]])) {   // intersect, :117-142
-          // PairCreationFunctor::process(i = pId, j): p = Q[j], q = Q[i]
-          const float wx = P.qx[pId] - P.qx[j], wy = P.qy[pId] - P.qy[j], wz = P.qz[pId] - P.qz[j];
-          const float distance = sqrtf(sqn3(wx, wy, wz));
-          acc = !(fabs(double(distance) - P.pair_distance) > P.pair_distance_eps);   // :162
-          if (acc && P.max_normal_difference > 0.f && P.nx != nullptr) {              // :166-180
-            const float qn0 = P.nx[pId], qn1 = P.ny[pId], qn2 = P.nz[pId];
-            const float pn0 = P.nx[j], pn1 = P.ny[j], pn2 = P.nz[j];
-            if (sqn3(qn0, qn1, qn2) > 0.f && sqn3(pn0, pn1, pn2) > 0.f) {
-              const double a1 = double(sqrtf(sqn3(qn0 - pn0, qn1 - pn1, qn2 - pn2)));
-              const double a2 = double(sqrtf(sqn3(qn0 + pn0, qn1 + pn1, qn2 + pn2)));
-              const float fnd = float(fmin(fabs(a1 - P.pair_normals_angle), fabs(a2 - P.pair_normals_angle)));
-              if (fnd > P.norm_threshold) acc = false;
+  __shared__ uint32_t st_j[kPairStage];
+  __shared__ uint32_t st_s[kPairStage];
+  __shared__ uint32_t st_n, st_base;
+  const uint32_t pId = blockIdx.x;
+  if (threadIdx.x == 0) st_n = 0;
+  __syncthreads();
+  const float cx = P.ux[pId], cy = P.uy[pId], cz = P.uz[pId];
+  const float wxi = P.qx[pId], wyi = P.qy[pId], wzi = P.qz[pId];
+  auto flush = [&]() {     // called by all threads, between barriers
+    const uint32_t n = st_n;
+    if (n == 0) return;
+    if (threadIdx.x == 0) st_base = atomicAdd(P.counter, 2u * n);
+    __syncthreads();
+    const uint32_t base = st_base;
+    for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) {
+      const uint32_t at = base + 2u * e;
+      if (at + 1u < P.cap) {
+        const uint32_t j = st_j[e];
+        const uint32_t ok = 2u * (pId * P.n_seq + st_s[e]);
+        P.ab[at] = make_int2(int(j), int(pId));     P.okey[at] = ok;          // pairs->emplace_back(j, i)  :214
+        P.ab[at + 1] = make_int2(int(pId), int(j)); P.okey[at + 1] = ok + 1u; // pairs->emplace_back(i, j)  :215
+      } else {
+        atomicOr(P.overflow, P.overflow_bit);
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) st_n = 0;
+    __syncthreads();
+  };
+  for (uint32_t s0 = 0; s0 < P.n_seq; s0 += blockDim.x) {
+    const uint32_t s = s0 + threadIdx.x;
+    bool acc = false;
+    uint32_t j = 0;
+    if (s < P.n_seq) {
+      j = P.seq_id[s];
+      if (pId > j) {
+        const float dx = P.ux[j] - cx, dy = P.uy[j] - cy, dz = P.uz[j] - cz;
+        const float t = sqrtf(sqn3(dx, dy, dz)) - P.nRadius;
+        if (t * t < P.eps_unit * P.eps_unit) {                               // intersectPoint, intersectionPrimitive.h:154-157
+          if (sphere_box(cx, cy, cz, P.nRadius, P.leaves[P.seq_leaf[s]])) {   // intersect, :117-142
+            // PairCreationFunctor::process(i = pId, j): p = Q[j], q = Q[i]
+            const float wx = wxi - P.qx[j], wy = wyi - P.qy[j], wz = wzi - P.qz[j];
+            const float distance = sqrtf(sqn3(wx, wy, wz));
+            acc = !(fabs(double(distance) - P.pair_distance) > P.pair_distance_eps);   // :162
+            if (acc && P.max_normal_difference > 0.f && P.nx != nullptr) {              // :166-180
+              const float qn0 = P.nx[pId], qn1 = P.ny[pId], qn2 = P.nz[pId];
+              const float pn0 = P.nx[j], pn1 = P.ny[j], pn2 = P.nz[j];
+              if (sqn3(qn0, qn1, qn2) > 0.f && sqn3(pn0, pn1, pn2) > 0.f) {
+                const double a1 = double(sqrtf(sqn3(qn0 - pn0, qn1 - pn1, qn2 - pn2)));
+                const double a2 = double(sqrtf(sqn3(qn0 + pn0, qn1 + pn1, qn2 + pn2)));
+                const float fnd = float(fmin(fabs(a1 - P.pair_normals_angle), fabs(a2 - P.pair_normals_angle)));
+                if (fnd > P.norm_threshold) acc = false;
+              }
             }
-          }
-          if (acc && P.max_color_distance > 0.f) {                                    // :182-192
-            float pr0 = -1.f, pr1 = -1.f, pr2 = -1.f, qr0 = -1.f, qr1 = -1.f, qr2 = -1.f;
-            if (P.cr != nullptr) { pr0 = P.cr[j]; pr1 = P.cg[j]; pr2 = P.cb[j]; qr0 = P.cr[pId]; qr1 = P.cg[pId]; qr2 = P.cb[pId]; }
-            const bool use_rgb = (pr0 >= 0.f && qr0 >= 0.f && P.b1rgb[0] >= 0.f && P.b2rgb[0] >= 0.f);
-            const bool good = sqrtf(sqn3(pr0 - P.b1rgb[0], pr1 - P.b1rgb[1], pr2 - P.b1rgb[2])) < P.max_color_distance &&
-                              sqrtf(sqn3(qr0 - P.b2rgb[0], qr1 - P.b2rgb[1], qr2 - P.b2rgb[2])) < P.max_color_distance;
-            if (use_rgb && !good) acc = false;
-          }
-          if (acc && P.max_translation_distance > 0.f) {                              // :194-200
-            const bool good =
-                sqrtf(sqn3(P.qx[j] - P.b1pos[0], P.qy[j] - P.b1pos[1], P.qz[j] - P.b1pos[2])) < P.max_translation_distance &&
-                sqrtf(sqn3(P.qx[pId] - P.b2pos[0], P.qy[pId] - P.b2pos[1], P.qz[pId] - P.b2pos[2])) < P.max_translation_distance;
-            if (!good) acc = false;
+            if (acc && P.max_color_distance > 0.f) {                                    // :182-192
+              float pr0 = -1.f, pr1 = -1.f, pr2 = -1.f, qr0 = -1.f, qr1 = -1.f, qr2 = -1.f;
+              if (P.cr != nullptr) { pr0 = P.cr[j]; pr1 = P.cg[j]; pr2 = P.cb[j]; qr0 = P.cr[pId]; qr1 = P.cg[pId]; qr2 = P.cb[pId]; }
+              const bool use_rgb = (pr0 >= 0.f && qr0 >= 0.f && P.b1rgb[0] >= 0.f && P.b2rgb[0] >= 0.f);
+              const bool good = sqrtf(sqn3(pr0 - P.b1rgb[0], pr1 - P.b1rgb[1], pr2 - P.b1rgb[2])) < P.max_color_distance &&
+                                sqrtf(sqn3(qr0 - P.b2rgb[0], qr1 - P.b2rgb[1], qr2 - P.b2rgb[2])) < P.max_color_distance;
+              if (use_rgb && !good) acc = false;
+            }
+            if (acc && P.max_translation_distance > 0.f) {                              // :194-200
+              const bool good =
+                  sqrtf(sqn3(P.qx[j] - P.b1pos[0], P.qy[j] - P.b1pos[1], P.qz[j] - P.b1pos[2])) < P.max_translation_distance &&
+                  sqrtf(sqn3(wxi - P.b2pos[0], wyi - P.b2pos[1], wzi - P.b2pos[2])) < P.max_translation_distance;
+              if (!good) acc = false;
+            }
           }
         }
       }
     }
-  }
-  // wave-aggregated, order-free append (order is carried by okey)
-  const unsigned long long m = __ballot(acc);
-  if (m == 0ull) return;
-  const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t leader = __ffsll((long long)m) - 1;
-  uint32_t base = 0;
-  if (lane == leader) base = atomicAdd(P.counter, 2u * uint32_t(__popcll(m)));
-  base = __shfl(base, leader);
-  if (acc) {
-    const uint32_t at = base + 2u * uint32_t(__popcll(m & ((1ull << lane) - 1ull)));
-    if (at + 1u < P.cap) {
-      const uint32_t ok = 2u * (pId * P.n_seq + s);
-      P.ab[at] = make_int2(int(j), int(pId));     P.okey[at] = ok;          // pairs->emplace_back(j, i)  :214
-      P.ab[at + 1] = make_int2(int(pId), int(j)); P.okey[at + 1] = ok + 1u; // pairs->emplace_back(i, j)  :215
-    } else {
-      atomicOr(P.overflow, P.overflow_bit);
+    if (acc) {
+      const uint32_t e = atomicAdd(&st_n, 1u);     // LDS atomic; st_n <= kPairStage - 256 + 256 by the flush rule below
+      st_j[e] = j; st_s[e] = s;
     }
+    __syncthreads();
+    if (st_n + blockDim.x > uint32_t(kPairStage)) flush();   // uniform: st_n is read after the barrier
   }
+  flush();
 }
 
 // ---------------------------------------------------------------------------
@@ -650,42 +673,70 @@ struct QuadParams {
   int4* quads; unsigned long long* tags; uint32_t* K_dev; uint32_t K_cap; uint32_t* overflow;
 };
 
+constexpr int kQuadStage = 1536;   // quads per workgroup between two flushes (24 B each)
+
+// One thread per pairs2 entry: hash lookup of its euclidean cell, walk of the set-1 chain.
+// Matches are staged in LDS and flushed with one global atomic per workgroup round.
 __global__ __launch_bounds__(256) void k_quads(QuadParams P) {
+  __shared__ int4 st_q[kQuadStage];
+  __shared__ unsigned long long st_t[kQuadStage];
+  __shared__ uint32_t st_n, st_base;
   const uint32_t m2 = min(*P.m2_dev, P.cap2);
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < m2; i += gridDim.x * blockDim.x) {
-    const uint32_t cell = P.cell2[i];
-    const unsigned long long mykey = ((unsigned long long)P.ht.epoch << 32) | cell;
-    uint32_t h = hash_cell(cell) & P.ht.mask;
-    uint32_t e = kNil;
-    while (true) {
-      const unsigned long long k = P.ht.keys[h];
-      if (k == mykey) { const unsigned long long hd = P.ht.heads[h]; e = (uint32_t(hd >> 32) == P.ht.epoch) ? uint32_t(hd) : kNil; break; }
-      if (uint32_t(k >> 32) != P.ht.epoch) break;
-      h = (h + 1u) & P.ht.mask;
-    }
-    if (e == kNil) continue;
-    const float4 eq = P.ew2[i];
-    const uint32_t* mk = P.mask2 + size_t(i) * kMaskWords;
-    const int2 ab2 = P.ab2[i];
-    const uint32_t ok2 = P.okey2[i];
-    while (e != kNil) {
-      const uint32_t b = P.bucket1[e];
-      if ((mk[b >> 5] >> (b & 31u)) & 1u) {
-        const float4 ep = P.ew1[e];
-        const float dx = eq.x - ep.x, dy = eq.y - ep.y, dz = eq.z - ep.z;
-        if (sqn3(dx, dy, dz) <= P.thr) {                                           // super4pcs.cc:160
-          const uint32_t at = atomicAdd(P.K_dev, 1u);
-          if (at < P.K_cap) {
-            const int2 ab1 = P.ab1[e];
-            P.quads[at] = make_int4(ab1.x, ab1.y, ab2.x, ab2.y);                   // :171-172
-            P.tags[at] = ((unsigned long long)P.okey1[e] << 32) | ok2;
-          } else {
-            atomicOr(P.overflow, 4u);
+  if (threadIdx.x == 0) st_n = 0;
+  __syncthreads();
+  for (uint32_t i0 = blockIdx.x * blockDim.x; i0 < m2; i0 += gridDim.x * blockDim.x) {
+    const uint32_t i = i0 + threadIdx.x;
+    if (i < m2) {
+      const uint32_t cell = P.cell2[i];
+      const unsigned long long mykey = ((unsigned long long)P.ht.epoch << 32) | cell;
+      uint32_t h = hash_cell(cell) & P.ht.mask;
+      uint32_t e = kNil;
+      while (true) {
+        const unsigned long long k = P.ht.keys[h];
+        if (k == mykey) { const unsigned long long hd = P.ht.heads[h]; e = (uint32_t(hd >> 32) == P.ht.epoch) ? uint32_t(hd) : kNil; break; }
+        if (uint32_t(k >> 32) != P.ht.epoch) break;
+        h = (h + 1u) & P.ht.mask;
+      }
+      if (e != kNil) {
+        const float4 eq = P.ew2[i];
+        const uint32_t* mk = P.mask2 + size_t(i) * kMaskWords;
+        const int2 ab2 = P.ab2[i];
+        const uint32_t ok2 = P.okey2[i];
+        while (e != kNil) {
+          const uint32_t b = P.bucket1[e];
+          if ((mk[b >> 5] >> (b & 31u)) & 1u) {
+            const float4 ep = P.ew1[e];
+            const float dx = eq.x - ep.x, dy = eq.y - ep.y, dz = eq.z - ep.z;
+            if (sqn3(dx, dy, dz) <= P.thr) {                                           // super4pcs.cc:160
+              const int2 ab1 = P.ab1[e];
+              const int4 quad = make_int4(ab1.x, ab1.y, ab2.x, ab2.y);                 // :171-172
+              const unsigned long long tag = ((unsigned long long)P.okey1[e] << 32) | ok2;
+              const uint32_t slot = atomicAdd(&st_n, 1u);
+              if (slot < uint32_t(kQuadStage)) { st_q[slot] = quad; st_t[slot] = tag; }
+              else {                                                                    // stage full: direct append
+                const uint32_t at = atomicAdd(P.K_dev, 1u);
+                if (at < P.K_cap) { P.quads[at] = quad; P.tags[at] = tag; } else atomicOr(P.overflow, 4u);
+              }
+            }
           }
+          e = P.next1[e];
         }
       }
-      e = P.next1[e];
     }
+    __syncthreads();
+    const uint32_t n = min(st_n, uint32_t(kQuadStage));
+    if (n) {
+      if (threadIdx.x == 0) st_base = atomicAdd(P.K_dev, n);
+      __syncthreads();
+      const uint32_t base = st_base;
+      for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) {
+        const uint32_t at = base + e;
+        if (at < P.K_cap) { P.quads[at] = st_q[e]; P.tags[at] = st_t[e]; } else atomicOr(P.overflow, 4u);
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) st_n = 0;
+    __syncthreads();
   }
 }
 
