@@ -99,8 +99,7 @@ def main():
     n_q, n_p = info.n_sampled_q, info.n_sampled_p
     sh = sharding.ShardedRansac(m, rank, world, dist, dev)
 
-    for _ in range(args.warmup):
-        sh.run_window()
+    sh.run_windows(args.warmup)
     m.profile_enable(True, False)
     m.profile_get(reset=True)
 
@@ -111,9 +110,7 @@ def main():
 
     sync()
     t0 = time.perf_counter()
-    cand = 0
-    for _ in range(args.steps):
-        cand += sh.run_window()
+    cand = sh.run_windows(args.steps)          # pipelined: host base selection of step t+1 overlaps the GPU pass of step t
     sync()
     dt = time.perf_counter() - t0
     prof = m.profile_get(reset=True)
@@ -129,8 +126,7 @@ def main():
     m.profile_enable(False, True)
     m.profile_get(reset=True)
     q_before = m.info().candidates_verified
-    for _ in range(2):
-        sh.run_window()
+    sh.run_windows(2)
     pk = m.profile_get(reset=True)
     q_after = m.info().candidates_verified
     queries = max((q_after - q_before) * n_q, 1)

@@ -132,6 +132,19 @@ int32_t s4p_verify_transforms(s4p_ctx* ctx, const float* transforms, int64_t B, 
 int32_t s4p_try_base(s4p_ctx* ctx, const int32_t* base_ids, float invariant1, float invariant2,
                      s4p_base_result* result);
 
+/* Pipelined form of s4p_try_base: _async enqueues the whole device pass of the base set by s4p_set_base
+ * and returns at once (the host can select the next base and build its pair octree meanwhile); _wait
+ * returns results in submission order.  At most two bases may be in flight. */
+int32_t s4p_try_base_async(s4p_ctx* ctx, const int32_t* base_ids, float invariant1, float invariant2);
+int32_t s4p_try_base_wait(s4p_ctx* ctx, s4p_base_result* result);
+
+/* Snapshot / restore of the persistent pair-octree permutation (PairCreationFunctor::ids,
+ * pairCreationFunctor.h:36): lets a speculative, pipelined driver roll the host state back to the
+ * exact point where the sequential reference stopped. */
+int32_t s4p_pair_state_words(const s4p_ctx* ctx);
+int32_t s4p_pair_state_save(const s4p_ctx* ctx, uint32_t* out);
+int32_t s4p_pair_state_restore(s4p_ctx* ctx, const uint32_t* in);
+
 /* Multi-GPU sharding by base: a rank that does NOT own the current base still has to
  * advance the persistent pair-octree permutation exactly as the two ExtractPairs calls of that base
  * would (intersectionNode.h:156-176 partitions functor.ids in place), so that later bases emit pairs in
@@ -158,6 +171,8 @@ typedef struct {
   uint64_t verify_l1_pass;       /* queries that passed the dilated fine bitmap, if enabled */
   double   pairs_ms_total, quads_ms_total;
   uint64_t pairs_launches, quads_launches;
+  double   host_octree_s;        /* host time in the pair-octree builds (loop 1 of IntersectionFunctor)   */
+  double   host_wait_s;          /* host time blocked in stream synchronisation                           */
 } s4p_profile;
 int32_t s4p_profile_enable(s4p_ctx* ctx, int32_t enable_events, int32_t count_point_tests);
 int32_t s4p_profile_get(s4p_ctx* ctx, s4p_profile* out, int32_t reset);

@@ -88,6 +88,11 @@ int32_t s4p_matcher_try_one_base(s4p_matcher* m, int32_t* ok, s4p_base_result* l
  *   commit    : the "if (lcp > best_LCP_)" update of TryCongruentSet (match4pcsBase.hpp:467-484) applied
  *               to a result that may have been produced on another rank; *ok = TryOneBase's return value. */
 int32_t s4p_matcher_next_base(s4p_matcher* m, int32_t run_device, int32_t* found, int32_t* base_ids, s4p_base_result* result);
+/* Pipelined next_base: the owner's device pass is only enqueued (at most two in flight); wait_base
+ * returns the results in submission order.  Lets a rank overlap its GPU pass with the host-side work of
+ * the following trials. */
+int32_t s4p_matcher_next_base_async(s4p_matcher* m, int32_t run_device, int32_t* found, int32_t* base_ids);
+int32_t s4p_matcher_wait_base(s4p_matcher* m, s4p_base_result* result);
 int32_t s4p_matcher_commit(s4p_matcher* m, int32_t found, const int32_t* base_ids, const s4p_base_result* result, int32_t* ok);
 
 /* Match4PCSBase::Perform_N_steps (match4pcsBase.hpp:208-274) without the final apply to Q:

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -62,17 +63,22 @@ struct s4p_ctx {
   DevBuf<int2> ab1, ab2; DevBuf<uint32_t> okey1, okey2, cell1, cell2, bucket1, next1, mask2; DevBuf<float4> ew1, ew2;
   DevBuf<int4> quads; DevBuf<unsigned long long> tags; DevBuf<uint32_t> counts, cand_idx; DevBuf<float4> cand_T;
   DevBuf<unsigned long long> ht_keys, ht_heads; uint32_t ht_mask = 0, epoch = 0;
-  DevBuf<DevCounters> ctr; PinBuf<DevCounters> hctr;
+  DevBuf<DevCounters> ctr; PinBuf<DevCounters> hctr[2];      // [pipeline slot]
   DevBuf<uint32_t> seq_id[2], seq_leaf[2]; DevBuf<float4> leaves[2];
-  PinBuf<uint32_t> hseq_id[2], hseq_leaf[2]; PinBuf<float4> hleaves[2];
+  PinBuf<uint32_t> hseq_id[2][2], hseq_leaf[2][2]; PinBuf<float4> hleaves[2][2];   // [slot][pair set]
+  int cur = 0;                       // slot used by the call in progress
+  uint32_t q_head = 0, q_tail = 0;   // async FIFO of s4p_try_base_async (depth 2)
+  BaseFrame slot_bf[2];
+  hipEvent_t done[2] = {nullptr, nullptr};
   DevBuf<float> tbuf; size_t tbuf_cap = 0;
 
   // profiling
   bool prof_events = false, prof_points = false;
-  hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev[2][6] = {{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}};
   s4p_profile prof{};
   uint64_t last_K = 0;
   uint32_t verify_blocks = 512;
+  double host_octree_s = 0, host_wait_s = 0;
 
   size_t verify_lds_bytes() const { return gcoarse.n * 4 + size_t(kVerifyThreads / 64) * 3 * kQueueEntries * 4; }
   LcpGrid dev_grid() const {
@@ -108,18 +114,20 @@ int32_t launch_pairs(s4p_ctx* c, int set, float pair_distance, float pair_normal
                      int bp1, int bp2) {
   const float nRadius = pair_distance / c->frame.ratio;                         // setRadius, pairCreationFunctor.h:124-129
   const float eps_n = pair_distance_epsilon / c->frame.ratio;                  // getNormalizedEpsilon, :131-133
-  c->tree.build(c->hux.data(), c->huy.data(), c->huz.data(), c->n_q, nRadius, eps_n, 50);
+  { auto t0 = std::chrono::steady_clock::now();
+    c->tree.build(c->hux.data(), c->huy.data(), c->huz.data(), c->n_q, nRadius, eps_n, 50);
+    c->host_octree_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
   const uint32_t n_seq = uint32_t(c->tree.seq_id.size());
   const uint32_t n_leaf = uint32_t(c->tree.leaves.size());
   DevBuf<int2>& ab = set == 0 ? c->ab1 : c->ab2;
   DevBuf<uint32_t>& okey = set == 0 ? c->okey1 : c->okey2;
   if (n_seq == 0) return S4P_OK;
-  std::memcpy(c->hseq_id[set].p, c->tree.seq_id.data(), n_seq * sizeof(uint32_t));
-  std::memcpy(c->hseq_leaf[set].p, c->tree.seq_leaf.data(), n_seq * sizeof(uint32_t));
-  std::memcpy(c->hleaves[set].p, c->tree.leaves.data(), n_leaf * sizeof(float4));
-  HIPCHK(c, hipMemcpyAsync(c->seq_id[set].p, c->hseq_id[set].p, n_seq * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->seq_leaf[set].p, c->hseq_leaf[set].p, n_seq * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->leaves[set].p, c->hleaves[set].p, n_leaf * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+  std::memcpy(c->hseq_id[c->cur][set].p, c->tree.seq_id.data(), n_seq * sizeof(uint32_t));
+  std::memcpy(c->hseq_leaf[c->cur][set].p, c->tree.seq_leaf.data(), n_seq * sizeof(uint32_t));
+  std::memcpy(c->hleaves[c->cur][set].p, c->tree.leaves.data(), n_leaf * sizeof(float4));
+  HIPCHK(c, hipMemcpyAsync(c->seq_id[set].p, c->hseq_id[c->cur][set].p, n_seq * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->seq_leaf[set].p, c->hseq_leaf[c->cur][set].p, n_seq * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->leaves[set].p, c->hleaves[c->cur][set].p, n_leaf * sizeof(float4), hipMemcpyHostToDevice, c->stream));
   PairParams P{};
   P.ux = c->ux.p; P.uy = c->uy.p; P.uz = c->uz.p; P.qx = c->qx.p; P.qy = c->qy.p; P.qz = c->qz.p;
   P.nx = c->has_normals ? c->qnx.p : nullptr; P.ny = c->qny.p; P.nz = c->qnz.p;
@@ -218,11 +226,11 @@ int32_t launch_verify(s4p_ctx* c, const BaseFrame& bf) {
   V.ctr = c->ctr.p; V.cand_idx = c->cand_idx.p; V.cand_T = c->cand_T.p;
   { const char* ab = getenv("S4P_ABLATE"); V.ablate = ab ? atoi(ab) : 0; }   // debugging aid, results are wrong when set
   hipLaunchKernelGGL(k_gate, dim3(1024), dim3(256), 0, c->stream, V);
-  if (c->prof_events) HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+  if (c->prof_events) HIPCHK(c, hipEventRecord(c->ev[c->cur][0], c->stream));
   const size_t lds = c->verify_lds_bytes();
   if (c->prof_points) hipLaunchKernelGGL(k_verify<true>, dim3(c->verify_blocks), dim3(kVerifyThreads), lds, c->stream, V);
   else hipLaunchKernelGGL(k_verify<false>, dim3(c->verify_blocks), dim3(kVerifyThreads), lds, c->stream, V);
-  if (c->prof_events) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+  if (c->prof_events) HIPCHK(c, hipEventRecord(c->ev[c->cur][1], c->stream));
   SelectParams S{};
   S.tags = c->tags.p; S.counts = c->counts.p; S.quads = c->quads.p; S.K_dev = &c->ctr.p->K; S.K_cap = uint32_t(c->max_quads);
   S.ctr = c->ctr.p; S.q4 = c->q4.p; S.base = bf;
@@ -232,10 +240,21 @@ int32_t launch_verify(s4p_ctx* c, const BaseFrame& bf) {
   return S4P_OK;
 }
 
-int32_t fetch_result(s4p_ctx* c, const BaseFrame& bf, s4p_base_result* r) {
-  HIPCHK(c, hipMemcpyAsync(c->hctr.p, c->ctr.p, sizeof(DevCounters), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  const DevCounters& d = *c->hctr.p;
+// enqueue the result read-back of the base in slot c->cur and mark its completion
+int32_t enqueue_result(s4p_ctx* c, const BaseFrame& bf) {
+  c->slot_bf[c->cur] = bf;
+  HIPCHK(c, hipMemcpyAsync(c->hctr[c->cur].p, c->ctr.p, sizeof(DevCounters), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipEventRecord(c->done[c->cur], c->stream));
+  return S4P_OK;
+}
+
+// wait for slot c->cur and turn its counters into an s4p_base_result
+int32_t finish_result(s4p_ctx* c, s4p_base_result* r, bool fused) {
+  { auto t0 = std::chrono::steady_clock::now();
+    HIPCHK(c, hipEventSynchronize(c->done[c->cur]));
+    c->host_wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+  const DevCounters& d = *c->hctr[c->cur].p;
+  const BaseFrame& bf = c->slot_bf[c->cur];
   if (int32_t rc = check_overflow(c, d.overflow)) return rc;
   std::memset(r, 0, sizeof(*r));
   r->n_pairs1 = d.m1; r->n_pairs2 = d.m2; r->n_quads = d.K; r->n_verified = d.C;
@@ -247,14 +266,25 @@ int32_t fetch_result(s4p_ctx* c, const BaseFrame& bf, s4p_base_result* r) {
   c->last_K = d.K;
   if (c->prof_events) {
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) {
+    if (hipEventElapsedTime(&ms, c->ev[c->cur][0], c->ev[c->cur][1]) == hipSuccess) {
       c->prof.verify_launches++; c->prof.verify_ms_total += ms;
       c->prof.verify_candidates += d.C; c->prof.verify_quads += d.K; c->prof.verify_queries += uint64_t(d.C) * c->n_q;
+    }
+    if (fused) {
+      if (hipEventElapsedTime(&ms, c->ev[c->cur][2], c->ev[c->cur][3]) == hipSuccess) { c->prof.pairs_ms_total += ms; c->prof.pairs_launches += 2; }
+      if (hipEventElapsedTime(&ms, c->ev[c->cur][3], c->ev[c->cur][4]) == hipSuccess) { c->prof.quads_ms_total += ms; c->prof.quads_launches += 1; }
     }
   }
   if (c->prof_points) { c->prof.verify_point_tests += d.point_tests; c->prof.verify_l0_pass += d.l0_pass; c->prof.verify_l1_pass += d.l1_pass; }
   return S4P_OK;
 }
+
+int32_t fetch_result(s4p_ctx* c, const BaseFrame& bf, s4p_base_result* r) {
+  if (int32_t rc = enqueue_result(c, bf)) return rc;
+  return finish_result(c, r, false);
+}
+
+#define S4P_NEED_IDLE(c) do { if ((c)->q_head != (c)->q_tail) S4P_FAIL(c, S4P_ERR_STATE, "asynchronous bases outstanding: call s4p_try_base_wait first"); (c)->cur = 0; } while (0)
 
 int32_t reset_counters(s4p_ctx* c) {
   hipLaunchKernelGGL(k_reset_counters, dim3(1), dim3(1), 0, c->stream, c->ctr.p);
@@ -311,7 +341,10 @@ int32_t s4p_create(const s4p_options* opt, const s4p_limits* lim, int32_t device
   A(c->ht_keys, hts); A(c->ht_heads, hts); c->ht_mask = hts - 1;
   A(c->ctr, 1);
 #undef A
-  if ((e = c->hctr.alloc(1)) != hipSuccess) return fail(e, "hipHostMalloc");
+  for (int sl = 0; sl < 2; ++sl) {
+    if ((e = c->hctr[sl].alloc(1)) != hipSuccess) return fail(e, "hipHostMalloc");
+    if ((e = hipEventCreateWithFlags(&c->done[sl], hipEventDisableTiming)) != hipSuccess) return fail(e, "hipEventCreate");
+  }
   if ((e = hipMemset(c->ht_keys.p, 0, size_t(hts) * 8)) != hipSuccess) return fail(e, "hipMemset");
   if ((e = hipMemset(c->ht_heads.p, 0, size_t(hts) * 8)) != hipSuccess) return fail(e, "hipMemset");
   if ((e = hipMemset(c->ctr.p, 0, sizeof(DevCounters))) != hipSuccess) return fail(e, "hipMemset");
@@ -322,7 +355,7 @@ int32_t s4p_create(const s4p_options* opt, const s4p_limits* lim, int32_t device
     if ((e = hipFuncSetAttribute((const void*)k_verify<true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds)) != hipSuccess) return fail(e, "hipFuncSetAttribute");
     if ((e = hipFuncSetAttribute((const void*)k_verify_T, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds)) != hipSuccess) return fail(e, "hipFuncSetAttribute");
   }
-  for (auto& ev : c->ev) if ((e = hipEventCreate(&ev)) != hipSuccess) return fail(e, "hipEventCreate");
+  for (auto& row : c->ev) for (auto& ev : row) if ((e = hipEventCreate(&ev)) != hipSuccess) return fail(e, "hipEventCreate");
   *out = c;
   return S4P_OK;
 }
@@ -337,10 +370,12 @@ void s4p_destroy(s4p_ctx* c) {
   c->qnx.free(); c->qny.free(); c->qnz.free(); c->qcr.free(); c->qcg.free(); c->qcb.free();
   c->ab1.free(); c->ab2.free(); c->okey1.free(); c->okey2.free(); c->cell1.free(); c->cell2.free();
   c->bucket1.free(); c->next1.free(); c->mask2.free(); c->ew1.free(); c->ew2.free();
-  c->quads.free(); c->tags.free(); c->counts.free(); c->cand_idx.free(); c->cand_T.free(); c->ht_keys.free(); c->ht_heads.free(); c->ctr.free(); c->hctr.free();
-  for (int s = 0; s < 2; ++s) { c->seq_id[s].free(); c->seq_leaf[s].free(); c->leaves[s].free(); c->hseq_id[s].free(); c->hseq_leaf[s].free(); c->hleaves[s].free(); }
+  c->quads.free(); c->tags.free(); c->counts.free(); c->cand_idx.free(); c->cand_T.free(); c->ht_keys.free(); c->ht_heads.free(); c->ctr.free(); c->hctr[0].free(); c->hctr[1].free();
+  for (int s = 0; s < 2; ++s) { c->seq_id[s].free(); c->seq_leaf[s].free(); c->leaves[s].free();
+    for (int sl = 0; sl < 2; ++sl) { c->hseq_id[sl][s].free(); c->hseq_leaf[sl][s].free(); c->hleaves[sl][s].free(); } }
   c->tbuf.free();
-  for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
+  for (auto& row : c->ev) for (auto& ev : row) if (ev) (void)hipEventDestroy(ev);
+  for (auto& ev : c->done) if (ev) (void)hipEventDestroy(ev);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -402,7 +437,7 @@ int32_t s4p_set_clouds(s4p_ctx* c, const float* px, const float* py, const float
   if (c->has_rgb) { HIPCHK(c, up(c->qcr, qr)); HIPCHK(c, up(c->qcg, qg)); HIPCHK(c, up(c->qcb, qb)); }
   for (int s = 0; s < 2; ++s) {
     HIPCHK(c, c->seq_id[s].alloc(n_q)); HIPCHK(c, c->seq_leaf[s].alloc(n_q)); HIPCHK(c, c->leaves[s].alloc(n_q));
-    HIPCHK(c, c->hseq_id[s].alloc(n_q)); HIPCHK(c, c->hseq_leaf[s].alloc(n_q)); HIPCHK(c, c->hleaves[s].alloc(n_q));
+    for (int sl = 0; sl < 2; ++sl) { HIPCHK(c, c->hseq_id[sl][s].alloc(n_q)); HIPCHK(c, c->hseq_leaf[sl][s].alloc(n_q)); HIPCHK(c, c->hleaves[sl][s].alloc(n_q)); }
   }
   c->clouds_set = true;
   return S4P_OK;
@@ -421,13 +456,14 @@ int32_t s4p_extract_pairs(s4p_ctx* c, float pair_distance, float pair_normals_an
   if (!c || !n_out) return S4P_ERR_BAD_ARG;
   if (!c->clouds_set) S4P_FAIL(c, S4P_ERR_STATE, "s4p_set_clouds not called");
   if (bp1 < 0 || bp1 > 3 || bp2 < 0 || bp2 > 3) S4P_FAIL(c, S4P_ERR_BAD_ARG, "base_point index out of [0,3]");
+  S4P_NEED_IDLE(c);
   HIPCHK(c, hipSetDevice(c->device));
   if (int32_t rc = reset_counters(c)) return rc;
   if (int32_t rc = launch_pairs(c, 0, pair_distance, pair_normals_angle, pair_distance_epsilon, bp1, bp2)) return rc;
-  HIPCHK(c, hipMemcpyAsync(c->hctr.p, c->ctr.p, sizeof(DevCounters), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->hctr[c->cur].p, c->ctr.p, sizeof(DevCounters), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  if (int32_t rc = check_overflow(c, c->hctr.p->overflow)) return rc;
-  const uint32_t m = c->hctr.p->m1;
+  if (int32_t rc = check_overflow(c, c->hctr[c->cur].p->overflow)) return rc;
+  const uint32_t m = c->hctr[c->cur].p->m1;
   *n_out = m;
   if (m == 0) return S4P_OK;
   if (!out_pairs || cap < int64_t(m)) S4P_FAIL(c, S4P_ERR_CAPACITY, "s4p_extract_pairs: output buffer too small");
@@ -452,6 +488,7 @@ int32_t s4p_find_congruent(s4p_ctx* c, float inv1, float inv2, float /*thr1*/, f
   if (uint64_t(m1) > c->max_pairs || uint64_t(m2) > c->max_pairs) S4P_FAIL(c, S4P_ERR_CAPACITY, "pair list longer than max_pairs");
   for (int64_t i = 0; i < 2 * m1; ++i) if (pairs1[i] < 0 || uint32_t(pairs1[i]) >= c->n_q) S4P_FAIL(c, S4P_ERR_BAD_ARG, "pair index out of range");
   for (int64_t i = 0; i < 2 * m2; ++i) if (pairs2[i] < 0 || uint32_t(pairs2[i]) >= c->n_q) S4P_FAIL(c, S4P_ERR_BAD_ARG, "pair index out of range");
+  S4P_NEED_IDLE(c);
   HIPCHK(c, hipSetDevice(c->device));
   if (int32_t rc = reset_counters(c)) return rc;
   std::vector<uint32_t> idx((size_t)std::max(m1, m2));
@@ -463,10 +500,10 @@ int32_t s4p_find_congruent(s4p_ctx* c, float inv1, float inv2, float /*thr1*/, f
   const uint32_t mm[2] = {uint32_t(m1), uint32_t(m2)};
   HIPCHK(c, hipMemcpyAsync(&c->ctr.p->m1, mm, 8, hipMemcpyHostToDevice, c->stream));
   if (int32_t rc = launch_quads(c, inv1, inv2, thr2)) return rc;
-  HIPCHK(c, hipMemcpyAsync(c->hctr.p, c->ctr.p, sizeof(DevCounters), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->hctr[c->cur].p, c->ctr.p, sizeof(DevCounters), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  if (int32_t rc = check_overflow(c, c->hctr.p->overflow)) return rc;
-  const uint32_t K = c->hctr.p->K;
+  if (int32_t rc = check_overflow(c, c->hctr[c->cur].p->overflow)) return rc;
+  const uint32_t K = c->hctr[c->cur].p->K;
   *n_out = K;
   if (K == 0) return S4P_OK;
   if (!out_quads || cap < int64_t(K)) S4P_FAIL(c, S4P_ERR_CAPACITY, "s4p_find_congruent: output buffer too small");
@@ -491,6 +528,7 @@ int32_t s4p_try_congruent_set(s4p_ctx* c, const int32_t* base_ids, const int32_t
   if (K < 0 || uint64_t(K) > c->max_quads) S4P_FAIL(c, S4P_ERR_CAPACITY, "more quads than max_quads");
   if (K > 0 && !quads) S4P_FAIL(c, S4P_ERR_BAD_ARG, "null quads");
   for (int64_t i = 0; i < 4 * K; ++i) if (quads[i] < 0 || uint32_t(quads[i]) >= c->n_q) S4P_FAIL(c, S4P_ERR_BAD_ARG, "quad index out of range");
+  S4P_NEED_IDLE(c);
   HIPCHK(c, hipSetDevice(c->device));
   if (int32_t rc = reset_counters(c)) return rc;
   const BaseFrame bf = make_base_frame(c, base_ids);
@@ -516,6 +554,7 @@ int32_t s4p_verify_transforms(s4p_ctx* c, const float* T, int64_t B, uint32_t* c
   if (!c || (B > 0 && (!T || !counts))) return S4P_ERR_BAD_ARG;
   if (!c->clouds_set) S4P_FAIL(c, S4P_ERR_STATE, "s4p_set_clouds not called");
   if (B <= 0) return S4P_OK;
+  S4P_NEED_IDLE(c);
   HIPCHK(c, hipSetDevice(c->device));
   DevBuf<float> dT; DevBuf<uint32_t> dC;
   HIPCHK(c, dT.alloc(size_t(B) * 16));
@@ -539,11 +578,13 @@ int32_t s4p_verify_transforms(s4p_ctx* c, const float* T, int64_t B, uint32_t* c
   return rc;
 }
 
-int32_t s4p_try_base(s4p_ctx* c, const int32_t* base_ids, float inv1, float inv2, s4p_base_result* result) {
-  if (!c || !base_ids || !result) return S4P_ERR_BAD_ARG;
+int32_t s4p_try_base_async(s4p_ctx* c, const int32_t* base_ids, float inv1, float inv2) {
+  if (!c || !base_ids) return S4P_ERR_BAD_ARG;
   if (!c->clouds_set) S4P_FAIL(c, S4P_ERR_STATE, "s4p_set_clouds not called");
   for (int i = 0; i < 4; ++i) if (base_ids[i] < 0 || uint32_t(base_ids[i]) >= c->n_p) S4P_FAIL(c, S4P_ERR_BAD_ARG, "base id out of range");
+  if (c->q_tail - c->q_head >= 2u) S4P_FAIL(c, S4P_ERR_STATE, "two asynchronous bases already in flight");
   HIPCHK(c, hipSetDevice(c->device));
+  c->cur = int(c->q_tail & 1u);
   if (int32_t rc = reset_counters(c)) return rc;
   // match4pcsBase.hpp:313-331: segment lengths / normal "angles" of the ordered base, two ExtractPairs
   auto seg = [&](const float* v, int a, int b) {
@@ -553,20 +594,44 @@ int32_t s4p_try_base(s4p_ctx* c, const int32_t* base_ids, float inv1, float inv2
   const float distance1 = seg(c->base_xyz, 0, 1), distance2 = seg(c->base_xyz, 2, 3);
   const float normal_angle1 = seg(c->base_nrm, 0, 1), normal_angle2 = seg(c->base_nrm, 2, 3);
   const float eps = 2.0f * c->opt.delta;                                          // distance_factor * delta
-  if (c->prof_events) HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+  if (c->prof_events) HIPCHK(c, hipEventRecord(c->ev[c->cur][2], c->stream));
   if (int32_t rc = launch_pairs(c, 0, distance1, normal_angle1, eps, 0, 1)) return rc;
   if (int32_t rc = launch_pairs(c, 1, distance2, normal_angle2, eps, 2, 3)) return rc;
-  if (c->prof_events) HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+  if (c->prof_events) HIPCHK(c, hipEventRecord(c->ev[c->cur][3], c->stream));
   if (int32_t rc = launch_quads(c, inv1, inv2, eps)) return rc;
-  if (c->prof_events) HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
+  if (c->prof_events) HIPCHK(c, hipEventRecord(c->ev[c->cur][4], c->stream));
   const BaseFrame bf = make_base_frame(c, base_ids);
   if (int32_t rc = launch_verify(c, bf)) return rc;
-  if (int32_t rc = fetch_result(c, bf, result)) return rc;
-  if (c->prof_events) {
-    float ms = 0.f;
-    if (hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) { c->prof.pairs_ms_total += ms; c->prof.pairs_launches += 2; }
-    if (hipEventElapsedTime(&ms, c->ev[3], c->ev[4]) == hipSuccess) { c->prof.quads_ms_total += ms; c->prof.quads_launches += 1; }
-  }
+  if (int32_t rc = enqueue_result(c, bf)) return rc;
+  c->q_tail++;
+  return S4P_OK;
+}
+
+int32_t s4p_try_base_wait(s4p_ctx* c, s4p_base_result* result) {
+  if (!c || !result) return S4P_ERR_BAD_ARG;
+  if (c->q_head == c->q_tail) S4P_FAIL(c, S4P_ERR_STATE, "no asynchronous base in flight");
+  HIPCHK(c, hipSetDevice(c->device));
+  c->cur = int(c->q_head & 1u);
+  c->q_head++;
+  return finish_result(c, result, true);
+}
+
+int32_t s4p_try_base(s4p_ctx* c, const int32_t* base_ids, float inv1, float inv2, s4p_base_result* result) {
+  if (!c || !base_ids || !result) return S4P_ERR_BAD_ARG;
+  if (c->q_head != c->q_tail) S4P_FAIL(c, S4P_ERR_STATE, "asynchronous bases outstanding: call s4p_try_base_wait first");
+  if (int32_t rc = s4p_try_base_async(c, base_ids, inv1, inv2)) return rc;
+  return s4p_try_base_wait(c, result);
+}
+
+int32_t s4p_pair_state_words(const s4p_ctx* c) { return c ? int32_t(c->tree.ids.size()) : 0; }
+int32_t s4p_pair_state_save(const s4p_ctx* c, uint32_t* out) {
+  if (!c || !out) return S4P_ERR_BAD_ARG;
+  std::memcpy(out, c->tree.ids.data(), c->tree.ids.size() * sizeof(uint32_t));
+  return S4P_OK;
+}
+int32_t s4p_pair_state_restore(s4p_ctx* c, const uint32_t* in) {
+  if (!c || !in) return S4P_ERR_BAD_ARG;
+  std::memcpy(c->tree.ids.data(), in, c->tree.ids.size() * sizeof(uint32_t));
   return S4P_OK;
 }
 
@@ -634,6 +699,8 @@ int32_t s4p_profile_enable(s4p_ctx* c, int32_t enable_events, int32_t count_poin
 }
 int32_t s4p_profile_get(s4p_ctx* c, s4p_profile* out, int32_t reset) {
   if (!c || !out) return S4P_ERR_BAD_ARG;
+  c->prof.host_octree_s = c->host_octree_s; c->prof.host_wait_s = c->host_wait_s;
+  if (reset) { c->host_octree_s = 0; c->host_wait_s = 0; }
   *out = c->prof;
   if (reset) c->prof = s4p_profile{};
   return S4P_OK;

@@ -87,6 +87,14 @@ struct s4p_matcher {
   uint64_t candidates_verified = 0, quads_total = 0, pairs_total = 0, bases_tried = 0;
   double seconds_select = 0, seconds_device = 0;
   bool ready = false;
+  // pipelined trials: bases whose device pass is in flight (at most two)
+  struct Prepared {
+    bool found = false, device = false;
+    int ids[4] = {0, 0, 0, 0};
+    std::mt19937 rng_before;               // host state before this trial was prepared (for exact roll-back)
+    std::vector<uint32_t> pair_state_before;
+  };
+  std::vector<Prepared> inflight;          // FIFO
 
   void set_identity() { for (int i = 0; i < 16; ++i) transform[i] = (i % 5 == 0) ? 1.f : 0.f; }
   V3 P(int i) const { return {Ps.x[i], Ps.y[i], Ps.z[i]}; }
@@ -192,11 +200,29 @@ bool select_quadrilateral(s4p_matcher* m, float& inv1, float& inv2, int ids[4]) 
       float best = std::numeric_limits<float>::max();
       const float too_small = float(std::pow(double(m->max_base_diameter * kBaseTooSmall), 2));
       const float* X = m->Ps.x.data(); const float* Y = m->Ps.y.data(); const float* Z = m->Ps.z.data();
-      for (size_t i = 0; i < n; ++i) {
-        const V3 p{X[i], Y[i], Z[i]};
-        if (sqn(sub(p, A)) >= too_small && sqn(sub(p, B)) >= too_small && sqn(sub(p, C)) >= too_small) {
-          const float dist = float(std::abs(double(pa * p.x + pb * p.y + pc * p.z) - 1.0));
-          if (dist < best) { best = dist; b4 = int(i); }
+      // Reference loop (match4pcsBase.cc:324-338): among points not closer than too_small (squared) to the three
+      // base points, the first one with the strictly smallest plane distance |A x + B y + C z - 1|.
+      // The reference evaluates the distance in double, float(|double(v) - 1.0|); for float v that equals the
+      // correctly rounded float |v - 1.0f| (the double difference is exact), so the scan runs in float and
+      // 16-point blocks whose minimum cannot beat the running best are skipped after one vector pass.
+      constexpr size_t kBlk = 16;
+      float dist[kBlk];
+      for (size_t i0 = 0; i0 < n; i0 += kBlk) {
+        const size_t cnt = std::min(kBlk, n - i0);
+        float blockmin = std::numeric_limits<float>::max();
+        for (size_t k = 0; k < cnt; ++k) {
+          const float v = (pa * X[i0 + k] + pb * Y[i0 + k]) + pc * Z[i0 + k];
+          const float d = std::fabs(v - 1.0f);
+          dist[k] = d;
+          blockmin = d < blockmin ? d : blockmin;
+        }
+        if (!(blockmin < best)) continue;
+        for (size_t k = 0; k < cnt; ++k) {
+          if (!(dist[k] < best)) continue;
+          const V3 p{X[i0 + k], Y[i0 + k], Z[i0 + k]};
+          if (sqn(sub(p, A)) >= too_small && sqn(sub(p, B)) >= too_small && sqn(sub(p, C)) >= too_small) {
+            best = dist[k]; b4 = int(i0 + k);
+          }
         }
       }
       if (b4 != -1) {
@@ -252,6 +278,46 @@ int32_t next_base(s4p_matcher* m, bool run_device, bool& found, int ids[4], s4p_
     if (int32_t rc = s4p_skip_base(m->ctx)) return m->ctx_fail(rc);
   }
   m->seconds_device += std::chrono::duration<double>(clk::now() - t0).count();
+  return S4P_OK;
+}
+
+// pipelined first half: enqueue the device pass and return; results come back through wait_base()
+int32_t next_base_async(s4p_matcher* m, bool run_device, bool snapshot, s4p_matcher::Prepared& pr) {
+  using clk = std::chrono::steady_clock;
+  float inv1 = 0, inv2 = 0;
+  if (snapshot) {
+    pr.rng_before = m->rng;
+    pr.pair_state_before.resize(size_t(s4p_pair_state_words(m->ctx)));
+    s4p_pair_state_save(m->ctx, pr.pair_state_before.data());
+  }
+  auto t0 = clk::now();
+  pr.found = select_quadrilateral(m, inv1, inv2, pr.ids);
+  m->seconds_select += std::chrono::duration<double>(clk::now() - t0).count();
+  pr.device = false;
+  if (!pr.found) return S4P_OK;
+  float bx[12], bn[12], bc[12];
+  fill_base_arrays(m, pr.ids, bx, bn, bc);
+  if (int32_t rc = s4p_set_base(m->ctx, bx, bn, bc)) return m->ctx_fail(rc);
+  t0 = clk::now();
+  if (run_device) {
+    if (int32_t rc = s4p_try_base_async(m->ctx, pr.ids, inv1, inv2)) return m->ctx_fail(rc);
+    pr.device = true;
+  } else {
+    if (int32_t rc = s4p_skip_base(m->ctx)) return m->ctx_fail(rc);
+  }
+  m->seconds_device += std::chrono::duration<double>(clk::now() - t0).count();
+  return S4P_OK;
+}
+
+int32_t wait_base(s4p_matcher* m, const s4p_matcher::Prepared& pr, s4p_base_result& r) {
+  using clk = std::chrono::steady_clock;
+  std::memset(&r, 0, sizeof(r));
+  if (!pr.device) return S4P_OK;
+  const auto t0 = clk::now();
+  if (int32_t rc = s4p_try_base_wait(m->ctx, &r)) return m->ctx_fail(rc);
+  m->seconds_device += std::chrono::duration<double>(clk::now() - t0).count();
+  m->bases_tried++;
+  m->pairs_total += r.n_pairs1 + r.n_pairs2; m->quads_total += r.n_quads; m->candidates_verified += r.n_verified;
   return S4P_OK;
 }
 
@@ -447,6 +513,27 @@ int32_t s4p_matcher_next_base(s4p_matcher* m, int32_t run_device, int32_t* found
   return rc;
 }
 
+int32_t s4p_matcher_next_base_async(s4p_matcher* m, int32_t run_device, int32_t* found, int32_t* base_ids) {
+  if (!m || !found || !base_ids) return S4P_ERR_BAD_ARG;
+  if (!m->ready) return m->fail(S4P_ERR_STATE, "matcher not initialised");
+  if (m->inflight.size() >= 2) return m->fail(S4P_ERR_STATE, "two bases already in flight");
+  s4p_matcher::Prepared pr;
+  const int32_t rc = next_base_async(m, run_device != 0, false, pr);
+  if (rc != S4P_OK) return rc;
+  *found = pr.found ? 1 : 0;
+  for (int t = 0; t < 4; ++t) base_ids[t] = pr.ids[t];
+  if (pr.device) m->inflight.push_back(std::move(pr));
+  return S4P_OK;
+}
+
+int32_t s4p_matcher_wait_base(s4p_matcher* m, s4p_base_result* result) {
+  if (!m || !result) return S4P_ERR_BAD_ARG;
+  if (m->inflight.empty()) return m->fail(S4P_ERR_STATE, "no base in flight");
+  s4p_matcher::Prepared pr = std::move(m->inflight.front());
+  m->inflight.erase(m->inflight.begin());
+  return wait_base(m, pr, *result);
+}
+
 int32_t s4p_matcher_commit(s4p_matcher* m, int32_t found, const int32_t* base_ids, const s4p_base_result* result, int32_t* ok) {
   if (!m || !base_ids || !result || !ok) return S4P_ERR_BAD_ARG;
   if (!m->ready) return m->fail(S4P_ERR_STATE, "matcher not initialised");
@@ -470,8 +557,26 @@ int32_t s4p_matcher_perform_n_steps(s4p_matcher* m, int32_t n, s4p_visitor_fn vi
   if (visitor) visitor(user, 0.f, m->best_lcp, transformation);          // match4pcsBase.hpp:232
   bool ok = false;
   const auto t0 = sclock::now();
-  for (int i = m->current_trial; i < m->current_trial + n; ++i) {
-    if (int32_t rc = try_one_base(m, ok, nullptr)) return rc;
+  // The reference loop "for i: TryOneBase; ...; if (stop) break" with the device pass of trial i+1 enqueued
+  // before the result of trial i is waited for.  Base selection never reads results, so the speculation only
+  // has to be rolled back (RNG + pair-octree permutation) when the loop stops.
+  const int end = m->current_trial + n;
+  int next_prep = m->current_trial;
+  std::vector<s4p_matcher::Prepared>& fifo = m->inflight;
+  fifo.clear();
+  int32_t rc = S4P_OK;
+  for (int i = m->current_trial; i < end && rc == S4P_OK; ++i) {
+    while (fifo.size() < 2 && next_prep < end) {
+      fifo.emplace_back();
+      if ((rc = next_base_async(m, true, true, fifo.back())) != S4P_OK) break;
+      ++next_prep;
+    }
+    if (rc != S4P_OK) break;
+    s4p_matcher::Prepared pr = std::move(fifo.front());
+    fifo.erase(fifo.begin());
+    s4p_base_result r;
+    if ((rc = wait_base(m, pr, r)) != S4P_OK) break;
+    ok = commit_base(m, pr.found, pr.ids, r);
     const float fraction_try = float(i) / float(m->number_of_trials);
     // integer seconds / integer max_time_seconds: reference quirk, :240-243
     const float fraction_time = float(std::chrono::duration_cast<std::chrono::seconds>(sclock::now() - t0).count() /
@@ -482,6 +587,15 @@ int32_t s4p_matcher_perform_n_steps(s4p_matcher* m, int32_t n, s4p_visitor_fn vi
     if (visitor) visitor(user, fraction, m->best_lcp, transformation);
     if (ok || i > m->number_of_trials || fraction >= 0.99 || m->best_lcp == 1.0) break;
   }
+  // drain speculative work and put the host state back where the sequential loop stopped
+  if (!fifo.empty()) {
+    m->rng = fifo.front().rng_before;
+    std::vector<uint32_t> st = fifo.front().pair_state_before;
+    for (auto& pr : fifo) { s4p_base_result dummy; if (pr.device) (void)s4p_try_base_wait(m->ctx, &dummy); }
+    if (!st.empty()) s4p_pair_state_restore(m->ctx, st.data());
+    fifo.clear();
+  }
+  if (rc != S4P_OK) return rc;
   m->current_trial += n;
   *improved = m->best_lcp > last_best ? 1 : 0;
   if (*improved) global_transform(m, transformation);

@@ -65,46 +65,71 @@ class ShardedRansac:
             c -= 1
         return c
 
+    # ------------------------------------------------------------------------------------------
+    def run_windows(self, n):
+        """Runs n windows (n*world trials).  Returns the candidates this rank verified.
+
+        world == 1: the engine's own pipelined Perform_N_steps.
+        world  > 1: window w+1 is prepared (own device pass enqueued, other ranks' bases advanced on
+        the host) BEFORE window w's result is waited for and reduced, so GPU pass, host-side base
+        selection and the 8-byte collective overlap.
+        """
+        if self.world == 1:
+            before = self.m.info().candidates_verified
+            _, _, done = self.m.perform_n_steps(n)
+            self.trials_done += n
+            got = int(self.m.info().candidates_verified - before)
+            self.local_candidates += got
+            return got
+        total = 0
+        pending = None
+        for _ in range(n):
+            cur = self._prepare_window()
+            if pending is not None:
+                total += self._finish_window(pending)
+            pending = cur
+        if pending is not None:
+            total += self._finish_window(pending)
+        return total
+
     def run_window(self):
-        """One window = `world` consecutive trials.  Returns the number of candidates this rank verified."""
-        if self.world == 1:                       # plain TryOneBase
-            found, base, r = self.m.next_base(run_device=True)
-            self.terminated = self.m.commit(found, base, r) or self.terminated
-            self.trials_done += 1
-            self.local_candidates += int(r.n_verified)
-            return int(r.n_verified)
-        import torch
-        thr_c = self._threshold_count()
-        mine = None
-        bases = []
+        return self.run_windows(1)
+
+    def _prepare_window(self):
+        bases, mine = [], None
         for j in range(self.world):
-            found, base, r = self.m.next_base(run_device=(j == self.rank))
-            bases.append((found, base))
             if j == self.rank:
-                mine = (found, base, r)
-        found, base, r = mine
-        usable = bool(found and r.n_pairs1 and r.n_pairs2 and r.n_quads)
+                found, base = self.m.next_base_async(True)
+                mine = found
+            else:
+                found, base, _ = self.m.next_base(run_device=False)
+            bases.append((found, base))
+        return bases, mine
+
+    def _finish_window(self, prepared):
+        import torch
+        from . import capi
+        bases, mine_found = prepared
+        r = self.m.wait_base() if mine_found else capi.BaseResult()
+        thr_c = self._threshold_count()
+        usable = bool(mine_found and r.n_pairs1 and r.n_pairs2 and r.n_quads)
         key = window_key(r.best_count, bool(r.has_best), usable, self.rank, thr_c)
-        self.local_candidates += int(r.n_verified)
         verified = int(r.n_verified)
-        if self.world > 1:
-            t = torch.tensor([key], dtype=torch.int64, device=self.device)
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-            key = int(t.item())
-        win = decode_key(key)
+        self.local_candidates += verified
+        t = torch.tensor([key], dtype=torch.int64, device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)           # the one data-path collective: 8 bytes
+        win = decode_key(int(t.item()))
         if win is not None:
             w_trial, w_count, crossed = win
-            cur = self.m.info().best_count
-            if w_count > cur:
-                rec = torch.zeros(self.RECORD_FLOATS, dtype=torch.float64, device=self.device)
+            if w_count > self.m.info().best_count:
                 if w_trial == self.rank:
                     vals = list(r.best_transform) + list(r.best_centroid2) + list(r.centroid1) + [float(v) for v in r.best_quad] + \
                         [float(r.n_pairs1), float(r.n_pairs2), float(r.n_quads), float(r.n_verified), float(r.best_count), float(r.has_best)]
                     rec = torch.tensor(vals, dtype=torch.float64, device=self.device)
-                if self.world > 1:
-                    self.dist.broadcast(rec, src=w_trial)
+                else:
+                    rec = torch.zeros(self.RECORD_FLOATS, dtype=torch.float64, device=self.device)
+                self.dist.broadcast(rec, src=w_trial)                 # winner's 4x4 etc., only when the window improved
                 v = rec.cpu().numpy()
-                from . import capi
                 wr = capi.BaseResult()
                 for i in range(16):
                     wr.best_transform[i] = np.float32(v[i])
