@@ -1,0 +1,88 @@
+// Mirrors the reference's tests/externalAppTest/main.cpp (an external application compiled against the
+// installed headers) plus the Testing::TestMatcher pattern of tests/testing.h:71-154 that re-exposes the
+// protected steps.  With a GPU it runs a registration; without one the constructor must throw.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+
+#include "super4pcs/algorithms/super4pcs.h"
+#include "super4pcs/shared4pcs.h"
+#include "super4pcs/utils/logger.h"
+
+using namespace GlobalRegistration;
+
+struct CountingVisitor {
+  mutable int calls = 0;
+  inline void operator()(float, float, Match4PCSBase::MatrixRef) const { ++calls; }
+  constexpr bool needsGlobalTransformation() const { return false; }
+};
+
+template <class BaseMatcher>
+class TestMatcher : public BaseMatcher {
+ public:
+  using BaseMatcher::BaseMatcher;
+  using PairsVector = typename BaseMatcher::PairsVector;
+  using Scalar = typename BaseMatcher::Scalar;
+  template <class S = typename BaseMatcher::DefaultSampler>
+  void init(const std::vector<Point3D>& P, const std::vector<Point3D>& Q, const S& s = S()) { BaseMatcher::init(P, Q, s); }
+  bool SelectQuadrilateral(Scalar& a, Scalar& b, int& b1, int& b2, int& b3, int& b4) {
+    return BaseMatcher::SelectQuadrilateral(a, b, b1, b2, b3, b4);
+  }
+  void ExtractPairs(Scalar d, Scalar na, Scalar e, int p1, int p2, PairsVector* out) const override {
+    BaseMatcher::ExtractPairs(d, na, e, p1, p2, out);
+  }
+  bool FindCongruentQuadrilaterals(Scalar i1, Scalar i2, Scalar t1, Scalar t2, const PairsVector& a, const PairsVector& b,
+                                   std::vector<Quadrilateral>* q) const override {
+    return BaseMatcher::FindCongruentQuadrilaterals(i1, i2, t1, t2, a, b, q);
+  }
+};
+
+int main(int argc, char** argv) {
+  const bool expect_gpu = argc > 1 && std::atoi(argv[1]) != 0;
+  Match4PCSOptions opt;
+  opt.delta = 0.05f;
+  opt.sample_size = 150;
+  if (!opt.configureOverlap(0.7f)) return 2;
+  Utils::Logger logger(Utils::NoLog);
+  std::mt19937 g(7);
+  std::normal_distribution<float> nd(0.f, 1.f);
+  std::vector<Point3D> P, Q;
+  for (int i = 0; i < 3000; ++i) {
+    float x = nd(g), y = nd(g), z = nd(g);
+    const float n = std::sqrt(x * x + y * y + z * z);
+    x /= n; y /= n; z = z / n * 0.5f;
+    P.emplace_back(x, y, z);
+    Q.emplace_back(0.8f * x - 0.6f * y + 0.3f, 0.6f * x + 0.8f * y - 0.2f, z + 0.1f);   // rotated about z + shifted
+  }
+  try {
+    TestMatcher<MatchSuper4PCS> matcher(opt, logger);
+    if (!expect_gpu) { std::puts("constructed without a GPU: unexpected"); return 3; }
+    Match4PCSBase::MatrixType mat = Match4PCSBase::MatrixType::Identity();
+    CountingVisitor vis;
+    std::vector<Point3D> Q2 = Q;
+    const float score = matcher.ComputeTransformation(P, &Q2, mat, Sampling::UniformDistSampler(), vis);
+    std::printf("score %.4f visitor calls %d sampled %zu/%zu\n", score, vis.calls, matcher.getFirstSampled().size(),
+                matcher.getSecondSampled().size());
+    if (!(score > 0.5f) || vis.calls < 2) return 4;
+    // empty sets (tests/externalAppTest/main.cpp): kLargeNumber
+    std::vector<Point3D> e1, e2;
+    if (matcher.ComputeTransformation(e1, &e2, mat) != Match4PCSBase::kLargeNumber) return 5;
+    // protected steps: pairs / quads through the virtuals
+    TestMatcher<MatchSuper4PCS> m2(opt, logger);
+    m2.init(P, Q);
+    float i1, i2; int b1, b2, b3, b4;
+    if (!m2.SelectQuadrilateral(i1, i2, b1, b2, b3, b4)) return 6;
+    Match4PCSBase::PairsVector p1, p2;
+    m2.ExtractPairs(0.8f, 0.f, Match4PCSBase::distance_factor * opt.delta, 0, 1, &p1);
+    m2.ExtractPairs(0.6f, 0.f, Match4PCSBase::distance_factor * opt.delta, 2, 3, &p2);
+    std::vector<Quadrilateral> quads;
+    m2.FindCongruentQuadrilaterals(i1, i2, 0.1f, 0.1f, p1, p2, &quads);
+    std::printf("pairs %zu %zu quads %zu\n", p1.size(), p2.size(), quads.size());
+    if (p1.empty() || p2.empty()) return 7;
+    return 0;
+  } catch (const std::exception& e) {
+    std::printf("exception: %s\n", e.what());
+    return expect_gpu ? 8 : 0;
+  }
+}

@@ -94,3 +94,52 @@ def test_empty_inputs_return_large_number(s4p_lib_built):
     m = capi.Matcher(capi.make_options(0.01, 0.5, 200))
     lcp, M, Q = m.compute_transformation(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32))
     assert lcp == np.float32(1e9)
+
+
+def test_gpu_against_committed_golden_vectors(s4p_lib_built):
+    """GPU path vs tests/golden/oracle_golden.json (no live oracle involved): registration result and
+    the stage vectors (pairs / quads / per-candidate counts) of one base."""
+    import hashlib
+    import json
+    import os
+    from super4pcs_amd import capi
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "oracle_golden.json")))
+
+    def digest(a):
+        return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+    g = gold["registration"]
+    P, Q, _ = H.small_pair(20000, delta=g["input"]["delta"], seed=31)
+    assert digest(P) == g["input"]["P_sha256"]
+    m = capi.Matcher(capi.make_options(g["input"]["delta"], g["input"]["overlap"], g["input"]["sample_size"], seed=g["input"]["seed"]))
+    lcp, M, Qt = m.compute_transformation(P, Q)
+    i = m.info()
+    assert (i.n_sampled_p, i.n_sampled_q, i.number_of_trials) == (g["n_P"], g["n_Q"], g["number_of_trials"])
+    assert float(lcp) == g["lcp"] and i.best_count == g["best_count"]
+    assert i.candidates_verified == g["candidates_verified"] and i.quads_total == g["quads"] and i.pairs_total == g["pairs"]
+    assert np.array_equal(M.reshape(-1), np.array(g["M"], np.float32))
+    assert digest(Qt) == g["Qt_sha256"]
+    # stage vectors
+    s = gold["stage"]
+    m2 = capi.Matcher(capi.make_options(g["input"]["delta"], g["input"]["overlap"], g["input"]["sample_size"], seed=g["input"]["seed"]))
+    m2.init_full(P, Q)
+    ctx = capi.Context(capi.make_options(g["input"]["delta"], g["input"]["overlap"], g["input"]["sample_size"]))
+    ctx.set_clouds(m2.sampled(0), m2.sampled(1))
+    hit = False
+    for _ in range(30):
+        found, i1, i2, base, bx = m2.select_quadrilateral()
+        if not found:
+            continue
+        ctx.set_base(bx)
+        d1 = float(np.float32(np.linalg.norm(bx[0] - bx[1]))); d2 = float(np.float32(np.linalg.norm(bx[2] - bx[3])))
+        p1 = ctx.extract_pairs(d1, 0.0, 0.02, 0, 1); p2 = ctx.extract_pairs(d2, 0.0, 0.02, 2, 3)
+        if base.tolist() != s["base"]:
+            continue
+        hit = True
+        assert digest(p1) == s["pairs1_sha256"] and digest(p2) == s["pairs2_sha256"]
+        quads = ctx.find_congruent(i1, i2, 0.02, p1, p2)
+        assert digest(quads) == s["quads_sha256"]
+        r, per = ctx.try_congruent_set(base, quads)
+        assert r.n_verified == s["n_verified"] and digest(per) == s["counts_sha256"] and r.best_count == s["max_count"]
+        break
+    assert hit
