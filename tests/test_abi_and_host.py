@@ -49,9 +49,10 @@ def test_product_never_imports_the_oracle():
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 if re.search(r"(from|import)\s+oracle|s4po_|libs4p_oracle|oracle/", txt):
                     bad.append(os.path.join(dirpath, f))
-    for f in os.listdir(os.path.join(ROOT, "include")):
-        if "s4po_" in open(os.path.join(ROOT, "include", f)).read():
-            bad.append(f)
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "include")):
+        for f in files:
+            if "s4po_" in open(os.path.join(dirpath, f)).read():
+                bad.append(f)
     assert not bad, bad
 
 
