@@ -40,8 +40,21 @@ def bytes_per_candidate(n_q, kbar, cells=27):
 
 
 def cpu_baseline(P, Q, budget_s):
-    """Oracle (CPU restatement of the reference path, 1 thread) on the same workload, bounded sample."""
+    """CPU path on the same workload, 1 thread (what MatchSuper4PCS does, super4pcs.cc:68-73), bounded sample.
+
+    kind "reference": the reference's own sources (oracle/_ref/libs4p_ref.so, built from /root/reference against
+    oracle/eigen_shim) run ComputeTransformation and are cut by a visitor exception after budget_s of RANSAC time.
+    kind "port": the oracle restatement, if the prebuilt reference library is not in the tree.
+    """
     from oracle import oracle as O
+    from oracle import reflib
+    if reflib.available():
+        rm = reflib.RefMatcher(O.make_options(DELTA, OVERLAP, SAMPLE))
+        cut, n, sec = rm.bench(P, Q, budget_s)
+        return {"value": n / max(sec, 1e-9), "unit": "candidates/s", "cores": 1, "kind": "reference",
+                "sample": "reference ComputeTransformation (kd-tree Verify with early exit) on the same clouds/seed, "
+                          "stopped after %.1f s of RANSAC time: %d candidates verified%s" % (sec, n, "" if cut else " (ran to completion)"),
+                "seconds": sec}
     O.build()
     om = O.Matcher(O.make_options(DELTA, OVERLAP, SAMPLE), full_counts=False, use_kdtree=True, keep_trace=False)
     om.init(P, Q)
