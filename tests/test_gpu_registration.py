@@ -143,3 +143,28 @@ def test_gpu_against_committed_golden_vectors(s4p_lib_built):
         assert r.n_verified == s["n_verified"] and digest(per) == s["counts_sha256"] and r.best_count == s["max_count"]
         break
     assert hit
+
+
+def test_gpu_against_the_reference_sources_directly(s4p_lib_built):
+    """GPU path vs oracle/_ref (the reference's own match4pcsBase.cc / super4pcs.cc compiled against the Eigen
+    shim): same LCP (integer inliers), same number of verified candidates, R and t within 1e-4."""
+    reflib = pytest.importorskip("oracle.reflib")
+    if not reflib.available():
+        pytest.skip("oracle/_ref/libs4p_ref.so not in the tree")
+    from oracle import oracle as O
+    from super4pcs_amd import capi
+    delta, overlap, n_s = 0.01, 0.6, 200
+    for seed, cloud_seed in ((5489, 31), (7, 12)):
+        P, Q, _ = H.small_pair(20000, delta=delta, seed=cloud_seed)
+        rm = reflib.RefMatcher(O.make_options(delta, overlap, n_s, seed=seed))
+        r_lcp, r_M, r_Q, r_n = rm.compute_transformation(P, Q)
+        gm = capi.Matcher(capi.make_options(delta, overlap, n_s, seed=seed))
+        g_lcp, g_M, g_Q = gm.compute_transformation(P, Q)
+        assert g_lcp == r_lcp
+        assert gm.info().candidates_verified == r_n
+        assert np.array_equal(g_M[:3, :3], r_M[:3, :3])
+        assert np.max(np.abs(g_M - r_M)) <= 1e-4 and np.max(np.abs(g_Q - r_Q)) <= 1e-4
+        rT, rl, rb, rc = rm.best()
+        gi = gm.info()
+        assert list(gi.base) == rb.tolist() and list(gi.congruent) == rc.tolist()
+        assert np.array_equal(np.array(gi.transform, np.float32).reshape(4, 4), rT)
