@@ -138,6 +138,18 @@ int32_t s4p_try_base(s4p_ctx* ctx, const int32_t* base_ids, float invariant1, fl
 int32_t s4p_try_base_async(s4p_ctx* ctx, const int32_t* base_ids, float invariant1, float invariant2);
 int32_t s4p_try_base_wait(s4p_ctx* ctx, s4p_base_result* result);
 
+/* Two-step form for a driver that prepares bases on another host thread:
+ *   s4p_stage_base   host-only part of the two ExtractPairs calls of a base (octree loop 1, which also advances the
+ *                    persistent permutation); with want_device_data the flat sequences are left in pinned staging
+ *                    slot `slot` (0 .. s4p_stage_slots()-1).  Touches no device state: it may run on a different
+ *                    thread than the one that owns the context, provided bases are staged in trial order.
+ *   s4p_try_base_staged_async   uploads slot `slot` and enqueues the device pass (base set by s4p_set_base).
+ * A slot may be re-staged once the s4p_try_base_wait of the base that used it has returned.
+ * s4p_try_base_async itself uses slots 0..2 round-robin; a threaded driver should use slots 3 and up or only the staged form. */
+int32_t s4p_stage_slots(const s4p_ctx* ctx);
+int32_t s4p_stage_base(s4p_ctx* ctx, const float* base_xyz, const float* base_nrm, int32_t want_device_data, int32_t slot);
+int32_t s4p_try_base_staged_async(s4p_ctx* ctx, int32_t slot, const int32_t* base_ids, float invariant1, float invariant2);
+
 /* Snapshot / restore of the persistent pair-octree permutation (PairCreationFunctor::ids,
  * pairCreationFunctor.h:36): lets a speculative, pipelined driver roll the host state back to the
  * exact point where the sequential reference stopped. */

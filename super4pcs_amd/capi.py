@@ -18,7 +18,7 @@ ERR_NAMES = {0: "OK", -1: "BAD_ARG", -2: "NO_DEVICE", -3: "HIP", -4: "OOM", -5: 
 EXPORTED_SYMBOLS = [
     "s4p_create", "s4p_destroy", "s4p_last_error", "s4p_device_name", "s4p_set_clouds", "s4p_set_base",
     "s4p_extract_pairs", "s4p_find_congruent", "s4p_try_congruent_set", "s4p_verify_transforms",
-    "s4p_try_base", "s4p_try_base_async", "s4p_try_base_wait", "s4p_pair_state_words", "s4p_pair_state_save", "s4p_pair_state_restore", "s4p_skip_base", "s4p_last_candidates", "s4p_transform_points", "s4p_profile_enable", "s4p_profile_get",
+    "s4p_try_base", "s4p_try_base_async", "s4p_try_base_wait", "s4p_pair_state_words", "s4p_pair_state_save", "s4p_pair_state_restore", "s4p_stage_slots", "s4p_stage_base", "s4p_try_base_staged_async", "s4p_skip_base", "s4p_last_candidates", "s4p_transform_points", "s4p_profile_enable", "s4p_profile_get",
     "s4p_selftest_ieee",
 ]
 
@@ -276,7 +276,7 @@ class MatcherInfo(C.Structure):
 MATCHER_SYMBOLS = [
     "s4p_matcher_create", "s4p_matcher_destroy", "s4p_matcher_last_error", "s4p_matcher_ctx", "s4p_uniform_dist_sample",
     "s4p_matcher_init", "s4p_matcher_init_full", "s4p_matcher_get_info", "s4p_matcher_get_sampled",
-    "s4p_matcher_select_quadrilateral", "s4p_matcher_try_one_base", "s4p_matcher_next_base", "s4p_matcher_next_base_async", "s4p_matcher_wait_base", "s4p_matcher_commit", "s4p_matcher_perform_n_steps",
+    "s4p_matcher_select_quadrilateral", "s4p_matcher_try_one_base", "s4p_matcher_next_base", "s4p_matcher_next_base_async", "s4p_matcher_wait_base", "s4p_matcher_set_sharding", "s4p_matcher_commit", "s4p_matcher_perform_n_steps",
     "s4p_matcher_global_transform", "s4p_matcher_compute_transformation",
 ]
 VISITOR_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_float, C.c_float, C.POINTER(C.c_float))
@@ -311,6 +311,8 @@ def _declare_matcher(L):
     L.s4p_matcher_try_one_base.argtypes = [vp, ip, C.POINTER(BaseResult)]
     L.s4p_matcher_next_base.restype = C.c_int32
     L.s4p_matcher_next_base.argtypes = [vp, C.c_int32, ip, ip, C.POINTER(BaseResult)]
+    L.s4p_matcher_set_sharding.restype = C.c_int32
+    L.s4p_matcher_set_sharding.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32]
     L.s4p_matcher_next_base_async.restype = C.c_int32
     L.s4p_matcher_next_base_async.argtypes = [vp, C.c_int32, ip, ip]
     L.s4p_matcher_wait_base.restype = C.c_int32
@@ -428,6 +430,9 @@ class Matcher:
         found = C.c_int32(); base = np.empty(4, np.int32); r = BaseResult()
         self._chk(self.L.s4p_matcher_next_base(self.h, int(run_device), C.byref(found), _i(base), C.byref(r)))
         return bool(found.value), base, r
+
+    def set_sharding(self, rank=0, world=1, producer_threads=True):
+        self._chk(self.L.s4p_matcher_set_sharding(self.h, rank, world, int(producer_threads)))
 
     def next_base_async(self, run_device=True):
         found = C.c_int32(); base = np.empty(4, np.int32)

@@ -65,7 +65,17 @@ struct s4p_ctx {
   DevBuf<unsigned long long> ht_keys, ht_heads; uint32_t ht_mask = 0, epoch = 0;
   DevBuf<DevCounters> ctr; PinBuf<DevCounters> hctr[2];      // [pipeline slot]
   DevBuf<uint32_t> seq_id[2], seq_leaf[2]; DevBuf<float4> leaves[2];
-  PinBuf<uint32_t> hseq_id[2][2], hseq_leaf[2][2]; PinBuf<float4> hleaves[2][2];   // [slot][pair set]
+  // Staging ring: host-built octree sequences of the two pair sets of a base, in pinned memory.  A slot is
+  // written by whoever stages the base (the caller thread, or the engine's octree thread through s4p_stage_base)
+  // and read by the H2D copies of s4p_try_base_staged_async; the engine recycles a slot after that base's wait.
+  struct StageSlot {
+    PinBuf<uint32_t> seq_id[2], seq_leaf[2]; PinBuf<float4> leaves[2];
+    uint32_t n_seq[2] = {0, 0}, n_leaf[2] = {0, 0};
+    float eps_unit[2] = {0, 0}, n_radius[2] = {0, 0}, distance[2] = {0, 0}, normal_angle[2] = {0, 0};
+  };
+  static constexpr int kStageSlots = 8;
+  StageSlot stage[kStageSlots];
+  uint32_t stage_rr = 0;             // round-robin slot for the self-staging (single-thread) paths
   int cur = 0;                       // slot used by the call in progress
   uint32_t q_head = 0, q_tail = 0;   // async FIFO of s4p_try_base_async (depth 2)
   BaseFrame slot_bf[2];
@@ -109,32 +119,40 @@ int32_t check_overflow(s4p_ctx* c, uint32_t ov) {
   return S4P_ERR_CAPACITY;
 }
 
-// Host side of ExtractPairs (super4pcs.cc:193-217): functor state, octree loop 1, upload, launch.
-int32_t launch_pairs(s4p_ctx* c, int set, float pair_distance, float pair_normals_angle, float pair_distance_epsilon,
-                     int bp1, int bp2) {
+// Host side of ExtractPairs (super4pcs.cc:193-217), part 1: functor radius/epsilon, octree loop 1, flat sequence
+// into a pinned staging slot.  Host-only (touches c->tree and the slot): may run on the engine's octree thread.
+void stage_pairs(s4p_ctx* c, int slot, int set, float pair_distance, float pair_normals_angle, float pair_distance_epsilon, bool copy) {
+  s4p_ctx::StageSlot& st = c->stage[slot];
   const float nRadius = pair_distance / c->frame.ratio;                         // setRadius, pairCreationFunctor.h:124-129
   const float eps_n = pair_distance_epsilon / c->frame.ratio;                  // getNormalizedEpsilon, :131-133
   { auto t0 = std::chrono::steady_clock::now();
     c->tree.build(c->hux.data(), c->huy.data(), c->huz.data(), c->n_q, nRadius, eps_n, 50);
     c->host_octree_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
-  const uint32_t n_seq = uint32_t(c->tree.seq_id.size());
-  const uint32_t n_leaf = uint32_t(c->tree.leaves.size());
+  if (!copy) return;
+  st.n_seq[set] = uint32_t(c->tree.seq_id.size()); st.n_leaf[set] = uint32_t(c->tree.leaves.size());
+  st.eps_unit[set] = c->tree.eps_unit; st.n_radius[set] = nRadius; st.distance[set] = pair_distance; st.normal_angle[set] = pair_normals_angle;
+  std::memcpy(st.seq_id[set].p, c->tree.seq_id.data(), st.n_seq[set] * sizeof(uint32_t));
+  std::memcpy(st.seq_leaf[set].p, c->tree.seq_leaf.data(), st.n_seq[set] * sizeof(uint32_t));
+  std::memcpy(st.leaves[set].p, c->tree.leaves.data(), st.n_leaf[set] * sizeof(float4));
+}
+
+// part 2: upload the staged sequence and launch loop 2 + the pair filters (k_pairs).
+int32_t launch_pairs_staged(s4p_ctx* c, int slot, int set, float pair_distance_epsilon, int bp1, int bp2) {
+  const s4p_ctx::StageSlot& st = c->stage[slot];
+  const uint32_t n_seq = st.n_seq[set], n_leaf = st.n_leaf[set];
   DevBuf<int2>& ab = set == 0 ? c->ab1 : c->ab2;
   DevBuf<uint32_t>& okey = set == 0 ? c->okey1 : c->okey2;
   if (n_seq == 0) return S4P_OK;
-  std::memcpy(c->hseq_id[c->cur][set].p, c->tree.seq_id.data(), n_seq * sizeof(uint32_t));
-  std::memcpy(c->hseq_leaf[c->cur][set].p, c->tree.seq_leaf.data(), n_seq * sizeof(uint32_t));
-  std::memcpy(c->hleaves[c->cur][set].p, c->tree.leaves.data(), n_leaf * sizeof(float4));
-  HIPCHK(c, hipMemcpyAsync(c->seq_id[set].p, c->hseq_id[c->cur][set].p, n_seq * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->seq_leaf[set].p, c->hseq_leaf[c->cur][set].p, n_seq * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->leaves[set].p, c->hleaves[c->cur][set].p, n_leaf * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->seq_id[set].p, st.seq_id[set].p, n_seq * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->seq_leaf[set].p, st.seq_leaf[set].p, n_seq * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->leaves[set].p, st.leaves[set].p, n_leaf * sizeof(float4), hipMemcpyHostToDevice, c->stream));
   PairParams P{};
   P.ux = c->ux.p; P.uy = c->uy.p; P.uz = c->uz.p; P.qx = c->qx.p; P.qy = c->qy.p; P.qz = c->qz.p;
   P.nx = c->has_normals ? c->qnx.p : nullptr; P.ny = c->qny.p; P.nz = c->qnz.p;
   P.cr = c->has_rgb ? c->qcr.p : nullptr; P.cg = c->qcg.p; P.cb = c->qcb.p;
   P.seq_id = c->seq_id[set].p; P.seq_leaf = c->seq_leaf[set].p; P.n_seq = n_seq; P.leaves = c->leaves[set].p;
-  P.n_q = c->n_q; P.nRadius = nRadius; P.eps_unit = c->tree.eps_unit;
-  P.pair_distance = pair_distance; P.pair_distance_eps = pair_distance_epsilon; P.pair_normals_angle = pair_normals_angle;
+  P.n_q = c->n_q; P.nRadius = st.n_radius[set]; P.eps_unit = st.eps_unit[set];
+  P.pair_distance = st.distance[set]; P.pair_distance_eps = pair_distance_epsilon; P.pair_normals_angle = st.normal_angle[set];
   P.max_normal_difference = c->opt.max_normal_difference; P.max_color_distance = c->opt.max_color_distance;
   P.max_translation_distance = c->opt.max_translation_distance;
   P.norm_threshold = float(0.5 * double(c->opt.max_normal_difference) * M_PI / 180.0);   // pairCreationFunctor.h:169-170
@@ -147,6 +165,19 @@ int32_t launch_pairs(s4p_ctx* c, int set, float pair_distance, float pair_normal
   hipLaunchKernelGGL(k_pairs, dim3(c->n_q), dim3(256), 0, c->stream, P);
   HIPCHK(c, hipGetLastError());
   return S4P_OK;
+}
+
+int32_t launch_pairs(s4p_ctx* c, int set, float pair_distance, float pair_normals_angle, float pair_distance_epsilon,
+                     int bp1, int bp2) {
+  const int slot = int(c->stage_rr % uint32_t(s4p_ctx::kStageSlots));
+  stage_pairs(c, slot, set, pair_distance, pair_normals_angle, pair_distance_epsilon, true);
+  return launch_pairs_staged(c, slot, set, pair_distance_epsilon, bp1, bp2);
+}
+
+// segment lengths / normal "angles" of an ordered base (match4pcsBase.hpp:318-326)
+inline float seg_len(const float* v, int a, int b) {
+  const float d0 = v[3 * a] - v[3 * b], d1 = v[3 * a + 1] - v[3 * b + 1], d2 = v[3 * a + 2] - v[3 * b + 2];
+  return std::sqrt(d0 * d0 + (d1 * d1 + d2 * d2));
 }
 
 // IndexedNormalSet ctor (normalset.h:114-124) + getNeighbors constants (normalset.hpp:174-191)
@@ -372,7 +403,8 @@ void s4p_destroy(s4p_ctx* c) {
   c->bucket1.free(); c->next1.free(); c->mask2.free(); c->ew1.free(); c->ew2.free();
   c->quads.free(); c->tags.free(); c->counts.free(); c->cand_idx.free(); c->cand_T.free(); c->ht_keys.free(); c->ht_heads.free(); c->ctr.free(); c->hctr[0].free(); c->hctr[1].free();
   for (int s = 0; s < 2; ++s) { c->seq_id[s].free(); c->seq_leaf[s].free(); c->leaves[s].free();
-    for (int sl = 0; sl < 2; ++sl) { c->hseq_id[sl][s].free(); c->hseq_leaf[sl][s].free(); c->hleaves[sl][s].free(); } }
+  }
+  for (auto& st : c->stage) for (int s = 0; s < 2; ++s) { st.seq_id[s].free(); st.seq_leaf[s].free(); st.leaves[s].free(); }
   c->tbuf.free();
   for (auto& row : c->ev) for (auto& ev : row) if (ev) (void)hipEventDestroy(ev);
   for (auto& ev : c->done) if (ev) (void)hipEventDestroy(ev);
@@ -437,7 +469,7 @@ int32_t s4p_set_clouds(s4p_ctx* c, const float* px, const float* py, const float
   if (c->has_rgb) { HIPCHK(c, up(c->qcr, qr)); HIPCHK(c, up(c->qcg, qg)); HIPCHK(c, up(c->qcb, qb)); }
   for (int s = 0; s < 2; ++s) {
     HIPCHK(c, c->seq_id[s].alloc(n_q)); HIPCHK(c, c->seq_leaf[s].alloc(n_q)); HIPCHK(c, c->leaves[s].alloc(n_q));
-    for (int sl = 0; sl < 2; ++sl) { HIPCHK(c, c->hseq_id[sl][s].alloc(n_q)); HIPCHK(c, c->hseq_leaf[sl][s].alloc(n_q)); HIPCHK(c, c->hleaves[sl][s].alloc(n_q)); }
+    for (auto& st : c->stage) { HIPCHK(c, st.seq_id[s].alloc(n_q)); HIPCHK(c, st.seq_leaf[s].alloc(n_q)); HIPCHK(c, st.leaves[s].alloc(n_q)); }
   }
   c->clouds_set = true;
   return S4P_OK;
@@ -578,25 +610,33 @@ int32_t s4p_verify_transforms(s4p_ctx* c, const float* T, int64_t B, uint32_t* c
   return rc;
 }
 
-int32_t s4p_try_base_async(s4p_ctx* c, const int32_t* base_ids, float inv1, float inv2) {
+int32_t s4p_stage_slots(const s4p_ctx*) { return s4p_ctx::kStageSlots; }
+
+int32_t s4p_stage_base(s4p_ctx* c, const float* base_xyz, const float* base_nrm, int32_t want_device_data, int32_t slot) {
+  if (!c || !base_xyz) return S4P_ERR_BAD_ARG;
+  if (!c->clouds_set) S4P_FAIL(c, S4P_ERR_STATE, "s4p_set_clouds not called");
+  if (want_device_data && (slot < 0 || slot >= s4p_ctx::kStageSlots)) S4P_FAIL(c, S4P_ERR_BAD_ARG, "bad staging slot");
+  float zero[12] = {0};
+  const float* nrm = base_nrm ? base_nrm : zero;
+  const float eps = 2.0f * c->opt.delta;                                          // distance_factor * delta
+  stage_pairs(c, slot, 0, seg_len(base_xyz, 0, 1), seg_len(nrm, 0, 1), eps, want_device_data != 0);
+  stage_pairs(c, slot, 1, seg_len(base_xyz, 2, 3), seg_len(nrm, 2, 3), eps, want_device_data != 0);
+  return S4P_OK;
+}
+
+int32_t s4p_try_base_staged_async(s4p_ctx* c, int32_t slot, const int32_t* base_ids, float inv1, float inv2) {
   if (!c || !base_ids) return S4P_ERR_BAD_ARG;
   if (!c->clouds_set) S4P_FAIL(c, S4P_ERR_STATE, "s4p_set_clouds not called");
+  if (slot < 0 || slot >= s4p_ctx::kStageSlots) S4P_FAIL(c, S4P_ERR_BAD_ARG, "bad staging slot");
   for (int i = 0; i < 4; ++i) if (base_ids[i] < 0 || uint32_t(base_ids[i]) >= c->n_p) S4P_FAIL(c, S4P_ERR_BAD_ARG, "base id out of range");
   if (c->q_tail - c->q_head >= 2u) S4P_FAIL(c, S4P_ERR_STATE, "two asynchronous bases already in flight");
   HIPCHK(c, hipSetDevice(c->device));
   c->cur = int(c->q_tail & 1u);
   if (int32_t rc = reset_counters(c)) return rc;
-  // match4pcsBase.hpp:313-331: segment lengths / normal "angles" of the ordered base, two ExtractPairs
-  auto seg = [&](const float* v, int a, int b) {
-    const float d0 = v[3 * a] - v[3 * b], d1 = v[3 * a + 1] - v[3 * b + 1], d2 = v[3 * a + 2] - v[3 * b + 2];
-    return std::sqrt(d0 * d0 + (d1 * d1 + d2 * d2));
-  };
-  const float distance1 = seg(c->base_xyz, 0, 1), distance2 = seg(c->base_xyz, 2, 3);
-  const float normal_angle1 = seg(c->base_nrm, 0, 1), normal_angle2 = seg(c->base_nrm, 2, 3);
-  const float eps = 2.0f * c->opt.delta;                                          // distance_factor * delta
+  const float eps = 2.0f * c->opt.delta;
   if (c->prof_events) HIPCHK(c, hipEventRecord(c->ev[c->cur][2], c->stream));
-  if (int32_t rc = launch_pairs(c, 0, distance1, normal_angle1, eps, 0, 1)) return rc;
-  if (int32_t rc = launch_pairs(c, 1, distance2, normal_angle2, eps, 2, 3)) return rc;
+  if (int32_t rc = launch_pairs_staged(c, slot, 0, eps, 0, 1)) return rc;
+  if (int32_t rc = launch_pairs_staged(c, slot, 1, eps, 2, 3)) return rc;
   if (c->prof_events) HIPCHK(c, hipEventRecord(c->ev[c->cur][3], c->stream));
   if (int32_t rc = launch_quads(c, inv1, inv2, eps)) return rc;
   if (c->prof_events) HIPCHK(c, hipEventRecord(c->ev[c->cur][4], c->stream));
@@ -605,6 +645,16 @@ int32_t s4p_try_base_async(s4p_ctx* c, const int32_t* base_ids, float inv1, floa
   if (int32_t rc = enqueue_result(c, bf)) return rc;
   c->q_tail++;
   return S4P_OK;
+}
+
+int32_t s4p_try_base_async(s4p_ctx* c, const int32_t* base_ids, float inv1, float inv2) {
+  if (!c || !base_ids) return S4P_ERR_BAD_ARG;
+  if (!c->clouds_set) S4P_FAIL(c, S4P_ERR_STATE, "s4p_set_clouds not called");
+  if (c->q_tail - c->q_head >= 2u) S4P_FAIL(c, S4P_ERR_STATE, "two asynchronous bases already in flight");
+  // self-staging: a private round-robin slot (3 >= pipeline depth + 1 slots are always safe to rotate through)
+  const int slot = int(c->stage_rr++ % 3u);
+  if (int32_t rc = s4p_stage_base(c, c->base_xyz, c->base_nrm, 1, slot)) return rc;
+  return s4p_try_base_staged_async(c, slot, base_ids, inv1, inv2);
 }
 
 int32_t s4p_try_base_wait(s4p_ctx* c, s4p_base_result* result) {
@@ -637,15 +687,7 @@ int32_t s4p_pair_state_restore(s4p_ctx* c, const uint32_t* in) {
 
 int32_t s4p_skip_base(s4p_ctx* c) {
   if (!c) return S4P_ERR_BAD_ARG;
-  if (!c->clouds_set) S4P_FAIL(c, S4P_ERR_STATE, "s4p_set_clouds not called");
-  auto seg = [&](const float* v, int a, int b) {
-    const float d0 = v[3 * a] - v[3 * b], d1 = v[3 * a + 1] - v[3 * b + 1], d2 = v[3 * a + 2] - v[3 * b + 2];
-    return std::sqrt(d0 * d0 + (d1 * d1 + d2 * d2));
-  };
-  const float eps_n = (2.0f * c->opt.delta) / c->frame.ratio;
-  c->tree.build(c->hux.data(), c->huy.data(), c->huz.data(), c->n_q, seg(c->base_xyz, 0, 1) / c->frame.ratio, eps_n, 50);
-  c->tree.build(c->hux.data(), c->huy.data(), c->huz.data(), c->n_q, seg(c->base_xyz, 2, 3) / c->frame.ratio, eps_n, 50);
-  return S4P_OK;
+  return s4p_stage_base(c, c->base_xyz, c->base_nrm, 0, 0);
 }
 
 int32_t s4p_last_candidates(s4p_ctx* c, int32_t* quads, int32_t* counts, int64_t cap, int64_t* n_out) {

@@ -13,10 +13,14 @@
 #include <array>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstring>
+#include <deque>
 #include <limits>
+#include <mutex>
 #include <random>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -91,10 +95,38 @@ struct s4p_matcher {
   struct Prepared {
     bool found = false, device = false;
     int ids[4] = {0, 0, 0, 0};
+    int slot = -1;                         // staging slot to recycle after the wait (producer mode)
     std::mt19937 rng_before;               // host state before this trial was prepared (for exact roll-back)
     std::vector<uint32_t> pair_state_before;
   };
   std::vector<Prepared> inflight;          // FIFO
+
+  // ---- optional producer: base selection and octree staging on two helper threads ------------------------
+  // Both are inherently sequential (RNG stream; persistent octree permutation) but independent of results and of
+  // each other's resource, so they pipeline: selector -> qa -> octree/staging -> qb -> main thread (launch/commit).
+  struct Trial {
+    long index = 0;
+    bool found = false, owned = false, staged = false;
+    int ids[4] = {0, 0, 0, 0};
+    float inv1 = 0, inv2 = 0;
+    float bx[12], bn[12], bc[12];
+    int slot = -1;
+    std::mt19937 rng_before;
+    std::vector<uint32_t> pair_before;
+  };
+  struct Producer {
+    bool enabled = false, running = false, stop = false;
+    int rank = 0, world = 1;
+    long next_index = 0;                   // next trial the selector will draw
+    long consumed = 0;                     // trials handed to the main thread
+    std::thread sel, tree;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<Trial> qa, qb;
+    std::vector<int> free_slots;
+    size_t cap_a = 24, cap_b = 6;
+    double select_s = 0;
+  } prod;
 
   void set_identity() { for (int i = 0; i < 16; ++i) transform[i] = (i % 5 == 0) ? 1.f : 0.f; }
   V3 P(int i) const { return {Ps.x[i], Ps.y[i], Ps.z[i]}; }
@@ -257,11 +289,119 @@ void global_transform(const s4p_matcher* m, float* M) {
   M[12] = M[13] = M[14] = 0.f; M[15] = 1.f;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// producer threads
+void selector_main(s4p_matcher* m) {
+  auto& P = m->prod;
+  while (true) {
+    { std::unique_lock<std::mutex> lk(P.mu);
+      P.cv.wait(lk, [&] { return P.stop || P.qa.size() < P.cap_a; });
+      if (P.stop) return; }
+    s4p_matcher::Trial t;
+    t.rng_before = m->rng;
+    const auto t0 = std::chrono::steady_clock::now();
+    t.found = select_quadrilateral(m, t.inv1, t.inv2, t.ids);
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (t.found) fill_base_arrays(m, t.ids, t.bx, t.bn, t.bc);
+    { std::lock_guard<std::mutex> lk(P.mu);
+      t.index = P.next_index++;
+      t.owned = (t.index % P.world) == P.rank;
+      P.select_s += dt;
+      P.qa.push_back(std::move(t)); }     // pushed even when stopping: nothing that advanced the RNG is ever dropped
+    P.cv.notify_all();
+  }
+}
+
+void tree_main(s4p_matcher* m) {
+  auto& P = m->prod;
+  while (true) {
+    s4p_matcher::Trial t;
+    { std::unique_lock<std::mutex> lk(P.mu);
+      P.cv.wait(lk, [&] { return P.stop || !P.qa.empty(); });
+      if (P.stop) return;
+      t = std::move(P.qa.front()); P.qa.pop_front(); }
+    P.cv.notify_all();
+    if (t.found && t.owned) {
+      std::unique_lock<std::mutex> lk(P.mu);
+      P.cv.wait(lk, [&] { return P.stop || !P.free_slots.empty(); });
+      if (P.stop) { P.qa.push_front(std::move(t)); return; }     // untouched: goes back to the head of qa
+      t.slot = P.free_slots.back(); P.free_slots.pop_back();
+    }
+    t.pair_before.resize(size_t(s4p_pair_state_words(m->ctx)));
+    s4p_pair_state_save(m->ctx, t.pair_before.data());
+    if (t.found) (void)s4p_stage_base(m->ctx, t.bx, t.bn, t.owned ? 1 : 0, t.owned ? t.slot : 0);
+    t.staged = true;
+    { std::unique_lock<std::mutex> lk(P.mu);
+      P.cv.wait(lk, [&] { return P.stop || P.qb.size() < P.cap_b; });
+      P.qb.push_back(std::move(t)); }     // also when stopping: its octree effect is already applied
+    P.cv.notify_all();
+  }
+}
+
+void producer_start(s4p_matcher* m) {
+  auto& P = m->prod;
+  if (P.running) return;
+  P.stop = false;
+  P.free_slots.clear();
+  const int nslots = s4p_stage_slots(m->ctx);
+  for (int sl = 3; sl < nslots; ++sl) P.free_slots.push_back(sl);      // 0..2 belong to s4p_try_base_async
+  P.next_index = P.consumed;
+  P.sel = std::thread(selector_main, m);
+  P.tree = std::thread(tree_main, m);
+  P.running = true;
+}
+
+// Stops the helpers and rewinds RNG + octree permutation to just before the first trial the main thread has not
+// consumed, i.e. to where a sequential run would be.
+void producer_stop(s4p_matcher* m) {
+  auto& P = m->prod;
+  if (!P.running) return;
+  { std::lock_guard<std::mutex> lk(P.mu); P.stop = true; }
+  P.cv.notify_all();
+  P.sel.join(); P.tree.join();
+  P.running = false;
+  if (!P.qb.empty()) {
+    m->rng = P.qb.front().rng_before;
+    s4p_pair_state_restore(m->ctx, P.qb.front().pair_before.data());
+  } else if (!P.qa.empty()) {
+    m->rng = P.qa.front().rng_before;
+  }
+  P.qa.clear(); P.qb.clear();
+  m->seconds_select += P.select_s; P.select_s = 0;
+}
+
+bool producer_pop(s4p_matcher* m, s4p_matcher::Trial& t) {
+  auto& P = m->prod;
+  producer_start(m);
+  { std::unique_lock<std::mutex> lk(P.mu);
+    P.cv.wait(lk, [&] { return !P.qb.empty(); });
+    t = std::move(P.qb.front()); P.qb.pop_front();
+    P.consumed = t.index + 1; }
+  P.cv.notify_all();
+  return true;
+}
+
+void producer_release_slot(s4p_matcher* m, int slot) {
+  if (slot < 0) return;
+  { std::lock_guard<std::mutex> lk(m->prod.mu); m->prod.free_slots.push_back(slot); }
+  m->prod.cv.notify_all();
+}
+
 // first half of TryOneBase (match4pcsBase.hpp:281-351): base selection + device pass (or state advance only)
+int32_t next_base_async(s4p_matcher* m, bool run_device, bool snapshot, s4p_matcher::Prepared& pr);
+int32_t wait_base(s4p_matcher* m, const s4p_matcher::Prepared& pr, s4p_base_result& r);
+
 int32_t next_base(s4p_matcher* m, bool run_device, bool& found, int ids[4], s4p_base_result& r) {
   using clk = std::chrono::steady_clock;
   float inv1 = 0, inv2 = 0;
   std::memset(&r, 0, sizeof(r));
+  if (m->prod.enabled) {                 // same thing through the producer queues
+    s4p_matcher::Prepared pr;
+    if (int32_t rc = next_base_async(m, run_device, false, pr)) return rc;
+    found = pr.found;
+    for (int t = 0; t < 4; ++t) ids[t] = pr.ids[t];
+    return wait_base(m, pr, r);
+  }
   auto t0 = clk::now();
   found = select_quadrilateral(m, inv1, inv2, ids);
   m->seconds_select += std::chrono::duration<double>(clk::now() - t0).count();
@@ -285,6 +425,22 @@ int32_t next_base(s4p_matcher* m, bool run_device, bool& found, int ids[4], s4p_
 int32_t next_base_async(s4p_matcher* m, bool run_device, bool snapshot, s4p_matcher::Prepared& pr) {
   using clk = std::chrono::steady_clock;
   float inv1 = 0, inv2 = 0;
+  if (m->prod.enabled) {
+    s4p_matcher::Trial t;
+    producer_pop(m, t);
+    if (t.owned != run_device) return m->fail(S4P_ERR_STATE, "sharding mismatch: the producer and the caller disagree on who owns this trial");
+    pr.found = t.found; pr.device = false; pr.slot = -1;
+    for (int k = 0; k < 4; ++k) pr.ids[k] = t.ids[k];
+    pr.rng_before = t.rng_before; pr.pair_state_before = std::move(t.pair_before);
+    if (t.found && t.owned) {
+      const auto t0 = clk::now();
+      if (int32_t rc = s4p_set_base(m->ctx, t.bx, t.bn, t.bc)) return m->ctx_fail(rc);
+      if (int32_t rc = s4p_try_base_staged_async(m->ctx, t.slot, t.ids, t.inv1, t.inv2)) { producer_release_slot(m, t.slot); return m->ctx_fail(rc); }
+      m->seconds_device += std::chrono::duration<double>(clk::now() - t0).count();
+      pr.device = true; pr.slot = t.slot;
+    }
+    return S4P_OK;
+  }
   if (snapshot) {
     pr.rng_before = m->rng;
     pr.pair_state_before.resize(size_t(s4p_pair_state_words(m->ctx)));
@@ -314,7 +470,9 @@ int32_t wait_base(s4p_matcher* m, const s4p_matcher::Prepared& pr, s4p_base_resu
   std::memset(&r, 0, sizeof(r));
   if (!pr.device) return S4P_OK;
   const auto t0 = clk::now();
-  if (int32_t rc = s4p_try_base_wait(m->ctx, &r)) return m->ctx_fail(rc);
+  const int32_t wrc = s4p_try_base_wait(m->ctx, &r);
+  producer_release_slot(m, pr.slot);
+  if (wrc) return m->ctx_fail(wrc);
   m->seconds_device += std::chrono::duration<double>(clk::now() - t0).count();
   m->bases_tried++;
   m->pairs_total += r.n_pairs1 + r.n_pairs2; m->quads_total += r.n_quads; m->candidates_verified += r.n_verified;
@@ -367,6 +525,7 @@ int32_t s4p_matcher_create(const s4p_options* opt, const s4p_limits* lim, int32_
 
 void s4p_matcher_destroy(s4p_matcher* m) {
   if (!m) return;
+  producer_stop(m);
   s4p_destroy(m->ctx);
   delete m;
 }
@@ -382,6 +541,8 @@ int64_t s4p_uniform_dist_sample(const float* x, const float* y, const float* z, 
 int32_t s4p_matcher_init(s4p_matcher* m, const s4p_cloud_view* p, const s4p_cloud_view* q, int32_t q_needs_shuffle) {
   if (!m) return S4P_ERR_BAD_ARG;
   if (!view_ok(p) || !view_ok(q) || p->n == 0 || q->n == 0) return m->fail(S4P_ERR_BAD_ARG, "s4p_matcher_init: empty or null cloud");
+  producer_stop(m);
+  m->prod.consumed = 0; m->prod.next_index = 0;
   m->ready = false;
   Cloud& Ps = m->Ps; Cloud& Qs = m->Qs;
   Ps = Cloud(); Qs = Cloud();
@@ -513,6 +674,14 @@ int32_t s4p_matcher_next_base(s4p_matcher* m, int32_t run_device, int32_t* found
   return rc;
 }
 
+int32_t s4p_matcher_set_sharding(s4p_matcher* m, int32_t rank, int32_t world, int32_t producer_threads) {
+  if (!m || world < 1 || rank < 0 || rank >= world) return S4P_ERR_BAD_ARG;
+  producer_stop(m);
+  m->prod.rank = rank; m->prod.world = world; m->prod.enabled = producer_threads != 0;
+  m->prod.consumed = 0; m->prod.next_index = 0;
+  return S4P_OK;
+}
+
 int32_t s4p_matcher_next_base_async(s4p_matcher* m, int32_t run_device, int32_t* found, int32_t* base_ids) {
   if (!m || !found || !base_ids) return S4P_ERR_BAD_ARG;
   if (!m->ready) return m->fail(S4P_ERR_STATE, "matcher not initialised");
@@ -588,11 +757,13 @@ int32_t s4p_matcher_perform_n_steps(s4p_matcher* m, int32_t n, s4p_visitor_fn vi
     if (ok || i > m->number_of_trials || fraction >= 0.99 || m->best_lcp == 1.0) break;
   }
   // drain speculative work and put the host state back where the sequential loop stopped
-  if (!fifo.empty()) {
+  if (m->prod.enabled) producer_stop(m);           // rewinds to the first trial not handed to this thread ...
+  if (!fifo.empty()) {                             // ... and these were handed over but not committed
     m->rng = fifo.front().rng_before;
     std::vector<uint32_t> st = fifo.front().pair_state_before;
-    for (auto& pr : fifo) { s4p_base_result dummy; if (pr.device) (void)s4p_try_base_wait(m->ctx, &dummy); }
+    for (auto& pr : fifo) { s4p_base_result dummy; if (pr.device) { (void)s4p_try_base_wait(m->ctx, &dummy); producer_release_slot(m, pr.slot); } }
     if (!st.empty()) s4p_pair_state_restore(m->ctx, st.data());
+    if (m->prod.enabled) m->prod.consumed -= long(fifo.size());
     fifo.clear();
   }
   if (rc != S4P_OK) return rc;

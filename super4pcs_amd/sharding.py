@@ -47,11 +47,13 @@ class ShardedRansac:
 
     RECORD_FLOATS = 16 + 3 + 3 + 4 + 6   # T, c2, c1, quad, (m1, m2, K, C, count, has_best)
 
-    def __init__(self, matcher, rank=0, world=1, dist=None, device=None):
+    def __init__(self, matcher, rank=0, world=1, dist=None, device=None, producer_threads=True):
         self.m, self.rank, self.world, self.dist, self.device = matcher, rank, world, dist, device
         self.trials_done = 0
         self.local_candidates = 0
         self.terminated = False
+        if producer_threads and hasattr(matcher, "set_sharding"):
+            matcher.set_sharding(rank, world, True)     # base selection + octree staging on helper threads
 
     def _threshold_count(self):
         info = self.m.info()

@@ -168,3 +168,34 @@ def test_gpu_against_the_reference_sources_directly(s4p_lib_built):
         gi = gm.info()
         assert list(gi.base) == rb.tolist() and list(gi.congruent) == rc.tolist()
         assert np.array_equal(np.array(gi.transform, np.float32).reshape(4, 4), rT)
+
+
+@pytest.mark.parametrize("n_s", [200, 300])
+def test_producer_threads_do_not_change_the_result(oracle_mod, s4p_lib_built, n_s):
+    """Base selection + octree staging on helper threads (s4p_matcher_set_sharding): same registration, and the
+    speculative run-ahead is rewound exactly (a second Perform_N_steps continues like the sequential code)."""
+    from super4pcs_amd import capi
+    O = oracle_mod
+    delta, overlap = 0.01, 0.6
+    P, Q, _ = H.small_pair(30000, delta=delta, seed=23)
+    om = O.Matcher(O.make_options(delta, overlap, n_s), keep_trace=True)
+    om.init(P, Q)
+    gm = capi.Matcher(capi.make_options(delta, overlap, n_s))
+    gm.set_sharding(0, 1, True)
+    gm.init_full(P, Q)
+    # two chunks of trials: the producer is stopped and rewound between them
+    for chunk in (7, 9):
+        for _ in range(chunk):
+            om.try_one_base()
+        gm.perform_n_steps(chunk)
+        assert gm.info().best_lcp == om.stats().best_lcp
+        assert gm.info().candidates_verified == om.stats().n_verified
+    # and step-wise calls through the queues
+    for _ in range(5):
+        o_ok = om.try_one_base()
+        g_ok, r = gm.try_one_base()
+        assert g_ok == o_ok and gm.info().candidates_verified == om.stats().n_verified
+    T, lcp, base, cong, c1, c2 = om.best()
+    gi = gm.info()
+    assert list(gi.base) == base.tolist() and list(gi.congruent) == cong.tolist()
+    assert np.array_equal(np.array(gi.transform, np.float32).reshape(4, 4), T)
