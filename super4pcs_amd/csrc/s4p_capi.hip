@@ -39,7 +39,6 @@ uint32_t next_pow2(uint64_t v) { uint64_t p = 1; while (p < v) p <<= 1; return u
 
 struct s4p_ctx {
   int device = 0;
-  hipStream_t stream = nullptr;
   std::string err;
   s4p_options opt{};
   uint64_t max_pairs = 0, max_quads = 0, max_grid_cells = 0;
@@ -59,12 +58,20 @@ struct s4p_ctx {
   // device state
   DevBuf<uint2> greach; DevBuf<uint32_t> glist_start, gcoarse; DevBuf<float4> gnbr; DevBuf<float4> q4;
   DevBuf<float> qx, qy, qz, ux, uy, uz, qnx, qny, qnz, qcr, qcg, qcb;
-  // pair sets
-  DevBuf<int2> ab1, ab2; DevBuf<uint32_t> okey1, okey2, cell1, cell2, bucket1, next1, mask2; DevBuf<float4> ew1, ew2;
-  DevBuf<int4> quads; DevBuf<unsigned long long> tags; DevBuf<uint32_t> counts, cand_idx; DevBuf<float4> cand_T;
-  DevBuf<unsigned long long> ht_keys, ht_heads; uint32_t ht_mask = 0, epoch = 0;
-  DevBuf<DevCounters> ctr; PinBuf<DevCounters> hctr[2];      // [pipeline slot]
-  DevBuf<uint32_t> seq_id[2], seq_leaf[2]; DevBuf<float4> leaves[2];
+  // Two lanes = two HIP streams with private per-base device buffers.  Consecutive bases alternate lanes, so the
+  // small latency-bound kernels of base t+1 (pairs, hash build, quad enumeration) run concurrently with the
+  // LCP scoring of base t instead of leaving most of the 256 CUs idle between them.
+  struct Lane {
+    hipStream_t stream = nullptr;
+    DevBuf<int2> ab1, ab2; DevBuf<uint32_t> okey1, okey2, cell1, cell2, bucket1, next1, mask2; DevBuf<float4> ew1, ew2;
+    DevBuf<int4> quads; DevBuf<unsigned long long> tags; DevBuf<uint32_t> counts, cand_idx; DevBuf<float4> cand_T;
+    DevBuf<unsigned long long> ht_keys, ht_heads; uint32_t ht_mask = 0, epoch = 0;
+    DevBuf<DevCounters> ctr;
+    DevBuf<uint32_t> seq_id[2], seq_leaf[2]; DevBuf<float4> leaves[2];
+  };
+  Lane lane[2];
+  int n_lanes = 2;
+  PinBuf<DevCounters> hctr[2];      // [pipeline slot == lane]
   // Staging ring: host-built octree sequences of the two pair sets of a base, in pinned memory.  A slot is
   // written by whoever stages the base (the caller thread, or the engine's octree thread through s4p_stage_base)
   // and read by the H2D copies of s4p_try_base_staged_async; the engine recycles a slot after that base's wait.
@@ -140,17 +147,17 @@ void stage_pairs(s4p_ctx* c, int slot, int set, float pair_distance, float pair_
 int32_t launch_pairs_staged(s4p_ctx* c, int slot, int set, float pair_distance_epsilon, int bp1, int bp2) {
   const s4p_ctx::StageSlot& st = c->stage[slot];
   const uint32_t n_seq = st.n_seq[set], n_leaf = st.n_leaf[set];
-  DevBuf<int2>& ab = set == 0 ? c->ab1 : c->ab2;
-  DevBuf<uint32_t>& okey = set == 0 ? c->okey1 : c->okey2;
+  DevBuf<int2>& ab = set == 0 ? c->lane[c->cur].ab1 : c->lane[c->cur].ab2;
+  DevBuf<uint32_t>& okey = set == 0 ? c->lane[c->cur].okey1 : c->lane[c->cur].okey2;
   if (n_seq == 0) return S4P_OK;
-  HIPCHK(c, hipMemcpyAsync(c->seq_id[set].p, st.seq_id[set].p, n_seq * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->seq_leaf[set].p, st.seq_leaf[set].p, n_seq * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->leaves[set].p, st.leaves[set].p, n_leaf * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->lane[c->cur].seq_id[set].p, st.seq_id[set].p, n_seq * sizeof(uint32_t), hipMemcpyHostToDevice, c->lane[c->cur].stream));
+  HIPCHK(c, hipMemcpyAsync(c->lane[c->cur].seq_leaf[set].p, st.seq_leaf[set].p, n_seq * sizeof(uint32_t), hipMemcpyHostToDevice, c->lane[c->cur].stream));
+  HIPCHK(c, hipMemcpyAsync(c->lane[c->cur].leaves[set].p, st.leaves[set].p, n_leaf * sizeof(float4), hipMemcpyHostToDevice, c->lane[c->cur].stream));
   PairParams P{};
   P.ux = c->ux.p; P.uy = c->uy.p; P.uz = c->uz.p; P.qx = c->qx.p; P.qy = c->qy.p; P.qz = c->qz.p;
   P.nx = c->has_normals ? c->qnx.p : nullptr; P.ny = c->qny.p; P.nz = c->qnz.p;
   P.cr = c->has_rgb ? c->qcr.p : nullptr; P.cg = c->qcg.p; P.cb = c->qcb.p;
-  P.seq_id = c->seq_id[set].p; P.seq_leaf = c->seq_leaf[set].p; P.n_seq = n_seq; P.leaves = c->leaves[set].p;
+  P.seq_id = c->lane[c->cur].seq_id[set].p; P.seq_leaf = c->lane[c->cur].seq_leaf[set].p; P.n_seq = n_seq; P.leaves = c->lane[c->cur].leaves[set].p;
   P.n_q = c->n_q; P.nRadius = st.n_radius[set]; P.eps_unit = st.eps_unit[set];
   P.pair_distance = st.distance[set]; P.pair_distance_eps = pair_distance_epsilon; P.pair_normals_angle = st.normal_angle[set];
   P.max_normal_difference = c->opt.max_normal_difference; P.max_color_distance = c->opt.max_color_distance;
@@ -160,9 +167,9 @@ int32_t launch_pairs_staged(s4p_ctx* c, int slot, int set, float pair_distance_e
     P.b1pos[k] = c->base_xyz[3 * bp1 + k]; P.b2pos[k] = c->base_xyz[3 * bp2 + k];
     P.b1rgb[k] = c->base_rgb[3 * bp1 + k]; P.b2rgb[k] = c->base_rgb[3 * bp2 + k];
   }
-  P.ab = ab.p; P.okey = okey.p; P.counter = set == 0 ? &c->ctr.p->m1 : &c->ctr.p->m2;
-  P.cap = uint32_t(c->max_pairs); P.overflow = &c->ctr.p->overflow; P.overflow_bit = set == 0 ? 1u : 2u;
-  hipLaunchKernelGGL(k_pairs, dim3(c->n_q), dim3(256), 0, c->stream, P);
+  P.ab = ab.p; P.okey = okey.p; P.counter = set == 0 ? &c->lane[c->cur].ctr.p->m1 : &c->lane[c->cur].ctr.p->m2;
+  P.cap = uint32_t(c->max_pairs); P.overflow = &c->lane[c->cur].ctr.p->overflow; P.overflow_bit = set == 0 ? 1u : 2u;
+  hipLaunchKernelGGL(k_pairs, dim3(c->n_q), dim3(256), 0, c->lane[c->cur].stream, P);
   HIPCHK(c, hipGetLastError());
   return S4P_OK;
 }
@@ -213,31 +220,31 @@ int32_t launch_quads(s4p_ctx* c, float inv1, float inv2, float thr2) {
   QuadGrid qg; ConeTable cone;
   quad_setup(c, thr2, qg, cone);
   if (qg.egSize > 1024) S4P_FAIL(c, S4P_ERR_UNSUPPORTED, "FindCongruentQuadrilaterals grid finer than 1024^3 cells (delta/extent too small)");
-  c->epoch++;
-  if (c->epoch == 0xFFFFFFFFu) {   // wrap: clear the table once every 4e9 bases
-    HIPCHK(c, hipMemsetAsync(c->ht_keys.p, 0, c->ht_keys.n * 8, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->ht_heads.p, 0, c->ht_heads.n * 8, c->stream));
-    c->epoch = 1;
+  c->lane[c->cur].epoch++;
+  if (c->lane[c->cur].epoch == 0xFFFFFFFFu) {   // wrap: clear the table once every 4e9 bases
+    HIPCHK(c, hipMemsetAsync(c->lane[c->cur].ht_keys.p, 0, c->lane[c->cur].ht_keys.n * 8, c->lane[c->cur].stream));
+    HIPCHK(c, hipMemsetAsync(c->lane[c->cur].ht_heads.p, 0, c->lane[c->cur].ht_heads.n * 8, c->lane[c->cur].stream));
+    c->lane[c->cur].epoch = 1;
   }
-  HashTable ht{c->ht_keys.p, c->ht_heads.p, c->ht_mask, c->epoch};
+  HashTable ht{c->lane[c->cur].ht_keys.p, c->lane[c->cur].ht_heads.p, c->lane[c->cur].ht_mask, c->lane[c->cur].epoch};
   PrepParams P1{};
   P1.ux = c->ux.p; P1.uy = c->uy.p; P1.uz = c->uz.p; P1.qx = c->qx.p; P1.qy = c->qy.p; P1.qz = c->qz.p;
-  P1.ab = c->ab1.p; P1.m_dev = &c->ctr.p->m1; P1.cap = uint32_t(c->max_pairs); P1.invariant = inv1; P1.qg = qg;
-  P1.cell = c->cell1.p; P1.bucket = c->bucket1.p; P1.ew = c->ew1.p; P1.next = c->next1.p; P1.mask = nullptr; P1.ht = ht;
+  P1.ab = c->lane[c->cur].ab1.p; P1.m_dev = &c->lane[c->cur].ctr.p->m1; P1.cap = uint32_t(c->max_pairs); P1.invariant = inv1; P1.qg = qg;
+  P1.cell = c->lane[c->cur].cell1.p; P1.bucket = c->lane[c->cur].bucket1.p; P1.ew = c->lane[c->cur].ew1.p; P1.next = c->lane[c->cur].next1.p; P1.mask = nullptr; P1.ht = ht;
   P1.cone.nb = 0;
-  hipLaunchKernelGGL(k_prep1, dim3(1024), dim3(256), 0, c->stream, P1);
+  hipLaunchKernelGGL(k_prep1, dim3(1024), dim3(256), 0, c->lane[c->cur].stream, P1);
   PrepParams P2{};
   P2.ux = c->ux.p; P2.uy = c->uy.p; P2.uz = c->uz.p; P2.qx = c->qx.p; P2.qy = c->qy.p; P2.qz = c->qz.p;
-  P2.ab = c->ab2.p; P2.m_dev = &c->ctr.p->m2; P2.cap = uint32_t(c->max_pairs); P2.invariant = inv2; P2.qg = qg;
-  P2.cell = c->cell2.p; P2.bucket = nullptr; P2.ew = c->ew2.p; P2.next = nullptr; P2.mask = c->mask2.p; P2.ht = ht;
+  P2.ab = c->lane[c->cur].ab2.p; P2.m_dev = &c->lane[c->cur].ctr.p->m2; P2.cap = uint32_t(c->max_pairs); P2.invariant = inv2; P2.qg = qg;
+  P2.cell = c->lane[c->cur].cell2.p; P2.bucket = nullptr; P2.ew = c->lane[c->cur].ew2.p; P2.next = nullptr; P2.mask = c->lane[c->cur].mask2.p; P2.ht = ht;
   P2.cone = cone;
-  hipLaunchKernelGGL(k_prep2, dim3(1024), dim3(256), 0, c->stream, P2);
+  hipLaunchKernelGGL(k_prep2, dim3(1024), dim3(256), 0, c->lane[c->cur].stream, P2);
   QuadParams Q{};
-  Q.ab1 = c->ab1.p; Q.okey1 = c->okey1.p; Q.bucket1 = c->bucket1.p; Q.ew1 = c->ew1.p; Q.next1 = c->next1.p;
-  Q.ab2 = c->ab2.p; Q.okey2 = c->okey2.p; Q.cell2 = c->cell2.p; Q.ew2 = c->ew2.p; Q.mask2 = c->mask2.p;
-  Q.m2_dev = &c->ctr.p->m2; Q.cap2 = uint32_t(c->max_pairs); Q.ht = ht; Q.thr = thr2;
-  Q.quads = c->quads.p; Q.tags = c->tags.p; Q.K_dev = &c->ctr.p->K; Q.K_cap = uint32_t(c->max_quads); Q.overflow = &c->ctr.p->overflow;
-  hipLaunchKernelGGL(k_quads, dim3(2048), dim3(256), 0, c->stream, Q);
+  Q.ab1 = c->lane[c->cur].ab1.p; Q.okey1 = c->lane[c->cur].okey1.p; Q.bucket1 = c->lane[c->cur].bucket1.p; Q.ew1 = c->lane[c->cur].ew1.p; Q.next1 = c->lane[c->cur].next1.p;
+  Q.ab2 = c->lane[c->cur].ab2.p; Q.okey2 = c->lane[c->cur].okey2.p; Q.cell2 = c->lane[c->cur].cell2.p; Q.ew2 = c->lane[c->cur].ew2.p; Q.mask2 = c->lane[c->cur].mask2.p;
+  Q.m2_dev = &c->lane[c->cur].ctr.p->m2; Q.cap2 = uint32_t(c->max_pairs); Q.ht = ht; Q.thr = thr2;
+  Q.quads = c->lane[c->cur].quads.p; Q.tags = c->lane[c->cur].tags.p; Q.K_dev = &c->lane[c->cur].ctr.p->K; Q.K_cap = uint32_t(c->max_quads); Q.overflow = &c->lane[c->cur].ctr.p->overflow;
+  hipLaunchKernelGGL(k_quads, dim3(2048), dim3(256), 0, c->lane[c->cur].stream, Q);
   HIPCHK(c, hipGetLastError());
   return S4P_OK;
 }
@@ -253,20 +260,20 @@ BaseFrame make_base_frame(const s4p_ctx* c, const int32_t* base_ids) {
 int32_t launch_verify(s4p_ctx* c, const BaseFrame& bf) {
   VerifyParams V{};
   V.grid = c->dev_grid(); V.q4 = c->q4.p; V.n_q = c->n_q; V.base = bf;
-  V.quads = c->quads.p; V.tags = c->tags.p; V.counts = c->counts.p; V.K_dev = &c->ctr.p->K; V.K_cap = uint32_t(c->max_quads);
-  V.ctr = c->ctr.p; V.cand_idx = c->cand_idx.p; V.cand_T = c->cand_T.p;
+  V.quads = c->lane[c->cur].quads.p; V.tags = c->lane[c->cur].tags.p; V.counts = c->lane[c->cur].counts.p; V.K_dev = &c->lane[c->cur].ctr.p->K; V.K_cap = uint32_t(c->max_quads);
+  V.ctr = c->lane[c->cur].ctr.p; V.cand_idx = c->lane[c->cur].cand_idx.p; V.cand_T = c->lane[c->cur].cand_T.p;
   { const char* ab = getenv("S4P_ABLATE"); V.ablate = ab ? atoi(ab) : 0; }   // debugging aid, results are wrong when set
-  hipLaunchKernelGGL(k_gate, dim3(1024), dim3(256), 0, c->stream, V);
-  if (c->prof_events) HIPCHK(c, hipEventRecord(c->ev[c->cur][0], c->stream));
+  hipLaunchKernelGGL(k_gate, dim3(1024), dim3(256), 0, c->lane[c->cur].stream, V);
+  if (c->prof_events) HIPCHK(c, hipEventRecord(c->ev[c->cur][0], c->lane[c->cur].stream));
   const size_t lds = c->verify_lds_bytes();
-  if (c->prof_points) hipLaunchKernelGGL(k_verify<true>, dim3(c->verify_blocks), dim3(kVerifyThreads), lds, c->stream, V);
-  else hipLaunchKernelGGL(k_verify<false>, dim3(c->verify_blocks), dim3(kVerifyThreads), lds, c->stream, V);
-  if (c->prof_events) HIPCHK(c, hipEventRecord(c->ev[c->cur][1], c->stream));
+  if (c->prof_points) hipLaunchKernelGGL(k_verify<true>, dim3(c->verify_blocks), dim3(kVerifyThreads), lds, c->lane[c->cur].stream, V);
+  else hipLaunchKernelGGL(k_verify<false>, dim3(c->verify_blocks), dim3(kVerifyThreads), lds, c->lane[c->cur].stream, V);
+  if (c->prof_events) HIPCHK(c, hipEventRecord(c->ev[c->cur][1], c->lane[c->cur].stream));
   SelectParams S{};
-  S.tags = c->tags.p; S.counts = c->counts.p; S.quads = c->quads.p; S.K_dev = &c->ctr.p->K; S.K_cap = uint32_t(c->max_quads);
-  S.ctr = c->ctr.p; S.q4 = c->q4.p; S.base = bf;
-  hipLaunchKernelGGL(k_select, dim3(512), dim3(256), 0, c->stream, S);
-  hipLaunchKernelGGL(k_winner, dim3(512), dim3(256), 0, c->stream, S);
+  S.tags = c->lane[c->cur].tags.p; S.counts = c->lane[c->cur].counts.p; S.quads = c->lane[c->cur].quads.p; S.K_dev = &c->lane[c->cur].ctr.p->K; S.K_cap = uint32_t(c->max_quads);
+  S.ctr = c->lane[c->cur].ctr.p; S.q4 = c->q4.p; S.base = bf;
+  hipLaunchKernelGGL(k_select, dim3(512), dim3(256), 0, c->lane[c->cur].stream, S);
+  hipLaunchKernelGGL(k_winner, dim3(512), dim3(256), 0, c->lane[c->cur].stream, S);
   HIPCHK(c, hipGetLastError());
   return S4P_OK;
 }
@@ -274,8 +281,8 @@ int32_t launch_verify(s4p_ctx* c, const BaseFrame& bf) {
 // enqueue the result read-back of the base in slot c->cur and mark its completion
 int32_t enqueue_result(s4p_ctx* c, const BaseFrame& bf) {
   c->slot_bf[c->cur] = bf;
-  HIPCHK(c, hipMemcpyAsync(c->hctr[c->cur].p, c->ctr.p, sizeof(DevCounters), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipEventRecord(c->done[c->cur], c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->hctr[c->cur].p, c->lane[c->cur].ctr.p, sizeof(DevCounters), hipMemcpyDeviceToHost, c->lane[c->cur].stream));
+  HIPCHK(c, hipEventRecord(c->done[c->cur], c->lane[c->cur].stream));
   return S4P_OK;
 }
 
@@ -318,8 +325,8 @@ int32_t fetch_result(s4p_ctx* c, const BaseFrame& bf, s4p_base_result* r) {
 #define S4P_NEED_IDLE(c) do { if ((c)->q_head != (c)->q_tail) S4P_FAIL(c, S4P_ERR_STATE, "asynchronous bases outstanding: call s4p_try_base_wait first"); (c)->cur = 0; } while (0)
 
 int32_t reset_counters(s4p_ctx* c) {
-  hipLaunchKernelGGL(k_reset_counters, dim3(1), dim3(1), 0, c->stream, c->ctr.p);
-  if (c->prof_points) HIPCHK(c, hipMemsetAsync(&c->ctr.p->point_tests, 0, 24, c->stream));
+  hipLaunchKernelGGL(k_reset_counters, dim3(1), dim3(1), 0, c->lane[c->cur].stream, c->lane[c->cur].ctr.p);
+  if (c->prof_points) HIPCHK(c, hipMemsetAsync(&c->lane[c->cur].ctr.p->point_tests, 0, 24, c->lane[c->cur].stream));
   return S4P_OK;
 }
 
@@ -362,24 +369,27 @@ int32_t s4p_create(const s4p_options* opt, const s4p_limits* lim, int32_t device
   auto fail = [&](hipError_t e, const char* what) { g_create_error = std::string(what) + ": " + hipGetErrorString(e); s4p_destroy(c); return e == hipErrorOutOfMemory ? S4P_ERR_OOM : S4P_ERR_HIP; };
   hipError_t e;
   if ((e = hipSetDevice(device)) != hipSuccess) return fail(e, "hipSetDevice");
-  if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
   const size_t mp = c->max_pairs, mq = c->max_quads;
-#define A(buf, cnt) if ((e = (buf).alloc(cnt)) != hipSuccess) return fail(e, "hipMalloc " #buf)
-  A(c->ab1, mp); A(c->ab2, mp); A(c->okey1, mp); A(c->okey2, mp); A(c->cell1, mp); A(c->cell2, mp);
-  A(c->bucket1, mp); A(c->next1, mp); A(c->mask2, mp * kMaskWords); A(c->ew1, mp); A(c->ew2, mp);
-  A(c->quads, mq); A(c->tags, mq); A(c->counts, mq); A(c->cand_idx, mq); A(c->cand_T, mq * 3);
   const uint32_t hts = next_pow2(2 * mp);
-  A(c->ht_keys, hts); A(c->ht_heads, hts); c->ht_mask = hts - 1;
-  A(c->ctr, 1);
+#define A(buf, cnt) if ((e = (buf).alloc(cnt)) != hipSuccess) return fail(e, "hipMalloc " #buf)
+  for (int li = 0; li < c->n_lanes; ++li) {
+    s4p_ctx::Lane& L = c->lane[li];
+    if ((e = hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
+    A(L.ab1, mp); A(L.ab2, mp); A(L.okey1, mp); A(L.okey2, mp); A(L.cell1, mp); A(L.cell2, mp);
+    A(L.bucket1, mp); A(L.next1, mp); A(L.mask2, mp * kMaskWords); A(L.ew1, mp); A(L.ew2, mp);
+    A(L.quads, mq); A(L.tags, mq); A(L.counts, mq); A(L.cand_idx, mq); A(L.cand_T, mq * 3);
+    A(L.ht_keys, hts); A(L.ht_heads, hts); L.ht_mask = hts - 1;
+    A(L.ctr, 1);
+    if ((e = hipMemset(L.ht_keys.p, 0, size_t(hts) * 8)) != hipSuccess) return fail(e, "hipMemset");
+    if ((e = hipMemset(L.ht_heads.p, 0, size_t(hts) * 8)) != hipSuccess) return fail(e, "hipMemset");
+    if ((e = hipMemset(L.ctr.p, 0, sizeof(DevCounters))) != hipSuccess) return fail(e, "hipMemset");
+    L.epoch = 0;
+  }
 #undef A
   for (int sl = 0; sl < 2; ++sl) {
     if ((e = c->hctr[sl].alloc(1)) != hipSuccess) return fail(e, "hipHostMalloc");
     if ((e = hipEventCreateWithFlags(&c->done[sl], hipEventDisableTiming)) != hipSuccess) return fail(e, "hipEventCreate");
   }
-  if ((e = hipMemset(c->ht_keys.p, 0, size_t(hts) * 8)) != hipSuccess) return fail(e, "hipMemset");
-  if ((e = hipMemset(c->ht_heads.p, 0, size_t(hts) * 8)) != hipSuccess) return fail(e, "hipMemset");
-  if ((e = hipMemset(c->ctr.p, 0, sizeof(DevCounters))) != hipSuccess) return fail(e, "hipMemset");
-  c->epoch = 0;
   {  // allow the verify kernels their dynamic LDS (coarse bitmap + survivor queues)
     const int max_lds = int(kCoarseMaxWords * 4 + (kVerifyThreads / 64) * 3 * kQueueEntries * 4);
     if ((e = hipFuncSetAttribute((const void*)k_verify<false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds)) != hipSuccess) return fail(e, "hipFuncSetAttribute");
@@ -394,21 +404,23 @@ int32_t s4p_create(const s4p_options* opt, const s4p_limits* lim, int32_t device
 void s4p_destroy(s4p_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  for (auto& L : c->lane) if (L.stream) (void)hipStreamSynchronize(L.stream);
   c->greach.free(); c->glist_start.free(); c->gnbr.free();
   c->gcoarse.free(); c->q4.free();
   c->qx.free(); c->qy.free(); c->qz.free(); c->ux.free(); c->uy.free(); c->uz.free();
   c->qnx.free(); c->qny.free(); c->qnz.free(); c->qcr.free(); c->qcg.free(); c->qcb.free();
-  c->ab1.free(); c->ab2.free(); c->okey1.free(); c->okey2.free(); c->cell1.free(); c->cell2.free();
-  c->bucket1.free(); c->next1.free(); c->mask2.free(); c->ew1.free(); c->ew2.free();
-  c->quads.free(); c->tags.free(); c->counts.free(); c->cand_idx.free(); c->cand_T.free(); c->ht_keys.free(); c->ht_heads.free(); c->ctr.free(); c->hctr[0].free(); c->hctr[1].free();
-  for (int s = 0; s < 2; ++s) { c->seq_id[s].free(); c->seq_leaf[s].free(); c->leaves[s].free();
+  for (auto& L : c->lane) {
+    L.ab1.free(); L.ab2.free(); L.okey1.free(); L.okey2.free(); L.cell1.free(); L.cell2.free();
+    L.bucket1.free(); L.next1.free(); L.mask2.free(); L.ew1.free(); L.ew2.free();
+    L.quads.free(); L.tags.free(); L.counts.free(); L.cand_idx.free(); L.cand_T.free(); L.ht_keys.free(); L.ht_heads.free(); L.ctr.free();
+    for (int s = 0; s < 2; ++s) { L.seq_id[s].free(); L.seq_leaf[s].free(); L.leaves[s].free(); }
   }
+  c->hctr[0].free(); c->hctr[1].free();
   for (auto& st : c->stage) for (int s = 0; s < 2; ++s) { st.seq_id[s].free(); st.seq_leaf[s].free(); st.leaves[s].free(); }
   c->tbuf.free();
   for (auto& row : c->ev) for (auto& ev : row) if (ev) (void)hipEventDestroy(ev);
   for (auto& ev : c->done) if (ev) (void)hipEventDestroy(ev);
-  if (c->stream) (void)hipStreamDestroy(c->stream);
+  for (auto& L : c->lane) if (L.stream) (void)hipStreamDestroy(L.stream);
   delete c;
 }
 
@@ -468,7 +480,7 @@ int32_t s4p_set_clouds(s4p_ctx* c, const float* px, const float* py, const float
   if (c->has_normals) { HIPCHK(c, up(c->qnx, qnx)); HIPCHK(c, up(c->qny, qny)); HIPCHK(c, up(c->qnz, qnz)); }
   if (c->has_rgb) { HIPCHK(c, up(c->qcr, qr)); HIPCHK(c, up(c->qcg, qg)); HIPCHK(c, up(c->qcb, qb)); }
   for (int s = 0; s < 2; ++s) {
-    HIPCHK(c, c->seq_id[s].alloc(n_q)); HIPCHK(c, c->seq_leaf[s].alloc(n_q)); HIPCHK(c, c->leaves[s].alloc(n_q));
+    for (auto& L : c->lane) { HIPCHK(c, L.seq_id[s].alloc(n_q)); HIPCHK(c, L.seq_leaf[s].alloc(n_q)); HIPCHK(c, L.leaves[s].alloc(n_q)); }
     for (auto& st : c->stage) { HIPCHK(c, st.seq_id[s].alloc(n_q)); HIPCHK(c, st.seq_leaf[s].alloc(n_q)); HIPCHK(c, st.leaves[s].alloc(n_q)); }
   }
   c->clouds_set = true;
@@ -492,16 +504,16 @@ int32_t s4p_extract_pairs(s4p_ctx* c, float pair_distance, float pair_normals_an
   HIPCHK(c, hipSetDevice(c->device));
   if (int32_t rc = reset_counters(c)) return rc;
   if (int32_t rc = launch_pairs(c, 0, pair_distance, pair_normals_angle, pair_distance_epsilon, bp1, bp2)) return rc;
-  HIPCHK(c, hipMemcpyAsync(c->hctr[c->cur].p, c->ctr.p, sizeof(DevCounters), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->hctr[c->cur].p, c->lane[c->cur].ctr.p, sizeof(DevCounters), hipMemcpyDeviceToHost, c->lane[c->cur].stream));
+  HIPCHK(c, hipStreamSynchronize(c->lane[c->cur].stream));
   if (int32_t rc = check_overflow(c, c->hctr[c->cur].p->overflow)) return rc;
   const uint32_t m = c->hctr[c->cur].p->m1;
   *n_out = m;
   if (m == 0) return S4P_OK;
   if (!out_pairs || cap < int64_t(m)) S4P_FAIL(c, S4P_ERR_CAPACITY, "s4p_extract_pairs: output buffer too small");
   std::vector<int2> ab(m); std::vector<uint32_t> ok(m);
-  HIPCHK(c, hipMemcpy(ab.data(), c->ab1.p, size_t(m) * sizeof(int2), hipMemcpyDeviceToHost));
-  HIPCHK(c, hipMemcpy(ok.data(), c->okey1.p, size_t(m) * 4, hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(ab.data(), c->lane[c->cur].ab1.p, size_t(m) * sizeof(int2), hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(ok.data(), c->lane[c->cur].okey1.p, size_t(m) * 4, hipMemcpyDeviceToHost));
   std::vector<uint32_t> order(m);
   std::iota(order.begin(), order.end(), 0u);
   std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return ok[a] < ok[b]; });
@@ -525,23 +537,23 @@ int32_t s4p_find_congruent(s4p_ctx* c, float inv1, float inv2, float /*thr1*/, f
   if (int32_t rc = reset_counters(c)) return rc;
   std::vector<uint32_t> idx((size_t)std::max(m1, m2));
   std::iota(idx.begin(), idx.end(), 0u);
-  HIPCHK(c, hipMemcpyAsync(c->ab1.p, pairs1, size_t(m1) * 8, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->ab2.p, pairs2, size_t(m2) * 8, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->okey1.p, idx.data(), size_t(m1) * 4, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->okey2.p, idx.data(), size_t(m2) * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->lane[c->cur].ab1.p, pairs1, size_t(m1) * 8, hipMemcpyHostToDevice, c->lane[c->cur].stream));
+  HIPCHK(c, hipMemcpyAsync(c->lane[c->cur].ab2.p, pairs2, size_t(m2) * 8, hipMemcpyHostToDevice, c->lane[c->cur].stream));
+  HIPCHK(c, hipMemcpyAsync(c->lane[c->cur].okey1.p, idx.data(), size_t(m1) * 4, hipMemcpyHostToDevice, c->lane[c->cur].stream));
+  HIPCHK(c, hipMemcpyAsync(c->lane[c->cur].okey2.p, idx.data(), size_t(m2) * 4, hipMemcpyHostToDevice, c->lane[c->cur].stream));
   const uint32_t mm[2] = {uint32_t(m1), uint32_t(m2)};
-  HIPCHK(c, hipMemcpyAsync(&c->ctr.p->m1, mm, 8, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(&c->lane[c->cur].ctr.p->m1, mm, 8, hipMemcpyHostToDevice, c->lane[c->cur].stream));
   if (int32_t rc = launch_quads(c, inv1, inv2, thr2)) return rc;
-  HIPCHK(c, hipMemcpyAsync(c->hctr[c->cur].p, c->ctr.p, sizeof(DevCounters), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->hctr[c->cur].p, c->lane[c->cur].ctr.p, sizeof(DevCounters), hipMemcpyDeviceToHost, c->lane[c->cur].stream));
+  HIPCHK(c, hipStreamSynchronize(c->lane[c->cur].stream));
   if (int32_t rc = check_overflow(c, c->hctr[c->cur].p->overflow)) return rc;
   const uint32_t K = c->hctr[c->cur].p->K;
   *n_out = K;
   if (K == 0) return S4P_OK;
   if (!out_quads || cap < int64_t(K)) S4P_FAIL(c, S4P_ERR_CAPACITY, "s4p_find_congruent: output buffer too small");
   std::vector<int4> q(K); std::vector<unsigned long long> t(K);
-  HIPCHK(c, hipMemcpy(q.data(), c->quads.p, size_t(K) * 16, hipMemcpyDeviceToHost));
-  HIPCHK(c, hipMemcpy(t.data(), c->tags.p, size_t(K) * 8, hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(q.data(), c->lane[c->cur].quads.p, size_t(K) * 16, hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(t.data(), c->lane[c->cur].tags.p, size_t(K) * 8, hipMemcpyDeviceToHost));
   std::vector<uint32_t> order(K);
   std::iota(order.begin(), order.end(), 0u);
   std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return t[a] < t[b]; });   // std::set<(id,i)> order
@@ -567,16 +579,16 @@ int32_t s4p_try_congruent_set(s4p_ctx* c, const int32_t* base_ids, const int32_t
   std::vector<unsigned long long> tg((size_t)K);
   std::iota(tg.begin(), tg.end(), 0ull);
   if (K > 0) {
-    HIPCHK(c, hipMemcpyAsync(c->quads.p, quads, size_t(K) * 16, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->tags.p, tg.data(), size_t(K) * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->lane[c->cur].quads.p, quads, size_t(K) * 16, hipMemcpyHostToDevice, c->lane[c->cur].stream));
+    HIPCHK(c, hipMemcpyAsync(c->lane[c->cur].tags.p, tg.data(), size_t(K) * 8, hipMemcpyHostToDevice, c->lane[c->cur].stream));
   }
   const uint32_t k32 = uint32_t(K);
-  HIPCHK(c, hipMemcpyAsync(&c->ctr.p->K, &k32, 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(&c->lane[c->cur].ctr.p->K, &k32, 4, hipMemcpyHostToDevice, c->lane[c->cur].stream));
   if (int32_t rc = launch_verify(c, bf)) return rc;
   if (int32_t rc = fetch_result(c, bf, result)) return rc;
   if (per_candidate && K > 0) {
     std::vector<uint32_t> cnt((size_t)K);
-    HIPCHK(c, hipMemcpy(cnt.data(), c->counts.p, size_t(K) * 4, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(cnt.data(), c->lane[c->cur].counts.p, size_t(K) * 4, hipMemcpyDeviceToHost));
     for (int64_t i = 0; i < K; ++i) per_candidate[i] = cnt[i] == kGateFailed ? -1 : int32_t(cnt[i]);
   }
   return S4P_OK;
@@ -594,16 +606,16 @@ int32_t s4p_verify_transforms(s4p_ctx* c, const float* T, int64_t B, uint32_t* c
   if (e != hipSuccess) { dT.free(); HIPCHK(c, e); }
   int32_t rc = S4P_OK;
   do {
-    if ((e = hipMemcpyAsync(dT.p, T, size_t(B) * 64, hipMemcpyHostToDevice, c->stream)) != hipSuccess) break;
+    if ((e = hipMemcpyAsync(dT.p, T, size_t(B) * 64, hipMemcpyHostToDevice, c->lane[c->cur].stream)) != hipSuccess) break;
     VerifyTParams V{};
     V.grid = c->dev_grid(); V.q4 = c->q4.p; V.n_q = c->n_q; V.T = dT.p; V.B = uint32_t(B);
-    V.counts = dC.p; V.ctr = c->ctr.p;
+    V.counts = dC.p; V.ctr = c->lane[c->cur].ctr.p;
     const uint32_t wpb = kVerifyThreads / 64;
     const uint32_t blocks = uint32_t(std::min<int64_t>((B + wpb - 1) / wpb, 512));
-    hipLaunchKernelGGL(k_verify_T, dim3(blocks), dim3(kVerifyThreads), c->verify_lds_bytes(), c->stream, V);
+    hipLaunchKernelGGL(k_verify_T, dim3(blocks), dim3(kVerifyThreads), c->verify_lds_bytes(), c->lane[c->cur].stream, V);
     if ((e = hipGetLastError()) != hipSuccess) break;
-    if ((e = hipMemcpyAsync(counts, dC.p, size_t(B) * 4, hipMemcpyDeviceToHost, c->stream)) != hipSuccess) break;
-    e = hipStreamSynchronize(c->stream);
+    if ((e = hipMemcpyAsync(counts, dC.p, size_t(B) * 4, hipMemcpyDeviceToHost, c->lane[c->cur].stream)) != hipSuccess) break;
+    e = hipStreamSynchronize(c->lane[c->cur].stream);
   } while (0);
   dT.free(); dC.free();
   if (e != hipSuccess) { c->err = std::string("s4p_verify_transforms: ") + hipGetErrorString(e); rc = S4P_ERR_HIP; }
@@ -634,12 +646,12 @@ int32_t s4p_try_base_staged_async(s4p_ctx* c, int32_t slot, const int32_t* base_
   c->cur = int(c->q_tail & 1u);
   if (int32_t rc = reset_counters(c)) return rc;
   const float eps = 2.0f * c->opt.delta;
-  if (c->prof_events) HIPCHK(c, hipEventRecord(c->ev[c->cur][2], c->stream));
+  if (c->prof_events) HIPCHK(c, hipEventRecord(c->ev[c->cur][2], c->lane[c->cur].stream));
   if (int32_t rc = launch_pairs_staged(c, slot, 0, eps, 0, 1)) return rc;
   if (int32_t rc = launch_pairs_staged(c, slot, 1, eps, 2, 3)) return rc;
-  if (c->prof_events) HIPCHK(c, hipEventRecord(c->ev[c->cur][3], c->stream));
+  if (c->prof_events) HIPCHK(c, hipEventRecord(c->ev[c->cur][3], c->lane[c->cur].stream));
   if (int32_t rc = launch_quads(c, inv1, inv2, eps)) return rc;
-  if (c->prof_events) HIPCHK(c, hipEventRecord(c->ev[c->cur][4], c->stream));
+  if (c->prof_events) HIPCHK(c, hipEventRecord(c->ev[c->cur][4], c->lane[c->cur].stream));
   const BaseFrame bf = make_base_frame(c, base_ids);
   if (int32_t rc = launch_verify(c, bf)) return rc;
   if (int32_t rc = enqueue_result(c, bf)) return rc;
@@ -698,9 +710,9 @@ int32_t s4p_last_candidates(s4p_ctx* c, int32_t* quads, int32_t* counts, int64_t
   if (cap < int64_t(K) || !quads || !counts) S4P_FAIL(c, S4P_ERR_CAPACITY, "s4p_last_candidates: output buffer too small");
   HIPCHK(c, hipSetDevice(c->device));
   std::vector<int4> q(K); std::vector<unsigned long long> t(K); std::vector<uint32_t> cn(K);
-  HIPCHK(c, hipMemcpy(q.data(), c->quads.p, K * 16, hipMemcpyDeviceToHost));
-  HIPCHK(c, hipMemcpy(t.data(), c->tags.p, K * 8, hipMemcpyDeviceToHost));
-  HIPCHK(c, hipMemcpy(cn.data(), c->counts.p, K * 4, hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(q.data(), c->lane[c->cur].quads.p, K * 16, hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(t.data(), c->lane[c->cur].tags.p, K * 8, hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(cn.data(), c->lane[c->cur].counts.p, K * 4, hipMemcpyDeviceToHost));
   std::vector<uint32_t> order(K);
   std::iota(order.begin(), order.end(), 0u);
   std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return t[a] < t[b]; });
@@ -718,19 +730,19 @@ int32_t s4p_transform_points(s4p_ctx* c, const float* M, float* x, float* y, flo
   HIPCHK(c, hipSetDevice(c->device));
   if (c->tbuf_cap < size_t(n) * 3) { HIPCHK(c, c->tbuf.alloc(size_t(n) * 3)); c->tbuf_cap = size_t(n) * 3; }
   float* dx = c->tbuf.p; float* dy = dx + n; float* dz = dy + n;
-  HIPCHK(c, hipMemcpyAsync(dx, x, size_t(n) * 4, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(dy, y, size_t(n) * 4, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(dz, z, size_t(n) * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(dx, x, size_t(n) * 4, hipMemcpyHostToDevice, c->lane[c->cur].stream));
+  HIPCHK(c, hipMemcpyAsync(dy, y, size_t(n) * 4, hipMemcpyHostToDevice, c->lane[c->cur].stream));
+  HIPCHK(c, hipMemcpyAsync(dz, z, size_t(n) * 4, hipMemcpyHostToDevice, c->lane[c->cur].stream));
   ApplyParams A{};
   for (int i = 0; i < 12; ++i) A.M[i] = M[i];
   A.x = dx; A.y = dy; A.z = dz; A.n = uint64_t(n);
   const uint32_t blocks = uint32_t(std::min<uint64_t>((uint64_t(n) + 255) / 256, 4096));
-  hipLaunchKernelGGL(k_apply, dim3(blocks), dim3(256), 0, c->stream, A);
+  hipLaunchKernelGGL(k_apply, dim3(blocks), dim3(256), 0, c->lane[c->cur].stream, A);
   HIPCHK(c, hipGetLastError());
-  HIPCHK(c, hipMemcpyAsync(x, dx, size_t(n) * 4, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipMemcpyAsync(y, dy, size_t(n) * 4, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipMemcpyAsync(z, dz, size_t(n) * 4, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpyAsync(x, dx, size_t(n) * 4, hipMemcpyDeviceToHost, c->lane[c->cur].stream));
+  HIPCHK(c, hipMemcpyAsync(y, dy, size_t(n) * 4, hipMemcpyDeviceToHost, c->lane[c->cur].stream));
+  HIPCHK(c, hipMemcpyAsync(z, dz, size_t(n) * 4, hipMemcpyDeviceToHost, c->lane[c->cur].stream));
+  HIPCHK(c, hipStreamSynchronize(c->lane[c->cur].stream));
   return S4P_OK;
 }
 
@@ -757,8 +769,8 @@ int32_t s4p_selftest_ieee(s4p_ctx* c, const float* a, const float* b, int64_t n,
   do {
     if ((e = hipMemcpy(d.p, a, size_t(n) * 4, hipMemcpyHostToDevice)) != hipSuccess) break;
     if ((e = hipMemcpy(d.p + n, b, size_t(n) * 4, hipMemcpyHostToDevice)) != hipSuccess) break;
-    hipLaunchKernelGGL(k_selftest, dim3(256), dim3(256), 0, c->stream, d.p, d.p + n, uint64_t(n), d.p + 2 * n, d.p + 3 * n, d.p + 4 * n);
-    if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) break;
+    hipLaunchKernelGGL(k_selftest, dim3(256), dim3(256), 0, c->lane[c->cur].stream, d.p, d.p + n, uint64_t(n), d.p + 2 * n, d.p + 3 * n, d.p + 4 * n);
+    if ((e = hipStreamSynchronize(c->lane[c->cur].stream)) != hipSuccess) break;
     if ((e = hipMemcpy(o_sqrt, d.p + 2 * n, size_t(n) * 4, hipMemcpyDeviceToHost)) != hipSuccess) break;
     if ((e = hipMemcpy(o_div, d.p + 3 * n, size_t(n) * 4, hipMemcpyDeviceToHost)) != hipSuccess) break;
     e = hipMemcpy(o_ma, d.p + 4 * n, size_t(n) * 4, hipMemcpyDeviceToHost);
