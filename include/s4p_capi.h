@@ -134,7 +134,9 @@ int32_t s4p_try_base(s4p_ctx* ctx, const int32_t* base_ids, float invariant1, fl
 
 /* Pipelined form of s4p_try_base: _async enqueues the whole device pass of the base set by s4p_set_base
  * and returns at once (the host can select the next base and build its pair octree meanwhile); _wait
- * returns results in submission order.  At most two bases may be in flight. */
+ * returns results in submission order.  Up to s4p_pipeline_depth() bases may be in flight; each runs on its own HIP
+ * stream with private buffers, so the small kernels of one base overlap the LCP scoring of another. */
+int32_t s4p_pipeline_depth(const s4p_ctx* ctx);
 int32_t s4p_try_base_async(s4p_ctx* ctx, const int32_t* base_ids, float invariant1, float invariant2);
 int32_t s4p_try_base_wait(s4p_ctx* ctx, s4p_base_result* result);
 
@@ -145,7 +147,7 @@ int32_t s4p_try_base_wait(s4p_ctx* ctx, s4p_base_result* result);
  *                    thread than the one that owns the context, provided bases are staged in trial order.
  *   s4p_try_base_staged_async   uploads slot `slot` and enqueues the device pass (base set by s4p_set_base).
  * A slot may be re-staged once the s4p_try_base_wait of the base that used it has returned.
- * s4p_try_base_async itself uses slots 0..2 round-robin; a threaded driver should use slots 3 and up or only the staged form. */
+ * s4p_try_base_async itself uses slots 0..5 round-robin; a threaded driver uses slots 6 and up. */
 int32_t s4p_stage_slots(const s4p_ctx* ctx);
 int32_t s4p_stage_base(s4p_ctx* ctx, const float* base_xyz, const float* base_nrm, int32_t want_device_data, int32_t slot);
 int32_t s4p_try_base_staged_async(s4p_ctx* ctx, int32_t slot, const int32_t* base_ids, float invariant1, float invariant2);

@@ -18,7 +18,7 @@ ERR_NAMES = {0: "OK", -1: "BAD_ARG", -2: "NO_DEVICE", -3: "HIP", -4: "OOM", -5: 
 EXPORTED_SYMBOLS = [
     "s4p_create", "s4p_destroy", "s4p_last_error", "s4p_device_name", "s4p_set_clouds", "s4p_set_base",
     "s4p_extract_pairs", "s4p_find_congruent", "s4p_try_congruent_set", "s4p_verify_transforms",
-    "s4p_try_base", "s4p_try_base_async", "s4p_try_base_wait", "s4p_pair_state_words", "s4p_pair_state_save", "s4p_pair_state_restore", "s4p_stage_slots", "s4p_stage_base", "s4p_try_base_staged_async", "s4p_skip_base", "s4p_last_candidates", "s4p_transform_points", "s4p_profile_enable", "s4p_profile_get",
+    "s4p_try_base", "s4p_try_base_async", "s4p_try_base_wait", "s4p_pair_state_words", "s4p_pair_state_save", "s4p_pair_state_restore", "s4p_stage_slots", "s4p_pipeline_depth", "s4p_stage_base", "s4p_try_base_staged_async", "s4p_skip_base", "s4p_last_candidates", "s4p_transform_points", "s4p_profile_enable", "s4p_profile_get",
     "s4p_selftest_ieee",
 ]
 
@@ -430,6 +430,11 @@ class Matcher:
         found = C.c_int32(); base = np.empty(4, np.int32); r = BaseResult()
         self._chk(self.L.s4p_matcher_next_base(self.h, int(run_device), C.byref(found), _i(base), C.byref(r)))
         return bool(found.value), base, r
+
+    def pipeline_depth(self):
+        self.L.s4p_pipeline_depth.restype = C.c_int32
+        self.L.s4p_pipeline_depth.argtypes = [C.c_void_p]
+        return int(self.L.s4p_pipeline_depth(self.ctx_handle()))
 
     def set_sharding(self, rank=0, world=1, producer_threads=True):
         self._chk(self.L.s4p_matcher_set_sharding(self.h, rank, world, int(producer_threads)))

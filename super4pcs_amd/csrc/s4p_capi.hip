@@ -69,9 +69,10 @@ struct s4p_ctx {
     DevBuf<DevCounters> ctr;
     DevBuf<uint32_t> seq_id[2], seq_leaf[2]; DevBuf<float4> leaves[2];
   };
-  Lane lane[2];
-  int n_lanes = 2;
-  PinBuf<DevCounters> hctr[2];      // [pipeline slot == lane]
+  static constexpr int kMaxLanes = 4;
+  Lane lane[kMaxLanes];
+  int n_lanes = 3;                   // S4P_LANES (1..4): bases in flight
+  PinBuf<DevCounters> hctr[kMaxLanes];      // [pipeline slot == lane]
   // Staging ring: host-built octree sequences of the two pair sets of a base, in pinned memory.  A slot is
   // written by whoever stages the base (the caller thread, or the engine's octree thread through s4p_stage_base)
   // and read by the H2D copies of s4p_try_base_staged_async; the engine recycles a slot after that base's wait.
@@ -80,18 +81,18 @@ struct s4p_ctx {
     uint32_t n_seq[2] = {0, 0}, n_leaf[2] = {0, 0};
     float eps_unit[2] = {0, 0}, n_radius[2] = {0, 0}, distance[2] = {0, 0}, normal_angle[2] = {0, 0};
   };
-  static constexpr int kStageSlots = 8;
+  static constexpr int kStageSlots = 12;   // 0..5: self-staging of s4p_try_base_async; 6..11: a threaded driver
   StageSlot stage[kStageSlots];
   uint32_t stage_rr = 0;             // round-robin slot for the self-staging (single-thread) paths
   int cur = 0;                       // slot used by the call in progress
   uint32_t q_head = 0, q_tail = 0;   // async FIFO of s4p_try_base_async (depth 2)
-  BaseFrame slot_bf[2];
-  hipEvent_t done[2] = {nullptr, nullptr};
+  BaseFrame slot_bf[4];
+  hipEvent_t done[4] = {nullptr, nullptr, nullptr, nullptr};
   DevBuf<float> tbuf; size_t tbuf_cap = 0;
 
   // profiling
   bool prof_events = false, prof_points = false;
-  hipEvent_t ev[2][6] = {{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}};
+  hipEvent_t ev[4][6] = {};
   s4p_profile prof{};
   uint64_t last_K = 0;
   uint32_t verify_blocks = 512;
@@ -360,6 +361,7 @@ int32_t s4p_create(const s4p_options* opt, const s4p_limits* lim, int32_t device
   }
   s4p_ctx* c = new s4p_ctx();
   c->device = device; c->opt = *opt;
+  if (const char* ln = getenv("S4P_LANES")) { const int v = atoi(ln); if (v >= 1 && v <= s4p_ctx::kMaxLanes) c->n_lanes = v; }
   snprintf(c->devname, sizeof c->devname, "%s (%s)", prop.name, prop.gcnArchName);
   c->max_pairs = (lim && lim->max_pairs) ? lim->max_pairs : (4ull << 20);
   c->max_quads = (lim && lim->max_quads) ? lim->max_quads : (16ull << 20);
@@ -386,7 +388,7 @@ int32_t s4p_create(const s4p_options* opt, const s4p_limits* lim, int32_t device
     L.epoch = 0;
   }
 #undef A
-  for (int sl = 0; sl < 2; ++sl) {
+  for (int sl = 0; sl < s4p_ctx::kMaxLanes; ++sl) {
     if ((e = c->hctr[sl].alloc(1)) != hipSuccess) return fail(e, "hipHostMalloc");
     if ((e = hipEventCreateWithFlags(&c->done[sl], hipEventDisableTiming)) != hipSuccess) return fail(e, "hipEventCreate");
   }
@@ -415,7 +417,7 @@ void s4p_destroy(s4p_ctx* c) {
     L.quads.free(); L.tags.free(); L.counts.free(); L.cand_idx.free(); L.cand_T.free(); L.ht_keys.free(); L.ht_heads.free(); L.ctr.free();
     for (int s = 0; s < 2; ++s) { L.seq_id[s].free(); L.seq_leaf[s].free(); L.leaves[s].free(); }
   }
-  c->hctr[0].free(); c->hctr[1].free();
+  for (auto& h : c->hctr) h.free();
   for (auto& st : c->stage) for (int s = 0; s < 2; ++s) { st.seq_id[s].free(); st.seq_leaf[s].free(); st.leaves[s].free(); }
   c->tbuf.free();
   for (auto& row : c->ev) for (auto& ev : row) if (ev) (void)hipEventDestroy(ev);
@@ -623,6 +625,7 @@ int32_t s4p_verify_transforms(s4p_ctx* c, const float* T, int64_t B, uint32_t* c
 }
 
 int32_t s4p_stage_slots(const s4p_ctx*) { return s4p_ctx::kStageSlots; }
+int32_t s4p_pipeline_depth(const s4p_ctx* c) { return c ? c->n_lanes : 0; }
 
 int32_t s4p_stage_base(s4p_ctx* c, const float* base_xyz, const float* base_nrm, int32_t want_device_data, int32_t slot) {
   if (!c || !base_xyz) return S4P_ERR_BAD_ARG;
@@ -641,9 +644,9 @@ int32_t s4p_try_base_staged_async(s4p_ctx* c, int32_t slot, const int32_t* base_
   if (!c->clouds_set) S4P_FAIL(c, S4P_ERR_STATE, "s4p_set_clouds not called");
   if (slot < 0 || slot >= s4p_ctx::kStageSlots) S4P_FAIL(c, S4P_ERR_BAD_ARG, "bad staging slot");
   for (int i = 0; i < 4; ++i) if (base_ids[i] < 0 || uint32_t(base_ids[i]) >= c->n_p) S4P_FAIL(c, S4P_ERR_BAD_ARG, "base id out of range");
-  if (c->q_tail - c->q_head >= 2u) S4P_FAIL(c, S4P_ERR_STATE, "two asynchronous bases already in flight");
+  if (c->q_tail - c->q_head >= uint32_t(c->n_lanes)) S4P_FAIL(c, S4P_ERR_STATE, "all lanes busy: call s4p_try_base_wait first");
   HIPCHK(c, hipSetDevice(c->device));
-  c->cur = int(c->q_tail & 1u);
+  c->cur = int(c->q_tail % uint32_t(c->n_lanes));
   if (int32_t rc = reset_counters(c)) return rc;
   const float eps = 2.0f * c->opt.delta;
   if (c->prof_events) HIPCHK(c, hipEventRecord(c->ev[c->cur][2], c->lane[c->cur].stream));
@@ -662,9 +665,9 @@ int32_t s4p_try_base_staged_async(s4p_ctx* c, int32_t slot, const int32_t* base_
 int32_t s4p_try_base_async(s4p_ctx* c, const int32_t* base_ids, float inv1, float inv2) {
   if (!c || !base_ids) return S4P_ERR_BAD_ARG;
   if (!c->clouds_set) S4P_FAIL(c, S4P_ERR_STATE, "s4p_set_clouds not called");
-  if (c->q_tail - c->q_head >= 2u) S4P_FAIL(c, S4P_ERR_STATE, "two asynchronous bases already in flight");
-  // self-staging: a private round-robin slot (3 >= pipeline depth + 1 slots are always safe to rotate through)
-  const int slot = int(c->stage_rr++ % 3u);
+  if (c->q_tail - c->q_head >= uint32_t(c->n_lanes)) S4P_FAIL(c, S4P_ERR_STATE, "all lanes busy: call s4p_try_base_wait first");
+  // self-staging: a private round-robin slot (pipeline depth + 1 slots are always safe to rotate through)
+  const int slot = int(c->stage_rr++ % uint32_t(c->n_lanes + 1));
   if (int32_t rc = s4p_stage_base(c, c->base_xyz, c->base_nrm, 1, slot)) return rc;
   return s4p_try_base_staged_async(c, slot, base_ids, inv1, inv2);
 }
@@ -673,7 +676,7 @@ int32_t s4p_try_base_wait(s4p_ctx* c, s4p_base_result* result) {
   if (!c || !result) return S4P_ERR_BAD_ARG;
   if (c->q_head == c->q_tail) S4P_FAIL(c, S4P_ERR_STATE, "no asynchronous base in flight");
   HIPCHK(c, hipSetDevice(c->device));
-  c->cur = int(c->q_head & 1u);
+  c->cur = int(c->q_head % uint32_t(c->n_lanes));
   c->q_head++;
   return finish_result(c, result, true);
 }

@@ -124,7 +124,7 @@ struct s4p_matcher {
     std::condition_variable cv;
     std::deque<Trial> qa, qb;
     std::vector<int> free_slots;
-    size_t cap_a = 24, cap_b = 6;
+    size_t cap_a = 24, cap_b = 4;
     double select_s = 0;
   } prod;
 
@@ -344,7 +344,7 @@ void producer_start(s4p_matcher* m) {
   P.stop = false;
   P.free_slots.clear();
   const int nslots = s4p_stage_slots(m->ctx);
-  for (int sl = 3; sl < nslots; ++sl) P.free_slots.push_back(sl);      // 0..2 belong to s4p_try_base_async
+  for (int sl = 6; sl < nslots; ++sl) P.free_slots.push_back(sl);      // 0..5 belong to s4p_try_base_async
   P.next_index = P.consumed;
   P.sel = std::thread(selector_main, m);
   P.tree = std::thread(tree_main, m);
@@ -685,7 +685,7 @@ int32_t s4p_matcher_set_sharding(s4p_matcher* m, int32_t rank, int32_t world, in
 int32_t s4p_matcher_next_base_async(s4p_matcher* m, int32_t run_device, int32_t* found, int32_t* base_ids) {
   if (!m || !found || !base_ids) return S4P_ERR_BAD_ARG;
   if (!m->ready) return m->fail(S4P_ERR_STATE, "matcher not initialised");
-  if (m->inflight.size() >= 2) return m->fail(S4P_ERR_STATE, "two bases already in flight");
+  if (int(m->inflight.size()) >= s4p_pipeline_depth(m->ctx)) return m->fail(S4P_ERR_STATE, "all lanes busy: wait_base first");
   s4p_matcher::Prepared pr;
   const int32_t rc = next_base_async(m, run_device != 0, false, pr);
   if (rc != S4P_OK) return rc;
@@ -735,7 +735,7 @@ int32_t s4p_matcher_perform_n_steps(s4p_matcher* m, int32_t n, s4p_visitor_fn vi
   fifo.clear();
   int32_t rc = S4P_OK;
   for (int i = m->current_trial; i < end && rc == S4P_OK; ++i) {
-    while (fifo.size() < 2 && next_prep < end) {
+    while (int(fifo.size()) < s4p_pipeline_depth(m->ctx) && next_prep < end) {
       fifo.emplace_back();
       if ((rc = next_base_async(m, true, true, fifo.back())) != S4P_OK) break;
       ++next_prep;

@@ -84,14 +84,14 @@ class ShardedRansac:
             self.local_candidates += got
             return got
         total = 0
-        pending = None
+        pending = []
+        depth = getattr(self.m, "pipeline_depth", lambda: 2)()
         for _ in range(n):
-            cur = self._prepare_window()
-            if pending is not None:
-                total += self._finish_window(pending)
-            pending = cur
-        if pending is not None:
-            total += self._finish_window(pending)
+            pending.append(self._prepare_window())
+            while len(pending) >= depth:
+                total += self._finish_window(pending.pop(0))
+        while pending:
+            total += self._finish_window(pending.pop(0))
         return total
 
     def run_window(self):
