@@ -80,6 +80,7 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline sample (0 = skip)")
+    ap.add_argument("--no-time-to-register", dest="time_to_register", action="store_false", default=True)
     ap.add_argument("--points", type=int, default=N_POINTS)
     ap.add_argument("--sample", type=int, default=SAMPLE)
     args = ap.parse_args()
@@ -146,6 +147,30 @@ def main():
     kbar = pk.verify_point_tests / queries
     m.profile_enable(False, False)
 
+    # time-to-register (the metric's second half): one whole ComputeTransformation on the same pair, wall time from
+    # call to return with inputs in host memory (sampling of both 1 M-point clouds, grid build, upload, all trials,
+    # final apply).  Reported, never part of `value`.
+    ttr = None
+    if world == 1 and args.time_to_register:
+        m2 = capi.Matcher(opt, device=local_rank, max_pairs=8 << 20, max_quads=64 << 20)
+        m2.set_sharding(0, 1, True)
+        t_reg = time.perf_counter()
+        lcp2, M2, _ = m2.compute_transformation(P, Q)
+        t_reg = time.perf_counter() - t_reg
+        i2 = m2.info()
+        ttr = {"seconds": t_reg, "lcp": float(lcp2), "trials_run": int(i2.bases_tried), "candidates_verified": int(i2.candidates_verified)}
+        del m2
+
+    traffic, traffic_note = None, "no PMC summary found"
+    pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_k_verify.json")
+    if os.path.exists(pmc_file):
+        try:
+            pj = json.load(open(pmc_file))
+            traffic = pj["hbm_bytes_per_launch"]
+            traffic_note = pj["note"]
+        except Exception:
+            pass
+
     if rank == 0:
         bc = bytes_per_candidate(n_q, kbar)
         launches = max(prof.verify_launches, 1)
@@ -162,9 +187,10 @@ def main():
                                    % (args.points, DELTA, args.sample, n_p, n_q),
                        "n_P": n_p, "n_Q": n_q, "delta": DELTA, "overlap": OVERLAP, "seed": SEED,
                        "candidates_timed": cand_all, "point_queries_per_s": cand_all * n_q / dt_max,
-                       "parallelism": "bases sharded over %d GPU(s), one allreduce(max) per window" % world},
+                       "parallelism": "bases sharded over %d GPU(s), one allreduce(max) per window" % world,
+                       "time_to_register": ttr},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
                          "kernel": "k_verify", "avg_launch_ms": avg_ms, "launches": int(prof.verify_launches),
                          "candidates_per_launch": cand_per_launch, "algorithmic_bytes_per_candidate": bc, "kbar": kbar,
                          "note": "algorithmic bytes (SURVEY.md 8d, no cache credit, c=27 cells) / HIP-event launch time; "
