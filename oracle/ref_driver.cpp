@@ -114,6 +114,25 @@ void s4pr_init(void* hh, const float* P, uint64_t nP, const float* Q, uint64_t n
   Handle* h = static_cast<Handle*>(hh);
   h->m->do_init(cloud(P, nullptr, nullptr, nP), cloud(Q, nullptr, nullptr, nQ));
 }
+// with per-point normals / colours (nullable) -- exercises the pair filters of pairCreationFunctor.h:166-200
+void s4pr_init_attr(void* hh, const float* P, const float* Pn, const float* Pc, uint64_t nP,
+                    const float* Q, const float* Qn, const float* Qc, uint64_t nQ) {
+  Handle* h = static_cast<Handle*>(hh);
+  h->m->do_init(cloud(P, Pn, Pc, nP), cloud(Q, Qn, Qc, nQ));
+}
+float s4pr_compute_transformation_attr(void* hh, const float* P, const float* Pn, const float* Pc, uint64_t nP,
+                                       float* Q, const float* Qn, const float* Qc, uint64_t nQ, float* M_rowmajor, int64_t* n_candidates) {
+  Handle* h = static_cast<Handle*>(hh);
+  std::vector<Point3D> p = cloud(P, Pn, Pc, nP), q = cloud(Q, Qn, Qc, nQ);
+  Match4PCSBase::MatrixType M = Match4PCSBase::MatrixType::Identity();
+  h->lcps.clear();
+  CandidateVisitor v{&h->lcps};
+  const float r = h->m->ComputeTransformation(p, &q, M, Sampling::UniformDistSampler(), v);
+  for (int a = 0; a < 4; ++a) for (int c = 0; c < 4; ++c) M_rowmajor[4 * a + c] = M(a, c);
+  for (uint64_t i = 0; i < nQ; ++i) { Q[3 * i] = q[i].x(); Q[3 * i + 1] = q[i].y(); Q[3 * i + 2] = q[i].z(); }
+  *n_candidates = int64_t(h->lcps.size());
+  return r;
+}
 void s4pr_get_stats(void* hh, int32_t* trials, int32_t* nP, int32_t* nQ, float* best_lcp, float* p_diameter) {
   Handle* h = static_cast<Handle*>(hh);
   *trials = h->m->number_of_trials_; *nP = int32_t(h->m->sampled_P_3D_.size()); *nQ = int32_t(h->m->sampled_Q_3D_.size());

@@ -50,6 +50,9 @@ def lib():
         L.s4pr_get_best.argtypes = [C.c_void_p, fp, fp, ip, ip]
         L.s4pr_compute_transformation.restype = C.c_float
         L.s4pr_compute_transformation.argtypes = [C.c_void_p, fp, C.c_uint64, fp, C.c_uint64, fp, C.POINTER(C.c_int64)]
+        L.s4pr_init_attr.argtypes = [C.c_void_p, fp, fp, fp, C.c_uint64, fp, fp, fp, C.c_uint64]
+        L.s4pr_compute_transformation_attr.restype = C.c_float
+        L.s4pr_compute_transformation_attr.argtypes = [C.c_void_p, fp, fp, fp, C.c_uint64, fp, fp, fp, C.c_uint64, fp, C.POINTER(C.c_int64)]
         L.s4pr_bench.restype = C.c_int32
         L.s4pr_bench.argtypes = [C.c_void_p, fp, C.c_uint64, fp, C.c_uint64, C.c_double, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
         _LIB = L
@@ -80,9 +83,22 @@ class RefMatcher:
         except Exception:
             pass
 
-    def init(self, P, Q):
+    def init(self, P, Q, Pn=None, Pc=None, Qn=None, Qc=None):
         P = np.ascontiguousarray(P, np.float32); Q = np.ascontiguousarray(Q, np.float32)
-        self.L.s4pr_init(self.h, _f(P), P.shape[0], _f(Q), Q.shape[0])
+        if Pn is None and Pc is None and Qn is None and Qc is None:
+            self.L.s4pr_init(self.h, _f(P), P.shape[0], _f(Q), Q.shape[0])
+            return
+        a = [None if x is None else np.ascontiguousarray(x, np.float32) for x in (Pn, Pc, Qn, Qc)]
+        g = [None if x is None else _f(x) for x in a]
+        self.L.s4pr_init_attr(self.h, _f(P), g[0], g[1], P.shape[0], _f(Q), g[2], g[3], Q.shape[0])
+
+    def compute_transformation_attr(self, P, Q, Pn=None, Pc=None, Qn=None, Qc=None):
+        P = np.ascontiguousarray(P, np.float32); Q = np.ascontiguousarray(Q, np.float32).copy()
+        a = [None if x is None else np.ascontiguousarray(x, np.float32) for x in (Pn, Pc, Qn, Qc)]
+        g = [None if x is None else _f(x) for x in a]
+        M = np.empty(16, np.float32); n = C.c_int64()
+        lcp = self.L.s4pr_compute_transformation_attr(self.h, _f(P), g[0], g[1], P.shape[0], _f(Q), g[2], g[3], Q.shape[0], _f(M), C.byref(n))
+        return lcp, M.reshape(4, 4), Q, int(n.value)
 
     def stats(self):
         t = C.c_int32(); a = C.c_int32(); b = C.c_int32(); l = C.c_float(); d = C.c_float()

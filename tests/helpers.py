@@ -26,3 +26,21 @@ def random_rigid(rng, scale_t=0.2):
     T[:3, :3] = R
     T[:3, 3] = rng.uniform(-scale_t, scale_t, 3)
     return T
+
+
+def attributes_for(P, Q, T_gt, seed=0):
+    """Per-point normals (radial direction, rotated consistently for Q) and colours (smooth function of position in
+    P's frame) so that normal / colour filters are satisfiable by the true correspondences."""
+    rng = np.random.default_rng(seed)
+    R = np.asarray(T_gt, np.float64)[:3, :3]
+    t = np.asarray(T_gt, np.float64)[:3, 3]
+    Pn = P / np.linalg.norm(P, axis=1, keepdims=True)
+    Qp = Q.astype(np.float64) @ R.T + t                      # Q mapped into P's frame
+    Qn_p = Qp / np.linalg.norm(Qp, axis=1, keepdims=True)
+    Qn = Qn_p @ R                                            # back-rotate the normal into Q's frame
+    def col(X):
+        c = 0.5 + 0.5 * np.sin(6.0 * X[:, [0, 1, 2]] + np.array([0.3, 1.1, 2.0]))
+        return c
+    Pc = col(P.astype(np.float64)) + 0.01 * rng.normal(size=P.shape)
+    Qc = col(Qp) + 0.01 * rng.normal(size=Q.shape)
+    return Pn.astype(np.float32), np.clip(Pc, 0, 1).astype(np.float32), Qn.astype(np.float32), np.clip(Qc, 0, 1).astype(np.float32)

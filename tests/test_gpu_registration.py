@@ -199,3 +199,45 @@ def test_producer_threads_do_not_change_the_result(oracle_mod, s4p_lib_built, n_
     gi = gm.info()
     assert list(gi.base) == base.tolist() and list(gi.congruent) == cong.tolist()
     assert np.array_equal(np.array(gi.transform, np.float32).reshape(4, 4), T)
+
+
+@pytest.mark.parametrize("opts", [dict(max_normal_difference=20.0), dict(max_color_distance=0.3),
+                                  dict(max_translation_distance=0.25), dict(max_normal_difference=30.0, max_color_distance=0.5)])
+def test_attribute_filters_on_gpu_match_oracle(oracle_mod, s4p_lib_built, opts):
+    """-a / -c / max_translation_distance (pairCreationFunctor.h:166-200) evaluated in k_pairs: same pair counts,
+    same candidates, same registration as the CPU path (which is itself pinned to the reference sources)."""
+    from super4pcs_amd import capi
+    O = oracle_mod
+    delta, overlap, n_s = 0.01, 0.6, 200
+    P, Q, T_gt = H.small_pair(20000, delta=delta, seed=31)
+    Pn, Pc, Qn, Qc = H.attributes_for(P, Q, T_gt)
+    om = O.Matcher(O.make_options(delta, overlap, n_s, **opts))
+    o_lcp, o_M, o_Q = om.compute_transformation(P, Q, Pn, Pc, Qn, Qc)
+    gm = capi.Matcher(capi.make_options(delta, overlap, n_s, **opts))
+    g_lcp, g_M, g_Q = gm.compute_transformation(P, Q, Pn, Pc, Qn, Qc)
+    gi, os_ = gm.info(), om.stats()
+    assert gi.pairs_total == os_.n_pairs and gi.quads_total == os_.n_quads and gi.candidates_verified == os_.n_verified
+    assert g_lcp == o_lcp and np.array_equal(g_M, o_M) and np.max(np.abs(g_Q - o_Q)) <= 1e-4
+    # the filters really filter: fewer pairs than the unfiltered run
+    om0 = O.Matcher(O.make_options(delta, overlap, n_s))
+    om0.compute_transformation(P, Q)
+    assert os_.n_pairs < om0.stats().n_pairs
+
+
+def test_small_clouds_use_whole_cloud_without_shuffle(oracle_mod, s4p_lib_built):
+    """|P|,|Q| <= sample_size: no sampling, no shuffle (match4pcsBase.hpp:115-119,134-138) -- the reference's own
+    pair_extraction test runs in this regime (200/150 points)."""
+    from super4pcs_amd import capi, datasets
+    O = oracle_mod
+    P = datasets.sphere_cloud(200, 1)
+    Q = (datasets.sphere_cloud(150, 2) * np.float32(1.0)).astype(np.float32)
+    om = O.Matcher(O.make_options(0.1, 0.5, 200), keep_trace=True)
+    gm = capi.Matcher(capi.make_options(0.1, 0.5, 200))
+    om.init(P, Q)
+    gm.init_full(P, Q)
+    assert np.array_equal(gm.sampled(0), om.cloud(0)) and np.array_equal(gm.sampled(1), om.cloud(1))
+    for _ in range(6):
+        o_ok = om.try_one_base()
+        g_ok, r = gm.try_one_base()
+        assert g_ok == o_ok
+        assert gm.info().best_lcp == om.stats().best_lcp and gm.info().candidates_verified == om.stats().n_verified

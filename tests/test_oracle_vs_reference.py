@@ -119,3 +119,39 @@ def test_compute_transformation_matches_reference(oracle_mod, seed):
     rT, rl, rb, rc = rm.best()
     oT, ol, ob, oc, _, _ = om.best()
     assert np.array_equal(rT, oT) and np.array_equal(rb, ob) and np.array_equal(rc, oc)
+
+
+@pytest.mark.parametrize("opts", [dict(max_normal_difference=20.0), dict(max_color_distance=0.3),
+                                  dict(max_translation_distance=0.25), dict(max_normal_difference=30.0, max_color_distance=0.5)])
+def test_attribute_filters_match_reference(oracle_mod, opts):
+    """Pair filters on normals / colours / translation (pairCreationFunctor.h:166-200): stage-level and end to end."""
+    O = oracle_mod
+    delta, overlap, n_s = 0.01, 0.6, 200
+    P, Q, T_gt = H.small_pair(20000, delta=delta, seed=31)
+    Pn, Pc, Qn, Qc = H.attributes_for(P, Q, T_gt)
+    rm = reflib.RefMatcher(O.make_options(delta, overlap, n_s, **opts))
+    om = O.Matcher(O.make_options(delta, overlap, n_s, **opts), full_counts=True)
+    rm.init(P, Q, Pn, Pc, Qn, Qc)
+    om.init(P, Q, Pn, Pc, Qn, Qc)
+    eps = 2.0 * delta
+    seen = 0
+    for _ in range(6):
+        r, o = rm.select_quadrilateral(), om.select_quadrilateral()
+        assert r[0] == o[0] and np.array_equal(r[3], o[3])
+        if not r[0]:
+            continue
+        bx = r[4]
+        bn = om.get_base()[1]
+        d1 = float(np.float32(np.linalg.norm(bx[0] - bx[1]))); d2 = float(np.float32(np.linalg.norm(bx[2] - bx[3])))
+        na1 = float(np.float32(np.linalg.norm(bn[0] - bn[1]))); na2 = float(np.float32(np.linalg.norm(bn[2] - bn[3])))
+        for d, na, a, b in ((d1, na1, 0, 1), (d2, na2, 2, 3)):
+            rp, op = rm.extract_pairs(d, na, eps, a, b), om.extract_pairs(d, na, eps, a, b)
+            assert np.array_equal(rp, op)
+            seen += len(rp)
+    assert seen > 0
+    rm2 = reflib.RefMatcher(O.make_options(delta, overlap, n_s, **opts))
+    om2 = O.Matcher(O.make_options(delta, overlap, n_s, **opts))
+    r_lcp, r_M, r_Q, r_n = rm2.compute_transformation_attr(P, Q, Pn, Pc, Qn, Qc)
+    o_lcp, o_M, o_Q = om2.compute_transformation(P, Q, Pn, Pc, Qn, Qc)
+    assert r_lcp == o_lcp and r_n == om2.stats().n_verified
+    assert np.array_equal(r_M[:3, :3], o_M[:3, :3]) and np.max(np.abs(r_M - o_M)) <= 1e-6
