@@ -75,3 +75,52 @@ def sphere_cloud(n, seed):
     d = rng.uniform(-1, 1, size=(n, 3))
     d /= np.linalg.norm(d, axis=1, keepdims=True)
     return d.astype(np.float32)
+
+
+def lidar_pair(n_points, delta=0.05, seed=5, extent=60.0, n_boxes=120, n_cyl=30, yaw_deg=30.0, shift=10.0):
+    """Config-4 style pair: two simulated terrestrial scans of one scene (ground plane, axis-aligned
+    boxes, vertical cylinders) from poses `shift` metres apart and `yaw_deg` apart, ~1/r^2 density, range noise
+    sigma = delta.  Returns (P, Q, T_gt) with Q expressed in the second scanner's frame."""
+    rng = np.random.default_rng(seed)
+    boxes = np.concatenate([rng.uniform(-extent / 2, extent / 2, (n_boxes, 2)), rng.uniform(1.5, 6.0, (n_boxes, 3))], axis=1)
+    cyls = np.concatenate([rng.uniform(-extent / 2, extent / 2, (n_cyl, 2)), rng.uniform(0.2, 0.8, (n_cyl, 1)), rng.uniform(3, 10, (n_cyl, 1))], axis=1)
+
+    def surface_samples(n):
+        pts = []
+        ng = n // 2
+        r = extent / 2 * np.sqrt(rng.uniform(0, 1, ng)) ** 1.5          # denser near the centre
+        a = rng.uniform(0, 2 * np.pi, ng)
+        pts.append(np.stack([r * np.cos(a), r * np.sin(a), np.zeros(ng)], 1))
+        nb = n - ng
+        which = rng.integers(0, n_boxes + n_cyl, nb)
+        u, v, w = rng.uniform(-0.5, 0.5, nb), rng.uniform(-0.5, 0.5, nb), rng.uniform(0, 1, nb)
+        out = np.zeros((nb, 3))
+        isb = which < n_boxes
+        b = boxes[np.minimum(which, n_boxes - 1)]
+        face = rng.integers(0, 4, nb)
+        bx = np.where(face < 2, (face * 2 - 1) * 0.5 * b[:, 2], u * b[:, 2])
+        by = np.where(face < 2, v * b[:, 3], ((face - 2) * 2 - 1) * 0.5 * b[:, 3])
+        out[isb] = np.stack([b[:, 0] + bx, b[:, 1] + by, w * b[:, 4]], 1)[isb]
+        c = cyls[np.clip(which - n_boxes, 0, n_cyl - 1)]
+        th = 2 * np.pi * (u + 0.5)
+        out[~isb] = np.stack([c[:, 0] + c[:, 2] * np.cos(th), c[:, 1] + c[:, 2] * np.sin(th), w * c[:, 3]], 1)[~isb]
+        pts.append(out)
+        return np.concatenate(pts)
+
+    def scan(pose_xy, n):
+        S = surface_samples(int(n * 1.6))
+        d = np.linalg.norm(S - np.array([pose_xy[0], pose_xy[1], 1.8]), axis=1)
+        keep = rng.uniform(0, 1, len(S)) < np.clip((6.0 / np.maximum(d, 1.0)) ** 1.2, 0, 1)
+        S = S[keep][:n]
+        dirs = S - np.array([pose_xy[0], pose_xy[1], 1.8])
+        dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+        return S + dirs * rng.normal(scale=delta, size=(len(S), 1))
+
+    P = scan((-shift / 2, 0.0), n_points)
+    Qw = scan((shift / 2, 0.0), n_points)
+    yaw = np.deg2rad(yaw_deg)
+    R = np.array([[np.cos(yaw), -np.sin(yaw), 0], [np.sin(yaw), np.cos(yaw), 0], [0, 0, 1]])
+    t = np.array([shift, 0.0, 0.0])
+    Q = (Qw - t) @ R            # second scanner frame: q = R^T (w - t)
+    T = np.eye(4); T[:3, :3] = R; T[:3, 3] = t
+    return P.astype(np.float32), Q.astype(np.float32), T

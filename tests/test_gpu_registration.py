@@ -241,3 +241,22 @@ def test_small_clouds_use_whole_cloud_without_shuffle(oracle_mod, s4p_lib_built)
         g_ok, r = gm.try_one_base()
         assert g_ok == o_ok
         assert gm.info().best_lcp == om.stats().best_lcp and gm.info().candidates_verified == om.stats().n_verified
+
+
+def test_config1_hippo_pair_matches_reference_run(s4p_lib_built):
+    """BASELINE.json configs[0]: hippo1 <-> hippo2, -o 0.7 -d 0.01 -n 200 (scripts/run-example.sh:68).  The fixture
+    holds the sampler outputs and the result of the reference's own ComputeTransformation (oracle/_ref)."""
+    import os
+    from super4pcs_amd import capi
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "hippo_config1.npz"))
+    assert g["Ps"].shape[0] == 5281                       # doc/Usage.md:80
+    m = capi.Matcher(capi.make_options(0.01, 0.7, 200))
+    m.init_sampled(g["Ps"], g["Qu"], q_needs_shuffle=True)
+    i = m.info()
+    assert (i.n_sampled_p, i.n_sampled_q, i.number_of_trials) == (5281, 200, int(g["n_trials"])) == (5281, 200, 139)
+    M, improved, done = m.perform_n_steps(i.number_of_trials)
+    i = m.info()
+    assert i.best_lcp == np.float32(g["lcp"]) and i.candidates_verified == int(g["n_candidates"])
+    assert list(i.base) == g["base"].tolist() and list(i.congruent) == g["congruent"].tolist()
+    assert np.array_equal(np.array(i.transform, np.float32).reshape(4, 4), g["transform"])
+    assert np.array_equal(M[:3, :3], g["M"][:3, :3]) and np.max(np.abs(M - g["M"])) <= 1e-4

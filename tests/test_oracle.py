@@ -143,3 +143,16 @@ def test_empty_and_tiny_inputs(oracle_mod):
     m = oracle_mod.Matcher(oracle_mod.make_options(0.1, 0.5, 200))
     lcp, M, Q = m.compute_transformation(X, X.copy())
     assert lcp == 1.0 and np.array_equal(Q, X)
+
+
+def test_config1_hippo_fixture_is_what_the_oracle_computes(oracle_mod):
+    """The committed config-1 fixture (made from the reference's own run) against the oracle, from the fixture's
+    sampled clouds alone: init (shuffle, centring, trials) + all trials."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "hippo_config1.npz"))
+    # a cloud that is already one point per voxel passes through the sampler unchanged
+    assert np.array_equal(oracle_mod.sample(g["Ps"], 0.01), g["Ps"]) and np.array_equal(oracle_mod.sample(g["Qu"], 0.01), g["Qu"])
+    m = oracle_mod.Matcher(oracle_mod.make_options(0.01, 0.7, 200))
+    lcp, M, Q = m.compute_transformation(g["Ps"], g["Qu"])
+    assert lcp == np.float32(g["lcp"]) and m.stats().n_verified == int(g["n_candidates"])
+    T, l2, base, cong, _, _ = m.best()
+    assert np.array_equal(T, g["transform"]) and np.array_equal(base, g["base"]) and np.array_equal(cong, g["congruent"])
