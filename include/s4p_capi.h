@@ -169,6 +169,11 @@ int32_t s4p_skip_base(s4p_ctx* ctx);
  * quads (4 ints), counts (-1 = gate failed); returns K via n_out. */
 int32_t s4p_last_candidates(s4p_ctx* ctx, int32_t* quads, int32_t* counts, int64_t cap, int64_t* n_out);
 
+/* For visitors that want every verified candidate (the reference calls v(-1, lcp, T) per candidate,
+ * match4pcsBase.hpp:458-465): inlier counts and row-major 4x4 transforms (centred frame) of the candidates verified
+ * by the base whose s4p_try_base_wait returned last, in reference order.  Valid until that lane is reused. */
+int32_t s4p_last_verified(s4p_ctx* ctx, uint32_t* counts, float* transforms16, int64_t cap, int64_t* n_out);
+
 /* ---- final apply: Match4PCSBase::Perform_N_steps tail (match4pcsBase.hpp:265-267) */
 /* xyz SoA in place: p <- (M * [p;1]).head<3>() for n points. */
 int32_t s4p_transform_points(s4p_ctx* ctx, const float* M, float* x, float* y, float* z, int64_t n);

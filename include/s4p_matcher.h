@@ -110,6 +110,12 @@ int32_t s4p_matcher_perform_n_steps(s4p_matcher* m, int32_t n, s4p_visitor_fn vi
                                     int32_t visitor_needs_global, float* transformation,
                                     int32_t* improved, int32_t* done);
 
+/* Per-candidate visitor calls: with enable != 0, s4p_matcher_perform_n_steps also calls visitor(user, -1, lcp, T) for
+ * every verified candidate of every trial, in the reference's order (match4pcsBase.hpp:458-465).  lcp is the full
+ * inlier fraction (the reference's Verify may have stopped early against its running best, so its value can be
+ * lower for candidates that cannot win).  Costs a device read-back per trial; off by default. */
+int32_t s4p_matcher_visit_candidates(s4p_matcher* m, int32_t enable);
+
 /* getGlobalTransform (match4pcsBase.hpp:224-229). */
 int32_t s4p_matcher_global_transform(s4p_matcher* m, float* transformation);
 

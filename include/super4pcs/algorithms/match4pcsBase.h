@@ -8,6 +8,7 @@
 
 #include <array>
 #include <stdexcept>
+#include <type_traits>
 #include <string>
 #include <utility>
 #include <vector>
@@ -113,6 +114,8 @@ class Match4PCSBase {
     to_rowmajor(transformation, M);
     VisitorThunk<Visitor> thunk{&v};
     int32_t improved = 0, done = 0;
+    // the reference also calls v(-1, lcp, T) once per verified candidate (:458-465); only pay for it when someone listens
+    check(s4p_matcher_visit_candidates(engine_, std::is_same<Visitor, DummyTransformVisitor>::value ? 0 : 1));
     check(s4p_matcher_perform_n_steps(engine_, n, &VisitorThunk<Visitor>::call, &thunk, v.needsGlobalTransformation() ? 1 : 0,
                                       M, &improved, &done));
     from_rowmajor(M, transformation);

@@ -18,7 +18,7 @@ ERR_NAMES = {0: "OK", -1: "BAD_ARG", -2: "NO_DEVICE", -3: "HIP", -4: "OOM", -5: 
 EXPORTED_SYMBOLS = [
     "s4p_create", "s4p_destroy", "s4p_last_error", "s4p_device_name", "s4p_set_clouds", "s4p_set_base",
     "s4p_extract_pairs", "s4p_find_congruent", "s4p_try_congruent_set", "s4p_verify_transforms",
-    "s4p_try_base", "s4p_try_base_async", "s4p_try_base_wait", "s4p_pair_state_words", "s4p_pair_state_save", "s4p_pair_state_restore", "s4p_stage_slots", "s4p_pipeline_depth", "s4p_stage_base", "s4p_try_base_staged_async", "s4p_skip_base", "s4p_last_candidates", "s4p_transform_points", "s4p_profile_enable", "s4p_profile_get",
+    "s4p_try_base", "s4p_last_verified", "s4p_try_base_async", "s4p_try_base_wait", "s4p_pair_state_words", "s4p_pair_state_save", "s4p_pair_state_restore", "s4p_stage_slots", "s4p_pipeline_depth", "s4p_stage_base", "s4p_try_base_staged_async", "s4p_skip_base", "s4p_last_candidates", "s4p_transform_points", "s4p_profile_enable", "s4p_profile_get",
     "s4p_selftest_ieee",
 ]
 
@@ -276,7 +276,7 @@ class MatcherInfo(C.Structure):
 MATCHER_SYMBOLS = [
     "s4p_matcher_create", "s4p_matcher_destroy", "s4p_matcher_last_error", "s4p_matcher_ctx", "s4p_uniform_dist_sample",
     "s4p_matcher_init", "s4p_matcher_init_full", "s4p_matcher_get_info", "s4p_matcher_get_sampled",
-    "s4p_matcher_select_quadrilateral", "s4p_matcher_try_one_base", "s4p_matcher_next_base", "s4p_matcher_next_base_async", "s4p_matcher_wait_base", "s4p_matcher_set_sharding", "s4p_matcher_commit", "s4p_matcher_perform_n_steps",
+    "s4p_matcher_select_quadrilateral", "s4p_matcher_try_one_base", "s4p_matcher_next_base", "s4p_matcher_next_base_async", "s4p_matcher_wait_base", "s4p_matcher_set_sharding", "s4p_matcher_visit_candidates", "s4p_matcher_commit", "s4p_matcher_perform_n_steps",
     "s4p_matcher_global_transform", "s4p_matcher_compute_transformation",
 ]
 VISITOR_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_float, C.c_float, C.POINTER(C.c_float))
@@ -436,6 +436,11 @@ class Matcher:
         self.L.s4p_pipeline_depth.argtypes = [C.c_void_p]
         return int(self.L.s4p_pipeline_depth(self.ctx_handle()))
 
+    def visit_candidates(self, enable=True):
+        self.L.s4p_matcher_visit_candidates.restype = C.c_int32
+        self.L.s4p_matcher_visit_candidates.argtypes = [C.c_void_p, C.c_int32]
+        self._chk(self.L.s4p_matcher_visit_candidates(self.h, int(enable)))
+
     def set_sharding(self, rank=0, world=1, producer_threads=True):
         self._chk(self.L.s4p_matcher_set_sharding(self.h, rank, world, int(producer_threads)))
 
@@ -462,7 +467,7 @@ class Matcher:
             cb = C.cast(None, VISITOR_FN)
         else:
             def tramp(user, fraction, lcp, Tp):
-                visitor(fraction, lcp, np.ctypeslib.as_array(Tp, shape=(16,)).reshape(4, 4))
+                visitor(fraction, lcp, np.ctypeslib.as_array(Tp, shape=(16,)).reshape(4, 4).copy())
             cb = VISITOR_FN(tramp)
         self._chk(self.L.s4p_matcher_perform_n_steps(self.h, n, cb, None, int(needs_global), _f(M), C.byref(imp), C.byref(done)))
         return M.reshape(4, 4), bool(imp.value), bool(done.value)

@@ -727,6 +727,36 @@ int32_t s4p_last_candidates(s4p_ctx* c, int32_t* quads, int32_t* counts, int64_t
   return S4P_OK;
 }
 
+// Verified candidates of the base whose s4p_try_base_wait returned last, in reference candidate order:
+// inlier count and the 3x4 transform each was scored with (cand_T, kept in HBM by k_gate).
+int32_t s4p_last_verified(s4p_ctx* c, uint32_t* counts, float* transforms16, int64_t cap, int64_t* n_out) {
+  if (!c || !n_out) return S4P_ERR_BAD_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  const s4p_ctx::Lane& L = c->lane[c->cur];
+  const uint32_t C = c->hctr[c->cur].p->C;
+  *n_out = int64_t(C);
+  if (C == 0) return S4P_OK;
+  if (cap < int64_t(C) || !counts || !transforms16) S4P_FAIL(c, S4P_ERR_CAPACITY, "s4p_last_verified: output buffer too small");
+  std::vector<uint32_t> idx(C); std::vector<float4> T(size_t(C) * 3);
+  HIPCHK(c, hipMemcpy(idx.data(), L.cand_idx.p, size_t(C) * 4, hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(T.data(), L.cand_T.p, size_t(C) * 48, hipMemcpyDeviceToHost));
+  const uint64_t K = c->last_K;
+  std::vector<unsigned long long> t(K); std::vector<uint32_t> cn(K);
+  HIPCHK(c, hipMemcpy(t.data(), L.tags.p, K * 8, hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(cn.data(), L.counts.p, K * 4, hipMemcpyDeviceToHost));
+  std::vector<uint32_t> order(C);
+  std::iota(order.begin(), order.end(), 0u);
+  std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return t[idx[a]] < t[idx[b]]; });
+  for (uint32_t i = 0; i < C; ++i) {
+    const uint32_t a = order[i];
+    counts[i] = cn[idx[a]];
+    float* o = transforms16 + 16 * size_t(i);
+    std::memcpy(o, &T[size_t(a) * 3], 48);
+    o[12] = 0.f; o[13] = 0.f; o[14] = 0.f; o[15] = 1.f;
+  }
+  return S4P_OK;
+}
+
 int32_t s4p_transform_points(s4p_ctx* c, const float* M, float* x, float* y, float* z, int64_t n) {
   if (!c || !M || (n > 0 && (!x || !y || !z))) return S4P_ERR_BAD_ARG;
   if (n <= 0) return S4P_OK;

@@ -91,6 +91,7 @@ struct s4p_matcher {
   uint64_t candidates_verified = 0, quads_total = 0, pairs_total = 0, bases_tried = 0;
   double seconds_select = 0, seconds_device = 0;
   bool ready = false;
+  bool visit_candidates = false;         // issue the reference's per-candidate visitor calls (fraction == -1)
   // pipelined trials: bases whose device pass is in flight (at most two)
   struct Prepared {
     bool found = false, device = false;
@@ -674,6 +675,12 @@ int32_t s4p_matcher_next_base(s4p_matcher* m, int32_t run_device, int32_t* found
   return rc;
 }
 
+int32_t s4p_matcher_visit_candidates(s4p_matcher* m, int32_t enable) {
+  if (!m) return S4P_ERR_BAD_ARG;
+  m->visit_candidates = enable != 0;
+  return S4P_OK;
+}
+
 int32_t s4p_matcher_set_sharding(s4p_matcher* m, int32_t rank, int32_t world, int32_t producer_threads) {
   if (!m || world < 1 || rank < 0 || rank >= world) return S4P_ERR_BAD_ARG;
   producer_stop(m);
@@ -745,6 +752,21 @@ int32_t s4p_matcher_perform_n_steps(s4p_matcher* m, int32_t n, s4p_visitor_fn vi
     fifo.erase(fifo.begin());
     s4p_base_result r;
     if ((rc = wait_base(m, pr, r)) != S4P_OK) break;
+    if (visitor && m->visit_candidates && pr.device && r.n_verified) {     // match4pcsBase.hpp:458-465
+      std::vector<uint32_t> cnt(size_t(r.n_verified)); std::vector<float> Ts(size_t(r.n_verified) * 16);
+      int64_t nv = 0;
+      if (int32_t vrc = s4p_last_verified(m->ctx, cnt.data(), Ts.data(), int64_t(r.n_verified), &nv)) { rc = m->ctx_fail(vrc); break; }
+      for (int64_t k = 0; k < nv; ++k) {
+        float* T = Ts.data() + 16 * size_t(k);
+        if (needs_global) {      // getGlobalTransform of :446-456: t_global = t + centroid_P - R * centroid_Q
+          for (int a = 0; a < 3; ++a) {
+            const float rq = T[4 * a] * m->centroid_q[0] + (T[4 * a + 1] * m->centroid_q[1] + T[4 * a + 2] * m->centroid_q[2]);
+            T[4 * a + 3] = (T[4 * a + 3] + m->centroid_p[a]) - rq;
+          }
+        }
+        visitor(user, -1.f, float(cnt[size_t(k)]) / float(m->Qs.size()), T);
+      }
+    }
     ok = commit_base(m, pr.found, pr.ids, r);
     const float fraction_try = float(i) / float(m->number_of_trials);
     // integer seconds / integer max_time_seconds: reference quirk, :240-243

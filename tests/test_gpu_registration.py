@@ -260,3 +260,44 @@ def test_config1_hippo_pair_matches_reference_run(s4p_lib_built):
     assert list(i.base) == g["base"].tolist() and list(i.congruent) == g["congruent"].tolist()
     assert np.array_equal(np.array(i.transform, np.float32).reshape(4, 4), g["transform"])
     assert np.array_equal(M[:3, :3], g["M"][:3, :3]) and np.max(np.abs(M - g["M"])) <= 1e-4
+
+
+def test_per_candidate_visitor_calls(oracle_mod, s4p_lib_built):
+    """match4pcsBase.hpp:458-465: the visitor sees every verified candidate (fraction == -1) in candidate order."""
+    from super4pcs_amd import capi
+    O = oracle_mod
+    delta, overlap, n_s = 0.01, 0.6, 200
+    P, Q, _ = H.small_pair(20000, delta=delta, seed=31)
+    om = H.init_oracle(O, P, Q, delta, overlap, n_s)          # full counts
+    gm = capi.Matcher(capi.make_options(delta, overlap, n_s))
+    gm.init_full(P, Q)
+    gm.visit_candidates(True)
+    seen, per_trial = [], []
+
+    def vis(fraction, lcp, T):
+        if fraction < 0:
+            seen.append((np.float32(lcp), T.copy()))
+        else:
+            per_trial.append(fraction)
+    n_trials = 8
+    gm.perform_n_steps(n_trials, visitor=vis)
+    want = []
+    for _ in range(n_trials):
+        ok, i1, i2, base, bx = om.select_quadrilateral()
+        if not ok:
+            continue
+        d1 = float(np.float32(np.linalg.norm(bx[0] - bx[1]))); d2 = float(np.float32(np.linalg.norm(bx[2] - bx[3])))
+        p1 = om.extract_pairs(d1, 0.0, 2 * delta, 0, 1); p2 = om.extract_pairs(d2, 0.0, 2 * delta, 2, 3)
+        if len(p1) == 0 or len(p2) == 0:
+            continue
+        quads = om.find_congruent(i1, i2, 2 * delta, p1, p2)
+        if len(quads) == 0:
+            continue
+        nb, per, _, _ = om.try_congruent_set(base, quads)
+        for k in np.nonzero(per >= 0)[0]:
+            okk, rms, T = om.compute_rigid(base, quads[k])
+            want.append((np.float32(per[k]) / np.float32(n_s), T))
+    assert len(seen) == len(want) == gm.info().candidates_verified and len(seen) > 50
+    assert len(per_trial) == n_trials + 1                      # v(0, ...) once, then once per trial
+    for (gl, gT), (wl, wT) in zip(seen, want):
+        assert gl == wl and np.array_equal(gT, wT)
