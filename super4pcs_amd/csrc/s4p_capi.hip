@@ -56,7 +56,7 @@ struct s4p_ctx {
   bool clouds_set = false;
 
   // device state
-  DevBuf<uint2> greach; DevBuf<uint32_t> glist_start, gcoarse; DevBuf<float4> gnbr; DevBuf<float4> q4;
+  DevBuf<uint2> greach; DevBuf<uint32_t> glist_start, gcoarse; DevBuf<float4> gnbr; DevBuf<float4> q4, q4v;
   DevBuf<float> qx, qy, qz, ux, uy, uz, qnx, qny, qnz, qcr, qcg, qcb;
   // Two lanes = two HIP streams with private per-base device buffers.  Consecutive bases alternate lanes, so the
   // small latency-bound kernels of base t+1 (pairs, hash build, quad enumeration) run concurrently with the
@@ -170,7 +170,7 @@ int32_t launch_pairs_staged(s4p_ctx* c, int slot, int set, float pair_distance_e
   }
   P.ab = ab.p; P.okey = okey.p; P.counter = set == 0 ? &c->lane[c->cur].ctr.p->m1 : &c->lane[c->cur].ctr.p->m2;
   P.cap = uint32_t(c->max_pairs); P.overflow = &c->lane[c->cur].ctr.p->overflow; P.overflow_bit = set == 0 ? 1u : 2u;
-  hipLaunchKernelGGL(k_pairs, dim3(c->n_q), dim3(256), 0, c->lane[c->cur].stream, P);
+  hipLaunchKernelGGL(k_pairs, dim3(std::min<uint32_t>(c->n_q, 512u)), dim3(256), 0, c->lane[c->cur].stream, P);
   HIPCHK(c, hipGetLastError());
   return S4P_OK;
 }
@@ -245,7 +245,7 @@ int32_t launch_quads(s4p_ctx* c, float inv1, float inv2, float thr2) {
   Q.ab2 = c->lane[c->cur].ab2.p; Q.okey2 = c->lane[c->cur].okey2.p; Q.cell2 = c->lane[c->cur].cell2.p; Q.ew2 = c->lane[c->cur].ew2.p; Q.mask2 = c->lane[c->cur].mask2.p;
   Q.m2_dev = &c->lane[c->cur].ctr.p->m2; Q.cap2 = uint32_t(c->max_pairs); Q.ht = ht; Q.thr = thr2;
   Q.quads = c->lane[c->cur].quads.p; Q.tags = c->lane[c->cur].tags.p; Q.K_dev = &c->lane[c->cur].ctr.p->K; Q.K_cap = uint32_t(c->max_quads); Q.overflow = &c->lane[c->cur].ctr.p->overflow;
-  hipLaunchKernelGGL(k_quads, dim3(2048), dim3(256), 0, c->lane[c->cur].stream, Q);
+  hipLaunchKernelGGL(k_quads, dim3(512), dim3(256), 0, c->lane[c->cur].stream, Q);
   HIPCHK(c, hipGetLastError());
   return S4P_OK;
 }
@@ -260,7 +260,7 @@ BaseFrame make_base_frame(const s4p_ctx* c, const int32_t* base_ids) {
 
 int32_t launch_verify(s4p_ctx* c, const BaseFrame& bf) {
   VerifyParams V{};
-  V.grid = c->dev_grid(); V.q4 = c->q4.p; V.n_q = c->n_q; V.base = bf;
+  V.grid = c->dev_grid(); V.q4 = c->q4.p; V.q4v = c->q4v.p; V.n_q = c->n_q; V.base = bf;
   V.quads = c->lane[c->cur].quads.p; V.tags = c->lane[c->cur].tags.p; V.counts = c->lane[c->cur].counts.p; V.K_dev = &c->lane[c->cur].ctr.p->K; V.K_cap = uint32_t(c->max_quads);
   V.ctr = c->lane[c->cur].ctr.p; V.cand_idx = c->lane[c->cur].cand_idx.p; V.cand_T = c->lane[c->cur].cand_T.p;
   { const char* ab = getenv("S4P_ABLATE"); V.ablate = ab ? atoi(ab) : 0; }   // debugging aid, results are wrong when set
@@ -408,7 +408,7 @@ void s4p_destroy(s4p_ctx* c) {
   (void)hipSetDevice(c->device);
   for (auto& L : c->lane) if (L.stream) (void)hipStreamSynchronize(L.stream);
   c->greach.free(); c->glist_start.free(); c->gnbr.free();
-  c->gcoarse.free(); c->q4.free();
+  c->gcoarse.free(); c->q4.free(); c->q4v.free();
   c->qx.free(); c->qy.free(); c->qz.free(); c->ux.free(); c->uy.free(); c->uz.free();
   c->qnx.free(); c->qny.free(); c->qnz.free(); c->qcr.free(); c->qcg.free(); c->qcb.free();
   for (auto& L : c->lane) {
@@ -471,6 +471,25 @@ int32_t s4p_set_clouds(s4p_ctx* c, const float* px, const float* py, const float
     for (int64_t i = 0; i < n_q; ++i) q4[size_t(i)] = make_float4(qx[i], qy[i], qz[i], 0.f);
     HIPCHK(c, c->q4.alloc(size_t(n_q)));
     HIPCHK(c, hipMemcpy(c->q4.p, q4.data(), size_t(n_q) * sizeof(float4), hipMemcpyHostToDevice));
+    // Second copy for the LCP sweep, in Morton order of the unit-cube coordinates: Verify only counts inliers, so
+    // the order of the queries is free, and spatially sorted queries keep the 64 lanes of a wave (and the 64
+    // survivors of a phase-2 batch) in neighbouring grid cells -> shared LDS words and shared cache lines.
+    std::vector<uint32_t> ord((size_t)n_q);
+    std::vector<uint32_t> key((size_t)n_q);
+    auto spread = [](uint32_t v) { v &= 0x3FFu; v = (v | (v << 16)) & 0x030000FFu; v = (v | (v << 8)) & 0x0300F00Fu;
+                                   v = (v | (v << 4)) & 0x030C30C3u; v = (v | (v << 2)) & 0x09249249u; return v; };
+    for (int64_t i = 0; i < n_q; ++i) {
+      ord[size_t(i)] = uint32_t(i);
+      const uint32_t a = uint32_t(std::min(std::max(c->hux[size_t(i)], 0.f), 0.999f) * 1024.f);
+      const uint32_t b = uint32_t(std::min(std::max(c->huy[size_t(i)], 0.f), 0.999f) * 1024.f);
+      const uint32_t d = uint32_t(std::min(std::max(c->huz[size_t(i)], 0.f), 0.999f) * 1024.f);
+      key[size_t(i)] = spread(a) | (spread(b) << 1) | (spread(d) << 2);
+    }
+    std::sort(ord.begin(), ord.end(), [&](uint32_t x, uint32_t y) { return key[x] < key[y]; });
+    std::vector<float4> qv((size_t)n_q);
+    for (int64_t i = 0; i < n_q; ++i) qv[size_t(i)] = q4[ord[size_t(i)]];
+    HIPCHK(c, c->q4v.alloc(size_t(n_q)));
+    HIPCHK(c, hipMemcpy(c->q4v.p, qv.data(), size_t(n_q) * sizeof(float4), hipMemcpyHostToDevice));
   }
   auto up = [&](DevBuf<float>& d, const float* src) -> hipError_t {
     hipError_t e = d.alloc(n_q); if (e != hipSuccess) return e;
@@ -610,7 +629,7 @@ int32_t s4p_verify_transforms(s4p_ctx* c, const float* T, int64_t B, uint32_t* c
   do {
     if ((e = hipMemcpyAsync(dT.p, T, size_t(B) * 64, hipMemcpyHostToDevice, c->lane[c->cur].stream)) != hipSuccess) break;
     VerifyTParams V{};
-    V.grid = c->dev_grid(); V.q4 = c->q4.p; V.n_q = c->n_q; V.T = dT.p; V.B = uint32_t(B);
+    V.grid = c->dev_grid(); V.q4 = c->q4v.p; V.n_q = c->n_q; V.T = dT.p; V.B = uint32_t(B);
     V.counts = dC.p; V.ctr = c->lane[c->cur].ctr.p;
     const uint32_t wpb = kVerifyThreads / 64;
     const uint32_t blocks = uint32_t(std::min<int64_t>((B + wpb - 1) / wpb, 512));

@@ -249,7 +249,7 @@ struct LcpGridHost {
     while (true) {
       cnx = ((nx - 1) >> cshift) + 1; cny = ((ny - 1) >> cshift) + 1; cnz = ((nz - 1) >> cshift) + 1;
       const uint64_t cw = (uint64_t(cnx) * cny * cnz + 31) / 32;
-      if (cw <= max_coarse_words) { coarse.assign(cw, 0u); break; }
+      if (cw <= max_coarse_words) { coarse.assign((cw + 3) & ~uint64_t(3), 0u); break; }   // padded to 16 B for the LDS staging
       ++cshift;
     }
     for (uint64_t w = 0; w < nwords; ++w) {

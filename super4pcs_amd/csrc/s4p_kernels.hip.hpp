@@ -131,35 +131,35 @@ __device__ __forceinline__ uint32_t wave_lcp_count(const LcpGrid& g, const uint3
   const uint32_t lane = threadIdx.x & 63u;
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
   uint32_t cnt = 0, qn = 0;
+  const uint32_t cmax = g.coarse_words * 32u - 1u;
+  const uint32_t unx = uint32_t(g.nx), uny = uint32_t(g.ny), unz = uint32_t(g.nz);
   for (uint32_t base = 0; base < n_q; base += 64) {
     const uint32_t i = base + lane;
-    bool surv = false;
-    float tx = 0.f, ty = 0.f, tz = 0.f;
-    if (i < n_q) {
-      const float4 q = q4[i];
-      // (mat * q.homogeneous()).head<3>() : ((m0*x + m1*y) + m2*z) + m3   (match4pcsBase.cc:532)
-      tx = ((T[0] * q.x + T[1] * q.y) + T[2] * q.z) + T[3];
-      ty = ((T[4] * q.x + T[5] * q.y) + T[6] * q.z) + T[7];
-      tz = ((T[8] * q.x + T[9] * q.y) + T[10] * q.z) + T[11];
-      int ix, iy, iz;
-      if (cell_coords(g, tx, ty, tz, ix, iy, iz)) {
-        const uint32_t cc = (uint32_t(iz >> g.cshift) * uint32_t(g.cny) + uint32_t(iy >> g.cshift)) * uint32_t(g.cnx) +
-                            uint32_t(ix >> g.cshift);
-        surv = (s_coarse[cc >> 5] >> (cc & 31u)) & 1u;
-      }
-    }
+    // Branch-free L0 test (the nested bounds checks of a short-circuit version cost more issue slots than the math).
+    const float4 q = q4[min(i, n_q - 1u)];
+    // (mat * q.homogeneous()).head<3>() : ((m0*x + m1*y) + m2*z) + m3   (match4pcsBase.cc:532)
+    const float tx = ((T[0] * q.x + T[1] * q.y) + T[2] * q.z) + T[3];
+    const float ty = ((T[4] * q.x + T[5] * q.y) + T[6] * q.z) + T[7];
+    const float tz = ((T[8] * q.x + T[9] * q.y) + T[10] * q.z) + T[11];
+    // float -> int conversion saturates and one unsigned compare per axis covers both bounds (a NaN coordinate maps
+    // to cell 0 and then fails every exact distance test, so it cannot create an inlier)
+    const int ix = int(floorf((tx - g.ox) * g.inv_h)), iy = int(floorf((ty - g.oy) * g.inv_h)), iz = int(floorf((tz - g.oz) * g.inv_h));
+    const bool inb = (uint32_t(ix) < unx) & (uint32_t(iy) < uny) & (uint32_t(iz) < unz) & (i < n_q);
+    const uint32_t cc = min(__umul24(__umul24(uint32_t(iz) >> g.cshift, uint32_t(g.cny)) + (uint32_t(iy) >> g.cshift), uint32_t(g.cnx)) +
+                            (uint32_t(ix) >> g.cshift), cmax);
+    const bool surv = inb & (((s_coarse[cc >> 5] >> (cc & 31u)) & 1u) != 0u);
     const unsigned long long m = __ballot(surv);
     if (COUNT && lane == 0) atomicAdd(point_tests + 1, (unsigned long long)__popcll(m));   // l0_pass
     if (surv) {
-      const uint32_t at = qn + uint32_t(__popcll(m & lt_mask));
-      s_queue[3 * at] = tx; s_queue[3 * at + 1] = ty; s_queue[3 * at + 2] = tz;
+      const uint32_t at = __umul24(qn + uint32_t(__popcll(m & lt_mask)), 3u);
+      s_queue[at] = tx; s_queue[at + 1] = ty; s_queue[at + 2] = tz;
     }
     qn += uint32_t(__popcll(m));
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     if (qn >= 64u) {
-      const uint32_t at = qn - 64u + lane;
-      const float x = s_queue[3 * at], y = s_queue[3 * at + 1], z = s_queue[3 * at + 2];
+      const uint32_t at = __umul24(qn - 64u + lane, 3u);
+      const float x = s_queue[at], y = s_queue[at + 1], z = s_queue[at + 2];
       cnt += SKIP_FINE ? uint32_t(x > 1e30f) : (fine_test<COUNT>(g, x, y, z, point_tests) ? 1u : 0u);
       qn -= 64u;
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -176,8 +176,23 @@ __device__ __forceinline__ uint32_t wave_lcp_count(const LcpGrid& g, const uint3
   return cnt;
 }
 
+// Global -> LDS copy of the coarse bitmap: 16 B per lane and four independent loads in flight per thread (a
+// word-at-a-time loop serialises ~13 L2 round trips per thread and cost ~50 us per launch).
 __device__ __forceinline__ void stage_coarse(const LcpGrid& g, uint32_t* s_coarse) {
-  for (uint32_t w = threadIdx.x; w < g.coarse_words; w += blockDim.x) s_coarse[w] = g.coarse[w];
+  const uint32_t n4 = g.coarse_words >> 2;                       // the host pads coarse_words to a multiple of 4
+  const uint4* src = reinterpret_cast<const uint4*>(g.coarse);
+  uint4* dst = reinterpret_cast<uint4*>(s_coarse);
+  for (uint32_t w = threadIdx.x; w < n4; w += 4u * blockDim.x) {
+    const uint32_t w1 = w + blockDim.x, w2 = w1 + blockDim.x, w3 = w2 + blockDim.x;
+    const uint4 a = src[w];
+    const uint4 b = src[min(w1, n4 - 1u)];
+    const uint4 c = src[min(w2, n4 - 1u)];
+    const uint4 d = src[min(w3, n4 - 1u)];
+    dst[w] = a;
+    if (w1 < n4) dst[w1] = b;
+    if (w2 < n4) dst[w2] = c;
+    if (w3 < n4) dst[w3] = d;
+  }
   __syncthreads();
 }
 
@@ -251,10 +266,11 @@ __device__ __forceinline__ bool rigid_gate(const BaseFrame& b, const float q[3][
 // the quad list whose length lives in device memory (no host round trip).
 // LDS: coarse bitmap (<= 48 KB) + 8 private survivor queues (1.5 KB each).
 // ---------------------------------------------------------------------------
-constexpr int kVerifyThreads = 512;
+constexpr int kVerifyThreads = 1024;
 struct VerifyParams {
   LcpGrid grid;
-  const float4* q4;                                     // sampled Q (centred), packed (x,y,z,0)
+  const float4* q4;                                     // sampled Q (centred), packed (x,y,z,0), original order (quad indices)
+  const float4* q4v;                                    // the same points in Morton order, for the LCP sweep
   uint32_t n_q;
   BaseFrame base;
   const int4* quads; const unsigned long long* tags; uint32_t* counts;
@@ -324,13 +340,23 @@ __global__ __launch_bounds__(kVerifyThreads) void k_verify(VerifyParams P) {
     const float T[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
     uint32_t cnt = 0;
     if (P.ablate == 2) cnt = uint32_t(T[3] > 1e30f);
-    else if (P.ablate == 1) cnt = wave_lcp_count<COUNT, true>(P.grid, s_coarse, s_queue, P.q4, P.n_q, T, &P.ctr->point_tests);
-    else cnt = wave_lcp_count<COUNT, false>(P.grid, s_coarse, s_queue, P.q4, P.n_q, T, &P.ctr->point_tests);
+    else if (P.ablate == 1) cnt = wave_lcp_count<COUNT, true>(P.grid, s_coarse, s_queue, P.q4v, P.n_q, T, &P.ctr->point_tests);
+    else cnt = wave_lcp_count<COUNT, false>(P.grid, s_coarse, s_queue, P.q4v, P.n_q, T, &P.ctr->point_tests);
     if (lane == 0) P.counts[P.cand_idx[i]] = cnt;
     local_best = max(local_best, cnt);
     any = true;
   }
-  if (lane == 0 && any) atomicMax(&P.ctr->best_count, local_best);
+  // One global atomic per workgroup, and only if it can raise the maximum: a per-wave atomicMax on the single
+  // result word serialised at ~90 ops/us (8192 waves = 0.09 ms per launch, measured with S4P_ABLATE=2).
+  __shared__ uint32_t s_best;
+  if (threadIdx.x == 0) s_best = 0;
+  __syncthreads();
+  if (lane == 0 && any) atomicMax(&s_best, local_best);
+  __syncthreads();
+  if (threadIdx.x == 0 && s_best > 0) {
+    const uint32_t cur = __hip_atomic_load(&P.ctr->best_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (s_best > cur) atomicMax(&P.ctr->best_count, s_best);
+  }
 }
 
 // k_select: best_tag = min tag among candidates whose count == best_count (first in
@@ -428,7 +454,7 @@ __device__ __forceinline__ bool sphere_box(float cx, float cy, float cz, float r
   return (dmin[0] + (dmin[1] + dmin[2])) < r2 && r2 < (dmax[0] + (dmax[1] + dmax[2]));
 }
 
-constexpr int kPairStage = 1024;   // accepted (pId, j) per workgroup between two flushes
+constexpr int kPairStage = 2048;   // accepted (pId, j) per workgroup between two flushes
 
 // One workgroup per primitive pId; threads sweep the sequence in chunks of 256.  Accepted slots are
 // staged in LDS and flushed with ONE global atomic per workgroup (a per-wave atomic on the single
@@ -436,12 +462,10 @@ constexpr int kPairStage = 1024;   // accepted (pId, j) per workgroup between tw
 __global__ __launch_bounds__(256) void k_pairs(PairParams P) {
   __shared__ uint32_t st_j[kPairStage];
   __shared__ uint32_t st_s[kPairStage];
+  __shared__ uint32_t st_p[kPairStage];
   __shared__ uint32_t st_n, st_base;
-  const uint32_t pId = blockIdx.x;
   if (threadIdx.x == 0) st_n = 0;
   __syncthreads();
-  const float cx = P.ux[pId], cy = P.uy[pId], cz = P.uz[pId];
-  const float wxi = P.qx[pId], wyi = P.qy[pId], wzi = P.qz[pId];
   auto flush = [&]() {     // called by all threads, between barriers
     const uint32_t n = st_n;
     if (n == 0) return;
@@ -451,7 +475,7 @@ __global__ __launch_bounds__(256) void k_pairs(PairParams P) {
     for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) {
       const uint32_t at = base + 2u * e;
       if (at + 1u < P.cap) {
-        const uint32_t j = st_j[e];
+        const uint32_t j = st_j[e], pId = st_p[e];
         const uint32_t ok = 2u * (pId * P.n_seq + st_s[e]);
         P.ab[at] = make_int2(int(j), int(pId));     P.okey[at] = ok;          // pairs->emplace_back(j, i)  :214
         P.ab[at + 1] = make_int2(int(pId), int(j)); P.okey[at + 1] = ok + 1u; // pairs->emplace_back(i, j)  :215
@@ -463,6 +487,11 @@ __global__ __launch_bounds__(256) void k_pairs(PairParams P) {
     if (threadIdx.x == 0) st_n = 0;
     __syncthreads();
   };
+  // each workgroup takes primitives blockIdx.x, blockIdx.x + gridDim.x, ... so the number of global atomics is
+  // ~ the number of workgroups (a few hundred), not the number of primitives
+  for (uint32_t pId = blockIdx.x; pId < P.n_q; pId += gridDim.x) {
+  const float cx = P.ux[pId], cy = P.uy[pId], cz = P.uz[pId];
+  const float wxi = P.qx[pId], wyi = P.qy[pId], wzi = P.qz[pId];
   for (uint32_t s0 = 0; s0 < P.n_seq; s0 += blockDim.x) {
     const uint32_t s = s0 + threadIdx.x;
     bool acc = false;
@@ -507,11 +536,12 @@ __global__ __launch_bounds__(256) void k_pairs(PairParams P) {
       }
     }
     if (acc) {
-      const uint32_t e = atomicAdd(&st_n, 1u);     // LDS atomic; st_n <= kPairStage - 256 + 256 by the flush rule below
-      st_j[e] = j; st_s[e] = s;
+      const uint32_t e = atomicAdd(&st_n, 1u);     // LDS atomic; room for 256 more is guaranteed by the flush rule below
+      st_j[e] = j; st_s[e] = s; st_p[e] = pId;
     }
     __syncthreads();
     if (st_n + blockDim.x > uint32_t(kPairStage)) flush();   // uniform: st_n is read after the barrier
+  }
   }
   flush();
 }
