@@ -187,7 +187,8 @@ typedef struct {
   uint64_t verify_point_tests;   /* P-point distance tests (k-bar numerator), if enabled */
   uint64_t verify_queries;       /* point queries (candidates * n_Q)                    */
   uint64_t verify_l0_pass;       /* queries that passed the LDS coarse bitmap, if enabled */
-  uint64_t verify_l1_pass;       /* queries that passed the dilated fine bitmap, if enabled */
+  uint64_t verify_l1_pass;       /* queries that passed the reach bitmap, if enabled */
+  uint64_t verify_l2_pass;       /* queries that passed the 4x4x4 sub-cell mask (go on to exact tests), if enabled */
   double   pairs_ms_total, quads_ms_total;
   uint64_t pairs_launches, quads_launches;
   double   host_octree_s;        /* host time in the pair-octree builds (loop 1 of IntersectionFunctor)   */

@@ -56,7 +56,7 @@ class Profile(C.Structure):
     _fields_ = [
         ("verify_launches", C.c_uint64), ("verify_ms_total", C.c_double), ("verify_candidates", C.c_uint64),
         ("verify_quads", C.c_uint64), ("verify_point_tests", C.c_uint64), ("verify_queries", C.c_uint64),
-        ("verify_l0_pass", C.c_uint64), ("verify_l1_pass", C.c_uint64),
+        ("verify_l0_pass", C.c_uint64), ("verify_l1_pass", C.c_uint64), ("verify_l2_pass", C.c_uint64),
         ("pairs_ms_total", C.c_double), ("quads_ms_total", C.c_double),
         ("pairs_launches", C.c_uint64), ("quads_launches", C.c_uint64),
         ("host_octree_s", C.c_double), ("host_wait_s", C.c_double),

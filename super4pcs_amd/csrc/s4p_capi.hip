@@ -56,7 +56,7 @@ struct s4p_ctx {
   bool clouds_set = false;
 
   // device state
-  DevBuf<uint2> greach; DevBuf<uint32_t> glist_start, gcoarse; DevBuf<float4> gnbr; DevBuf<float4> q4, q4v;
+  DevBuf<uint2> greach; DevBuf<uint4> glist_hdr; DevBuf<uint32_t> gcoarse; DevBuf<float4> gnbr; DevBuf<float4> q4, q4v;
   DevBuf<float> qx, qy, qz, ux, uy, uz, qnx, qny, qnz, qcr, qcg, qcb;
   // Two lanes = two HIP streams with private per-base device buffers.  Consecutive bases alternate lanes, so the
   // small latency-bound kernels of base t+1 (pairs, hash build, quad enumeration) run concurrently with the
@@ -101,7 +101,7 @@ struct s4p_ctx {
   size_t verify_lds_bytes() const { return gcoarse.n * 4 + size_t(kVerifyThreads / 64) * 3 * kQueueEntries * 4; }
   LcpGrid dev_grid() const {
     LcpGrid g;
-    g.reach = greach.p; g.list_start = glist_start.p; g.nbr = gnbr.p;
+    g.reach = greach.p; g.list_hdr = glist_hdr.p; g.nbr = gnbr.p;
     g.coarse = gcoarse.p; g.coarse_words = uint32_t(gcoarse.n);
     g.cshift = hgrid.cshift; g.cnx = hgrid.cnx; g.cny = hgrid.cny;
     g.ox = hgrid.ox; g.oy = hgrid.oy; g.oz = hgrid.oz; g.inv_h = hgrid.inv_h;
@@ -314,7 +314,7 @@ int32_t finish_result(s4p_ctx* c, s4p_base_result* r, bool fused) {
       if (hipEventElapsedTime(&ms, c->ev[c->cur][3], c->ev[c->cur][4]) == hipSuccess) { c->prof.quads_ms_total += ms; c->prof.quads_launches += 1; }
     }
   }
-  if (c->prof_points) { c->prof.verify_point_tests += d.point_tests; c->prof.verify_l0_pass += d.l0_pass; c->prof.verify_l1_pass += d.l1_pass; }
+  if (c->prof_points) { c->prof.verify_point_tests += d.point_tests; c->prof.verify_l0_pass += d.l0_pass; c->prof.verify_l1_pass += d.l1_pass; c->prof.verify_l2_pass += d.l2_pass; }
   return S4P_OK;
 }
 
@@ -327,7 +327,7 @@ int32_t fetch_result(s4p_ctx* c, const BaseFrame& bf, s4p_base_result* r) {
 
 int32_t reset_counters(s4p_ctx* c) {
   hipLaunchKernelGGL(k_reset_counters, dim3(1), dim3(1), 0, c->lane[c->cur].stream, c->lane[c->cur].ctr.p);
-  if (c->prof_points) HIPCHK(c, hipMemsetAsync(&c->lane[c->cur].ctr.p->point_tests, 0, 24, c->lane[c->cur].stream));
+  if (c->prof_points) HIPCHK(c, hipMemsetAsync(&c->lane[c->cur].ctr.p->point_tests, 0, 32, c->lane[c->cur].stream));
   return S4P_OK;
 }
 
@@ -407,7 +407,7 @@ void s4p_destroy(s4p_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   for (auto& L : c->lane) if (L.stream) (void)hipStreamSynchronize(L.stream);
-  c->greach.free(); c->glist_start.free(); c->gnbr.free();
+  c->greach.free(); c->glist_hdr.free(); c->gnbr.free();
   c->gcoarse.free(); c->q4.free(); c->q4v.free();
   c->qx.free(); c->qy.free(); c->qz.free(); c->ux.free(); c->uy.free(); c->uz.free();
   c->qnx.free(); c->qny.free(); c->qnz.free(); c->qcr.free(); c->qcg.free(); c->qcb.free();
@@ -464,7 +464,27 @@ int32_t s4p_set_clouds(s4p_ctx* c, const float* px, const float* py, const float
     std::vector<uint32_t>().swap(src);          // the host mirror is not needed afterwards
     return e;
   };
-  HIPCHK(c, upu(c->glist_start, c->hgrid.list_start));
+  {
+    const size_t nr = c->hgrid.reach_cell.size();
+    std::vector<uint4> hdr(nr);
+    for (size_t r = 0; r < nr; ++r) hdr[r] = make_uint4(c->hgrid.list_start[r], c->hgrid.list_start[r + 1] - c->hgrid.list_start[r], 0u, 0u);
+    HIPCHK(c, c->glist_hdr.alloc(nr));
+    HIPCHK(c, hipMemcpy(c->glist_hdr.p, hdr.data(), nr * sizeof(uint4), hipMemcpyHostToDevice));
+    DevBuf<uint32_t> dcell;
+    HIPCHK(c, dcell.alloc(nr));
+    hipError_t e = hipMemcpy(dcell.p, c->hgrid.reach_cell.data(), nr * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+      MaskParams M{};
+      M.list_hdr = c->glist_hdr.p; M.nbr = c->gnbr.p; M.cell_id = dcell.p; M.n_reach = uint32_t(nr);
+      M.ox = c->hgrid.ox; M.oy = c->hgrid.oy; M.oz = c->hgrid.oz; M.h = c->hgrid.h; M.nx = c->hgrid.nx; M.ny = c->hgrid.ny;
+      M.reach2 = double(c->hgrid.reach_radius) * double(c->hgrid.reach_radius);
+      hipLaunchKernelGGL(k_build_masks, dim3(uint32_t((nr + 255) / 256)), dim3(256), 0, c->lane[0].stream, M);
+      e = hipStreamSynchronize(c->lane[0].stream);
+    }
+    dcell.free();
+    HIPCHK(c, e);
+    std::vector<uint32_t>().swap(c->hgrid.list_start); std::vector<uint32_t>().swap(c->hgrid.reach_cell);
+  }
   HIPCHK(c, upu(c->gcoarse, c->hgrid.coarse));
   {
     std::vector<float4> q4((size_t)n_q);

@@ -177,6 +177,8 @@ struct LcpGridHost {
   std::vector<uint32_t> reach_bits;         // cell c reachable: some P point within 1.01*delta of its box
   std::vector<uint32_t> reach_prefix;       // reachable cells before each bitmap word
   std::vector<uint32_t> list_start;         // n_reach + 1
+  std::vector<uint32_t> reach_cell;         // linear cell id of the r-th reachable cell
+  float reach_radius = 0.f;                 // 1.01 * delta
   std::vector<float> nbr;                   // 4 floats per entry (x,y,z,0), grouped by reachable cell
   std::vector<uint32_t> coarse;             // OR of 2^cshift-cubes of reach_bits; <= max_coarse_words
   uint64_t ncell() const { return uint64_t(nx) * uint64_t(ny) * uint64_t(nz); }
@@ -232,12 +234,13 @@ struct LcpGridHost {
     }
     std::sort(inc.begin(), inc.end());
     reach_bits.assign(nwords, 0u);
-    list_start.clear();
+    list_start.clear(); reach_cell.clear();
+    reach_radius = float(reach);
     nbr.resize(inc.size() * 4);
     uint64_t prev = ~0ull;
     for (size_t k = 0; k < inc.size(); ++k) {
       const uint64_t c = inc[k] >> 32; const uint32_t i = uint32_t(inc[k]);
-      if (c != prev) { list_start.push_back(uint32_t(k)); reach_bits[c >> 5] |= (1u << (c & 31u)); prev = c; }
+      if (c != prev) { list_start.push_back(uint32_t(k)); reach_cell.push_back(uint32_t(c)); reach_bits[c >> 5] |= (1u << (c & 31u)); prev = c; }
       nbr[4 * k] = px[i]; nbr[4 * k + 1] = py[i]; nbr[4 * k + 2] = pz[i]; nbr[4 * k + 3] = 0.f;
     }
     list_start.push_back(uint32_t(inc.size()));

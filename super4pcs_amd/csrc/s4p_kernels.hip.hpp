@@ -52,7 +52,7 @@ struct DevCounters {
   uint32_t overflow;                // bit0 pairs1, bit1 pairs2, bit2 quads
   unsigned long long best_tag;      // min tag among candidates with best_count
   unsigned long long point_tests;   // optional instrumentation (COUNT kernels only)
-  unsigned long long l0_pass, l1_pass;
+  unsigned long long l0_pass, l1_pass, l2_pass;
   uint32_t cursor;                  // k_verify work cursor
   // winner record
   int32_t best_quad[4];
@@ -68,14 +68,15 @@ struct DevCounters {
 //   L0  coarse bitmap (OR of 2^s-cubes of the reach bitmap), <= 48 KB, staged in LDS;
 //   L1  reach bitmap: bit(c) = some P point lies within 1.01*delta of the box of cell c,
 //       stored as {bits, rank-prefix} records (one 8 B load gives the bit and the rank);
-//   L2  per reachable cell, the contiguous list of exactly those P points (float4 copies):
-//       one range load, then one 16 B load per exact distance test -- no neighbour-cell walk.
+//   L2  per reachable cell, a 16 B header {list start, count, 64-bit mask of the 4x4x4 sub-cells (edge h/4) that
+//       some listed point can reach} and the contiguous list of exactly those P points (float4 copies): one
+//       header load, a sub-cell bit test that drops most near-misses, then one 16 B load per exact distance test.
 // The reach records and range table (~2 MB per 10^5 points) are L2-cache resident; the
 // point lists (~400 B per P point) stream from Infinity Cache / HBM.
 // ---------------------------------------------------------------------------
 struct LcpGrid {
   const uint2* reach;           // per 32-cell word: {reach bits, number of reachable cells before this word}
-  const uint32_t* list_start;   // n_reach + 1 offsets into nbr
+  const uint4* list_hdr;        // per reachable cell: {first entry in nbr, entry count, 4x4x4 sub-cell reach mask lo, hi}
   const float4* nbr;            // P points (x,y,z,0) grouped by reachable cell
   const uint32_t* coarse;       // coarse bitmap (global copy, staged to LDS by the kernels)
   uint32_t coarse_words;
@@ -108,7 +109,16 @@ __device__ __forceinline__ bool fine_test(const LcpGrid& g, float tx, float ty, 
   if (!((w.x >> sh) & 1u)) return false;
   if (COUNT) atomicAdd(point_tests + 2, 1ull);     // l1_pass
   const uint32_t rank = w.y + uint32_t(__popc(w.x & ((1u << sh) - 1u)));
-  const uint32_t s = g.list_start[rank], e = g.list_start[rank + 1];
+  const uint4 hdr = g.list_hdr[rank];
+  // sub-cell of the query inside its cell (conservative: the mask was built with 1 % slack, rounding here is ~1e-5 cell)
+  const float rx = (tx - g.ox) * g.inv_h - float(ix), ry = (ty - g.oy) * g.inv_h - float(iy), rz = (tz - g.oz) * g.inv_h - float(iz);
+  const uint32_t sx = min(uint32_t(max(int(rx * 4.f), 0)), 3u), sy = min(uint32_t(max(int(ry * 4.f), 0)), 3u),
+                 sz = min(uint32_t(max(int(rz * 4.f), 0)), 3u);
+  const uint32_t sb = sz * 16u + sy * 4u + sx;
+  const uint32_t mword = sb < 32u ? hdr.z : hdr.w;
+  if (!((mword >> (sb & 31u)) & 1u)) return false;
+  if (COUNT) atomicAdd(point_tests + 3, 1ull);     // l2_pass
+  const uint32_t s = hdr.x, e = hdr.x + hdr.y;
   for (uint32_t p = s; p < e; ++p) {
     const float4 pp = g.nbr[p];
     const float dx = tx - pp.x, dy = ty - pp.y, dz = tz - pp.z;
@@ -116,6 +126,35 @@ __device__ __forceinline__ bool fine_test(const LcpGrid& g, float tx, float ty, 
     if (sqn3(dx, dy, dz) <= g.sq_eps) return true;          // kdtree.h:417-421  sqdist <= cl_dist
   }
   return false;
+}
+
+// One-off (s4p_set_clouds): fills hdr.z/.w, the 4x4x4 sub-cell reach masks, from the point lists.
+// bit(sx,sy,sz) = some listed point lies within `reach` of the sub-box; double precision, same slack as the lists.
+struct MaskParams {
+  uint4* list_hdr; const float4* nbr; const uint32_t* cell_id; uint32_t n_reach;
+  float ox, oy, oz, h; int nx, ny; double reach2;
+};
+__global__ __launch_bounds__(256) void k_build_masks(MaskParams P) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= P.n_reach) return;
+  uint4 hdr = P.list_hdr[r];
+  const uint32_t c = P.cell_id[r];
+  const int ix = int(c % uint32_t(P.nx)), iy = int((c / uint32_t(P.nx)) % uint32_t(P.ny)), iz = int(c / (uint32_t(P.nx) * uint32_t(P.ny)));
+  const double q = double(P.h) * 0.25;
+  const double bx = double(P.ox) + double(ix) * double(P.h), by = double(P.oy) + double(iy) * double(P.h), bz = double(P.oz) + double(iz) * double(P.h);
+  unsigned long long mask = 0ull;
+  for (uint32_t p = hdr.x; p < hdr.x + hdr.y; ++p) {
+    const float4 pp = P.nbr[p];
+    for (int s = 0; s < 64; ++s) {
+      const double lo[3] = {bx + (s & 3) * q, by + ((s >> 2) & 3) * q, bz + (s >> 4) * q};
+      const double v[3] = {double(pp.x), double(pp.y), double(pp.z)};
+      double d2 = 0;
+      for (int k = 0; k < 3; ++k) { const double d = v[k] < lo[k] ? lo[k] - v[k] : (v[k] > lo[k] + q ? v[k] - (lo[k] + q) : 0.0); d2 += d * d; }
+      if (d2 <= P.reach2) mask |= (1ull << s);
+    }
+  }
+  hdr.z = uint32_t(mask); hdr.w = uint32_t(mask >> 32);
+  P.list_hdr[r] = hdr;
 }
 
 // Number of sampled-Q points that T brings within delta of a sampled-P point: Verify()
