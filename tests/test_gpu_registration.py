@@ -301,3 +301,29 @@ def test_per_candidate_visitor_calls(oracle_mod, s4p_lib_built):
     assert len(per_trial) == n_trials + 1                      # v(0, ...) once, then once per trial
     for (gl, gT), (wl, wT) in zip(seen, want):
         assert gl == wl and np.array_equal(gT, wT)
+
+
+@pytest.mark.parametrize("producer", [False, True])
+def test_early_termination_is_exact(oracle_mod, s4p_lib_built, producer):
+    """terminate_threshold < 1 (configureOverlap's second argument): the loop stops at the first trial whose best LCP
+    exceeds it (match4pcsBase.hpp:255).  The pipelined engine has speculative bases in flight at that moment; they
+    must not leak into the result, the candidate count, or the host state a following Perform_N_steps starts from."""
+    from super4pcs_amd import capi
+    O = oracle_mod
+    delta, overlap, n_s, thr = 0.01, 0.6, 200, 0.45
+    P, Q, _ = H.small_pair(20000, delta=delta, seed=31)
+    om = O.Matcher(O.make_options(delta, overlap, n_s, terminate_threshold=thr))
+    o_lcp, o_M, o_Q = om.compute_transformation(P, Q)
+    gm = capi.Matcher(capi.make_options(delta, overlap, n_s, terminate_threshold=thr))
+    if producer:
+        gm.set_sharding(0, 1, True)
+    g_lcp, g_M, g_Q = gm.compute_transformation(P, Q)
+    assert o_lcp > thr and g_lcp == o_lcp and np.array_equal(g_M, o_M)
+    assert gm.info().candidates_verified == om.stats().n_verified
+    assert om.stats().n_verified < 571588                     # it really stopped early (the full run verifies 571 588)
+    # continue both for a few more trials: same bases, same state afterwards
+    for _ in range(4):
+        o_ok = om.try_one_base()
+        g_ok, _r = gm.try_one_base()
+        assert g_ok == o_ok
+    assert gm.info().candidates_verified == om.stats().n_verified and gm.info().best_lcp == om.stats().best_lcp

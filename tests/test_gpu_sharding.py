@@ -1,0 +1,66 @@
+"""-m gpu: the multi-rank driver with the real engine.  Two processes share the one GPU of the test box and talk
+over gloo (the collective is 8 bytes, its transport is irrelevant to correctness); each owns every second trial.
+Both must end in exactly the state the sequential CPU oracle reaches after the same number of trials."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DELTA, OVERLAP, N_S, N_WINDOWS = 0.01, 0.6, 250, 12
+
+
+def _worker(rank, world, port, producer, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from super4pcs_amd import capi, sharding
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    P, Q, _ = H.small_pair(30000, delta=DELTA, seed=23)
+    m = capi.Matcher(capi.make_options(DELTA, OVERLAP, N_S), device=0, max_pairs=1 << 20, max_quads=4 << 20)
+    m.init_full(P, Q)
+    sh = sharding.ShardedRansac(m, rank, world, dist, None, producer_threads=producer)
+    if not producer:
+        m.set_sharding(rank, world, False)
+    got = sh.run_windows(N_WINDOWS)
+    i = m.info()
+    q.put((rank, float(i.best_lcp), list(i.base), list(i.congruent), list(i.transform), int(got)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+@pytest.mark.parametrize("producer", [False, True])
+def test_two_ranks_match_the_sequential_oracle(oracle_mod, s4p_lib_built, producer):
+    import torch.multiprocessing as mp
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, producer, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    O = oracle_mod
+    P, Q, _ = H.small_pair(30000, delta=DELTA, seed=23)
+    om = O.Matcher(O.make_options(DELTA, OVERLAP, N_S))
+    om.init(P, Q)
+    for _ in range(N_WINDOWS * world):
+        om.try_one_base()
+    T, lcp, base, cong, _, _ = om.best()
+    for r in res:
+        assert r[1] == lcp and r[2] == base.tolist() and r[3] == cong.tolist()
+        assert np.array_equal(np.array(r[4], np.float32).reshape(4, 4), T)
+    assert res[0][5] + res[1][5] == om.stats().n_verified        # every candidate verified exactly once, on one rank
+    assert res[0][5] > 0 and res[1][5] > 0
