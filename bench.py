@@ -91,12 +91,21 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback of the product path)")
+    # S4P_BENCH_ONE_GPU=1 (testing only): all ranks share GPU 0 and the 8-byte collective goes over gloo, to exercise
+    # the N>1 code path on a single-GPU box.  The driver's multi-GPU runs use one GPU per rank and RCCL.
+    one_gpu = os.environ.get("S4P_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=dev)     # "nccl" is RCCL on ROCm
+        if one_gpu:
+            dist.init_process_group(backend="gloo")
+            dev = torch.device("cpu")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)     # "nccl" is RCCL on ROCm
 
     from super4pcs_amd import build as B
     if rank == 0 and B.needs_build():
