@@ -14,7 +14,7 @@ LIB = os.path.join(LIBDIR, "libsuper4pcs_amd.so")
 # parity depends on IEEE sqrt and divide.
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
                "-fhip-fp32-correctly-rounded-divide-sqrt", "-fPIC", "-shared", "-Wall", "-Wno-unused-function"]
-SOURCES = ["s4p_capi.hip", "s4p_engine.cpp"]
+SOURCES = ["s4p_capi.hip", "s4p_sampler.hip", "s4p_engine.cpp"]
 
 
 def _hipcc():

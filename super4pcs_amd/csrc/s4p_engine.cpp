@@ -14,6 +14,7 @@
 #include <chrono>
 #include <cmath>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <limits>
@@ -25,6 +26,10 @@
 #include <vector>
 
 #include "s4p_matcher.h"
+
+namespace s4p {
+long long gpu_uniform_dist_sample(const float* x, const float* y, const float* z, long long n, float delta, long long* out_index);
+}
 
 namespace {
 
@@ -58,8 +63,20 @@ struct VoxelHash {
   }
 };
 
+constexpr int64_t kGpuSamplerMin = 32768;
+
 // sampling.h:104-121: first point per delta-voxel, voxel = int(floor(coord * (1.0f / delta))).
+// Large clouds go through the device sampler (s4p_sampler.hip) when a GPU is visible; the host hash below is the
+// same function for small clouds and for facade users that sample before any matcher (hence any device) exists.
 int64_t voxel_first_hits(const float* x, const float* y, const float* z, int64_t n, float delta, int64_t* out) {
+  if (n >= kGpuSamplerMin) {
+    const char* force = std::getenv("S4P_SAMPLER");
+    if (!(force && std::strcmp(force, "host") == 0)) {
+      static_assert(sizeof(long long) == sizeof(int64_t), "index type");
+      const long long k = s4p::gpu_uniform_dist_sample(x, y, z, n, delta, reinterpret_cast<long long*>(out));
+      if (k >= 0) return int64_t(k);
+    }
+  }
   const float scale = 1.0f / delta;
   std::unordered_map<VoxelKey, char, VoxelHash> seen;
   seen.reserve(size_t(n / 4 + 16));

@@ -198,3 +198,21 @@ def test_fused_try_base_matches_oracle_trace(setup):
                 assert list(r.best_quad) == quads[first].tolist()
         total_c += nb
     assert total_c > 0
+
+
+def test_gpu_sampler_equals_host_and_oracle(oracle_mod, s4p_lib_built, monkeypatch):
+    """UniformDistSampler on the device (s4p_sampler.hip) vs the host hash vs the oracle: identical kept indices,
+    in input order, including duplicates, negative coordinates and a ragged size."""
+    from super4pcs_amd import capi, datasets
+    P, Q, _ = datasets.bumpy_pair(300007, 0.5, 0.004, seed=9)
+    X = np.concatenate([P, P[:1000], Q - 0.7]).astype(np.float32)          # exact duplicates + negative octants
+    for delta in (0.004, 0.02):
+        dev = capi.uniform_dist_sample(X, delta)
+        monkeypatch.setenv("S4P_SAMPLER", "host")
+        host = capi.uniform_dist_sample(X, delta)
+        monkeypatch.delenv("S4P_SAMPLER")
+        assert np.array_equal(dev, host) and np.all(np.diff(dev) > 0)
+        assert np.array_equal(X[dev], oracle_mod.sample(X, delta))
+    # coordinates whose voxel index does not fit the 21-bit device key fall back to the host path, same answer
+    Y = (X[:40000] * np.float32(1e7)).astype(np.float32)
+    assert np.array_equal(Y[capi.uniform_dist_sample(Y, 0.004)], oracle_mod.sample(Y, 0.004))
