@@ -447,45 +447,65 @@ int32_t s4p_set_clouds(s4p_ctx* c, const float* px, const float* py, const float
   c->hqx.assign(qx, qx + n_q); c->hqy.assign(qy, qy + n_q); c->hqz.assign(qz, qz + n_q);
   c->frame.build(c->hqx, c->hqy, c->hqz, c->hux, c->huy, c->huz);
   c->tree.reset(c->n_q);
-  if (!c->hgrid.build(c->hpx, c->hpy, c->hpz, c->opt.delta, c->max_grid_cells, kCoarseMaxWords)) S4P_FAIL(c, S4P_ERR_STATE, "LCP grid build failed");
-  {
-    std::vector<uint2> rw(c->hgrid.reach_bits.size());
-    for (size_t w = 0; w < rw.size(); ++w) rw[w] = make_uint2(c->hgrid.reach_bits[w], c->hgrid.reach_prefix[w]);
-    HIPCHK(c, c->greach.alloc(rw.size()));
-    HIPCHK(c, hipMemcpy(c->greach.p, rw.data(), rw.size() * sizeof(uint2), hipMemcpyHostToDevice));
-    HIPCHK(c, c->gnbr.alloc(c->hgrid.nbr.size() / 4));
-    HIPCHK(c, hipMemcpy(c->gnbr.p, c->hgrid.nbr.data(), c->hgrid.nbr.size() * 4, hipMemcpyHostToDevice));
-    std::vector<uint32_t>().swap(c->hgrid.reach_bits); std::vector<uint32_t>().swap(c->hgrid.reach_prefix);
-    std::vector<float>().swap(c->hgrid.nbr);
-  }
-  auto upu = [&](DevBuf<uint32_t>& d, std::vector<uint32_t>& src) -> hipError_t {
-    hipError_t e = d.alloc(src.size()); if (e != hipSuccess) return e;
-    e = hipMemcpy(d.p, src.data(), src.size() * 4, hipMemcpyHostToDevice);
-    std::vector<uint32_t>().swap(src);          // the host mirror is not needed afterwards
-    return e;
-  };
-  {
-    const size_t nr = c->hgrid.reach_cell.size();
-    std::vector<uint4> hdr(nr);
-    for (size_t r = 0; r < nr; ++r) hdr[r] = make_uint4(c->hgrid.list_start[r], c->hgrid.list_start[r + 1] - c->hgrid.list_start[r], 0u, 0u);
-    HIPCHK(c, c->glist_hdr.alloc(nr));
-    HIPCHK(c, hipMemcpy(c->glist_hdr.p, hdr.data(), nr * sizeof(uint4), hipMemcpyHostToDevice));
-    DevBuf<uint32_t> dcell;
-    HIPCHK(c, dcell.alloc(nr));
-    hipError_t e = hipMemcpy(dcell.p, c->hgrid.reach_cell.data(), nr * 4, hipMemcpyHostToDevice);
-    if (e == hipSuccess) {
+  if (!c->hgrid.plan(c->hpx, c->hpy, c->hpz, c->opt.delta, c->max_grid_cells, kCoarseMaxWords)) S4P_FAIL(c, S4P_ERR_STATE, "LCP grid planning failed");
+  {  // device build of the LCP structure (counting formulation, see k_grid_* in s4p_kernels.hip.hpp)
+    hipStream_t st = c->lane[0].stream;
+    const uint64_t nc = c->hgrid.ncell();
+    const uint32_t nwords = uint32_t((nc + 31) / 32);
+    DevBuf<float> dpx, dpy, dpz; DevBuf<uint32_t> cell_count, word_pop, hdr_count, cell_id, cursor, totals;
+    hipError_t e = hipSuccess;
+    int32_t rc = S4P_OK;
+    auto step = [&](hipError_t r) { if (e == hipSuccess) e = r; return e == hipSuccess; };
+    do {
+      if (!step(dpx.alloc(n_p)) || !step(dpy.alloc(n_p)) || !step(dpz.alloc(n_p)) || !step(cell_count.alloc(nc)) ||
+          !step(word_pop.alloc(nwords)) || !step(totals.alloc(2)) || !step(c->greach.alloc(nwords)) || !step(c->gcoarse.alloc(c->hgrid.coarse_words))) break;
+      step(hipMemcpyAsync(dpx.p, c->hpx.data(), n_p * 4, hipMemcpyHostToDevice, st));
+      step(hipMemcpyAsync(dpy.p, c->hpy.data(), n_p * 4, hipMemcpyHostToDevice, st));
+      step(hipMemcpyAsync(dpz.p, c->hpz.data(), n_p * 4, hipMemcpyHostToDevice, st));
+      step(hipMemsetAsync(cell_count.p, 0, nc * 4, st));
+      step(hipMemsetAsync(c->gcoarse.p, 0, size_t(c->hgrid.coarse_words) * 4, st));
+      if (e != hipSuccess) break;
+      GridBuildParams G{};
+      G.px = dpx.p; G.py = dpy.p; G.pz = dpz.p; G.n_p = uint32_t(n_p);
+      G.ox = c->hgrid.ox; G.oy = c->hgrid.oy; G.oz = c->hgrid.oz; G.h = c->hgrid.h; G.inv_h = c->hgrid.inv_h;
+      G.nx = c->hgrid.nx; G.ny = c->hgrid.ny; G.nz = c->hgrid.nz; G.reach2 = c->hgrid.reach * c->hgrid.reach;
+      G.cell_count = cell_count.p; G.reach = c->greach.p; G.n_words = nwords;
+      G.coarse = c->gcoarse.p; G.cshift = c->hgrid.cshift; G.cnx = c->hgrid.cnx; G.cny = c->hgrid.cny;
+      hipLaunchKernelGGL(k_grid_count, dim3(2048), dim3(256), 0, st, G);
+      hipLaunchKernelGGL(k_grid_words, dim3(1024), dim3(256), 0, st, G, word_pop.p);
+      hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, st, word_pop.p, nwords, totals.p);
+      uint32_t n_reach = 0;
+      step(hipMemcpyAsync(&n_reach, totals.p, 4, hipMemcpyDeviceToHost, st));
+      if (!step(hipStreamSynchronize(st))) break;
+      if (n_reach == 0) { c->err = "LCP grid: no reachable cell"; rc = S4P_ERR_STATE; break; }
+      if (!step(hdr_count.alloc(n_reach)) || !step(cell_id.alloc(n_reach)) || !step(cursor.alloc(n_reach)) || !step(c->glist_hdr.alloc(n_reach))) break;
+      G.list_hdr = c->glist_hdr.p; G.cell_id = cell_id.p; G.cursor = cursor.p;
+      hipLaunchKernelGGL(k_grid_headers, dim3(1024), dim3(256), 0, st, G, word_pop.p, hdr_count.p);
+      // list starts = exclusive scan of the per-cell counts (kept: hdr_count -> copy before scanning in place)
+      DevBuf<uint32_t> starts;
+      if (!step(starts.alloc(n_reach))) break;
+      step(hipMemcpyAsync(starts.p, hdr_count.p, size_t(n_reach) * 4, hipMemcpyDeviceToDevice, st));
+      hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, st, starts.p, n_reach, totals.p + 1);
+      uint32_t n_entries = 0;
+      step(hipMemcpyAsync(&n_entries, totals.p + 1, 4, hipMemcpyDeviceToHost, st));
+      if (!step(hipStreamSynchronize(st))) { starts.free(); break; }
+      if (!step(c->gnbr.alloc(n_entries))) { starts.free(); break; }
+      G.nbr = c->gnbr.p;
+      hipLaunchKernelGGL(k_grid_hdr_pack, dim3(1024), dim3(256), 0, st, G, starts.p, hdr_count.p, n_reach);
+      hipLaunchKernelGGL(k_grid_fill, dim3(2048), dim3(256), 0, st, G);
       MaskParams M{};
-      M.list_hdr = c->glist_hdr.p; M.nbr = c->gnbr.p; M.cell_id = dcell.p; M.n_reach = uint32_t(nr);
+      M.list_hdr = c->glist_hdr.p; M.nbr = c->gnbr.p; M.cell_id = cell_id.p; M.n_reach = n_reach;
       M.ox = c->hgrid.ox; M.oy = c->hgrid.oy; M.oz = c->hgrid.oz; M.h = c->hgrid.h; M.nx = c->hgrid.nx; M.ny = c->hgrid.ny;
-      M.reach2 = double(c->hgrid.reach_radius) * double(c->hgrid.reach_radius);
-      hipLaunchKernelGGL(k_build_masks, dim3(uint32_t((nr + 255) / 256)), dim3(256), 0, c->lane[0].stream, M);
-      e = hipStreamSynchronize(c->lane[0].stream);
-    }
-    dcell.free();
+      M.reach2 = G.reach2;
+      hipLaunchKernelGGL(k_build_masks, dim3((n_reach + 255) / 256), dim3(256), 0, st, M);
+      step(hipGetLastError());
+      step(hipStreamSynchronize(st));
+      starts.free();
+    } while (0);
+    dpx.free(); dpy.free(); dpz.free(); cell_count.free(); word_pop.free(); hdr_count.free(); cell_id.free(); cursor.free(); totals.free();
+    if (rc != S4P_OK) return rc;
     HIPCHK(c, e);
-    std::vector<uint32_t>().swap(c->hgrid.list_start); std::vector<uint32_t>().swap(c->hgrid.reach_cell);
   }
-  HIPCHK(c, upu(c->gcoarse, c->hgrid.coarse));
   {
     std::vector<float4> q4((size_t)n_q);
     for (int64_t i = 0; i < n_q; ++i) q4[size_t(i)] = make_float4(qx[i], qy[i], qz[i], 0.f);

@@ -170,26 +170,20 @@ class PairOctree {
 };
 
 // ---------------------------------------------------------------------------
+// Dimensioning of the LCP grid (the structure itself is built on the device, s4p_kernels.hip.hpp k_grid_*).
 struct LcpGridHost {
   float ox = 0, oy = 0, oz = 0, h = 1, inv_h = 1;
   int nx = 1, ny = 1, nz = 1;
   int cshift = 0, cnx = 1, cny = 1, cnz = 1;
-  std::vector<uint32_t> reach_bits;         // cell c reachable: some P point within 1.01*delta of its box
-  std::vector<uint32_t> reach_prefix;       // reachable cells before each bitmap word
-  std::vector<uint32_t> list_start;         // n_reach + 1
-  std::vector<uint32_t> reach_cell;         // linear cell id of the r-th reachable cell
-  float reach_radius = 0.f;                 // 1.01 * delta
-  std::vector<float> nbr;                   // 4 floats per entry (x,y,z,0), grouped by reachable cell
-  std::vector<uint32_t> coarse;             // OR of 2^cshift-cubes of reach_bits; <= max_coarse_words
+  uint32_t coarse_words = 0;
+  double reach = 0;                         // 1.01 * delta
   uint64_t ncell() const { return uint64_t(nx) * uint64_t(ny) * uint64_t(nz); }
 
-  static inline int cell_of(float v, float o, float inv_h) { return int(std::floor((v - o) * inv_h)); }
-
-  // Cell edge h >= 1.002*delta.  A query q is mapped to cell floor((q-o)*inv_h) in float; a P point p
-  // with |q-p| <= delta then satisfies dist(p, box(cell)) <= delta + rounding slack, so it is listed
-  // for that cell by the 1.01*delta reach test below (slack 1e-2*delta >> float rounding of the cell map).
-  bool build(const std::vector<float>& px, const std::vector<float>& py, const std::vector<float>& pz,
-             float delta, uint64_t max_cells, uint32_t max_coarse_words) {
+  // Cell edge h >= 1.002*delta.  A query q is mapped to cell floor((q-o)*inv_h) in float; a P point p with
+  // |q-p| <= delta then satisfies dist(p, box(cell)) <= delta + rounding slack, so it is listed for that cell by the
+  // 1.01*delta reach test (slack 1e-2*delta >> float rounding of the cell map).  One cell of padding on every side.
+  bool plan(const std::vector<float>& px, const std::vector<float>& py, const std::vector<float>& pz,
+            float delta, uint64_t max_cells, uint32_t max_coarse_words) {
     const size_t n = px.size();
     if (n == 0) return false;
     float lo[3] = {px[0], py[0], pz[0]}, hi[3] = {px[0], py[0], pz[0]};
@@ -210,60 +204,13 @@ struct LcpGridHost {
     }
     inv_h = 1.0f / h;
     ox = lo[0] - 1.5f * h; oy = lo[1] - 1.5f * h; oz = lo[2] - 1.5f * h;
-    const uint64_t nc = ncell();
-    const uint64_t nwords = (nc + 31) / 32;
-    // (cell, point) incidences: point i is listed for every neighbour cell whose box it can reach
-    const double reach = double(delta) * 1.01, reach2 = reach * reach;
-    std::vector<uint64_t> inc;                        // (cell << 32) | point index
-    inc.reserve(n * 8);
-    for (size_t i = 0; i < n; ++i) {
-      const int ix = cell_of(px[i], ox, inv_h), iy = cell_of(py[i], oy, inv_h), iz = cell_of(pz[i], oz, inv_h);
-      if (ix < 1 || iy < 1 || iz < 1 || ix >= nx - 1 || iy >= ny - 1 || iz >= nz - 1) return false;   // cannot happen by construction
-      const double p[3] = {px[i], py[i], pz[i]};
-      for (int dz = -1; dz <= 1; ++dz) for (int dy = -1; dy <= 1; ++dy) for (int dx = -1; dx <= 1; ++dx) {
-        const int c[3] = {ix + dx, iy + dy, iz + dz};
-        const double o[3] = {ox, oy, oz};
-        double d2 = 0;
-        for (int k = 0; k < 3; ++k) {
-          const double blo = o[k] + double(c[k]) * double(h), bhi = blo + double(h);
-          const double d = p[k] < blo ? blo - p[k] : (p[k] > bhi ? p[k] - bhi : 0.0);
-          d2 += d * d;
-        }
-        if (d2 <= reach2) inc.push_back(((uint64_t(c[2]) * ny + c[1]) * nx + c[0]) << 32 | uint64_t(i));
-      }
-    }
-    std::sort(inc.begin(), inc.end());
-    reach_bits.assign(nwords, 0u);
-    list_start.clear(); reach_cell.clear();
-    reach_radius = float(reach);
-    nbr.resize(inc.size() * 4);
-    uint64_t prev = ~0ull;
-    for (size_t k = 0; k < inc.size(); ++k) {
-      const uint64_t c = inc[k] >> 32; const uint32_t i = uint32_t(inc[k]);
-      if (c != prev) { list_start.push_back(uint32_t(k)); reach_cell.push_back(uint32_t(c)); reach_bits[c >> 5] |= (1u << (c & 31u)); prev = c; }
-      nbr[4 * k] = px[i]; nbr[4 * k + 1] = py[i]; nbr[4 * k + 2] = pz[i]; nbr[4 * k + 3] = 0.f;
-    }
-    list_start.push_back(uint32_t(inc.size()));
-    reach_prefix.resize(nwords);
-    uint32_t run = 0;
-    for (uint64_t w = 0; w < nwords; ++w) { reach_prefix[w] = run; run += uint32_t(__builtin_popcount(reach_bits[w])); }
-    // coarse level: smallest shift whose bitmap fits the LDS budget
-    cshift = 0;
+    reach = double(delta) * 1.01;
+    cshift = 0;      // coarse level: smallest shift whose bitmap fits the LDS budget (padded to 16 B for the staging)
     while (true) {
       cnx = ((nx - 1) >> cshift) + 1; cny = ((ny - 1) >> cshift) + 1; cnz = ((nz - 1) >> cshift) + 1;
       const uint64_t cw = (uint64_t(cnx) * cny * cnz + 31) / 32;
-      if (cw <= max_coarse_words) { coarse.assign((cw + 3) & ~uint64_t(3), 0u); break; }   // padded to 16 B for the LDS staging
+      if (cw <= max_coarse_words) { coarse_words = uint32_t((cw + 3) & ~uint64_t(3)); break; }
       ++cshift;
-    }
-    for (uint64_t w = 0; w < nwords; ++w) {
-      uint32_t bits = reach_bits[w];
-      while (bits) {
-        const int bpos = __builtin_ctz(bits); bits &= bits - 1;
-        const uint64_t c = w * 32 + bpos;
-        const int ix = int(c % uint64_t(nx)), iy = int((c / uint64_t(nx)) % uint64_t(ny)), iz = int(c / (uint64_t(nx) * ny));
-        const uint64_t cc = (uint64_t(iz >> cshift) * cny + (iy >> cshift)) * cnx + (ix >> cshift);
-        coarse[cc >> 5] |= (1u << (cc & 31u));
-      }
     }
     return true;
   }

@@ -128,7 +128,110 @@ __device__ __forceinline__ bool fine_test(const LcpGrid& g, float tx, float ty, 
   return false;
 }
 
-// One-off (s4p_set_clouds): fills hdr.z/.w, the 4x4x4 sub-cell reach masks, from the point lists.
+// ---------------------------------------------------------------------------
+// Device build of the LCP structure (s4p_set_clouds; replaces KdTree::finalize, kdtree.h:349-364,554-635).
+// Counting formulation, no sort: (1) count (cell, point) incidences into a dense per-cell array, (2) per 32-cell
+// word: reach bits + popcount, (3) scan -> rank prefix, (4) per reachable cell: header count + cell id, (5) scan ->
+// list starts, (6) second incidence pass fills the lists through per-cell cursors, (7) sub-cell masks, coarse bitmap.
+// The order of the points inside a list is whatever the atomics produce; the predicate "some listed point within
+// delta" does not depend on it.
+// ---------------------------------------------------------------------------
+struct GridBuildParams {
+  const float* px; const float* py; const float* pz; uint32_t n_p;
+  float ox, oy, oz, h, inv_h; int nx, ny, nz; double reach2;
+  uint32_t* cell_count;          // dense, one per cell (temporary)
+  uint2* reach; uint32_t n_words;
+  uint4* list_hdr; uint32_t* cell_id; uint32_t* cursor; float4* nbr;
+  uint32_t* coarse; int cshift, cnx, cny;
+};
+
+// incidence (point i, neighbour k of its cell): true if the point can reach that cell's box
+__device__ __forceinline__ bool grid_incidence(const GridBuildParams& P, uint32_t i, int k, uint32_t& cell) {
+  const float x = P.px[i], y = P.py[i], z = P.pz[i];
+  const int ix = int(floorf((x - P.ox) * P.inv_h)) + (k % 3) - 1, iy = int(floorf((y - P.oy) * P.inv_h)) + ((k / 3) % 3) - 1,
+            iz = int(floorf((z - P.oz) * P.inv_h)) + (k / 9) - 1;
+  if (ix < 0 || iy < 0 || iz < 0 || ix >= P.nx || iy >= P.ny || iz >= P.nz) return false;
+  const double v[3] = {double(x), double(y), double(z)};
+  const double lo[3] = {double(P.ox) + double(ix) * double(P.h), double(P.oy) + double(iy) * double(P.h), double(P.oz) + double(iz) * double(P.h)};
+  double d2 = 0;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) { const double hi = lo[a] + double(P.h); const double d = v[a] < lo[a] ? lo[a] - v[a] : (v[a] > hi ? v[a] - hi : 0.0); d2 += d * d; }
+  cell = (uint32_t(iz) * uint32_t(P.ny) + uint32_t(iy)) * uint32_t(P.nx) + uint32_t(ix);
+  return d2 <= P.reach2;
+}
+__global__ __launch_bounds__(256) void k_grid_count(GridBuildParams P) {
+  const uint64_t total = uint64_t(P.n_p) * 27u;
+  for (uint64_t t = blockIdx.x * uint64_t(blockDim.x) + threadIdx.x; t < total; t += uint64_t(gridDim.x) * blockDim.x) {
+    uint32_t cell;
+    if (grid_incidence(P, uint32_t(t / 27u), int(t % 27u), cell)) atomicAdd(&P.cell_count[cell], 1u);
+  }
+}
+__global__ __launch_bounds__(256) void k_grid_words(GridBuildParams P, uint32_t* word_pop) {
+  for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < P.n_words; w += gridDim.x * blockDim.x) {
+    uint32_t bits = 0;
+    const uint64_t ncell = uint64_t(P.nx) * P.ny * P.nz;
+    for (uint32_t b = 0; b < 32; ++b) { const uint64_t c = uint64_t(w) * 32u + b; if (c < ncell && P.cell_count[c] != 0u) bits |= (1u << b); }
+    P.reach[w].x = bits;
+    word_pop[w] = uint32_t(__popc(bits));
+  }
+}
+// single-workgroup exclusive scan of n values (in place); *total = sum.  n up to a few million (one-off use).
+__global__ __launch_bounds__(1024) void k_scan_exclusive(uint32_t* v, uint32_t n, uint32_t* total) {
+  __shared__ uint32_t s_part[1024];
+  const uint32_t per = (n + 1023u) / 1024u;
+  const uint32_t b0 = min(threadIdx.x * per, n), b1 = min(b0 + per, n);
+  uint32_t sum = 0;
+  for (uint32_t b = b0; b < b1; ++b) sum += v[b];
+  s_part[threadIdx.x] = sum;
+  __syncthreads();
+  for (uint32_t off = 1; off < 1024; off <<= 1) {
+    const uint32_t t = threadIdx.x >= off ? s_part[threadIdx.x - off] : 0u;
+    __syncthreads();
+    s_part[threadIdx.x] += t;
+    __syncthreads();
+  }
+  uint32_t run = s_part[threadIdx.x] - sum;
+  for (uint32_t b = b0; b < b1; ++b) { const uint32_t c = v[b]; v[b] = run; run += c; }
+  if (threadIdx.x == 1023) *total = s_part[1023];
+}
+__global__ __launch_bounds__(256) void k_grid_headers(GridBuildParams P, const uint32_t* word_prefix, uint32_t* hdr_count) {
+  for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < P.n_words; w += gridDim.x * blockDim.x) {
+    uint32_t bits = P.reach[w].x, rank = word_prefix[w];
+    P.reach[w].y = rank;
+    while (bits) {
+      const uint32_t b = uint32_t(__ffs(int(bits))) - 1u; bits &= bits - 1u;
+      const uint32_t c = w * 32u + b;
+      hdr_count[rank] = P.cell_count[c];
+      P.cell_id[rank] = c;
+      // coarse level: OR of the 2^cshift-cubes
+      const int ix = int(c % uint32_t(P.nx)), iy = int((c / uint32_t(P.nx)) % uint32_t(P.ny)), iz = int(c / (uint32_t(P.nx) * uint32_t(P.ny)));
+      const uint32_t cc = (uint32_t(iz >> P.cshift) * uint32_t(P.cny) + uint32_t(iy >> P.cshift)) * uint32_t(P.cnx) + uint32_t(ix >> P.cshift);
+      atomicOr(&P.coarse[cc >> 5], 1u << (cc & 31u));
+      ++rank;
+    }
+  }
+}
+__global__ __launch_bounds__(256) void k_grid_hdr_pack(GridBuildParams P, const uint32_t* list_start, const uint32_t* hdr_count, uint32_t n_reach) {
+  for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n_reach; r += gridDim.x * blockDim.x) {
+    P.list_hdr[r] = make_uint4(list_start[r], hdr_count[r], 0u, 0u);
+    P.cursor[r] = 0u;
+  }
+}
+__global__ __launch_bounds__(256) void k_grid_fill(GridBuildParams P) {
+  const uint64_t total = uint64_t(P.n_p) * 27u;
+  for (uint64_t t = blockIdx.x * uint64_t(blockDim.x) + threadIdx.x; t < total; t += uint64_t(gridDim.x) * blockDim.x) {
+    uint32_t cell;
+    const uint32_t i = uint32_t(t / 27u);
+    if (grid_incidence(P, i, int(t % 27u), cell)) {
+      const uint2 w = P.reach[cell >> 5];
+      const uint32_t rank = w.y + uint32_t(__popc(w.x & ((1u << (cell & 31u)) - 1u)));
+      const uint32_t at = P.list_hdr[rank].x + atomicAdd(&P.cursor[rank], 1u);
+      P.nbr[at] = make_float4(P.px[i], P.py[i], P.pz[i], 0.f);
+    }
+  }
+}
+
+// Fills hdr.z/.w, the 4x4x4 sub-cell reach masks, from the point lists.
 // bit(sx,sy,sz) = some listed point lies within `reach` of the sub-box; double precision, same slack as the lists.
 struct MaskParams {
   uint4* list_hdr; const float4* nbr; const uint32_t* cell_id; uint32_t n_reach;
