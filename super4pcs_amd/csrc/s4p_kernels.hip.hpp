@@ -275,10 +275,8 @@ __device__ __forceinline__ uint32_t wave_lcp_count(const LcpGrid& g, const uint3
   uint32_t cnt = 0, qn = 0;
   const uint32_t cmax = g.coarse_words * 32u - 1u;
   const uint32_t unx = uint32_t(g.nx), uny = uint32_t(g.ny), unz = uint32_t(g.nz);
-  for (uint32_t base = 0; base < n_q; base += 64) {
-    const uint32_t i = base + lane;
-    // Branch-free L0 test (the nested bounds checks of a short-circuit version cost more issue slots than the math).
-    const float4 q = q4[min(i, n_q - 1u)];
+  // One 64-query chunk: branch-free L0 test, ballot compaction into the queue, drain 64 survivors when available.
+  auto chunk = [&](const float4 q, const uint32_t i) {
     // (mat * q.homogeneous()).head<3>() : ((m0*x + m1*y) + m2*z) + m3   (match4pcsBase.cc:532)
     const float tx = ((T[0] * q.x + T[1] * q.y) + T[2] * q.z) + T[3];
     const float ty = ((T[4] * q.x + T[5] * q.y) + T[6] * q.z) + T[7];
@@ -307,6 +305,20 @@ __device__ __forceinline__ uint32_t wave_lcp_count(const LcpGrid& g, const uint3
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       __builtin_amdgcn_wave_barrier();
     }
+  };
+  // The sweep is latency-bound (one dependent L2 round trip per 64 queries and wave): issue the loads of four
+  // chunks back to back, then work through them, so four round trips overlap instead of queueing up.
+  const uint32_t last = n_q - 1u;
+  for (uint32_t base = 0; base < n_q; base += 256) {
+    const uint32_t i0 = base + lane, i1 = i0 + 64u, i2 = i0 + 128u, i3 = i0 + 192u;
+    const float4 q0 = q4[min(i0, last)];
+    const float4 q1 = q4[min(i1, last)];
+    const float4 q2 = q4[min(i2, last)];
+    const float4 q3 = q4[min(i3, last)];
+    chunk(q0, i0);
+    if (base + 64u < n_q) chunk(q1, i1);
+    if (base + 128u < n_q) chunk(q2, i2);
+    if (base + 192u < n_q) chunk(q3, i3);
   }
   if (lane < qn) {
     const float x = s_queue[3 * lane], y = s_queue[3 * lane + 1], z = s_queue[3 * lane + 2];
@@ -462,7 +474,7 @@ __global__ __launch_bounds__(256) void k_gate(VerifyParams P) {
 // device memory: no host round trip).
 // LDS: coarse bitmap (<= 48 KB) + 8 private survivor queues (1.5 KB each).
 template <bool COUNT>
-__global__ __launch_bounds__(kVerifyThreads) void k_verify(VerifyParams P) {
+__global__ __launch_bounds__(kVerifyThreads, 8) void k_verify(VerifyParams P) {   // 8 waves/SIMD: two 1024-thread workgroups per CU
   extern __shared__ uint32_t s_mem[];
   uint32_t* s_coarse = s_mem;
   float* s_queue = reinterpret_cast<float*>(s_mem + P.grid.coarse_words) + (threadIdx.x >> 6) * (3 * kQueueEntries);
