@@ -119,11 +119,13 @@ __device__ __forceinline__ bool fine_test(const LcpGrid& g, float tx, float ty, 
   if (!((mword >> (sb & 31u)) & 1u)) return false;
   if (COUNT) atomicAdd(point_tests + 3, 1ull);     // l2_pass
   const uint32_t s = hdr.x, e = hdr.x + hdr.y;
-  for (uint32_t p = s; p < e; ++p) {
-    const float4 pp = g.nbr[p];
-    const float dx = tx - pp.x, dy = ty - pp.y, dz = tz - pp.z;
-    if (COUNT) atomicAdd(point_tests, 1ull);
-    if (sqn3(dx, dy, dz) <= g.sq_eps) return true;          // kdtree.h:417-421  sqdist <= cl_dist
+  for (uint32_t p = s; p < e; p += 2) {                       // two independent 16 B loads per dependent step
+    const float4 pa = g.nbr[p];                               // (four per step spills at the 64-VGPR budget: 44 M vs 61 M cand/s)
+    const float4 pb = g.nbr[min(p + 1u, e - 1u)];
+    if (COUNT) atomicAdd(point_tests, (p + 1u < e) ? 2ull : 1ull);
+    const bool ha = sqn3(tx - pa.x, ty - pa.y, tz - pa.z) <= g.sq_eps;   // kdtree.h:417-421  sqdist <= cl_dist
+    const bool hb = sqn3(tx - pb.x, ty - pb.y, tz - pb.z) <= g.sq_eps;
+    if (ha | hb) return true;
   }
   return false;
 }
