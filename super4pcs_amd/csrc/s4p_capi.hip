@@ -67,7 +67,7 @@ struct s4p_ctx {
     DevBuf<int4> quads; DevBuf<unsigned long long> tags; DevBuf<uint32_t> counts, cand_idx; DevBuf<float4> cand_T;
     DevBuf<unsigned long long> ht_keys, ht_heads; uint32_t ht_mask = 0, epoch = 0;
     DevBuf<DevCounters> ctr;
-    DevBuf<uint32_t> seq_id[2], seq_leaf[2]; DevBuf<float4> leaves[2];
+    DevBuf<uint32_t> seq[2];          // device copy of a staged sequence blob (layout: StageSlot)
   };
   static constexpr int kMaxLanes = 4;
   Lane lane[kMaxLanes];
@@ -77,8 +77,11 @@ struct s4p_ctx {
   // written by whoever stages the base (the caller thread, or the engine's octree thread through s4p_stage_base)
   // and read by the H2D copies of s4p_try_base_staged_async; the engine recycles a slot after that base's wait.
   struct StageSlot {
-    PinBuf<uint32_t> seq_id[2], seq_leaf[2]; PinBuf<float4> leaves[2];
+    // one blob per pair set, uploaded with a single copy: seq_id[n_seq] | seq_leaf[n_seq] | pad to 16 B | leaves[n_leaf]
+    PinBuf<uint32_t> seq[2];
     uint32_t n_seq[2] = {0, 0}, n_leaf[2] = {0, 0};
+    static uint32_t leaf_word(uint32_t n_seq) { return (2u * n_seq + 3u) & ~3u; }
+    static size_t blob_words(size_t n_q) { return 2 * n_q + 4 + 4 * n_q; }
     float eps_unit[2] = {0, 0}, n_radius[2] = {0, 0}, distance[2] = {0, 0}, normal_angle[2] = {0, 0};
   };
   static constexpr int kStageSlots = 12;   // 0..5: self-staging of s4p_try_base_async; 6..11: a threaded driver
@@ -137,11 +140,11 @@ void stage_pairs(s4p_ctx* c, int slot, int set, float pair_distance, float pair_
     c->tree.build(c->hux.data(), c->huy.data(), c->huz.data(), c->n_q, nRadius, eps_n, 50);
     c->host_octree_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
   if (!copy) return;
-  st.n_seq[set] = uint32_t(c->tree.seq_id.size()); st.n_leaf[set] = uint32_t(c->tree.leaves.size());
+  st.n_seq[set] = c->tree.n_seq(); st.n_leaf[set] = c->tree.n_leaf();
   st.eps_unit[set] = c->tree.eps_unit; st.n_radius[set] = nRadius; st.distance[set] = pair_distance; st.normal_angle[set] = pair_normals_angle;
-  std::memcpy(st.seq_id[set].p, c->tree.seq_id.data(), st.n_seq[set] * sizeof(uint32_t));
-  std::memcpy(st.seq_leaf[set].p, c->tree.seq_leaf.data(), st.n_seq[set] * sizeof(uint32_t));
-  std::memcpy(st.leaves[set].p, c->tree.leaves.data(), st.n_leaf[set] * sizeof(float4));
+  static_assert(sizeof(Leaf) == sizeof(float4), "leaf records are uploaded as float4");
+  uint32_t* blob = st.seq[set].p;
+  c->tree.flatten(blob, blob + st.n_seq[set], reinterpret_cast<Leaf*>(blob + s4p_ctx::StageSlot::leaf_word(st.n_seq[set])));
 }
 
 // part 2: upload the staged sequence and launch loop 2 + the pair filters (k_pairs).
@@ -151,14 +154,14 @@ int32_t launch_pairs_staged(s4p_ctx* c, int slot, int set, float pair_distance_e
   DevBuf<int2>& ab = set == 0 ? c->lane[c->cur].ab1 : c->lane[c->cur].ab2;
   DevBuf<uint32_t>& okey = set == 0 ? c->lane[c->cur].okey1 : c->lane[c->cur].okey2;
   if (n_seq == 0) return S4P_OK;
-  HIPCHK(c, hipMemcpyAsync(c->lane[c->cur].seq_id[set].p, st.seq_id[set].p, n_seq * sizeof(uint32_t), hipMemcpyHostToDevice, c->lane[c->cur].stream));
-  HIPCHK(c, hipMemcpyAsync(c->lane[c->cur].seq_leaf[set].p, st.seq_leaf[set].p, n_seq * sizeof(uint32_t), hipMemcpyHostToDevice, c->lane[c->cur].stream));
-  HIPCHK(c, hipMemcpyAsync(c->lane[c->cur].leaves[set].p, st.leaves[set].p, n_leaf * sizeof(float4), hipMemcpyHostToDevice, c->lane[c->cur].stream));
+  const uint32_t leaf_word = s4p_ctx::StageSlot::leaf_word(n_seq);
+  uint32_t* dseq = c->lane[c->cur].seq[set].p;
+  HIPCHK(c, hipMemcpyAsync(dseq, st.seq[set].p, (size_t(leaf_word) + 4u * n_leaf) * sizeof(uint32_t), hipMemcpyHostToDevice, c->lane[c->cur].stream));
   PairParams P{};
   P.ux = c->ux.p; P.uy = c->uy.p; P.uz = c->uz.p; P.qx = c->qx.p; P.qy = c->qy.p; P.qz = c->qz.p;
   P.nx = c->has_normals ? c->qnx.p : nullptr; P.ny = c->qny.p; P.nz = c->qnz.p;
   P.cr = c->has_rgb ? c->qcr.p : nullptr; P.cg = c->qcg.p; P.cb = c->qcb.p;
-  P.seq_id = c->lane[c->cur].seq_id[set].p; P.seq_leaf = c->lane[c->cur].seq_leaf[set].p; P.n_seq = n_seq; P.leaves = c->lane[c->cur].leaves[set].p;
+  P.seq_id = dseq; P.seq_leaf = dseq + n_seq; P.n_seq = n_seq; P.leaves = reinterpret_cast<const float4*>(dseq + leaf_word);
   P.n_q = c->n_q; P.nRadius = st.n_radius[set]; P.eps_unit = st.eps_unit[set];
   P.pair_distance = st.distance[set]; P.pair_distance_eps = pair_distance_epsilon; P.pair_normals_angle = st.normal_angle[set];
   P.max_normal_difference = c->opt.max_normal_difference; P.max_color_distance = c->opt.max_color_distance;
@@ -415,10 +418,10 @@ void s4p_destroy(s4p_ctx* c) {
     L.ab1.free(); L.ab2.free(); L.okey1.free(); L.okey2.free(); L.cell1.free(); L.cell2.free();
     L.bucket1.free(); L.next1.free(); L.mask2.free(); L.ew1.free(); L.ew2.free();
     L.quads.free(); L.tags.free(); L.counts.free(); L.cand_idx.free(); L.cand_T.free(); L.ht_keys.free(); L.ht_heads.free(); L.ctr.free();
-    for (int s = 0; s < 2; ++s) { L.seq_id[s].free(); L.seq_leaf[s].free(); L.leaves[s].free(); }
+    for (int s = 0; s < 2; ++s) L.seq[s].free();
   }
   for (auto& h : c->hctr) h.free();
-  for (auto& st : c->stage) for (int s = 0; s < 2; ++s) { st.seq_id[s].free(); st.seq_leaf[s].free(); st.leaves[s].free(); }
+  for (auto& st : c->stage) for (int s = 0; s < 2; ++s) st.seq[s].free();
   c->tbuf.free();
   for (auto& row : c->ev) for (auto& ev : row) if (ev) (void)hipEventDestroy(ev);
   for (auto& ev : c->done) if (ev) (void)hipEventDestroy(ev);
@@ -541,8 +544,8 @@ int32_t s4p_set_clouds(s4p_ctx* c, const float* px, const float* py, const float
   if (c->has_normals) { HIPCHK(c, up(c->qnx, qnx)); HIPCHK(c, up(c->qny, qny)); HIPCHK(c, up(c->qnz, qnz)); }
   if (c->has_rgb) { HIPCHK(c, up(c->qcr, qr)); HIPCHK(c, up(c->qcg, qg)); HIPCHK(c, up(c->qcb, qb)); }
   for (int s = 0; s < 2; ++s) {
-    for (auto& L : c->lane) { HIPCHK(c, L.seq_id[s].alloc(n_q)); HIPCHK(c, L.seq_leaf[s].alloc(n_q)); HIPCHK(c, L.leaves[s].alloc(n_q)); }
-    for (auto& st : c->stage) { HIPCHK(c, st.seq_id[s].alloc(n_q)); HIPCHK(c, st.seq_leaf[s].alloc(n_q)); HIPCHK(c, st.leaves[s].alloc(n_q)); }
+    for (auto& L : c->lane) HIPCHK(c, L.seq[s].alloc(s4p_ctx::StageSlot::blob_words(n_q)));
+    for (auto& st : c->stage) HIPCHK(c, st.seq[s].alloc(s4p_ctx::StageSlot::blob_words(n_q)));
   }
   c->clouds_set = true;
   return S4P_OK;
@@ -756,6 +759,7 @@ int32_t s4p_pair_state_save(const s4p_ctx* c, uint32_t* out) {
 int32_t s4p_pair_state_restore(s4p_ctx* c, const uint32_t* in) {
   if (!c || !in) return S4P_ERR_BAD_ARG;
   std::memcpy(c->tree.ids.data(), in, c->tree.ids.size() * sizeof(uint32_t));
+  c->tree.forget_splits();          // the remembered cell boundaries belong to the permutation being replaced
   return S4P_OK;
 }
 

@@ -19,12 +19,14 @@
 #include <deque>
 #include <limits>
 #include <mutex>
+#include <atomic>
 #include <random>
 #include <string>
 #include <thread>
 #include <unordered_map>
 #include <vector>
 
+#include "s4p_host_structs.hpp"
 #include "s4p_matcher.h"
 
 namespace s4p {
@@ -98,6 +100,8 @@ struct s4p_matcher {
   Cloud Ps, Qs;
   float centroid_p[3] = {0, 0, 0}, centroid_q[3] = {0, 0, 0};
   float p_diameter = 0.f, max_base_diameter = -1.f;
+  std::vector<float> P4;                 // sampled P as (x, y, z, 0) records: one cache line per random draw of the base search
+  s4p::FourthPointIndex fourth;          // block-pruned 4th-point search over the sampled P
   int number_of_trials = 0, current_trial = 0;
   float best_lcp = 0.f; uint32_t best_count = 0;
   float transform[16];
@@ -139,11 +143,22 @@ struct s4p_matcher {
     long consumed = 0;                     // trials handed to the main thread
     std::thread sel, tree;
     std::mutex mu;
-    std::condition_variable cv;
+    // one condition per wait reason: a hand-off wakes only the thread that can use it, and a full queue's
+    // producer is woken at the low-water mark (half empty), not once per item
+    std::condition_variable cv_a_space, cv_a_item, cv_b_space, cv_b_item, cv_slot;
     std::deque<Trial> qa, qb;
+    // == qa.size() / qb.size(), readable without the lock: a starved stage spins on these for a few hundred
+    // microseconds before it sleeps.  (When the launch thread waits on the helpers -- 8 trials per window at
+    // world 8 -- every hand-off to a *sleeping* thread costs the notifier a futex wake + IPI; measured on the MI355X
+    // host that quadrupled the per-trial cost of the chain.  Streaming stages that spin never sleep; when the GPU is
+    // the bottleneck the queues fill up and the helpers sleep on "space", woken once per half queue.)
+    std::atomic<size_t> qa_ready{0}, qb_ready{0};
+    std::atomic<bool> stop_flag{false};
+    static constexpr int kSpinMicros = 250;
     std::vector<int> free_slots;
-    size_t cap_a = 24, cap_b = 4;
+    size_t cap_a = 24, cap_b = 8;          // set_sharding: >= 3 windows of trials, so the helpers run ahead of a whole window
     double select_s = 0;
+    void wake_all() { cv_a_space.notify_all(); cv_a_item.notify_all(); cv_b_space.notify_all(); cv_b_item.notify_all(); cv_slot.notify_all(); }
   } prod;
 
   void set_identity() { for (int i = 0; i < 16; ++i) transform[i] = (i % 5 == 0) ? 1.f : 0.f; }
@@ -195,20 +210,36 @@ double segment_segment(V3 p1, V3 p2, V3 q1, V3 q2, double& inv1, double& inv2) {
   return double(len(r));
 }
 
-// match4pcsBase.cc:185-218
+// match4pcsBase.cc:185-218.  Same draws, same winner as the reference loop, arranged for the producer's serial chain:
+//  * `rng() % n` through an exact multiply-high remainder (n is loop-invariant);
+//  * the area test on the squared cross product first -- sqrt is monotone, so a candidate whose squared area does
+//    not exceed the best one's cannot pass `wide > widest`; the square root is taken only for the few that can.
 bool pick_triangle(s4p_matcher* m, int& b1, int& b2, int& b3) {
-  const int n = int(m->Ps.size());
+  const uint32_t n = uint32_t(m->Ps.size());
   b1 = b2 = b3 = -1;
-  const int first = int(m->rng() % (unsigned long)n);
+  if (n == 0) return false;
+  const uint64_t magic = ~0ull / n + 1ull;                       // exact for every 32-bit dividend
+  auto draw = [&]() {
+    const uint32_t a = uint32_t(m->rng());                       // mt19937 yields 32-bit values
+    return uint32_t((static_cast<unsigned __int128>(magic * a) * n) >> 64);
+  };
+  // all 2001 draws first (the stream does not depend on the points), prefetching the records they address
+  uint32_t idx[2001];
+  const float* P = m->P4.data();
+  for (int t = 0; t < 2001; ++t) { idx[t] = draw(); __builtin_prefetch(P + 4 * size_t(idx[t])); }
+  const uint32_t first = idx[0];
   const float limit = m->max_base_diameter * m->max_base_diameter;
-  float widest = 0.f;
-  const V3 o = m->P(first);
+  float widest = 0.f, widest_sq = 0.f;
+  const V3 o{P[4 * size_t(first)], P[4 * size_t(first) + 1], P[4 * size_t(first) + 2]};
   for (int t = 0; t < 1000; ++t) {
-    const int second = int(m->rng() % (unsigned long)n);
-    const int third = int(m->rng() % (unsigned long)n);
-    const V3 u = sub(m->P(second), o), w = sub(m->P(third), o);
-    const float wide = len(cross(u, w));
-    if (wide > widest && sqn(u) < limit && sqn(w) < limit) { widest = wide; b1 = first; b2 = second; b3 = third; }
+    const uint32_t second = idx[1 + 2 * t], third = idx[2 + 2 * t];
+    const float* ps = P + 4 * size_t(second); const float* pt = P + 4 * size_t(third);
+    const V3 u{ps[0] - o.x, ps[1] - o.y, ps[2] - o.z}, w{pt[0] - o.x, pt[1] - o.y, pt[2] - o.z};
+    const float sq = sqn(cross(u, w));
+    if (!(sq > widest_sq)) continue;
+    if (!(sqn(u) < limit && sqn(w) < limit)) continue;
+    const float wide = std::sqrt(sq);
+    if (wide > widest) { widest = wide; widest_sq = sq; b1 = int(first); b2 = int(second); b3 = int(third); }
   }
   return b1 != -1 && b2 != -1 && b3 != -1;
 }
@@ -235,7 +266,6 @@ bool order_quadrilateral(s4p_matcher* m, int ids[4], float& inv1, float& inv2) {
 // match4pcsBase.cc:279-351
 bool select_quadrilateral(s4p_matcher* m, float& inv1, float& inv2, int ids[4]) {
   const float kBaseTooSmall = 0.2f;
-  const size_t n = m->Ps.size();
   for (int attempt = 0; attempt < 1000; ++attempt) {
     int b1, b2, b3;
     if (!pick_triangle(m, b1, b2, b3)) return false;
@@ -247,34 +277,15 @@ bool select_quadrilateral(s4p_matcher* m, float& inv1, float& inv2, int ids[4]) 
       const float pb = float((x2 * z1 - x3 * z1 - x1 * z2 + x3 * z2 + x1 * z3 - x2 * z3) / denom);
       const float pc = float((-x2 * y1 + x3 * y1 + x1 * y2 - x3 * y2 - x1 * y3 + x2 * y3) / denom);
       int b4 = -1;
-      float best = std::numeric_limits<float>::max();
       const float too_small = float(std::pow(double(m->max_base_diameter * kBaseTooSmall), 2));
-      const float* X = m->Ps.x.data(); const float* Y = m->Ps.y.data(); const float* Z = m->Ps.z.data();
       // Reference loop (match4pcsBase.cc:324-338): among points not closer than too_small (squared) to the three
       // base points, the first one with the strictly smallest plane distance |A x + B y + C z - 1|.
       // The reference evaluates the distance in double, float(|double(v) - 1.0|); for float v that equals the
-      // correctly rounded float |v - 1.0f| (the double difference is exact), so the scan runs in float and
-      // 16-point blocks whose minimum cannot beat the running best are skipped after one vector pass.
-      constexpr size_t kBlk = 16;
-      float dist[kBlk];
-      for (size_t i0 = 0; i0 < n; i0 += kBlk) {
-        const size_t cnt = std::min(kBlk, n - i0);
-        float blockmin = std::numeric_limits<float>::max();
-        for (size_t k = 0; k < cnt; ++k) {
-          const float v = (pa * X[i0 + k] + pb * Y[i0 + k]) + pc * Z[i0 + k];
-          const float d = std::fabs(v - 1.0f);
-          dist[k] = d;
-          blockmin = d < blockmin ? d : blockmin;
-        }
-        if (!(blockmin < best)) continue;
-        for (size_t k = 0; k < cnt; ++k) {
-          if (!(dist[k] < best)) continue;
-          const V3 p{X[i0 + k], Y[i0 + k], Z[i0 + k]};
-          if (sqn(sub(p, A)) >= too_small && sqn(sub(p, B)) >= too_small && sqn(sub(p, C)) >= too_small) {
-            best = dist[k]; b4 = int(i0 + k);
-          }
-        }
-      }
+      // correctly rounded float |v - 1.0f| (the double difference is exact), so the search runs in float, and through
+      // FourthPointIndex, which skips the blocks of P whose bounding box lies further from the plane than the best
+      // point found so far (s4p_host_structs.hpp).
+      const float pA[3] = {A.x, A.y, A.z}, pB[3] = {B.x, B.y, B.z}, pC[3] = {C.x, C.y, C.z};
+      b4 = m->fourth.query(pa, pb, pc, pA, pB, pC, too_small);
       if (b4 != -1) {
         ids[0] = b1; ids[1] = b2; ids[2] = b3; ids[3] = b4;
         if (order_quadrilateral(m, ids, inv1, inv2)) return true;
@@ -309,11 +320,18 @@ void global_transform(const s4p_matcher* m, float* M) {
 
 // ---------------------------------------------------------------------------------------------------------
 // producer threads
+inline void spin_until_ready(const std::atomic<size_t>& ready, const std::atomic<bool>& stop, int micros) {
+  if (ready.load(std::memory_order_acquire) != 0) return;
+  const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(micros);
+  while (ready.load(std::memory_order_acquire) == 0 && !stop.load(std::memory_order_relaxed) && std::chrono::steady_clock::now() < until)
+    for (int k = 0; k < 16; ++k) __builtin_ia32_pause();
+}
+
 void selector_main(s4p_matcher* m) {
   auto& P = m->prod;
   while (true) {
     { std::unique_lock<std::mutex> lk(P.mu);
-      P.cv.wait(lk, [&] { return P.stop || P.qa.size() < P.cap_a; });
+      P.cv_a_space.wait(lk, [&] { return P.stop || P.qa.size() < P.cap_a; });
       if (P.stop) return; }
     s4p_matcher::Trial t;
     t.rng_before = m->rng;
@@ -325,8 +343,9 @@ void selector_main(s4p_matcher* m) {
       t.index = P.next_index++;
       t.owned = (t.index % P.world) == P.rank;
       P.select_s += dt;
-      P.qa.push_back(std::move(t)); }     // pushed even when stopping: nothing that advanced the RNG is ever dropped
-    P.cv.notify_all();
+      P.qa.push_back(std::move(t));       // pushed even when stopping: nothing that advanced the RNG is ever dropped
+      P.qa_ready.store(P.qa.size(), std::memory_order_release); }
+    P.cv_a_item.notify_one();
   }
 }
 
@@ -334,14 +353,18 @@ void tree_main(s4p_matcher* m) {
   auto& P = m->prod;
   while (true) {
     s4p_matcher::Trial t;
+    bool wake_selector = false;
+    spin_until_ready(P.qa_ready, P.stop_flag, s4p_matcher::Producer::kSpinMicros);
     { std::unique_lock<std::mutex> lk(P.mu);
-      P.cv.wait(lk, [&] { return P.stop || !P.qa.empty(); });
+      P.cv_a_item.wait(lk, [&] { return P.stop || !P.qa.empty(); });
       if (P.stop) return;
-      t = std::move(P.qa.front()); P.qa.pop_front(); }
-    P.cv.notify_all();
+      t = std::move(P.qa.front()); P.qa.pop_front();
+      P.qa_ready.store(P.qa.size(), std::memory_order_release);
+      wake_selector = P.qa.size() == P.cap_a / 2; }
+    if (wake_selector) P.cv_a_space.notify_one();
     if (t.found && t.owned) {
       std::unique_lock<std::mutex> lk(P.mu);
-      P.cv.wait(lk, [&] { return P.stop || !P.free_slots.empty(); });
+      P.cv_slot.wait(lk, [&] { return P.stop || !P.free_slots.empty(); });
       if (P.stop) { P.qa.push_front(std::move(t)); return; }     // untouched: goes back to the head of qa
       t.slot = P.free_slots.back(); P.free_slots.pop_back();
     }
@@ -350,16 +373,17 @@ void tree_main(s4p_matcher* m) {
     if (t.found) (void)s4p_stage_base(m->ctx, t.bx, t.bn, t.owned ? 1 : 0, t.owned ? t.slot : 0);
     t.staged = true;
     { std::unique_lock<std::mutex> lk(P.mu);
-      P.cv.wait(lk, [&] { return P.stop || P.qb.size() < P.cap_b; });
-      P.qb.push_back(std::move(t)); }     // also when stopping: its octree effect is already applied
-    P.cv.notify_all();
+      P.cv_b_space.wait(lk, [&] { return P.stop || P.qb.size() < P.cap_b; });
+      P.qb.push_back(std::move(t));       // also when stopping: its octree effect is already applied
+      P.qb_ready.store(P.qb.size(), std::memory_order_release); }
+    P.cv_b_item.notify_one();
   }
 }
 
 void producer_start(s4p_matcher* m) {
   auto& P = m->prod;
   if (P.running) return;
-  P.stop = false;
+  P.stop = false; P.stop_flag.store(false);
   P.free_slots.clear();
   const int nslots = s4p_stage_slots(m->ctx);
   for (int sl = 6; sl < nslots; ++sl) P.free_slots.push_back(sl);      // 0..5 belong to s4p_try_base_async
@@ -374,8 +398,8 @@ void producer_start(s4p_matcher* m) {
 void producer_stop(s4p_matcher* m) {
   auto& P = m->prod;
   if (!P.running) return;
-  { std::lock_guard<std::mutex> lk(P.mu); P.stop = true; }
-  P.cv.notify_all();
+  { std::lock_guard<std::mutex> lk(P.mu); P.stop = true; P.stop_flag.store(true); }
+  P.wake_all();
   P.sel.join(); P.tree.join();
   P.running = false;
   if (!P.qb.empty()) {
@@ -384,25 +408,29 @@ void producer_stop(s4p_matcher* m) {
   } else if (!P.qa.empty()) {
     m->rng = P.qa.front().rng_before;
   }
-  P.qa.clear(); P.qb.clear();
+  P.qa.clear(); P.qb.clear(); P.qa_ready.store(0); P.qb_ready.store(0);
   m->seconds_select += P.select_s; P.select_s = 0;
 }
 
 bool producer_pop(s4p_matcher* m, s4p_matcher::Trial& t) {
   auto& P = m->prod;
   producer_start(m);
+  spin_until_ready(P.qb_ready, P.stop_flag, s4p_matcher::Producer::kSpinMicros);
+  bool wake_tree = false;
   { std::unique_lock<std::mutex> lk(P.mu);
-    P.cv.wait(lk, [&] { return !P.qb.empty(); });
+    P.cv_b_item.wait(lk, [&] { return !P.qb.empty(); });
     t = std::move(P.qb.front()); P.qb.pop_front();
+    P.qb_ready.store(P.qb.size(), std::memory_order_release);
+    wake_tree = P.qb.size() == P.cap_b / 2;
     P.consumed = t.index + 1; }
-  P.cv.notify_all();
+  if (wake_tree) P.cv_b_space.notify_one();
   return true;
 }
 
 void producer_release_slot(s4p_matcher* m, int slot) {
   if (slot < 0) return;
   { std::lock_guard<std::mutex> lk(m->prod.mu); m->prod.free_slots.push_back(slot); }
-  m->prod.cv.notify_all();
+  m->prod.cv_slot.notify_one();
 }
 
 // first half of TryOneBase (match4pcsBase.hpp:281-351): base selection + device pass (or state advance only)
@@ -601,6 +629,14 @@ int32_t s4p_matcher_init(s4p_matcher* m, const s4p_cloud_view* p, const s4p_clou
   m->best_lcp = 0.f; m->best_count = 0;
   for (int t = 0; t < 4; ++t) { m->base[t] = 0; m->congruent[t] = 0; }
   m->set_identity();
+  // host-side search structures of SelectQuadrilateral, built while the device builds its own
+  std::thread host_index([m, &Ps] {
+    const size_t np = Ps.size();
+    m->P4.resize(4 * np);
+    for (size_t i = 0; i < np; ++i) { m->P4[4 * i] = Ps.x[i]; m->P4[4 * i + 1] = Ps.y[i]; m->P4[4 * i + 2] = Ps.z[i]; m->P4[4 * i + 3] = 0.f; }
+    m->fourth.build(Ps.x.data(), Ps.y.data(), Ps.z.data(), np);
+  });
+  struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } join_host_index{host_index};
   // Initialize() -> device structures; then best_LCP_ = Verify(identity)   (:199-201)
   if (int32_t rc = s4p_set_clouds(m->ctx, Ps.x.data(), Ps.y.data(), Ps.z.data(), int64_t(Ps.size()),
                                   Qs.x.data(), Qs.y.data(), Qs.z.data(),
@@ -703,6 +739,8 @@ int32_t s4p_matcher_set_sharding(s4p_matcher* m, int32_t rank, int32_t world, in
   producer_stop(m);
   m->prod.rank = rank; m->prod.world = world; m->prod.enabled = producer_threads != 0;
   m->prod.consumed = 0; m->prod.next_index = 0;
+  m->prod.cap_b = std::max<size_t>(8, 3 * size_t(world));      // the launch thread consumes a window (world trials) at a time
+  m->prod.cap_a = std::max<size_t>(24, 3 * size_t(world));
   return S4P_OK;
 }
 

@@ -8,6 +8,7 @@
 //      so the emission order of call k depends on calls 1..k-1.
 //      Output: the flat "sequence" (leaf-major, position-minor) the k_pairs kernel walks.
 //  * UnitFrame  : PairCreationFunctor::synch3DContent (pairCreationFunctor.h:90-122).
+//  * FourthPointIndex: block-pruned form of the 4th-point scan of SelectQuadrilateral (match4pcsBase.cc:324-338).
 //  * LcpGridHost: uniform grid over the sampled P cloud replacing the kd-tree of
 //      Match4PCSBase::initKdTree (match4pcsBase.cc:353-363); same inlier predicate.
 //
@@ -17,7 +18,9 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <deque>
 #include <limits>
+#include <utility>
 #include <vector>
 
 namespace s4p {
@@ -58,13 +61,14 @@ struct UnitFrame {
 class PairOctree {
  public:
   std::vector<uint32_t> ids;                 // persistent permutation
-  // outputs of build()
-  std::vector<uint32_t> seq_id, seq_leaf;
-  std::vector<Leaf> leaves;
   float eps_unit = 0.f;                      // power-of-two rounded epsilon
   float n_radius = 0.f;
 
-  void reset(uint32_t n) { ids.resize(n); for (uint32_t i = 0; i < n; ++i) ids[i] = i; }
+  void reset(uint32_t n) { ids.resize(n); for (uint32_t i = 0; i < n; ++i) ids[i] = i; forget_splits(); }
+
+  // Must be called whenever `ids` is overwritten from outside (state restore): the remembered splits describe
+  // the permutation they were made on.
+  void forget_splits() { memo_.clear(); shells_.clear(); shell_words_ = 0; }
 
   // GetRoundedEpsilonValue, intersectionFunctor.h:59-67
   static float rounded_epsilon(float eps, int* lvl) {
@@ -73,6 +77,8 @@ class PairOctree {
     return float(1.f / std::pow(2, lvlMax));
   }
 
+  // Loop 1: refines the tree and permutes `ids`.  The leaves stay in nxt_/early_ until flatten() is asked for them
+  // (a rank that only advances the permutation for a base it does not own never flattens).
   void build(const float* ux, const float* uy, const float* uz, uint32_t n, float radius_unit, float eps_in,
              uint32_t min_node_size = 50) {
     u_[0] = ux; u_[1] = uy; u_[2] = uz;
@@ -81,7 +87,8 @@ class PairOctree {
     eps_unit = rounded_epsilon(eps_in, &lvlMax);
     if (ids.size() != n) reset(n);                                // intersectionFunctor.h:139-144
     cur_.clear(); nxt_.clear(); early_.clear();
-    nxt_.push_back(Node{{0.5f, 0.5f, 0.5f}, 0u, n});              // buildUnitRootNode
+    if (memo_.empty()) memo_.push_back(Memo{});
+    nxt_.push_back(Node{{0.5f, 0.5f, 0.5f}, 0u, n, 0});           // buildUnitRootNode
     int lvl = 0;
     while (lvl != lvlMax - 1) {                                   // first loop, :154-191
       if (nxt_.empty()) break;
@@ -91,31 +98,113 @@ class PairOctree {
       nxt_.clear();
       const float reach = half + eps_unit;
       for (const Node& nd : cur_) {
-        bool hit = false;
-        for (uint32_t p = 0; p < n && !hit; ++p) hit = sphere_touches_box(ux[p], uy[p], uz[p], radius_unit, nd.c, reach);
-        if (!hit) continue;
+        if (!any_sphere_touches(nd, n, radius_unit, reach)) continue;
         if (int(nd.end) - int(nd.begin) > int(min_node_size)) split8(nd, half);
         else early_.push_back(EarlyNode{nd, reach});
       }
       ++lvl;
     }
-    // flatten: final-level children first, then the parked early leaves (second loop order, :201-232)
-    leaves.clear(); seq_id.clear(); seq_leaf.clear();
+    n_seq_ = 0;
+    for (const Node& nd : nxt_) n_seq_ += nd.end - nd.begin;
+    for (const EarlyNode& en : early_) n_seq_ += en.node.end - en.node.begin;
+  }
+
+  uint32_t n_seq() const { return n_seq_; }
+  uint32_t n_leaf() const { return uint32_t(nxt_.size() + early_.size()); }
+
+  // The flat "sequence" k_pairs walks: final-level children first, then the parked early leaves
+  // (second loop order, intersectionFunctor.h:201-232).  seq_id/seq_leaf hold n_seq() entries, leaves n_leaf().
+  void flatten(uint32_t* seq_id, uint32_t* seq_leaf, Leaf* leaves) const {
+    uint32_t li = 0, at = 0;
     auto emit = [&](const Node& nd, float h) {
-      const uint32_t li = uint32_t(leaves.size());
-      leaves.push_back(Leaf{nd.c[0], nd.c[1], nd.c[2], h});
-      for (uint32_t k = nd.begin; k < nd.end; ++k) { seq_id.push_back(ids[k]); seq_leaf.push_back(li); }
+      leaves[li] = Leaf{nd.c[0], nd.c[1], nd.c[2], h};
+      for (uint32_t k = nd.begin; k < nd.end; ++k, ++at) { seq_id[at] = ids[k]; seq_leaf[at] = li; }
+      ++li;
     };
     for (const Node& nd : nxt_) emit(nd, eps_unit * 2.f);
     for (const EarlyNode& en : early_) emit(en.node, en.reach);
   }
 
  private:
-  struct Node { float c[3]; uint32_t begin, end; };
+  struct Node { float c[3]; uint32_t begin, end; int32_t memo; };
+  // Cell centres never change and `ids` persists, so the FIRST split of a cell fixes its eight child ranges for
+  // good: children only permute inside their own ranges, and the reference's two-pointer partition of an already
+  // partitioned range swaps nothing and returns the same cut (l stops at the cut, r just below it, `l > r` breaks,
+  // intersectionNode.h:156-176).  Later splits of that cell therefore replay the remembered boundaries instead of
+  // re-scanning the points: same `ids`, same children, a build costs the sphere/box tests only.
+  struct Memo { bool split = false; int32_t shell = -1; uint32_t bound[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}; int32_t child[8] = {-1, -1, -1, -1, -1, -1, -1, -1}; };
+  std::vector<Memo> memo_;
+
+  // "Does ANY primitive sphere touch this cell?" (the p-loop of intersectionFunctor.h:163-188 only needs existence).
+  // The sphere centres are the cloud's own points and never move, and a cell's centre never moves either, so each
+  // cell keeps the points binned by their distance to its centre (built the first time the cell is tested).  A sphere
+  // of radius r can only touch a box of inflated half-edge h if its centre lies within sqrt(3) h of distance r from
+  // the box centre, so only the bins of that shell are tested -- nearest-to-r first -- with the exact predicate;
+  // everything outside the shell fails it by construction (the margin below is ~1000x the float rounding of either
+  // side).  On the benchmark cloud this turns ~7200 sphere/box tests per build into a few hundred.
+  static constexpr int kShellBins = 128;
+  static constexpr float kShellWidth = 1.75f / kShellBins;      // unit cube: distances < sqrt(3)
+  struct Shells { std::vector<uint32_t> order; uint32_t start[kShellBins + 1]; };
+  std::deque<Shells> shells_;
+  size_t shell_words_ = 0;
+  static constexpr size_t kShellBudgetWords = size_t(16) << 20;  // 64 MB of bins at most; beyond that: plain loop
+
+  static int shell_bin(float d) { const int b = int(d * (1.0f / kShellWidth)); return b < 0 ? 0 : (b >= kShellBins ? kShellBins - 1 : b); }
+
+  void build_shells(Memo& mm, const float* c, uint32_t n) {
+    if (shell_words_ + n > kShellBudgetWords) return;
+    shells_.emplace_back();
+    Shells& sh = shells_.back();
+    std::vector<uint8_t> bin(n);
+    for (int b = 0; b <= kShellBins; ++b) sh.start[b] = 0;
+    for (uint32_t p = 0; p < n; ++p) {
+      const float dx = u_[0][p] - c[0], dy = u_[1][p] - c[1], dz = u_[2][p] - c[2];
+      const float d = std::sqrt(dx * dx + dy * dy + dz * dz);
+      bin[p] = uint8_t(d == d ? shell_bin(d) : kShellBins - 1);
+      ++sh.start[bin[p] + 1];
+    }
+    for (int b = 1; b <= kShellBins; ++b) sh.start[b] += sh.start[b - 1];
+    sh.order.resize(n);
+    uint32_t at[kShellBins];
+    for (int b = 0; b < kShellBins; ++b) at[b] = sh.start[b];
+    for (uint32_t p = 0; p < n; ++p) sh.order[at[bin[p]]++] = p;
+    shell_words_ += n;
+    mm.shell = int32_t(shells_.size() - 1);
+  }
+
+  bool any_sphere_touches(const Node& nd, uint32_t n, float r, float reach) {
+    const float* ux = u_[0]; const float* uy = u_[1]; const float* uz = u_[2];
+    Memo& mm = memo_[size_t(nd.memo)];
+    if (mm.shell < 0) build_shells(mm, nd.c, n);
+    const float D = 1.7320508f * reach + 1e-3f;
+    if (mm.shell < 0 || !(r == r) || !(D == D) || shells_[size_t(mm.shell)].order.size() != n) {
+      for (uint32_t p = 0; p < n; ++p) if (sphere_touches_box(ux[p], uy[p], uz[p], r, nd.c, reach)) return true;
+      return false;
+    }
+    const Shells& sh = shells_[size_t(mm.shell)];
+    // bins are taken one wider than the shell on either side; the last bin also holds everything beyond 1.75
+    const int b_lo = r - D <= 0.f ? 0 : std::max(0, shell_bin(r - D) - 1);
+    const int b_hi = std::min(kShellBins - 1, shell_bin(r + D) + 1);
+    const int bc = std::min(b_hi, std::max(b_lo, shell_bin(r)));
+    auto test_bin = [&](int b) {
+      for (uint32_t k = sh.start[b]; k < sh.start[b + 1]; ++k) {
+        const uint32_t p = sh.order[k];
+        if (sphere_touches_box(ux[p], uy[p], uz[p], r, nd.c, reach)) return true;
+      }
+      return false;
+    };
+    const int span = std::max(bc - b_lo, b_hi - bc);
+    for (int k = 0; k <= span; ++k) {
+      if (bc + k <= b_hi && test_bin(bc + k)) return true;
+      if (k > 0 && bc - k >= b_lo && test_bin(bc - k)) return true;
+    }
+    return false;
+  }
   struct EarlyNode { Node node; float reach; };
   const float* u_[3] = {nullptr, nullptr, nullptr};
   std::vector<Node> cur_, nxt_;
   std::vector<EarlyNode> early_;
+  uint32_t n_seq_ = 0;
 
   // HyperSphere::intersect, intersectionPrimitive.h:117-142 (Arvo box/sphere-surface test)
   static bool sphere_touches_box(float cx, float cy, float cz, float r, const float* nc, float h) {
@@ -132,7 +221,10 @@ class PairOctree {
     return (lo_t[0] + (lo_t[1] + lo_t[2])) < r2 && r2 < (hi_t[0] + (hi_t[1] + hi_t[2]));
   }
 
-  // NdNode::_split, intersectionNode.h:156-176: in-place partition of ids[start,end) around v on axis d
+  // NdNode::_split, intersectionNode.h:156-176: in-place partition of ids[start,end) around v on axis d.
+  // (`ids` persists across builds and the cell centres never change, so after the first few bases every range
+  // arrives almost partitioned and this two-pointer scan is branch-predictable; a branch-free count/collect/swap
+  // formulation was measured 2x slower on such input.)
   uint32_t partition(int start, int end, unsigned d, float v) {
     const float* a = u_[d];
     int l = start, r = end - 1;
@@ -152,6 +244,7 @@ class PairOctree {
     Node ch[8];
     for (auto& c : ch) c = parent;
     const float q = parent_half / 2.f;
+    const bool known = memo_[size_t(parent.memo)].split;
     for (unsigned d = 0; d < 3; ++d) {
       const unsigned n_split = 1u << d;         // nbInterval/2
       const unsigned span = 8u / n_split;       // intervalNode
@@ -159,14 +252,146 @@ class PairOctree {
       for (unsigned s = 0; s < n_split; ++s) {
         const unsigned b = s * span, e = (s + 1) * span;
         const float centre = ch[b].c[d];
-        const uint32_t cut = partition(int(ch[b].begin), int(ch[e - 1].end), d, centre);
+        const uint32_t cut = known ? memo_[size_t(parent.memo)].bound[b + mid]
+                                   : partition(int(ch[b].begin), int(ch[e - 1].end), d, centre);
         const float lo = centre - q, hi = centre + q;
         for (unsigned i = b; i < b + mid; ++i) { ch[i].c[d] = lo; ch[i].end = cut; }
         for (unsigned i = b + mid; i < e; ++i) { ch[i].c[d] = hi; ch[i].begin = cut; }
       }
     }
-    for (const Node& c : ch) if (c.end != c.begin) nxt_.push_back(c);
+    if (!known) {
+      Memo& mm = memo_[size_t(parent.memo)];
+      for (unsigned i = 0; i < 8; ++i) mm.bound[i] = ch[i].begin;
+      mm.bound[8] = ch[7].end;
+      mm.split = true;
+    }
+    for (unsigned i = 0; i < 8; ++i) {
+      if (ch[i].end == ch[i].begin) continue;
+      int32_t cm = memo_[size_t(parent.memo)].child[i];
+      if (cm < 0) { cm = int32_t(memo_.size()); memo_.push_back(Memo{}); memo_[size_t(parent.memo)].child[i] = cm; }
+      ch[i].memo = cm;
+      nxt_.push_back(ch[i]);
+    }
   }
+};
+
+// ---------------------------------------------------------------------------
+// FourthPointIndex: the 4th-point search of SelectQuadrilateral (match4pcsBase.cc:324-338) without touching every
+// sampled P point.  The reference walks all of P for the point with the smallest |a x + b y + c z - 1| that is not
+// within `too_small` of the three base points; the first index wins ties.  Here P is kept a second time in Morton
+// order, in blocks of 32 points with their bounding boxes: a block whose box cannot come closer to the plane than the
+// best distance found so far is skipped after one interval evaluation, so a query reads the ~5 % of P that lies near
+// the plane.  The per-point distance is the same float expression as the linear scan, and the winner is the
+// lexicographic minimum of (distance, original index) -- exactly the first strictly smaller distance in index order.
+// The box bound is relaxed by a margin far above the float rounding of either evaluation, so no block that could
+// hold the winner (or a tie) is ever skipped.
+class FourthPointIndex {
+ public:
+  static constexpr uint32_t kBlock = 32;
+  bool empty() const { return n_ == 0; }
+
+  void build(const float* x, const float* y, const float* z, size_t n) {
+    n_ = n;
+    nb_ = (n + kBlock - 1) / kBlock;
+    float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+    for (size_t i = 0; i < n; ++i) {
+      const float v[3] = {x[i], y[i], z[i]};
+      for (int k = 0; k < 3; ++k) { if (i == 0 || v[k] < lo[k]) lo[k] = v[k]; if (i == 0 || v[k] > hi[k]) hi[k] = v[k]; }
+    }
+    for (int k = 0; k < 3; ++k) absmax_[k] = std::max(std::fabs(lo[k]), std::fabs(hi[k]));
+    // spatial order: counting sort by the Morton code of a coarse grid cell (about four points per cell), input
+    // order kept inside a cell -- O(n), a fraction of a millisecond where a comparison sort took several
+    int bits = 3;
+    while (bits < 7 && (size_t(1) << (3 * (bits + 1))) <= n / 4 + 1) ++bits;
+    const float cells = float(1u << bits);
+    auto spread = [](uint32_t v) { v &= 0x3FFu; v = (v | (v << 16)) & 0x030000FFu; v = (v | (v << 8)) & 0x0300F00Fu;
+                                   v = (v | (v << 4)) & 0x030C30C3u; v = (v | (v << 2)) & 0x09249249u; return v; };
+    std::vector<uint32_t> code(n), start((size_t(1) << (3 * bits)) + 1, 0u), order(n);
+    float scale[3];
+    for (int k = 0; k < 3; ++k) scale[k] = hi[k] > lo[k] ? cells / (hi[k] - lo[k]) : 0.f;
+    for (size_t i = 0; i < n; ++i) {
+      uint32_t q[3];
+      const float v[3] = {x[i], y[i], z[i]};
+      for (int k = 0; k < 3; ++k) {
+        const float t = (v[k] - lo[k]) * scale[k];
+        q[k] = uint32_t(std::min(cells - 1.f, std::max(0.f, t)));       // NaN -> 0
+      }
+      code[i] = spread(q[0]) | (spread(q[1]) << 1) | (spread(q[2]) << 2);
+      ++start[code[i] + 1];
+    }
+    for (size_t c = 1; c < start.size(); ++c) start[c] += start[c - 1];
+    for (size_t i = 0; i < n; ++i) order[start[code[i]]++] = uint32_t(i);
+    const size_t padded = nb_ * kBlock;
+    bx_.assign(padded, 0.f); by_.assign(padded, 0.f); bz_.assign(padded, 0.f); bi_.assign(padded, 0xFFFFFFFFu);
+    for (int k = 0; k < 3; ++k) { blo_[k].assign(nb_, 0.f); bhi_[k].assign(nb_, 0.f); }
+    for (size_t b = 0; b < nb_; ++b) {
+      const size_t s = b * kBlock, e = std::min(n, s + kBlock);
+      for (size_t k = s; k < padded && k < s + kBlock; ++k) {
+        const uint32_t src = order[std::min(k, e - 1)];      // pad the last block with copies of a real point
+        bx_[k] = x[src]; by_[k] = y[src]; bz_[k] = z[src];
+        bi_[k] = k < e ? src : 0xFFFFFFFFu;                          // ...that can never win (index = +inf)
+      }
+      for (size_t k = s; k < e; ++k) {
+        const float v[3] = {bx_[k], by_[k], bz_[k]};
+        for (int d = 0; d < 3; ++d) {
+          if (k == s || v[d] < blo_[d][b]) blo_[d][b] = v[d];
+          if (k == s || v[d] > bhi_[d][b]) bhi_[d][b] = v[d];
+        }
+      }
+    }
+    lb_.resize(nb_);
+  }
+
+  // Returns the index (into the original arrays) or -1.  A, B, C: the base triangle; pa, pb, pc: the plane.
+  int query(float pa, float pb, float pc, const float* A, const float* B, const float* C, float too_small) {
+    const float margin = 4e-6f * (std::fabs(pa) * absmax_[0] + std::fabs(pb) * absmax_[1] + std::fabs(pc) * absmax_[2] + 1.0f);
+    // interval of (a x + b y + c z - 1) over each block's box: the low end takes, per axis, the box face on the side
+    // the coefficient's sign points away from
+    const float* __restrict x0 = (pa >= 0.f ? blo_[0] : bhi_[0]).data(); const float* __restrict x1 = (pa >= 0.f ? bhi_[0] : blo_[0]).data();
+    const float* __restrict y0 = (pb >= 0.f ? blo_[1] : bhi_[1]).data(); const float* __restrict y1 = (pb >= 0.f ? bhi_[1] : blo_[1]).data();
+    const float* __restrict z0 = (pc >= 0.f ? blo_[2] : bhi_[2]).data(); const float* __restrict z1 = (pc >= 0.f ? bhi_[2] : blo_[2]).data();
+    float* __restrict lbp = lb_.data();
+    for (size_t b = 0; b < nb_; ++b) {
+      const float vmin = ((pa * x0[b] + pb * y0[b]) + pc * z0[b]) - 1.0f;
+      const float vmax = ((pa * x1[b] + pb * y1[b]) + pc * z1[b]) - 1.0f;
+      const float away = vmin > -vmax ? vmin : -vmax;
+      lbp[b] = (away > 0.0f ? away : 0.0f) - margin;
+    }
+    float best = std::numeric_limits<float>::max();
+    uint32_t best_i = 0xFFFFFFFFu;
+    auto visit = [&](size_t b) {
+      const size_t s = b * kBlock;
+      float dist[kBlock];
+      float blockmin = std::numeric_limits<float>::max();
+      for (uint32_t k = 0; k < kBlock; ++k) {
+        const float v = (pa * bx_[s + k] + pb * by_[s + k]) + pc * bz_[s + k];
+        const float d = std::fabs(v - 1.0f);
+        dist[k] = d;
+        blockmin = d < blockmin ? d : blockmin;
+      }
+      if (!(blockmin <= best)) return;
+      for (uint32_t k = 0; k < kBlock; ++k) {
+        const float d = dist[k];
+        const uint32_t i = bi_[s + k];
+        if (!(d < best || (d == best && i < best_i && best_i != 0xFFFFFFFFu))) continue;
+        const float p[3] = {bx_[s + k], by_[s + k], bz_[s + k]};
+        if (i != 0xFFFFFFFFu && far_enough(p, A, too_small) && far_enough(p, B, too_small) && far_enough(p, C, too_small)) { best = d; best_i = i; }
+      }
+    };
+    for (size_t b = 0; b < nb_; ++b) if (lb_[b] <= 0.0f) visit(b);          // boxes the plane passes through
+    for (size_t b = 0; b < nb_; ++b) if (lb_[b] > 0.0f && lb_[b] <= best) visit(b);
+    return best_i == 0xFFFFFFFFu ? -1 : int(best_i);
+  }
+
+ private:
+  static bool far_enough(const float* p, const float* q, float too_small) {
+    const float dx = p[0] - q[0], dy = p[1] - q[1], dz = p[2] - q[2];
+    return dx * dx + (dy * dy + dz * dz) >= too_small;                  // (p - q).squaredNorm(), Eigen order
+  }
+  size_t n_ = 0, nb_ = 0;
+  float absmax_[3] = {0, 0, 0};
+  std::vector<float> bx_, by_, bz_, blo_[3], bhi_[3], lb_;
+  std::vector<uint32_t> bi_;
 };
 
 // ---------------------------------------------------------------------------

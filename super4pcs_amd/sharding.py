@@ -41,9 +41,41 @@ def decode_key(key):
     return 0xFFFF - (key & 0xFFFF), key >> 16, False
 
 
+class _KeySlot:
+    """One in-flight 8-byte reduction.  On a GPU rank the key goes pinned host -> device -> all_reduce -> pinned host
+    with non-blocking copies and an event, so the launch thread never blocks on the collective it has just issued;
+    with CPU tensors (gloo: tests, single-GPU dry runs) the all_reduce itself is synchronous."""
+
+    def __init__(self, device):
+        import torch
+        self.on_gpu = device is not None and getattr(device, "type", str(device)) == "cuda"
+        if self.on_gpu:
+            self.host = torch.zeros(1, dtype=torch.int64).pin_memory()
+            self.dev = torch.zeros(1, dtype=torch.int64, device=device)
+            self.event = torch.cuda.Event()
+        else:
+            self.host = torch.zeros(1, dtype=torch.int64)
+            self.dev = self.host
+        self.view = self.host.numpy()
+
+    def post(self, dist, key):
+        self.view[0] = key
+        if self.on_gpu:
+            self.dev.copy_(self.host, non_blocking=True)
+        dist.all_reduce(self.dev, op=dist.ReduceOp.MAX)             # the one data-path collective: 8 bytes
+        if self.on_gpu:
+            self.host.copy_(self.dev, non_blocking=True)
+            self.event.record()
+
+    def result(self):
+        if self.on_gpu:
+            self.event.synchronize()
+        return int(self.view[0])
+
+
 class ShardedRansac:
-    """Drives a matcher (super4pcs_amd.capi.Matcher or a test double with the same three methods
-    next_base / commit / info) in windows of `world` trials."""
+    """Drives a matcher (super4pcs_amd.capi.Matcher or a test double with the same methods
+    next_base / next_base_async / wait_base / commit / info) in windows of `world` trials."""
 
     RECORD_FLOATS = 16 + 3 + 3 + 4 + 6   # T, c2, c1, quad, (m1, m2, K, C, count, has_best)
 
@@ -52,29 +84,41 @@ class ShardedRansac:
         self.trials_done = 0
         self.local_candidates = 0
         self.terminated = False
+        self._thr_count = None
+        self._best_count = None
+        self._slots = None
+        self._slot_rr = 0
         if producer_threads and hasattr(matcher, "set_sharding"):
             matcher.set_sharding(rank, world, True)     # base selection + octree staging on helper threads
 
     def _threshold_count(self):
-        info = self.m.info()
-        # lcp > terminate_threshold  <=>  count/n > thr (float): find the largest count that does not cross
-        n = info.n_sampled_q
-        thr = np.float32(self.m.opt.terminate_threshold)
-        c = int(np.floor(float(thr) * n))
-        while c < n and not (np.float32(c + 1) / np.float32(n) > thr):
-            c += 1
-        while c >= 0 and (np.float32(c) / np.float32(n) > thr):
-            c -= 1
-        return c
+        """Largest inlier count that does NOT cross the terminate threshold (fixed once the clouds are sampled)."""
+        if self._thr_count is None:
+            info = self.m.info()
+            # lcp > terminate_threshold  <=>  count/n > thr (float): find the largest count that does not cross
+            n = info.n_sampled_q
+            thr = np.float32(self.m.opt.terminate_threshold)
+            c = int(np.floor(float(thr) * n))
+            while c < n and not (np.float32(c + 1) / np.float32(n) > thr):
+                c += 1
+            while c >= 0 and (np.float32(c) / np.float32(n) > thr):
+                c -= 1
+            self._thr_count = c
+        return self._thr_count
 
     # ------------------------------------------------------------------------------------------
     def run_windows(self, n):
         """Runs n windows (n*world trials).  Returns the candidates this rank verified.
 
         world == 1: the engine's own pipelined Perform_N_steps.
-        world  > 1: window w+1 is prepared (own device pass enqueued, other ranks' bases advanced on
-        the host) BEFORE window w's result is waited for and reduced, so GPU pass, host-side base
-        selection and the 8-byte collective overlap.
+        world  > 1: a three-stage software pipeline per rank.  Window w+d is *prepared* (own device pass enqueued,
+        the other ranks' bases advanced on the host) while the device passes of windows w+1..w+d-1 are in flight
+        (d = lanes of the context); window w's result is then waited for and its 8-byte key *posted* to the
+        all-reduce, and only after that is the reduction of window w-1 *completed* (read back, winner committed).
+        GPU pass, host-side base selection and the collective therefore overlap, and the launch thread never waits
+        on a collective it has just issued.  Every rank executes the same sequence of collectives.
+        After the terminate threshold is crossed the remaining in-flight windows are drained without being
+        committed (the sequential loop would not have run them, match4pcsBase.hpp:255).
         """
         if self.world == 1:
             before = self.m.info().candidates_verified
@@ -83,15 +127,26 @@ class ShardedRansac:
             got = int(self.m.info().candidates_verified - before)
             self.local_candidates += got
             return got
+        if self._slots is None:
+            self._slots = [_KeySlot(self.device), _KeySlot(self.device)]
+        self._best_count = int(self.m.info().best_count)
         total = 0
-        pending = []
+        prepared, posted = [], None
         depth = getattr(self.m, "pipeline_depth", lambda: 2)()
         for _ in range(n):
-            pending.append(self._prepare_window())
-            while len(pending) >= depth:
-                total += self._finish_window(pending.pop(0))
-        while pending:
-            total += self._finish_window(pending.pop(0))
+            prepared.append(self._prepare_window())
+            if len(prepared) >= depth:
+                nxt = self._post_window(prepared.pop(0))
+                if posted is not None:
+                    total += self._complete_window(posted)
+                posted = nxt
+        while prepared:
+            nxt = self._post_window(prepared.pop(0))
+            if posted is not None:
+                total += self._complete_window(posted)
+            posted = nxt
+        if posted is not None:
+            total += self._complete_window(posted)
         return total
 
     def run_window(self):
@@ -108,22 +163,32 @@ class ShardedRansac:
             bases.append((found, base))
         return bases, mine
 
-    def _finish_window(self, prepared):
-        import torch
+    def _post_window(self, prepared):
         from . import capi
         bases, mine_found = prepared
         r = self.m.wait_base() if mine_found else capi.BaseResult()
-        thr_c = self._threshold_count()
-        usable = bool(mine_found and r.n_pairs1 and r.n_pairs2 and r.n_quads)
-        key = window_key(r.best_count, bool(r.has_best), usable, self.rank, thr_c)
         verified = int(r.n_verified)
         self.local_candidates += verified
-        t = torch.tensor([key], dtype=torch.int64, device=self.device)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)           # the one data-path collective: 8 bytes
-        win = decode_key(int(t.item()))
+        slot = None
+        if not self.terminated:
+            usable = bool(mine_found and r.n_pairs1 and r.n_pairs2 and r.n_quads)
+            key = window_key(r.best_count, bool(r.has_best), usable, self.rank, self._threshold_count())
+            slot = self._slots[self._slot_rr]
+            self._slot_rr ^= 1
+            slot.post(self.dist, key)
+        return bases, r, verified, slot
+
+    def _complete_window(self, posted):
+        import torch
+        from . import capi
+        bases, r, verified, slot = posted
+        self.trials_done += self.world
+        if slot is None or self.terminated:
+            return verified
+        win = decode_key(slot.result())
         if win is not None:
             w_trial, w_count, crossed = win
-            if w_count > self.m.info().best_count:
+            if w_count > self._best_count:
                 if w_trial == self.rank:
                     vals = list(r.best_transform) + list(r.best_centroid2) + list(r.centroid1) + [float(v) for v in r.best_quad] + \
                         [float(r.n_pairs1), float(r.n_pairs2), float(r.n_quads), float(r.n_verified), float(r.best_count), float(r.has_best)]
@@ -142,6 +207,6 @@ class ShardedRansac:
                 wr.n_pairs1, wr.n_pairs2, wr.n_quads, wr.n_verified = int(v[26]), int(v[27]), int(v[28]), int(v[29])
                 wr.best_count, wr.has_best = int(v[30]), int(v[31])
                 ok = self.m.commit(True, bases[w_trial][1], wr)
+                self._best_count = int(wr.best_count)
                 self.terminated = self.terminated or ok or crossed
-        self.trials_done += self.world
         return verified

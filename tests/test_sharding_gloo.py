@@ -126,3 +126,25 @@ def test_two_ranks_reach_the_sequential_result(seed):
     m = FakeMatcher(seed, n_windows * world)
     total = sum(5 for (f, c, u) in m.table if f and u)
     assert res[0][3] + res[1][3] == total
+
+
+@pytest.mark.parametrize("seed", [4, 6, 8, 21])
+def test_termination_inside_a_window_matches_the_sequential_break(seed):
+    """The sequential loop stops at the first trial whose LCP crosses the terminate threshold (match4pcsBase.hpp:255);
+    the sharded driver has later windows in flight by then and must drain them without committing."""
+    import torch.multiprocessing as mp
+    world, n_windows, thr = 2, 16, 0.9
+    want = sequential(seed, n_windows * world, thr)
+    probe = FakeMatcher(seed, n_windows * world, thr=thr)
+    assert want[0] / probe.n_q > thr and want[1] < n_windows * world - 2 * world, "seed does not terminate early; pick another"
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, seed, n_windows, thr, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert (res[0][1], res[0][2]) == want and (res[1][1], res[1][2]) == want
