@@ -77,7 +77,8 @@ def sphere_cloud(n, seed):
     return d.astype(np.float32)
 
 
-def lidar_pair(n_points, delta=0.05, seed=5, extent=60.0, n_boxes=120, n_cyl=30, yaw_deg=30.0, shift=10.0):
+def lidar_pair(n_points, delta=0.05, seed=5, extent=60.0, n_boxes=120, n_cyl=30, yaw_deg=30.0, shift=10.0,
+               first_scan_points=None, second_scan_points=None):
     """Config-4 style pair: two simulated terrestrial scans of one scene (ground plane, axis-aligned
     boxes, vertical cylinders) from poses `shift` metres apart and `yaw_deg` apart, ~1/r^2 density, range noise
     sigma = delta.  Returns (P, Q, T_gt) with Q expressed in the second scanner's frame."""
@@ -108,19 +109,37 @@ def lidar_pair(n_points, delta=0.05, seed=5, extent=60.0, n_boxes=120, n_cyl=30,
         return np.concatenate(pts)
 
     def scan(pose_xy, n):
-        S = surface_samples(int(n * 1.6))
-        d = np.linalg.norm(S - np.array([pose_xy[0], pose_xy[1], 1.8]), axis=1)
-        keep = rng.uniform(0, 1, len(S)) < np.clip((6.0 / np.maximum(d, 1.0)) ** 1.2, 0, 1)
-        S = S[keep][:n]
+        if n <= 0:
+            return np.zeros((0, 3))
+        got, have = [], 0
+        while have < n:                                              # range-dependent thinning keeps ~1/3: draw until n
+            S = surface_samples(min(max(n, 1 << 16), 1 << 22))
+            d = np.linalg.norm(S - np.array([pose_xy[0], pose_xy[1], 1.8]), axis=1)
+            keep = rng.uniform(0, 1, len(S)) < np.clip((6.0 / np.maximum(d, 1.0)) ** 1.2, 0, 1)
+            got.append(S[keep]); have += int(keep.sum())
+        S = np.concatenate(got)[:n]
         dirs = S - np.array([pose_xy[0], pose_xy[1], 1.8])
         dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
         return S + dirs * rng.normal(scale=delta, size=(len(S), 1))
 
-    P = scan((-shift / 2, 0.0), n_points)
-    Qw = scan((shift / 2, 0.0), n_points)
+    P = scan((-shift / 2, 0.0), n_points if first_scan_points is None else first_scan_points)
+    Qw = scan((shift / 2, 0.0), n_points if second_scan_points is None else second_scan_points)
     yaw = np.deg2rad(yaw_deg)
     R = np.array([[np.cos(yaw), -np.sin(yaw), 0], [np.sin(yaw), np.cos(yaw), 0], [0, 0, 1]])
     t = np.array([shift, 0.0, 0.0])
     Q = (Qw - t) @ R            # second scanner frame: q = R^T (w - t)
     T = np.eye(4); T[:3, :3] = R; T[:3, 3] = t
     return P.astype(np.float32), Q.astype(np.float32), T
+
+
+def part_in_whole_pair(n_scene, n_query, delta=0.05, seed=9, radius=7.0, spot=(4.0, 3.0, 1.0)):
+    """Config-5 style pair (BASELINE.json configs[4]): a `n_query`-point query cut out of a second scan (everything
+    within `radius` metres of `spot`, in world coordinates) against a `n_scene`-point scene; P = scene, Q = query in
+    the second scanner's frame.  Returns (P, Q, T_gt)."""
+    P, _, T = lidar_pair(n_scene, delta=delta, seed=seed, second_scan_points=0)
+    _, Qfull, _ = lidar_pair(max(24 * n_query, 1 << 16), delta=delta, seed=seed, first_scan_points=0)   # same scene, same poses
+    Qw = Qfull.astype(np.float64) @ T[:3, :3].T + T[:3, 3]
+    near = np.nonzero(np.linalg.norm(Qw - np.asarray(spot), axis=1) < radius)[0]
+    if len(near) > n_query:
+        near = np.sort(np.random.default_rng(seed + 1).choice(near, n_query, replace=False))
+    return P, Qfull[near], T

@@ -1,0 +1,141 @@
+"""-m gpu: the other workloads BASELINE.json lists (configs[1], [3], [4]) as parity cases.
+
+At these sizes a whole CPU registration is out of reach, so parity is checked where it is cheap and size-independent:
+  * sampling (device sampler) and initialisation against the oracle's host code: sampled clouds, trial count,
+    initial LCP -- bit-exact;
+  * the first bases stage by stage through the C ABI: base selection (block-pruned 4th-point search over ~10^6
+    sampled P points), pair sets in emission order, congruent quads -- bit-exact;
+  * LCP counts of a batch of transforms (identity, ground truth, perturbations) against the oracle's kd-tree;
+  * engine invariants over a run of bases: best LCP never decreases and equals a recount of the returned transform.
+Sizes default to the BASELINE.json ones; S4P_TEST_SCALE=0.2 shrinks them for a quick run.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+SCALE = float(os.environ.get("S4P_TEST_SCALE", "1.0"))
+
+
+def _centred_truth(om, T_gt):
+    cP, cQ, _, _ = om.frame()
+    Tg = np.asarray(T_gt, np.float64)
+    Tc = np.eye(4)
+    Tc[:3, :3] = Tg[:3, :3]
+    Tc[:3, 3] = Tg[:3, :3] @ cQ + Tg[:3, 3] - cP
+    return Tc
+
+
+def _stagewise_parity(O, capi, P, Q, T_gt, delta, overlap, n_s, n_bases, max_pairs, max_quads, lcp_floor, need_quads=True):
+    om = O.Matcher(O.make_options(delta, overlap, n_s), full_counts=True, use_kdtree=True, keep_trace=True)
+    om.init(P, Q)
+    gm = capi.Matcher(capi.make_options(delta, overlap, n_s), max_pairs=max_pairs, max_quads=max_quads)
+    gm.init_full(P, Q)                                   # device sampler (clouds >= 32768 points) + device grid build
+    Ps, Qs = om.cloud(0), om.cloud(1)
+    assert np.array_equal(gm.sampled(0), Ps) and np.array_equal(gm.sampled(1), Qs)
+    os_, gi = om.stats(), gm.info()
+    assert (gi.n_sampled_p, gi.n_sampled_q, gi.number_of_trials) == (os_.n_P, os_.n_Q, os_.number_of_trials)
+    assert gi.best_lcp == os_.best_lcp                   # Verify(identity)
+
+    # LCP counts on a batch of transforms, through the stage-level ABI on the same sampled clouds
+    ctx = capi.Context(capi.make_options(delta, overlap, n_s), max_pairs=max_pairs, max_quads=max_quads)
+    ctx.set_clouds(Ps, Qs)
+    rng = np.random.default_rng(3)
+    Tc = _centred_truth(om, T_gt)
+    Ts = [np.eye(4, dtype=np.float32), Tc.astype(np.float32)]
+    for _ in range(12):
+        Tp = np.eye(4)
+        Tp[:3, :3] += 0.003 * rng.normal(size=(3, 3))
+        Tp[:3, 3] = rng.normal(scale=2 * delta, size=3)
+        Ts.append((Tp @ Tc).astype(np.float32))
+    for _ in range(6):
+        Ts.append(H.random_rigid(rng, 1.0))
+    Ts = np.stack(Ts)
+    got, want = ctx.verify_transforms(Ts), om.verify_batch(Ts)
+    assert np.array_equal(got, want)
+    assert got[1] >= lcp_floor * Qs.shape[0]             # the ground truth is a real match
+
+    # first bases, stage by stage
+    eps = 2.0 * delta
+    total_quads = 0
+    for _ in range(n_bases):
+        ok, i1, i2, base, bx = om.select_quadrilateral()
+        g_ok, g_i1, g_i2, g_base, _ = gm.select_quadrilateral()
+        assert (g_ok, g_i1, g_i2) == (ok, i1, i2) and (not ok or np.array_equal(g_base, base))
+        if not ok:
+            continue
+        ctx.set_base(bx)
+        d1 = float(np.float32(np.linalg.norm(bx[0] - bx[1])))
+        d2 = float(np.float32(np.linalg.norm(bx[2] - bx[3])))
+        sets = []
+        for d, a, b in ((d1, 0, 1), (d2, 2, 3)):
+            want_p = om.extract_pairs(d, 0.0, eps, a, b)
+            got_p = ctx.extract_pairs(d, 0.0, eps, a, b)
+            assert np.array_equal(got_p, want_p)          # same pairs, same emission order
+            sets.append(want_p)
+        if sets[0].shape[0] and sets[1].shape[0]:
+            want_q = om.find_congruent(i1, i2, eps, sets[0], sets[1], cap=1 << 23)
+            got_q = ctx.find_congruent(i1, i2, eps, sets[0], sets[1], cap=1 << 23)
+            assert np.array_equal(got_q, want_q)
+            total_quads += want_q.shape[0]
+    assert total_quads > 0 or not need_quads
+    return om, gm, ctx
+
+
+def _engine_invariants(gm, ctx, n_steps, need_candidates=True):
+    best = gm.info().best_lcp
+    for _ in range(n_steps):
+        gm.try_one_base()
+        now = gm.info().best_lcp
+        assert now >= best
+        best = now
+    gi = gm.info()
+    T = np.array(gi.transform, np.float32).reshape(1, 4, 4)
+    recount = ctx.verify_transforms(T)[0]
+    assert recount == gi.best_count and np.float32(recount) / np.float32(gi.n_sampled_q) == np.float32(gi.best_lcp)
+    assert gi.candidates_verified > 0 or not need_candidates
+
+
+def test_config1_partial_scan_pair_whole_registration(oracle_mod, s4p_lib_built):
+    """configs[1] (Stanford Bunny partial scans, ~40 k points, ~45 % overlap; the asset is not in this image, a synthetic
+    partial-scan pair of the same size/overlap stands in): the WHOLE registration against the oracle."""
+    from super4pcs_amd import capi, datasets as D
+    delta, overlap, n_s = 0.008, 0.45, 300
+    P, Q, T_gt = D.bumpy_pair(40000, overlap=overlap, delta=delta, noise_sigma=0.3 * delta, seed=31)
+    om = oracle_mod.Matcher(oracle_mod.make_options(delta, overlap, n_s), full_counts=False, use_kdtree=True, keep_trace=False)
+    o_lcp, o_M, o_Q = om.compute_transformation(P, Q)
+    gm = capi.Matcher(capi.make_options(delta, overlap, n_s))
+    g_lcp, g_M, g_Q = gm.compute_transformation(P, Q)
+    os_, gi = om.stats(), gm.info()
+    assert (gi.n_sampled_p, gi.n_sampled_q, gi.number_of_trials) == (os_.n_P, os_.n_Q, os_.number_of_trials)
+    assert (gi.pairs_total, gi.quads_total, gi.candidates_verified) == (os_.n_pairs, os_.n_quads, os_.n_verified)
+    assert g_lcp == o_lcp and np.array_equal(g_M, o_M) and np.max(np.abs(g_Q - o_Q)) <= 1e-4
+    assert np.max(np.abs(g_M[:3, :3] - T_gt[:3, :3])) < 0.05      # and it is the right pose
+
+
+def test_config3_lidar_pair_5m_points(oracle_mod, s4p_lib_built):
+    """configs[3]: 5 M-point LiDAR-style pair (the per-GPU share of the sharded job is the same registration state)."""
+    from super4pcs_amd import capi, datasets as D
+    n = int(5_000_000 * SCALE)
+    delta = 0.05
+    P, Q, T_gt = D.lidar_pair(n, delta=delta)
+    om, gm, ctx = _stagewise_parity(oracle_mod, capi, P, Q, T_gt, delta, 0.4, 2000, 3, 8 << 20, 64 << 20, 0.15)
+    _engine_invariants(gm, ctx, 12)
+
+
+def test_config4_part_in_whole_10m_scene(oracle_mod, s4p_lib_built):
+    """configs[4]: 100 k-point query in a 10 M-point scene (P = scene: ~10^6 sampled points in the LCP grid and in the
+    base search)."""
+    from super4pcs_amd import capi, datasets as D
+    delta = 0.05
+    P, Q, T_gt = D.part_in_whole_pair(int(10_000_000 * SCALE), int(100_000 * SCALE), delta=delta)
+    assert Q.shape[0] >= int(50_000 * SCALE)
+    assert P.shape[0] == int(10_000_000 * SCALE)
+    # the 4th base point may lie anywhere in the scene (match4pcsBase.cc:324-338 bounds only the triangle), so most bases
+    # have a second segment longer than the query and no quads: pair parity on every base, quad parity where there are any
+    om, gm, ctx = _stagewise_parity(oracle_mod, capi, P, Q, T_gt, delta, 0.2, 2000, 6, 8 << 20, 64 << 20, 0.3, need_quads=False)
+    _engine_invariants(gm, ctx, 8, need_candidates=False)
