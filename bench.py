@@ -202,6 +202,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
                          "kernel": "k_verify", "avg_launch_ms": avg_ms, "launches": int(prof.verify_launches),
                          "candidates_per_launch": cand_per_launch, "algorithmic_bytes_per_candidate": bc, "kbar": kbar,
+                         "filter_pass_fraction": {"coarse_bitmap": pk.verify_l0_pass / queries, "reach_bit": pk.verify_l1_pass / queries,
+                                                  "subcell_mask": pk.verify_l2_pass / queries},
                          "note": "algorithmic bytes (SURVEY.md 8d, no cache credit, c=27 cells) / HIP-event launch time; "
                                  "the bitmap early-out means most of these bytes are never fetched"},
             "stage_ms_per_step": {"pairs": prof.pairs_ms_total / max(prof.quads_launches, 1),

@@ -101,7 +101,7 @@ struct s4p_ctx {
   uint32_t verify_blocks = 512;
   double host_octree_s = 0, host_wait_s = 0;
 
-  size_t verify_lds_bytes() const { return gcoarse.n * 4 + size_t(kVerifyThreads / 64) * 3 * kQueueEntries * 4; }
+  size_t verify_lds_bytes() const { return gcoarse.n * 4 + size_t(kVerifyThreads / 64) * kQueueEntries * sizeof(uint2); }
   LcpGrid dev_grid() const {
     LcpGrid g;
     g.reach = greach.p; g.list_hdr = glist_hdr.p; g.nbr = gnbr.p;
@@ -365,6 +365,7 @@ int32_t s4p_create(const s4p_options* opt, const s4p_limits* lim, int32_t device
   s4p_ctx* c = new s4p_ctx();
   c->device = device; c->opt = *opt;
   if (const char* ln = getenv("S4P_LANES")) { const int v = atoi(ln); if (v >= 1 && v <= s4p_ctx::kMaxLanes) c->n_lanes = v; }
+  if (const char* vb = getenv("S4P_VERIFY_BLOCKS")) { const int v = atoi(vb); if (v >= 64 && v <= 4096) c->verify_blocks = uint32_t(v); }   // tuning knob
   snprintf(c->devname, sizeof c->devname, "%s (%s)", prop.name, prop.gcnArchName);
   c->max_pairs = (lim && lim->max_pairs) ? lim->max_pairs : (4ull << 20);
   c->max_quads = (lim && lim->max_quads) ? lim->max_quads : (16ull << 20);

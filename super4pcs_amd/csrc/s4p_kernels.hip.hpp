@@ -86,7 +86,7 @@ struct LcpGrid {
   float sq_eps;                 // fl(delta*delta)
 };
 
-constexpr int kQueueEntries = 128;                 // per-wave survivor queue (3 floats per entry)
+constexpr int kQueueEntries = 128;                 // per-wave survivor queue ({query, rank} per entry)
 constexpr int kCoarseMaxWords = 12288;             // 48 KB
 
 __device__ __forceinline__ bool cell_coords(const LcpGrid& g, float tx, float ty, float tz, int& ix, int& iy, int& iz) {
@@ -98,20 +98,30 @@ __device__ __forceinline__ bool cell_coords(const LcpGrid& g, float tx, float ty
   return true;
 }
 
-// L1 + L2 + exact point tests for one transformed query point.
+// value held by every lane of the wave -> SGPR
+__device__ __forceinline__ float wave_uniform(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
+
+// (mat * q.homogeneous()).head<3>() : ((m0*x + m1*y) + m2*z) + m3   (match4pcsBase.cc:532)
+__device__ __forceinline__ void transform_point(const float* T, const float4 q, float& tx, float& ty, float& tz) {
+  tx = ((T[0] * q.x + T[1] * q.y) + T[2] * q.z) + T[3];
+  ty = ((T[4] * q.x + T[5] * q.y) + T[6] * q.z) + T[7];
+  tz = ((T[8] * q.x + T[9] * q.y) + T[10] * q.z) + T[11];
+}
+
+// L2 + exact point tests for query i, whose cell is the `rank`-th reachable one (L0 and L1 already passed).
+// The transformed point is recomputed here -- the same three expressions, hence the same bits -- rather than carried
+// through the queue: 18 flops for the ~10 % of queries that get this far against two LDS words per queued query.
 template <bool COUNT>
-__device__ __forceinline__ bool fine_test(const LcpGrid& g, float tx, float ty, float tz, unsigned long long* point_tests) {
-  int ix, iy, iz;
-  if (!cell_coords(g, tx, ty, tz, ix, iy, iz)) return false;
-  const uint32_t c = (uint32_t(iz) * uint32_t(g.ny) + uint32_t(iy)) * uint32_t(g.nx) + uint32_t(ix);
-  const uint2 w = g.reach[c >> 5];
-  const uint32_t sh = c & 31u;
-  if (!((w.x >> sh) & 1u)) return false;
-  if (COUNT) atomicAdd(point_tests + 2, 1ull);     // l1_pass
-  const uint32_t rank = w.y + uint32_t(__popc(w.x & ((1u << sh) - 1u)));
+__device__ __forceinline__ bool fine_test(const LcpGrid& g, const float4* q4, const float* T, uint32_t i, uint32_t rank,
+                                          unsigned long long* point_tests) {
   const uint4 hdr = g.list_hdr[rank];
+  float tx, ty, tz;
+  transform_point(T, q4[i], tx, ty, tz);
   // sub-cell of the query inside its cell (conservative: the mask was built with 1 % slack, rounding here is ~1e-5 cell)
-  const float rx = (tx - g.ox) * g.inv_h - float(ix), ry = (ty - g.oy) * g.inv_h - float(iy), rz = (tz - g.oz) * g.inv_h - float(iz);
+  const float ux = (tx - g.ox) * g.inv_h, uy = (ty - g.oy) * g.inv_h, uz = (tz - g.oz) * g.inv_h;
+  const float rx = ux - floorf(ux), ry = uy - floorf(uy), rz = uz - floorf(uz);
   const uint32_t sx = min(uint32_t(max(int(rx * 4.f), 0)), 3u), sy = min(uint32_t(max(int(ry * 4.f), 0)), 3u),
                  sz = min(uint32_t(max(int(rz * 4.f), 0)), 3u);
   const uint32_t sb = sz * 16u + sy * 4u + sx;
@@ -120,7 +130,7 @@ __device__ __forceinline__ bool fine_test(const LcpGrid& g, float tx, float ty, 
   if (COUNT) atomicAdd(point_tests + 3, 1ull);     // l2_pass
   const uint32_t s = hdr.x, e = hdr.x + hdr.y;
   for (uint32_t p = s; p < e; p += 2) {                       // two independent 16 B loads per dependent step
-    const float4 pa = g.nbr[p];                               // (four per step spills at the 64-VGPR budget: 44 M vs 61 M cand/s)
+    const float4 pa = g.nbr[p];
     const float4 pb = g.nbr[min(p + 1u, e - 1u)];
     if (COUNT) atomicAdd(point_tests, (p + 1u < e) ? 2ull : 1ull);
     const bool ha = sqn3(tx - pa.x, ty - pa.y, tz - pa.z) <= g.sq_eps;   // kdtree.h:417-421  sqdist <= cl_dist
@@ -265,24 +275,28 @@ __global__ __launch_bounds__(256) void k_build_masks(MaskParams P) {
 // Number of sampled-Q points that T brings within delta of a sampled-P point: Verify()
 // (match4pcsBase.cc:508-567) without the early exit, for one wave64.
 //   s_coarse : LDS copy of the coarse bitmap (workgroup-shared)
-//   s_queue  : this wave's private LDS queue (3 * kQueueEntries floats)
-// Phase 1 (every query): transform + L0 test out of LDS; survivors are compacted into the
-// queue with a ballot/prefix.  Phase 2 (64 survivors at a time, one per lane): L1/L2 + points.
+//   s_queue  : this wave's private LDS queue (kQueueEntries entries of {query index, reachable-cell rank})
+// Phase 1 (every query, four 64-query chunks per step): transform, cell, L0 test out of LDS; the L0 survivors then
+// read their reach word (L1, one 8-byte gather, issued for all four chunks back to back so the round trips overlap)
+// and the queries whose cell is reachable are compacted into the queue with a ballot/prefix.
+// Phase 2 (64 queued queries at a time, one per lane): list header + sub-cell mask (L2), then the exact tests.
+// Doing L1 in phase 1 means phase 2 runs on ~10 % of the queries instead of the ~25 % that pass L0, and its
+// dependent chain is header -> points instead of reach word -> header -> points.
 template <bool COUNT, bool SKIP_FINE = false>
-__device__ __forceinline__ uint32_t wave_lcp_count(const LcpGrid& g, const uint32_t* s_coarse, float* s_queue,
+__device__ __forceinline__ uint32_t wave_lcp_count(const LcpGrid& g, const uint32_t* s_coarse, uint2* s_queue,
                                                    const float4* q4, uint32_t n_q, const float* T,
                                                    unsigned long long* point_tests) {
+  constexpr uint32_t kNone = 0xFFFFFFFFu;
   const uint32_t lane = threadIdx.x & 63u;
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
   uint32_t cnt = 0, qn = 0;
   const uint32_t cmax = g.coarse_words * 32u - 1u;
   const uint32_t unx = uint32_t(g.nx), uny = uint32_t(g.ny), unz = uint32_t(g.nz);
-  // One 64-query chunk: branch-free L0 test, ballot compaction into the queue, drain 64 survivors when available.
-  auto chunk = [&](const float4 q, const uint32_t i) {
-    // (mat * q.homogeneous()).head<3>() : ((m0*x + m1*y) + m2*z) + m3   (match4pcsBase.cc:532)
-    const float tx = ((T[0] * q.x + T[1] * q.y) + T[2] * q.z) + T[3];
-    const float ty = ((T[4] * q.x + T[5] * q.y) + T[6] * q.z) + T[7];
-    const float tz = ((T[8] * q.x + T[9] * q.y) + T[10] * q.z) + T[11];
+  const bool dims24 = unx < (1u << 24) && uny * unz < (1u << 24);      // uniform: 24-bit multiplies are full rate
+  // cell of query i under T, or kNone if it falls outside the grid or into a coarse cube nothing can reach
+  auto locate = [&](const float4 q, const uint32_t i) -> uint32_t {
+    float tx, ty, tz;
+    transform_point(T, q, tx, ty, tz);
     // float -> int conversion saturates and one unsigned compare per axis covers both bounds (a NaN coordinate maps
     // to cell 0 and then fails every exact distance test, so it cannot create an inlier)
     const int ix = int(floorf((tx - g.ox) * g.inv_h)), iy = int(floorf((ty - g.oy) * g.inv_h)), iz = int(floorf((tz - g.oz) * g.inv_h));
@@ -290,26 +304,35 @@ __device__ __forceinline__ uint32_t wave_lcp_count(const LcpGrid& g, const uint3
     const uint32_t cc = min(__umul24(__umul24(uint32_t(iz) >> g.cshift, uint32_t(g.cny)) + (uint32_t(iy) >> g.cshift), uint32_t(g.cnx)) +
                             (uint32_t(ix) >> g.cshift), cmax);
     const bool surv = inb & (((s_coarse[cc >> 5] >> (cc & 31u)) & 1u) != 0u);
-    const unsigned long long m = __ballot(surv);
-    if (COUNT && lane == 0) atomicAdd(point_tests + 1, (unsigned long long)__popcll(m));   // l0_pass
-    if (surv) {
-      const uint32_t at = __umul24(qn + uint32_t(__popcll(m & lt_mask)), 3u);
-      s_queue[at] = tx; s_queue[at + 1] = ty; s_queue[at + 2] = tz;
+    const uint32_t c = dims24 ? __umul24(__umul24(uint32_t(iz), uny) + uint32_t(iy), unx) + uint32_t(ix)
+                              : (uint32_t(iz) * uny + uint32_t(iy)) * unx + uint32_t(ix);
+    return surv ? c : kNone;
+  };
+  auto fine = [&](const uint2 e) -> uint32_t {
+    if (SKIP_FINE) return uint32_t(e.y == kNone);
+    return fine_test<COUNT>(g, q4, T, e.x, e.y, point_tests) ? 1u : 0u;
+  };
+  // L1 for one chunk + compaction; drains 64 queued queries when that many are waiting
+  auto push = [&](const uint32_t c, const uint2 w, const uint32_t i) {
+    const uint32_t sh = c & 31u;
+    const bool reach = (c != kNone) & (((w.x >> sh) & 1u) != 0u);
+    const unsigned long long m = __ballot(reach);
+    const unsigned long long m0 = COUNT ? __ballot(c != kNone) : 0ull;
+    if (COUNT && lane == 0) {
+      atomicAdd(point_tests + 1, (unsigned long long)__popcll(m0));                      // l0_pass
+      atomicAdd(point_tests + 2, (unsigned long long)__popcll(m));                       // l1_pass
     }
+    if (reach) s_queue[qn + uint32_t(__popcll(m & lt_mask))] = make_uint2(i, w.y + uint32_t(__popc(w.x & ((1u << sh) - 1u))));
     qn += uint32_t(__popcll(m));
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     if (qn >= 64u) {
-      const uint32_t at = __umul24(qn - 64u + lane, 3u);
-      const float x = s_queue[at], y = s_queue[at + 1], z = s_queue[at + 2];
-      cnt += SKIP_FINE ? uint32_t(x > 1e30f) : (fine_test<COUNT>(g, x, y, z, point_tests) ? 1u : 0u);
+      cnt += fine(s_queue[qn - 64u + lane]);
       qn -= 64u;
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       __builtin_amdgcn_wave_barrier();
     }
   };
-  // The sweep is latency-bound (one dependent L2 round trip per 64 queries and wave): issue the loads of four
-  // chunks back to back, then work through them, so four round trips overlap instead of queueing up.
   const uint32_t last = n_q - 1u;
   for (uint32_t base = 0; base < n_q; base += 256) {
     const uint32_t i0 = base + lane, i1 = i0 + 64u, i2 = i0 + 128u, i3 = i0 + 192u;
@@ -317,15 +340,15 @@ __device__ __forceinline__ uint32_t wave_lcp_count(const LcpGrid& g, const uint3
     const float4 q1 = q4[min(i1, last)];
     const float4 q2 = q4[min(i2, last)];
     const float4 q3 = q4[min(i3, last)];
-    chunk(q0, i0);
-    if (base + 64u < n_q) chunk(q1, i1);
-    if (base + 128u < n_q) chunk(q2, i2);
-    if (base + 192u < n_q) chunk(q3, i3);
+    const uint32_t c0 = locate(q0, i0), c1 = locate(q1, i1), c2 = locate(q2, i2), c3 = locate(q3, i3);
+    // reach words of the L0 survivors; rejected lanes read word 0 (one broadcast line)
+    const uint2 w0 = g.reach[c0 == kNone ? 0u : c0 >> 5];
+    const uint2 w1 = g.reach[c1 == kNone ? 0u : c1 >> 5];
+    const uint2 w2 = g.reach[c2 == kNone ? 0u : c2 >> 5];
+    const uint2 w3 = g.reach[c3 == kNone ? 0u : c3 >> 5];
+    push(c0, w0, i0); push(c1, w1, i1); push(c2, w2, i2); push(c3, w3, i3);
   }
-  if (lane < qn) {
-    const float x = s_queue[3 * lane], y = s_queue[3 * lane + 1], z = s_queue[3 * lane + 2];
-    cnt += SKIP_FINE ? uint32_t(x > 1e30f) : (fine_test<COUNT>(g, x, y, z, point_tests) ? 1u : 0u);
-  }
+  if (lane < qn) cnt += fine(s_queue[lane]);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
   __builtin_amdgcn_wave_barrier();
@@ -420,7 +443,7 @@ __device__ __forceinline__ bool rigid_gate(const BaseFrame& b, const float q[3][
 // ---------------------------------------------------------------------------
 // k_verify: persistent workgroups of 8 waves; one wave64 per candidate quad, striding over
 // the quad list whose length lives in device memory (no host round trip).
-// LDS: coarse bitmap (<= 48 KB) + 8 private survivor queues (1.5 KB each).
+// LDS: coarse bitmap (<= 48 KB) + 16 private survivor queues (1 KB each).
 // ---------------------------------------------------------------------------
 constexpr int kVerifyThreads = 1024;
 struct VerifyParams {
@@ -474,12 +497,12 @@ __global__ __launch_bounds__(256) void k_gate(VerifyParams P) {
 // k_verify: Verify() (match4pcsBase.cc:508-567, no early exit) of every gated candidate.
 // Persistent workgroups of 8 waves striding over the gated candidate list (its length lives in
 // device memory: no host round trip).
-// LDS: coarse bitmap (<= 48 KB) + 8 private survivor queues (1.5 KB each).
+// LDS: coarse bitmap (<= 48 KB) + 16 private survivor queues (1 KB each).
 template <bool COUNT>
 __global__ __launch_bounds__(kVerifyThreads, 8) void k_verify(VerifyParams P) {   // 8 waves/SIMD: two 1024-thread workgroups per CU
   extern __shared__ uint32_t s_mem[];
   uint32_t* s_coarse = s_mem;
-  float* s_queue = reinterpret_cast<float*>(s_mem + P.grid.coarse_words) + (threadIdx.x >> 6) * (3 * kQueueEntries);
+  uint2* s_queue = reinterpret_cast<uint2*>(s_mem + P.grid.coarse_words) + (threadIdx.x >> 6) * kQueueEntries;
   const uint32_t C = P.ctr->C;
   if (blockIdx.x * (kVerifyThreads / 64) >= C) return;   // more workgroups than candidates
   stage_coarse(P.grid, s_coarse);
@@ -493,7 +516,10 @@ __global__ __launch_bounds__(kVerifyThreads, 8) void k_verify(VerifyParams P) { 
   for (uint32_t i = wave; i < C; i += nwaves) {
     const float4* src = P.cand_T + 3 * size_t(i);
     const float4 r0 = src[0], r1 = src[1], r2 = src[2];
-    const float T[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
+    // one candidate per wave: its 3x4 lives in scalar registers
+    const float T[12] = {wave_uniform(r0.x), wave_uniform(r0.y), wave_uniform(r0.z), wave_uniform(r0.w),
+                         wave_uniform(r1.x), wave_uniform(r1.y), wave_uniform(r1.z), wave_uniform(r1.w),
+                         wave_uniform(r2.x), wave_uniform(r2.y), wave_uniform(r2.z), wave_uniform(r2.w)};
     uint32_t cnt = 0;
     if (P.ablate == 2) cnt = uint32_t(T[3] > 1e30f);
     else if (P.ablate == 1) cnt = wave_lcp_count<COUNT, true>(P.grid, s_coarse, s_queue, P.q4v, P.n_q, T, &P.ctr->point_tests);
@@ -558,7 +584,7 @@ struct VerifyTParams {
 __global__ __launch_bounds__(kVerifyThreads) void k_verify_T(VerifyTParams P) {
   extern __shared__ uint32_t s_mem[];
   uint32_t* s_coarse = s_mem;
-  float* s_queue = reinterpret_cast<float*>(s_mem + P.grid.coarse_words) + (threadIdx.x >> 6) * (3 * kQueueEntries);
+  uint2* s_queue = reinterpret_cast<uint2*>(s_mem + P.grid.coarse_words) + (threadIdx.x >> 6) * kQueueEntries;
   stage_coarse(P.grid, s_coarse);
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -566,7 +592,7 @@ __global__ __launch_bounds__(kVerifyThreads) void k_verify_T(VerifyTParams P) {
   for (uint32_t k = wave; k < P.B; k += nwaves) {
     float T[12];
 #pragma unroll
-    for (int i = 0; i < 12; ++i) T[i] = P.T[16 * size_t(k) + i];
+    for (int i = 0; i < 12; ++i) T[i] = wave_uniform(P.T[16 * size_t(k) + i]);
     const uint32_t cnt = wave_lcp_count<false, false>(P.grid, s_coarse, s_queue, P.q4, P.n_q, T, nullptr);
     if (lane == 0) P.counts[k] = cnt;
   }
