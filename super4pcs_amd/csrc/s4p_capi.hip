@@ -147,17 +147,16 @@ void stage_pairs(s4p_ctx* c, int slot, int set, float pair_distance, float pair_
   c->tree.flatten(blob, blob + st.n_seq[set], reinterpret_cast<Leaf*>(blob + s4p_ctx::StageSlot::leaf_word(st.n_seq[set])));
 }
 
-// part 2: upload the staged sequence and launch loop 2 + the pair filters (k_pairs).
-int32_t launch_pairs_staged(s4p_ctx* c, int slot, int set, float pair_distance_epsilon, int bp1, int bp2) {
+// part 2: upload the staged sequence of one set and fill its kernel parameters.
+int32_t upload_pairs_staged(s4p_ctx* c, int slot, int set, float pair_distance_epsilon, int bp1, int bp2, PairParams& P) {
   const s4p_ctx::StageSlot& st = c->stage[slot];
   const uint32_t n_seq = st.n_seq[set], n_leaf = st.n_leaf[set];
   DevBuf<int2>& ab = set == 0 ? c->lane[c->cur].ab1 : c->lane[c->cur].ab2;
   DevBuf<uint32_t>& okey = set == 0 ? c->lane[c->cur].okey1 : c->lane[c->cur].okey2;
-  if (n_seq == 0) return S4P_OK;
   const uint32_t leaf_word = s4p_ctx::StageSlot::leaf_word(n_seq);
   uint32_t* dseq = c->lane[c->cur].seq[set].p;
-  HIPCHK(c, hipMemcpyAsync(dseq, st.seq[set].p, (size_t(leaf_word) + 4u * n_leaf) * sizeof(uint32_t), hipMemcpyHostToDevice, c->lane[c->cur].stream));
-  PairParams P{};
+  if (n_seq) HIPCHK(c, hipMemcpyAsync(dseq, st.seq[set].p, (size_t(leaf_word) + 4u * n_leaf) * sizeof(uint32_t), hipMemcpyHostToDevice, c->lane[c->cur].stream));
+  P = PairParams{};
   P.ux = c->ux.p; P.uy = c->uy.p; P.uz = c->uz.p; P.qx = c->qx.p; P.qy = c->qy.p; P.qz = c->qz.p;
   P.nx = c->has_normals ? c->qnx.p : nullptr; P.ny = c->qny.p; P.nz = c->qnz.p;
   P.cr = c->has_rgb ? c->qcr.p : nullptr; P.cg = c->qcg.p; P.cb = c->qcb.p;
@@ -173,9 +172,21 @@ int32_t launch_pairs_staged(s4p_ctx* c, int slot, int set, float pair_distance_e
   }
   P.ab = ab.p; P.okey = okey.p; P.counter = set == 0 ? &c->lane[c->cur].ctr.p->m1 : &c->lane[c->cur].ctr.p->m2;
   P.cap = uint32_t(c->max_pairs); P.overflow = &c->lane[c->cur].ctr.p->overflow; P.overflow_bit = set == 0 ? 1u : 2u;
-  hipLaunchKernelGGL(k_pairs, dim3(std::min<uint32_t>(c->n_q, 512u)), dim3(256), 0, c->lane[c->cur].stream, P);
+  return S4P_OK;
+}
+
+// loop 2 + the pair filters (k_pairs) for one set, or for both sets of a base in one launch
+int32_t launch_pairs_kernel(s4p_ctx* c, const PairParams2& PP, int n_sets) {
+  hipLaunchKernelGGL(k_pairs, dim3(std::min<uint32_t>(c->n_q, 512u), uint32_t(n_sets)), dim3(256), 0, c->lane[c->cur].stream, PP);
   HIPCHK(c, hipGetLastError());
   return S4P_OK;
+}
+
+int32_t launch_pairs_staged(s4p_ctx* c, int slot, int set, float pair_distance_epsilon, int bp1, int bp2) {
+  PairParams2 PP{};
+  if (int32_t rc = upload_pairs_staged(c, slot, set, pair_distance_epsilon, bp1, bp2, PP.set[0])) return rc;
+  if (PP.set[0].n_seq == 0) return S4P_OK;
+  return launch_pairs_kernel(c, PP, 1);
 }
 
 int32_t launch_pairs(s4p_ctx* c, int set, float pair_distance, float pair_normals_angle, float pair_distance_epsilon,
@@ -236,13 +247,12 @@ int32_t launch_quads(s4p_ctx* c, float inv1, float inv2, float thr2) {
   P1.ab = c->lane[c->cur].ab1.p; P1.m_dev = &c->lane[c->cur].ctr.p->m1; P1.cap = uint32_t(c->max_pairs); P1.invariant = inv1; P1.qg = qg;
   P1.cell = c->lane[c->cur].cell1.p; P1.bucket = c->lane[c->cur].bucket1.p; P1.ew = c->lane[c->cur].ew1.p; P1.next = c->lane[c->cur].next1.p; P1.mask = nullptr; P1.ht = ht;
   P1.cone.nb = 0;
-  hipLaunchKernelGGL(k_prep1, dim3(1024), dim3(256), 0, c->lane[c->cur].stream, P1);
   PrepParams P2{};
   P2.ux = c->ux.p; P2.uy = c->uy.p; P2.uz = c->uz.p; P2.qx = c->qx.p; P2.qy = c->qy.p; P2.qz = c->qz.p;
   P2.ab = c->lane[c->cur].ab2.p; P2.m_dev = &c->lane[c->cur].ctr.p->m2; P2.cap = uint32_t(c->max_pairs); P2.invariant = inv2; P2.qg = qg;
   P2.cell = c->lane[c->cur].cell2.p; P2.bucket = nullptr; P2.ew = c->lane[c->cur].ew2.p; P2.next = nullptr; P2.mask = c->lane[c->cur].mask2.p; P2.ht = ht;
   P2.cone = cone;
-  hipLaunchKernelGGL(k_prep2, dim3(1024), dim3(256), 0, c->lane[c->cur].stream, P2);
+  hipLaunchKernelGGL(k_prep, dim3(1024, 2), dim3(256), 0, c->lane[c->cur].stream, P1, P2);
   QuadParams Q{};
   Q.ab1 = c->lane[c->cur].ab1.p; Q.okey1 = c->lane[c->cur].okey1.p; Q.bucket1 = c->lane[c->cur].bucket1.p; Q.ew1 = c->lane[c->cur].ew1.p; Q.next1 = c->lane[c->cur].next1.p;
   Q.ab2 = c->lane[c->cur].ab2.p; Q.okey2 = c->lane[c->cur].okey2.p; Q.cell2 = c->lane[c->cur].cell2.p; Q.ew2 = c->lane[c->cur].ew2.p; Q.mask2 = c->lane[c->cur].mask2.p;
@@ -451,7 +461,9 @@ int32_t s4p_set_clouds(s4p_ctx* c, const float* px, const float* py, const float
   c->hqx.assign(qx, qx + n_q); c->hqy.assign(qy, qy + n_q); c->hqz.assign(qz, qz + n_q);
   c->frame.build(c->hqx, c->hqy, c->hqz, c->hux, c->huy, c->huz);
   c->tree.reset(c->n_q);
-  if (!c->hgrid.plan(c->hpx, c->hpy, c->hpz, c->opt.delta, c->max_grid_cells, kCoarseMaxWords)) S4P_FAIL(c, S4P_ERR_STATE, "LCP grid planning failed");
+  float cell_factor = 1.002f;
+  if (const char* cf = getenv("S4P_CELL_FACTOR")) cell_factor = float(atof(cf));      // tuning knob: LCP cell edge / delta
+  if (!c->hgrid.plan(c->hpx, c->hpy, c->hpz, c->opt.delta, c->max_grid_cells, kCoarseMaxWords, cell_factor)) S4P_FAIL(c, S4P_ERR_STATE, "LCP grid planning failed");
   {  // device build of the LCP structure (counting formulation, see k_grid_* in s4p_kernels.hip.hpp)
     hipStream_t st = c->lane[0].stream;
     const uint64_t nc = c->hgrid.ncell();
@@ -713,8 +725,10 @@ int32_t s4p_try_base_staged_async(s4p_ctx* c, int32_t slot, const int32_t* base_
   if (int32_t rc = reset_counters(c)) return rc;
   const float eps = 2.0f * c->opt.delta;
   if (c->prof_events) HIPCHK(c, hipEventRecord(c->ev[c->cur][2], c->lane[c->cur].stream));
-  if (int32_t rc = launch_pairs_staged(c, slot, 0, eps, 0, 1)) return rc;
-  if (int32_t rc = launch_pairs_staged(c, slot, 1, eps, 2, 3)) return rc;
+  { PairParams2 PP{};                                  // both pair sets: two uploads, one launch
+    if (int32_t rc = upload_pairs_staged(c, slot, 0, eps, 0, 1, PP.set[0])) return rc;
+    if (int32_t rc = upload_pairs_staged(c, slot, 1, eps, 2, 3, PP.set[1])) return rc;
+    if (int32_t rc = launch_pairs_kernel(c, PP, 2)) return rc; }
   if (c->prof_events) HIPCHK(c, hipEventRecord(c->ev[c->cur][3], c->lane[c->cur].stream));
   if (int32_t rc = launch_quads(c, inv1, inv2, eps)) return rc;
   if (c->prof_events) HIPCHK(c, hipEventRecord(c->ev[c->cur][4], c->lane[c->cur].stream));

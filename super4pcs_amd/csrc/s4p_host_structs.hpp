@@ -408,7 +408,7 @@ struct LcpGridHost {
   // |q-p| <= delta then satisfies dist(p, box(cell)) <= delta + rounding slack, so it is listed for that cell by the
   // 1.01*delta reach test (slack 1e-2*delta >> float rounding of the cell map).  One cell of padding on every side.
   bool plan(const std::vector<float>& px, const std::vector<float>& py, const std::vector<float>& pz,
-            float delta, uint64_t max_cells, uint32_t max_coarse_words) {
+            float delta, uint64_t max_cells, uint32_t max_coarse_words, float cell_factor = 1.002f) {
     const size_t n = px.size();
     if (n == 0) return false;
     float lo[3] = {px[0], py[0], pz[0]}, hi[3] = {px[0], py[0], pz[0]};
@@ -417,7 +417,7 @@ struct LcpGridHost {
       lo[1] = std::min(lo[1], py[i]); hi[1] = std::max(hi[1], py[i]);
       lo[2] = std::min(lo[2], pz[i]); hi[2] = std::max(hi[2], pz[i]);
     }
-    h = delta * 1.002f;
+    h = delta * (cell_factor >= 1.002f ? cell_factor : 1.002f);
     if (!(h > 0.f)) return false;
     while (true) {
       const double ex = (double(hi[0]) - lo[0]) / h, ey = (double(hi[1]) - lo[1]) / h, ez = (double(hi[2]) - lo[2]) / h;

@@ -129,9 +129,9 @@ __device__ __forceinline__ bool fine_test(const LcpGrid& g, const float4* q4, co
   if (!((mword >> (sb & 31u)) & 1u)) return false;
   if (COUNT) atomicAdd(point_tests + 3, 1ull);     // l2_pass
   const uint32_t s = hdr.x, e = hdr.x + hdr.y;
-  for (uint32_t p = s; p < e; p += 2) {                       // two independent 16 B loads per dependent step
+  for (uint32_t p = s; p < e; p += 2) {                       // two independent 16 B loads per dependent step (four: slower)
     const float4 pa = g.nbr[p];
-    const float4 pb = g.nbr[min(p + 1u, e - 1u)];
+    const float4 pb = g.nbr[min(p + 1u, e - 1u)];            // (predicating this load away on odd tails was measured slower)
     if (COUNT) atomicAdd(point_tests, (p + 1u < e) ? 2ull : 1ull);
     const bool ha = sqn3(tx - pa.x, ty - pa.y, tz - pa.z) <= g.sq_eps;   // kdtree.h:417-421  sqdist <= cl_dist
     const bool hb = sqn3(tx - pb.x, ty - pb.y, tz - pb.z) <= g.sq_eps;
@@ -641,7 +641,10 @@ constexpr int kPairStage = 2048;   // accepted (pId, j) per workgroup between tw
 // One workgroup per primitive pId; threads sweep the sequence in chunks of 256.  Accepted slots are
 // staged in LDS and flushed with ONE global atomic per workgroup (a per-wave atomic on the single
 // output cursor serialises at ~90 ops/us and dominated the first version of this kernel).
-__global__ __launch_bounds__(256) void k_pairs(PairParams P) {
+// The two pair sets of a base are independent: one launch, blockIdx.y picks the set (gridDim.y = 1 for a single set).
+struct PairParams2 { PairParams set[2]; };
+__global__ __launch_bounds__(256) void k_pairs(PairParams2 PP) {
+  const PairParams& P = PP.set[blockIdx.y];
   __shared__ uint32_t st_j[kPairStage];
   __shared__ uint32_t st_s[kPairStage];
   __shared__ uint32_t st_p[kPairStage];
@@ -777,7 +780,7 @@ struct PrepParams {
   ConeTable cone;
 };
 
-__global__ __launch_bounds__(256) void k_prep1(PrepParams P) {
+__device__ __forceinline__ void prep1_body(const PrepParams& P) {
   const uint32_t m = min(*P.m_dev, P.cap);
   for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < m; e += gridDim.x * blockDim.x) {
     const int2 ab = P.ab[e];
@@ -835,8 +838,7 @@ __device__ __forceinline__ void quat_from_z_to(float nx, float ny, float nz, flo
   q[0] = s * 0.5f;
 }
 
-__global__ __launch_bounds__(256) void k_prep2(PrepParams P) {
-  __shared__ uint32_t smask[256 * kMaskWords];
+__device__ __forceinline__ void prep2_body(const PrepParams& P, uint32_t* smask) {
   const uint32_t m = min(*P.m_dev, P.cap);
   const uint32_t nthreads = gridDim.x * blockDim.x;
   uint32_t* my = smask + threadIdx.x * kMaskWords;
@@ -872,6 +874,12 @@ __global__ __launch_bounds__(256) void k_prep2(PrepParams P) {
 #pragma unroll
     for (int w = 0; w < kMaskWords; ++w) P.mask[size_t(e) * kMaskWords + w] = my[w];
   }
+}
+// Set 1 (hash insert) and set 2 (cone masks) are prepared by one launch: blockIdx.y == 0 -> set 1, 1 -> set 2.
+__global__ __launch_bounds__(256) void k_prep(PrepParams P1, PrepParams P2) {
+  __shared__ uint32_t smask[256 * kMaskWords];
+  if (blockIdx.y == 0) prep1_body(P1);
+  else prep2_body(P2, smask);
 }
 
 struct QuadParams {
