@@ -495,8 +495,8 @@ __global__ __launch_bounds__(256) void k_gate(VerifyParams P) {
 }
 
 // k_verify: Verify() (match4pcsBase.cc:508-567, no early exit) of every gated candidate.
-// Persistent workgroups of 8 waves striding over the gated candidate list (its length lives in
-// device memory: no host round trip).
+// Persistent 1024-thread workgroups, each working through its slice of the gated candidate list (the list's
+// length lives in device memory: no host round trip).
 // LDS: coarse bitmap (<= 48 KB) + 16 private survivor queues (1 KB each).
 template <bool COUNT>
 __global__ __launch_bounds__(kVerifyThreads, 8) void k_verify(VerifyParams P) {   // 8 waves/SIMD: two 1024-thread workgroups per CU
@@ -504,16 +504,23 @@ __global__ __launch_bounds__(kVerifyThreads, 8) void k_verify(VerifyParams P) { 
   uint32_t* s_coarse = s_mem;
   uint2* s_queue = reinterpret_cast<uint2*>(s_mem + P.grid.coarse_words) + (threadIdx.x >> 6) * kQueueEntries;
   const uint32_t C = P.ctr->C;
-  if (blockIdx.x * (kVerifyThreads / 64) >= C) return;   // more workgroups than candidates
-  stage_coarse(P.grid, s_coarse);
+  // Work split: every workgroup owns a contiguous slice of the gated candidate list (static: a single-address global
+  // cursor caps at ~90 dequeues/us, MI355X_MICROARCH "dequeue"); inside the slice its 16 waves take candidates from an
+  // LDS counter, so a wave that drew cheap candidates (few L0 survivors) simply takes more.  Slices differ by at most
+  // one candidate, against "one or two candidates per wave" for a static stride over waves.
+  const uint32_t lo = uint32_t((uint64_t(C) * blockIdx.x) / gridDim.x), hi = uint32_t((uint64_t(C) * (blockIdx.x + 1u)) / gridDim.x);
+  if (lo >= hi) return;                                    // more workgroups than candidates (uniform)
+  __shared__ uint32_t s_next;
+  if (threadIdx.x == 0) s_next = lo;
+  stage_coarse(P.grid, s_coarse);                          // ends with a workgroup barrier
   const uint32_t lane = threadIdx.x & 63u;
   uint32_t local_best = 0;
   bool any = false;
-  // After k_gate every candidate costs about the same (n_Q queries), so a static stride balances
-  // well; a single-address atomic cursor would cap at ~90 dequeues/us (MI355X_MICROARCH "dequeue").
-  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
-  for (uint32_t i = wave; i < C; i += nwaves) {
+  while (true) {
+    uint32_t i = 0;
+    if (lane == 0) i = atomicAdd(&s_next, 1u);
+    i = uint32_t(__builtin_amdgcn_readfirstlane(int(i)));
+    if (i >= hi) break;
     const float4* src = P.cand_T + 3 * size_t(i);
     const float4 r0 = src[0], r1 = src[1], r2 = src[2];
     // one candidate per wave: its 3x4 lives in scalar registers
