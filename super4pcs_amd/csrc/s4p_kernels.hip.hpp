@@ -1,4 +1,4 @@
-// s4p_kernels.cuh -- gfx950 device code of the Super4PCS hot path (HIP, wave64).
+// s4p_kernels.hip.hpp -- gfx950 device code of the Super4PCS hot path (HIP, wave64).
 //
 // Compiled ONLY for gfx950 with -ffp-contract=off: every float expression below is
 // evaluated as separate IEEE mul/add (no FMA), with correctly rounded sqrtf and '/',
@@ -9,7 +9,7 @@
 // Reference functions restated here (paths under /root/reference/src/super4pcs/):
 //   k_pairs        accelerators/pairExtraction/intersectionFunctor.h:197-233 (loop 2),
 //                  intersectionPrimitive.h:117-157, algorithms/pairCreationFunctor.h:151-218
-//   k_prep1/2      algorithms/super4pcs.cc:118-146, accelerators/normalset.hpp:110-127,162-203
+//   k_prep         algorithms/super4pcs.cc:118-146, accelerators/normalset.hpp:110-127,162-203
 //   k_quads        algorithms/super4pcs.cc:151-163
 //   k_verify       algorithms/match4pcsBase.cc:365-500 (ComputeRigidTransformation),
 //                  match4pcsBase.cc:508-567 (Verify), accelerators/kdtree.h:417-421 (predicate)
