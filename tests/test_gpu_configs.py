@@ -104,7 +104,7 @@ def test_config1_partial_scan_pair_whole_registration(oracle_mod, s4p_lib_built)
     """configs[1] (Stanford Bunny partial scans, ~40 k points, ~45 % overlap; the asset is not in this image, a synthetic
     partial-scan pair of the same size/overlap stands in): the WHOLE registration against the oracle."""
     from super4pcs_amd import capi, datasets as D
-    delta, overlap, n_s = 0.008, 0.45, 300
+    delta, overlap, n_s = 0.008, 0.45, 350
     P, Q, T_gt = D.bumpy_pair(40000, overlap=overlap, delta=delta, noise_sigma=0.3 * delta, seed=31)
     om = oracle_mod.Matcher(oracle_mod.make_options(delta, overlap, n_s), full_counts=False, use_kdtree=True, keep_trace=False)
     o_lcp, o_M, o_Q = om.compute_transformation(P, Q)
