@@ -47,5 +47,26 @@ def build(force=False, verbose=False):
     return LIB
 
 
+BINDIR = os.path.join(_HERE, "bin")
+CLI = os.path.join(BINDIR, "Super4PCS")
+CLI_SRC = os.path.join(ROOT, "demos", "Super4PCS", "super4pcs_test.cc")
+
+
+def build_cli(force=False):
+    """The command-line program (demos/Super4PCS) against the facade headers and the library: plain host C++."""
+    build()
+    deps = [CLI_SRC, os.path.join(ROOT, "demos", "demo-utils.h"), LIB,
+            os.path.join(ROOT, "include", "super4pcs", "io", "io.h"),
+            os.path.join(ROOT, "include", "super4pcs", "algorithms", "match4pcsBase.h")]
+    if not force and os.path.exists(CLI) and all(os.path.getmtime(d) <= os.path.getmtime(CLI) for d in deps):
+        return CLI
+    os.makedirs(BINDIR, exist_ok=True)
+    cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-Wall", "-I" + os.path.join(ROOT, "include"), CLI_SRC,
+           "-L" + LIBDIR, "-lsuper4pcs_amd", "-Wl,-rpath,$ORIGIN/../lib", "-o", CLI]
+    subprocess.check_call(cmd)
+    return CLI
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_cli(force="--force" in sys.argv))
