@@ -79,8 +79,9 @@ class ShardedRansac:
 
     RECORD_FLOATS = 16 + 3 + 3 + 4 + 6   # T, c2, c1, quad, (m1, m2, K, C, count, has_best)
 
-    def __init__(self, matcher, rank=0, world=1, dist=None, device=None, producer_threads=True):
+    def __init__(self, matcher, rank=0, world=1, dist=None, device=None, producer_threads=True, force_windows=False):
         self.m, self.rank, self.world, self.dist, self.device = matcher, rank, world, dist, device
+        self.force_windows = force_windows      # run the windowed (collective) path even for world == 1 (tests)
         self.trials_done = 0
         self.local_candidates = 0
         self.terminated = False
@@ -120,7 +121,7 @@ class ShardedRansac:
         After the terminate threshold is crossed the remaining in-flight windows are drained without being
         committed (the sequential loop would not have run them, match4pcsBase.hpp:255).
         """
-        if self.world == 1:
+        if self.world == 1 and not self.force_windows:
             before = self.m.info().candidates_verified
             _, _, done = self.m.perform_n_steps(n)
             self.trials_done += n

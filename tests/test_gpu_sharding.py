@@ -64,3 +64,45 @@ def test_two_ranks_match_the_sequential_oracle(oracle_mod, s4p_lib_built, produc
         assert np.array_equal(np.array(r[4], np.float32).reshape(4, 4), T)
     assert res[0][5] + res[1][5] == om.stats().n_verified        # every candidate verified exactly once, on one rank
     assert res[0][5] > 0 and res[1][5] > 0
+
+
+def _rccl_worker(port, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from super4pcs_amd import capi, sharding
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=dev)
+    P, Q, _ = H.small_pair(30000, delta=DELTA, seed=23)
+    m = capi.Matcher(capi.make_options(DELTA, OVERLAP, N_S), device=0, max_pairs=1 << 20, max_quads=4 << 20)
+    m.init_full(P, Q)
+    sh = sharding.ShardedRansac(m, 0, 1, dist, dev, producer_threads=True, force_windows=True)
+    got = sh.run_windows(2 * N_WINDOWS)
+    i = m.info()
+    q.put((float(i.best_lcp), list(i.base), list(i.congruent), list(i.transform), int(got)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_windowed_driver_over_rccl(oracle_mod, s4p_lib_built):
+    """The collective path as the multi-GPU job runs it -- pinned key, non-blocking copies, all_reduce(MAX) and the
+    winner broadcast on device tensors over RCCL -- with the one rank a single-GPU box allows."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
+    p.start()
+    r = q.get(timeout=300)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    O = oracle_mod
+    P, Q, _ = H.small_pair(30000, delta=DELTA, seed=23)
+    om = O.Matcher(O.make_options(DELTA, OVERLAP, N_S))
+    om.init(P, Q)
+    for _ in range(2 * N_WINDOWS):
+        om.try_one_base()
+    T, lcp, base, cong, _, _ = om.best()
+    assert r[0] == lcp and r[1] == base.tolist() and r[2] == cong.tolist()
+    assert np.array_equal(np.array(r[3], np.float32).reshape(4, 4), T)
+    assert r[4] == om.stats().n_verified
