@@ -99,6 +99,7 @@ struct s4p_ctx {
   s4p_profile prof{};
   uint64_t last_K = 0;
   uint32_t verify_blocks = 512;
+  int ablate = 0;                    // S4P_ABLATE (profiling aid, read once at creation)
   double host_octree_s = 0, host_wait_s = 0;
 
   size_t verify_lds_bytes() const { return gcoarse.n * 4 + size_t(kVerifyThreads / 64) * kQueueEntries * sizeof(uint2); }
@@ -276,7 +277,7 @@ int32_t launch_verify(s4p_ctx* c, const BaseFrame& bf) {
   V.grid = c->dev_grid(); V.q4 = c->q4.p; V.q4v = c->q4v.p; V.n_q = c->n_q; V.base = bf;
   V.quads = c->lane[c->cur].quads.p; V.tags = c->lane[c->cur].tags.p; V.counts = c->lane[c->cur].counts.p; V.K_dev = &c->lane[c->cur].ctr.p->K; V.K_cap = uint32_t(c->max_quads);
   V.ctr = c->lane[c->cur].ctr.p; V.cand_idx = c->lane[c->cur].cand_idx.p; V.cand_T = c->lane[c->cur].cand_T.p;
-  { const char* ab = getenv("S4P_ABLATE"); V.ablate = ab ? atoi(ab) : 0; }   // debugging aid, results are wrong when set
+  V.ablate = c->ablate;
   hipLaunchKernelGGL(k_gate, dim3(1024), dim3(256), 0, c->lane[c->cur].stream, V);
   if (c->prof_events) HIPCHK(c, hipEventRecord(c->ev[c->cur][0], c->lane[c->cur].stream));
   const size_t lds = c->verify_lds_bytes();
@@ -375,6 +376,10 @@ int32_t s4p_create(const s4p_options* opt, const s4p_limits* lim, int32_t device
   s4p_ctx* c = new s4p_ctx();
   c->device = device; c->opt = *opt;
   if (const char* ln = getenv("S4P_LANES")) { const int v = atoi(ln); if (v >= 1 && v <= s4p_ctx::kMaxLanes) c->n_lanes = v; }
+  if (const char* ab = getenv("S4P_ABLATE")) {       // profiling aid: drops parts of k_verify, so counts are WRONG
+    c->ablate = atoi(ab);
+    if (c->ablate) fprintf(stderr, "super4pcs_amd: S4P_ABLATE=%d is set: k_verify skips work, every result of this context is invalid\n", c->ablate);
+  }
   if (const char* vb = getenv("S4P_VERIFY_BLOCKS")) { const int v = atoi(vb); if (v >= 64 && v <= 4096) c->verify_blocks = uint32_t(v); }   // tuning knob
   snprintf(c->devname, sizeof c->devname, "%s (%s)", prop.name, prop.gcnArchName);
   c->max_pairs = (lim && lim->max_pairs) ? lim->max_pairs : (4ull << 20);
