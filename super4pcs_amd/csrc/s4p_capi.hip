@@ -412,7 +412,7 @@ int32_t s4p_create(const s4p_options* opt, const s4p_limits* lim, int32_t device
     if ((e = hipEventCreateWithFlags(&c->done[sl], hipEventDisableTiming)) != hipSuccess) return fail(e, "hipEventCreate");
   }
   {  // allow the verify kernels their dynamic LDS (coarse bitmap + survivor queues)
-    const int max_lds = int(kCoarseMaxWords * 4 + (kVerifyThreads / 64) * 3 * kQueueEntries * 4);
+    const int max_lds = int(kCoarseMaxWords * 4 + (kVerifyThreads / 64) * kQueueEntries * sizeof(uint2));
     if ((e = hipFuncSetAttribute((const void*)k_verify<false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds)) != hipSuccess) return fail(e, "hipFuncSetAttribute");
     if ((e = hipFuncSetAttribute((const void*)k_verify<true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds)) != hipSuccess) return fail(e, "hipFuncSetAttribute");
     if ((e = hipFuncSetAttribute((const void*)k_verify_T, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds)) != hipSuccess) return fail(e, "hipFuncSetAttribute");
