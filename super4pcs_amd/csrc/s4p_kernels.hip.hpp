@@ -441,9 +441,9 @@ __device__ __forceinline__ bool rigid_gate(const BaseFrame& b, const float q[3][
 }
 
 // ---------------------------------------------------------------------------
-// k_verify: persistent workgroups of 8 waves; one wave64 per candidate quad, striding over
-// the quad list whose length lives in device memory (no host round trip).
-// LDS: coarse bitmap (<= 48 KB) + 16 private survivor queues (1 KB each).
+// k_gate / k_verify parameters.  k_verify: persistent 1024-thread workgroups, one wave64 per gated candidate; the
+// lengths of the quad list and of the gated list live in device memory (no host round trip).
+// LDS per workgroup: coarse bitmap (<= 48 KB) + 16 private survivor queues (1 KB each).
 // ---------------------------------------------------------------------------
 constexpr int kVerifyThreads = 1024;
 struct VerifyParams {
