@@ -49,13 +49,13 @@ def build(force=False, verbose=False):
 
 BINDIR = os.path.join(_HERE, "bin")
 CLI = os.path.join(BINDIR, "Super4PCS")
-CLI_SRC = os.path.join(ROOT, "demos", "Super4PCS", "super4pcs_test.cc")
+CLI_SRC = os.path.join(ROOT, "demos", "Super4PCS", "super4pcs_cli.cc")
 
 
 def build_cli(force=False):
     """The command-line program (demos/Super4PCS) against the facade headers and the library: plain host C++."""
     build()
-    deps = [CLI_SRC, os.path.join(ROOT, "demos", "demo-utils.h"), LIB,
+    deps = [CLI_SRC, os.path.join(ROOT, "demos", "cli_options.h"), LIB,
             os.path.join(ROOT, "include", "super4pcs", "io", "io.h"),
             os.path.join(ROOT, "include", "super4pcs", "algorithms", "match4pcsBase.h")]
     if not force and os.path.exists(CLI) and all(os.path.getmtime(d) <= os.path.getmtime(CLI) for d in deps):
