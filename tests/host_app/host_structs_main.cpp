@@ -3,6 +3,7 @@
 //   octree <file>   file: n, then n lines "x y z" (sampled, centred Q), then k, then k lines "distance epsilon".
 //                   Replays PairOctree (split memo + distance shells) over the k calls; prints, per call,
 //                   "n_seq n_leaf" followed by the permutation `ids` and the flattened sequence ids.
+//   frame <file>    same file format (only the points are used): prints UnitFrame's centre and ratio as hex floats.
 //   fourth <seed>   randomized check of FourthPointIndex against the literal loop of match4pcsBase.cc:324-338;
 //                   prints "queries <q> mismatches <m>".
 #include <cmath>
@@ -35,6 +36,16 @@ static int run_octree(const char* path) {
     for (uint32_t i = 0; i < tree.n_seq(); ++i) std::printf("%u ", sid[i]);
     std::printf("\n");
   }
+  return 0;
+}
+
+static int run_frame(const char* path) {
+  std::ifstream f(path);
+  size_t n = 0; f >> n;
+  std::vector<float> qx(n), qy(n), qz(n), ux, uy, uz;
+  for (size_t i = 0; i < n; ++i) f >> qx[i] >> qy[i] >> qz[i];
+  s4p::UnitFrame frame; frame.build(qx, qy, qz, ux, uy, uz);
+  std::printf("%a %a %a %a\n", double(frame.gcenter[0]), double(frame.gcenter[1]), double(frame.gcenter[2]), double(frame.ratio));
   return 0;
 }
 
@@ -84,7 +95,8 @@ static int run_fourth(unsigned seed) {
 
 int main(int argc, char** argv) {
   if (argc == 3 && !std::strcmp(argv[1], "octree")) return run_octree(argv[2]);
+  if (argc == 3 && !std::strcmp(argv[1], "frame")) return run_frame(argv[2]);
   if (argc == 3 && !std::strcmp(argv[1], "fourth")) return run_fourth(unsigned(std::atoi(argv[2])));
-  std::fprintf(stderr, "usage: %s octree <file> | fourth <seed>\n", argv[0]);
+  std::fprintf(stderr, "usage: %s octree <file> | frame <file> | fourth <seed>\n", argv[0]);
   return 2;
 }

@@ -46,6 +46,10 @@ def test_pair_octree_matches_oracle_permutation(oracle_mod, host_app, tmp_path, 
         f.write("%d\n" % len(calls))
         for d, e in calls:
             f.write("%.9g %.9g\n" % (np.float32(d), np.float32(e)))
+    # synch3DContent (pairCreationFunctor.h:90-122): same centre and ratio, bit for bit
+    fr = subprocess.run([host_app, "frame", str(path)], check=True, capture_output=True, text=True).stdout.split()
+    _, _, g, ratio = om.frame()
+    assert [float.fromhex(v) for v in fr[:3]] == [float(v) for v in g] and float.fromhex(fr[3]) == float(np.float32(ratio))
     out = subprocess.run([host_app, "octree", str(path)], check=True, capture_output=True, text=True).stdout.split("\n")
     n = q.shape[0]
     for c, (d, e) in enumerate(calls):
