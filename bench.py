@@ -170,13 +170,20 @@ def main():
         ttr = {"seconds": t_reg, "lcp": float(lcp2), "trials_run": int(i2.bases_tried), "candidates_verified": int(i2.candidates_verified)}
         del m2
 
-    traffic, traffic_note = None, "no PMC summary found"
+    traffic, traffic_note, limiter = None, "no PMC summary found", None
     pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_k_verify.json")
     if os.path.exists(pmc_file):
         try:
             pj = json.load(open(pmc_file))
             traffic = pj["hbm_bytes_per_launch"]
             traffic_note = pj["note"]
+            ta = pj.get("ta") or {}
+            if ta.get("TA_BUSY_avr") and ta.get("GRBM_GUI_ACTIVE"):
+                # what actually binds k_verify: the gather-address path, not HBM
+                limiter = {"unit": "TA (texture addresser: divergent 8/16-byte gathers)",
+                           "busy_frac": ta["TA_BUSY_avr"] / (ta["GRBM_GUI_ACTIVE"] / 8.0),
+                           "wavefront_gathers_per_launch": ta.get("TA_FLAT_READ_WAVEFRONTS_sum"),
+                           "source": "profiles/r01_pmc_k_verify.json (rocprofv3 --pmc, S4P_LANES=1; GRBM_GUI_ACTIVE is summed over the 8 XCDs)"}
         except Exception:
             pass
 
@@ -199,7 +206,7 @@ def main():
                        "parallelism": "bases sharded over %d GPU(s), one allreduce(max) per window" % world,
                        "time_to_register": ttr},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note, "limiter": limiter,
                          "kernel": "k_verify", "avg_launch_ms": avg_ms, "launches": int(prof.verify_launches),
                          "candidates_per_launch": cand_per_launch, "algorithmic_bytes_per_candidate": bc, "kbar": kbar,
                          "filter_pass_fraction": {"coarse_bitmap": pk.verify_l0_pass / queries, "reach_bit": pk.verify_l1_pass / queries,
