@@ -57,7 +57,9 @@ const char* s4p_matcher_last_error(const s4p_matcher* m);
 s4p_ctx* s4p_matcher_ctx(s4p_matcher* m);   /* the device context, for profiling */
 
 /* UniformDistSampler::operator() (src/super4pcs/sampling.h:104-121): keeps the first point of
- * every delta-voxel in input order.  out_index receives the kept input indices (capacity n). */
+ * every delta-voxel in input order.  out_index receives the kept input indices (capacity n).
+ * Returns the number kept, 0 on bad arguments, -1 if the device sampler hit a HIP error (printed to stderr;
+ * there is no silent host fallback for errors -- the host hash only serves small clouds and machines without a device). */
 int64_t s4p_uniform_dist_sample(const float* x, const float* y, const float* z, int64_t n, float delta,
                                 int64_t* out_index);
 

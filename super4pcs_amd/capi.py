@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsuper4pcs_amd.so")
+# S4P_LIB: explicit path of the shared library (A/B runs of kernel variants on the GPU box); default = the in-tree build
+LIB_PATH = os.environ.get("S4P_LIB") or os.path.join(_HERE, "lib", "libsuper4pcs_amd.so")
 
 S4P_OK = 0
 ERR_NAMES = {0: "OK", -1: "BAD_ARG", -2: "NO_DEVICE", -3: "HIP", -4: "OOM", -5: "CAPACITY", -6: "UNSUPPORTED", -7: "STATE"}

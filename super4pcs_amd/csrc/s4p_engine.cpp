@@ -30,7 +30,7 @@
 #include "s4p_matcher.h"
 
 namespace s4p {
-long long gpu_uniform_dist_sample(const float* x, const float* y, const float* z, long long n, float delta, long long* out_index);
+long long gpu_uniform_dist_sample(const float* x, const float* y, const float* z, long long n, float delta, long long* out_index, int device);
 }
 
 namespace {
@@ -69,14 +69,17 @@ constexpr int64_t kGpuSamplerMin = 32768;
 
 // sampling.h:104-121: first point per delta-voxel, voxel = int(floor(coord * (1.0f / delta))).
 // Large clouds go through the device sampler (s4p_sampler.hip) when a GPU is visible; the host hash below is the
-// same function for small clouds and for facade users that sample before any matcher (hence any device) exists.
-int64_t voxel_first_hits(const float* x, const float* y, const float* z, int64_t n, float delta, int64_t* out) {
+// same function for small clouds, for voxel coordinates beyond +-2^20 and for facade users that sample on a machine
+// without any HIP device (the Sampler concept of the reference is host code, sampling.h).  A HIP *error* of the device
+// sampler is not papered over: it is returned as -1 (and was printed to stderr by the sampler).
+int64_t voxel_first_hits(const float* x, const float* y, const float* z, int64_t n, float delta, int64_t* out, int device = -1) {
   if (n >= kGpuSamplerMin) {
     const char* force = std::getenv("S4P_SAMPLER");
     if (!(force && std::strcmp(force, "host") == 0)) {
       static_assert(sizeof(long long) == sizeof(int64_t), "index type");
-      const long long k = s4p::gpu_uniform_dist_sample(x, y, z, n, delta, reinterpret_cast<long long*>(out));
+      const long long k = s4p::gpu_uniform_dist_sample(x, y, z, n, delta, reinterpret_cast<long long*>(out), device);
       if (k >= 0) return int64_t(k);
+      if (k == -2) return -1;
     }
   }
   const float scale = 1.0f / delta;
@@ -95,6 +98,7 @@ int64_t voxel_first_hits(const float* x, const float* y, const float* z, int64_t
 struct s4p_matcher {
   s4p_options opt{};
   s4p_ctx* ctx = nullptr;
+  int device = 0;
   std::string err;
   std::mt19937 rng;
   Cloud Ps, Qs;
@@ -563,7 +567,7 @@ int32_t s4p_matcher_create(const s4p_options* opt, const s4p_limits* lim, int32_
   s4p_ctx* ctx = nullptr;
   if (int32_t rc = s4p_create(opt, lim, device, &ctx)) return rc;
   s4p_matcher* m = new s4p_matcher();
-  m->opt = *opt; m->ctx = ctx; m->rng.seed(opt->random_seed);
+  m->opt = *opt; m->ctx = ctx; m->device = device; m->rng.seed(opt->random_seed);
   m->set_identity();
   *out = m;
   return S4P_OK;
@@ -655,10 +659,12 @@ int32_t s4p_matcher_init(s4p_matcher* m, const s4p_cloud_view* p, const s4p_clou
 int32_t s4p_matcher_init_full(s4p_matcher* m, const s4p_cloud_view* P, const s4p_cloud_view* Q) {
   if (!m) return S4P_ERR_BAD_ARG;
   if (!view_ok(P) || !view_ok(Q) || P->n == 0 || Q->n == 0) return m->fail(S4P_ERR_BAD_ARG, "empty or null cloud");
+  bool sampler_failed = false;
   auto subset = [&](const s4p_cloud_view& v, bool sample, std::vector<std::vector<float>>& store) -> s4p_cloud_view {
     if (!sample) return v;                                          // "use whole cloud", match4pcsBase.hpp:115-119
     std::vector<int64_t> idx(size_t(v.n));
-    const int64_t k = voxel_first_hits(v.x, v.y, v.z, v.n, m->opt.delta, idx.data());
+    const int64_t k = voxel_first_hits(v.x, v.y, v.z, v.n, m->opt.delta, idx.data(), m->device);
+    if (k < 0) { sampler_failed = true; return v; }
     const float* src[9] = {v.x, v.y, v.z, v.nx, v.ny, v.nz, v.r, v.g, v.b};
     store.assign(9, {});
     const float* dst[9];
@@ -675,6 +681,7 @@ int32_t s4p_matcher_init_full(s4p_matcher* m, const s4p_cloud_view* P, const s4p
   const bool sample_q = uint64_t(Q->n) > m->opt.sample_size;
   const s4p_cloud_view pv = subset(*P, sample_p, sp);
   const s4p_cloud_view qv = subset(*Q, sample_q, sq);
+  if (sampler_failed) return m->fail(S4P_ERR_HIP, "device UniformDistSampler failed (HIP error, see stderr); no silent host fallback");
   return s4p_matcher_init(m, &pv, &qv, sample_q ? 1 : 0);
 }
 

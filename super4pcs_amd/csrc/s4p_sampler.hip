@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdio>
 #include <mutex>
 #include <vector>
 
@@ -98,6 +99,7 @@ namespace {
 struct SamplerState {
   std::mutex mu;
   bool probed = false, usable = false;
+  int device = -1;                 // the device the stream and buffers below live on
   hipStream_t stream = nullptr;
   float* d_xyz = nullptr; size_t cap_pts = 0;
   unsigned long long* d_keys = nullptr; uint32_t* d_vals = nullptr; size_t cap_tab = 0;
@@ -107,56 +109,74 @@ struct SamplerState {
 SamplerState g_sampler;
 }  // namespace
 
-// Returns the number of kept points, or -1 if the device path is unavailable / not applicable (caller uses the host path).
-long long gpu_uniform_dist_sample(const float* x, const float* y, const float* z, long long n, float delta, long long* out_index) {
+// Returns the number of kept points; -1 if the device path is NOT APPLICABLE (no HIP device visible -- a facade user may
+// sample before any matcher exists -- or a voxel coordinate outside +-2^20: the caller's host hash is the same function);
+// -2 on a HIP ERROR, which the caller reports loudly instead of hiding it behind the host path.
+long long gpu_uniform_dist_sample(const float* x, const float* y, const float* z, long long n, float delta, long long* out_index, int device) {
   if (n <= 0 || n >= 0x7FFFFFF0ll) return -1;
   SamplerState& S = g_sampler;
   std::lock_guard<std::mutex> lk(S.mu);
+  if (S.probed && S.usable && device >= 0 && device != S.device) {      // another GPU than last time: start over on it
+    (void)hipSetDevice(S.device);
+    if (S.d_xyz) { (void)hipFree(S.d_xyz); (void)hipFree(S.d_slot); (void)hipFree(S.d_out); }
+    if (S.d_keys) { (void)hipFree(S.d_keys); (void)hipFree(S.d_vals); }
+    if (S.d_blocks) (void)hipFree(S.d_blocks);
+    if (S.d_misc) (void)hipFree(S.d_misc);
+    if (S.stream) (void)hipStreamDestroy(S.stream);
+    S.d_xyz = nullptr; S.d_slot = S.d_out = S.d_blocks = S.d_misc = nullptr; S.d_keys = nullptr; S.d_vals = nullptr;
+    S.cap_pts = S.cap_tab = S.cap_blocks = 0; S.stream = nullptr; S.probed = false; S.usable = false;
+  }
   if (!S.probed) {
     S.probed = true;
     int ndev = 0;
-    if (hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0 && hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking) == hipSuccess) S.usable = true;
+    if (hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0) {
+      if (device < 0) { if (hipGetDevice(&device) != hipSuccess) device = 0; }
+      if (device < ndev && hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking) == hipSuccess) { S.usable = true; S.device = device; }
+    }
   }
   if (!S.usable) return -1;
-  auto ok = [](hipError_t e) { return e == hipSuccess; };
+  device = S.device;
+  hipError_t last = hipSuccess;
+  auto ok = [&last](hipError_t e) { if (e != hipSuccess) { last = e; fprintf(stderr, "super4pcs_amd: device sampler: %s\n", hipGetErrorString(e)); } return e == hipSuccess; };
+  if (device >= 0 && !ok(hipSetDevice(device))) return -2;
   const size_t un = size_t(n);
   size_t tab = 1; while (tab < 2 * un) tab <<= 1;
   const uint32_t nblocks = uint32_t((un + kScanBlock - 1) / kScanBlock);
   if (S.cap_pts < un) {
     if (S.d_xyz) { (void)hipFree(S.d_xyz); (void)hipFree(S.d_slot); (void)hipFree(S.d_out); }
     S.d_xyz = nullptr; S.cap_pts = 0;
-    if (!ok(hipMalloc((void**)&S.d_xyz, un * 12)) || !ok(hipMalloc((void**)&S.d_slot, un * 4)) || !ok(hipMalloc((void**)&S.d_out, un * 4))) return -1;
+    if (!ok(hipMalloc((void**)&S.d_xyz, un * 12)) || !ok(hipMalloc((void**)&S.d_slot, un * 4)) || !ok(hipMalloc((void**)&S.d_out, un * 4))) return -2;
     S.cap_pts = un;
   }
   if (S.cap_tab < tab) {
     if (S.d_keys) { (void)hipFree(S.d_keys); (void)hipFree(S.d_vals); }
     S.d_keys = nullptr; S.cap_tab = 0;
-    if (!ok(hipMalloc((void**)&S.d_keys, tab * 8)) || !ok(hipMalloc((void**)&S.d_vals, tab * 4))) return -1;
+    if (!ok(hipMalloc((void**)&S.d_keys, tab * 8)) || !ok(hipMalloc((void**)&S.d_vals, tab * 4))) return -2;
     S.cap_tab = tab;
   }
   if (S.cap_blocks < nblocks) {
     if (S.d_blocks) (void)hipFree(S.d_blocks);
     S.d_blocks = nullptr; S.cap_blocks = 0;
-    if (!ok(hipMalloc((void**)&S.d_blocks, size_t(nblocks) * 4))) return -1;
+    if (!ok(hipMalloc((void**)&S.d_blocks, size_t(nblocks) * 4))) return -2;
     S.cap_blocks = nblocks;
   }
-  if (!S.d_misc && !ok(hipMalloc((void**)&S.d_misc, 8))) return -1;
+  if (!S.d_misc && !ok(hipMalloc((void**)&S.d_misc, 8))) return -2;
   float* dx = S.d_xyz; float* dy = dx + un; float* dz = dy + un;
   if (!ok(hipMemcpyAsync(dx, x, un * 4, hipMemcpyHostToDevice, S.stream)) || !ok(hipMemcpyAsync(dy, y, un * 4, hipMemcpyHostToDevice, S.stream)) ||
-      !ok(hipMemcpyAsync(dz, z, un * 4, hipMemcpyHostToDevice, S.stream))) return -1;
+      !ok(hipMemcpyAsync(dz, z, un * 4, hipMemcpyHostToDevice, S.stream))) return -2;
   if (!ok(hipMemsetAsync(S.d_keys, 0xFF, tab * 8, S.stream)) || !ok(hipMemsetAsync(S.d_vals, 0xFF, tab * 4, S.stream)) ||
-      !ok(hipMemsetAsync(S.d_misc, 0, 8, S.stream))) return -1;
+      !ok(hipMemsetAsync(S.d_misc, 0, 8, S.stream))) return -2;
   const float scale = 1.0f / delta;                                                      // sampling.h:76
   hipLaunchKernelGGL(k_vox_insert, dim3(2048), dim3(256), 0, S.stream, dx, dy, dz, uint32_t(un), scale, S.d_keys, S.d_vals, uint32_t(tab - 1), S.d_slot, S.d_misc + 1);
   hipLaunchKernelGGL(k_vox_flag, dim3(nblocks), dim3(kScanBlock), 0, S.stream, S.d_vals, S.d_slot, uint32_t(un), S.d_blocks);
   hipLaunchKernelGGL(k_vox_scan, dim3(1), dim3(1024), 0, S.stream, S.d_blocks, nblocks, S.d_misc);
   hipLaunchKernelGGL(k_vox_write, dim3(nblocks), dim3(kScanBlock), 0, S.stream, S.d_vals, S.d_slot, uint32_t(un), S.d_blocks, S.d_out);
   uint32_t misc[2] = {0, 0};
-  if (!ok(hipGetLastError()) || !ok(hipMemcpyAsync(misc, S.d_misc, 8, hipMemcpyDeviceToHost, S.stream)) || !ok(hipStreamSynchronize(S.stream))) return -1;
+  if (!ok(hipGetLastError()) || !ok(hipMemcpyAsync(misc, S.d_misc, 8, hipMemcpyDeviceToHost, S.stream)) || !ok(hipStreamSynchronize(S.stream))) return -2;
   if (misc[1]) return -1;                         // a voxel coordinate outside +-2^20: host path handles it
   const uint32_t kept = misc[0];
   std::vector<uint32_t> idx(kept);
-  if (kept && !ok(hipMemcpy(idx.data(), S.d_out, size_t(kept) * 4, hipMemcpyDeviceToHost))) return -1;
+  if (kept && !ok(hipMemcpy(idx.data(), S.d_out, size_t(kept) * 4, hipMemcpyDeviceToHost))) return -2;
   for (uint32_t i = 0; i < kept; ++i) out_index[i] = (long long)idx[i];
   return (long long)kept;
 }
