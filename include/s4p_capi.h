@@ -123,6 +123,10 @@ int32_t s4p_try_congruent_set(s4p_ctx* ctx, const int32_t* base_ids, const int32
 /* Match4PCSBase::Verify (match4pcsBase.cc:508-567) for B explicit row-major 4x4
  * transforms: counts[b] = number of sampled-Q points with a sampled-P point within delta. */
 int32_t s4p_verify_transforms(s4p_ctx* ctx, const float* transforms, int64_t B, uint32_t* counts);
+/* Same, through the instrumented kernel (slower): stats4 = {exact point tests, queries that passed the coarse bitmap,
+ * the reach bitmap, the sub-cell mask} summed over the batch -- the measured inputs of the roofline's byte model
+ * (DESIGN.md section 7).  Measurement aid, no reference counterpart. */
+int32_t s4p_verify_transforms_counted(s4p_ctx* ctx, const float* transforms, int64_t B, uint32_t* counts, uint64_t* stats4);
 
 /* ---- fused, device-resident A -> B -> C for one base -------------------------
  * Equivalent to the body of Match4PCSBase::TryOneBase after SelectQuadrilateral

@@ -55,6 +55,7 @@ def lib():
         L.s4po_destroy.argtypes = [C.c_void_p]
         L.s4po_set_mode.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.s4po_set_budget.argtypes = [C.c_void_p, C.c_double]
+        L.s4po_set_threads.argtypes = [C.c_void_p, C.c_int]
         L.s4po_budget_hit.restype = C.c_int32
         L.s4po_budget_hit.argtypes = [C.c_void_p]
         L.s4po_sample.restype = C.c_uint64
@@ -146,6 +147,10 @@ class Matcher:
 
     def set_mode(self, full_counts, use_kdtree=True, keep_trace=False):
         self.L.s4po_set_mode(self.h, int(full_counts), int(use_kdtree), int(keep_trace))
+
+    def set_threads(self, n):
+        """OpenMP threads of the candidate loop (baseline B of BASELINE.md section 3); 1 = the reference's serial loop."""
+        self.L.s4po_set_threads(self.h, int(n))
 
     def set_budget(self, seconds):
         self.L.s4po_set_budget(self.h, float(seconds))

@@ -849,10 +849,17 @@ struct Matcher {
 
   // ---- match4pcsBase.cc:508-567  Verify ---------------------------------------
   float verify(const float* T, unsigned* good_out = nullptr) {
+    uint64_t q = 0;
+    const float r = verify_against(T, best_LCP, good_out, &q);
+    n_verify_queries += q;
+    return r;
+  }
+  // The loop of Verify with the running best passed in (const: callable from the OpenMP candidate loop of baseline B)
+  float verify_against(const float* T, const float best_so_far, unsigned* good_out, uint64_t* queries) const {
     const float epsilon = opt.delta;
     unsigned good_points = 0;
     const size_t number_of_points = Qs.size();
-    const size_t terminate_value = size_t(best_LCP * float(number_of_points));
+    const size_t terminate_value = size_t(best_so_far * float(number_of_points));
     const float sq_eps = epsilon * epsilon;
     for (size_t i = 0; i < number_of_points; ++i) {
       const float* q = Qs[i].pos;
@@ -862,7 +869,7 @@ struct Matcher {
       bool hit;
       if (use_kdtree) hit = kd.closest(t, sq_eps) != -1;
       else hit = brute_hit(t, sq_eps);
-      n_verify_queries++;
+      ++*queries;
       if (hit) good_points++;
       if (!full_counts && number_of_points - i + good_points < terminate_value) break;
     }
@@ -887,6 +894,7 @@ struct Matcher {
     for (int k = 0; k < 3; ++k) centroid1[k] = ((cbase[0].pos[k] + cbase[1].pos[k]) + cbase[2].pos[k]) / 3.f;
     size_t nb = 0;
     if (per_cand) per_cand->assign(quads.size(), -1);
+    if (omp_threads > 1) return try_congruent_set_omp(b1, b2, b3, b4, cbase, centroid1, quads, nbCongruent, per_cand, best_count, best_index);
     for (int i = 0; i < int(quads.size()); ++i) {
       if (budget_seconds > 0 && (i & 15) == 0 &&
           std::chrono::duration<double>(std::chrono::steady_clock::now() - budget_t0).count() > budget_seconds) {
@@ -917,6 +925,68 @@ struct Matcher {
             if (best_index) *best_index = i;
           }
         }
+      }
+    }
+    nbCongruent = nb;
+    return best_LCP > opt.terminate_threshold;
+  }
+
+  // Baseline B of BASELINE.md section 3 ("best-effort CPU"): the candidate loop of TryCongruentSet under
+  // `#pragma omp parallel for`, as the reference's legacy Match4PCS does by default (match4pcsBase.h:190-192,
+  // match4pcsBase.hpp:390-393).  Every thread scores its candidates with the early exit against the best LCP the
+  // base STARTED with (a read-only snapshot), then one ordered pass applies "first strictly greater wins": an
+  // abandoned candidate could not have won, so base, winner and transform equal the serial loop's.
+  // BENCH/TEST INFRASTRUCTURE, like the rest of this file.
+  int omp_threads = 1;
+  bool try_congruent_set_omp(int b1, int b2, int b3, int b4, const P3* cbase, const float* centroid1,
+                             const std::vector<std::array<int, 4>>& quads, size_t& nbCongruent, std::vector<int>* per_cand,
+                             unsigned* best_count, int* best_index) {
+    const double pi = std::acos(-1);
+    const int K = int(quads.size());
+    std::vector<int> good_of(size_t(K), -1);
+    const float snapshot = best_LCP;
+    uint64_t queries = 0; size_t nb = 0;
+    bool stop = false;
+#pragma omp parallel for schedule(dynamic, 16) num_threads(omp_threads) reduction(+ : queries, nb)
+    for (int i = 0; i < K; ++i) {
+      if (stop) continue;
+      if (budget_seconds > 0 && (i & 15) == 0 &&
+          std::chrono::duration<double>(std::chrono::steady_clock::now() - budget_t0).count() > budget_seconds) {
+        stop = true;          // benign race: a flag that only ever goes to true
+        continue;
+      }
+      const P3 cc[4] = {Qs[quads[i][0]], Qs[quads[i][1]], Qs[quads[i][2]], Qs[quads[i][3]]};
+      float centroid2[3];
+      for (int k = 0; k < 3; ++k) centroid2[k] = ((cc[0].pos[k] + cc[1].pos[k]) + cc[2].pos[k]) / 3.f;
+      float rms = -1; float T[16];
+      const bool ok = compute_rigid(cbase, cc, centroid1, centroid2, float(double(opt.max_angle) * pi / 180.0), T, rms);
+      if (ok && rms >= 0.f && rms < 2.0f * opt.delta) {
+        unsigned good = 0;
+        verify_against(T, snapshot, &good, &queries);
+        good_of[size_t(i)] = int(good);
+        nb++;
+      }
+    }
+    if (stop) budget_hit = true;
+    n_verify_queries += queries; n_verified += nb;
+    for (int i = 0; i < K; ++i) {                                   // ordered selection, match4pcsBase.hpp:467-484
+      if (good_of[size_t(i)] < 0) continue;
+      if (per_cand) (*per_cand)[size_t(i)] = good_of[size_t(i)];
+      const float lcp = float(unsigned(good_of[size_t(i)])) / float(Qs.size());
+      if (lcp > best_LCP) {
+        const P3 cc[4] = {Qs[quads[i][0]], Qs[quads[i][1]], Qs[quads[i][2]], Qs[quads[i][3]]};
+        float centroid2[3];
+        for (int k = 0; k < 3; ++k) centroid2[k] = ((cc[0].pos[k] + cc[1].pos[k]) + cc[2].pos[k]) / 3.f;
+        float rms = -1; float T[16];
+        compute_rigid(cbase, cc, centroid1, centroid2, float(double(opt.max_angle) * pi / 180.0), T, rms);
+        base_ids[0] = b1; base_ids[1] = b2; base_ids[2] = b3; base_ids[3] = b4;
+        for (int k = 0; k < 4; ++k) current_congruent[k] = quads[i][k];
+        best_LCP = lcp;
+        std::memcpy(transform, T, sizeof(T));
+        std::memcpy(qcentroid1, centroid1, 3 * sizeof(float));
+        std::memcpy(qcentroid2, centroid2, sizeof(centroid2));
+        if (best_count) *best_count = unsigned(good_of[size_t(i)]);
+        if (best_index) *best_index = i;
       }
     }
     nbCongruent = nb;
@@ -1066,6 +1136,8 @@ void s4po_set_budget(void* h, double seconds) {
   m->budget_seconds = seconds; m->budget_t0 = std::chrono::steady_clock::now(); m->budget_hit = false;
 }
 int32_t s4po_budget_hit(void* h) { return static_cast<Matcher*>(h)->budget_hit ? 1 : 0; }
+// bench-only: number of OpenMP threads of the candidate loop (1 = the reference's serial loop)
+void s4po_set_threads(void* h, int n) { static_cast<Matcher*>(h)->omp_threads = n < 1 ? 1 : n; }
 void s4po_set_mode(void* h, int full_counts, int use_kdtree, int keep_trace) {
   Matcher* m = static_cast<Matcher*>(h);
   m->full_counts = full_counts != 0; m->use_kdtree = use_kdtree != 0; m->keep_trace = keep_trace != 0;

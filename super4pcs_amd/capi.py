@@ -18,7 +18,7 @@ ERR_NAMES = {0: "OK", -1: "BAD_ARG", -2: "NO_DEVICE", -3: "HIP", -4: "OOM", -5: 
 
 EXPORTED_SYMBOLS = [
     "s4p_create", "s4p_destroy", "s4p_last_error", "s4p_device_name", "s4p_set_clouds", "s4p_set_base",
-    "s4p_extract_pairs", "s4p_find_congruent", "s4p_try_congruent_set", "s4p_verify_transforms",
+    "s4p_extract_pairs", "s4p_find_congruent", "s4p_try_congruent_set", "s4p_verify_transforms", "s4p_verify_transforms_counted",
     "s4p_try_base", "s4p_last_verified", "s4p_try_base_async", "s4p_try_base_wait", "s4p_pair_state_words", "s4p_pair_state_save", "s4p_pair_state_restore", "s4p_stage_slots", "s4p_pipeline_depth", "s4p_stage_base", "s4p_try_base_staged_async", "s4p_skip_base", "s4p_last_candidates", "s4p_transform_points", "s4p_profile_enable", "s4p_profile_get",
     "s4p_selftest_ieee",
 ]
@@ -96,6 +96,8 @@ def load_library():
     L.s4p_try_congruent_set.argtypes = [vp, ip, ip, C.c_int64, ip, C.POINTER(BaseResult)]
     L.s4p_verify_transforms.restype = C.c_int32
     L.s4p_verify_transforms.argtypes = [vp, fp, C.c_int64, C.POINTER(C.c_uint32)]
+    L.s4p_verify_transforms_counted.restype = C.c_int32
+    L.s4p_verify_transforms_counted.argtypes = [vp, fp, C.c_int64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
     L.s4p_try_base.restype = C.c_int32
     L.s4p_try_base.argtypes = [vp, ip, C.c_float, C.c_float, C.POINTER(BaseResult)]
     L.s4p_skip_base.restype = C.c_int32
@@ -221,6 +223,14 @@ class Context:
         out = np.empty(T.shape[0], np.uint32)
         self._chk(self.L.s4p_verify_transforms(self.h, _f(T), T.shape[0], out.ctypes.data_as(C.POINTER(C.c_uint32))))
         return out
+
+    def verify_stats(self, T):
+        """Instrumented Verify of a batch: {"tests", "l0", "l1", "l2"} summed over the batch (roofline byte model)."""
+        T = np.ascontiguousarray(T, np.float32).reshape(-1, 16)
+        out = np.empty(T.shape[0], np.uint32)
+        st = (C.c_uint64 * 4)()
+        self._chk(self.L.s4p_verify_transforms_counted(self.h, _f(T), T.shape[0], out.ctypes.data_as(C.POINTER(C.c_uint32)), st))
+        return {"tests": int(st[0]), "l0": int(st[1]), "l1": int(st[2]), "l2": int(st[3]), "counts": out}
 
     def try_base(self, base_ids, inv1, inv2):
         base_ids = np.ascontiguousarray(base_ids, np.int32)
@@ -395,6 +405,17 @@ class Matcher:
         p = Profile()
         self._chk(self.L.s4p_profile_get(self.ctx_handle(), C.byref(p), int(reset)))
         return p
+
+    def last_candidates(self, cap):
+        """Quads (reference order) and per-candidate inlier counts (-1 = rms gate failed) of the base whose device pass
+        finished last (s4p_last_candidates on the matcher's context): parity checks only."""
+        cap = max(int(cap), 1)
+        quads = np.empty((cap, 4), np.int32); counts = np.empty(cap, np.int32)
+        K = C.c_int64()
+        rc = self.L.s4p_last_candidates(self.ctx_handle(), _i(quads), _i(counts), cap, C.byref(K))
+        if rc != S4P_OK:
+            raise S4PError(rc, self.L.s4p_last_error(self.ctx_handle()).decode())
+        return quads[:K.value].copy(), counts[:K.value].copy()
 
     def init_full(self, P, Q, Pn=None, Prgb=None, Qn=None, Qrgb=None):
         vp, vq = _View(P, Pn, Prgb), _View(Q, Qn, Qrgb)

@@ -66,7 +66,9 @@ struct s4p_ctx {
     DevBuf<int2> ab1, ab2; DevBuf<uint32_t> okey1, okey2, cell1, cell2, bucket1, next1, mask2; DevBuf<float4> ew1, ew2;
     DevBuf<int4> quads; DevBuf<unsigned long long> tags; DevBuf<uint32_t> counts, cand_idx; DevBuf<float4> cand_T;
     DevBuf<unsigned long long> ht_keys, ht_heads; uint32_t ht_mask = 0, epoch = 0;
-    DevBuf<DevCounters> ctr;
+    DevBuf<DevCounters> ctr;          // [0] live counters of the base in flight, [1] its result record (what the host reads)
+    DevBuf<uint4> slots;              // k_verify: per-workgroup best, reduced by its last workgroup
+    bool dirty = false;               // a stage-level call left the live counters non-zero: clear before a fused pass
     DevBuf<uint32_t> seq[2];          // device copy of a staged sequence blob (layout: StageSlot)
   };
   static constexpr int kMaxLanes = 4;
@@ -77,11 +79,11 @@ struct s4p_ctx {
   // written by whoever stages the base (the caller thread, or the engine's octree thread through s4p_stage_base)
   // and read by the H2D copies of s4p_try_base_staged_async; the engine recycles a slot after that base's wait.
   struct StageSlot {
-    // one blob per pair set, uploaded with a single copy: seq_id[n_seq] | seq_leaf[n_seq] | pad to 16 B | leaves[n_leaf]
+    // one blob per pair set, uploaded with a single copy: seq_id[n_seq] | leaf_off[n_leaf + 1] | pad to 16 B | leaves[n_leaf]
     PinBuf<uint32_t> seq[2];
     uint32_t n_seq[2] = {0, 0}, n_leaf[2] = {0, 0};
-    static uint32_t leaf_word(uint32_t n_seq) { return (2u * n_seq + 3u) & ~3u; }
-    static size_t blob_words(size_t n_q) { return 2 * n_q + 4 + 4 * n_q; }
+    static uint32_t leaf_word(uint32_t n_seq, uint32_t n_leaf) { return (n_seq + n_leaf + 1u + 3u) & ~3u; }
+    static size_t blob_words(size_t n_q) { return 2 * n_q + 8 + 4 * n_q; }      // n_leaf <= n_seq <= n_q
     float eps_unit[2] = {0, 0}, n_radius[2] = {0, 0}, distance[2] = {0, 0}, normal_angle[2] = {0, 0};
   };
   static constexpr int kStageSlots = 12;   // 0..5: self-staging of s4p_try_base_async; 6..11: a threaded driver
@@ -100,9 +102,10 @@ struct s4p_ctx {
   uint64_t last_K = 0;
   uint32_t verify_blocks = 512;
   int ablate = 0;                    // S4P_ABLATE (profiling aid, read once at creation)
+  bool fused = true;                 // S4P_FUSED=0: per-pair preparation and the rms gate as separate launches (A/B aid)
   double host_octree_s = 0, host_wait_s = 0;
 
-  size_t verify_lds_bytes() const { return gcoarse.n * 4 + size_t(kVerifyThreads / 64) * kQueueEntries * sizeof(uint2); }
+  size_t verify_lds_bytes() const { return gcoarse.n * 4 + size_t(kVerifyThreads / 64) * kQueueWordsPerWave * 4; }
   LcpGrid dev_grid() const {
     LcpGrid g;
     g.reach = greach.p; g.list_hdr = glist_hdr.p; g.nbr = gnbr.p;
@@ -145,23 +148,22 @@ void stage_pairs(s4p_ctx* c, int slot, int set, float pair_distance, float pair_
   st.eps_unit[set] = c->tree.eps_unit; st.n_radius[set] = nRadius; st.distance[set] = pair_distance; st.normal_angle[set] = pair_normals_angle;
   static_assert(sizeof(Leaf) == sizeof(float4), "leaf records are uploaded as float4");
   uint32_t* blob = st.seq[set].p;
-  c->tree.flatten(blob, blob + st.n_seq[set], reinterpret_cast<Leaf*>(blob + s4p_ctx::StageSlot::leaf_word(st.n_seq[set])));
+  c->tree.flatten(blob, blob + st.n_seq[set], reinterpret_cast<Leaf*>(blob + s4p_ctx::StageSlot::leaf_word(st.n_seq[set], st.n_leaf[set])));
 }
 
 // part 2: upload the staged sequence of one set and fill its kernel parameters.
 int32_t upload_pairs_staged(s4p_ctx* c, int slot, int set, float pair_distance_epsilon, int bp1, int bp2, PairParams& P) {
   const s4p_ctx::StageSlot& st = c->stage[slot];
+  s4p_ctx::Lane& L = c->lane[c->cur];
   const uint32_t n_seq = st.n_seq[set], n_leaf = st.n_leaf[set];
-  DevBuf<int2>& ab = set == 0 ? c->lane[c->cur].ab1 : c->lane[c->cur].ab2;
-  DevBuf<uint32_t>& okey = set == 0 ? c->lane[c->cur].okey1 : c->lane[c->cur].okey2;
-  const uint32_t leaf_word = s4p_ctx::StageSlot::leaf_word(n_seq);
-  uint32_t* dseq = c->lane[c->cur].seq[set].p;
-  if (n_seq) HIPCHK(c, hipMemcpyAsync(dseq, st.seq[set].p, (size_t(leaf_word) + 4u * n_leaf) * sizeof(uint32_t), hipMemcpyHostToDevice, c->lane[c->cur].stream));
+  const uint32_t leaf_word = s4p_ctx::StageSlot::leaf_word(n_seq, n_leaf);
+  uint32_t* dseq = L.seq[set].p;
+  if (n_seq) HIPCHK(c, hipMemcpyAsync(dseq, st.seq[set].p, (size_t(leaf_word) + 4u * n_leaf) * sizeof(uint32_t), hipMemcpyHostToDevice, L.stream));
   P = PairParams{};
   P.ux = c->ux.p; P.uy = c->uy.p; P.uz = c->uz.p; P.qx = c->qx.p; P.qy = c->qy.p; P.qz = c->qz.p;
   P.nx = c->has_normals ? c->qnx.p : nullptr; P.ny = c->qny.p; P.nz = c->qnz.p;
   P.cr = c->has_rgb ? c->qcr.p : nullptr; P.cg = c->qcg.p; P.cb = c->qcb.p;
-  P.seq_id = dseq; P.seq_leaf = dseq + n_seq; P.n_seq = n_seq; P.leaves = reinterpret_cast<const float4*>(dseq + leaf_word);
+  P.seq_id = dseq; P.n_seq = n_seq; P.leaf_off = dseq + n_seq; P.leaves = reinterpret_cast<const float4*>(dseq + leaf_word); P.n_leaf = n_leaf;
   P.n_q = c->n_q; P.nRadius = st.n_radius[set]; P.eps_unit = st.eps_unit[set];
   P.pair_distance = st.distance[set]; P.pair_distance_eps = pair_distance_epsilon; P.pair_normals_angle = st.normal_angle[set];
   P.max_normal_difference = c->opt.max_normal_difference; P.max_color_distance = c->opt.max_color_distance;
@@ -171,30 +173,30 @@ int32_t upload_pairs_staged(s4p_ctx* c, int slot, int set, float pair_distance_e
     P.b1pos[k] = c->base_xyz[3 * bp1 + k]; P.b2pos[k] = c->base_xyz[3 * bp2 + k];
     P.b1rgb[k] = c->base_rgb[3 * bp1 + k]; P.b2rgb[k] = c->base_rgb[3 * bp2 + k];
   }
-  P.ab = ab.p; P.okey = okey.p; P.counter = set == 0 ? &c->lane[c->cur].ctr.p->m1 : &c->lane[c->cur].ctr.p->m2;
-  P.cap = uint32_t(c->max_pairs); P.overflow = &c->lane[c->cur].ctr.p->overflow; P.overflow_bit = set == 0 ? 1u : 2u;
+  P.ab = set == 0 ? L.ab1.p : L.ab2.p; P.okey = set == 0 ? L.okey1.p : L.okey2.p;
+  P.counter = set == 0 ? &L.ctr.p->m1 : &L.ctr.p->m2;
+  P.cap = uint32_t(c->max_pairs); P.overflow = &L.ctr.p->overflow; P.overflow_bit = set == 0 ? 1u : 2u;
+  P.do_prep = 0;
   return S4P_OK;
 }
 
-// loop 2 + the pair filters (k_pairs) for one set, or for both sets of a base in one launch
+// loop 2 + the pair filters (k_pairs) for one set, or for both sets of a base in one launch: one wave per primitive,
+// a few primitives per wave so that the end-of-workgroup append is one atomic per ~8 primitives
 int32_t launch_pairs_kernel(s4p_ctx* c, const PairParams2& PP, int n_sets) {
-  hipLaunchKernelGGL(k_pairs, dim3(std::min<uint32_t>(c->n_q, 512u), uint32_t(n_sets)), dim3(256), 0, c->lane[c->cur].stream, PP);
+  const uint32_t wgs = std::min<uint32_t>(std::max<uint32_t>((c->n_q + 2u * kPairWaves - 1u) / (2u * kPairWaves), 1u), 1024u);
+  hipLaunchKernelGGL(k_pairs, dim3(wgs, uint32_t(n_sets)), dim3(64 * kPairWaves), 0, c->lane[c->cur].stream, PP);
   HIPCHK(c, hipGetLastError());
   return S4P_OK;
-}
-
-int32_t launch_pairs_staged(s4p_ctx* c, int slot, int set, float pair_distance_epsilon, int bp1, int bp2) {
-  PairParams2 PP{};
-  if (int32_t rc = upload_pairs_staged(c, slot, set, pair_distance_epsilon, bp1, bp2, PP.set[0])) return rc;
-  if (PP.set[0].n_seq == 0) return S4P_OK;
-  return launch_pairs_kernel(c, PP, 1);
 }
 
 int32_t launch_pairs(s4p_ctx* c, int set, float pair_distance, float pair_normals_angle, float pair_distance_epsilon,
                      int bp1, int bp2) {
   const int slot = int(c->stage_rr % uint32_t(s4p_ctx::kStageSlots));
   stage_pairs(c, slot, set, pair_distance, pair_normals_angle, pair_distance_epsilon, true);
-  return launch_pairs_staged(c, slot, set, pair_distance_epsilon, bp1, bp2);
+  PairParams2 PP{};
+  if (int32_t rc = upload_pairs_staged(c, slot, set, pair_distance_epsilon, bp1, bp2, PP.set[0].pair)) return rc;
+  if (PP.set[0].pair.n_seq == 0) return S4P_OK;
+  return launch_pairs_kernel(c, PP, 1);
 }
 
 // segment lengths / normal "angles" of an ordered base (match4pcsBase.hpp:318-326)
@@ -232,38 +234,6 @@ void quad_setup(const s4p_ctx* c, float distance_threshold2, QuadGrid& qg, ConeT
   }
 }
 
-int32_t launch_quads(s4p_ctx* c, float inv1, float inv2, float thr2) {
-  QuadGrid qg; ConeTable cone;
-  quad_setup(c, thr2, qg, cone);
-  if (qg.egSize > 1024) S4P_FAIL(c, S4P_ERR_UNSUPPORTED, "FindCongruentQuadrilaterals grid finer than 1024^3 cells (delta/extent too small)");
-  c->lane[c->cur].epoch++;
-  if (c->lane[c->cur].epoch == 0xFFFFFFFFu) {   // wrap: clear the table once every 4e9 bases
-    HIPCHK(c, hipMemsetAsync(c->lane[c->cur].ht_keys.p, 0, c->lane[c->cur].ht_keys.n * 8, c->lane[c->cur].stream));
-    HIPCHK(c, hipMemsetAsync(c->lane[c->cur].ht_heads.p, 0, c->lane[c->cur].ht_heads.n * 8, c->lane[c->cur].stream));
-    c->lane[c->cur].epoch = 1;
-  }
-  HashTable ht{c->lane[c->cur].ht_keys.p, c->lane[c->cur].ht_heads.p, c->lane[c->cur].ht_mask, c->lane[c->cur].epoch};
-  PrepParams P1{};
-  P1.ux = c->ux.p; P1.uy = c->uy.p; P1.uz = c->uz.p; P1.qx = c->qx.p; P1.qy = c->qy.p; P1.qz = c->qz.p;
-  P1.ab = c->lane[c->cur].ab1.p; P1.m_dev = &c->lane[c->cur].ctr.p->m1; P1.cap = uint32_t(c->max_pairs); P1.invariant = inv1; P1.qg = qg;
-  P1.cell = c->lane[c->cur].cell1.p; P1.bucket = c->lane[c->cur].bucket1.p; P1.ew = c->lane[c->cur].ew1.p; P1.next = c->lane[c->cur].next1.p; P1.mask = nullptr; P1.ht = ht;
-  P1.cone.nb = 0;
-  PrepParams P2{};
-  P2.ux = c->ux.p; P2.uy = c->uy.p; P2.uz = c->uz.p; P2.qx = c->qx.p; P2.qy = c->qy.p; P2.qz = c->qz.p;
-  P2.ab = c->lane[c->cur].ab2.p; P2.m_dev = &c->lane[c->cur].ctr.p->m2; P2.cap = uint32_t(c->max_pairs); P2.invariant = inv2; P2.qg = qg;
-  P2.cell = c->lane[c->cur].cell2.p; P2.bucket = nullptr; P2.ew = c->lane[c->cur].ew2.p; P2.next = nullptr; P2.mask = c->lane[c->cur].mask2.p; P2.ht = ht;
-  P2.cone = cone;
-  hipLaunchKernelGGL(k_prep, dim3(1024, 2), dim3(256), 0, c->lane[c->cur].stream, P1, P2);
-  QuadParams Q{};
-  Q.ab1 = c->lane[c->cur].ab1.p; Q.okey1 = c->lane[c->cur].okey1.p; Q.bucket1 = c->lane[c->cur].bucket1.p; Q.ew1 = c->lane[c->cur].ew1.p; Q.next1 = c->lane[c->cur].next1.p;
-  Q.ab2 = c->lane[c->cur].ab2.p; Q.okey2 = c->lane[c->cur].okey2.p; Q.cell2 = c->lane[c->cur].cell2.p; Q.ew2 = c->lane[c->cur].ew2.p; Q.mask2 = c->lane[c->cur].mask2.p;
-  Q.m2_dev = &c->lane[c->cur].ctr.p->m2; Q.cap2 = uint32_t(c->max_pairs); Q.ht = ht; Q.thr = thr2;
-  Q.quads = c->lane[c->cur].quads.p; Q.tags = c->lane[c->cur].tags.p; Q.K_dev = &c->lane[c->cur].ctr.p->K; Q.K_cap = uint32_t(c->max_quads); Q.overflow = &c->lane[c->cur].ctr.p->overflow;
-  hipLaunchKernelGGL(k_quads, dim3(512), dim3(256), 0, c->lane[c->cur].stream, Q);
-  HIPCHK(c, hipGetLastError());
-  return S4P_OK;
-}
-
 BaseFrame make_base_frame(const s4p_ctx* c, const int32_t* base_ids) {
   BaseFrame b{};
   for (int i = 0; i < 3; ++i) { b.p[i][0] = c->hpx[base_ids[i]]; b.p[i][1] = c->hpy[base_ids[i]]; b.p[i][2] = c->hpz[base_ids[i]]; }
@@ -272,23 +242,71 @@ BaseFrame make_base_frame(const s4p_ctx* c, const int32_t* base_ids) {
   return b;
 }
 
+// Parameters of FindCongruentQuadrilaterals for the lane's current base: a fresh hash epoch, the per-set preparation
+// records (consumed by k_pairs on the fused path, by k_prep otherwise) and the enumeration record.
+int32_t quad_params(s4p_ctx* c, float inv1, float inv2, float thr2, PrepParams& P1, PrepParams& P2, QuadParams& Q) {
+  s4p_ctx::Lane& L = c->lane[c->cur];
+  QuadGrid qg; ConeTable cone;
+  quad_setup(c, thr2, qg, cone);
+  if (qg.egSize > 1024) S4P_FAIL(c, S4P_ERR_UNSUPPORTED, "FindCongruentQuadrilaterals grid finer than 1024^3 cells (delta/extent too small)");
+  L.epoch++;
+  if (L.epoch == 0xFFFFFFFFu) {   // wrap: clear the table once every 4e9 bases
+    HIPCHK(c, hipMemsetAsync(L.ht_keys.p, 0, L.ht_keys.n * 8, L.stream));
+    HIPCHK(c, hipMemsetAsync(L.ht_heads.p, 0, L.ht_heads.n * 8, L.stream));
+    L.epoch = 1;
+  }
+  HashTable ht{L.ht_keys.p, L.ht_heads.p, L.ht_mask, L.epoch};
+  P1 = PrepParams{};
+  P1.ux = c->ux.p; P1.uy = c->uy.p; P1.uz = c->uz.p; P1.qx = c->qx.p; P1.qy = c->qy.p; P1.qz = c->qz.p;
+  P1.ab = L.ab1.p; P1.m_dev = &L.ctr.p->m1; P1.cap = uint32_t(c->max_pairs); P1.invariant = inv1; P1.qg = qg;
+  P1.cell = L.cell1.p; P1.bucket = L.bucket1.p; P1.ew = L.ew1.p; P1.next = L.next1.p; P1.mask = nullptr; P1.ht = ht;
+  P1.cone.nb = 0;
+  P2 = PrepParams{};
+  P2.ux = c->ux.p; P2.uy = c->uy.p; P2.uz = c->uz.p; P2.qx = c->qx.p; P2.qy = c->qy.p; P2.qz = c->qz.p;
+  P2.ab = L.ab2.p; P2.m_dev = &L.ctr.p->m2; P2.cap = uint32_t(c->max_pairs); P2.invariant = inv2; P2.qg = qg;
+  P2.cell = L.cell2.p; P2.bucket = nullptr; P2.ew = L.ew2.p; P2.next = nullptr; P2.mask = L.mask2.p; P2.ht = ht;
+  P2.cone = cone;
+  Q = QuadParams{};
+  Q.ab1 = L.ab1.p; Q.okey1 = L.okey1.p; Q.bucket1 = L.bucket1.p; Q.ew1 = L.ew1.p; Q.next1 = L.next1.p;
+  Q.ab2 = L.ab2.p; Q.okey2 = L.okey2.p; Q.cell2 = L.cell2.p; Q.ew2 = L.ew2.p; Q.mask2 = L.mask2.p;
+  Q.m2_dev = &L.ctr.p->m2; Q.cap2 = uint32_t(c->max_pairs); Q.ht = ht; Q.thr = thr2;
+  Q.quads = L.quads.p; Q.tags = L.tags.p; Q.K_dev = &L.ctr.p->K; Q.K_cap = uint32_t(c->max_quads); Q.overflow = &L.ctr.p->overflow;
+  Q.do_gate = 0;
+  return S4P_OK;
+}
+
+GateParams gate_params(s4p_ctx* c, const BaseFrame& bf) {
+  s4p_ctx::Lane& L = c->lane[c->cur];
+  GateParams G{};
+  G.q4 = c->q4.p; G.base = bf; G.counts = L.counts.p; G.cand_idx = L.cand_idx.p; G.cand_T = L.cand_T.p; G.C_dev = &L.ctr.p->C;
+  return G;
+}
+
+void launch_prep_kernel(s4p_ctx* c, const PrepParams& P1, const PrepParams& P2) {
+  hipLaunchKernelGGL(k_prep, dim3(1024, 2), dim3(256), 0, c->lane[c->cur].stream, P1, P2);
+}
+void launch_quads_kernel(s4p_ctx* c, const QuadParams& Q) {
+  hipLaunchKernelGGL(k_quads, dim3(512), dim3(256), 0, c->lane[c->cur].stream, Q);
+}
+void launch_gate_kernel(s4p_ctx* c, const GateParams& G) {
+  s4p_ctx::Lane& L = c->lane[c->cur];
+  GateKernelParams K{G, L.quads.p, &L.ctr.p->K, uint32_t(c->max_quads)};
+  hipLaunchKernelGGL(k_gate, dim3(1024), dim3(256), 0, L.stream, K);
+}
+
+// Verify of every gated candidate + winner selection + result record (k_verify), bracketed by the profiling events
 int32_t launch_verify(s4p_ctx* c, const BaseFrame& bf) {
+  s4p_ctx::Lane& L = c->lane[c->cur];
   VerifyParams V{};
   V.grid = c->dev_grid(); V.q4 = c->q4.p; V.q4v = c->q4v.p; V.n_q = c->n_q; V.base = bf;
-  V.quads = c->lane[c->cur].quads.p; V.tags = c->lane[c->cur].tags.p; V.counts = c->lane[c->cur].counts.p; V.K_dev = &c->lane[c->cur].ctr.p->K; V.K_cap = uint32_t(c->max_quads);
-  V.ctr = c->lane[c->cur].ctr.p; V.cand_idx = c->lane[c->cur].cand_idx.p; V.cand_T = c->lane[c->cur].cand_T.p;
+  V.quads = L.quads.p; V.tags = L.tags.p; V.counts = L.counts.p; V.cand_idx = L.cand_idx.p; V.cand_T = L.cand_T.p;
+  V.ctr = L.ctr.p; V.res = L.ctr.p + 1; V.slots = L.slots.p; V.count_tests = c->prof_points ? 1 : 0;
   V.ablate = c->ablate;
-  hipLaunchKernelGGL(k_gate, dim3(1024), dim3(256), 0, c->lane[c->cur].stream, V);
-  if (c->prof_events) HIPCHK(c, hipEventRecord(c->ev[c->cur][0], c->lane[c->cur].stream));
+  if (c->prof_events) HIPCHK(c, hipEventRecord(c->ev[c->cur][0], L.stream));
   const size_t lds = c->verify_lds_bytes();
-  if (c->prof_points) hipLaunchKernelGGL(k_verify<true>, dim3(c->verify_blocks), dim3(kVerifyThreads), lds, c->lane[c->cur].stream, V);
-  else hipLaunchKernelGGL(k_verify<false>, dim3(c->verify_blocks), dim3(kVerifyThreads), lds, c->lane[c->cur].stream, V);
-  if (c->prof_events) HIPCHK(c, hipEventRecord(c->ev[c->cur][1], c->lane[c->cur].stream));
-  SelectParams S{};
-  S.tags = c->lane[c->cur].tags.p; S.counts = c->lane[c->cur].counts.p; S.quads = c->lane[c->cur].quads.p; S.K_dev = &c->lane[c->cur].ctr.p->K; S.K_cap = uint32_t(c->max_quads);
-  S.ctr = c->lane[c->cur].ctr.p; S.q4 = c->q4.p; S.base = bf;
-  hipLaunchKernelGGL(k_select, dim3(512), dim3(256), 0, c->lane[c->cur].stream, S);
-  hipLaunchKernelGGL(k_winner, dim3(512), dim3(256), 0, c->lane[c->cur].stream, S);
+  if (c->prof_points) hipLaunchKernelGGL(k_verify<true>, dim3(c->verify_blocks), dim3(kVerifyThreads), lds, L.stream, V);
+  else hipLaunchKernelGGL(k_verify<false>, dim3(c->verify_blocks), dim3(kVerifyThreads), lds, L.stream, V);
+  if (c->prof_events) HIPCHK(c, hipEventRecord(c->ev[c->cur][1], L.stream));
   HIPCHK(c, hipGetLastError());
   return S4P_OK;
 }
@@ -296,7 +314,7 @@ int32_t launch_verify(s4p_ctx* c, const BaseFrame& bf) {
 // enqueue the result read-back of the base in slot c->cur and mark its completion
 int32_t enqueue_result(s4p_ctx* c, const BaseFrame& bf) {
   c->slot_bf[c->cur] = bf;
-  HIPCHK(c, hipMemcpyAsync(c->hctr[c->cur].p, c->lane[c->cur].ctr.p, sizeof(DevCounters), hipMemcpyDeviceToHost, c->lane[c->cur].stream));
+  HIPCHK(c, hipMemcpyAsync(c->hctr[c->cur].p, c->lane[c->cur].ctr.p + 1, sizeof(DevCounters), hipMemcpyDeviceToHost, c->lane[c->cur].stream));
   HIPCHK(c, hipEventRecord(c->done[c->cur], c->lane[c->cur].stream));
   return S4P_OK;
 }
@@ -341,7 +359,8 @@ int32_t fetch_result(s4p_ctx* c, const BaseFrame& bf, s4p_base_result* r) {
 
 int32_t reset_counters(s4p_ctx* c) {
   hipLaunchKernelGGL(k_reset_counters, dim3(1), dim3(1), 0, c->lane[c->cur].stream, c->lane[c->cur].ctr.p);
-  if (c->prof_points) HIPCHK(c, hipMemsetAsync(&c->lane[c->cur].ctr.p->point_tests, 0, 32, c->lane[c->cur].stream));
+  HIPCHK(c, hipGetLastError());
+  c->lane[c->cur].dirty = false;
   return S4P_OK;
 }
 
@@ -380,7 +399,8 @@ int32_t s4p_create(const s4p_options* opt, const s4p_limits* lim, int32_t device
     c->ablate = atoi(ab);
     if (c->ablate) fprintf(stderr, "super4pcs_amd: S4P_ABLATE=%d is set: k_verify skips work, every result of this context is invalid\n", c->ablate);
   }
-  if (const char* vb = getenv("S4P_VERIFY_BLOCKS")) { const int v = atoi(vb); if (v >= 64 && v <= 4096) c->verify_blocks = uint32_t(v); }   // tuning knob
+  if (const char* vb = getenv("S4P_VERIFY_BLOCKS")) { const int v = atoi(vb); if (v >= 64 && v <= kVerifyMaxBlocks) c->verify_blocks = uint32_t(v); }   // tuning knob
+  if (const char* fu = getenv("S4P_FUSED")) c->fused = atoi(fu) != 0;
   snprintf(c->devname, sizeof c->devname, "%s (%s)", prop.name, prop.gcnArchName);
   c->max_pairs = (lim && lim->max_pairs) ? lim->max_pairs : (4ull << 20);
   c->max_quads = (lim && lim->max_quads) ? lim->max_quads : (16ull << 20);
@@ -400,11 +420,11 @@ int32_t s4p_create(const s4p_options* opt, const s4p_limits* lim, int32_t device
     A(L.bucket1, mp); A(L.next1, mp); A(L.mask2, mp * kMaskWords); A(L.ew1, mp); A(L.ew2, mp);
     A(L.quads, mq); A(L.tags, mq); A(L.counts, mq); A(L.cand_idx, mq); A(L.cand_T, mq * 3);
     A(L.ht_keys, hts); A(L.ht_heads, hts); L.ht_mask = hts - 1;
-    A(L.ctr, 1);
+    A(L.ctr, 2); A(L.slots, kVerifyMaxBlocks);
     if ((e = hipMemset(L.ht_keys.p, 0, size_t(hts) * 8)) != hipSuccess) return fail(e, "hipMemset");
     if ((e = hipMemset(L.ht_heads.p, 0, size_t(hts) * 8)) != hipSuccess) return fail(e, "hipMemset");
-    if ((e = hipMemset(L.ctr.p, 0, sizeof(DevCounters))) != hipSuccess) return fail(e, "hipMemset");
-    L.epoch = 0;
+    if ((e = hipMemset(L.ctr.p, 0, 2 * sizeof(DevCounters))) != hipSuccess) return fail(e, "hipMemset");
+    L.epoch = 0; L.dirty = true;                        // first use of a lane starts with an explicit clear (best_tag = ~0)
   }
 #undef A
   for (int sl = 0; sl < s4p_ctx::kMaxLanes; ++sl) {
@@ -412,10 +432,11 @@ int32_t s4p_create(const s4p_options* opt, const s4p_limits* lim, int32_t device
     if ((e = hipEventCreateWithFlags(&c->done[sl], hipEventDisableTiming)) != hipSuccess) return fail(e, "hipEventCreate");
   }
   {  // allow the verify kernels their dynamic LDS (coarse bitmap + survivor queues)
-    const int max_lds = int(kCoarseMaxWords * 4 + (kVerifyThreads / 64) * kQueueEntries * sizeof(uint2));
+    const int max_lds = int(kCoarseMaxWords * 4 + (kVerifyThreads / 64) * kQueueWordsPerWave * 4);
     if ((e = hipFuncSetAttribute((const void*)k_verify<false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds)) != hipSuccess) return fail(e, "hipFuncSetAttribute");
     if ((e = hipFuncSetAttribute((const void*)k_verify<true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds)) != hipSuccess) return fail(e, "hipFuncSetAttribute");
-    if ((e = hipFuncSetAttribute((const void*)k_verify_T, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds)) != hipSuccess) return fail(e, "hipFuncSetAttribute");
+    if ((e = hipFuncSetAttribute((const void*)k_verify_T<false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds)) != hipSuccess) return fail(e, "hipFuncSetAttribute");
+    if ((e = hipFuncSetAttribute((const void*)k_verify_T<true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds)) != hipSuccess) return fail(e, "hipFuncSetAttribute");
   }
   for (auto& row : c->ev) for (auto& ev : row) if ((e = hipEventCreate(&ev)) != hipSuccess) return fail(e, "hipEventCreate");
   *out = c;
@@ -433,7 +454,7 @@ void s4p_destroy(s4p_ctx* c) {
   for (auto& L : c->lane) {
     L.ab1.free(); L.ab2.free(); L.okey1.free(); L.okey2.free(); L.cell1.free(); L.cell2.free();
     L.bucket1.free(); L.next1.free(); L.mask2.free(); L.ew1.free(); L.ew2.free();
-    L.quads.free(); L.tags.free(); L.counts.free(); L.cand_idx.free(); L.cand_T.free(); L.ht_keys.free(); L.ht_heads.free(); L.ctr.free();
+    L.quads.free(); L.tags.free(); L.counts.free(); L.cand_idx.free(); L.cand_T.free(); L.ht_keys.free(); L.ht_heads.free(); L.ctr.free(); L.slots.free();
     for (int s = 0; s < 2; ++s) L.seq[s].free();
   }
   for (auto& h : c->hctr) h.free();
@@ -459,6 +480,7 @@ int32_t s4p_set_clouds(s4p_ctx* c, const float* px, const float* py, const float
   if (!px || !py || !pz || !qx || !qy || !qz || n_p <= 0 || n_q <= 0) S4P_FAIL(c, S4P_ERR_BAD_ARG, "s4p_set_clouds: null or empty cloud");
   if (n_q > 46340) S4P_FAIL(c, S4P_ERR_UNSUPPORTED, "sampled Q larger than 46340 points: 32-bit pair order keys would overflow");
   if (n_p > 0x7FFFFFF0ll) S4P_FAIL(c, S4P_ERR_UNSUPPORTED, "sampled P too large");
+  if (c->q_head != c->q_tail) S4P_FAIL(c, S4P_ERR_STATE, "s4p_set_clouds: asynchronous bases outstanding (their kernels read the buffers this call replaces): call s4p_try_base_wait first");
   HIPCHK(c, hipSetDevice(c->device));
   c->clouds_set = false;
   c->n_p = uint32_t(n_p); c->n_q = uint32_t(n_q);
@@ -585,6 +607,7 @@ int32_t s4p_extract_pairs(s4p_ctx* c, float pair_distance, float pair_normals_an
   S4P_NEED_IDLE(c);
   HIPCHK(c, hipSetDevice(c->device));
   if (int32_t rc = reset_counters(c)) return rc;
+  c->lane[c->cur].dirty = true;
   if (int32_t rc = launch_pairs(c, 0, pair_distance, pair_normals_angle, pair_distance_epsilon, bp1, bp2)) return rc;
   HIPCHK(c, hipMemcpyAsync(c->hctr[c->cur].p, c->lane[c->cur].ctr.p, sizeof(DevCounters), hipMemcpyDeviceToHost, c->lane[c->cur].stream));
   HIPCHK(c, hipStreamSynchronize(c->lane[c->cur].stream));
@@ -625,7 +648,12 @@ int32_t s4p_find_congruent(s4p_ctx* c, float inv1, float inv2, float /*thr1*/, f
   HIPCHK(c, hipMemcpyAsync(c->lane[c->cur].okey2.p, idx.data(), size_t(m2) * 4, hipMemcpyHostToDevice, c->lane[c->cur].stream));
   const uint32_t mm[2] = {uint32_t(m1), uint32_t(m2)};
   HIPCHK(c, hipMemcpyAsync(&c->lane[c->cur].ctr.p->m1, mm, 8, hipMemcpyHostToDevice, c->lane[c->cur].stream));
-  if (int32_t rc = launch_quads(c, inv1, inv2, thr2)) return rc;
+  c->lane[c->cur].dirty = true;
+  { PrepParams P1, P2; QuadParams Q;
+    if (int32_t rc = quad_params(c, inv1, inv2, thr2, P1, P2, Q)) return rc;
+    launch_prep_kernel(c, P1, P2);
+    launch_quads_kernel(c, Q);
+    HIPCHK(c, hipGetLastError()); }
   HIPCHK(c, hipMemcpyAsync(c->hctr[c->cur].p, c->lane[c->cur].ctr.p, sizeof(DevCounters), hipMemcpyDeviceToHost, c->lane[c->cur].stream));
   HIPCHK(c, hipStreamSynchronize(c->lane[c->cur].stream));
   if (int32_t rc = check_overflow(c, c->hctr[c->cur].p->overflow)) return rc;
@@ -666,6 +694,7 @@ int32_t s4p_try_congruent_set(s4p_ctx* c, const int32_t* base_ids, const int32_t
   }
   const uint32_t k32 = uint32_t(K);
   HIPCHK(c, hipMemcpyAsync(&c->lane[c->cur].ctr.p->K, &k32, 4, hipMemcpyHostToDevice, c->lane[c->cur].stream));
+  launch_gate_kernel(c, gate_params(c, bf));
   if (int32_t rc = launch_verify(c, bf)) return rc;
   if (int32_t rc = fetch_result(c, bf, result)) return rc;
   if (per_candidate && K > 0) {
@@ -676,32 +705,52 @@ int32_t s4p_try_congruent_set(s4p_ctx* c, const int32_t* base_ids, const int32_t
   return S4P_OK;
 }
 
-int32_t s4p_verify_transforms(s4p_ctx* c, const float* T, int64_t B, uint32_t* counts) {
+namespace {
+int32_t verify_transforms_impl(s4p_ctx* c, const float* T, int64_t B, uint32_t* counts, uint64_t* stats4) {
   if (!c || (B > 0 && (!T || !counts))) return S4P_ERR_BAD_ARG;
   if (!c->clouds_set) S4P_FAIL(c, S4P_ERR_STATE, "s4p_set_clouds not called");
   if (B <= 0) return S4P_OK;
   S4P_NEED_IDLE(c);
   HIPCHK(c, hipSetDevice(c->device));
+  s4p_ctx::Lane& L = c->lane[c->cur];
   DevBuf<float> dT; DevBuf<uint32_t> dC;
   HIPCHK(c, dT.alloc(size_t(B) * 16));
   hipError_t e = dC.alloc(size_t(B));
   if (e != hipSuccess) { dT.free(); HIPCHK(c, e); }
   int32_t rc = S4P_OK;
   do {
-    if ((e = hipMemcpyAsync(dT.p, T, size_t(B) * 64, hipMemcpyHostToDevice, c->lane[c->cur].stream)) != hipSuccess) break;
+    if (stats4) { if ((rc = reset_counters(c)) != S4P_OK) break; L.dirty = true; }
+    if ((e = hipMemcpyAsync(dT.p, T, size_t(B) * 64, hipMemcpyHostToDevice, L.stream)) != hipSuccess) break;
     VerifyTParams V{};
     V.grid = c->dev_grid(); V.q4 = c->q4v.p; V.n_q = c->n_q; V.T = dT.p; V.B = uint32_t(B);
-    V.counts = dC.p; V.ctr = c->lane[c->cur].ctr.p;
+    V.counts = dC.p; V.ctr = L.ctr.p;
     const uint32_t wpb = kVerifyThreads / 64;
     const uint32_t blocks = uint32_t(std::min<int64_t>((B + wpb - 1) / wpb, 512));
-    hipLaunchKernelGGL(k_verify_T, dim3(blocks), dim3(kVerifyThreads), c->verify_lds_bytes(), c->lane[c->cur].stream, V);
+    if (stats4) hipLaunchKernelGGL(k_verify_T<true>, dim3(blocks), dim3(kVerifyThreads), c->verify_lds_bytes(), L.stream, V);
+    else hipLaunchKernelGGL(k_verify_T<false>, dim3(blocks), dim3(kVerifyThreads), c->verify_lds_bytes(), L.stream, V);
     if ((e = hipGetLastError()) != hipSuccess) break;
-    if ((e = hipMemcpyAsync(counts, dC.p, size_t(B) * 4, hipMemcpyDeviceToHost, c->lane[c->cur].stream)) != hipSuccess) break;
-    e = hipStreamSynchronize(c->lane[c->cur].stream);
+    if ((e = hipMemcpyAsync(counts, dC.p, size_t(B) * 4, hipMemcpyDeviceToHost, L.stream)) != hipSuccess) break;
+    if (stats4 && (e = hipMemcpyAsync(c->hctr[c->cur].p, L.ctr.p, sizeof(DevCounters), hipMemcpyDeviceToHost, L.stream)) != hipSuccess) break;
+    e = hipStreamSynchronize(L.stream);
+    if (stats4 && e == hipSuccess) {
+      const DevCounters& d = *c->hctr[c->cur].p;
+      stats4[0] = d.point_tests; stats4[1] = d.l0_pass; stats4[2] = d.l1_pass; stats4[3] = d.l2_pass;
+    }
   } while (0);
   dT.free(); dC.free();
+  if (rc != S4P_OK) return rc;
   if (e != hipSuccess) { c->err = std::string("s4p_verify_transforms: ") + hipGetErrorString(e); rc = S4P_ERR_HIP; }
   return rc;
+}
+}  // namespace
+
+int32_t s4p_verify_transforms(s4p_ctx* c, const float* T, int64_t B, uint32_t* counts) {
+  return verify_transforms_impl(c, T, B, counts, nullptr);
+}
+
+int32_t s4p_verify_transforms_counted(s4p_ctx* c, const float* T, int64_t B, uint32_t* counts, uint64_t* stats4) {
+  if (!stats4) return S4P_ERR_BAD_ARG;
+  return verify_transforms_impl(c, T, B, counts, stats4);
 }
 
 int32_t s4p_stage_slots(const s4p_ctx*) { return s4p_ctx::kStageSlots; }
@@ -727,17 +776,29 @@ int32_t s4p_try_base_staged_async(s4p_ctx* c, int32_t slot, const int32_t* base_
   if (c->q_tail - c->q_head >= uint32_t(c->n_lanes)) S4P_FAIL(c, S4P_ERR_STATE, "all lanes busy: call s4p_try_base_wait first");
   HIPCHK(c, hipSetDevice(c->device));
   c->cur = int(c->q_tail % uint32_t(c->n_lanes));
-  if (int32_t rc = reset_counters(c)) return rc;
+  s4p_ctx::Lane& L = c->lane[c->cur];
+  // The device pass of one base: 2 uploads and 3 launches (k_pairs: both pair sets + their preparation; k_quads:
+  // enumeration + rigid transform + rms gate; k_verify: LCP of every candidate + winner + result record + counters
+  // cleared for the lane's next base), then the read-back of the result record.
+  if (L.dirty) { if (int32_t rc = reset_counters(c)) return rc; }
   const float eps = 2.0f * c->opt.delta;
-  if (c->prof_events) HIPCHK(c, hipEventRecord(c->ev[c->cur][2], c->lane[c->cur].stream));
-  { PairParams2 PP{};                                  // both pair sets: two uploads, one launch
-    if (int32_t rc = upload_pairs_staged(c, slot, 0, eps, 0, 1, PP.set[0])) return rc;
-    if (int32_t rc = upload_pairs_staged(c, slot, 1, eps, 2, 3, PP.set[1])) return rc;
-    if (int32_t rc = launch_pairs_kernel(c, PP, 2)) return rc; }
-  if (c->prof_events) HIPCHK(c, hipEventRecord(c->ev[c->cur][3], c->lane[c->cur].stream));
-  if (int32_t rc = launch_quads(c, inv1, inv2, eps)) return rc;
-  if (c->prof_events) HIPCHK(c, hipEventRecord(c->ev[c->cur][4], c->lane[c->cur].stream));
   const BaseFrame bf = make_base_frame(c, base_ids);
+  PrepParams P1, P2; QuadParams Q;
+  if (int32_t rc = quad_params(c, inv1, inv2, eps, P1, P2, Q)) return rc;
+  if (c->prof_events) HIPCHK(c, hipEventRecord(c->ev[c->cur][2], L.stream));
+  { PairParams2 PP{};
+    if (int32_t rc = upload_pairs_staged(c, slot, 0, eps, 0, 1, PP.set[0].pair)) return rc;
+    if (int32_t rc = upload_pairs_staged(c, slot, 1, eps, 2, 3, PP.set[1].pair)) return rc;
+    PP.set[0].prep = P1; PP.set[1].prep = P2;
+    PP.set[0].pair.do_prep = PP.set[1].pair.do_prep = c->fused ? 1 : 0;
+    if (int32_t rc = launch_pairs_kernel(c, PP, 2)) return rc; }
+  if (c->prof_events) HIPCHK(c, hipEventRecord(c->ev[c->cur][3], L.stream));
+  if (!c->fused) launch_prep_kernel(c, P1, P2);
+  if (c->fused) { Q.do_gate = 1; Q.gate = gate_params(c, bf); }
+  launch_quads_kernel(c, Q);
+  if (!c->fused) launch_gate_kernel(c, gate_params(c, bf));
+  HIPCHK(c, hipGetLastError());
+  if (c->prof_events) HIPCHK(c, hipEventRecord(c->ev[c->cur][4], L.stream));
   if (int32_t rc = launch_verify(c, bf)) return rc;
   if (int32_t rc = enqueue_result(c, bf)) return rc;
   c->q_tail++;

@@ -557,6 +557,18 @@ int32_t try_one_base(s4p_matcher* m, bool& ok, s4p_base_result* last) {
 
 bool view_ok(const s4p_cloud_view* v) { return v && v->x && v->y && v->z && v->n >= 0; }
 
+// Bases started with s4p_matcher_next_base_async and never waited for: their kernels still read the lane buffers, and
+// the context's FIFO must stay in step with m->inflight.  Called before anything that re-initialises or restarts.
+void drain_inflight(s4p_matcher* m) {
+  for (auto& pr : m->inflight) {
+    if (!pr.device) continue;
+    s4p_base_result dummy;
+    (void)s4p_try_base_wait(m->ctx, &dummy);
+    producer_release_slot(m, pr.slot);
+  }
+  m->inflight.clear();
+}
+
 }  // namespace
 
 extern "C" {
@@ -592,6 +604,7 @@ int32_t s4p_matcher_init(s4p_matcher* m, const s4p_cloud_view* p, const s4p_clou
   if (!m) return S4P_ERR_BAD_ARG;
   if (!view_ok(p) || !view_ok(q) || p->n == 0 || q->n == 0) return m->fail(S4P_ERR_BAD_ARG, "s4p_matcher_init: empty or null cloud");
   producer_stop(m);
+  drain_inflight(m);
   m->prod.consumed = 0; m->prod.next_index = 0;
   m->ready = false;
   Cloud& Ps = m->Ps; Cloud& Qs = m->Qs;
@@ -801,7 +814,7 @@ int32_t s4p_matcher_perform_n_steps(s4p_matcher* m, int32_t n, s4p_visitor_fn vi
   const int end = m->current_trial + n;
   int next_prep = m->current_trial;
   std::vector<s4p_matcher::Prepared>& fifo = m->inflight;
-  fifo.clear();
+  drain_inflight(m);                       // leftovers of next_base_async calls the caller never waited for
   int32_t rc = S4P_OK;
   for (int i = m->current_trial; i < end && rc == S4P_OK; ++i) {
     while (int(fifo.size()) < s4p_pipeline_depth(m->ctx) && next_prep < end) {

@@ -113,16 +113,19 @@ class PairOctree {
   uint32_t n_leaf() const { return uint32_t(nxt_.size() + early_.size()); }
 
   // The flat "sequence" k_pairs walks: final-level children first, then the parked early leaves
-  // (second loop order, intersectionFunctor.h:201-232).  seq_id/seq_leaf hold n_seq() entries, leaves n_leaf().
-  void flatten(uint32_t* seq_id, uint32_t* seq_leaf, Leaf* leaves) const {
+  // (second loop order, intersectionFunctor.h:201-232).  seq_id holds n_seq() point ids; leaf l owns the slots
+  // [leaf_off[l], leaf_off[l+1]) of it (n_leaf() + 1 offsets; leaves are never empty), leaves[l] is its box.
+  void flatten(uint32_t* seq_id, uint32_t* leaf_off, Leaf* leaves) const {
     uint32_t li = 0, at = 0;
     auto emit = [&](const Node& nd, float h) {
       leaves[li] = Leaf{nd.c[0], nd.c[1], nd.c[2], h};
-      for (uint32_t k = nd.begin; k < nd.end; ++k, ++at) { seq_id[at] = ids[k]; seq_leaf[at] = li; }
+      leaf_off[li] = at;
+      for (uint32_t k = nd.begin; k < nd.end; ++k, ++at) seq_id[at] = ids[k];
       ++li;
     };
     for (const Node& nd : nxt_) emit(nd, eps_unit * 2.f);
     for (const EarlyNode& en : early_) emit(en.node, en.reach);
+    leaf_off[li] = at;
   }
 
  private:
@@ -423,7 +426,8 @@ struct LcpGridHost {
       const double ex = (double(hi[0]) - lo[0]) / h, ey = (double(hi[1]) - lo[1]) / h, ez = (double(hi[2]) - lo[2]) / h;
       if (ex < 2.0e9 && ey < 2.0e9 && ez < 2.0e9) {
         nx = int(ex) + 4; ny = int(ey) + 4; nz = int(ez) + 4;
-        if (ncell() <= max_cells && ncell() < 0xFFFFFFF0ull) break;
+        // nx and ny*nz below 2^24: the kernels form the linear cell index with two 24-bit multiply-adds
+        if (ncell() <= max_cells && ncell() < 0xFFFFFFF0ull && nx < (1 << 24) && uint64_t(ny) * uint64_t(nz) < (1ull << 24)) break;
       }
       h *= 1.25f;
     }

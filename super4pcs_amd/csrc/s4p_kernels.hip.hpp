@@ -9,10 +9,11 @@
 // Reference functions restated here (paths under /root/reference/src/super4pcs/):
 //   k_pairs        accelerators/pairExtraction/intersectionFunctor.h:197-233 (loop 2),
 //                  intersectionPrimitive.h:117-157, algorithms/pairCreationFunctor.h:151-218
-//   k_prep         algorithms/super4pcs.cc:118-146, accelerators/normalset.hpp:110-127,162-203
+//   k_prep (and the append step of k_pairs)  algorithms/super4pcs.cc:118-146, accelerators/normalset.hpp:110-127,162-203
 //   k_quads        algorithms/super4pcs.cc:151-163
-//   k_verify       algorithms/match4pcsBase.cc:365-500 (ComputeRigidTransformation),
-//                  match4pcsBase.cc:508-567 (Verify), accelerators/kdtree.h:417-421 (predicate)
+//   k_gate/k_quads algorithms/match4pcsBase.cc:365-500 (ComputeRigidTransformation + rms gate, match4pcsBase.hpp:436-439)
+//   k_verify       match4pcsBase.cc:508-567 (Verify), accelerators/kdtree.h:417-421 (predicate),
+//                  match4pcsBase.hpp:467-484 (first strictly greater LCP wins)
 //   k_apply        algorithms/match4pcsBase.hpp:265-267
 #pragma once
 #include <hip/hip_runtime.h>
@@ -53,7 +54,7 @@ struct DevCounters {
   unsigned long long best_tag;      // min tag among candidates with best_count
   unsigned long long point_tests;   // optional instrumentation (COUNT kernels only)
   unsigned long long l0_pass, l1_pass, l2_pass;
-  uint32_t cursor;                  // k_verify work cursor
+  uint32_t done;                    // k_verify: workgroups that have published their best (last one selects the winner)
   // winner record
   int32_t best_quad[4];
   float best_T[16];
@@ -86,17 +87,10 @@ struct LcpGrid {
   float sq_eps;                 // fl(delta*delta)
 };
 
-constexpr int kQueueEntries = 128;                 // per-wave survivor queue ({query, rank} per entry)
-constexpr int kCoarseMaxWords = 12288;             // 48 KB
-
-__device__ __forceinline__ bool cell_coords(const LcpGrid& g, float tx, float ty, float tz, int& ix, int& iy, int& iz) {
-  const float fx = floorf((tx - g.ox) * g.inv_h);
-  const float fy = floorf((ty - g.oy) * g.inv_h);
-  const float fz = floorf((tz - g.oz) * g.inv_h);
-  if (!(fx >= 0.f && fx < float(g.nx) && fy >= 0.f && fy < float(g.ny) && fz >= 0.f && fz < float(g.nz))) return false;
-  ix = int(fx); iy = int(fy); iz = int(fz);
-  return true;
-}
+constexpr int kQueueAEntries = 192;                // per-wave queue A (query index, 4 B): 63 left over + two 64-query chunks
+constexpr int kQueueBEntries = 128;                // per-wave queue B ({query, rank}, 8 B): 63 left over + one batch of 64
+constexpr int kQueueWordsPerWave = kQueueAEntries + 2 * kQueueBEntries;       // in 32-bit words (1.75 KB)
+constexpr int kCoarseMaxWords = 12288;             // 48 KB: with 28 KB of queues, two 1024-thread workgroups fit one CU's 160 KB
 
 // value held by every lane of the wave -> SGPR
 __device__ __forceinline__ float wave_uniform(float v) {
@@ -110,34 +104,54 @@ __device__ __forceinline__ void transform_point(const float* T, const float4 q, 
   tz = ((T[8] * q.x + T[9] * q.y) + T[10] * q.z) + T[11];
 }
 
-// L2 + exact point tests for query i, whose cell is the `rank`-th reachable one (L0 and L1 already passed).
-// The transformed point is recomputed here -- the same three expressions, hence the same bits -- rather than carried
-// through the queue: 18 flops for the ~10 % of queries that get this far against two LDS words per queued query.
-template <bool COUNT>
-__device__ __forceinline__ bool fine_test(const LcpGrid& g, const float4* q4, const float* T, uint32_t i, uint32_t rank,
-                                          unsigned long long* point_tests) {
-  const uint4 hdr = g.list_hdr[rank];
-  float tx, ty, tz;
-  transform_point(T, q4[i], tx, ty, tz);
-  // sub-cell of the query inside its cell (conservative: the mask was built with 1 % slack, rounding here is ~1e-5 cell)
-  const float ux = (tx - g.ox) * g.inv_h, uy = (ty - g.oy) * g.inv_h, uz = (tz - g.oz) * g.inv_h;
-  const float rx = ux - floorf(ux), ry = uy - floorf(uy), rz = uz - floorf(uz);
-  const uint32_t sx = min(uint32_t(max(int(rx * 4.f), 0)), 3u), sy = min(uint32_t(max(int(ry * 4.f), 0)), 3u),
-                 sz = min(uint32_t(max(int(rz * 4.f), 0)), 3u);
-  const uint32_t sb = sz * 16u + sy * 4u + sx;
-  const uint32_t mword = sb < 32u ? hdr.z : hdr.w;
-  if (!((mword >> (sb & 31u)) & 1u)) return false;
-  if (COUNT) atomicAdd(point_tests + 3, 1ull);     // l2_pass
-  const uint32_t s = hdr.x, e = hdr.x + hdr.y;
-  for (uint32_t p = s; p < e; p += 2) {                       // two independent 16 B loads per dependent step (four: slower)
-    const float4 pa = g.nbr[p];
-    const float4 pb = g.nbr[min(p + 1u, e - 1u)];            // (predicating this load away on odd tails was measured slower)
-    if (COUNT) atomicAdd(point_tests, (p + 1u < e) ? 2ull : 1ull);
-    const bool ha = sqn3(tx - pa.x, ty - pa.y, tz - pa.z) <= g.sq_eps;   // kdtree.h:417-421  sqdist <= cl_dist
-    const bool hb = sqn3(tx - pb.x, ty - pb.y, tz - pb.z) <= g.sq_eps;
-    if (ha | hb) return true;
+// Candidate transform in GRID units: U = diag(1/h) * (T - origin), so that floor(U * [q;1]) is the cell of the
+// transformed query.  Evaluated with fused multiply-adds: nine instructions per query instead of the 30 of "exact
+// transform, subtract origin, scale", and that is what stage 1 spends most of its time on.  It only LOCATES the query:
+// the result may differ from the exactly rounded cell coordinate by ~1e-5 cell, which the structure absorbs by
+// construction (a cell lists every P point within 1.01*delta of its box, LcpGridHost::plan; the 4x4x4 sub-cell masks
+// carry the same 1 % slack).  The inlier predicate itself (fine_batch) uses the exact, un-fused transform_point.
+// Only the coarse copy lives across the query loop (12 registers); the exact 3x4 and the fine-unit transform are
+// re-derived from the candidate's record where the dense stages need them -- keeping all 36 values live cost ~25 % of
+// the loop's instructions in scalar-register spills.
+struct GridXf { float u[12]; };
+__device__ __forceinline__ void load_rows(const float4* Tsrc, float T[12]) {      // 3x4 row-major; same address in every lane
+  const float4 r0 = Tsrc[0], r1 = Tsrc[1], r2 = Tsrc[2];
+  T[0] = r0.x; T[1] = r0.y; T[2] = r0.z; T[3] = r0.w; T[4] = r1.x; T[5] = r1.y; T[6] = r1.z; T[7] = r1.w;
+  T[8] = r2.x; T[9] = r2.y; T[10] = r2.z; T[11] = r2.w;
+}
+__device__ __forceinline__ GridXf make_grid_xf(const LcpGrid& g, const float* T, const float scale) {   // scale: 1 or 2^-cshift
+  GridXf X;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const float o = r == 0 ? g.ox : (r == 1 ? g.oy : g.oz);
+    X.u[4 * r + 0] = (T[4 * r + 0] * g.inv_h) * scale;
+    X.u[4 * r + 1] = (T[4 * r + 1] * g.inv_h) * scale;
+    X.u[4 * r + 2] = (T[4 * r + 2] * g.inv_h) * scale;
+    X.u[4 * r + 3] = ((T[4 * r + 3] - o) * g.inv_h) * scale;
   }
-  return false;
+  return X;
+}
+__device__ __forceinline__ float coarse_scale(const LcpGrid& g) { return __builtin_bit_cast(float, (127u - uint32_t(g.cshift)) << 23); }   // 2^-cshift
+// a * b + c on the low 24 bits of a and b, full rate (the compiler turns __umul24(a, b) + c into the quarter-rate
+// v_mad_u64_u32 here)
+__device__ __forceinline__ uint32_t mad24(uint32_t a, uint32_t b, uint32_t c) {
+  uint32_t r;
+  asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+// floor(x) as an integer in one instruction (V_CVT_FLR_I32_F32; the compiler only emits v_floor + v_cvt)
+__device__ __forceinline__ int floor_to_int(float x) {
+  int i;
+  asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(i) : "v"(x));
+  return i;
+}
+// Integer cell coordinates of a query: floor of its position in grid units (u = X.u: fine cells, X.uc: coarse cubes).
+// ONE definition for every stage, so all of them see bit-identical cells (plain IEEE fma, no reassociation:
+// -ffp-contract=off only forbids *implicit* fusing).
+__device__ __forceinline__ void grid_cell(const float* u, const float4 q, int& ix, int& iy, int& iz) {
+  ix = floor_to_int(__builtin_fmaf(u[0], q.x, __builtin_fmaf(u[1], q.y, __builtin_fmaf(u[2], q.z, u[3]))));
+  iy = floor_to_int(__builtin_fmaf(u[4], q.x, __builtin_fmaf(u[5], q.y, __builtin_fmaf(u[6], q.z, u[7]))));
+  iz = floor_to_int(__builtin_fmaf(u[8], q.x, __builtin_fmaf(u[9], q.y, __builtin_fmaf(u[10], q.z, u[11]))));
 }
 
 // ---------------------------------------------------------------------------
@@ -272,83 +286,180 @@ __global__ __launch_bounds__(256) void k_build_masks(MaskParams P) {
   P.list_hdr[r] = hdr;
 }
 
+// Exact stage for one batch of up to 64 queued queries (lane = query; `valid` lanes hold an entry {query i, rank of its
+// reachable cell}): L2 (list header + 4x4x4 sub-cell mask), then the exact inlier predicate against the listed points.
+// The per-query lists differ a lot in length, so a lane-per-query loop runs as long as the longest list of the batch
+// with most lanes idle -- and every step is a 64-lane gather whether one lane or all of them still need it (that loop
+// was ~100 of the 165 wavefront gathers per candidate of the round-1 kernel).  Here the (query, point) pairs of the
+// whole batch are flattened: an inclusive prefix over the list lengths gives every pair a global index, round r tests
+// pairs [64 r, 64 r + 64) with all lanes busy -- pair-lane j finds its owner query by a binary search over the prefix
+// (cross-lane reads), fetches the owner's transformed point the same way, loads ONE point and tests it.
+// Gathers per batch: ceil(sum of lengths / 64) instead of 2 * ceil(max length / 2).
+// Predicate and point data are unchanged (kdtree.h:417-421), so counts stay bit-identical.
+template <bool COUNT>
+__device__ __forceinline__ bool fine_batch(const LcpGrid& g, const float4* q4, const float4* Tsrc, bool valid,
+                                           uint32_t i, uint32_t rank, unsigned long long* point_tests) {
+  const uint32_t lane = threadIdx.x & 63u;
+  float tx = 0.f, ty = 0.f, tz = 0.f;
+  uint32_t s = 0, len = 0;
+  if (valid) {
+    const uint4 hdr = g.list_hdr[rank];
+    const float4 q = q4[i];
+    float T[12];
+    load_rows(Tsrc, T);
+    transform_point(T, q, tx, ty, tz);                          // exact (reference order, no fma)
+    int ix, iy, iz;
+    grid_cell(make_grid_xf(g, T, 1.f).u, q, ix, iy, iz);        // the cell stage 2 put this query in
+    // sub-cell of the exact point inside THAT cell, clamped (the exact point can sit ~1e-5 cell outside it)
+    const float rx = (tx - g.ox) * g.inv_h - float(ix), ry = (ty - g.oy) * g.inv_h - float(iy), rz = (tz - g.oz) * g.inv_h - float(iz);
+    const uint32_t sx = uint32_t(min(max(int(rx * 4.f), 0), 3)), sy = uint32_t(min(max(int(ry * 4.f), 0), 3)),
+                   sz = uint32_t(min(max(int(rz * 4.f), 0), 3));
+    const uint32_t sb = sz * 16u + sy * 4u + sx;
+    const uint32_t mword = sb < 32u ? hdr.z : hdr.w;
+    if ((mword >> (sb & 31u)) & 1u) { s = hdr.x; len = hdr.y; }
+  }
+  if (COUNT) {
+    const unsigned long long l2 = __ballot(len != 0u);
+    uint32_t tot = len;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
+    if (lane == 0) { atomicAdd(point_tests + 3, (unsigned long long)__popcll(l2)); atomicAdd(point_tests, (unsigned long long)tot); }
+  }
+  // inclusive prefix of the list lengths over the wave
+  uint32_t incl = len;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t up = uint32_t(__shfl_up(int(incl), o));
+    if (lane >= uint32_t(o)) incl += up;
+  }
+  const uint32_t total = uint32_t(__builtin_amdgcn_readlane(int(incl), 63));
+  unsigned long long hitmask = 0ull;               // wave-uniform: bit L = the query of lane L has an inlier
+  for (uint32_t base = 0; base < total; base += 64u) {
+    const uint32_t j = base + lane;                // this lane's (query, point) pair
+    // owner = number of lanes whose inclusive prefix is <= j (the prefix is non-decreasing): lower-bound search
+    uint32_t lo = 0u, hi = 63u;     // j < total, so the owner is one of the 64 lanes
+#pragma unroll
+    for (int it = 0; it < 6; ++it) {               // 64 -> 1 in six halvings
+      const uint32_t mid = (lo + hi) >> 1;
+      const uint32_t v = uint32_t(__shfl(int(incl), int(mid)));
+      if (v <= j) lo = mid + 1u; else hi = mid;
+    }
+    const uint32_t owner = min(lo, 63u);
+    const uint32_t o_incl = uint32_t(__shfl(int(incl), int(owner)));
+    const uint32_t o_len = uint32_t(__shfl(int(len), int(owner)));
+    const uint32_t o_s = uint32_t(__shfl(int(s), int(owner)));
+    const float ox = __shfl(tx, int(owner)), oy = __shfl(ty, int(owner)), oz = __shfl(tz, int(owner));
+    bool h = false;
+    if (j < total) {
+      const float4 p = g.nbr[o_s + (j - (o_incl - o_len))];
+      h = sqn3(ox - p.x, oy - p.y, oz - p.z) <= g.sq_eps;               // kdtree.h:417-421  sqdist <= cl_dist
+    }
+    unsigned long long hb = __ballot(h);
+    while (hb) {                                   // scalar loop over the (few) hits of this round
+      const int l = __builtin_ctzll(hb);
+      hb &= hb - 1ull;
+      hitmask |= 1ull << uint32_t(__builtin_amdgcn_readlane(int(owner), l));
+    }
+  }
+  return ((hitmask >> lane) & 1ull) != 0ull;
+}
+
 // Number of sampled-Q points that T brings within delta of a sampled-P point: Verify()
 // (match4pcsBase.cc:508-567) without the early exit, for one wave64.
 //   s_coarse : LDS copy of the coarse bitmap (workgroup-shared)
-//   s_queue  : this wave's private LDS queue (kQueueEntries entries of {query index, reachable-cell rank})
-// Phase 1 (every query, four 64-query chunks per step): transform, cell, L0 test out of LDS; the L0 survivors then
-// read their reach word (L1, one 8-byte gather, issued for all four chunks back to back so the round trips overlap)
-// and the queries whose cell is reachable are compacted into the queue with a ballot/prefix.
-// Phase 2 (64 queued queries at a time, one per lane): list header + sub-cell mask (L2), then the exact tests.
-// Doing L1 in phase 1 means phase 2 runs on ~10 % of the queries instead of the ~25 % that pass L0, and its
-// dependent chain is header -> points instead of reach word -> header -> points.
+//   s_queue  : this wave's private LDS: queue A (query indices that passed L0) and queue B ({query, rank}: passed L1)
+// Stage 1 (every query, two 64-query chunks per step): position in COARSE-cube units (9 fma + 3 floor-converts), L0
+//   test against the LDS bitmap; the ~15 % that survive are compacted (ballot/prefix) into queue A.  About 36
+//   instructions per 64 queries -- the kernel is instruction-issue bound (SQ busy ~99 % in the round-1 profile), so
+//   this loop is kept to the bone: no fine cell, no global gather besides the coalesced 16-byte query load.
+// Stage 2 (whenever 64 entries wait in A, i.e. on dense lanes): query re-read, fine cell, ONE 8-byte gather of the
+//   reach word (L1), rank of the cell among the reachable ones; survivors (~70 %) are compacted into queue B.
+// Stage 3 (whenever 64 entries wait in B): fine_batch -- header, sub-cell mask, exact tests.
+// Compared with the round-1 kernel (fine cell + L1 gather issued for all 64 lanes of every chunk, 85 % of them idle):
+// 5 + 5 instead of 32 reach-word gathers per candidate at n_Q = 2000 and about half the instructions.
 template <bool COUNT, bool SKIP_FINE = false>
 __device__ __forceinline__ uint32_t wave_lcp_count(const LcpGrid& g, const uint32_t* s_coarse, uint2* s_queue,
-                                                   const float4* q4, uint32_t n_q, const float* T,
+                                                   const float4* q4, uint32_t n_q, const float4* Tsrc,
                                                    unsigned long long* point_tests) {
   constexpr uint32_t kNone = 0xFFFFFFFFu;
   const uint32_t lane = threadIdx.x & 63u;
-  const unsigned long long lt_mask = (1ull << lane) - 1ull;
-  uint32_t cnt = 0, qn = 0;
+  uint32_t* qa = reinterpret_cast<uint32_t*>(s_queue);
+  uint2* qb = s_queue + kQueueAEntries / 2;
+  uint32_t cnt = 0, na = 0, nb = 0;
   const uint32_t cmax = g.coarse_words * 32u - 1u;
   const uint32_t unx = uint32_t(g.nx), uny = uint32_t(g.ny), unz = uint32_t(g.nz);
-  const bool dims24 = unx < (1u << 24) && uny * unz < (1u << 24);      // uniform: 24-bit multiplies are full rate
-  // cell of query i under T, or kNone if it falls outside the grid or into a coarse cube nothing can reach
-  auto locate = [&](const float4 q, const uint32_t i) -> uint32_t {
-    float tx, ty, tz;
-    transform_point(T, q, tx, ty, tz);
-    // float -> int conversion saturates and one unsigned compare per axis covers both bounds (a NaN coordinate maps
-    // to cell 0 and then fails every exact distance test, so it cannot create an inlier)
-    const int ix = int(floorf((tx - g.ox) * g.inv_h)), iy = int(floorf((ty - g.oy) * g.inv_h)), iz = int(floorf((tz - g.oz) * g.inv_h));
-    const bool inb = (uint32_t(ix) < unx) & (uint32_t(iy) < uny) & (uint32_t(iz) < unz) & (i < n_q);
-    const uint32_t cc = min(__umul24(__umul24(uint32_t(iz) >> g.cshift, uint32_t(g.cny)) + (uint32_t(iy) >> g.cshift), uint32_t(g.cnx)) +
-                            (uint32_t(ix) >> g.cshift), cmax);
-    const bool surv = inb & (((s_coarse[cc >> 5] >> (cc & 31u)) & 1u) != 0u);
-    const uint32_t c = dims24 ? __umul24(__umul24(uint32_t(iz), uny) + uint32_t(iy), unx) + uint32_t(ix)
-                              : (uint32_t(iz) * uny + uint32_t(iy)) * unx + uint32_t(ix);
-    return surv ? c : kNone;
+  const uint32_t ucx = uint32_t(g.cnx), ucy = uint32_t(g.cny), ucz = ((unz - 1u) >> g.cshift) + 1u;
+  GridXf XC;                                             // coarse-cube units: the only transform live across the loop
+  { float T[12]; load_rows(Tsrc, T); XC = make_grid_xf(g, T, coarse_scale(g)); }
+  // L0: does query i fall into a coarse cube some P point can reach?  (float -> int conversion saturates and one
+  // unsigned compare per axis covers both bounds; a NaN coordinate maps to cube 0 and later fails every exact test)
+  auto coarse_hit = [&](const float4 q, const uint32_t i) -> bool {
+    int ix, iy, iz;
+    grid_cell(XC.u, q, ix, iy, iz);
+    const bool inb = (uint32_t(ix) < ucx) & (uint32_t(iy) < ucy) & (uint32_t(iz) < ucz) & (i < n_q);
+    const uint32_t cc = min(mad24(mad24(uint32_t(iz), ucy, uint32_t(iy)), ucx, uint32_t(ix)), cmax);
+    return inb & (((s_coarse[cc >> 5] >> (cc & 31u)) & 1u) != 0u);
   };
-  auto fine = [&](const uint2 e) -> uint32_t {
-    if (SKIP_FINE) return uint32_t(e.y == kNone);
-    return fine_test<COUNT>(g, q4, T, e.x, e.y, point_tests) ? 1u : 0u;
+  auto lds_fence = [&]() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); };
+  auto rank_below = [&](const unsigned long long m) -> uint32_t {       // set bits of m below this lane
+    return __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u));
   };
-  // L1 for one chunk + compaction; drains 64 queued queries when that many are waiting
-  auto push = [&](const uint32_t c, const uint2 w, const uint32_t i) {
+  // stage 3 on the top n (<= 64) entries of queue B
+  auto drain_b = [&](const uint32_t n) {
+    const bool valid = lane < n;
+    const uint2 e = qb[nb - n + min(lane, n - 1u)];
+    if (SKIP_FINE) cnt += uint32_t(valid && e.y == kNone);
+    else cnt += fine_batch<COUNT>(g, q4, Tsrc, valid, e.x, e.y, point_tests) ? 1u : 0u;
+    nb -= n;
+    lds_fence();
+  };
+  // stage 2 on the top n (<= 64) entries of queue A; needs nb < 64 on entry (queue B holds 128)
+  auto drain_a = [&](const uint32_t n) {
+    const bool valid = lane < n;
+    const uint32_t i = qa[na - n + min(lane, n - 1u)];
+    na -= n;
+    int ix, iy, iz;
+    { float T[12]; load_rows(Tsrc, T); grid_cell(make_grid_xf(g, T, 1.f).u, q4[i], ix, iy, iz); }
+    const bool inb = valid & (uint32_t(ix) < unx) & (uint32_t(iy) < uny) & (uint32_t(iz) < unz);
+    // 24-bit multiplies are full rate (a 32-bit v_mul_lo is not); LcpGridHost::plan keeps nx and ny*nz below 2^24
+    const uint32_t c = inb ? mad24(mad24(uint32_t(iz), uny, uint32_t(iy)), unx, uint32_t(ix)) : 0u;
+    const uint2 w = g.reach[c >> 5];
     const uint32_t sh = c & 31u;
-    const bool reach = (c != kNone) & (((w.x >> sh) & 1u) != 0u);
+    const bool reach = inb & (((w.x >> sh) & 1u) != 0u);
     const unsigned long long m = __ballot(reach);
-    const unsigned long long m0 = COUNT ? __ballot(c != kNone) : 0ull;
-    if (COUNT && lane == 0) {
-      atomicAdd(point_tests + 1, (unsigned long long)__popcll(m0));                      // l0_pass
-      atomicAdd(point_tests + 2, (unsigned long long)__popcll(m));                       // l1_pass
-    }
-    if (reach) s_queue[qn + uint32_t(__popcll(m & lt_mask))] = make_uint2(i, w.y + uint32_t(__popc(w.x & ((1u << sh) - 1u))));
-    qn += uint32_t(__popcll(m));
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    if (qn >= 64u) {
-      cnt += fine(s_queue[qn - 64u + lane]);
-      qn -= 64u;
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-    }
+    if (COUNT && lane == 0) atomicAdd(point_tests + 2, (unsigned long long)__popcll(m));          // l1_pass
+    if (reach) qb[nb + rank_below(m)] = make_uint2(i, w.y + uint32_t(__popc(w.x & ((1u << sh) - 1u))));
+    nb += uint32_t(__popcll(m));
+    lds_fence();
+  };
+  // stage 1 compaction of one chunk; queue A holds kQueueAEntries = 63 + 2 * 64 + 1
+  auto push = [&](const bool surv, const uint32_t i) {
+    const unsigned long long m = __ballot(surv);
+    if (m == 0ull) return;                               // Morton-ordered queries: whole chunks miss the surface
+    if (COUNT && lane == 0) atomicAdd(point_tests + 1, (unsigned long long)__popcll(m));          // l0_pass
+    if (surv) qa[na + rank_below(m)] = i;
+    na += uint32_t(__popcll(m));
   };
   const uint32_t last = n_q - 1u;
-  for (uint32_t base = 0; base < n_q; base += 256) {
-    const uint32_t i0 = base + lane, i1 = i0 + 64u, i2 = i0 + 128u, i3 = i0 + 192u;
-    const float4 q0 = q4[min(i0, last)];
-    const float4 q1 = q4[min(i1, last)];
-    const float4 q2 = q4[min(i2, last)];
-    const float4 q3 = q4[min(i3, last)];
-    const uint32_t c0 = locate(q0, i0), c1 = locate(q1, i1), c2 = locate(q2, i2), c3 = locate(q3, i3);
-    // reach words of the L0 survivors; rejected lanes read word 0 (one broadcast line)
-    const uint2 w0 = g.reach[c0 == kNone ? 0u : c0 >> 5];
-    const uint2 w1 = g.reach[c1 == kNone ? 0u : c1 >> 5];
-    const uint2 w2 = g.reach[c2 == kNone ? 0u : c2 >> 5];
-    const uint2 w3 = g.reach[c3 == kNone ? 0u : c3 >> 5];
-    push(c0, w0, i0); push(c1, w1, i1); push(c2, w2, i2); push(c3, w3, i3);
+  for (uint32_t base = 0;; base += 128u) {
+    const bool more = base < n_q;                        // wave-uniform
+    if (more) {
+      const uint32_t i0 = base + lane, i1 = i0 + 64u;
+      const float4 q0 = q4[min(i0, last)];
+      const float4 q1 = q4[min(i1, last)];
+      const bool h0 = coarse_hit(q0, i0), h1 = coarse_hit(q1, i1);
+      push(h0, i0); push(h1, i1);
+      lds_fence();
+    }
+    // One code site per stage (the exact stage is ~1000 instructions: inlining it at every push cost 16 KB of code).
+    // Full batches of 64 are drained as they become available; partial ones only after the last chunk.
+    while (true) {
+      if (nb >= 64u || (!more && na == 0u && nb != 0u)) { drain_b(min(nb, 64u)); continue; }
+      if (na >= 64u || (!more && na != 0u)) { drain_a(min(na, 64u)); continue; }
+      break;
+    }
+    if (!more) break;
   }
-  if (lane < qn) cnt += fine(s_queue[lane]);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
   __builtin_amdgcn_wave_barrier();
@@ -441,305 +552,7 @@ __device__ __forceinline__ bool rigid_gate(const BaseFrame& b, const float q[3][
 }
 
 // ---------------------------------------------------------------------------
-// k_gate / k_verify parameters.  k_verify: persistent 1024-thread workgroups, one wave64 per gated candidate; the
-// lengths of the quad list and of the gated list live in device memory (no host round trip).
-// LDS per workgroup: coarse bitmap (<= 48 KB) + 16 private survivor queues (1 KB each).
-// ---------------------------------------------------------------------------
-constexpr int kVerifyThreads = 1024;
-struct VerifyParams {
-  LcpGrid grid;
-  const float4* q4;                                     // sampled Q (centred), packed (x,y,z,0), original order (quad indices)
-  const float4* q4v;                                    // the same points in Morton order, for the LCP sweep
-  uint32_t n_q;
-  BaseFrame base;
-  const int4* quads; const unsigned long long* tags; uint32_t* counts;
-  const uint32_t* K_dev; uint32_t K_cap;
-  uint32_t* cand_idx; float4* cand_T;                   // gated candidates: quad index + 3x4 transform
-  DevCounters* ctr;
-  int ablate;                                           // S4P_ABLATE debugging only (0 = full kernel)
-};
-
-// k_gate: one thread per congruent quad: ComputeRigidTransformation + rms gate
-// (match4pcsBase.cc:365-500, match4pcsBase.hpp:436-439).  Passing candidates are compacted
-// (wave-aggregated append) into cand_idx / cand_T so that the scoring kernel sees a dense,
-// perfectly balanceable list; failing ones get counts[k] = kGateFailed.
-__global__ __launch_bounds__(256) void k_gate(VerifyParams P) {
-  const uint32_t K = min(*P.K_dev, P.K_cap);
-  const uint32_t lane = threadIdx.x & 63u;
-  for (uint32_t k0 = (blockIdx.x * blockDim.x + threadIdx.x) & ~63u; k0 < K; k0 += gridDim.x * blockDim.x) {
-    const uint32_t k = k0 + lane;
-    float T[12]; float c2[3];
-    bool ok = false;
-    if (k < K) {
-      const int4 qd = P.quads[k];
-      const float4 a = P.q4[qd.x], b = P.q4[qd.y], c = P.q4[qd.z];
-      float q[3][3] = {{a.x, a.y, a.z}, {b.x, b.y, b.z}, {c.x, c.y, c.z}};
-      ok = rigid_gate(P.base, q, T, c2);
-      if (!ok) P.counts[k] = kGateFailed;
-    }
-    const unsigned long long pass = __ballot(ok);
-    if (pass == 0ull) continue;
-    const uint32_t leader = __ffsll((long long)pass) - 1;
-    uint32_t base = 0;
-    if (lane == leader) base = atomicAdd(&P.ctr->C, uint32_t(__popcll(pass)));
-    base = __shfl(base, leader);
-    if (ok) {
-      const uint32_t at = base + uint32_t(__popcll(pass & ((1ull << lane) - 1ull)));
-      P.cand_idx[at] = k;
-      float4* dst = P.cand_T + 3 * size_t(at);
-      dst[0] = make_float4(T[0], T[1], T[2], T[3]);
-      dst[1] = make_float4(T[4], T[5], T[6], T[7]);
-      dst[2] = make_float4(T[8], T[9], T[10], T[11]);
-    }
-  }
-}
-
-// k_verify: Verify() (match4pcsBase.cc:508-567, no early exit) of every gated candidate.
-// Persistent 1024-thread workgroups, each working through its slice of the gated candidate list (the list's
-// length lives in device memory: no host round trip).
-// LDS: coarse bitmap (<= 48 KB) + 16 private survivor queues (1 KB each).
-template <bool COUNT>
-__global__ __launch_bounds__(kVerifyThreads, 8) void k_verify(VerifyParams P) {   // 8 waves/SIMD: two 1024-thread workgroups per CU
-  extern __shared__ uint32_t s_mem[];
-  uint32_t* s_coarse = s_mem;
-  uint2* s_queue = reinterpret_cast<uint2*>(s_mem + P.grid.coarse_words) + (threadIdx.x >> 6) * kQueueEntries;
-  const uint32_t C = P.ctr->C;
-  // Work split: every workgroup owns a contiguous slice of the gated candidate list (static: a single-address global
-  // cursor caps at ~90 dequeues/us, MI355X_MICROARCH "dequeue"); inside the slice its 16 waves take candidates from an
-  // LDS counter, so a wave that drew cheap candidates (few L0 survivors) simply takes more.  Slices differ by at most
-  // one candidate, against "one or two candidates per wave" for a static stride over waves.
-  const uint32_t lo = uint32_t((uint64_t(C) * blockIdx.x) / gridDim.x), hi = uint32_t((uint64_t(C) * (blockIdx.x + 1u)) / gridDim.x);
-  if (lo >= hi) return;                                    // more workgroups than candidates (uniform)
-  __shared__ uint32_t s_next;
-  if (threadIdx.x == 0) s_next = lo;
-  stage_coarse(P.grid, s_coarse);                          // ends with a workgroup barrier
-  const uint32_t lane = threadIdx.x & 63u;
-  uint32_t local_best = 0;
-  bool any = false;
-  while (true) {
-    uint32_t i = 0;
-    if (lane == 0) i = atomicAdd(&s_next, 1u);
-    i = uint32_t(__builtin_amdgcn_readfirstlane(int(i)));
-    if (i >= hi) break;
-    const float4* src = P.cand_T + 3 * size_t(i);
-    const float4 r0 = src[0], r1 = src[1], r2 = src[2];
-    // one candidate per wave: its 3x4 lives in scalar registers
-    const float T[12] = {wave_uniform(r0.x), wave_uniform(r0.y), wave_uniform(r0.z), wave_uniform(r0.w),
-                         wave_uniform(r1.x), wave_uniform(r1.y), wave_uniform(r1.z), wave_uniform(r1.w),
-                         wave_uniform(r2.x), wave_uniform(r2.y), wave_uniform(r2.z), wave_uniform(r2.w)};
-    uint32_t cnt = 0;
-    if (P.ablate == 2) cnt = uint32_t(T[3] > 1e30f);
-    else if (P.ablate == 1) cnt = wave_lcp_count<COUNT, true>(P.grid, s_coarse, s_queue, P.q4v, P.n_q, T, &P.ctr->point_tests);
-    else cnt = wave_lcp_count<COUNT, false>(P.grid, s_coarse, s_queue, P.q4v, P.n_q, T, &P.ctr->point_tests);
-    if (lane == 0) P.counts[P.cand_idx[i]] = cnt;
-    local_best = max(local_best, cnt);
-    any = true;
-  }
-  // One global atomic per workgroup, and only if it can raise the maximum: a per-wave atomicMax on the single
-  // result word serialised at ~90 ops/us (8192 waves = 0.09 ms per launch, measured with S4P_ABLATE=2).
-  __shared__ uint32_t s_best;
-  if (threadIdx.x == 0) s_best = 0;
-  __syncthreads();
-  if (lane == 0 && any) atomicMax(&s_best, local_best);
-  __syncthreads();
-  if (threadIdx.x == 0 && s_best > 0) {
-    const uint32_t cur = __hip_atomic_load(&P.ctr->best_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (s_best > cur) atomicMax(&P.ctr->best_count, s_best);
-  }
-}
-
-// k_select: best_tag = min tag among candidates whose count == best_count (first in
-// reference order wins: match4pcsBase.hpp:468 strict '>').
-struct SelectParams {
-  const unsigned long long* tags; const uint32_t* counts; const int4* quads;
-  const uint32_t* K_dev; uint32_t K_cap; DevCounters* ctr;
-  const float4* q4; BaseFrame base;
-};
-__global__ __launch_bounds__(256) void k_select(SelectParams P) {
-  const uint32_t K = min(*P.K_dev, P.K_cap);
-  if (P.ctr->C == 0) return;
-  const uint32_t best = P.ctr->best_count;
-  for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < K; k += gridDim.x * blockDim.x)
-    if (P.counts[k] == best) atomicMin(&P.ctr->best_tag, P.tags[k]);
-}
-__global__ __launch_bounds__(256) void k_winner(SelectParams P) {
-  const uint32_t K = min(*P.K_dev, P.K_cap);
-  if (P.ctr->C == 0) return;
-  const unsigned long long bt = P.ctr->best_tag;
-  const uint32_t best = P.ctr->best_count;
-  for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < K; k += gridDim.x * blockDim.x) {
-    if (P.tags[k] == bt && P.counts[k] == best) {
-      const int4 qd = P.quads[k];
-      const float4 a = P.q4[qd.x], b = P.q4[qd.y], c = P.q4[qd.z];
-      float q[3][3] = {{a.x, a.y, a.z}, {b.x, b.y, b.z}, {c.x, c.y, c.z}};
-      float T[12], c2[3];
-      rigid_gate(P.base, q, T, c2);
-      for (int i = 0; i < 12; ++i) P.ctr->best_T[i] = T[i];
-      P.ctr->best_T[12] = 0.f; P.ctr->best_T[13] = 0.f; P.ctr->best_T[14] = 0.f; P.ctr->best_T[15] = 1.f;
-      for (int i = 0; i < 3; ++i) P.ctr->best_c2[i] = c2[i];
-      P.ctr->best_quad[0] = qd.x; P.ctr->best_quad[1] = qd.y; P.ctr->best_quad[2] = qd.z; P.ctr->best_quad[3] = qd.w;
-      P.ctr->has_best = 1u;
-    }
-  }
-}
-
-// k_verify_T: Verify() for explicit transforms (one wave per transform).
-struct VerifyTParams {
-  LcpGrid grid; const float4* q4; uint32_t n_q;
-  const float* T; uint32_t B; uint32_t* counts; DevCounters* ctr;
-};
-__global__ __launch_bounds__(kVerifyThreads) void k_verify_T(VerifyTParams P) {
-  extern __shared__ uint32_t s_mem[];
-  uint32_t* s_coarse = s_mem;
-  uint2* s_queue = reinterpret_cast<uint2*>(s_mem + P.grid.coarse_words) + (threadIdx.x >> 6) * kQueueEntries;
-  stage_coarse(P.grid, s_coarse);
-  const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
-  for (uint32_t k = wave; k < P.B; k += nwaves) {
-    float T[12];
-#pragma unroll
-    for (int i = 0; i < 12; ++i) T[i] = wave_uniform(P.T[16 * size_t(k) + i]);
-    const uint32_t cnt = wave_lcp_count<false, false>(P.grid, s_coarse, s_queue, P.q4, P.n_q, T, nullptr);
-    if (lane == 0) P.counts[k] = cnt;
-  }
-}
-
-// ---------------------------------------------------------------------------
-// k_pairs: loop 2 of IntersectionFunctor::process + PairCreationFunctor::process.
-// One thread per (primitive pId, sequence slot s); the sequence is the concatenation
-// of the leaf ranges of the host-built octree, so (pId, s) order == reference order.
-// Accepted (i=pId, j) appends (j,i) then (i,j) with order keys 2*(pId*n_seq+s)+{0,1}.
-// ---------------------------------------------------------------------------
-struct PairParams {
-  const float* ux; const float* uy; const float* uz;     // unit-cube coordinates of sampled Q
-  const float* qx; const float* qy; const float* qz;     // world (centred) coordinates
-  const float* nx; const float* ny; const float* nz;     // normals or nullptr
-  const float* cr; const float* cg; const float* cb;     // rgb or nullptr
-  const uint32_t* seq_id; const uint32_t* seq_leaf; uint32_t n_seq;
-  const float4* leaves;                                    // (cx, cy, cz, halfEdge argument)
-  uint32_t n_q;
-  float nRadius, eps_unit;
-  double pair_distance, pair_distance_eps, pair_normals_angle;
-  float max_normal_difference, max_color_distance, max_translation_distance, norm_threshold;
-  float b1pos[3], b2pos[3], b1rgb[3], b2rgb[3];
-  int2* ab; uint32_t* okey; uint32_t* counter; uint32_t cap; uint32_t* overflow; uint32_t overflow_bit;
-};
-
-__device__ __forceinline__ bool sphere_box(float cx, float cy, float cz, float r, float4 leaf) {
-  const float h = leaf.w;
-  float dmin[3], dmax[3];
-  const float c[3] = {cx, cy, cz};
-  const float nc[3] = {leaf.x, leaf.y, leaf.z};
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const float mn = nc[k] - h, mx = nc[k] + h;
-    const float sqmin = (c[k] - mn) * (c[k] - mn);
-    const float sqmax = (c[k] - mx) * (c[k] - mx);
-    dmin[k] = (c[k] < mn) ? sqmin : ((c[k] > mx) ? sqmax : 0.f);
-    dmax[k] = (sqmin < sqmax) ? sqmax : sqmin;
-  }
-  const float r2 = r * r;
-  return (dmin[0] + (dmin[1] + dmin[2])) < r2 && r2 < (dmax[0] + (dmax[1] + dmax[2]));
-}
-
-constexpr int kPairStage = 2048;   // accepted (pId, j) per workgroup between two flushes
-
-// One workgroup per primitive pId; threads sweep the sequence in chunks of 256.  Accepted slots are
-// staged in LDS and flushed with ONE global atomic per workgroup (a per-wave atomic on the single
-// output cursor serialises at ~90 ops/us and dominated the first version of this kernel).
-// The two pair sets of a base are independent: one launch, blockIdx.y picks the set (gridDim.y = 1 for a single set).
-struct PairParams2 { PairParams set[2]; };
-__global__ __launch_bounds__(256) void k_pairs(PairParams2 PP) {
-  const PairParams& P = PP.set[blockIdx.y];
-  __shared__ uint32_t st_j[kPairStage];
-  __shared__ uint32_t st_s[kPairStage];
-  __shared__ uint32_t st_p[kPairStage];
-  __shared__ uint32_t st_n, st_base;
-  if (threadIdx.x == 0) st_n = 0;
-  __syncthreads();
-  auto flush = [&]() {     // called by all threads, between barriers
-    const uint32_t n = st_n;
-    if (n == 0) return;
-    if (threadIdx.x == 0) st_base = atomicAdd(P.counter, 2u * n);
-    __syncthreads();
-    const uint32_t base = st_base;
-    for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) {
-      const uint32_t at = base + 2u * e;
-      if (at + 1u < P.cap) {
-        const uint32_t j = st_j[e], pId = st_p[e];
-        const uint32_t ok = 2u * (pId * P.n_seq + st_s[e]);
-        P.ab[at] = make_int2(int(j), int(pId));     P.okey[at] = ok;          // pairs->emplace_back(j, i)  :214
-        P.ab[at + 1] = make_int2(int(pId), int(j)); P.okey[at + 1] = ok + 1u; // pairs->emplace_back(i, j)  :215
-      } else {
-        atomicOr(P.overflow, P.overflow_bit);
-      }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) st_n = 0;
-    __syncthreads();
-  };
-  // each workgroup takes primitives blockIdx.x, blockIdx.x + gridDim.x, ... so the number of global atomics is
-  // ~ the number of workgroups (a few hundred), not the number of primitives
-  for (uint32_t pId = blockIdx.x; pId < P.n_q; pId += gridDim.x) {
-  const float cx = P.ux[pId], cy = P.uy[pId], cz = P.uz[pId];
-  const float wxi = P.qx[pId], wyi = P.qy[pId], wzi = P.qz[pId];
-  for (uint32_t s0 = 0; s0 < P.n_seq; s0 += blockDim.x) {
-    const uint32_t s = s0 + threadIdx.x;
-    bool acc = false;
-    uint32_t j = 0;
-    if (s < P.n_seq) {
-      j = P.seq_id[s];
-      if (pId > j) {
-        const float dx = P.ux[j] - cx, dy = P.uy[j] - cy, dz = P.uz[j] - cz;
-        const float t = sqrtf(sqn3(dx, dy, dz)) - P.nRadius;
-        if (t * t < P.eps_unit * P.eps_unit) {                               // intersectPoint, intersectionPrimitive.h:154-157
-          if (sphere_box(cx, cy, cz, P.nRadius, P.leaves[P.seq_leaf[s]])) {   // intersect, :117-142
-            // PairCreationFunctor::process(i = pId, j): p = Q[j], q = Q[i]
-            const float wx = wxi - P.qx[j], wy = wyi - P.qy[j], wz = wzi - P.qz[j];
-            const float distance = sqrtf(sqn3(wx, wy, wz));
-            acc = !(fabs(double(distance) - P.pair_distance) > P.pair_distance_eps);   // :162
-            if (acc && P.max_normal_difference > 0.f && P.nx != nullptr) {              // :166-180
-              const float qn0 = P.nx[pId], qn1 = P.ny[pId], qn2 = P.nz[pId];
-              const float pn0 = P.nx[j], pn1 = P.ny[j], pn2 = P.nz[j];
-              if (sqn3(qn0, qn1, qn2) > 0.f && sqn3(pn0, pn1, pn2) > 0.f) {
-                const double a1 = double(sqrtf(sqn3(qn0 - pn0, qn1 - pn1, qn2 - pn2)));
-                const double a2 = double(sqrtf(sqn3(qn0 + pn0, qn1 + pn1, qn2 + pn2)));
-                const float fnd = float(fmin(fabs(a1 - P.pair_normals_angle), fabs(a2 - P.pair_normals_angle)));
-                if (fnd > P.norm_threshold) acc = false;
-              }
-            }
-            if (acc && P.max_color_distance > 0.f) {                                    // :182-192
-              float pr0 = -1.f, pr1 = -1.f, pr2 = -1.f, qr0 = -1.f, qr1 = -1.f, qr2 = -1.f;
-              if (P.cr != nullptr) { pr0 = P.cr[j]; pr1 = P.cg[j]; pr2 = P.cb[j]; qr0 = P.cr[pId]; qr1 = P.cg[pId]; qr2 = P.cb[pId]; }
-              const bool use_rgb = (pr0 >= 0.f && qr0 >= 0.f && P.b1rgb[0] >= 0.f && P.b2rgb[0] >= 0.f);
-              const bool good = sqrtf(sqn3(pr0 - P.b1rgb[0], pr1 - P.b1rgb[1], pr2 - P.b1rgb[2])) < P.max_color_distance &&
-                                sqrtf(sqn3(qr0 - P.b2rgb[0], qr1 - P.b2rgb[1], qr2 - P.b2rgb[2])) < P.max_color_distance;
-              if (use_rgb && !good) acc = false;
-            }
-            if (acc && P.max_translation_distance > 0.f) {                              // :194-200
-              const bool good =
-                  sqrtf(sqn3(P.qx[j] - P.b1pos[0], P.qy[j] - P.b1pos[1], P.qz[j] - P.b1pos[2])) < P.max_translation_distance &&
-                  sqrtf(sqn3(wxi - P.b2pos[0], wyi - P.b2pos[1], wzi - P.b2pos[2])) < P.max_translation_distance;
-              if (!good) acc = false;
-            }
-          }
-        }
-      }
-    }
-    if (acc) {
-      const uint32_t e = atomicAdd(&st_n, 1u);     // LDS atomic; room for 256 more is guaranteed by the flush rule below
-      st_j[e] = j; st_s[e] = s; st_p[e] = pId;
-    }
-    __syncthreads();
-    if (st_n + blockDim.x > uint32_t(kPairStage)) flush();   // uniform: st_n is read after the barrier
-  }
-  }
-  flush();
-}
-
-// ---------------------------------------------------------------------------
-// Congruent-quad enumeration (FindCongruentQuadrilaterals, super4pcs.cc:80-177).
+// Congruent-quad enumeration, preparation side (FindCongruentQuadrilaterals, super4pcs.cc:80-177).
 // set 1 entries are chained per euclidean cell in an epoch-tagged hash table
 // (no per-base clearing); set 2 entries carry a 343-bit cone mask of direction buckets.
 // ---------------------------------------------------------------------------
@@ -775,6 +588,8 @@ struct HashTable {
   uint32_t epoch;
 };
 
+// Per-set preparation parameters.  `ab`/`m_dev`/`cap` are only read by the stand-alone k_prep (stage-level entry
+// points); the fused pair kernel hands every pair over in registers.
 struct PrepParams {
   const float* ux; const float* uy; const float* uz;
   const float* qx; const float* qy; const float* qz;
@@ -787,38 +602,35 @@ struct PrepParams {
   ConeTable cone;
 };
 
-__device__ __forceinline__ void prep1_body(const PrepParams& P) {
-  const uint32_t m = min(*P.m_dev, P.cap);
-  for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < m; e += gridDim.x * blockDim.x) {
-    const int2 ab = P.ab[e];
-    const float p1x = P.ux[ab.x], p1y = P.uy[ab.x], p1z = P.uz[ab.x];
-    const float p2x = P.ux[ab.y], p2y = P.uy[ab.y], p2z = P.uz[ab.y];
-    float nx = p2x - p1x, ny = p2y - p1y, nz = p2z - p1z;
-    const float posx = p1x + P.invariant * nx, posy = p1y + P.invariant * ny, posz = p1z + P.invariant * nz;  // super4pcs.cc:123
-    normalize3(nx, ny, nz);                                                                                  // :121
-    const uint32_t cell = index_pos(posx, posy, posz, P.qg);
-    P.cell[e] = cell;
-    P.bucket[e] = index_normal(nx, ny, nz, P.qg.nepsilon);
-    const float w1x = P.qx[ab.x], w1y = P.qy[ab.x], w1z = P.qz[ab.x];
-    const float w2x = P.qx[ab.y], w2y = P.qy[ab.y], w2z = P.qz[ab.y];
-    P.ew[e] = make_float4(w1x + (w2x - w1x) * P.invariant, w1y + (w2y - w1y) * P.invariant,
-                          w1z + (w2z - w1z) * P.invariant, 0.f);                                            // :157
-    // insert into the cell hash (find-or-claim slot, then push on the chain)
-    const unsigned long long mykey = ((unsigned long long)P.ht.epoch << 32) | cell;
-    uint32_t h = hash_cell(cell) & P.ht.mask;
-    while (true) {
-      const unsigned long long k = __hip_atomic_load(&P.ht.keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (k == mykey) break;
-      if (uint32_t(k >> 32) != P.ht.epoch) {
-        const unsigned long long old = atomicCAS(&P.ht.keys[h], k, mykey);
-        if (old == k || old == mykey) break;
-        continue;   // somebody claimed it for another cell: re-read the same slot
-      }
-      h = (h + 1u) & P.ht.mask;
+// set 1, one pair (entry e = (ab.x, ab.y)): invariant point, cell, direction bucket, world point, hash insert
+__device__ __forceinline__ void prep1_item(const PrepParams& P, const uint32_t e, const int2 ab) {
+  const float p1x = P.ux[ab.x], p1y = P.uy[ab.x], p1z = P.uz[ab.x];
+  const float p2x = P.ux[ab.y], p2y = P.uy[ab.y], p2z = P.uz[ab.y];
+  float nx = p2x - p1x, ny = p2y - p1y, nz = p2z - p1z;
+  const float posx = p1x + P.invariant * nx, posy = p1y + P.invariant * ny, posz = p1z + P.invariant * nz;  // super4pcs.cc:123
+  normalize3(nx, ny, nz);                                                                                  // :121
+  const uint32_t cell = index_pos(posx, posy, posz, P.qg);
+  P.cell[e] = cell;
+  P.bucket[e] = index_normal(nx, ny, nz, P.qg.nepsilon);
+  const float w1x = P.qx[ab.x], w1y = P.qy[ab.x], w1z = P.qz[ab.x];
+  const float w2x = P.qx[ab.y], w2y = P.qy[ab.y], w2z = P.qz[ab.y];
+  P.ew[e] = make_float4(w1x + (w2x - w1x) * P.invariant, w1y + (w2y - w1y) * P.invariant,
+                        w1z + (w2z - w1z) * P.invariant, 0.f);                                            // :157
+  // insert into the cell hash (find-or-claim slot, then push on the chain)
+  const unsigned long long mykey = ((unsigned long long)P.ht.epoch << 32) | cell;
+  uint32_t h = hash_cell(cell) & P.ht.mask;
+  while (true) {
+    const unsigned long long k = __hip_atomic_load(&P.ht.keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (k == mykey) break;
+    if (uint32_t(k >> 32) != P.ht.epoch) {
+      const unsigned long long old = atomicCAS(&P.ht.keys[h], k, mykey);
+      if (old == k || old == mykey) break;
+      continue;   // somebody claimed it for another cell: re-read the same slot
     }
-    const unsigned long long prev = atomicExch(&P.ht.heads[h], ((unsigned long long)P.ht.epoch << 32) | e);
-    P.next[e] = (uint32_t(prev >> 32) == P.ht.epoch) ? uint32_t(prev) : kNil;
+    h = (h + 1u) & P.ht.mask;
   }
+  const unsigned long long prev = atomicExch(&P.ht.heads[h], ((unsigned long long)P.ht.epoch << 32) | e);
+  P.next[e] = (uint32_t(prev >> 32) == P.ht.epoch) ? uint32_t(prev) : kNil;
 }
 
 // Quaternion::setFromTwoVectors(zhat, n) (Eigen/Geometry) + closed-form replacement of
@@ -845,48 +657,297 @@ __device__ __forceinline__ void quat_from_z_to(float nx, float ny, float nz, flo
   q[0] = s * 0.5f;
 }
 
-__device__ __forceinline__ void prep2_body(const PrepParams& P, uint32_t* smask) {
-  const uint32_t m = min(*P.m_dev, P.cap);
-  const uint32_t nthreads = gridDim.x * blockDim.x;
-  uint32_t* my = smask + threadIdx.x * kMaskWords;
-  for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < m; e += nthreads) {
-    const int2 ab = P.ab[e];
-    const float p1x = P.ux[ab.x], p1y = P.uy[ab.x], p1z = P.uz[ab.x];
-    const float p2x = P.ux[ab.y], p2y = P.uy[ab.y], p2z = P.uz[ab.y];
-    const float nx = p2x - p1x, ny = p2y - p1y, nz = p2z - p1z;
-    const float qx_ = p1x + P.invariant * nx, qy_ = p1y + P.invariant * ny, qz_ = p1z + P.invariant * nz;   // super4pcs.cc:141
-    P.cell[e] = index_pos(qx_, qy_, qz_, P.qg);
-    const float w1x = P.qx[ab.x], w1y = P.qy[ab.x], w1z = P.qz[ab.x];
-    const float w2x = P.qx[ab.y], w2y = P.qy[ab.y], w2z = P.qz[ab.y];
-    P.ew[e] = make_float4(w1x + P.invariant * (w2x - w1x), w1y + P.invariant * (w2y - w1y),
-                          w1z + P.invariant * (w2z - w1z), 0.f);                                          // :142
-    float q[4];
-    float qnx = nx, qny = ny, qnz = nz;
-    normalize3(qnx, qny, qnz);                          // queryn = (p2-p1).normalized()            super4pcs.cc:144
-    quat_from_z_to(qnx, qny, qnz, q);                   // setFromTwoVectors normalises it again    normalset.hpp:181
+// set 2, one pair: invariant point, cell, world point, 343-bit cone mask (built in the caller's LDS row `my`)
+__device__ __forceinline__ void prep2_item(const PrepParams& P, const uint32_t e, const int2 ab, uint32_t* my) {
+  const float p1x = P.ux[ab.x], p1y = P.uy[ab.x], p1z = P.uz[ab.x];
+  const float p2x = P.ux[ab.y], p2y = P.uy[ab.y], p2z = P.uz[ab.y];
+  const float nx = p2x - p1x, ny = p2y - p1y, nz = p2z - p1z;
+  const float qx_ = p1x + P.invariant * nx, qy_ = p1y + P.invariant * ny, qz_ = p1z + P.invariant * nz;   // super4pcs.cc:141
+  P.cell[e] = index_pos(qx_, qy_, qz_, P.qg);
+  const float w1x = P.qx[ab.x], w1y = P.qy[ab.x], w1z = P.qz[ab.x];
+  const float w2x = P.qx[ab.y], w2y = P.qy[ab.y], w2z = P.qz[ab.y];
+  P.ew[e] = make_float4(w1x + P.invariant * (w2x - w1x), w1y + P.invariant * (w2y - w1y),
+                        w1z + P.invariant * (w2z - w1z), 0.f);                                          // :142
+  float q[4];
+  float qnx = nx, qny = ny, qnz = nz;
+  normalize3(qnx, qny, qnz);                          // queryn = (p2-p1).normalized()            super4pcs.cc:144
+  quat_from_z_to(qnx, qny, qnz, q);                   // setFromTwoVectors normalises it again    normalset.hpp:181
 #pragma unroll
-    for (int w = 0; w < kMaskWords; ++w) my[w] = 0u;
-    for (int a = 0; a < P.cone.nb; ++a) {               // normalset.hpp:186-196
-      const float vx = P.cone.v[a][0], vy = P.cone.v[a][1], vz = P.cone.v[a][2];
-      float ux_, uy_, uz_;
-      cross3(q[1], q[2], q[3], vx, vy, vz, ux_, uy_, uz_);            // QuaternionBase::_transformVector
-      ux_ += ux_; uy_ += uy_; uz_ += uz_;
-      float cx, cy, cz;
-      cross3(q[1], q[2], q[3], ux_, uy_, uz_, cx, cy, cz);
-      float dx = (vx + q[0] * ux_) + cx, dy = (vy + q[0] * uy_) + cy, dz = (vz + q[0] * uz_) + cz;
-      normalize3(dx, dy, dz);
-      const uint32_t id = index_normal(dx, dy, dz, P.qg.nepsilon);
-      if (id < 343u) my[id >> 5] |= (1u << (id & 31u));
-    }
-#pragma unroll
-    for (int w = 0; w < kMaskWords; ++w) P.mask[size_t(e) * kMaskWords + w] = my[w];
+  for (int w = 0; w < kMaskWords; ++w) my[w] = 0u;
+  for (int a = 0; a < P.cone.nb; ++a) {               // normalset.hpp:186-196
+    const float vx = P.cone.v[a][0], vy = P.cone.v[a][1], vz = P.cone.v[a][2];
+    float ux_, uy_, uz_;
+    cross3(q[1], q[2], q[3], vx, vy, vz, ux_, uy_, uz_);            // QuaternionBase::_transformVector
+    ux_ += ux_; uy_ += uy_; uz_ += uz_;
+    float cx, cy, cz;
+    cross3(q[1], q[2], q[3], ux_, uy_, uz_, cx, cy, cz);
+    float dx = (vx + q[0] * ux_) + cx, dy = (vy + q[0] * uy_) + cy, dz = (vz + q[0] * uz_) + cz;
+    normalize3(dx, dy, dz);
+    const uint32_t id = index_normal(dx, dy, dz, P.qg.nepsilon);
+    if (id < 343u) my[id >> 5] |= (1u << (id & 31u));
   }
+#pragma unroll
+  for (int w = 0; w < kMaskWords; ++w) P.mask[size_t(e) * kMaskWords + w] = my[w];
 }
-// Set 1 (hash insert) and set 2 (cone masks) are prepared by one launch: blockIdx.y == 0 -> set 1, 1 -> set 2.
+
+// Stand-alone preparation of two uploaded pair lists (s4p_find_congruent): blockIdx.y == 0 -> set 1, 1 -> set 2.
+// The fused path (s4p_try_base*) prepares every pair inside k_pairs, where it is produced.
 __global__ __launch_bounds__(256) void k_prep(PrepParams P1, PrepParams P2) {
   __shared__ uint32_t smask[256 * kMaskWords];
-  if (blockIdx.y == 0) prep1_body(P1);
-  else prep2_body(P2, smask);
+  const PrepParams& P = blockIdx.y == 0 ? P1 : P2;
+  const uint32_t m = min(*P.m_dev, P.cap);
+  for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < m; e += gridDim.x * blockDim.x) {
+    if (blockIdx.y == 0) prep1_item(P, e, P.ab[e]);
+    else prep2_item(P, e, P.ab[e], smask + threadIdx.x * kMaskWords);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// k_pairs: loop 2 of IntersectionFunctor::process (intersectionFunctor.h:197-233) + PairCreationFunctor::process
+// (pairCreationFunctor.h:151-218), and -- on the fused path -- the per-pair preparation of FindCongruentQuadrilaterals.
+//
+// The host hands over the leaves of its octree (loop 1) as a flat sequence of point ids plus, per leaf, its box and
+// its slot range.  As the reference does, a primitive first tests the leaf BOX (:205) and only the points of leaves
+// its sphere touches are examined (:208-220), so the work is (primitives x touched leaves x their points), not n_Q^2.
+// One wave64 per primitive pId.  Leaves are taken 64 at a time (lane = leaf): box test, then the (leaf, point) slots of
+// the touched leaves are flattened with a prefix over the leaf sizes -- the same owner search as fine_batch -- so every
+// round of 64 lanes tests 64 real points.  Accepted (i = pId, j) are compacted by ballot/prefix into the wave's private
+// LDS stage (no LDS atomics) and appended with ONE global atomic per workgroup at the end (per wave if its stage
+// fills up first): (j,i) then (i,j) with order keys 2*(pId*n_seq + slot) + {0,1}, monotone in the reference's
+// emission order.
+// ---------------------------------------------------------------------------
+struct PairParams {
+  const float* ux; const float* uy; const float* uz;     // unit-cube coordinates of sampled Q
+  const float* qx; const float* qy; const float* qz;     // world (centred) coordinates
+  const float* nx; const float* ny; const float* nz;     // normals or nullptr
+  const float* cr; const float* cg; const float* cb;     // rgb or nullptr
+  const uint32_t* seq_id; uint32_t n_seq;                  // point ids, leaf-major
+  const uint32_t* leaf_off; const float4* leaves; uint32_t n_leaf;   // slot range and (cx, cy, cz, halfEdge argument) per leaf
+  uint32_t n_q;
+  float nRadius, eps_unit;
+  double pair_distance, pair_distance_eps, pair_normals_angle;
+  float max_normal_difference, max_color_distance, max_translation_distance, norm_threshold;
+  float b1pos[3], b2pos[3], b1rgb[3], b2rgb[3];
+  int2* ab; uint32_t* okey; uint32_t* counter; uint32_t cap; uint32_t* overflow; uint32_t overflow_bit;
+  int do_prep;                                             // fused path: prepare each pair for k_quads as it is appended
+};
+
+__device__ __forceinline__ bool sphere_box(float cx, float cy, float cz, float r, float4 leaf) {
+  const float h = leaf.w;
+  float dmin[3], dmax[3];
+  const float c[3] = {cx, cy, cz};
+  const float nc[3] = {leaf.x, leaf.y, leaf.z};
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float mn = nc[k] - h, mx = nc[k] + h;
+    const float sqmin = (c[k] - mn) * (c[k] - mn);
+    const float sqmax = (c[k] - mx) * (c[k] - mx);
+    dmin[k] = (c[k] < mn) ? sqmin : ((c[k] > mx) ? sqmax : 0.f);
+    dmax[k] = (sqmin < sqmax) ? sqmax : sqmin;
+  }
+  const float r2 = r * r;
+  return (dmin[0] + (dmin[1] + dmin[2])) < r2 && r2 < (dmax[0] + (dmax[1] + dmax[2]));
+}
+
+// PairCreationFunctor::process(i = pId, j) filters (pairCreationFunctor.h:151-218): p = Q[j], q = Q[i]
+__device__ __forceinline__ bool pair_filters(const PairParams& P, const uint32_t pId, const uint32_t j,
+                                             const float wxi, const float wyi, const float wzi) {
+  const float wx = wxi - P.qx[j], wy = wyi - P.qy[j], wz = wzi - P.qz[j];
+  const float distance = sqrtf(sqn3(wx, wy, wz));
+  bool acc = !(fabs(double(distance) - P.pair_distance) > P.pair_distance_eps);   // :162
+  if (acc && P.max_normal_difference > 0.f && P.nx != nullptr) {              // :166-180
+    const float qn0 = P.nx[pId], qn1 = P.ny[pId], qn2 = P.nz[pId];
+    const float pn0 = P.nx[j], pn1 = P.ny[j], pn2 = P.nz[j];
+    if (sqn3(qn0, qn1, qn2) > 0.f && sqn3(pn0, pn1, pn2) > 0.f) {
+      const double a1 = double(sqrtf(sqn3(qn0 - pn0, qn1 - pn1, qn2 - pn2)));
+      const double a2 = double(sqrtf(sqn3(qn0 + pn0, qn1 + pn1, qn2 + pn2)));
+      const float fnd = float(fmin(fabs(a1 - P.pair_normals_angle), fabs(a2 - P.pair_normals_angle)));
+      if (fnd > P.norm_threshold) acc = false;
+    }
+  }
+  if (acc && P.max_color_distance > 0.f) {                                    // :182-192
+    float pr0 = -1.f, pr1 = -1.f, pr2 = -1.f, qr0 = -1.f, qr1 = -1.f, qr2 = -1.f;
+    if (P.cr != nullptr) { pr0 = P.cr[j]; pr1 = P.cg[j]; pr2 = P.cb[j]; qr0 = P.cr[pId]; qr1 = P.cg[pId]; qr2 = P.cb[pId]; }
+    const bool use_rgb = (pr0 >= 0.f && qr0 >= 0.f && P.b1rgb[0] >= 0.f && P.b2rgb[0] >= 0.f);
+    const bool good = sqrtf(sqn3(pr0 - P.b1rgb[0], pr1 - P.b1rgb[1], pr2 - P.b1rgb[2])) < P.max_color_distance &&
+                      sqrtf(sqn3(qr0 - P.b2rgb[0], qr1 - P.b2rgb[1], qr2 - P.b2rgb[2])) < P.max_color_distance;
+    if (use_rgb && !good) acc = false;
+  }
+  if (acc && P.max_translation_distance > 0.f) {                              // :194-200
+    const bool good =
+        sqrtf(sqn3(P.qx[j] - P.b1pos[0], P.qy[j] - P.b1pos[1], P.qz[j] - P.b1pos[2])) < P.max_translation_distance &&
+        sqrtf(sqn3(wxi - P.b2pos[0], wyi - P.b2pos[1], wzi - P.b2pos[2])) < P.max_translation_distance;
+    if (!good) acc = false;
+  }
+  return acc;
+}
+
+constexpr int kPairStageW = 448;   // accepted (pId, j, slot) per wave between two flushes (12 B each)
+constexpr int kPairWaves = 4;      // waves per workgroup
+
+struct PairSet { PairParams pair; PrepParams prep; };
+struct PairParams2 { PairSet set[2]; };
+
+// The two pair sets of a base are independent: one launch, blockIdx.y picks the set (gridDim.y = 1 for a single set).
+__global__ __launch_bounds__(64 * kPairWaves) void k_pairs(PairParams2 PP) {
+  const PairParams& P = PP.set[blockIdx.y].pair;
+  const PrepParams& R = PP.set[blockIdx.y].prep;
+  __shared__ uint32_t st_j[kPairWaves][kPairStageW];
+  __shared__ uint32_t st_s[kPairWaves][kPairStageW];
+  __shared__ uint32_t st_p[kPairWaves][kPairStageW];
+  __shared__ uint32_t smask[64 * kPairWaves * kMaskWords];
+  __shared__ uint32_t s_cnt[kPairWaves], s_base;
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  uint32_t* my_mask = smask + threadIdx.x * kMaskWords;
+  uint32_t n_st = 0;                                     // staged entries of this wave (wave-uniform)
+  // writes the wave's n_st staged entries at pair positions base, base + 2, ...: two ordered pairs per entry, one
+  // pair per lane (the set-2 preparation is ~3000 instructions per pair, so pairs, not entries, are spread over lanes)
+  auto write_out = [&](const uint32_t base) {
+    for (uint32_t pe = lane; pe < 2u * n_st; pe += 64u) {
+      const uint32_t e = pe >> 1, second = pe & 1u;
+      const uint32_t at = base + pe;
+      if ((at | 1u) < P.cap) {                             // both pairs of an entry fit, or neither is written
+        const uint32_t j = st_j[wave][e], pId = st_p[wave][e];
+        const uint32_t ok = 2u * (pId * P.n_seq + st_s[wave][e]) + second;
+        // pairs->emplace_back(j, i) then pairs->emplace_back(i, j)   pairCreationFunctor.h:214-215
+        const int2 pr = second ? make_int2(int(pId), int(j)) : make_int2(int(j), int(pId));
+        P.ab[at] = pr; P.okey[at] = ok;
+        if (P.do_prep) {
+          if (blockIdx.y == 0) prep1_item(R, at, pr);
+          else prep2_item(R, at, pr, my_mask);
+        }
+      } else {
+        atomicOr(P.overflow, P.overflow_bit);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  };
+  const uint32_t gw = blockIdx.x * kPairWaves + wave, nw = gridDim.x * kPairWaves;
+  for (uint32_t pId = gw; pId < P.n_q; pId += nw) {
+    const float cx = P.ux[pId], cy = P.uy[pId], cz = P.uz[pId];
+    const float wxi = P.qx[pId], wyi = P.qy[pId], wzi = P.qz[pId];
+    for (uint32_t tile = 0; tile < P.n_leaf; tile += 64u) {
+      const uint32_t l = tile + lane;
+      uint32_t beg = 0, len = 0;
+      if (l < P.n_leaf && sphere_box(cx, cy, cz, P.nRadius, P.leaves[l])) {     // intersect, intersectionPrimitive.h:117-142
+        beg = P.leaf_off[l];
+        len = P.leaf_off[l + 1u] - beg;
+      }
+      uint32_t incl = len;                               // inclusive prefix of the touched leaves' sizes
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t up = uint32_t(__shfl_up(int(incl), o));
+        if (lane >= uint32_t(o)) incl += up;
+      }
+      const uint32_t total = uint32_t(__builtin_amdgcn_readlane(int(incl), 63));
+      for (uint32_t base = 0; base < total; base += 64u) {
+        const uint32_t t = base + lane;                  // this lane's (leaf, point) slot
+        uint32_t lo = 0u, hi = 63u;                      // owner leaf: first lane whose inclusive prefix exceeds t
+#pragma unroll
+        for (int it = 0; it < 6; ++it) {
+          const uint32_t mid = (lo + hi) >> 1;
+          const uint32_t v = uint32_t(__shfl(int(incl), int(mid)));
+          if (v <= t) lo = mid + 1u; else hi = mid;
+        }
+        const uint32_t owner = min(lo, 63u);
+        const uint32_t o_incl = uint32_t(__shfl(int(incl), int(owner)));
+        const uint32_t o_len = uint32_t(__shfl(int(len), int(owner)));
+        const uint32_t o_beg = uint32_t(__shfl(int(beg), int(owner)));
+        bool acc = false;
+        uint32_t j = 0, s = 0;
+        if (t < total) {
+          s = o_beg + (t - (o_incl - o_len));
+          j = P.seq_id[s];
+          if (pId > j) {                                                          // intersectionFunctor.h:210
+            const float dx = P.ux[j] - cx, dy = P.uy[j] - cy, dz = P.uz[j] - cz;
+            const float d = sqrtf(sqn3(dx, dy, dz)) - P.nRadius;
+            if (d * d < P.eps_unit * P.eps_unit)                                  // intersectPoint, intersectionPrimitive.h:154-157
+              acc = pair_filters(P, pId, j, wxi, wyi, wzi);
+          }
+        }
+        const unsigned long long m = __ballot(acc);
+        if (m != 0ull) {
+          if (acc) {
+            const uint32_t e = n_st + __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u));
+            st_j[wave][e] = j; st_s[wave][e] = s; st_p[wave][e] = pId;
+          }
+          n_st += uint32_t(__popcll(m));
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          if (n_st + 64u > uint32_t(kPairStageW)) {      // stage full before the end: this wave appends on its own
+            uint32_t b = 0;
+            if (lane == 0) b = atomicAdd(P.counter, 2u * n_st);
+            b = uint32_t(__builtin_amdgcn_readfirstlane(int(b)));
+            write_out(b);
+            n_st = 0;
+          }
+        }
+      }
+    }
+  }
+  // end of the workgroup's primitives: ONE global atomic for the four waves' leftovers
+  if (lane == 0) s_cnt[wave] = n_st;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t tot = 0;
+    for (int w = 0; w < kPairWaves; ++w) tot += s_cnt[w];
+    s_base = tot ? atomicAdd(P.counter, 2u * tot) : 0u;
+  }
+  __syncthreads();
+  uint32_t before = 0;
+  for (uint32_t w = 0; w < wave; ++w) before += s_cnt[w];
+  if (n_st) write_out(s_base + 2u * before);
+}
+
+// ---------------------------------------------------------------------------
+// ComputeRigidTransformation + rms gate of one congruent quad (match4pcsBase.cc:365-500, match4pcsBase.hpp:436-439)
+// and the compaction of the passing candidates.  Shared by k_gate (stage-level entry point) and k_quads (fused path).
+// ---------------------------------------------------------------------------
+struct GateParams {
+  const float4* q4;                                     // sampled Q (centred), packed (x,y,z,0), original order (quad indices)
+  BaseFrame base;
+  uint32_t* counts;                                     // per quad: kGateFailed, later the inlier count
+  uint32_t* cand_idx; float4* cand_T;                   // gated candidates: quad index + 3x4 transform
+  uint32_t* C_dev;
+};
+__device__ __forceinline__ bool gate_quad(const GateParams& G, const int4 qd, float T[12]) {
+  const float4 a = G.q4[qd.x], b = G.q4[qd.y], c = G.q4[qd.z];
+  const float q[3][3] = {{a.x, a.y, a.z}, {b.x, b.y, b.z}, {c.x, c.y, c.z}};
+  float c2[3];
+  return rigid_gate(G.base, q, T, c2);
+}
+__device__ __forceinline__ void store_candidate(const GateParams& G, const uint32_t at, const uint32_t k, const float T[12]) {
+  G.cand_idx[at] = k;
+  float4* dst = G.cand_T + 3 * size_t(at);
+  dst[0] = make_float4(T[0], T[1], T[2], T[3]);
+  dst[1] = make_float4(T[4], T[5], T[6], T[7]);
+  dst[2] = make_float4(T[8], T[9], T[10], T[11]);
+}
+
+// k_gate: one thread per congruent quad (s4p_try_congruent_set, where the quads come from the caller).  Passing
+// candidates are compacted (wave-aggregated append) into cand_idx / cand_T so that the scoring kernel sees a dense,
+// perfectly balanceable list; failing ones get counts[k] = kGateFailed.
+struct GateKernelParams { GateParams g; const int4* quads; const uint32_t* K_dev; uint32_t K_cap; };
+__global__ __launch_bounds__(256) void k_gate(GateKernelParams P) {
+  const uint32_t K = min(*P.K_dev, P.K_cap);
+  const uint32_t lane = threadIdx.x & 63u;
+  for (uint32_t k0 = (blockIdx.x * blockDim.x + threadIdx.x) & ~63u; k0 < K; k0 += gridDim.x * blockDim.x) {
+    const uint32_t k = k0 + lane;
+    float T[12];
+    bool ok = false;
+    if (k < K) {
+      ok = gate_quad(P.g, P.quads[k], T);
+      if (!ok) P.g.counts[k] = kGateFailed;
+    }
+    const unsigned long long pass = __ballot(ok);
+    if (pass == 0ull) continue;
+    const uint32_t leader = __ffsll((long long)pass) - 1;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(P.g.C_dev, uint32_t(__popcll(pass)));
+    base = __shfl(base, leader);
+    if (ok) store_candidate(P.g, base + uint32_t(__popcll(pass & ((1ull << lane) - 1ull))), k, T);
+  }
 }
 
 struct QuadParams {
@@ -898,17 +959,22 @@ struct QuadParams {
   HashTable ht;
   float thr;                   // distance_threshold2 (compared against a SQUARED norm: quirk super4pcs.cc:160)
   int4* quads; unsigned long long* tags; uint32_t* K_dev; uint32_t K_cap; uint32_t* overflow;
+  int do_gate; GateParams gate;                          // fused path: gate every quad as it is appended
 };
 
 constexpr int kQuadStage = 1536;   // quads per workgroup between two flushes (24 B each)
 
-// One thread per pairs2 entry: hash lookup of its euclidean cell, walk of the set-1 chain.
-// Matches are staged in LDS and flushed with one global atomic per workgroup round.
+// One thread per pairs2 entry: hash lookup of its euclidean cell, walk of the set-1 chain (super4pcs.cc:151-163).
+// Matches are staged in LDS and flushed with one global atomic per workgroup round; on the fused path the flush also
+// runs ComputeRigidTransformation + the rms gate on the staged quads -- one thread per quad, all 256 lanes busy,
+// instead of a separate launch that re-reads them -- and appends the survivors to the candidate list (one more
+// atomic per 256 quads).
 __global__ __launch_bounds__(256) void k_quads(QuadParams P) {
   __shared__ int4 st_q[kQuadStage];
   __shared__ unsigned long long st_t[kQuadStage];
-  __shared__ uint32_t st_n, st_base;
+  __shared__ uint32_t st_n, st_base, s_wc[4], s_cbase;
   const uint32_t m2 = min(*P.m2_dev, P.cap2);
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   if (threadIdx.x == 0) st_n = 0;
   __syncthreads();
   for (uint32_t i0 = blockIdx.x * blockDim.x; i0 < m2; i0 += gridDim.x * blockDim.x) {
@@ -940,9 +1006,16 @@ __global__ __launch_bounds__(256) void k_quads(QuadParams P) {
               const unsigned long long tag = ((unsigned long long)P.okey1[e] << 32) | ok2;
               const uint32_t slot = atomicAdd(&st_n, 1u);
               if (slot < uint32_t(kQuadStage)) { st_q[slot] = quad; st_t[slot] = tag; }
-              else {                                                                    // stage full: direct append
+              else {                                                                    // stage full (rare): direct append
                 const uint32_t at = atomicAdd(P.K_dev, 1u);
-                if (at < P.K_cap) { P.quads[at] = quad; P.tags[at] = tag; } else atomicOr(P.overflow, 4u);
+                if (at < P.K_cap) {
+                  P.quads[at] = quad; P.tags[at] = tag;
+                  if (P.do_gate) {
+                    float T[12];
+                    if (gate_quad(P.gate, quad, T)) store_candidate(P.gate, atomicAdd(P.gate.C_dev, 1u), at, T);
+                    else P.gate.counts[at] = kGateFailed;
+                  }
+                } else atomicOr(P.overflow, 4u);
               }
             }
           }
@@ -952,18 +1025,183 @@ __global__ __launch_bounds__(256) void k_quads(QuadParams P) {
     }
     __syncthreads();
     const uint32_t n = min(st_n, uint32_t(kQuadStage));
-    if (n) {
+    if (n) {                                                   // uniform
       if (threadIdx.x == 0) st_base = atomicAdd(P.K_dev, n);
       __syncthreads();
       const uint32_t base = st_base;
-      for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) {
+      for (uint32_t c0 = 0; c0 < n; c0 += blockDim.x) {        // uniform trip count
+        const uint32_t e = c0 + threadIdx.x;
         const uint32_t at = base + e;
-        if (at < P.K_cap) { P.quads[at] = st_q[e]; P.tags[at] = st_t[e]; } else atomicOr(P.overflow, 4u);
+        const bool live = e < n && at < P.K_cap;
+        if (e < n && at >= P.K_cap) atomicOr(P.overflow, 4u);
+        int4 quad = make_int4(0, 0, 0, 0);
+        if (live) { quad = st_q[e]; P.quads[at] = quad; P.tags[at] = st_t[e]; }
+        if (P.do_gate) {                                        // uniform
+          float T[12];
+          const bool ok = live && gate_quad(P.gate, quad, T);
+          if (live && !ok) P.gate.counts[at] = kGateFailed;
+          const unsigned long long pass = __ballot(ok);
+          if (lane == 0) s_wc[wave] = uint32_t(__popcll(pass));
+          __syncthreads();
+          if (threadIdx.x == 0) { const uint32_t tot = s_wc[0] + s_wc[1] + s_wc[2] + s_wc[3]; s_cbase = tot ? atomicAdd(P.gate.C_dev, tot) : 0u; }
+          __syncthreads();
+          if (ok) {
+            uint32_t before = 0;
+            for (uint32_t w = 0; w < wave; ++w) before += s_wc[w];
+            store_candidate(P.gate, s_cbase + before + uint32_t(__popcll(pass & ((1ull << lane) - 1ull))), at, T);
+          }
+          __syncthreads();                                      // s_wc / s_cbase are rewritten by the next chunk
+        }
       }
     }
     __syncthreads();
     if (threadIdx.x == 0) st_n = 0;
     __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------
+// k_verify: Verify() (match4pcsBase.cc:508-567, no early exit) of every gated candidate, then -- in the same launch --
+// the selection of the base's winner (match4pcsBase.hpp:467-484: the first candidate in reference order with the
+// strictly greatest LCP), its transform, and the result record the host reads.
+// Persistent 1024-thread workgroups, one wave64 per gated candidate; the length of the gated list lives in device
+// memory (no host round trip).  LDS per workgroup: coarse bitmap (<= 48 KB) + 16 x 1.75 KB private survivor queues.
+// ---------------------------------------------------------------------------
+constexpr int kVerifyThreads = 1024;
+constexpr int kVerifyMaxBlocks = 4096;
+struct VerifyParams {
+  LcpGrid grid;
+  const float4* q4;                                     // sampled Q (centred), packed (x,y,z,0), original order (quad indices)
+  const float4* q4v;                                    // the same points in Morton order, for the LCP sweep
+  uint32_t n_q;
+  BaseFrame base;
+  const int4* quads; const unsigned long long* tags; uint32_t* counts;
+  const uint32_t* cand_idx; const float4* cand_T;       // gated candidates: quad index + 3x4 transform
+  DevCounters* ctr;                                     // live counters of the base (reset by the last workgroup)
+  DevCounters* res;                                     // result record of the base (copied to the host)
+  uint4* slots;                                         // per workgroup: {best count, its candidate, tag lo, tag hi}
+  int count_tests;                                      // instrumentation counters are live: carry them into res
+  int ablate;                                           // S4P_ABLATE debugging only (0 = full kernel)
+};
+
+// better(a, b): a wins over b if its count is greater, or equal with a smaller tag (= earlier in reference order)
+__device__ __forceinline__ bool slot_better(const uint32_t ca, const unsigned long long ta, const uint32_t cb, const unsigned long long tb, const bool b_valid) {
+  return !b_valid || ca > cb || (ca == cb && ta < tb);
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(kVerifyThreads, 8) void k_verify(VerifyParams P) {   // 8 waves/SIMD: two 1024-thread workgroups per CU
+  extern __shared__ uint32_t s_mem[];
+  uint32_t* s_coarse = s_mem;
+  uint2* s_queue = reinterpret_cast<uint2*>(s_mem + P.grid.coarse_words) + (threadIdx.x >> 6) * (kQueueWordsPerWave / 2);
+  __shared__ uint32_t s_next, s_last;
+  __shared__ uint32_t s_wcnt[kVerifyThreads / 64], s_wcand[kVerifyThreads / 64];
+  __shared__ unsigned long long s_wtag[kVerifyThreads / 64];
+  const uint32_t C = P.ctr->C;
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  // Work split: every workgroup owns a contiguous slice of the gated candidate list (static: a single-address global
+  // cursor caps at ~90 dequeues/us, MI355X_MICROARCH "dequeue"); inside the slice its 16 waves take candidates from an
+  // LDS counter, so a wave that drew cheap candidates (few L0 survivors) simply takes more.  Slices differ by at most
+  // one candidate, against "one or two candidates per wave" for a static stride over waves.
+  const uint32_t lo = uint32_t((uint64_t(C) * blockIdx.x) / gridDim.x), hi = uint32_t((uint64_t(C) * (blockIdx.x + 1u)) / gridDim.x);
+  uint32_t b_cnt = 0, b_cand = kNil; unsigned long long b_tag = ~0ull;      // this wave's best (wave-uniform)
+  if (lo < hi) {                                           // (uniform) otherwise: more workgroups than candidates
+    if (threadIdx.x == 0) s_next = lo;
+    stage_coarse(P.grid, s_coarse);                        // ends with a workgroup barrier
+    while (true) {
+      uint32_t i = 0;
+      if (lane == 0) i = atomicAdd(&s_next, 1u);
+      i = uint32_t(__builtin_amdgcn_readfirstlane(int(i)));
+      if (i >= hi) break;
+      const float4* src = P.cand_T + 3 * size_t(i);         // one candidate per wave
+      uint32_t cnt = 0;
+      if (P.ablate == 2) cnt = uint32_t(src[0].w > 1e30f);
+      else if (P.ablate == 1) cnt = wave_lcp_count<COUNT, true>(P.grid, s_coarse, s_queue, P.q4v, P.n_q, src, &P.ctr->point_tests);
+      else cnt = wave_lcp_count<COUNT, false>(P.grid, s_coarse, s_queue, P.q4v, P.n_q, src, &P.ctr->point_tests);
+      const uint32_t k = uint32_t(__builtin_amdgcn_readfirstlane(int(P.cand_idx[i])));
+      const unsigned long long tag = P.tags[k];
+      if (lane == 0) P.counts[k] = cnt;
+      if (slot_better(cnt, tag, b_cnt, b_tag, b_cand != kNil)) { b_cnt = cnt; b_tag = tag; b_cand = i; }
+    }
+  }
+  // ---- selection: wave bests -> workgroup best -> slot; the last workgroup to finish reduces the slots ----
+  if (lane == 0) { s_wcnt[wave] = b_cnt; s_wcand[wave] = b_cand; s_wtag[wave] = b_tag; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t bc = 0, bi = kNil; unsigned long long bt = ~0ull;
+    for (uint32_t w = 0; w < uint32_t(kVerifyThreads / 64); ++w)
+      if (s_wcand[w] != kNil && slot_better(s_wcnt[w], s_wtag[w], bc, bt, bi != kNil)) { bc = s_wcnt[w]; bt = s_wtag[w]; bi = s_wcand[w]; }
+    P.slots[blockIdx.x] = make_uint4(bc, bi, uint32_t(bt), uint32_t(bt >> 32));
+    __threadfence();                                       // release (agent scope): the slot is visible before the ticket
+    const uint32_t ticket = atomicAdd(&P.ctr->done, 1u);
+    s_last = (ticket == gridDim.x - 1u) ? 1u : 0u;
+  }
+  __syncthreads();
+  if (s_last == 0u) return;
+  __threadfence();                                         // acquire: the other workgroups' slots
+  // (the arrays of the wave-level reduction are reused for the slot-level one: one entry per wave)
+  uint32_t bc = 0, bi = kNil; unsigned long long bt = ~0ull;
+  for (uint32_t b = threadIdx.x; b < gridDim.x; b += blockDim.x) {
+    const uint4 s = P.slots[b];
+    const unsigned long long t = (unsigned long long)s.z | ((unsigned long long)s.w << 32);
+    if (s.y != kNil && slot_better(s.x, t, bc, bt, bi != kNil)) { bc = s.x; bt = t; bi = s.y; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {                       // wave reduction
+    const uint32_t oc = uint32_t(__shfl_xor(int(bc), o)), oi = uint32_t(__shfl_xor(int(bi), o));
+    const uint32_t tl = uint32_t(__shfl_xor(int(uint32_t(bt)), o)), th = uint32_t(__shfl_xor(int(uint32_t(bt >> 32)), o));
+    const unsigned long long ot = (unsigned long long)tl | ((unsigned long long)th << 32);
+    if (oi != kNil && slot_better(oc, ot, bc, bt, bi != kNil)) { bc = oc; bt = ot; bi = oi; }
+  }
+  if (lane == 0) { s_wcnt[wave] = bc; s_wcand[wave] = bi; s_wtag[wave] = bt; }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  bc = 0; bi = kNil; bt = ~0ull;
+  for (uint32_t w = 0; w < uint32_t(kVerifyThreads / 64); ++w)
+    if (s_wcand[w] != kNil && slot_better(s_wcnt[w], s_wtag[w], bc, bt, bi != kNil)) { bc = s_wcnt[w]; bt = s_wtag[w]; bi = s_wcand[w]; }
+  DevCounters* c = P.ctr;
+  DevCounters* r = P.res;
+  r->m1 = c->m1; r->m2 = c->m2; r->K = c->K; r->C = C; r->overflow = c->overflow;
+  r->best_count = bc; r->best_tag = bt; r->has_best = 0u;
+  if (COUNT || P.count_tests) { r->point_tests = c->point_tests; r->l0_pass = c->l0_pass; r->l1_pass = c->l1_pass; r->l2_pass = c->l2_pass; }
+  if (bi != kNil) {                                        // recompute the winner's 4x4 (ComputeRigidTransformation)
+    const uint32_t k = P.cand_idx[bi];
+    const int4 qd = P.quads[k];
+    const float4 a = P.q4[qd.x], b = P.q4[qd.y], cc = P.q4[qd.z];
+    const float q[3][3] = {{a.x, a.y, a.z}, {b.x, b.y, b.z}, {cc.x, cc.y, cc.z}};
+    float T[12], c2[3];
+    rigid_gate(P.base, q, T, c2);
+    for (int i = 0; i < 12; ++i) r->best_T[i] = T[i];
+    r->best_T[12] = 0.f; r->best_T[13] = 0.f; r->best_T[14] = 0.f; r->best_T[15] = 1.f;
+    for (int i = 0; i < 3; ++i) r->best_c2[i] = c2[i];
+    r->best_quad[0] = qd.x; r->best_quad[1] = qd.y; r->best_quad[2] = qd.z; r->best_quad[3] = qd.w;
+    r->has_best = 1u;
+  }
+  // the live counters are ready for the next base on this lane (no separate reset launch)
+  c->m1 = 0; c->m2 = 0; c->K = 0; c->C = 0; c->best_count = 0; c->overflow = 0; c->best_tag = ~0ull; c->has_best = 0;
+  c->point_tests = 0; c->l0_pass = 0; c->l1_pass = 0; c->l2_pass = 0;
+  __threadfence();
+  c->done = 0;
+}
+
+// k_verify_T: Verify() for explicit transforms (one wave per transform).
+struct VerifyTParams {
+  LcpGrid grid; const float4* q4; uint32_t n_q;
+  const float* T; uint32_t B; uint32_t* counts; DevCounters* ctr;
+};
+template <bool COUNT>
+__global__ __launch_bounds__(kVerifyThreads) void k_verify_T(VerifyTParams P) {
+  extern __shared__ uint32_t s_mem[];
+  uint32_t* s_coarse = s_mem;
+  uint2* s_queue = reinterpret_cast<uint2*>(s_mem + P.grid.coarse_words) + (threadIdx.x >> 6) * (kQueueWordsPerWave / 2);
+  stage_coarse(P.grid, s_coarse);
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+  for (uint32_t k = wave; k < P.B; k += nwaves) {
+    const uint32_t cnt = wave_lcp_count<COUNT, false>(P.grid, s_coarse, s_queue, P.q4, P.n_q,
+                                                      reinterpret_cast<const float4*>(P.T + 16 * size_t(k)), COUNT ? &P.ctr->point_tests : nullptr);
+    if (lane == 0) P.counts[k] = cnt;
   }
 }
 
@@ -991,9 +1229,12 @@ __global__ void k_selftest(const float* a, const float* b, uint64_t n, float* o_
   }
 }
 
+// Stage-level entry points start from explicitly cleared counters; on the fused path the last workgroup of k_verify
+// leaves them cleared for the next base of the lane.
 __global__ void k_reset_counters(DevCounters* c) {
   c->m1 = 0; c->m2 = 0; c->K = 0; c->C = 0; c->best_count = 0; c->overflow = 0;
-  c->best_tag = ~0ull; c->has_best = 0; c->cursor = 0;
+  c->best_tag = ~0ull; c->has_best = 0; c->done = 0;
+  c->point_tests = 0; c->l0_pass = 0; c->l1_pass = 0; c->l2_pass = 0;
 }
 
 }  // namespace s4p

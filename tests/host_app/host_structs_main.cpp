@@ -25,11 +25,12 @@ static int run_octree(const char* path) {
   size_t k = 0; f >> k;
   s4p::UnitFrame frame; frame.build(qx, qy, qz, ux, uy, uz);
   s4p::PairOctree tree; tree.reset(uint32_t(n));
-  std::vector<uint32_t> sid(n), sleaf(n); std::vector<s4p::Leaf> leaves(n);
+  std::vector<uint32_t> sid(n), loff(n + 1); std::vector<s4p::Leaf> leaves(n);
   for (size_t c = 0; c < k; ++c) {
     float d = 0, eps = 0; f >> d >> eps;
     tree.build(ux.data(), uy.data(), uz.data(), uint32_t(n), d / frame.ratio, eps / frame.ratio, 50);
-    tree.flatten(sid.data(), sleaf.data(), leaves.data());
+    tree.flatten(sid.data(), loff.data(), leaves.data());
+    if (loff[tree.n_leaf()] != tree.n_seq() || loff[0] != 0) { std::printf("bad leaf offsets\n"); return 1; }
     std::printf("%u %u\n", tree.n_seq(), tree.n_leaf());
     for (size_t i = 0; i < n; ++i) std::printf("%u ", tree.ids[i]);
     std::printf("\n");

@@ -86,6 +86,76 @@ def _stagewise_parity(O, capi, P, Q, T_gt, delta, overlap, n_s, n_bases, max_pai
     return om, gm, ctx
 
 
+def _fused_bases_vs_oracle(O, capi, P, Q, delta, overlap, n_s, n_bases, max_pairs, max_quads, count_sample=1500, skip_bases=0):
+    """The fused device pass (s4p_try_base through the engine's TryOneBase) of consecutive bases against the oracle:
+    counts of pairs / quads / candidates, the ordered quad list, per-candidate inlier counts (deterministic subsample,
+    full-count oracle), and -- in the reference's early-exit mode -- TryOneBase's return value, best LCP, winner, 4x4."""
+    from bench import seg_len32
+    oopt = O.make_options(delta, overlap, n_s)
+    om_ref = O.Matcher(oopt, full_counts=False, use_kdtree=True, keep_trace=True)
+    om_full = O.Matcher(oopt, full_counts=True, use_kdtree=True, keep_trace=False)
+    om_ref.init(P, Q); om_full.init(P, Q)
+    gm = capi.Matcher(capi.make_options(delta, overlap, n_s), max_pairs=max_pairs, max_quads=max_quads)
+    gm.init_full(P, Q)
+    assert np.array_equal(gm.sampled(0), om_ref.cloud(0)) and np.array_equal(gm.sampled(1), om_ref.cloud(1))
+    assert gm.info().best_lcp == om_ref.stats().best_lcp
+    eps = 2.0 * delta
+    for _ in range(skip_bases):                      # advance RNG + pair-octree permutation everywhere, score nothing
+        for om in (om_ref, om_full):
+            ok, _i1, _i2, _b, bx = om.select_quadrilateral()
+            if ok:
+                om.extract_pairs(seg_len32(bx[0], bx[1]), 0.0, eps, 0, 1)
+                om.extract_pairs(seg_len32(bx[2], bx[3]), 0.0, eps, 2, 3)
+        gm.next_base(run_device=False)
+    tot_quads = tot_cand = 0
+    for b in range(n_bases):
+        g_ok, r = gm.try_one_base()
+        g_quads, g_counts = gm.last_candidates(r.n_quads)
+        assert om_ref.try_one_base() == g_ok
+        rec = om_ref.trace()[0][-1]
+        if rec[0]:
+            assert (r.n_pairs1, r.n_pairs2) == (rec[5], rec[6])
+            if rec[5] and rec[6]:
+                assert (r.n_quads, r.n_verified) == (rec[7], rec[8])
+        T, lcp, base, cong, _c1, _c2 = om_ref.best()
+        gi = gm.info()
+        assert gi.best_lcp == lcp and list(gi.base) == base.tolist() and list(gi.congruent) == cong.tolist()
+        assert np.array_equal(np.array(gi.transform, np.float32).reshape(4, 4), T)
+        ok, i1, i2, obase, bx = om_full.select_quadrilateral()
+        if not ok:
+            continue
+        p1 = om_full.extract_pairs(seg_len32(bx[0], bx[1]), 0.0, eps, 0, 1)
+        p2 = om_full.extract_pairs(seg_len32(bx[2], bx[3]), 0.0, eps, 2, 3)
+        if not (len(p1) and len(p2)):
+            assert r.n_quads == 0
+            continue
+        o_quads = om_full.find_congruent(i1, i2, eps, p1, p2, cap=max(int(r.n_quads) + 16, 1 << 16))
+        assert np.array_equal(o_quads, g_quads)                       # std::set<(id, i)> order
+        K = len(o_quads)
+        if K:
+            idx = np.unique(np.concatenate([np.arange(0, K, max(K // count_sample, 1)), np.arange(min(K, 128)),
+                                            np.flatnonzero(g_counts == g_counts.max())[:4]]))
+            _nb, per, _bc, _bi = om_full.try_congruent_set(obase, o_quads[idx])
+            assert np.array_equal(per, g_counts[idx])
+        tot_quads += K
+        tot_cand += int(r.n_verified)
+    return gm, tot_quads, tot_cand
+
+
+def test_config2_1m_pair_fused_path(oracle_mod, s4p_lib_built):
+    """configs[2], the BENCHMARKED workload (1 M-point pair, delta = 0.004, n = 2000, n_P ~ 57 k): the fused pass of
+    several consecutive bases of the benchmark's own seeded sequence (the bases bench.py times after its warm-up)."""
+    from super4pcs_amd import capi, datasets as D
+    import bench
+    P, Q, _ = D.bumpy_pair(int(bench.N_POINTS * SCALE), overlap=bench.OVERLAP, delta=bench.DELTA, seed=bench.SEED)
+    gm, quads, cand = _fused_bases_vs_oracle(oracle_mod, capi, P, Q, bench.DELTA, bench.OVERLAP, bench.SAMPLE, 3,
+                                             bench.MAX_PAIRS, bench.MAX_QUADS, skip_bases=5)
+    assert quads > 0 and cand > 0
+    if SCALE == 1.0:
+        i = gm.info()
+        assert (i.n_sampled_p, i.n_sampled_q, i.number_of_trials) == (57207, 2000, 594)
+
+
 def _engine_invariants(gm, ctx, n_steps, need_candidates=True):
     best = gm.info().best_lcp
     for _ in range(n_steps):
@@ -125,6 +195,10 @@ def test_config3_lidar_pair_5m_points(oracle_mod, s4p_lib_built):
     P, Q, T_gt = D.lidar_pair(n, delta=delta)
     om, gm, ctx = _stagewise_parity(oracle_mod, capi, P, Q, T_gt, delta, 0.4, 2000, 3, 8 << 20, 64 << 20, 0.15)
     _engine_invariants(gm, ctx, 12)
+    del om, gm, ctx
+    # and the fused path (what a rank of the sharded job runs per owned base), two consecutive bases
+    _gm, quads, cand = _fused_bases_vs_oracle(oracle_mod, capi, P, Q, delta, 0.4, 2000, 2, 8 << 20, 64 << 20, count_sample=600)
+    assert quads > 0 and cand > 0
 
 
 def test_config4_part_in_whole_10m_scene(oracle_mod, s4p_lib_built):
@@ -139,3 +213,8 @@ def test_config4_part_in_whole_10m_scene(oracle_mod, s4p_lib_built):
     # have a second segment longer than the query and no quads: pair parity on every base, quad parity where there are any
     om, gm, ctx = _stagewise_parity(oracle_mod, capi, P, Q, T_gt, delta, 0.2, 2000, 6, 8 << 20, 64 << 20, 0.3, need_quads=False)
     _engine_invariants(gm, ctx, 8, need_candidates=False)
+    del om, gm, ctx
+    # Bases whose second segment fits inside the query DO produce quads and candidates: walk the seeded sequence (fused
+    # path against the oracle on every base) until some have been seen, so that this config cannot pass on empty lists.
+    _gm, quads, cand = _fused_bases_vs_oracle(oracle_mod, capi, P, Q, delta, 0.2, 2000, 10, 8 << 20, 64 << 20, count_sample=400)
+    assert quads > 0 and cand > 0
