@@ -344,7 +344,19 @@ def main():
         """Fresh matcher, same seed: W untimed steps, then exactly K timed steps between barrier + synchronize."""
         m = capi.Matcher(opt, device=local_rank, max_pairs=MAX_PAIRS, max_quads=MAX_QUADS)
         m.init_full(P, Q)                       # sampling, grid build, upload: outside the timed region
-        sh = sharding.ShardedRansac(m, rank, world, dist, dev)
+        if world > 1:
+            # the C++ sharded loop behind the C ABI (s4p_shard_*): RCCL all-reduce(max) of one 8-byte key per window
+            sh = capi.Shard(m, rank, world, True)
+            if one_gpu:
+                sh.use_collective(capi.torch_collective(dist))          # single-GPU dry run: gloo through the callback provider
+            else:
+                idt = torch.zeros(128, dtype=torch.uint8, device=dev)
+                if rank == 0:
+                    idt.copy_(torch.frombuffer(bytearray(capi.rccl_unique_id()), dtype=torch.uint8))
+                dist.broadcast(idt, src=0)
+                sh.use_rccl(local_rank, idt.cpu().numpy().tobytes())
+        else:
+            sh = sharding.ShardedRansac(m, rank, world, dist, dev)      # world 1: the engine's own pipelined Perform_N_steps
         sh.run_windows(warmup)
         m.profile_enable(True, False)
         m.profile_get(reset=True)
@@ -369,6 +381,8 @@ def main():
     m = sh = None
     for _ in range(max(args.repeats, 1)):
         if m is not None:
+            if hasattr(sh, "close"):
+                sh.close()
             m.close()
         m, sh, dt_max, cand_all, prof = timed_region(args.steps, args.warmup)
         runs.append((cand_all / dt_max, dt_max, cand_all, prof))
@@ -454,7 +468,7 @@ def main():
                                    % (args.points, DELTA, args.sample, n_p, n_q),
                        "n_P": n_p, "n_Q": n_q, "delta": DELTA, "overlap": OVERLAP, "seed": SEED,
                        "candidates_timed": cand_all, "point_queries_per_s": cand_all * n_q / dt_max,
-                       "parallelism": "bases sharded over %d GPU(s), one allreduce(max) per window" % world,
+                       "parallelism": "bases sharded over %d GPU(s), one 8-byte ncclAllReduce(max) per window (C++ loop, s4p_shard_run_windows)" % world,
                        "time_to_register": ttr},
             "parity": parity,
             "roofline": {

@@ -181,6 +181,12 @@ int32_t s4p_last_verified(s4p_ctx* ctx, uint32_t* counts, float* transforms16, i
 /* ---- final apply: Match4PCSBase::Perform_N_steps tail (match4pcsBase.hpp:265-267) */
 /* xyz SoA in place: p <- (M * [p;1]).head<3>() for n points. */
 int32_t s4p_transform_points(s4p_ctx* ctx, const float* M, float* x, float* y, float* z, int64_t n);
+/* Same for a cloud that already lives in HBM: x, y, z are DEVICE pointers, transformed in place. */
+int32_t s4p_transform_points_device(s4p_ctx* ctx, const float* M, float* dev_x, float* dev_y, float* dev_z, int64_t n);
+/* Measurement aid: times k_apply (out_ms[0], the product's VALU kernel) and its v_mfma_f32_4x4x1 variant (out_ms[1]) on n
+ * device-resident synthetic points, `reps` launches each, and counts the coordinates on which the two differ
+ * (why the final apply is not on the matrix cores). */
+int32_t s4p_apply_bench(s4p_ctx* ctx, int64_t n, int32_t reps, double* out_ms2, uint64_t* mismatch, float* max_abs);
 
 /* ---- instrumentation ------------------------------------------------------- */
 typedef struct {

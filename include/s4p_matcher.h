@@ -75,6 +75,11 @@ int32_t s4p_matcher_init_full(s4p_matcher* m, const s4p_cloud_view* P, const s4p
 int32_t s4p_matcher_get_info(s4p_matcher* m, s4p_matcher_info* out);
 /* getFirstSampled (which=0) / getSecondSampled (which=1), match4pcsBase.h:88-95; centred coordinates. */
 int32_t s4p_matcher_get_sampled(s4p_matcher* m, int32_t which, float* x, float* y, float* z);
+/* Normals / colours of the same points, in the same (engine) order -- for Q that is the order after the shuffle and the
+ * truncation to sample_size of match4pcsBase.hpp:129-138.  Any of the six output pointers may be NULL.  *has_normals /
+ * *has_rgb (nullable) tell whether the cloud carried them at init (otherwise zeros / -1 are written, as Point3D defaults). */
+int32_t s4p_matcher_get_sampled_attrs(s4p_matcher* m, int32_t which, float* nx, float* ny, float* nz,
+                                      float* r, float* g, float* b, int32_t* has_normals, int32_t* has_rgb);
 
 /* Match4PCSBase::SelectQuadrilateral (match4pcsBase.cc:279-351).  base_xyz: 12 floats (ordered base). */
 int32_t s4p_matcher_select_quadrilateral(s4p_matcher* m, int32_t* found, float* invariant1, float* invariant2,
@@ -127,6 +132,44 @@ int32_t s4p_matcher_global_transform(s4p_matcher* m, float* transformation);
 int32_t s4p_matcher_compute_transformation(s4p_matcher* m, const s4p_cloud_view* P, const s4p_cloud_view* Q,
                                            float* qx_out, float* qy_out, float* qz_out,
                                            float* transformation, float* lcp);
+
+/* opt.terminate_threshold of the matcher (the sharded loop needs it to rank "crossed the threshold" outcomes). */
+float s4p_matcher_terminate_threshold(const s4p_matcher* m);
+
+/* ---- multi-GPU: bases sharded over the GPUs of one node, one process per GPU ------------------
+ * Every rank walks the same base sequence; rank (t mod world) runs the device pass of trial t; after each window of
+ * `world` trials ONE 8-byte all-reduce(MAX) of a packed key picks the winner exactly as the sequential loop of
+ * Match4PCSBase::Perform_N_steps would (match4pcsBase.hpp:236-256, 467-484), and the winner's record is broadcast only
+ * when the window improved the best LCP.  Implemented in C++ (super4pcs_amd/csrc/s4p_shard.cpp); the built-in
+ * collective calls RCCL (rccl.h) over xGMI, a caller-supplied one (MPI, gloo, ...) plugs into the same loop. */
+typedef struct s4p_shard s4p_shard;
+typedef struct {
+  void* user;
+  int32_t (*allreduce_max_u64)(void* user, uint64_t* key);                     /* in place, MAX over all ranks; 0 = ok */
+  int32_t (*broadcast)(void* user, void* buf, int64_t bytes, int32_t root);    /* root's bytes to every rank; 0 = ok   */
+} s4p_collective;
+
+/* ncclGetUniqueId: rank 0 calls it and hands the 128 bytes to the other ranks by any means (file, MPI, env, ...). */
+int32_t s4p_rccl_unique_id(uint8_t* out128);
+/* Declares matcher m rank `rank` of `world` (as s4p_matcher_set_sharding does) and creates the sharded driver. */
+int32_t s4p_shard_create(s4p_matcher* m, int32_t rank, int32_t world, int32_t producer_threads, s4p_shard** out);
+void    s4p_shard_destroy(s4p_shard* s);
+const char* s4p_shard_last_error(const s4p_shard* s);
+/* ncclCommInitRank on `device` (the matcher's GPU); collective = ncclAllReduce(uint64, max) / ncclBroadcast on a private stream. */
+int32_t s4p_shard_use_rccl(s4p_shard* s, int32_t device, const uint8_t* unique_id128);
+int32_t s4p_shard_use_collective(s4p_shard* s, const s4p_collective* coll);
+/* n_windows windows (n_windows * world trials of the common sequence) through the pipelined loop; *candidates_local = candidates
+ * this rank verified, *terminated = the terminate threshold was crossed (later windows are drained, not committed). */
+int32_t s4p_shard_run_windows(s4p_shard* s, int32_t n_windows, uint64_t* candidates_local, int32_t* terminated);
+/* Match4PCSBase::ComputeTransformation over `world` GPUs: same arguments and result as s4p_matcher_compute_transformation,
+ * called by every rank with the same clouds. */
+int32_t s4p_shard_compute_transformation(s4p_shard* s, const s4p_cloud_view* P, const s4p_cloud_view* Q,
+                                         float* qx_out, float* qy_out, float* qz_out, float* transformation, float* lcp);
+/* Host-only self-check of the window loop on recorded outcomes (no matcher, no GPU): the CPU tests drive it over gloo. */
+int32_t s4p_shard_replay(int32_t rank, int32_t world, const s4p_collective* coll, int32_t n_windows, int32_t depth,
+                         uint32_t threshold_count, uint32_t start_best_count, const int32_t* found,
+                         const s4p_base_result* results, int32_t* commit_trials, uint32_t* commit_counts, int32_t commit_cap,
+                         int32_t* n_commits, int32_t* terminated, uint64_t* trials_done);
 
 #ifdef __cplusplus
 }

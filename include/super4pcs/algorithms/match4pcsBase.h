@@ -149,7 +149,11 @@ class Match4PCSBase {
     if (found) {
       base_3D_.resize(4);
       for (int t = 0; t < 4; ++t) base_3D_[t] = sampled_P_3D_[size_t(ids[t])];
-      check(s4p_set_base(s4p_matcher_ctx(engine_), bx, nullptr, nullptr));
+      // base normals / colours feed the pair filters of the ExtractPairs hook (pairCreationFunctor.h:166-192)
+      float bn[12], bc[12];
+      for (int t = 0; t < 4; ++t)
+        for (int k = 0; k < 3; ++k) { bn[3 * t + k] = base_3D_[t].normal()(k); bc[3 * t + k] = base_3D_[t].rgb()(k); }
+      check(s4p_set_base(s4p_matcher_ctx(engine_), bx, bn, bc));
     }
     return found != 0;
   }
@@ -241,19 +245,22 @@ class Match4PCSBase {
     for (int k = 0; k < 3; ++k) { centroid_P_(k) = i.centroid_p[k]; centroid_Q_(k) = i.centroid_q[k]; }
     for (int k = 0; k < 4; ++k) { base_[k] = i.base[k]; current_congruent_[k] = i.congruent[k]; }
   }
-  // The engine keeps positions only; normals / colours of the sampled points are recovered by matching the
-  // centred coordinates back to the sampler's output order (P keeps its order; Q is a shuffled prefix).
-  void pull_sampled(int which, const std::vector<Point3D>& source, std::vector<Point3D>& out) {
+  // Sampled clouds as the engine holds them: centred positions plus the normals / colours that travelled with each
+  // point through sampling, shuffle and truncation (match4pcsBase.hpp:112-138).
+  void pull_sampled(int which, const std::vector<Point3D>&, std::vector<Point3D>& out) {
     s4p_matcher_info i;
     check(s4p_matcher_get_info(engine_, &i));
     const size_t n = size_t(which == 0 ? i.n_sampled_p : i.n_sampled_q);
-    std::vector<float> x(n), y(n), z(n);
-    check(s4p_matcher_get_sampled(engine_, which, x.data(), y.data(), z.data()));
+    std::vector<float> v[9];
+    for (auto& a : v) a.resize(n);
+    int32_t has_n = 0, has_c = 0;
+    check(s4p_matcher_get_sampled(engine_, which, v[0].data(), v[1].data(), v[2].data()));
+    check(s4p_matcher_get_sampled_attrs(engine_, which, v[3].data(), v[4].data(), v[5].data(), v[6].data(), v[7].data(), v[8].data(), &has_n, &has_c));
     out.assign(n, Point3D());
-    const bool same_order = (which == 0) || n == source.size();
     for (size_t k = 0; k < n; ++k) {
-      if (same_order && k < source.size()) out[k] = source[k];
-      out[k].x() = x[k]; out[k].y() = y[k]; out[k].z() = z[k];
+      out[k].x() = v[0][k]; out[k].y() = v[1][k]; out[k].z() = v[2][k];
+      if (has_n) out[k].set_normal(typename Point3D::VectorType(v[3][k], v[4][k], v[5][k]));
+      if (has_c) out[k].set_rgb(typename Point3D::VectorType(v[6][k], v[7][k], v[8][k]));
     }
   }
 };

@@ -23,11 +23,21 @@ class MatchSuper4PCS : public Match4PCSBase {
                     int base_point2, PairsVector* pairs) const override {
     pairs->clear();
     s4p_ctx* ctx = s4p_matcher_ctx(engine_);
-    const size_t nq = sampled_Q_3D_.size();
-    std::vector<int32_t> buf(2 * std::max<size_t>(nq * nq, 16));
+    // The call advances the persistent octree permutation, so it cannot simply be repeated with a larger buffer: the
+    // state is saved first and restored if the first (modest) buffer turns out too small (*n_out tells the need).
+    std::vector<uint32_t> state(size_t(s4p_pair_state_words(ctx)));
+    check(s4p_pair_state_save(ctx, state.data()));
+    std::vector<int32_t> buf(2 * (size_t(1) << 16));
     int64_t m = 0;
-    check(s4p_extract_pairs(ctx, pair_distance, pair_normals_angle, pair_distance_epsilon, base_point1, base_point2, buf.data(),
-                            int64_t(buf.size() / 2), &m));
+    int32_t rc = s4p_extract_pairs(ctx, pair_distance, pair_normals_angle, pair_distance_epsilon, base_point1, base_point2, buf.data(),
+                                   int64_t(buf.size() / 2), &m);
+    if (rc == S4P_ERR_CAPACITY && m > int64_t(buf.size() / 2)) {
+      check(s4p_pair_state_restore(ctx, state.data()));
+      buf.resize(2 * size_t(m));
+      rc = s4p_extract_pairs(ctx, pair_distance, pair_normals_angle, pair_distance_epsilon, base_point1, base_point2, buf.data(),
+                             int64_t(buf.size() / 2), &m);
+    }
+    check(rc);
     pairs->reserve(size_t(m));
     for (int64_t i = 0; i < m; ++i) pairs->emplace_back(buf[size_t(2 * i)], buf[size_t(2 * i + 1)]);
   }

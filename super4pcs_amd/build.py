@@ -14,7 +14,7 @@ LIB = os.path.join(LIBDIR, "libsuper4pcs_amd.so")
 # parity depends on IEEE sqrt and divide.
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
                "-fhip-fp32-correctly-rounded-divide-sqrt", "-fPIC", "-shared", "-Wall", "-Wno-unused-function"]
-SOURCES = ["s4p_capi.hip", "s4p_sampler.hip", "s4p_engine.cpp"]
+SOURCES = ["s4p_capi.hip", "s4p_sampler.hip", "s4p_engine.cpp", "s4p_shard.cpp"]
 
 
 def _hipcc():
@@ -32,19 +32,31 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _compile(out, defines=(), verbose=False):
+    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    cmd = [_hipcc()] + HIPCC_FLAGS + ["-D" + d for d in defines] + ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+    for s in srcs:
+        cmd += ["-x", "hip", s]
+    cmd += ["-ldl", "-o", out]              # s4p_shard.cpp binds RCCL at run time (dlopen)
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return out
+
+
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
-    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    cmd = [_hipcc()] + HIPCC_FLAGS + ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
-    for s in srcs:
-        cmd += ["-x", "hip", s]
-    cmd += ["-o", LIB]
-    if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    subprocess.check_call(cmd)
-    return LIB
+    return _compile(LIB, (), verbose)
+
+
+def build_variant(name, defines):
+    """A/B aid: the same sources with extra -D switches (e.g. S4P_FINE_FLAT=1) -> scratch/lib<name>.so; select it on the
+    GPU box with S4P_LIB=<path> (tools/ab_one.py)."""
+    d = os.path.join(ROOT, "scratch")
+    os.makedirs(d, exist_ok=True)
+    return _compile(os.path.join(d, "lib%s.so" % name), defines)
 
 
 BINDIR = os.path.join(_HERE, "bin")

@@ -19,7 +19,7 @@ ERR_NAMES = {0: "OK", -1: "BAD_ARG", -2: "NO_DEVICE", -3: "HIP", -4: "OOM", -5: 
 EXPORTED_SYMBOLS = [
     "s4p_create", "s4p_destroy", "s4p_last_error", "s4p_device_name", "s4p_set_clouds", "s4p_set_base",
     "s4p_extract_pairs", "s4p_find_congruent", "s4p_try_congruent_set", "s4p_verify_transforms", "s4p_verify_transforms_counted",
-    "s4p_try_base", "s4p_last_verified", "s4p_try_base_async", "s4p_try_base_wait", "s4p_pair_state_words", "s4p_pair_state_save", "s4p_pair_state_restore", "s4p_stage_slots", "s4p_pipeline_depth", "s4p_stage_base", "s4p_try_base_staged_async", "s4p_skip_base", "s4p_last_candidates", "s4p_transform_points", "s4p_profile_enable", "s4p_profile_get",
+    "s4p_transform_points_device", "s4p_apply_bench", "s4p_try_base", "s4p_last_verified", "s4p_try_base_async", "s4p_try_base_wait", "s4p_pair_state_words", "s4p_pair_state_save", "s4p_pair_state_restore", "s4p_stage_slots", "s4p_pipeline_depth", "s4p_stage_base", "s4p_try_base_staged_async", "s4p_skip_base", "s4p_last_candidates", "s4p_transform_points", "s4p_profile_enable", "s4p_profile_get",
     "s4p_selftest_ieee",
 ]
 
@@ -96,8 +96,9 @@ def load_library():
     L.s4p_try_congruent_set.argtypes = [vp, ip, ip, C.c_int64, ip, C.POINTER(BaseResult)]
     L.s4p_verify_transforms.restype = C.c_int32
     L.s4p_verify_transforms.argtypes = [vp, fp, C.c_int64, C.POINTER(C.c_uint32)]
-    L.s4p_verify_transforms_counted.restype = C.c_int32
-    L.s4p_verify_transforms_counted.argtypes = [vp, fp, C.c_int64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
+    if hasattr(L, "s4p_verify_transforms_counted"):      # (an older library named by S4P_LIB for an A/B run may lack the newest entries)
+        L.s4p_verify_transforms_counted.restype = C.c_int32
+        L.s4p_verify_transforms_counted.argtypes = [vp, fp, C.c_int64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
     L.s4p_try_base.restype = C.c_int32
     L.s4p_try_base.argtypes = [vp, ip, C.c_float, C.c_float, C.POINTER(BaseResult)]
     L.s4p_skip_base.restype = C.c_int32
@@ -106,6 +107,11 @@ def load_library():
     L.s4p_last_candidates.argtypes = [vp, ip, ip, C.c_int64, C.POINTER(C.c_int64)]
     L.s4p_transform_points.restype = C.c_int32
     L.s4p_transform_points.argtypes = [vp, fp, fp, fp, fp, C.c_int64]
+    if hasattr(L, "s4p_apply_bench"):
+        L.s4p_transform_points_device.restype = C.c_int32
+        L.s4p_transform_points_device.argtypes = [vp, fp, vp, vp, vp, C.c_int64]
+        L.s4p_apply_bench.restype = C.c_int32
+        L.s4p_apply_bench.argtypes = [vp, C.c_int64, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_float)]
     L.s4p_profile_enable.restype = C.c_int32
     L.s4p_profile_enable.argtypes = [vp, C.c_int32, C.c_int32]
     L.s4p_profile_get.restype = C.c_int32
@@ -251,6 +257,12 @@ class Context:
         self._chk(self.L.s4p_transform_points(self.h, _f(M), _f(x), _f(y), _f(z), x.shape[0]))
         return np.stack([x, y, z], axis=1)
 
+    def apply_bench(self, n, reps=20):
+        """(ms per launch VALU, ms per launch MFMA, mismatching coordinates, max |difference|) of the final apply on n points."""
+        ms = (C.c_double * 2)(); mm = C.c_uint64(); mx = C.c_float()
+        self._chk(self.L.s4p_apply_bench(self.h, int(n), int(reps), ms, C.byref(mm), C.byref(mx)))
+        return ms[0], ms[1], int(mm.value), float(mx.value)
+
     def profile_enable(self, events=True, point_tests=False):
         self._chk(self.L.s4p_profile_enable(self.h, int(events), int(point_tests)))
 
@@ -284,6 +296,11 @@ class MatcherInfo(C.Structure):
     ]
 
 
+SHARD_SYMBOLS = [
+    "s4p_rccl_unique_id", "s4p_shard_create", "s4p_shard_destroy", "s4p_shard_last_error", "s4p_shard_use_rccl",
+    "s4p_shard_use_collective", "s4p_shard_run_windows", "s4p_shard_compute_transformation", "s4p_shard_replay",
+    "s4p_matcher_terminate_threshold",
+]
 MATCHER_SYMBOLS = [
     "s4p_matcher_create", "s4p_matcher_destroy", "s4p_matcher_last_error", "s4p_matcher_ctx", "s4p_uniform_dist_sample",
     "s4p_matcher_init", "s4p_matcher_init_full", "s4p_matcher_get_info", "s4p_matcher_get_sampled",
@@ -509,3 +526,150 @@ class Matcher:
         lcp = C.c_float()
         self._chk(self.L.s4p_matcher_compute_transformation(self.h, C.byref(vp.view), C.byref(vq.view), _f(qx), _f(qy), _f(qz), _f(M), C.byref(lcp)))
         return lcp.value, M.reshape(4, 4), np.stack([qx, qy, qz], axis=1)
+
+
+# ----------------------------------------------------------------------------------------------
+# multi-GPU: the C++ sharded trial loop (super4pcs_amd/csrc/s4p_shard.cpp, include/s4p_matcher.h)
+# ----------------------------------------------------------------------------------------------
+COLL_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.POINTER(C.c_uint64))
+COLL_BROADCAST_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32)
+
+
+class Collective(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("allreduce_max_u64", COLL_ALLREDUCE_FN), ("broadcast", COLL_BROADCAST_FN)]
+
+
+_SHARD_DECLARED = False
+
+
+def _declare_shard(L):
+    global _SHARD_DECLARED
+    if _SHARD_DECLARED:
+        return
+    _declare_matcher(L)
+    vp = C.c_void_p; ip = C.POINTER(C.c_int32); fp = C.POINTER(C.c_float); cv = C.POINTER(CloudView)
+    L.s4p_rccl_unique_id.restype = C.c_int32
+    L.s4p_rccl_unique_id.argtypes = [C.POINTER(C.c_uint8)]
+    L.s4p_shard_create.restype = C.c_int32
+    L.s4p_shard_create.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.POINTER(vp)]
+    L.s4p_shard_destroy.argtypes = [vp]
+    L.s4p_shard_last_error.restype = C.c_char_p
+    L.s4p_shard_last_error.argtypes = [vp]
+    L.s4p_shard_use_rccl.restype = C.c_int32
+    L.s4p_shard_use_rccl.argtypes = [vp, C.c_int32, C.POINTER(C.c_uint8)]
+    L.s4p_shard_use_collective.restype = C.c_int32
+    L.s4p_shard_use_collective.argtypes = [vp, C.POINTER(Collective)]
+    L.s4p_shard_run_windows.restype = C.c_int32
+    L.s4p_shard_run_windows.argtypes = [vp, C.c_int32, C.POINTER(C.c_uint64), ip]
+    L.s4p_shard_compute_transformation.restype = C.c_int32
+    L.s4p_shard_compute_transformation.argtypes = [vp, cv, cv, fp, fp, fp, fp, fp]
+    L.s4p_shard_replay.restype = C.c_int32
+    L.s4p_shard_replay.argtypes = [C.c_int32, C.c_int32, C.POINTER(Collective), C.c_int32, C.c_int32, C.c_uint32, C.c_uint32, ip,
+                                   C.POINTER(BaseResult), ip, C.POINTER(C.c_uint32), C.c_int32, ip, ip, C.POINTER(C.c_uint64)]
+    L.s4p_matcher_terminate_threshold.restype = C.c_float
+    L.s4p_matcher_terminate_threshold.argtypes = [vp]
+    _SHARD_DECLARED = True
+
+
+def torch_collective(dist):
+    """An s4p_collective whose two operations run over a torch.distributed process group with CPU tensors (gloo): the
+    provider the CPU tests and single-GPU dry runs plug into the C++ loop.  Keep the returned object alive."""
+    import torch
+
+    def allreduce(user, keyp):
+        t = torch.tensor([keyp[0]], dtype=torch.int64)           # keys stay below 2^63
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        keyp[0] = int(t.item())
+        return 0
+
+    def broadcast(user, buf, nbytes, root):
+        arr = (C.c_uint8 * nbytes).from_address(buf)
+        t = torch.frombuffer(arr, dtype=torch.uint8).clone()
+        dist.broadcast(t, src=root)
+        C.memmove(buf, t.numpy().ctypes.data, nbytes)
+        return 0
+
+    coll = Collective()
+    coll.user = None
+    coll.allreduce_max_u64 = COLL_ALLREDUCE_FN(allreduce)
+    coll.broadcast = COLL_BROADCAST_FN(broadcast)
+    return coll
+
+
+def rccl_unique_id():
+    L = load_library(); _declare_shard(L)
+    buf = (C.c_uint8 * 128)()
+    rc = L.s4p_rccl_unique_id(buf)
+    if rc != S4P_OK:
+        raise S4PError(rc, "ncclGetUniqueId failed (is librccl loadable?)")
+    return bytes(buf)
+
+
+class Shard:
+    """One rank of the sharded trial loop over a Matcher (s4p_shard)."""
+
+    def __init__(self, matcher, rank, world, producer_threads=True):
+        self.L = load_library(); _declare_shard(self.L)
+        self.m, self.rank, self.world = matcher, rank, world
+        h = C.c_void_p()
+        rc = self.L.s4p_shard_create(matcher.h, rank, world, int(producer_threads), C.byref(h))
+        if rc != S4P_OK:
+            raise S4PError(rc, "s4p_shard_create failed")
+        self.h = h
+        self._coll = None
+        self.terminated = False
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.s4p_shard_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != S4P_OK:
+            raise S4PError(rc, self.L.s4p_shard_last_error(self.h).decode())
+
+    def use_rccl(self, device, unique_id):
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        self._chk(self.L.s4p_shard_use_rccl(self.h, device, buf))
+
+    def use_collective(self, coll):
+        self._coll = coll                       # the callbacks must outlive the shard
+        self._chk(self.L.s4p_shard_use_collective(self.h, C.byref(coll)))
+
+    def run_windows(self, n):
+        cand = C.c_uint64(); term = C.c_int32()
+        self._chk(self.L.s4p_shard_run_windows(self.h, n, C.byref(cand), C.byref(term)))
+        self.terminated = bool(term.value)
+        return int(cand.value)
+
+    def compute_transformation(self, P, Q):
+        vp, vq = _View(P), _View(Q)
+        n = vq.view.n
+        qx = vq.cols[0].copy(); qy = vq.cols[1].copy(); qz = vq.cols[2].copy()
+        M = np.eye(4, dtype=np.float32).reshape(16)
+        lcp = C.c_float()
+        self._chk(self.L.s4p_shard_compute_transformation(self.h, C.byref(vp.view), C.byref(vq.view), _f(qx), _f(qy), _f(qz), _f(M), C.byref(lcp)))
+        return lcp.value, M.reshape(4, 4), np.stack([qx, qy, qz], axis=1)
+
+
+def shard_replay(rank, world, coll, found, results, depth, threshold_count, start_best):
+    """s4p_shard_replay: the C++ window loop on recorded outcomes of this rank's trials (host only)."""
+    L = load_library(); _declare_shard(L)
+    n = len(found)
+    f = (C.c_int32 * n)(*[int(x) for x in found])
+    r = (BaseResult * n)(*results)
+    cap = n * world + 4
+    ct = (C.c_int32 * cap)(); cc = (C.c_uint32 * cap)()
+    nc = C.c_int32(); term = C.c_int32(); td = C.c_uint64()
+    rc = L.s4p_shard_replay(rank, world, C.byref(coll), n, depth, threshold_count, start_best, f, r, ct, cc, cap,
+                            C.byref(nc), C.byref(term), C.byref(td))
+    if rc != S4P_OK:
+        raise S4PError(rc, "s4p_shard_replay failed")
+    k = min(nc.value, cap)
+    return [(ct[i], cc[i]) for i in range(k)], bool(term.value), int(td.value)

@@ -93,7 +93,8 @@ struct s4p_ctx {
   uint32_t q_head = 0, q_tail = 0;   // async FIFO of s4p_try_base_async (depth 2)
   BaseFrame slot_bf[4];
   hipEvent_t done[4] = {nullptr, nullptr, nullptr, nullptr};
-  DevBuf<float> tbuf; size_t tbuf_cap = 0;
+  DevBuf<float> tbuf; size_t tbuf_cap = 0;      // s4p_transform_points: two device + two pinned staging chunks
+  PinBuf<float> tpin; hipEvent_t tev[2] = {nullptr, nullptr};
 
   // profiling
   bool prof_events = false, prof_points = false;
@@ -102,7 +103,10 @@ struct s4p_ctx {
   uint64_t last_K = 0;
   uint32_t verify_blocks = 512;
   int ablate = 0;                    // S4P_ABLATE (profiling aid, read once at creation)
-  bool fused = true;                 // S4P_FUSED=0: per-pair preparation and the rms gate as separate launches (A/B aid)
+  // A/B aids: S4P_FUSE_PREP=1 prepares every pair inside k_pairs instead of a k_prep launch (measured
+  // slower: the ~3000-instruction cone mask of a set-2 pair lands on whichever wave found the pair); S4P_FUSE_GATE=0 runs
+  // the rigid transform + rms gate as a k_gate launch instead of inside k_quads' flush (measured slower)
+  bool fuse_prep = false, fuse_gate = true;
   double host_octree_s = 0, host_wait_s = 0;
 
   size_t verify_lds_bytes() const { return gcoarse.n * 4 + size_t(kVerifyThreads / 64) * kQueueWordsPerWave * 4; }
@@ -400,7 +404,8 @@ int32_t s4p_create(const s4p_options* opt, const s4p_limits* lim, int32_t device
     if (c->ablate) fprintf(stderr, "super4pcs_amd: S4P_ABLATE=%d is set: k_verify skips work, every result of this context is invalid\n", c->ablate);
   }
   if (const char* vb = getenv("S4P_VERIFY_BLOCKS")) { const int v = atoi(vb); if (v >= 64 && v <= kVerifyMaxBlocks) c->verify_blocks = uint32_t(v); }   // tuning knob
-  if (const char* fu = getenv("S4P_FUSED")) c->fused = atoi(fu) != 0;
+  if (const char* fu = getenv("S4P_FUSE_PREP")) c->fuse_prep = atoi(fu) != 0;
+  if (const char* fu = getenv("S4P_FUSE_GATE")) c->fuse_gate = atoi(fu) != 0;
   snprintf(c->devname, sizeof c->devname, "%s (%s)", prop.name, prop.gcnArchName);
   c->max_pairs = (lim && lim->max_pairs) ? lim->max_pairs : (4ull << 20);
   c->max_quads = (lim && lim->max_quads) ? lim->max_quads : (16ull << 20);
@@ -459,7 +464,8 @@ void s4p_destroy(s4p_ctx* c) {
   }
   for (auto& h : c->hctr) h.free();
   for (auto& st : c->stage) for (int s = 0; s < 2; ++s) st.seq[s].free();
-  c->tbuf.free();
+  c->tbuf.free(); c->tpin.free();
+  for (auto& e : c->tev) if (e) (void)hipEventDestroy(e);
   for (auto& row : c->ev) for (auto& ev : row) if (ev) (void)hipEventDestroy(ev);
   for (auto& ev : c->done) if (ev) (void)hipEventDestroy(ev);
   for (auto& L : c->lane) if (L.stream) (void)hipStreamDestroy(L.stream);
@@ -777,7 +783,7 @@ int32_t s4p_try_base_staged_async(s4p_ctx* c, int32_t slot, const int32_t* base_
   HIPCHK(c, hipSetDevice(c->device));
   c->cur = int(c->q_tail % uint32_t(c->n_lanes));
   s4p_ctx::Lane& L = c->lane[c->cur];
-  // The device pass of one base: 2 uploads and 3 launches (k_pairs: both pair sets + their preparation; k_quads:
+  // The device pass of one base: 2 uploads and 4 launches (k_pairs: both pair sets; k_prep: their preparation; k_quads:
   // enumeration + rigid transform + rms gate; k_verify: LCP of every candidate + winner + result record + counters
   // cleared for the lane's next base), then the read-back of the result record.
   if (L.dirty) { if (int32_t rc = reset_counters(c)) return rc; }
@@ -790,13 +796,13 @@ int32_t s4p_try_base_staged_async(s4p_ctx* c, int32_t slot, const int32_t* base_
     if (int32_t rc = upload_pairs_staged(c, slot, 0, eps, 0, 1, PP.set[0].pair)) return rc;
     if (int32_t rc = upload_pairs_staged(c, slot, 1, eps, 2, 3, PP.set[1].pair)) return rc;
     PP.set[0].prep = P1; PP.set[1].prep = P2;
-    PP.set[0].pair.do_prep = PP.set[1].pair.do_prep = c->fused ? 1 : 0;
+    PP.set[0].pair.do_prep = PP.set[1].pair.do_prep = c->fuse_prep ? 1 : 0;
     if (int32_t rc = launch_pairs_kernel(c, PP, 2)) return rc; }
   if (c->prof_events) HIPCHK(c, hipEventRecord(c->ev[c->cur][3], L.stream));
-  if (!c->fused) launch_prep_kernel(c, P1, P2);
-  if (c->fused) { Q.do_gate = 1; Q.gate = gate_params(c, bf); }
+  if (!c->fuse_prep) launch_prep_kernel(c, P1, P2);
+  if (c->fuse_gate) { Q.do_gate = 1; Q.gate = gate_params(c, bf); }
   launch_quads_kernel(c, Q);
-  if (!c->fused) launch_gate_kernel(c, gate_params(c, bf));
+  if (!c->fuse_gate) launch_gate_kernel(c, gate_params(c, bf));
   HIPCHK(c, hipGetLastError());
   if (c->prof_events) HIPCHK(c, hipEventRecord(c->ev[c->cur][4], L.stream));
   if (int32_t rc = launch_verify(c, bf)) return rc;
@@ -901,25 +907,121 @@ int32_t s4p_last_verified(s4p_ctx* c, uint32_t* counts, float* transforms16, int
   return S4P_OK;
 }
 
+namespace {
+void launch_apply(s4p_ctx* c, const float* M, float* dx, float* dy, float* dz, uint64_t n, int variant, hipStream_t st) {
+  ApplyParams A{};
+  for (int i = 0; i < 12; ++i) A.M[i] = M[i];
+  A.x = dx; A.y = dy; A.z = dz; A.n = n;
+  // 16 B per lane would need AoS; SoA with 4 B per lane coalesces to full 256 B wave requests, 8192 workgroups keep
+  // every CU's queue full for the grid-stride loop
+  const uint32_t blocks = uint32_t(std::min<uint64_t>((n + 255) / 256, 8192));
+  if (variant == 1) hipLaunchKernelGGL(k_apply_mfma, dim3(blocks), dim3(256), 0, st, A);
+  else hipLaunchKernelGGL(k_apply, dim3(blocks), dim3(256), 0, st, A);
+}
+}  // namespace
+
+// Device-resident form: x, y, z are DEVICE pointers (SoA), transformed in place on the context's stream 0; returns after
+// the kernel has completed.  For callers that keep the full-resolution cloud in HBM.
+int32_t s4p_transform_points_device(s4p_ctx* c, const float* M, float* dx, float* dy, float* dz, int64_t n) {
+  if (!c || !M || (n > 0 && (!dx || !dy || !dz))) return S4P_ERR_BAD_ARG;
+  if (n <= 0) return S4P_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  launch_apply(c, M, dx, dy, dz, uint64_t(n), 0, c->lane[0].stream);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(c->lane[0].stream));
+  return S4P_OK;
+}
+
+// Host-pointer form (Match4PCSBase::Perform_N_steps tail): the cloud is streamed through two pinned staging buffers in
+// chunks, so that the host->pinned copy of chunk k+1, the PCIe transfers and k_apply of chunk k and the pinned->host
+// copy of chunk k-1 overlap (a single pageable hipMemcpy per array serialises all of them).
 int32_t s4p_transform_points(s4p_ctx* c, const float* M, float* x, float* y, float* z, int64_t n) {
   if (!c || !M || (n > 0 && (!x || !y || !z))) return S4P_ERR_BAD_ARG;
   if (n <= 0) return S4P_OK;
   HIPCHK(c, hipSetDevice(c->device));
-  if (c->tbuf_cap < size_t(n) * 3) { HIPCHK(c, c->tbuf.alloc(size_t(n) * 3)); c->tbuf_cap = size_t(n) * 3; }
-  float* dx = c->tbuf.p; float* dy = dx + n; float* dz = dy + n;
-  HIPCHK(c, hipMemcpyAsync(dx, x, size_t(n) * 4, hipMemcpyHostToDevice, c->lane[c->cur].stream));
-  HIPCHK(c, hipMemcpyAsync(dy, y, size_t(n) * 4, hipMemcpyHostToDevice, c->lane[c->cur].stream));
-  HIPCHK(c, hipMemcpyAsync(dz, z, size_t(n) * 4, hipMemcpyHostToDevice, c->lane[c->cur].stream));
-  ApplyParams A{};
-  for (int i = 0; i < 12; ++i) A.M[i] = M[i];
-  A.x = dx; A.y = dy; A.z = dz; A.n = uint64_t(n);
-  const uint32_t blocks = uint32_t(std::min<uint64_t>((uint64_t(n) + 255) / 256, 4096));
-  hipLaunchKernelGGL(k_apply, dim3(blocks), dim3(256), 0, c->lane[c->cur].stream, A);
-  HIPCHK(c, hipGetLastError());
-  HIPCHK(c, hipMemcpyAsync(x, dx, size_t(n) * 4, hipMemcpyDeviceToHost, c->lane[c->cur].stream));
-  HIPCHK(c, hipMemcpyAsync(y, dy, size_t(n) * 4, hipMemcpyDeviceToHost, c->lane[c->cur].stream));
-  HIPCHK(c, hipMemcpyAsync(z, dz, size_t(n) * 4, hipMemcpyDeviceToHost, c->lane[c->cur].stream));
-  HIPCHK(c, hipStreamSynchronize(c->lane[c->cur].stream));
+  constexpr size_t kChunk = size_t(1) << 20;                        // points per chunk: 12 MB per staging buffer
+  const size_t chunk = std::min<size_t>(kChunk, size_t(n));
+  if (c->tbuf_cap < 2 * 3 * chunk) { HIPCHK(c, c->tbuf.alloc(2 * 3 * chunk)); c->tbuf_cap = 2 * 3 * chunk; }
+  if (c->tpin.n < 2 * 3 * chunk) HIPCHK(c, c->tpin.alloc(2 * 3 * chunk));
+  if (!c->tev[0]) for (auto& e : c->tev) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  hipStream_t st = c->lane[0].stream;
+  const size_t nchunks = (size_t(n) + chunk - 1) / chunk;
+  auto drain = [&](size_t k) -> hipError_t {                         // pinned -> caller, once chunk k's D2H has landed
+    const int b = int(k & 1);
+    hipError_t e = hipEventSynchronize(c->tev[b]);
+    if (e != hipSuccess) return e;
+    const size_t off = k * chunk, m = std::min(chunk, size_t(n) - off);
+    const float* p = c->tpin.p + size_t(b) * 3 * chunk;
+    std::memcpy(x + off, p, m * 4); std::memcpy(y + off, p + chunk, m * 4); std::memcpy(z + off, p + 2 * chunk, m * 4);
+    return hipSuccess;
+  };
+  for (size_t k = 0; k < nchunks; ++k) {
+    const int b = int(k & 1);
+    if (k >= 2) HIPCHK(c, drain(k - 2));                             // frees staging buffer b
+    const size_t off = k * chunk, m = std::min(chunk, size_t(n) - off);
+    float* p = c->tpin.p + size_t(b) * 3 * chunk;
+    float* d = c->tbuf.p + size_t(b) * 3 * chunk;
+    std::memcpy(p, x + off, m * 4); std::memcpy(p + chunk, y + off, m * 4); std::memcpy(p + 2 * chunk, z + off, m * 4);
+    HIPCHK(c, hipMemcpyAsync(d, p, 3 * chunk * 4, hipMemcpyHostToDevice, st));
+    launch_apply(c, M, d, d + chunk, d + 2 * chunk, uint64_t(m), 0, st);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(p, d, 3 * chunk * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipEventRecord(c->tev[b], st));
+  }
+  if (nchunks >= 2) HIPCHK(c, drain(nchunks - 2));
+  HIPCHK(c, drain(nchunks - 1));
+  return S4P_OK;
+}
+
+// Measurement aid (bench.py): k_apply on n device-resident synthetic points, `reps` timed launches
+// per variant (0 = VALU, the product path; 1 = v_mfma_f32_4x4x1 chain).  out_ms[variant] = mean HIP-event time per
+// launch; *mismatch = coordinates where the MFMA result is not bit-identical to the VALU result; *max_abs = their
+// largest absolute difference.
+int32_t s4p_apply_bench(s4p_ctx* c, int64_t n, int32_t reps, double* out_ms, uint64_t* mismatch, float* max_abs) {
+  if (!c || n <= 0 || reps <= 0 || !out_ms || !mismatch || !max_abs) return S4P_ERR_BAD_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t un = size_t(n);
+  std::vector<float> h(3 * un);
+  uint32_t sd = 12345u;
+  for (auto& v : h) { sd = sd * 1664525u + 1013904223u; v = (float(sd >> 8) / 16777216.f - 0.5f) * 4.f; }
+  const float M[12] = {0.36f, 0.48f, -0.8f, 0.125f, -0.8f, 0.6f, 0.f, -0.75f, 0.48f, 0.64f, 0.6f, 0.3125f};   // a rotation | t
+  DevBuf<float> src, a, b;
+  hipError_t e = hipSuccess;
+  auto ok = [&](hipError_t r) { if (e == hipSuccess) e = r; return e == hipSuccess; };
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  hipStream_t st = c->lane[0].stream;
+  std::vector<float> ra, rb;
+  do {
+    if (!ok(src.alloc(3 * un)) || !ok(a.alloc(3 * un)) || !ok(b.alloc(3 * un))) break;
+    if (!ok(hipEventCreate(&e0)) || !ok(hipEventCreate(&e1))) break;
+    if (!ok(hipMemcpy(src.p, h.data(), 3 * un * 4, hipMemcpyHostToDevice))) break;
+    for (int variant = 0; variant < 2 && e == hipSuccess; ++variant) {
+      float* d = variant == 0 ? a.p : b.p;
+      ok(hipMemcpyAsync(d, src.p, 3 * un * 4, hipMemcpyDeviceToDevice, st));
+      launch_apply(c, M, d, d + un, d + 2 * un, uint64_t(n), variant, st);                 // result kept for the comparison (and warm-up)
+      DevBuf<float> scratch;
+      if (!ok(scratch.alloc(3 * un))) break;
+      ok(hipMemcpyAsync(scratch.p, src.p, 3 * un * 4, hipMemcpyDeviceToDevice, st));
+      ok(hipEventRecord(e0, st));
+      for (int r = 0; r < reps; ++r) launch_apply(c, M, scratch.p, scratch.p + un, scratch.p + 2 * un, uint64_t(n), variant, st);
+      ok(hipEventRecord(e1, st));
+      ok(hipStreamSynchronize(st));
+      float ms = 0.f;
+      if (e == hipSuccess) ok(hipEventElapsedTime(&ms, e0, e1));
+      out_ms[variant] = double(ms) / reps;
+      scratch.free();
+    }
+    if (e != hipSuccess) break;
+    ra.resize(3 * un); rb.resize(3 * un);
+    if (!ok(hipMemcpy(ra.data(), a.p, 3 * un * 4, hipMemcpyDeviceToHost)) || !ok(hipMemcpy(rb.data(), b.p, 3 * un * 4, hipMemcpyDeviceToHost))) break;
+    uint64_t mm = 0; float mx = 0.f;
+    for (size_t i = 0; i < 3 * un; ++i) if (std::memcmp(&ra[i], &rb[i], 4) != 0) { ++mm; mx = std::max(mx, std::fabs(ra[i] - rb[i])); }
+    *mismatch = mm; *max_abs = mx;
+  } while (0);
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  src.free(); a.free(); b.free();
+  HIPCHK(c, e);
   return S4P_OK;
 }
 

@@ -594,6 +594,7 @@ void s4p_matcher_destroy(s4p_matcher* m) {
 
 const char* s4p_matcher_last_error(const s4p_matcher* m) { return m ? m->err.c_str() : s4p_last_error(nullptr); }
 s4p_ctx* s4p_matcher_ctx(s4p_matcher* m) { return m ? m->ctx : nullptr; }
+float s4p_matcher_terminate_threshold(const s4p_matcher* m) { return m ? m->opt.terminate_threshold : 0.f; }
 
 int64_t s4p_uniform_dist_sample(const float* x, const float* y, const float* z, int64_t n, float delta, int64_t* out) {
   if (!x || !y || !z || !out || n <= 0 || !(delta > 0.f)) return 0;
@@ -716,6 +717,22 @@ int32_t s4p_matcher_get_sampled(s4p_matcher* m, int32_t which, float* x, float* 
   if (!m || !x || !y || !z) return S4P_ERR_BAD_ARG;
   const Cloud& c = which == 0 ? m->Ps : m->Qs;
   std::memcpy(x, c.x.data(), c.size() * 4); std::memcpy(y, c.y.data(), c.size() * 4); std::memcpy(z, c.z.data(), c.size() * 4);
+  return S4P_OK;
+}
+
+int32_t s4p_matcher_get_sampled_attrs(s4p_matcher* m, int32_t which, float* nx, float* ny, float* nz, float* r, float* g, float* b,
+                                      int32_t* has_normals, int32_t* has_rgb) {
+  if (!m) return S4P_ERR_BAD_ARG;
+  const Cloud& c = which == 0 ? m->Ps : m->Qs;
+  const size_t n = c.size();
+  auto put = [n](float* dst, const std::vector<float>& src, bool have, float dflt) {
+    if (!dst) return;
+    if (have) std::memcpy(dst, src.data(), n * 4); else for (size_t i = 0; i < n; ++i) dst[i] = dflt;
+  };
+  put(nx, c.nx, c.has_n, 0.f); put(ny, c.ny, c.has_n, 0.f); put(nz, c.nz, c.has_n, 0.f);
+  put(r, c.r, c.has_c, -1.f); put(g, c.g, c.has_c, -1.f); put(b, c.b, c.has_c, -1.f);
+  if (has_normals) *has_normals = c.has_n ? 1 : 0;
+  if (has_rgb) *has_rgb = c.has_c ? 1 : 0;
   return S4P_OK;
 }
 

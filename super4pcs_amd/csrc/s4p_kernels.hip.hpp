@@ -87,10 +87,15 @@ struct LcpGrid {
   float sq_eps;                 // fl(delta*delta)
 };
 
-constexpr int kQueueAEntries = 192;                // per-wave queue A (query index, 4 B): 63 left over + two 64-query chunks
-constexpr int kQueueBEntries = 128;                // per-wave queue B ({query, rank}, 8 B): 63 left over + one batch of 64
-constexpr int kQueueWordsPerWave = kQueueAEntries + 2 * kQueueBEntries;       // in 32-bit words (1.75 KB)
-constexpr int kCoarseMaxWords = 12288;             // 48 KB: with 28 KB of queues, two 1024-thread workgroups fit one CU's 160 KB
+// The sweep takes four 64-query chunks per step (S4P_SWEEP_PIPE = 0, the measured best) or two, software-pipelined three
+// deep (S4P_SWEEP_PIPE = 1: next step's query loads and this step's reach gathers in flight while the previous step is
+// consumed -- measured no faster: the kernel is not waiting on the sweep's loads).
+#ifndef S4P_SWEEP_PIPE
+#define S4P_SWEEP_PIPE 0
+#endif
+constexpr int kQueueEntries = S4P_SWEEP_PIPE ? 192 : 320;     // per-wave survivor queue ({query, rank}, 8 B): 63 left over + one step
+constexpr int kQueueWordsPerWave = 2 * kQueueEntries + 64;    // in 32-bit words: the queue + the 256 B item-owner table (S4P_FINE_FLAT = 2)
+constexpr int kCoarseMaxWords = S4P_SWEEP_PIPE ? 12288 : 8704;   // 48 / 34 KB: + 16 x 1.75 / 2.75 KB of queues, two workgroups per CU (160 KB)
 
 // value held by every lane of the wave -> SGPR
 __device__ __forceinline__ float wave_uniform(float v) {
@@ -287,18 +292,28 @@ __global__ __launch_bounds__(256) void k_build_masks(MaskParams P) {
 }
 
 // Exact stage for one batch of up to 64 queued queries (lane = query; `valid` lanes hold an entry {query i, rank of its
-// reachable cell}): L2 (list header + 4x4x4 sub-cell mask), then the exact inlier predicate against the listed points.
-// The per-query lists differ a lot in length, so a lane-per-query loop runs as long as the longest list of the batch
-// with most lanes idle -- and every step is a 64-lane gather whether one lane or all of them still need it (that loop
-// was ~100 of the 165 wavefront gathers per candidate of the round-1 kernel).  Here the (query, point) pairs of the
-// whole batch are flattened: an inclusive prefix over the list lengths gives every pair a global index, round r tests
-// pairs [64 r, 64 r + 64) with all lanes busy -- pair-lane j finds its owner query by a binary search over the prefix
-// (cross-lane reads), fetches the owner's transformed point the same way, loads ONE point and tests it.
-// Gathers per batch: ceil(sum of lengths / 64) instead of 2 * ceil(max length / 2).
-// Predicate and point data are unchanged (kdtree.h:417-421), so counts stay bit-identical.
+// reachable cell}): L2 (list header + 4x4x4 sub-cell mask), then the exact inlier predicate against the listed points
+// (kdtree.h:417-421: sqdist <= cl_dist).  The exact 3x4 is re-read from the candidate's record (three broadcast loads)
+// instead of being kept in scalar registers across the query sweep.
+// Two formulations of the point loop, selected at build time (measured against each other):
+//   S4P_FINE_FLAT = 0  lane-per-query: every lane walks its own list, two 16-byte loads per dependent step; the batch
+//                      takes as long as its longest list, ~20 instructions per step;
+//   S4P_FINE_FLAT = 1  the (query, point) pairs of the batch are flattened -- inclusive prefix over the list lengths, pair
+//                      lane j finds its owner by a binary search over the prefix with cross-lane reads -- so every
+//                      64-lane gather tests 64 real pairs: a quarter of the gathers, ~90 instructions per round, but six
+//                      dependent LDS round trips per round;
+//   S4P_FINE_FLAT = 2  work items of FOUR consecutive list points: every query writes its lane id once per item into a
+//                      byte table in LDS (s_own), item lane j reads its owner there, fetches the owner's transformed
+//                      point and list range by cross-lane reads and tests four points loaded back to back.  A batch
+//                      takes ~2 rounds with ONE memory wait each instead of ~13 dependent steps: the point loop was
+//                      ~40 of the ~60 dependent memory waits of a candidate, and waves sat in s_waitcnt 60 % of the time.
+#ifndef S4P_FINE_FLAT
+#define S4P_FINE_FLAT 0
+#endif
+constexpr int kOwnItems = 192;                     // per-wave item-owner table (S4P_FINE_FLAT = 2): 192 B + 64 B of hit flags
 template <bool COUNT>
 __device__ __forceinline__ bool fine_batch(const LcpGrid& g, const float4* q4, const float4* Tsrc, bool valid,
-                                           uint32_t i, uint32_t rank, unsigned long long* point_tests) {
+                                           uint32_t i, uint32_t rank, unsigned long long* point_tests, uint8_t* s_own) {
   const uint32_t lane = threadIdx.x & 63u;
   float tx = 0.f, ty = 0.f, tz = 0.f;
   uint32_t s = 0, len = 0;
@@ -309,7 +324,7 @@ __device__ __forceinline__ bool fine_batch(const LcpGrid& g, const float4* q4, c
     load_rows(Tsrc, T);
     transform_point(T, q, tx, ty, tz);                          // exact (reference order, no fma)
     int ix, iy, iz;
-    grid_cell(make_grid_xf(g, T, 1.f).u, q, ix, iy, iz);        // the cell stage 2 put this query in
+    grid_cell(make_grid_xf(g, T, 1.f).u, q, ix, iy, iz);        // the cell the sweep put this query in
     // sub-cell of the exact point inside THAT cell, clamped (the exact point can sit ~1e-5 cell outside it)
     const float rx = (tx - g.ox) * g.inv_h - float(ix), ry = (ty - g.oy) * g.inv_h - float(iy), rz = (tz - g.oz) * g.inv_h - float(iz);
     const uint32_t sx = uint32_t(min(max(int(rx * 4.f), 0), 3)), sy = uint32_t(min(max(int(ry * 4.f), 0), 3)),
@@ -325,6 +340,55 @@ __device__ __forceinline__ bool fine_batch(const LcpGrid& g, const float4* q4, c
     for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
     if (lane == 0) { atomicAdd(point_tests + 3, (unsigned long long)__popcll(l2)); atomicAdd(point_tests, (unsigned long long)tot); }
   }
+#if S4P_FINE_FLAT == 2
+  const uint32_t cnt4 = (len + 3u) >> 2;           // this query's items
+  uint32_t incl = cnt4;                            // inclusive prefix of the item counts over the wave
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t up = uint32_t(__shfl_up(int(incl), o));
+    if (lane >= uint32_t(o)) incl += up;
+  }
+  const uint32_t excl = incl - cnt4;
+  const uint32_t total = uint32_t(__builtin_amdgcn_readlane(int(incl), 63));
+  uint8_t* s_hit = s_own + kOwnItems;              // one flag per query of the batch
+  s_hit[lane] = 0;
+  for (uint32_t wbase = 0; wbase < total; wbase += uint32_t(kOwnItems)) {       // (one window unless the lists are very long)
+    for (uint32_t k = 0; __ballot(k < cnt4) != 0ull; ++k) {
+      const uint32_t pos = excl + k - wbase;       // (wraps for items before the window)
+      if (k < cnt4 && pos < uint32_t(kOwnItems)) s_own[pos] = uint8_t(lane);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t wend = min(total - wbase, uint32_t(kOwnItems));
+    for (uint32_t base = 0; base < wend; base += 64u) {
+      const uint32_t j = base + lane;              // item within the window
+      const bool live = j < wend;
+      const uint32_t owner = live ? uint32_t(s_own[j]) : 0u;
+      // the owner's list range and transformed point by cross-lane reads: issued by ALL lanes (a ds_bpermute only
+      // delivers data of lanes that are active when it executes, and the owner of a live item may be any lane)
+      const uint32_t o_excl = uint32_t(__shfl(int(excl), int(owner)));
+      const uint32_t o_len = uint32_t(__shfl(int(len), int(owner)));
+      const uint32_t o_s = uint32_t(__shfl(int(s), int(owner)));
+      const float ox = __shfl(tx, int(owner)), oy = __shfl(ty, int(owner)), oz = __shfl(tz, int(owner));
+      if (live) {
+        const uint32_t first = o_s + 4u * (wbase + j - o_excl), lastp = o_s + o_len - 1u;
+        const float4 pa = g.nbr[first];
+        const float4 pb = g.nbr[min(first + 1u, lastp)];
+        const float4 pc = g.nbr[min(first + 2u, lastp)];
+        const float4 pd = g.nbr[min(first + 3u, lastp)];
+        const bool ha = sqn3(ox - pa.x, oy - pa.y, oz - pa.z) <= g.sq_eps, hb = sqn3(ox - pb.x, oy - pb.y, oz - pb.z) <= g.sq_eps;
+        const bool hc = sqn3(ox - pc.x, oy - pc.y, oz - pc.z) <= g.sq_eps, hd = sqn3(ox - pd.x, oy - pd.y, oz - pd.z) <= g.sq_eps;
+        if (ha || hb || hc || hd) s_hit[owner] = 1;   // (several items of one query may write the same 1)
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  const bool hit = s_hit[lane] != 0;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  return hit;
+#elif S4P_FINE_FLAT == 1
   // inclusive prefix of the list lengths over the wave
   uint32_t incl = len;
 #pragma unroll
@@ -337,7 +401,7 @@ __device__ __forceinline__ bool fine_batch(const LcpGrid& g, const float4* q4, c
   for (uint32_t base = 0; base < total; base += 64u) {
     const uint32_t j = base + lane;                // this lane's (query, point) pair
     // owner = number of lanes whose inclusive prefix is <= j (the prefix is non-decreasing): lower-bound search
-    uint32_t lo = 0u, hi = 63u;     // j < total, so the owner is one of the 64 lanes
+    uint32_t lo = 0u, hi = 63u;                    // j < total, so the owner is one of the 64 lanes
 #pragma unroll
     for (int it = 0; it < 6; ++it) {               // 64 -> 1 in six halvings
       const uint32_t mid = (lo + hi) >> 1;
@@ -352,7 +416,7 @@ __device__ __forceinline__ bool fine_batch(const LcpGrid& g, const float4* q4, c
     bool h = false;
     if (j < total) {
       const float4 p = g.nbr[o_s + (j - (o_incl - o_len))];
-      h = sqn3(ox - p.x, oy - p.y, oz - p.z) <= g.sq_eps;               // kdtree.h:417-421  sqdist <= cl_dist
+      h = sqn3(ox - p.x, oy - p.y, oz - p.z) <= g.sq_eps;
     }
     unsigned long long hb = __ballot(h);
     while (hb) {                                   // scalar loop over the (few) hits of this round
@@ -362,104 +426,138 @@ __device__ __forceinline__ bool fine_batch(const LcpGrid& g, const float4* q4, c
     }
   }
   return ((hitmask >> lane) & 1ull) != 0ull;
+#else
+  const uint32_t e = s + len;
+  for (uint32_t p = s; p < e; p += 2) {                       // two independent 16 B loads per dependent step (four: slower)
+    const float4 pa = g.nbr[p];
+    const float4 pb = g.nbr[min(p + 1u, e - 1u)];            // (predicating this load away on odd tails was measured slower)
+    const bool ha = sqn3(tx - pa.x, ty - pa.y, tz - pa.z) <= g.sq_eps;
+    const bool hb = sqn3(tx - pb.x, ty - pb.y, tz - pb.z) <= g.sq_eps;
+    if (ha | hb) return true;
+  }
+  return false;
+#endif
 }
 
 // Number of sampled-Q points that T brings within delta of a sampled-P point: Verify()
 // (match4pcsBase.cc:508-567) without the early exit, for one wave64.
 //   s_coarse : LDS copy of the coarse bitmap (workgroup-shared)
-//   s_queue  : this wave's private LDS: queue A (query indices that passed L0) and queue B ({query, rank}: passed L1)
-// Stage 1 (every query, two 64-query chunks per step): position in COARSE-cube units (9 fma + 3 floor-converts), L0
-//   test against the LDS bitmap; the ~15 % that survive are compacted (ballot/prefix) into queue A.  About 36
-//   instructions per 64 queries -- the kernel is instruction-issue bound (SQ busy ~99 % in the round-1 profile), so
-//   this loop is kept to the bone: no fine cell, no global gather besides the coalesced 16-byte query load.
-// Stage 2 (whenever 64 entries wait in A, i.e. on dense lanes): query re-read, fine cell, ONE 8-byte gather of the
-//   reach word (L1), rank of the cell among the reachable ones; survivors (~70 %) are compacted into queue B.
-// Stage 3 (whenever 64 entries wait in B): fine_batch -- header, sub-cell mask, exact tests.
-// Compared with the round-1 kernel (fine cell + L1 gather issued for all 64 lanes of every chunk, 85 % of them idle):
-// 5 + 5 instead of 32 reach-word gathers per candidate at n_Q = 2000 and about half the instructions.
+//   s_queue  : this wave's private LDS queue ({query index, reachable-cell rank}, kQueueEntries entries)
+// Sweep (every query, four 64-query chunks per step):
+//   position in grid units (9 fma + 3 floor-converts: GridXf), L0 test of the cell's coarse cube against the LDS
+//   bitmap, then the L1 reach word (8 B gather; rejected lanes read word 0, one broadcast line); queries whose cell is
+//   reachable are compacted by ballot/prefix into the queue together with the cell's rank among the reachable ones.
+// Exact stage (fine_batch) whenever 64 entries wait, and once more for the rest.
+// The kernel is instruction-issue bound (SQ busy ~99 % in the round-1 profile), so the sweep is kept to the bone: the
+// round-1 version spent ~75 instructions per 64 queries here (exact transform, subtract origin, scale, floor, convert,
+// two index computations with a run-time 24-bit select), this one ~50.
 template <bool COUNT, bool SKIP_FINE = false>
 __device__ __forceinline__ uint32_t wave_lcp_count(const LcpGrid& g, const uint32_t* s_coarse, uint2* s_queue,
                                                    const float4* q4, uint32_t n_q, const float4* Tsrc,
                                                    unsigned long long* point_tests) {
   constexpr uint32_t kNone = 0xFFFFFFFFu;
   const uint32_t lane = threadIdx.x & 63u;
-  uint32_t* qa = reinterpret_cast<uint32_t*>(s_queue);
-  uint2* qb = s_queue + kQueueAEntries / 2;
-  uint32_t cnt = 0, na = 0, nb = 0;
+  uint32_t cnt = 0, qn = 0;
   const uint32_t cmax = g.coarse_words * 32u - 1u;
   const uint32_t unx = uint32_t(g.nx), uny = uint32_t(g.ny), unz = uint32_t(g.nz);
-  const uint32_t ucx = uint32_t(g.cnx), ucy = uint32_t(g.cny), ucz = ((unz - 1u) >> g.cshift) + 1u;
-  GridXf XC;                                             // coarse-cube units: the only transform live across the loop
-  { float T[12]; load_rows(Tsrc, T); XC = make_grid_xf(g, T, coarse_scale(g)); }
-  // L0: does query i fall into a coarse cube some P point can reach?  (float -> int conversion saturates and one
-  // unsigned compare per axis covers both bounds; a NaN coordinate maps to cube 0 and later fails every exact test)
-  auto coarse_hit = [&](const float4 q, const uint32_t i) -> bool {
+  const uint32_t ucx = uint32_t(g.cnx), ucy = uint32_t(g.cny);
+  GridXf X;                                              // fine-cell units: the only transform live across the sweep
+  { float T[12]; load_rows(Tsrc, T); X = make_grid_xf(g, T, 1.f); }
+  // cell of query i under T, or kNone if it falls outside the grid or into a coarse cube nothing can reach
+  // (float -> int conversion saturates and one unsigned compare per axis covers both bounds; a NaN coordinate maps to
+  // cell 0 and then fails every exact distance test, so it cannot create an inlier)
+  auto locate = [&](const float4 q, const uint32_t i) -> uint32_t {
     int ix, iy, iz;
-    grid_cell(XC.u, q, ix, iy, iz);
-    const bool inb = (uint32_t(ix) < ucx) & (uint32_t(iy) < ucy) & (uint32_t(iz) < ucz) & (i < n_q);
-    const uint32_t cc = min(mad24(mad24(uint32_t(iz), ucy, uint32_t(iy)), ucx, uint32_t(ix)), cmax);
-    return inb & (((s_coarse[cc >> 5] >> (cc & 31u)) & 1u) != 0u);
+    grid_cell(X.u, q, ix, iy, iz);
+    const bool inb = (uint32_t(ix) < unx) & (uint32_t(iy) < uny) & (uint32_t(iz) < unz) & (i < n_q);
+    const uint32_t cc = min(mad24(mad24(uint32_t(iz) >> g.cshift, ucy, uint32_t(iy) >> g.cshift), ucx, uint32_t(ix) >> g.cshift), cmax);
+    const uint32_t bit = (s_coarse[cc >> 5] >> (cc & 31u)) & 1u;
+    // 24-bit multiplies are full rate (a 32-bit v_mul_lo is not); LcpGridHost::plan keeps nx and ny*nz below 2^24
+    const uint32_t c = mad24(mad24(uint32_t(iz), uny, uint32_t(iy)), unx, uint32_t(ix));
+    return (inb & (bit != 0u)) ? c : kNone;
   };
   auto lds_fence = [&]() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); };
-  auto rank_below = [&](const unsigned long long m) -> uint32_t {       // set bits of m below this lane
-    return __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u));
-  };
-  // stage 3 on the top n (<= 64) entries of queue B
-  auto drain_b = [&](const uint32_t n) {
-    const bool valid = lane < n;
-    const uint2 e = qb[nb - n + min(lane, n - 1u)];
-    if (SKIP_FINE) cnt += uint32_t(valid && e.y == kNone);
-    else cnt += fine_batch<COUNT>(g, q4, Tsrc, valid, e.x, e.y, point_tests) ? 1u : 0u;
-    nb -= n;
-    lds_fence();
-  };
-  // stage 2 on the top n (<= 64) entries of queue A; needs nb < 64 on entry (queue B holds 128)
-  auto drain_a = [&](const uint32_t n) {
-    const bool valid = lane < n;
-    const uint32_t i = qa[na - n + min(lane, n - 1u)];
-    na -= n;
-    int ix, iy, iz;
-    { float T[12]; load_rows(Tsrc, T); grid_cell(make_grid_xf(g, T, 1.f).u, q4[i], ix, iy, iz); }
-    const bool inb = valid & (uint32_t(ix) < unx) & (uint32_t(iy) < uny) & (uint32_t(iz) < unz);
-    // 24-bit multiplies are full rate (a 32-bit v_mul_lo is not); LcpGridHost::plan keeps nx and ny*nz below 2^24
-    const uint32_t c = inb ? mad24(mad24(uint32_t(iz), uny, uint32_t(iy)), unx, uint32_t(ix)) : 0u;
-    const uint2 w = g.reach[c >> 5];
+  // L1 for one chunk + compaction
+  auto push = [&](const uint32_t c, const uint2 w, const uint32_t i) {
     const uint32_t sh = c & 31u;
-    const bool reach = inb & (((w.x >> sh) & 1u) != 0u);
+    const bool reach = (c != kNone) & (((w.x >> sh) & 1u) != 0u);
     const unsigned long long m = __ballot(reach);
-    if (COUNT && lane == 0) atomicAdd(point_tests + 2, (unsigned long long)__popcll(m));          // l1_pass
-    if (reach) qb[nb + rank_below(m)] = make_uint2(i, w.y + uint32_t(__popc(w.x & ((1u << sh) - 1u))));
-    nb += uint32_t(__popcll(m));
+    if (COUNT) {
+      const unsigned long long m0 = __ballot(c != kNone);
+      if (lane == 0) { atomicAdd(point_tests + 1, (unsigned long long)__popcll(m0)); atomicAdd(point_tests + 2, (unsigned long long)__popcll(m)); }
+    }
+    if (m == 0ull) return;
+    if (reach) s_queue[qn + __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u))] =
+        make_uint2(i, w.y + uint32_t(__popc(w.x & ((1u << sh) - 1u))));
+    qn += uint32_t(__popcll(m));
+  };
+  // exact stage on the top n (<= 64) entries of the queue: ONE code site (inlined at every push it was 16 KB of code)
+  auto drain = [&](const uint32_t n) {
+    const bool valid = lane < n;
+    const uint2 e = s_queue[qn - n + min(lane, n - 1u)];
+    if (SKIP_FINE) cnt += uint32_t(valid && e.y == kNone);
+    else cnt += fine_batch<COUNT>(g, q4, Tsrc, valid, e.x, e.y, point_tests, reinterpret_cast<uint8_t*>(s_queue + kQueueEntries)) ? 1u : 0u;
+    qn -= n;
     lds_fence();
   };
-  // stage 1 compaction of one chunk; queue A holds kQueueAEntries = 63 + 2 * 64 + 1
-  auto push = [&](const bool surv, const uint32_t i) {
-    const unsigned long long m = __ballot(surv);
-    if (m == 0ull) return;                               // Morton-ordered queries: whole chunks miss the surface
-    if (COUNT && lane == 0) atomicAdd(point_tests + 1, (unsigned long long)__popcll(m));          // l0_pass
-    if (surv) qa[na + rank_below(m)] = i;
-    na += uint32_t(__popcll(m));
-  };
+#if S4P_SWEEP_PIPE
+  // Software pipeline over steps of two chunks (128 queries): while step t is located and its reach words are requested,
+  // the query loads of step t+1 are already in flight and the reach words of step t-1 are consumed.  A wave thus never
+  // waits for a load it has just issued; in the round-1 kernel every step exposed two dependent round trips (query ->
+  // reach word), 16 of the ~40 memory waits of a candidate, and waves spent 60 % of their cycles in s_waitcnt.
   const uint32_t last = n_q - 1u;
-  for (uint32_t base = 0;; base += 128u) {
-    const bool more = base < n_q;                        // wave-uniform
+  const uint32_t steps = (n_q + 127u) >> 7;
+  float4 qa = q4[min(lane, last)], qb = q4[min(lane + 64u, last)];           // step 0
+  uint32_t pc0 = kNone, pc1 = kNone, pi = 0;                                  // step t-1: cells, first query index
+  uint2 pw0 = make_uint2(0u, 0u), pw1 = make_uint2(0u, 0u);
+  for (uint32_t t = 0;; ++t) {
+    const bool more = t < steps;                         // wave-uniform
+    uint32_t c0 = kNone, c1 = kNone;
+    uint2 w0 = make_uint2(0u, 0u), w1 = make_uint2(0u, 0u);
+    const uint32_t i0 = (t << 7) + lane;
     if (more) {
-      const uint32_t i0 = base + lane, i1 = i0 + 64u;
-      const float4 q0 = q4[min(i0, last)];
-      const float4 q1 = q4[min(i1, last)];
-      const bool h0 = coarse_hit(q0, i0), h1 = coarse_hit(q1, i1);
-      push(h0, i0); push(h1, i1);
+      const float4 q0 = qa, q1 = qb;
+      const uint32_t n0 = i0 + 128u;
+      qa = q4[min(n0, last)]; qb = q4[min(n0 + 64u, last)];                   // step t+1 (clamped re-reads past the end)
+      c0 = locate(q0, i0); c1 = locate(q1, i0 + 64u);
+      // reach words of the L0 survivors; rejected lanes read word 0 (one broadcast line)
+      w0 = g.reach[c0 == kNone ? 0u : c0 >> 5];
+      w1 = g.reach[c1 == kNone ? 0u : c1 >> 5];
+    }
+    if (t != 0u) {                                        // consume step t-1
+      push(pc0, pw0, pi); push(pc1, pw1, pi + 64u);
       lds_fence();
     }
-    // One code site per stage (the exact stage is ~1000 instructions: inlining it at every push cost 16 KB of code).
-    // Full batches of 64 are drained as they become available; partial ones only after the last chunk.
-    while (true) {
-      if (nb >= 64u || (!more && na == 0u && nb != 0u)) { drain_b(min(nb, 64u)); continue; }
-      if (na >= 64u || (!more && na != 0u)) { drain_a(min(na, 64u)); continue; }
-      break;
-    }
+    pc0 = c0; pc1 = c1; pw0 = w0; pw1 = w1; pi = i0;
+    // full batches as they become available (the queue holds 63 + 2 * 64 entries), the partial one after the last step
+    while (qn >= 64u || (!more && qn != 0u)) drain(min(qn, 64u));
     if (!more) break;
   }
+#else
+  // Four chunks per step: four query loads, then four reach-word gathers in flight.
+  const uint32_t last = n_q - 1u;
+  for (uint32_t base = 0;; base += 256u) {
+    const bool more = base < n_q;                        // wave-uniform
+    if (more) {
+      const uint32_t i0 = base + lane, i1 = i0 + 64u, i2 = i0 + 128u, i3 = i0 + 192u;
+      const float4 q0 = q4[min(i0, last)];
+      const float4 q1 = q4[min(i1, last)];
+      const float4 q2 = q4[min(i2, last)];
+      const float4 q3 = q4[min(i3, last)];
+      const uint32_t c0 = locate(q0, i0), c1 = locate(q1, i1), c2 = locate(q2, i2), c3 = locate(q3, i3);
+      // reach words of the L0 survivors; rejected lanes read word 0 (one broadcast line)
+      const uint2 w0 = g.reach[c0 == kNone ? 0u : c0 >> 5];
+      const uint2 w1 = g.reach[c1 == kNone ? 0u : c1 >> 5];
+      const uint2 w2 = g.reach[c2 == kNone ? 0u : c2 >> 5];
+      const uint2 w3 = g.reach[c3 == kNone ? 0u : c3 >> 5];
+      push(c0, w0, i0); push(c1, w1, i1); push(c2, w2, i2); push(c3, w3, i3);
+      lds_fence();
+    }
+    // full batches as they become available (the queue holds 63 + 4 * 64 entries), the partial one after the last chunk
+    while (qn >= 64u || (!more && qn != 0u)) drain(min(qn, 64u));
+    if (!more) break;
+  }
+#endif
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
   __builtin_amdgcn_wave_barrier();
@@ -1065,7 +1163,7 @@ __global__ __launch_bounds__(256) void k_quads(QuadParams P) {
 // the selection of the base's winner (match4pcsBase.hpp:467-484: the first candidate in reference order with the
 // strictly greatest LCP), its transform, and the result record the host reads.
 // Persistent 1024-thread workgroups, one wave64 per gated candidate; the length of the gated list lives in device
-// memory (no host round trip).  LDS per workgroup: coarse bitmap (<= 48 KB) + 16 x 1.75 KB private survivor queues.
+// memory (no host round trip).  LDS per workgroup: coarse bitmap (<= 34 KB) + 16 x 2.75 KB private survivor queues / item tables.
 // ---------------------------------------------------------------------------
 constexpr int kVerifyThreads = 1024;
 constexpr int kVerifyMaxBlocks = 4096;
@@ -1217,6 +1315,30 @@ __global__ __launch_bounds__(256) void k_apply(ApplyParams P) {
     P.x[i] = ((P.M[0] * x + P.M[1] * y) + P.M[2] * z) + P.M[3];
     P.y[i] = ((P.M[4] * x + P.M[5] * y) + P.M[6] * z) + P.M[7];
     P.z[i] = ((P.M[8] * x + P.M[9] * y) + P.M[10] * z) + P.M[11];
+  }
+}
+
+// The same contraction on the matrix cores, kept ONLY as the measured alternative:
+// v_mfma_f32_4x4x1_16b_f32 = 16 independent 4x4x1 outer products, so with lane l <-> point l (block l/4, column l%4) four
+// accumulating instructions (k = x, y, z, 1) leave rows 0..2 of [R|t] * [p;1] for point l in lane l's own registers.
+// Each step is a FUSED multiply-add, so the result differs from the reference's separately rounded
+// ((m0*x + m1*y) + m2*z) + m3 in the last bit of many coordinates -- which is why the product path does not use it.
+__global__ __launch_bounds__(256) void k_apply_mfma(ApplyParams P) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const uint32_t lane = threadIdx.x & 63u, row = lane & 3u;
+  // A operand of step k: lane (block, i) holds M[i][k]; row 3 is the homogeneous row (0 0 0 1), never stored
+  const float a0 = row < 3u ? P.M[4 * row + 0] : 0.f, a1 = row < 3u ? P.M[4 * row + 1] : 0.f,
+              a2 = row < 3u ? P.M[4 * row + 2] : 0.f, a3 = row < 3u ? P.M[4 * row + 3] : 1.f;
+  const uint64_t nround = (P.n + 63ull) & ~63ull;            // whole waves: the MFMA needs all 64 lanes
+  for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < nround; i += (uint64_t)gridDim.x * blockDim.x) {
+    const bool live = i < P.n;
+    const float x = live ? P.x[i] : 0.f, y = live ? P.y[i] : 0.f, z = live ? P.z[i] : 0.f;
+    f4 acc = {0.f, 0.f, 0.f, 0.f};
+    acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a0, x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a1, y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a2, z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a3, 1.f, acc, 0, 0, 0);
+    if (live) { P.x[i] = acc[0]; P.y[i] = acc[1]; P.z[i] = acc[2]; }
   }
 }
 

@@ -1,0 +1,449 @@
+// s4p_shard.cpp -- sharding of RANSAC bases over the GPUs of one node, in C++ behind the C ABI (include/s4p_matcher.h,
+// "multi-GPU" section).
+//
+// One process per GPU.  Every rank walks the SAME sequence of bases (same RNG, same pair-octree state:
+// match4pcsBase.cc:185-351 never reads results); the rank that owns a trial runs the fused device pass, the others only
+// advance host state.  After a window of `world` consecutive trials (one per rank) ONE all-reduce(MAX) of one packed
+// 64-bit key selects the winner exactly as the sequential reference would (match4pcsBase.hpp:467-484: the first strictly
+// greater LCP wins; :255: stop at the first trial whose best LCP exceeds the terminate threshold); the winner's result
+// record travels by one broadcast, only when the window improved the best LCP.
+//
+// The collective is 8 bytes: latency-bound, xGMI link bandwidth is irrelevant.  The built-in provider calls RCCL
+// (rccl.h: ncclAllReduce / ncclBroadcast on a private HIP stream, key staged through pinned memory, completion by event,
+// so the launch thread never blocks on a collective it has just issued).  RCCL is bound at run time (dlopen), reusing the
+// copy the process has already loaded if any, so that a process that also uses torch.distributed holds ONE RCCL.
+// A caller-supplied provider (s4p_collective: MPI, gloo through callbacks, the tests) plugs into the same loop.
+//
+// The window loop is written against a small operations table, bound either to a matcher (the public entry points
+// next_base / next_base_async / wait_base / commit) or to recorded outcomes (s4p_shard_replay: the host-only
+// self-check the CPU tests drive over gloo with 2 and 4 ranks).
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <dlfcn.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "s4p_matcher.h"
+
+namespace {
+
+constexpr uint64_t kCrossBit = 1ull << 62;
+
+// Packs one trial's outcome so that max() over the window reproduces the sequential reference.
+// usable: pairs1, pairs2 and quads all non-empty (otherwise TryOneBase returned before TryCongruentSet).  A trial whose
+// count exceeds the terminate threshold outranks everything and, among those, the earliest wins; otherwise the higher
+// count wins and ties go to the earliest trial.
+uint64_t window_key(uint32_t count, bool has_best, bool usable, uint32_t trial_in_window, uint32_t threshold_count) {
+  if (!(has_best && usable)) return 0;
+  const uint64_t inv_t = 0xFFFFull - trial_in_window;
+  if (count > threshold_count) return kCrossBit | (inv_t << 32) | uint64_t(count);
+  return (uint64_t(count) << 16) | inv_t;
+}
+struct Decoded { bool any; uint32_t trial; uint32_t count; bool crossed; };
+Decoded decode_key(uint64_t key) {
+  if (key == 0) return {false, 0, 0, false};
+  if (key & kCrossBit) return {true, uint32_t(0xFFFFull - ((key >> 32) & 0xFFFFull)), uint32_t(key & 0xFFFFFFFFull), true};
+  return {true, uint32_t(0xFFFFull - (key & 0xFFFFull)), uint32_t(key >> 16), false};
+}
+
+// Largest inlier count that does NOT cross the terminate threshold: lcp = float(count) / float(n_q) > threshold is
+// evaluated in float exactly as commit does (match4pcsBase.cc:566, match4pcsBase.hpp:496).
+uint32_t threshold_count_for(uint32_t n_q, float thr) {
+  long c = long(std::floor(double(thr) * double(n_q)));
+  if (c < 0) c = 0;
+  if (c > long(n_q)) c = long(n_q);
+  while (c < long(n_q) && !(float(c + 1) / float(n_q) > thr)) ++c;
+  while (c >= 0 && (float(c) / float(n_q) > thr)) --c;
+  return c < 0 ? 0u : uint32_t(c);
+}
+
+// ---- RCCL, bound at run time ------------------------------------------------------------------------------------
+struct Rccl {
+  void* lib = nullptr;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclAllReduce) AllReduce = nullptr;
+  decltype(&ncclBroadcast) Broadcast = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  std::string err;
+  bool load() {
+    if (lib) return true;
+    const char* names[] = {"librccl.so.1", "librccl.so"};
+    for (const char* n : names) if ((lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL))) break;      // the copy already in the process
+    if (!lib) for (const char* n : names) if ((lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!lib) for (const char* n : {"/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) if ((lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!lib) { err = std::string("cannot load librccl: ") + dlerror(); return false; }
+    GetUniqueId = reinterpret_cast<decltype(GetUniqueId)>(dlsym(lib, "ncclGetUniqueId"));
+    CommInitRank = reinterpret_cast<decltype(CommInitRank)>(dlsym(lib, "ncclCommInitRank"));
+    CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
+    AllReduce = reinterpret_cast<decltype(AllReduce)>(dlsym(lib, "ncclAllReduce"));
+    Broadcast = reinterpret_cast<decltype(Broadcast)>(dlsym(lib, "ncclBroadcast"));
+    GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
+    if (!GetUniqueId || !CommInitRank || !CommDestroy || !AllReduce || !Broadcast) { err = "librccl lacks an expected symbol"; lib = nullptr; return false; }
+    return true;
+  }
+};
+Rccl g_rccl;
+static_assert(sizeof(ncclUniqueId) == 128, "s4p_rccl_unique_id hands out 128 bytes");
+
+// ---- collective providers: post() / result() are split so that the RCCL one can be asynchronous ---------------------
+struct Collective {
+  virtual ~Collective() {}
+  virtual int32_t post(int slot, uint64_t key) = 0;          // all-reduce(MAX) of one key; slot in {0, 1}
+  virtual int32_t result(int slot, uint64_t* key) = 0;
+  virtual int32_t broadcast(void* buf, size_t bytes, int root) = 0;
+  std::string err;
+};
+
+struct CallbackCollective : Collective {                     // caller-supplied, synchronous
+  s4p_collective c;
+  uint64_t val[2] = {0, 0};
+  explicit CallbackCollective(const s4p_collective& cc) : c(cc) {}
+  int32_t post(int slot, uint64_t key) override {
+    val[slot] = key;
+    const int32_t rc = c.allreduce_max_u64(c.user, &val[slot]);
+    if (rc) err = "caller's allreduce_max_u64 failed";
+    return rc ? S4P_ERR_STATE : S4P_OK;
+  }
+  int32_t result(int slot, uint64_t* key) override { *key = val[slot]; return S4P_OK; }
+  int32_t broadcast(void* buf, size_t bytes, int root) override {
+    const int32_t rc = c.broadcast(c.user, buf, int64_t(bytes), root);
+    if (rc) err = "caller's broadcast failed";
+    return rc ? S4P_ERR_STATE : S4P_OK;
+  }
+};
+
+struct RcclCollective : Collective {                         // RCCL over xGMI, one communicator per matcher
+  int device = 0, rank = 0, world = 1;
+  ncclComm_t comm = nullptr;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  uint64_t* host = nullptr;                                  // pinned: [0..1] keys, then a 256-byte record
+  uint64_t* dev = nullptr;
+  static constexpr size_t kRecBytes = 256, kBytes = 16 + kRecBytes;
+  bool hip_ok(hipError_t e, const char* what) { if (e != hipSuccess) { err = std::string(what) + ": " + hipGetErrorString(e); return false; } return true; }
+  bool nccl_ok(ncclResult_t r, const char* what) {
+    if (r != ncclSuccess) { err = std::string(what) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "rccl error"); return false; }
+    return true;
+  }
+  int32_t init(int dev_index, int r, int w, const uint8_t* id128) {
+    device = dev_index; rank = r; world = w;
+    if (!g_rccl.load()) { err = g_rccl.err; return S4P_ERR_STATE; }
+    if (!hip_ok(hipSetDevice(device), "hipSetDevice")) return S4P_ERR_HIP;
+    ncclUniqueId id;
+    std::memcpy(&id, id128, sizeof id);
+    if (!nccl_ok(g_rccl.CommInitRank(&comm, world, id, rank), "ncclCommInitRank")) return S4P_ERR_STATE;
+    if (!hip_ok(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking), "hipStreamCreate")) return S4P_ERR_HIP;
+    for (auto& e : ev) if (!hip_ok(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate")) return S4P_ERR_HIP;
+    if (!hip_ok(hipHostMalloc((void**)&host, kBytes, hipHostMallocDefault), "hipHostMalloc")) return S4P_ERR_HIP;
+    if (!hip_ok(hipMalloc((void**)&dev, kBytes), "hipMalloc")) return S4P_ERR_HIP;
+    return S4P_OK;
+  }
+  ~RcclCollective() override {
+    (void)hipSetDevice(device);
+    if (stream) (void)hipStreamSynchronize(stream);
+    if (comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(comm);
+    for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+    if (host) (void)hipHostFree(host);
+    if (dev) (void)hipFree(dev);
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+  int32_t post(int slot, uint64_t key) override {            // pinned -> device -> ncclAllReduce -> pinned, closed by an event
+    host[slot] = key;
+    if (!hip_ok(hipMemcpyAsync(dev + slot, host + slot, 8, hipMemcpyHostToDevice, stream), "hipMemcpyAsync")) return S4P_ERR_HIP;
+    if (!nccl_ok(g_rccl.AllReduce(dev + slot, dev + slot, 1, ncclUint64, ncclMax, comm, stream), "ncclAllReduce")) return S4P_ERR_STATE;
+    if (!hip_ok(hipMemcpyAsync(host + slot, dev + slot, 8, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync")) return S4P_ERR_HIP;
+    if (!hip_ok(hipEventRecord(ev[slot], stream), "hipEventRecord")) return S4P_ERR_HIP;
+    return S4P_OK;
+  }
+  int32_t result(int slot, uint64_t* key) override {
+    if (!hip_ok(hipEventSynchronize(ev[slot]), "hipEventSynchronize")) return S4P_ERR_HIP;
+    *key = host[slot];
+    return S4P_OK;
+  }
+  int32_t broadcast(void* buf, size_t bytes, int root) override {
+    if (bytes > kRecBytes) { err = "broadcast record too large"; return S4P_ERR_BAD_ARG; }
+    char* hrec = reinterpret_cast<char*>(host) + 16;
+    char* drec = reinterpret_cast<char*>(dev) + 16;
+    if (rank == root) std::memcpy(hrec, buf, bytes);
+    if (!hip_ok(hipMemcpyAsync(drec, hrec, bytes, hipMemcpyHostToDevice, stream), "hipMemcpyAsync")) return S4P_ERR_HIP;
+    if (!nccl_ok(g_rccl.Broadcast(drec, drec, bytes, ncclChar, root, comm, stream), "ncclBroadcast")) return S4P_ERR_STATE;
+    if (!hip_ok(hipMemcpyAsync(hrec, drec, bytes, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync")) return S4P_ERR_HIP;
+    if (!hip_ok(hipStreamSynchronize(stream), "hipStreamSynchronize")) return S4P_ERR_HIP;
+    std::memcpy(buf, hrec, bytes);
+    return S4P_OK;
+  }
+};
+
+// ---- the window loop -----------------------------------------------------------------------------------------------
+struct TrialOps {                                            // what the loop needs from "a matcher"
+  std::function<int32_t(bool run_device, bool* found, int32_t ids[4])> prepare;     // own trial: enqueue; other ranks': advance host state
+  std::function<int32_t(s4p_base_result*)> wait_own;                                // result of the oldest enqueued own trial
+  std::function<int32_t(const int32_t ids[4], const s4p_base_result*, bool* ok)> commit;
+  int depth = 2;
+};
+
+struct BaseId { bool found = false; int32_t ids[4] = {0, 0, 0, 0}; };
+struct Window { std::vector<BaseId> bases; bool mine_found = false; s4p_base_result r{}; uint64_t verified = 0; int slot = -1; };
+
+struct Loop {
+  int rank = 0, world = 1;
+  Collective* coll = nullptr;
+  TrialOps ops;
+  uint32_t threshold_count = 0, best_count = 0;
+  bool terminated = false;
+  uint64_t trials_done = 0, local_candidates = 0;
+  int slot_rr = 0;
+  std::string err;
+  int32_t fail(int32_t rc, const std::string& m) { err = m; return rc; }
+
+  int32_t prepare_window(Window& w) {
+    w.bases.resize(size_t(world));
+    for (int j = 0; j < world; ++j) {
+      bool found = false;
+      if (int32_t rc = ops.prepare(j == rank, &found, w.bases[size_t(j)].ids)) return rc;
+      w.bases[size_t(j)].found = found;
+      if (j == rank) w.mine_found = found;
+    }
+    return S4P_OK;
+  }
+  int32_t post_window(Window& w) {
+    std::memset(&w.r, 0, sizeof w.r);
+    if (w.mine_found) if (int32_t rc = ops.wait_own(&w.r)) return rc;
+    w.verified = w.r.n_verified;
+    local_candidates += w.verified;
+    w.slot = -1;
+    if (!terminated) {
+      const bool usable = w.mine_found && w.r.n_pairs1 && w.r.n_pairs2 && w.r.n_quads;
+      const uint64_t key = window_key(w.r.best_count, w.r.has_best != 0, usable, uint32_t(rank), threshold_count);
+      w.slot = slot_rr;
+      slot_rr ^= 1;
+      if (int32_t rc = coll->post(w.slot, key)) return fail(rc, coll->err);
+    }
+    return S4P_OK;
+  }
+  int32_t complete_window(Window& w) {
+    trials_done += uint64_t(world);
+    if (w.slot < 0 || terminated) return S4P_OK;
+    uint64_t key = 0;
+    if (int32_t rc = coll->result(w.slot, &key)) return fail(rc, coll->err);
+    const Decoded d = decode_key(key);
+    if (d.any && d.count > best_count) {                     // the window improved the best LCP: fetch the winner's record
+      if (d.trial >= uint32_t(world)) return fail(S4P_ERR_STATE, "corrupt window key");
+      s4p_base_result wr = w.r;                              // (the owner's own record; everybody else receives it)
+      if (int32_t rc = coll->broadcast(&wr, sizeof wr, int(d.trial))) return fail(rc, coll->err);
+      bool ok = false;
+      if (int32_t rc = ops.commit(w.bases[d.trial].ids, &wr, &ok)) return rc;
+      best_count = wr.best_count;
+      terminated = terminated || ok || d.crossed;
+    }
+    return S4P_OK;
+  }
+  // n windows (n * world trials) through a three-stage software pipeline: window w+d is PREPARED (own device pass
+  // enqueued, the other ranks' bases advanced on the host) while the passes of windows w+1..w+d-1 are in flight;
+  // window w's result is waited for and its key POSTED; only then is the reduction of window w-1 COMPLETED.
+  int32_t run(int n) {
+    std::deque<Window> prepared;
+    Window posted; bool have_posted = false;
+    auto advance = [&]() -> int32_t {
+      Window nxt = std::move(prepared.front());
+      prepared.pop_front();
+      if (int32_t rc = post_window(nxt)) return rc;
+      if (have_posted) if (int32_t rc = complete_window(posted)) return rc;
+      posted = std::move(nxt);
+      have_posted = true;
+      return S4P_OK;
+    };
+    for (int w = 0; w < n; ++w) {
+      prepared.emplace_back();
+      if (int32_t rc = prepare_window(prepared.back())) return rc;
+      if (int(prepared.size()) >= ops.depth) if (int32_t rc = advance()) return rc;
+    }
+    while (!prepared.empty()) if (int32_t rc = advance()) return rc;
+    if (have_posted) if (int32_t rc = complete_window(posted)) return rc;
+    return S4P_OK;
+  }
+};
+
+}  // namespace
+
+struct s4p_shard {
+  s4p_matcher* m = nullptr;
+  Loop loop;
+  Collective* coll = nullptr;
+  std::string err;
+  ~s4p_shard() { delete coll; }
+};
+
+extern "C" {
+
+int32_t s4p_rccl_unique_id(uint8_t* out128) {
+  if (!out128) return S4P_ERR_BAD_ARG;
+  if (!g_rccl.load()) return S4P_ERR_STATE;
+  ncclUniqueId id;
+  if (g_rccl.GetUniqueId(&id) != ncclSuccess) return S4P_ERR_STATE;
+  std::memcpy(out128, &id, sizeof id);
+  return S4P_OK;
+}
+
+int32_t s4p_shard_create(s4p_matcher* m, int32_t rank, int32_t world, int32_t producer_threads, s4p_shard** out) {
+  if (!m || !out || world < 1 || rank < 0 || rank >= world || world > 0xFFFF) return S4P_ERR_BAD_ARG;
+  *out = nullptr;
+  if (int32_t rc = s4p_matcher_set_sharding(m, rank, world, producer_threads)) return rc;
+  s4p_shard* s = new s4p_shard();
+  s->m = m;
+  s->loop.rank = rank; s->loop.world = world;
+  *out = s;
+  return S4P_OK;
+}
+
+void s4p_shard_destroy(s4p_shard* s) { delete s; }
+const char* s4p_shard_last_error(const s4p_shard* s) { return s ? s->err.c_str() : "null shard"; }
+
+int32_t s4p_shard_use_rccl(s4p_shard* s, int32_t device, const uint8_t* unique_id128) {
+  if (!s || !unique_id128) return S4P_ERR_BAD_ARG;
+  RcclCollective* c = new RcclCollective();
+  const int32_t rc = c->init(device, s->loop.rank, s->loop.world, unique_id128);
+  if (rc) { s->err = c->err; delete c; return rc; }
+  delete s->coll;
+  s->coll = c;
+  return S4P_OK;
+}
+
+int32_t s4p_shard_use_collective(s4p_shard* s, const s4p_collective* coll) {
+  if (!s || !coll || !coll->allreduce_max_u64 || !coll->broadcast) return S4P_ERR_BAD_ARG;
+  delete s->coll;
+  s->coll = new CallbackCollective(*coll);
+  return S4P_OK;
+}
+
+int32_t s4p_shard_run_windows(s4p_shard* s, int32_t n_windows, uint64_t* candidates_local, int32_t* terminated) {
+  if (!s || n_windows < 0) return S4P_ERR_BAD_ARG;
+  if (!s->coll) { s->err = "no collective: call s4p_shard_use_rccl or s4p_shard_use_collective first"; return S4P_ERR_STATE; }
+  s4p_matcher* m = s->m;
+  s4p_matcher_info info;
+  if (int32_t rc = s4p_matcher_get_info(m, &info)) { s->err = s4p_matcher_last_error(m); return rc; }
+  Loop& L = s->loop;
+  L.coll = s->coll;
+  L.best_count = info.best_count;
+  L.threshold_count = threshold_count_for(uint32_t(info.n_sampled_q), s4p_matcher_terminate_threshold(m));
+  L.ops.depth = std::max(1, s4p_pipeline_depth(s4p_matcher_ctx(m)));
+  L.ops.prepare = [m, s](bool run_device, bool* found, int32_t ids[4]) -> int32_t {
+    int32_t f = 0;
+    int32_t rc;
+    if (run_device) rc = s4p_matcher_next_base_async(m, 1, &f, ids);
+    else { s4p_base_result dummy; rc = s4p_matcher_next_base(m, 0, &f, ids, &dummy); }
+    if (rc) s->err = s4p_matcher_last_error(m);
+    *found = f != 0;
+    return rc;
+  };
+  L.ops.wait_own = [m, s](s4p_base_result* r) -> int32_t {
+    const int32_t rc = s4p_matcher_wait_base(m, r);
+    if (rc) s->err = s4p_matcher_last_error(m);
+    return rc;
+  };
+  L.ops.commit = [m, s](const int32_t ids[4], const s4p_base_result* r, bool* ok) -> int32_t {
+    int32_t o = 0;
+    const int32_t rc = s4p_matcher_commit(m, 1, ids, r, &o);
+    if (rc) s->err = s4p_matcher_last_error(m);
+    *ok = o != 0;
+    return rc;
+  };
+  const uint64_t before = L.local_candidates;
+  const int32_t rc = L.run(n_windows);
+  if (rc && s->err.empty()) s->err = L.err;
+  if (candidates_local) *candidates_local = L.local_candidates - before;
+  if (terminated) *terminated = L.terminated ? 1 : 0;
+  return rc;
+}
+
+// Whole ComputeTransformation over `world` GPUs: every rank initialises identically (same clouds, same seed), the trial
+// loop runs in windows until the trial budget is spent or the terminate threshold is crossed, and every rank ends with
+// the same best transform (commit runs everywhere); the caller's Q is transformed on every rank that passes buffers.
+int32_t s4p_shard_compute_transformation(s4p_shard* s, const s4p_cloud_view* P, const s4p_cloud_view* Q,
+                                         float* qx, float* qy, float* qz, float* M, float* lcp) {
+  if (!s || !M || !lcp) return S4P_ERR_BAD_ARG;
+  s4p_matcher* m = s->m;
+  *lcp = 1e9f;                                                     // kLargeNumber, match4pcsBase.hpp:69-70
+  if (!P || !Q || P->n == 0 || Q->n == 0) return S4P_OK;
+  if (int32_t rc = s4p_matcher_init_full(m, P, Q)) { s->err = s4p_matcher_last_error(m); return rc; }
+  s->loop.terminated = false; s->loop.trials_done = 0;
+  s4p_matcher_info info;
+  if (int32_t rc = s4p_matcher_get_info(m, &info)) return rc;
+  const float lcp0 = info.best_lcp;
+  if (info.best_lcp != 1.f) {
+    const int world = s->loop.world;
+    const int windows = (info.number_of_trials + world - 1) / world;
+    // in slices, so that a crossed threshold stops the job within a few windows (the loop itself only stops committing)
+    for (int done = 0; done < windows && !s->loop.terminated;) {
+      const int n = std::min(windows - done, 8 * std::max(1, s->loop.ops.depth));
+      int32_t term = 0;
+      if (int32_t rc = s4p_shard_run_windows(s, n, nullptr, &term)) return rc;
+      done += n;
+    }
+  }
+  if (int32_t rc = s4p_matcher_get_info(m, &info)) return rc;
+  *lcp = info.best_lcp;
+  if (info.best_lcp > lcp0) {
+    if (int32_t rc = s4p_matcher_global_transform(m, M)) return rc;
+    if (qx && qy && qz) {                                           // match4pcsBase.hpp:259-268
+      if (qx != Q->x) std::memcpy(qx, Q->x, size_t(Q->n) * 4);
+      if (qy != Q->y) std::memcpy(qy, Q->y, size_t(Q->n) * 4);
+      if (qz != Q->z) std::memcpy(qz, Q->z, size_t(Q->n) * 4);
+      if (int32_t rc = s4p_transform_points(s4p_matcher_ctx(m), M, qx, qy, qz, Q->n)) { s->err = s4p_last_error(s4p_matcher_ctx(m)); return rc; }
+    }
+  } else {
+    std::memcpy(M, info.transform, sizeof(float) * 16);
+  }
+  return S4P_OK;
+}
+
+// Host-only self-check of the window loop (no matcher, no GPU): this rank replays recorded outcomes of ITS trials
+// (found[w], results[w] for window w) through the same Loop and the given collective, and logs every commit.
+// The CPU tests run it over gloo with 2 and 4 ranks against the sequential semantics.
+int32_t s4p_shard_replay(int32_t rank, int32_t world, const s4p_collective* coll, int32_t n_windows, int32_t depth,
+                         uint32_t threshold_count, uint32_t start_best_count, const int32_t* found,
+                         const s4p_base_result* results, int32_t* commit_trials, uint32_t* commit_counts, int32_t commit_cap,
+                         int32_t* n_commits, int32_t* terminated, uint64_t* trials_done) {
+  if (!coll || !coll->allreduce_max_u64 || !coll->broadcast || world < 1 || rank < 0 || rank >= world || !found || !results || !n_commits)
+    return S4P_ERR_BAD_ARG;
+  CallbackCollective cc(*coll);
+  Loop L;
+  L.rank = rank; L.world = world; L.coll = &cc; L.threshold_count = threshold_count; L.best_count = start_best_count;
+  L.ops.depth = std::max(1, depth);
+  int prepared = 0, waited = 0, trial = 0;
+  std::deque<int> own;                                               // windows whose own trial is "in flight"
+  *n_commits = 0;
+  L.ops.prepare = [&](bool run_device, bool* f, int32_t ids[4]) -> int32_t {
+    const int t = trial++;                                           // global trial index = window * world + position
+    ids[0] = t; ids[1] = ids[2] = ids[3] = 0;
+    if (run_device) { *f = found[prepared] != 0; if (*f) own.push_back(prepared); ++prepared; }
+    else *f = true;                                                  // what other ranks found does not enter the key
+    return S4P_OK;
+  };
+  L.ops.wait_own = [&](s4p_base_result* r) -> int32_t {
+    if (own.empty()) return S4P_ERR_STATE;
+    *r = results[own.front()];
+    own.pop_front(); ++waited;
+    return S4P_OK;
+  };
+  L.ops.commit = [&](const int32_t ids[4], const s4p_base_result* r, bool* ok) -> int32_t {
+    if (*n_commits < commit_cap) { if (commit_trials) commit_trials[*n_commits] = ids[0]; if (commit_counts) commit_counts[*n_commits] = r->best_count; }
+    ++*n_commits;
+    *ok = r->best_count > threshold_count;
+    return S4P_OK;
+  };
+  const int32_t rc = L.run(n_windows);
+  if (terminated) *terminated = L.terminated ? 1 : 0;
+  if (trials_done) *trials_done = L.trials_done;
+  return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,113 @@
+"""CPU (-m "not gpu"): the C++ sharded trial loop (super4pcs_amd/csrc/s4p_shard.cpp) over torch.distributed (gloo) with
+world sizes 2 and 4.  No GPU: every rank replays recorded outcomes of its own trials through s4p_shard_replay, i.e.
+through the SAME window loop (key packing, all-reduce(MAX), winner broadcast, commit, termination, pipelining) that
+s4p_shard_run_windows runs over a real matcher, with the collective supplied through the s4p_collective callbacks.
+The commits every rank performs must be exactly those of the sequential reference loop
+(match4pcsBase.hpp:236-256 "stop at the first crossing trial", :467-484 "first strictly greater LCP wins")."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+N_Q = 100
+
+
+def outcome_table(seed, n_trials):
+    rng = np.random.default_rng(seed)
+    # (found, inlier count, usable = pairs1/pairs2/quads all non-empty)
+    return [(bool(rng.random() < 0.9), int(rng.integers(0, N_Q)), bool(rng.random() < 0.85)) for _ in range(n_trials)]
+
+
+def sequential_commits(table, start_best, threshold_count):
+    """What Perform_N_steps does with these outcomes: commit on every strictly greater count, stop after a crossing one."""
+    best, commits = start_best, []
+    for t, (found, count, usable) in enumerate(table):
+        if found and usable and count > best:
+            best = count
+            commits.append((t, count))
+        if best > threshold_count:
+            break
+    return commits
+
+
+def _worker(rank, world, port, seed, n_windows, threshold_count, depth, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from super4pcs_amd import capi
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    table = outcome_table(seed, n_windows * world)
+    found, results = [], []
+    for w in range(n_windows):
+        f, count, usable = table[w * world + rank]
+        r = capi.BaseResult()
+        if f and usable:
+            r.n_pairs1 = r.n_pairs2 = r.n_quads = 10
+            r.n_verified = 5
+            r.best_count = count
+            r.has_best = 1
+            r.best_quad[0] = w * world + rank
+        found.append(f)
+        results.append(r)
+    coll = capi.torch_collective(dist)
+    commits, terminated, trials_done = capi.shard_replay(rank, world, coll, found, results, depth, threshold_count, 3)
+    q.put((rank, commits, terminated, trials_done))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(world, seed, n_windows, threshold_count, depth):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, seed, n_windows, threshold_count, depth, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return res
+
+
+@pytest.mark.parametrize("world,seed,depth", [(2, 1, 3), (2, 2, 1), (4, 3, 3), (4, 5, 2)])
+def test_native_loop_commits_equal_the_sequential_loop(world, seed, depth, s4p_lib_built):
+    n_windows = 12
+    res = _run(world, seed, n_windows, N_Q, depth)                      # threshold never crossed
+    want = sequential_commits(outcome_table(seed, n_windows * world), 3, N_Q)
+    assert want, "seed produces no improvement; pick another"
+    for rank, commits, terminated, trials_done in res:
+        # one commit per improving WINDOW: the window's winner is the earliest trial with the window's greatest count, which
+        # is what the sequential loop ends the window with; intermediate improvements inside a window are not replayed
+        seq_by_window = {}
+        for t, c in want:
+            seq_by_window[t // world] = (t, c)
+        assert commits == [seq_by_window[w] for w in sorted(seq_by_window)]
+        assert not terminated and trials_done == n_windows * world
+
+
+@pytest.mark.parametrize("world,seed", [(2, 4), (2, 8), (4, 6), (4, 21)])
+def test_native_loop_stops_committing_at_the_first_crossing_trial(world, seed, s4p_lib_built):
+    n_windows, thr = 16, 89
+    table = outcome_table(seed, n_windows * world)
+    want = sequential_commits(table, 3, thr)
+    assert want and want[-1][1] > thr and want[-1][0] < (n_windows - 3) * world, "seed does not terminate early; pick another"
+    res = _run(world, seed, n_windows, thr, 3)
+    for rank, commits, terminated, trials_done in res:
+        assert terminated
+        assert commits[-1] == want[-1]                                   # the crossing trial, not a later / greater one
+        seq_by_window = {}
+        for t, c in want:
+            seq_by_window[t // world] = (t, c)
+        assert commits == [seq_by_window[w] for w in sorted(seq_by_window)]
