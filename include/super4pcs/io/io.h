@@ -22,6 +22,7 @@
 #define S4P_FACADE_IO_H_
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <iostream>
@@ -111,138 +112,180 @@ class IOManager {
                     normals, tris, mtls);
   }
 
+  // Polyworks text matrix: four rows of four fixed-point numbers (six decimals, what std::to_string prints), each padded
+  // with a leading blank when it has no minus sign so that the columns line up; two blanks between columns.
   inline bool WriteMatrix(const std::string& name, const Mat4dArg& mat, MATRIX_MODE mode) {
-    std::ofstream sstr;
-    sstr.open(name, std::ofstream::out | std::ofstream::trunc);
-    bool status = false;
-    if (mode == POLYWORKS) {
-      auto formatValue = [](double v) { return v >= 0. ? std::string(" ") + std::to_string(v) : std::to_string(v); };
-      sstr << "VERSION\t=\t1\n";
-      sstr << "MATRIX\t=\n";
-      for (int j = 0; j != 4; ++j)
-        sstr << formatValue(mat(j, 0)) << "  " << formatValue(mat(j, 1)) << "  " << formatValue(mat(j, 2)) << "  "
-             << formatValue(mat(j, 3)) << "\n";
-      status = true;
+    std::ofstream out(name, std::ofstream::out | std::ofstream::trunc);
+    if (mode != POLYWORKS) return false;
+    std::string text = "VERSION\t=\t1\nMATRIX\t=\n";
+    for (int row = 0; row < 4; ++row) {
+      for (int col = 0; col < 4; ++col) {
+        const double value = mat(row, col);
+        if (col) text += "  ";
+        if (!(value < 0.)) text += ' ';             // (NaN prints without a sign, so it gets the pad as well)
+        text += std::to_string(value);
+      }
+      text += '\n';
     }
-    sstr.close();
-    return status;
+    out << text;
+    return true;
   }
 
  private:
   static inline Vec3 vec3(float x, float y, float z) { Vec3 r; r(0) = x; r(1) = y; r(2) = z; return r; }
 
+  // ---------------------------------------------------------------- text scanning helper
+  // A cursor over one line with the conversions of C's scanf family ("%f", "%d", a literal character), each returning
+  // false -- and leaving its output untouched -- at the first mismatch, after which every later conversion fails too.
+  // The readers below are written against it; the values it yields are those the reference obtains from sscanf.
+  struct LineCursor {
+    const char* p;
+    bool ok = true;
+    explicit LineCursor(const char* s) : p(s) {}
+    void skip_blank() { while (*p == ' ' || *p == '\t' || *p == '\n' || *p == '\v' || *p == '\f' || *p == '\r') ++p; }
+    // first blank-delimited word (empty if the line is blank); stays in front of the rest of the line
+    std::string word() {
+      skip_blank();
+      const char* b = p;
+      while (*p && !(*p == ' ' || *p == '\t' || *p == '\n' || *p == '\v' || *p == '\f' || *p == '\r')) ++p;
+      return std::string(b, p);
+    }
+    bool real(float& out) {
+      if (!ok) return false;
+      skip_blank();
+      char* end = nullptr;
+      const float v = std::strtof(p, &end);
+      if (end == p) return ok = false;
+      p = end; out = v;
+      return true;
+    }
+    bool integer(int& out) {
+      if (!ok) return false;
+      skip_blank();
+      char* end = nullptr;
+      const long v = std::strtol(p, &end, 10);
+      if (end == p) return ok = false;
+      p = end; out = int(v);
+      return true;
+    }
+    bool literal(char c) {                       // no blank skipping: "1//2" matches "%d//%d", "1 //2" does not
+      if (!ok) return false;
+      if (*p != c) return ok = false;
+      ++p;
+      return true;
+    }
+  };
+
   // ---------------------------------------------------------------- OBJ (io.cc:138-268)
+  // Statements: "v x y z", "vt u v", "vn x y z", "f ..." (index layout decided by which attribute lists are non-empty
+  // when the face is met), "mtllib name"; everything else is ignored.
   inline bool ReadObj(const char* filename, std::vector<Point3D>& v, std::vector<TexCoord>& tex_coords,
                       std::vector<Vec3>& normals, std::vector<tripple>& tris, std::vector<std::string>& mtls) {
-    std::ifstream f(filename, std::ios::in);
-    if (!f || f.fail()) return false;
+    std::ifstream file(filename, std::ios::in);
+    if (!file) return false;
     v.clear();
     tris.clear();
-    float x = 0.f, y = 0.f, z = 0.f;          // kept across lines like the reference's locals (a short "v" line reuses them)
-    std::string line;
-    while (std::getline(f, line)) {
+    float xyz[3] = {0.f, 0.f, 0.f};              // survives from line to line: a short "v"/"vn" line reuses the previous values
+    auto in_range = [](int i, size_t n) { return i >= 1 && size_t(i) <= n; };   // (the reference indexes unchecked)
+    for (std::string line; std::getline(file, line);) {
       if (!line.empty() && line.back() == '\r') line.pop_back();
-      const char* str = line.c_str();
-      char ch[128];
-      ch[0] = '\0';
-      if (std::sscanf(str, "%127s", ch) != 1) continue;
-      if (std::strcmp(ch, "v") == 0) {
-        std::sscanf(str, "%*s %f %f %f", &x, &y, &z);
-        v.emplace_back(x, y, z);
-        v.back().set_rgb(vec3(0.f, 0.f, 0.f));
-      } else if (std::strcmp(ch, "vt") == 0) {
-        TexCoord tc;
-        tc.coeffRef(0) = tc.coeffRef(1) = tc.coeffRef(2) = tc.coeffRef(3) = 0.f;
-        std::sscanf(str, "%*s %f %f", &tc.coeffRef(0), &tc.coeffRef(1));
-        tex_coords.push_back(tc);
-      } else if (std::strcmp(ch, "vn") == 0) {
-        std::sscanf(str, "%*s %f %f %f", &x, &y, &z);
-        normals.push_back(vec3(x, y, z));
-      } else if (std::strcmp(ch, "f") == 0) {
-        tripple t;
-        if (normals.size() && !tex_coords.size())
-          std::sscanf(str, "%*s %d//%d %d//%d %d//%d", &t.a, &t.n1, &t.b, &t.n2, &t.c, &t.n3);
-        else if (normals.size() && tex_coords.size())
-          std::sscanf(str, "%*s %d/%d/%d %d/%d/%d %d/%d/%d", &t.a, &t.t1, &t.n1, &t.b, &t.t2, &t.n2, &t.c, &t.t3, &t.n3);
-        else if (!normals.size() && tex_coords.size())
-          std::sscanf(str, "%*s %d/%d %d/%d %d/%d", &t.a, &t.t1, &t.b, &t.t2, &t.c, &t.t3);
-        else
-          std::sscanf(str, "%*s %d %d %d", &t.a, &t.b, &t.c);
-        tris.push_back(t);
-        if (normals.size()) {
-          auto ok = [](int i, size_t n) { return i >= 1 && size_t(i) <= n; };   // the reference indexes unchecked
-          if (ok(t.a, v.size()) && ok(t.n1, normals.size())) v[t.a - 1].set_normal(normals[t.n1 - 1]);
-          if (ok(t.b, v.size()) && ok(t.n2, normals.size())) v[t.b - 1].set_normal(normals[t.n2 - 1]);
-          if (ok(t.c, v.size()) && ok(t.n3, normals.size())) v[t.c - 1].set_normal(normals[t.n3 - 1]);
+      LineCursor cur(line.c_str());
+      const std::string kind = cur.word();
+      if (kind == "v" || kind == "vn") {
+        cur.real(xyz[0]) && cur.real(xyz[1]) && cur.real(xyz[2]);
+        if (kind == "v") {
+          v.emplace_back(xyz[0], xyz[1], xyz[2]);
+          v.back().set_rgb(vec3(0.f, 0.f, 0.f));
+        } else {
+          normals.push_back(vec3(xyz[0], xyz[1], xyz[2]));
         }
-      } else if (std::strcmp(ch, "mtllib") == 0) {
+      } else if (kind == "vt") {
+        TexCoord tc;
+        for (int k = 0; k < 4; ++k) tc.coeffRef(k) = 0.f;
+        cur.real(tc.coeffRef(0)) && cur.real(tc.coeffRef(1));
+        tex_coords.push_back(tc);
+      } else if (kind == "f") {
+        tripple t;
+        int* vert[3] = {&t.a, &t.b, &t.c};
+        int* tex[3] = {&t.t1, &t.t2, &t.t3};
+        int* nrm[3] = {&t.n1, &t.n2, &t.n3};
+        const bool with_n = !normals.empty(), with_t = !tex_coords.empty();
+        for (int corner = 0; corner < 3 && cur.ok; ++corner) {
+          cur.integer(*vert[corner]);
+          if (with_n && with_t) { cur.literal('/') && cur.integer(*tex[corner]) && cur.literal('/') && cur.integer(*nrm[corner]); }
+          else if (with_n) { cur.literal('/') && cur.literal('/') && cur.integer(*nrm[corner]); }
+          else if (with_t) { cur.literal('/') && cur.integer(*tex[corner]); }
+        }
+        tris.push_back(t);
+        if (with_n)
+          for (int corner = 0; corner < 3; ++corner)
+            if (in_range(*vert[corner], v.size()) && in_range(*nrm[corner], normals.size()))
+              v[size_t(*vert[corner] - 1)].set_normal(normals[size_t(*nrm[corner] - 1)]);
+      } else if (kind == "mtllib") {
         mtls.push_back(line.size() > 7 ? line.substr(7) : std::string());
       }
     }
-    f.close();
 
-    if (tris.size() == 0) {
-      // vertex and normal lists but no face: the i-th normal belongs to the i-th vertex
+    if (tris.empty()) {
+      // point set: the i-th normal belongs to the i-th vertex when the two lists have the same length
       if (v.size() == normals.size())
         for (size_t i = 0; i < v.size(); ++i) v[i].set_normal(normals[i]);
     } else if (!normals.empty()) {
-      // normals came through the faces: rebuild the array one-to-one with the vertices
+      // mesh: normals were attached through the faces; hand them back one per vertex
       normals.clear();
       normals.reserve(v.size());
-      for (size_t i = 0; i != v.size(); ++i) normals.push_back(v[i].normal());
+      for (const Point3D& pt : v) normals.push_back(pt.normal());
     }
 
-    if (mtls.size()) {
-      std::ifstream m(mtls[0].c_str(), std::ios::in);
-      std::string token, img_name;
-      while (m >> token) {
+    if (!mtls.empty()) {                         // textures need OpenCV in the reference; they are named and skipped
+      std::ifstream material(mtls[0].c_str(), std::ios::in);
+      for (std::string token; material >> token;)
         if (token == "map_Kd") {
-          m >> img_name;
-          std::cerr << "OpenCV is required to load material textures. Skipping " << img_name.c_str() << std::endl;
+          std::string image;
+          material >> image;
+          std::cerr << "OpenCV is required to load material textures. Skipping " << image.c_str() << std::endl;
         }
-      }
     }
-    return v.size() != 0;
+    return !v.empty();
   }
 
   // ---------------------------------------------------------------- PTX (io.cc:83-136)
+  // "columns", "rows", eight lines of scanner pose, then one "x y z intensity r g b" record per line.
+  // Numbers are taken with the stream extraction the reference uses (a record that stops early leaves the remaining
+  // fields at their previous values and the point is kept), hence a persistent record and istringstream per line.
   inline bool ReadPtx(const char* filename, std::vector<Point3D>& vertex) {
-    std::ifstream f(filename, std::ios::in);
-    if (!f || f.fail()) {
+    std::ifstream file(filename, std::ios::in);
+    if (!file) {
       std::cerr << "(PTX) error opening file" << std::endl;
       return false;
     }
     std::string line;
-    int rows = 0, cols = 0;
-    { std::getline(f, line); std::stringstream ss(line); ss >> cols; }
-    { std::getline(f, line); std::stringstream ss(line); ss >> rows; }
-    const long long numOfVertices = (long long)cols * rows;
-    for (int i = 0; i < 8; i++) std::getline(f, line);   // scanner pose matrices: ignored like the reference
+    auto header_int = [&]() { int value = 0; std::getline(file, line); std::istringstream(line) >> value; return value; };
+    const int columns = header_int();
+    const int rows = header_int();
+    const long long expected = (long long)columns * rows;
+    for (int skipped = 0; skipped < 8; ++skipped) std::getline(file, line);
     vertex.clear();
-    if (numOfVertices > 0) vertex.reserve(size_t(numOfVertices));
-    Point3D ptx;
-    float intensity = 0.f;
-    Vec3 rgb = vec3(0.f, 0.f, 0.f);
-    for (long long i = 0; i < numOfVertices && !f.eof(); i++) {
-      std::getline(f, line);
-      std::stringstream ss(line);
-      ss >> ptx.x();
-      ss >> ptx.y();
-      ss >> ptx.z();
-      ss >> intensity;
-      ss >> rgb(0);
-      ss >> rgb(1);
-      ss >> rgb(2);
-      ptx.set_rgb(rgb);
-      vertex.push_back(ptx);
+    if (expected > 0) vertex.reserve(size_t(expected));
+    struct { float pos[3] = {0.f, 0.f, 0.f}; float intensity = 0.f; float rgb[3] = {0.f, 0.f, 0.f}; } rec;
+    for (long long count = 0; count < expected && !file.eof(); ++count) {
+      std::getline(file, line);
+      std::istringstream fields(line);
+      fields >> rec.pos[0] >> rec.pos[1] >> rec.pos[2] >> rec.intensity >> rec.rgb[0] >> rec.rgb[1] >> rec.rgb[2];
+      Point3D pt(rec.pos[0], rec.pos[1], rec.pos[2]);
+      pt.set_rgb(vec3(rec.rgb[0], rec.rgb[1], rec.rgb[2]));
+      vertex.push_back(pt);
     }
-    return (long long)vertex.size() == numOfVertices;
+    return (long long)vertex.size() == expected;
   }
 
   // ---------------------------------------------------------------- PLY (io_ply.h)
   enum PLYFormat { BINARY_BIG_ENDIAN_1, BINARY_LITTLE_ENDIAN_1, ASCII_1 };
 
-  // io_ply.h:20-124: returns the offset of the first body byte (0 on error)
+  // PLY header (io_ply.h:20-124) as a keyword-driven scan over blank-separated words.  Returns the offset of the first
+  // body byte (0 on error).  What counts: "format <kind> 1.0"; "element vertex|face <n>" (other elements switch property
+  // counting off); per "property": float/double add one vertex property, uchar adds one and flags colour, list is skipped;
+  // "comment" / "*obj_info*" lines are skipped to their end.
   static inline unsigned int readPlyHeader(const char* filename, unsigned int& numOfVertices, unsigned int& numOfFaces,
                                            PLYFormat& format, unsigned int& numOfVertexProperties, bool& haveColor) {
     std::ifstream in(filename, std::ios_base::in | std::ios_base::binary);
@@ -252,53 +295,40 @@ class IOManager {
     }
     numOfVertexProperties = 0; numOfVertices = 0; numOfFaces = 0; haveColor = false;
     format = ASCII_1;
-    std::string current, currentelement;
-    in >> current;
-    if (current != "ply") {
-      std::cerr << "(PLY) not a PLY file" << std::endl;
-      return 0;
-    }
-    in >> current;
-    while (current != "end_header") {
-      if (!in) {
-        std::cerr << "(PLY) error parsing header (no end_header)" << std::endl;   // the reference loops forever here
-        return 0;
+    auto fail = [](const char* why) { std::cerr << "(PLY) " << why << std::endl; return 0u; };
+    std::string word;
+    if (!(in >> word) || word != "ply") return fail("not a PLY file");
+    bool counting = false;                         // inside an element whose properties are counted (vertex or face)
+    while (true) {
+      if (!(in >> word)) return fail("error parsing header (no end_header)");   // (the reference never returns here)
+      if (word == "end_header") break;
+      if (word == "format") {
+        std::string kind, version;
+        in >> kind >> version;
+        if (kind == "ascii") format = ASCII_1;
+        else if (kind == "binary_little_endian") format = BINARY_LITTLE_ENDIAN_1;
+        else if (kind == "binary_big_endian") format = BINARY_BIG_ENDIAN_1;
+        else return fail("error parsing header (format)");
+        if (version != "1.0") return fail("error parsing header - bad version");
+      } else if (word == "element") {
+        std::string what;
+        in >> what;
+        counting = what == "vertex" || what == "face";
+        if (what == "vertex") in >> numOfVertices;
+        else if (what == "face") in >> numOfFaces;
+        else std::cerr << "(PLY) ignoring unknown element " << what << std::endl;
+      } else if (word == "property" && counting) {
+        std::string type, skipped;
+        in >> type;
+        if (type == "float" || type == "double") { ++numOfVertexProperties; in >> skipped; }
+        else if (type == "uchar") { ++numOfVertexProperties; haveColor = true; in >> skipped; }
+        else if (type == "list") { in >> skipped >> skipped >> skipped; }
+        else return fail("error parsing header (property)");
+      } else if (word == "comment" || word.find("obj_info") != std::string::npos) {
+        std::getline(in, word);
       }
-      if (current == "format") {
-        in >> current;
-        const std::string kind = current;
-        in >> current;
-        if (kind != "binary_big_endian" && kind != "binary_little_endian" && kind != "ascii") {
-          std::cerr << "(PLY) error parsing header (format)" << std::endl;
-          return 0;
-        }
-        if (current != "1.0") {
-          std::cerr << "(PLY) error parsing header - bad version" << std::endl;
-          return 0;
-        }
-        format = kind == "ascii" ? ASCII_1 : (kind == "binary_big_endian" ? BINARY_BIG_ENDIAN_1 : BINARY_LITTLE_ENDIAN_1);
-      } else if (current == "element") {
-        in >> current;
-        if (current == "vertex") { currentelement = current; in >> numOfVertices; }
-        else if (current == "face") { currentelement = current; in >> numOfFaces; }
-        else { std::cerr << "(PLY) ignoring unknown element " << current << std::endl; currentelement = ""; }
-      } else if (currentelement != "" && current == "property") {
-        in >> current;
-        if (current == "float" || current == "double") { numOfVertexProperties++; in >> current; }
-        else if (current == "uchar") { numOfVertexProperties++; haveColor = true; in >> current; }
-        else if (current == "list") { in >> current; in >> current; in >> current; }
-        else {
-          std::cerr << "(PLY) error parsing header (property)" << std::endl;
-          return 0;
-        }
-      } else if (current == "comment" || current.find("obj_info") != std::string::npos) {
-        std::string rest;
-        std::getline(in, rest);
-      }
-      in >> current;
     }
-    const unsigned int headerSize = (unsigned int)in.tellg();
-    return headerSize + 1;       // the byte after the end-of-line that follows "end_header"
+    return (unsigned int)in.tellg() + 1u;          // the byte after the end-of-line that follows "end_header"
   }
 
   static inline void swap4(void* p, unsigned int count) {   // bigLittleEndianSwap, io_ply.h:127-141

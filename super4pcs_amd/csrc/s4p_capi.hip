@@ -57,6 +57,7 @@ struct s4p_ctx {
 
   // device state
   DevBuf<uint2> greach; DevBuf<uint4> glist_hdr; DevBuf<uint32_t> gcoarse; DevBuf<float4> gnbr; DevBuf<float4> q4, q4v;
+  DevBuf<uint2> qquant; QuantQ qq{}; bool qlds = false;      // 16-bit copy of the Morton-ordered queries for the LDS-resident sweep
   DevBuf<float> qx, qy, qz, ux, uy, uz, qnx, qny, qnz, qcr, qcg, qcb;
   // Two lanes = two HIP streams with private per-base device buffers.  Consecutive bases alternate lanes, so the
   // small latency-bound kernels of base t+1 (pairs, hash build, quad enumeration) run concurrently with the
@@ -64,7 +65,7 @@ struct s4p_ctx {
   struct Lane {
     hipStream_t stream = nullptr;
     DevBuf<int2> ab1, ab2; DevBuf<uint32_t> okey1, okey2, cell1, cell2, bucket1, next1, mask2; DevBuf<float4> ew1, ew2;
-    DevBuf<int4> quads; DevBuf<unsigned long long> tags; DevBuf<uint32_t> counts, cand_idx; DevBuf<float4> cand_T;
+    DevBuf<int4> quads; DevBuf<unsigned long long> tags; DevBuf<uint32_t> counts, cand_idx, cand_cnt; DevBuf<float4> cand_T;
     DevBuf<unsigned long long> ht_keys, ht_heads; uint32_t ht_mask = 0, epoch = 0;
     DevBuf<DevCounters> ctr;          // [0] live counters of the base in flight, [1] its result record (what the host reads)
     DevBuf<uint4> slots;              // k_verify: per-workgroup best, reduced by its last workgroup
@@ -109,7 +110,11 @@ struct s4p_ctx {
   bool fuse_prep = false, fuse_gate = true;
   double host_octree_s = 0, host_wait_s = 0;
 
-  size_t verify_lds_bytes() const { return gcoarse.n * 4 + size_t(kVerifyThreads / 64) * kQueueWordsPerWave * 4; }
+  size_t verify_lds_bytes() const {
+    return gcoarse.n * 4 + (qlds ? size_t((n_q + 127u) & ~127u) * 8 : 0) + size_t(kVerifyThreads / 64) * kQueueWordsPerWave * 4;
+  }
+  // workgroups of the scoring kernel: a slice holds < 65536 candidates (their offset travels in 16 bits of a queue entry)
+  uint32_t verify_grid() const { return std::min<uint32_t>(uint32_t(kVerifyMaxBlocks), std::max<uint32_t>(verify_blocks, uint32_t((max_quads + 65534) / 65535))); }
   LcpGrid dev_grid() const {
     LcpGrid g;
     g.reach = greach.p; g.list_hdr = glist_hdr.p; g.nbr = gnbr.p;
@@ -282,7 +287,7 @@ int32_t quad_params(s4p_ctx* c, float inv1, float inv2, float thr2, PrepParams& 
 GateParams gate_params(s4p_ctx* c, const BaseFrame& bf) {
   s4p_ctx::Lane& L = c->lane[c->cur];
   GateParams G{};
-  G.q4 = c->q4.p; G.base = bf; G.counts = L.counts.p; G.cand_idx = L.cand_idx.p; G.cand_T = L.cand_T.p; G.C_dev = &L.ctr.p->C;
+  G.q4 = c->q4.p; G.base = bf; G.counts = L.counts.p; G.cand_idx = L.cand_idx.p; G.cand_T = L.cand_T.p; G.cand_cnt = L.cand_cnt.p; G.C_dev = &L.ctr.p->C;
   return G;
 }
 
@@ -302,14 +307,15 @@ void launch_gate_kernel(s4p_ctx* c, const GateParams& G) {
 int32_t launch_verify(s4p_ctx* c, const BaseFrame& bf) {
   s4p_ctx::Lane& L = c->lane[c->cur];
   VerifyParams V{};
-  V.grid = c->dev_grid(); V.q4 = c->q4.p; V.q4v = c->q4v.p; V.n_q = c->n_q; V.base = bf;
-  V.quads = L.quads.p; V.tags = L.tags.p; V.counts = L.counts.p; V.cand_idx = L.cand_idx.p; V.cand_T = L.cand_T.p;
+  V.grid = c->dev_grid(); V.q4 = c->q4.p; V.q4v = c->q4v.p; V.qq = c->qq; V.n_q = c->n_q; V.base = bf;
+  V.quads = L.quads.p; V.tags = L.tags.p; V.counts = L.counts.p; V.cand_idx = L.cand_idx.p; V.cand_T = L.cand_T.p; V.cand_cnt = L.cand_cnt.p;
   V.ctr = L.ctr.p; V.res = L.ctr.p + 1; V.slots = L.slots.p; V.count_tests = c->prof_points ? 1 : 0;
   V.ablate = c->ablate;
   if (c->prof_events) HIPCHK(c, hipEventRecord(c->ev[c->cur][0], L.stream));
   const size_t lds = c->verify_lds_bytes();
-  if (c->prof_points) hipLaunchKernelGGL(k_verify<true>, dim3(c->verify_blocks), dim3(kVerifyThreads), lds, L.stream, V);
-  else hipLaunchKernelGGL(k_verify<false>, dim3(c->verify_blocks), dim3(kVerifyThreads), lds, L.stream, V);
+  const dim3 grid(c->verify_grid()), block(kVerifyThreads);
+  if (c->prof_points) { if (c->qlds) hipLaunchKernelGGL((k_verify<true, true>), grid, block, lds, L.stream, V); else hipLaunchKernelGGL((k_verify<true, false>), grid, block, lds, L.stream, V); }
+  else { if (c->qlds) hipLaunchKernelGGL((k_verify<false, true>), grid, block, lds, L.stream, V); else hipLaunchKernelGGL((k_verify<false, false>), grid, block, lds, L.stream, V); }
   if (c->prof_events) HIPCHK(c, hipEventRecord(c->ev[c->cur][1], L.stream));
   HIPCHK(c, hipGetLastError());
   return S4P_OK;
@@ -423,7 +429,7 @@ int32_t s4p_create(const s4p_options* opt, const s4p_limits* lim, int32_t device
     if ((e = hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
     A(L.ab1, mp); A(L.ab2, mp); A(L.okey1, mp); A(L.okey2, mp); A(L.cell1, mp); A(L.cell2, mp);
     A(L.bucket1, mp); A(L.next1, mp); A(L.mask2, mp * kMaskWords); A(L.ew1, mp); A(L.ew2, mp);
-    A(L.quads, mq); A(L.tags, mq); A(L.counts, mq); A(L.cand_idx, mq); A(L.cand_T, mq * 3);
+    A(L.quads, mq); A(L.tags, mq); A(L.counts, mq); A(L.cand_idx, mq); A(L.cand_cnt, mq); A(L.cand_T, mq * 3);
     A(L.ht_keys, hts); A(L.ht_heads, hts); L.ht_mask = hts - 1;
     A(L.ctr, 2); A(L.slots, kVerifyMaxBlocks);
     if ((e = hipMemset(L.ht_keys.p, 0, size_t(hts) * 8)) != hipSuccess) return fail(e, "hipMemset");
@@ -436,12 +442,12 @@ int32_t s4p_create(const s4p_options* opt, const s4p_limits* lim, int32_t device
     if ((e = c->hctr[sl].alloc(1)) != hipSuccess) return fail(e, "hipHostMalloc");
     if ((e = hipEventCreateWithFlags(&c->done[sl], hipEventDisableTiming)) != hipSuccess) return fail(e, "hipEventCreate");
   }
-  {  // allow the verify kernels their dynamic LDS (coarse bitmap + survivor queues)
-    const int max_lds = int(kCoarseMaxWords * 4 + (kVerifyThreads / 64) * kQueueWordsPerWave * 4);
-    if ((e = hipFuncSetAttribute((const void*)k_verify<false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds)) != hipSuccess) return fail(e, "hipFuncSetAttribute");
-    if ((e = hipFuncSetAttribute((const void*)k_verify<true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds)) != hipSuccess) return fail(e, "hipFuncSetAttribute");
-    if ((e = hipFuncSetAttribute((const void*)k_verify_T<false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds)) != hipSuccess) return fail(e, "hipFuncSetAttribute");
-    if ((e = hipFuncSetAttribute((const void*)k_verify_T<true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds)) != hipSuccess) return fail(e, "hipFuncSetAttribute");
+  {  // allow the verify kernels their dynamic LDS (coarse bitmap + quantised queries + survivor queues)
+    const int max_lds = int(kCoarseMaxWords * 4 + kLdsQueries * 8 + (kVerifyThreads / 64) * kQueueWordsPerWave * 4);
+    const void* fns[] = {(const void*)k_verify<false, false>, (const void*)k_verify<false, true>, (const void*)k_verify<true, false>, (const void*)k_verify<true, true>,
+                         (const void*)k_verify_T<false, false>, (const void*)k_verify_T<false, true>, (const void*)k_verify_T<true, false>, (const void*)k_verify_T<true, true>};
+    for (const void* fn : fns)
+      if ((e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds)) != hipSuccess) return fail(e, "hipFuncSetAttribute");
   }
   for (auto& row : c->ev) for (auto& ev : row) if ((e = hipEventCreate(&ev)) != hipSuccess) return fail(e, "hipEventCreate");
   *out = c;
@@ -453,13 +459,13 @@ void s4p_destroy(s4p_ctx* c) {
   (void)hipSetDevice(c->device);
   for (auto& L : c->lane) if (L.stream) (void)hipStreamSynchronize(L.stream);
   c->greach.free(); c->glist_hdr.free(); c->gnbr.free();
-  c->gcoarse.free(); c->q4.free(); c->q4v.free();
+  c->gcoarse.free(); c->q4.free(); c->q4v.free(); c->qquant.free();
   c->qx.free(); c->qy.free(); c->qz.free(); c->ux.free(); c->uy.free(); c->uz.free();
   c->qnx.free(); c->qny.free(); c->qnz.free(); c->qcr.free(); c->qcg.free(); c->qcb.free();
   for (auto& L : c->lane) {
     L.ab1.free(); L.ab2.free(); L.okey1.free(); L.okey2.free(); L.cell1.free(); L.cell2.free();
     L.bucket1.free(); L.next1.free(); L.mask2.free(); L.ew1.free(); L.ew2.free();
-    L.quads.free(); L.tags.free(); L.counts.free(); L.cand_idx.free(); L.cand_T.free(); L.ht_keys.free(); L.ht_heads.free(); L.ctr.free(); L.slots.free();
+    L.quads.free(); L.tags.free(); L.counts.free(); L.cand_idx.free(); L.cand_cnt.free(); L.cand_T.free(); L.ht_keys.free(); L.ht_heads.free(); L.ctr.free(); L.slots.free();
     for (int s = 0; s < 2; ++s) L.seq[s].free();
   }
   for (auto& h : c->hctr) h.free();
@@ -579,6 +585,35 @@ int32_t s4p_set_clouds(s4p_ctx* c, const float* px, const float* py, const float
     for (int64_t i = 0; i < n_q; ++i) qv[size_t(i)] = q4[ord[size_t(i)]];
     HIPCHK(c, c->q4v.alloc(size_t(n_q)));
     HIPCHK(c, hipMemcpy(c->q4v.p, qv.data(), size_t(n_q) * sizeof(float4), hipMemcpyHostToDevice));
+    // 16-bit quantisation of the same points over their bounding box, for the sweep's LDS copy (s4p_kernels.hip.hpp,
+    // "LCP scoring").  Used when the sample fits the LDS budget and half a quantisation step stays below 0.004 cell
+    // (the structure's slack is 0.01 cell); otherwise the sweep reads the float points from global memory.
+    float lo[3] = {qv[0].x, qv[0].y, qv[0].z}, hi[3] = {qv[0].x, qv[0].y, qv[0].z};
+    for (const float4& p : qv) {
+      lo[0] = std::min(lo[0], p.x); hi[0] = std::max(hi[0], p.x);
+      lo[1] = std::min(lo[1], p.y); hi[1] = std::max(hi[1], p.y);
+      lo[2] = std::min(lo[2], p.z); hi[2] = std::max(hi[2], p.z);
+    }
+    bool fine_enough = true;
+    for (int k = 0; k < 3; ++k) {
+      c->qq.lo[k] = lo[k];
+      c->qq.step[k] = (hi[k] > lo[k]) ? (hi[k] - lo[k]) / 65535.0f : 1.0f;
+      if (!(0.5f * c->qq.step[k] * c->hgrid.inv_h < 0.004f)) fine_enough = false;
+    }
+    c->qlds = fine_enough && n_q <= int64_t(kLdsQueries) && getenv("S4P_NO_QLDS") == nullptr;
+    std::vector<uint2> packed((size_t)n_q);
+    for (int64_t i = 0; i < n_q; ++i) {
+      uint32_t u[3];
+      const float v[3] = {qv[size_t(i)].x, qv[size_t(i)].y, qv[size_t(i)].z};
+      for (int k = 0; k < 3; ++k) {
+        const double t = std::floor((double(v[k]) - double(lo[k])) / double(c->qq.step[k]) + 0.5);
+        u[k] = uint32_t(std::min(65535.0, std::max(0.0, t)));
+      }
+      packed[size_t(i)] = make_uint2(u[0] | (u[1] << 16), u[2]);
+    }
+    HIPCHK(c, c->qquant.alloc(size_t(n_q)));
+    HIPCHK(c, hipMemcpy(c->qquant.p, packed.data(), size_t(n_q) * sizeof(uint2), hipMemcpyHostToDevice));
+    c->qq.packed = c->qquant.p;
   }
   auto up = [&](DevBuf<float>& d, const float* src) -> hipError_t {
     hipError_t e = d.alloc(n_q); if (e != hipSuccess) return e;
@@ -727,13 +762,15 @@ int32_t verify_transforms_impl(s4p_ctx* c, const float* T, int64_t B, uint32_t* 
   do {
     if (stats4) { if ((rc = reset_counters(c)) != S4P_OK) break; L.dirty = true; }
     if ((e = hipMemcpyAsync(dT.p, T, size_t(B) * 64, hipMemcpyHostToDevice, L.stream)) != hipSuccess) break;
+    if ((e = hipMemsetAsync(dC.p, 0, size_t(B) * 4, L.stream)) != hipSuccess) break;       // counts are accumulated atomically
     VerifyTParams V{};
-    V.grid = c->dev_grid(); V.q4 = c->q4v.p; V.n_q = c->n_q; V.T = dT.p; V.B = uint32_t(B);
+    V.grid = c->dev_grid(); V.q4 = c->q4v.p; V.qq = c->qq; V.n_q = c->n_q; V.T = dT.p; V.B = uint32_t(B);
     V.counts = dC.p; V.ctr = L.ctr.p;
     const uint32_t wpb = kVerifyThreads / 64;
-    const uint32_t blocks = uint32_t(std::min<int64_t>((B + wpb - 1) / wpb, 512));
-    if (stats4) hipLaunchKernelGGL(k_verify_T<true>, dim3(blocks), dim3(kVerifyThreads), c->verify_lds_bytes(), L.stream, V);
-    else hipLaunchKernelGGL(k_verify_T<false>, dim3(blocks), dim3(kVerifyThreads), c->verify_lds_bytes(), L.stream, V);
+    const uint32_t blocks = uint32_t(std::max<int64_t>(std::min<int64_t>((B + wpb - 1) / wpb, 512), (B + 65534) / 65535));   // slices < 65536 transforms
+    const size_t lds = c->verify_lds_bytes();
+    if (stats4) { if (c->qlds) hipLaunchKernelGGL((k_verify_T<true, true>), dim3(blocks), dim3(kVerifyThreads), lds, L.stream, V); else hipLaunchKernelGGL((k_verify_T<true, false>), dim3(blocks), dim3(kVerifyThreads), lds, L.stream, V); }
+    else { if (c->qlds) hipLaunchKernelGGL((k_verify_T<false, true>), dim3(blocks), dim3(kVerifyThreads), lds, L.stream, V); else hipLaunchKernelGGL((k_verify_T<false, false>), dim3(blocks), dim3(kVerifyThreads), lds, L.stream, V); }
     if ((e = hipGetLastError()) != hipSuccess) break;
     if ((e = hipMemcpyAsync(counts, dC.p, size_t(B) * 4, hipMemcpyDeviceToHost, L.stream)) != hipSuccess) break;
     if (stats4 && (e = hipMemcpyAsync(c->hctr[c->cur].p, L.ctr.p, sizeof(DevCounters), hipMemcpyDeviceToHost, L.stream)) != hipSuccess) break;

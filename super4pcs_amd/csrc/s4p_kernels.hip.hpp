@@ -87,15 +87,9 @@ struct LcpGrid {
   float sq_eps;                 // fl(delta*delta)
 };
 
-// The sweep takes four 64-query chunks per step (S4P_SWEEP_PIPE = 0, the measured best) or two, software-pipelined three
-// deep (S4P_SWEEP_PIPE = 1: next step's query loads and this step's reach gathers in flight while the previous step is
-// consumed -- measured no faster: the kernel is not waiting on the sweep's loads).
-#ifndef S4P_SWEEP_PIPE
-#define S4P_SWEEP_PIPE 0
-#endif
-constexpr int kQueueEntries = S4P_SWEEP_PIPE ? 192 : 320;     // per-wave survivor queue ({query, rank}, 8 B): 63 left over + one step
-constexpr int kQueueWordsPerWave = 2 * kQueueEntries + 64;    // in 32-bit words: the queue + the 256 B item-owner table (S4P_FINE_FLAT = 2)
-constexpr int kCoarseMaxWords = S4P_SWEEP_PIPE ? 12288 : 8704;   // 48 / 34 KB: + 16 x 1.75 / 2.75 KB of queues, two workgroups per CU (160 KB)
+constexpr int kQueueEntries = 192;                 // per-wave survivor queue (8 B entries): 63 left over + one step of 2 x 64
+constexpr int kQueueWordsPerWave = 2 * kQueueEntries;     // in 32-bit words (1.5 KB)
+constexpr int kCoarseMaxWords = 9216;              // 36 KB: + 20 KB of queries + 16 x 1.5 KB of queues = 80 KB, two workgroups per CU
 
 // value held by every lane of the wave -> SGPR
 __device__ __forceinline__ float wave_uniform(float v) {
@@ -114,7 +108,7 @@ __device__ __forceinline__ void transform_point(const float* T, const float4 q, 
 // transform, subtract origin, scale", and that is what stage 1 spends most of its time on.  It only LOCATES the query:
 // the result may differ from the exactly rounded cell coordinate by ~1e-5 cell, which the structure absorbs by
 // construction (a cell lists every P point within 1.01*delta of its box, LcpGridHost::plan; the 4x4x4 sub-cell masks
-// carry the same 1 % slack).  The inlier predicate itself (fine_batch) uses the exact, un-fused transform_point.
+// carry the same 1 % slack).  The inlier predicate itself (exact_batch) uses the exact, un-fused transform_point.
 // Only the coarse copy lives across the query loop (12 registers); the exact 3x4 and the fine-unit transform are
 // re-derived from the candidate's record where the dense stages need them -- keeping all 36 values live cost ~25 % of
 // the loop's instructions in scalar-register spills.
@@ -291,185 +285,143 @@ __global__ __launch_bounds__(256) void k_build_masks(MaskParams P) {
   P.list_hdr[r] = hdr;
 }
 
-// Exact stage for one batch of up to 64 queued queries (lane = query; `valid` lanes hold an entry {query i, rank of its
-// reachable cell}): L2 (list header + 4x4x4 sub-cell mask), then the exact inlier predicate against the listed points
-// (kdtree.h:417-421: sqdist <= cl_dist).  The exact 3x4 is re-read from the candidate's record (three broadcast loads)
-// instead of being kept in scalar registers across the query sweep.
-// Two formulations of the point loop, selected at build time (measured against each other):
-//   S4P_FINE_FLAT = 0  lane-per-query: every lane walks its own list, two 16-byte loads per dependent step; the batch
-//                      takes as long as its longest list, ~20 instructions per step;
-//   S4P_FINE_FLAT = 1  the (query, point) pairs of the batch are flattened -- inclusive prefix over the list lengths, pair
-//                      lane j finds its owner by a binary search over the prefix with cross-lane reads -- so every
-//                      64-lane gather tests 64 real pairs: a quarter of the gathers, ~90 instructions per round, but six
-//                      dependent LDS round trips per round;
-//   S4P_FINE_FLAT = 2  work items of FOUR consecutive list points: every query writes its lane id once per item into a
-//                      byte table in LDS (s_own), item lane j reads its owner there, fetches the owner's transformed
-//                      point and list range by cross-lane reads and tests four points loaded back to back.  A batch
-//                      takes ~2 rounds with ONE memory wait each instead of ~13 dependent steps: the point loop was
-//                      ~40 of the ~60 dependent memory waits of a candidate, and waves sat in s_waitcnt 60 % of the time.
-#ifndef S4P_FINE_FLAT
-#define S4P_FINE_FLAT 0
-#endif
-constexpr int kOwnItems = 192;                     // per-wave item-owner table (S4P_FINE_FLAT = 2): 192 B + 64 B of hit flags
-template <bool COUNT>
-__device__ __forceinline__ bool fine_batch(const LcpGrid& g, const float4* q4, const float4* Tsrc, bool valid,
-                                           uint32_t i, uint32_t rank, unsigned long long* point_tests, uint8_t* s_own) {
+// ---------------------------------------------------------------------------
+// LCP scoring: Verify() (match4pcsBase.cc:508-567) without the early exit.
+//
+// What bounds this kernel (profiles/r02_*): not instruction issue (-14 % VALU: -2 % time), not the latency of the sweep's
+// loads (software-pipelining them: no change), not the number of dependent steps of the exact stage (a quarter of them:
+// slower), not the wave-level work granularity (1/2/4/8 items per candidate: same time) -- but the L2 -> L1 line traffic:
+// 20 M line requests per launch, 1350 per candidate, of which ~500 were the 32 KB query array that every wave re-streams
+// for every candidate through a 32 KB L1 it shares with the gathers.  Hence:
+//   * the sampled-Q points the SWEEP reads live in LDS, quantised to 3 x 16 bit over Q's bounding box (8 B per query,
+//     16 KB for n_Q = 2000): no global traffic for the sweep's queries at all.  The sweep only LOCATES a query; the
+//     quantisation moves it by < 2e-3 cell, inside the 1 % slack the structure is built with (LcpGridHost::plan).  The
+//     exact stage still reads the exact float query for the inlier predicate, and uses the SAME quantised value for
+//     the cell, so both stages agree bit for bit.  Clouds whose sample does not fit (n_Q > kLdsQueries) or whose extent
+//     needs more than 16 bits keep the float array in global memory (QLDS = false).
+//   * the survivor queue keeps the cell's rank (8 B entries), so the exact stage does not gather the reach word again;
+//   * the queue persists across candidates, so exact-stage batches are always full (3.3 per candidate instead of 3 + 1).
+//
+// Per wave:
+//   sweep of a candidate (two 64-query chunks per step): position in grid units (3 converts + 9 fma + 3 floor-converts),
+//     L0 test of the cell's coarse cube against the LDS bitmap, L1 reach word (8 B gather; rejected lanes read word 0,
+//     one broadcast line); queries whose cell is reachable are compacted (ballot/prefix) into the wave's LDS queue as
+//     {query | candidate << 16, rank of the cell among the reachable ones};
+//   exact stage whenever 64 entries wait (and once at the end): lane per entry -- the candidate's exact 3x4, list header,
+//     4x4x4 sub-cell mask, then the exact predicate sqdist <= delta^2 (kdtree.h:417-421) against the listed points, two
+//     16-byte loads per dependent step; hits are counted per candidate with one atomic per (batch, candidate).
+// A workgroup owns a contiguous slice of candidates, so when its waves are done its candidates' counts are final and it
+// can reduce them to its best (count, then smallest tag = first in reference order) without any grid-wide step.
+// ---------------------------------------------------------------------------
+constexpr int kLdsQueries = 2560;                  // sampled-Q points that fit the LDS copy (20 KB)
+
+struct QuantQ {                  // 16-bit fixed point over the bounding box of the sampled Q (centred coordinates)
+  float lo[3], step[3];          // q~ = lo + step * u, u in [0, 65535]
+  const uint2* packed;           // per query (sweep order): {x | y << 16, z}
+};
+
+struct LcpTask {                 // what the scoring loop needs besides the grid
+  const float4* q4;              // sampled Q (centred), packed (x,y,z,0), in the order of the sweep
+  uint32_t n_q;
+  QuantQ qq;                     // (QLDS kernels)
+  const float4* T;               // candidate transforms: row-major 3x4 at T + t_stride * candidate
+  uint32_t t_stride;             // in float4: 3 (cand_T records) or 4 (caller's 4x4 matrices)
+  uint32_t* cand_cnt;            // per candidate: inlier count, accumulated atomically (zero on entry)
+  unsigned long long* point_tests;   // instrumentation (COUNT kernels only)
+};
+
+// The locating transform of a candidate: grid units, and for QLDS folded with the de-quantisation
+// (X * (lo + step * u) + t = (X * diag(step)) * u + (X * lo + t)), so a query costs 3 converts + 9 fma + 3 floor-converts.
+template <bool QLDS>
+__device__ __forceinline__ GridXf locating_xf(const LcpGrid& g, const LcpTask& K, const float* T) {
+  GridXf X = make_grid_xf(g, T, 1.f);
+  if (QLDS) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const float t = __builtin_fmaf(X.u[4 * r], K.qq.lo[0], __builtin_fmaf(X.u[4 * r + 1], K.qq.lo[1], __builtin_fmaf(X.u[4 * r + 2], K.qq.lo[2], X.u[4 * r + 3])));
+      X.u[4 * r] *= K.qq.step[0]; X.u[4 * r + 1] *= K.qq.step[1]; X.u[4 * r + 2] *= K.qq.step[2];
+      X.u[4 * r + 3] = t;
+    }
+  }
+  return X;
+}
+// the sweep's view of query i: quantised coordinates as floats (QLDS) or the float point itself
+template <bool QLDS>
+__device__ __forceinline__ float4 sweep_query(const LcpTask& K, const uint2* s_q, const uint32_t i) {
+  if (QLDS) {
+    const uint2 w = s_q[i];
+    return make_float4(float(w.x & 0xFFFFu), float(w.x >> 16), float(w.y), 0.f);
+  }
+  return K.q4[i];
+}
+
+// Exact stage for the top n (<= 64) queue entries: lane = entry {query i, candidate ci, rank of the query's cell}.
+template <bool COUNT, bool QLDS>
+__device__ __forceinline__ void exact_batch(const LcpGrid& g, const LcpTask& K, const uint2* s_q, const bool valid,
+                                            const uint32_t i, const uint32_t ci, const uint32_t rank) {
   const uint32_t lane = threadIdx.x & 63u;
-  float tx = 0.f, ty = 0.f, tz = 0.f;
-  uint32_t s = 0, len = 0;
+  bool hit = false;
   if (valid) {
     const uint4 hdr = g.list_hdr[rank];
-    const float4 q = q4[i];
     float T[12];
-    load_rows(Tsrc, T);
+    load_rows(K.T + size_t(K.t_stride) * ci, T);
+    const float4 q = K.q4[i];
+    float tx, ty, tz;
     transform_point(T, q, tx, ty, tz);                          // exact (reference order, no fma)
     int ix, iy, iz;
-    grid_cell(make_grid_xf(g, T, 1.f).u, q, ix, iy, iz);        // the cell the sweep put this query in
-    // sub-cell of the exact point inside THAT cell, clamped (the exact point can sit ~1e-5 cell outside it)
+    grid_cell(locating_xf<QLDS>(g, K, T).u, sweep_query<QLDS>(K, s_q, i), ix, iy, iz);   // the cell the sweep put this query in
+    // sub-cell of the exact point inside THAT cell, clamped (the exact point can sit a few 1e-3 cell outside it)
     const float rx = (tx - g.ox) * g.inv_h - float(ix), ry = (ty - g.oy) * g.inv_h - float(iy), rz = (tz - g.oz) * g.inv_h - float(iz);
     const uint32_t sx = uint32_t(min(max(int(rx * 4.f), 0), 3)), sy = uint32_t(min(max(int(ry * 4.f), 0), 3)),
                    sz = uint32_t(min(max(int(rz * 4.f), 0), 3));
     const uint32_t sb = sz * 16u + sy * 4u + sx;
     const uint32_t mword = sb < 32u ? hdr.z : hdr.w;
-    if ((mword >> (sb & 31u)) & 1u) { s = hdr.x; len = hdr.y; }
-  }
-  if (COUNT) {
-    const unsigned long long l2 = __ballot(len != 0u);
-    uint32_t tot = len;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
-    if (lane == 0) { atomicAdd(point_tests + 3, (unsigned long long)__popcll(l2)); atomicAdd(point_tests, (unsigned long long)tot); }
-  }
-#if S4P_FINE_FLAT == 2
-  const uint32_t cnt4 = (len + 3u) >> 2;           // this query's items
-  uint32_t incl = cnt4;                            // inclusive prefix of the item counts over the wave
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const uint32_t up = uint32_t(__shfl_up(int(incl), o));
-    if (lane >= uint32_t(o)) incl += up;
-  }
-  const uint32_t excl = incl - cnt4;
-  const uint32_t total = uint32_t(__builtin_amdgcn_readlane(int(incl), 63));
-  uint8_t* s_hit = s_own + kOwnItems;              // one flag per query of the batch
-  s_hit[lane] = 0;
-  for (uint32_t wbase = 0; wbase < total; wbase += uint32_t(kOwnItems)) {       // (one window unless the lists are very long)
-    for (uint32_t k = 0; __ballot(k < cnt4) != 0ull; ++k) {
-      const uint32_t pos = excl + k - wbase;       // (wraps for items before the window)
-      if (k < cnt4 && pos < uint32_t(kOwnItems)) s_own[pos] = uint8_t(lane);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    const uint32_t wend = min(total - wbase, uint32_t(kOwnItems));
-    for (uint32_t base = 0; base < wend; base += 64u) {
-      const uint32_t j = base + lane;              // item within the window
-      const bool live = j < wend;
-      const uint32_t owner = live ? uint32_t(s_own[j]) : 0u;
-      // the owner's list range and transformed point by cross-lane reads: issued by ALL lanes (a ds_bpermute only
-      // delivers data of lanes that are active when it executes, and the owner of a live item may be any lane)
-      const uint32_t o_excl = uint32_t(__shfl(int(excl), int(owner)));
-      const uint32_t o_len = uint32_t(__shfl(int(len), int(owner)));
-      const uint32_t o_s = uint32_t(__shfl(int(s), int(owner)));
-      const float ox = __shfl(tx, int(owner)), oy = __shfl(ty, int(owner)), oz = __shfl(tz, int(owner));
-      if (live) {
-        const uint32_t first = o_s + 4u * (wbase + j - o_excl), lastp = o_s + o_len - 1u;
-        const float4 pa = g.nbr[first];
-        const float4 pb = g.nbr[min(first + 1u, lastp)];
-        const float4 pc = g.nbr[min(first + 2u, lastp)];
-        const float4 pd = g.nbr[min(first + 3u, lastp)];
-        const bool ha = sqn3(ox - pa.x, oy - pa.y, oz - pa.z) <= g.sq_eps, hb = sqn3(ox - pb.x, oy - pb.y, oz - pb.z) <= g.sq_eps;
-        const bool hc = sqn3(ox - pc.x, oy - pc.y, oz - pc.z) <= g.sq_eps, hd = sqn3(ox - pd.x, oy - pd.y, oz - pd.z) <= g.sq_eps;
-        if (ha || hb || hc || hd) s_hit[owner] = 1;   // (several items of one query may write the same 1)
+    if ((mword >> (sb & 31u)) & 1u) {
+      if (COUNT) { atomicAdd(K.point_tests + 3, 1ull); atomicAdd(K.point_tests, (unsigned long long)hdr.y); }   // l2_pass, listed points
+      const uint32_t e = hdr.x + hdr.y;
+      for (uint32_t p = hdr.x; p < e; p += 2) {                 // two independent 16 B loads per dependent step (four: slower)
+        const float4 pa = g.nbr[p];
+        const float4 pb = g.nbr[min(p + 1u, e - 1u)];          // (predicating this load away on odd tails was measured slower)
+        const bool ha = sqn3(tx - pa.x, ty - pa.y, tz - pa.z) <= g.sq_eps;
+        const bool hb = sqn3(tx - pb.x, ty - pb.y, tz - pb.z) <= g.sq_eps;
+        if (ha | hb) { hit = true; break; }
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
   }
-  const bool hit = s_hit[lane] != 0;
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  return hit;
-#elif S4P_FINE_FLAT == 1
-  // inclusive prefix of the list lengths over the wave
-  uint32_t incl = len;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const uint32_t up = uint32_t(__shfl_up(int(incl), o));
-    if (lane >= uint32_t(o)) incl += up;
+  // hits per candidate: the entries of a batch belong to one to three consecutive candidates
+  unsigned long long todo = __ballot(valid);
+  const unsigned long long hits = __ballot(hit);
+  while (todo) {
+    const int leader = __builtin_ctzll(todo);
+    const uint32_t cv = uint32_t(__builtin_amdgcn_readlane(int(ci), leader));
+    const unsigned long long same = __ballot(valid && ci == cv);
+    const uint32_t n = uint32_t(__popcll(hits & same));
+    if (n != 0u && lane == uint32_t(leader)) atomicAdd(K.cand_cnt + cv, n);
+    todo &= ~same;
   }
-  const uint32_t total = uint32_t(__builtin_amdgcn_readlane(int(incl), 63));
-  unsigned long long hitmask = 0ull;               // wave-uniform: bit L = the query of lane L has an inlier
-  for (uint32_t base = 0; base < total; base += 64u) {
-    const uint32_t j = base + lane;                // this lane's (query, point) pair
-    // owner = number of lanes whose inclusive prefix is <= j (the prefix is non-decreasing): lower-bound search
-    uint32_t lo = 0u, hi = 63u;                    // j < total, so the owner is one of the 64 lanes
-#pragma unroll
-    for (int it = 0; it < 6; ++it) {               // 64 -> 1 in six halvings
-      const uint32_t mid = (lo + hi) >> 1;
-      const uint32_t v = uint32_t(__shfl(int(incl), int(mid)));
-      if (v <= j) lo = mid + 1u; else hi = mid;
-    }
-    const uint32_t owner = min(lo, 63u);
-    const uint32_t o_incl = uint32_t(__shfl(int(incl), int(owner)));
-    const uint32_t o_len = uint32_t(__shfl(int(len), int(owner)));
-    const uint32_t o_s = uint32_t(__shfl(int(s), int(owner)));
-    const float ox = __shfl(tx, int(owner)), oy = __shfl(ty, int(owner)), oz = __shfl(tz, int(owner));
-    bool h = false;
-    if (j < total) {
-      const float4 p = g.nbr[o_s + (j - (o_incl - o_len))];
-      h = sqn3(ox - p.x, oy - p.y, oz - p.z) <= g.sq_eps;
-    }
-    unsigned long long hb = __ballot(h);
-    while (hb) {                                   // scalar loop over the (few) hits of this round
-      const int l = __builtin_ctzll(hb);
-      hb &= hb - 1ull;
-      hitmask |= 1ull << uint32_t(__builtin_amdgcn_readlane(int(owner), l));
-    }
-  }
-  return ((hitmask >> lane) & 1ull) != 0ull;
-#else
-  const uint32_t e = s + len;
-  for (uint32_t p = s; p < e; p += 2) {                       // two independent 16 B loads per dependent step (four: slower)
-    const float4 pa = g.nbr[p];
-    const float4 pb = g.nbr[min(p + 1u, e - 1u)];            // (predicating this load away on odd tails was measured slower)
-    const bool ha = sqn3(tx - pa.x, ty - pa.y, tz - pa.z) <= g.sq_eps;
-    const bool hb = sqn3(tx - pb.x, ty - pb.y, tz - pb.z) <= g.sq_eps;
-    if (ha | hb) return true;
-  }
-  return false;
-#endif
 }
 
-// Number of sampled-Q points that T brings within delta of a sampled-P point: Verify()
-// (match4pcsBase.cc:508-567) without the early exit, for one wave64.
-//   s_coarse : LDS copy of the coarse bitmap (workgroup-shared)
-//   s_queue  : this wave's private LDS queue ({query index, reachable-cell rank}, kQueueEntries entries)
-// Sweep (every query, four 64-query chunks per step):
-//   position in grid units (9 fma + 3 floor-converts: GridXf), L0 test of the cell's coarse cube against the LDS
-//   bitmap, then the L1 reach word (8 B gather; rejected lanes read word 0, one broadcast line); queries whose cell is
-//   reachable are compacted by ballot/prefix into the queue together with the cell's rank among the reachable ones.
-// Exact stage (fine_batch) whenever 64 entries wait, and once more for the rest.
-// The kernel is instruction-issue bound (SQ busy ~99 % in the round-1 profile), so the sweep is kept to the bone: the
-// round-1 version spent ~75 instructions per 64 queries here (exact transform, subtract origin, scale, floor, convert,
-// two index computations with a run-time 24-bit select), this one ~50.
-template <bool COUNT, bool SKIP_FINE = false>
-__device__ __forceinline__ uint32_t wave_lcp_count(const LcpGrid& g, const uint32_t* s_coarse, uint2* s_queue,
-                                                   const float4* q4, uint32_t n_q, const float4* Tsrc,
-                                                   unsigned long long* point_tests) {
+// The scoring loop of one wave over the candidates [cand_lo + *s_next .. cand_hi) of its workgroup (drawn from the LDS
+// counter).  s_coarse: LDS copy of the coarse bitmap; s_q: LDS copy of the quantised queries (QLDS); s_queue: this
+// wave's private LDS queue (kQueueEntries entries).
+template <bool COUNT, bool SKIP_FINE, bool QLDS>
+__device__ __forceinline__ void wave_score(const LcpGrid& g, const LcpTask& K, const uint32_t* s_coarse, const uint2* s_q,
+                                           uint2* s_queue, uint32_t* s_next, const uint32_t cand_lo, const uint32_t cand_hi) {
   constexpr uint32_t kNone = 0xFFFFFFFFu;
   const uint32_t lane = threadIdx.x & 63u;
-  uint32_t cnt = 0, qn = 0;
+  uint32_t qn = 0;
   const uint32_t cmax = g.coarse_words * 32u - 1u;
   const uint32_t unx = uint32_t(g.nx), uny = uint32_t(g.ny), unz = uint32_t(g.nz);
   const uint32_t ucx = uint32_t(g.cnx), ucy = uint32_t(g.cny);
-  GridXf X;                                              // fine-cell units: the only transform live across the sweep
-  { float T[12]; load_rows(Tsrc, T); X = make_grid_xf(g, T, 1.f); }
-  // cell of query i under T, or kNone if it falls outside the grid or into a coarse cube nothing can reach
-  // (float -> int conversion saturates and one unsigned compare per axis covers both bounds; a NaN coordinate maps to
-  // cell 0 and then fails every exact distance test, so it cannot create an inlier)
+  GridXf X;                                              // locating transform of the current candidate
+  uint32_t cl = 0, q_at = K.n_q;                         // current candidate (relative to cand_lo), next query
+  // cell of query i under the current candidate, or kNone if it falls outside the grid or into a coarse cube nothing
+  // can reach (float -> int conversion saturates and one unsigned compare per axis covers both bounds; a NaN coordinate
+  // maps to cell 0 and then fails every exact distance test, so it cannot create an inlier)
   auto locate = [&](const float4 q, const uint32_t i) -> uint32_t {
     int ix, iy, iz;
     grid_cell(X.u, q, ix, iy, iz);
-    const bool inb = (uint32_t(ix) < unx) & (uint32_t(iy) < uny) & (uint32_t(iz) < unz) & (i < n_q);
+    const bool inb = (uint32_t(ix) < unx) & (uint32_t(iy) < uny) & (uint32_t(iz) < unz) & (i < K.n_q);
     const uint32_t cc = min(mad24(mad24(uint32_t(iz) >> g.cshift, ucy, uint32_t(iy) >> g.cshift), ucx, uint32_t(ix) >> g.cshift), cmax);
     const uint32_t bit = (s_coarse[cc >> 5] >> (cc & 31u)) & 1u;
     // 24-bit multiplies are full rate (a 32-bit v_mul_lo is not); LcpGridHost::plan keeps nx and ny*nz below 2^24
@@ -484,84 +436,58 @@ __device__ __forceinline__ uint32_t wave_lcp_count(const LcpGrid& g, const uint3
     const unsigned long long m = __ballot(reach);
     if (COUNT) {
       const unsigned long long m0 = __ballot(c != kNone);
-      if (lane == 0) { atomicAdd(point_tests + 1, (unsigned long long)__popcll(m0)); atomicAdd(point_tests + 2, (unsigned long long)__popcll(m)); }
+      if (lane == 0) { atomicAdd(K.point_tests + 1, (unsigned long long)__popcll(m0)); atomicAdd(K.point_tests + 2, (unsigned long long)__popcll(m)); }
     }
     if (m == 0ull) return;
     if (reach) s_queue[qn + __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u))] =
-        make_uint2(i, w.y + uint32_t(__popc(w.x & ((1u << sh) - 1u))));
+        make_uint2(i | (cl << 16), w.y + uint32_t(__popc(w.x & ((1u << sh) - 1u))));
     qn += uint32_t(__popcll(m));
   };
-  // exact stage on the top n (<= 64) entries of the queue: ONE code site (inlined at every push it was 16 KB of code)
-  auto drain = [&](const uint32_t n) {
-    const bool valid = lane < n;
-    const uint2 e = s_queue[qn - n + min(lane, n - 1u)];
-    if (SKIP_FINE) cnt += uint32_t(valid && e.y == kNone);
-    else cnt += fine_batch<COUNT>(g, q4, Tsrc, valid, e.x, e.y, point_tests, reinterpret_cast<uint8_t*>(s_queue + kQueueEntries)) ? 1u : 0u;
-    qn -= n;
-    lds_fence();
-  };
-#if S4P_SWEEP_PIPE
-  // Software pipeline over steps of two chunks (128 queries): while step t is located and its reach words are requested,
-  // the query loads of step t+1 are already in flight and the reach words of step t-1 are consumed.  A wave thus never
-  // waits for a load it has just issued; in the round-1 kernel every step exposed two dependent round trips (query ->
-  // reach word), 16 of the ~40 memory waits of a candidate, and waves spent 60 % of their cycles in s_waitcnt.
-  const uint32_t last = n_q - 1u;
-  const uint32_t steps = (n_q + 127u) >> 7;
-  float4 qa = q4[min(lane, last)], qb = q4[min(lane + 64u, last)];           // step 0
-  uint32_t pc0 = kNone, pc1 = kNone, pi = 0;                                  // step t-1: cells, first query index
-  uint2 pw0 = make_uint2(0u, 0u), pw1 = make_uint2(0u, 0u);
-  for (uint32_t t = 0;; ++t) {
-    const bool more = t < steps;                         // wave-uniform
-    uint32_t c0 = kNone, c1 = kNone;
-    uint2 w0 = make_uint2(0u, 0u), w1 = make_uint2(0u, 0u);
-    const uint32_t i0 = (t << 7) + lane;
-    if (more) {
-      const float4 q0 = qa, q1 = qb;
-      const uint32_t n0 = i0 + 128u;
-      qa = q4[min(n0, last)]; qb = q4[min(n0 + 64u, last)];                   // step t+1 (clamped re-reads past the end)
-      c0 = locate(q0, i0); c1 = locate(q1, i0 + 64u);
-      // reach words of the L0 survivors; rejected lanes read word 0 (one broadcast line)
-      w0 = g.reach[c0 == kNone ? 0u : c0 >> 5];
-      w1 = g.reach[c1 == kNone ? 0u : c1 >> 5];
+  bool flush = false;
+  while (true) {
+    if (q_at >= K.n_q && !flush) {                       // (wave-uniform) next candidate
+      uint32_t nxt = 0;
+      if (lane == 0) nxt = atomicAdd(s_next, 1u);
+      nxt = uint32_t(__builtin_amdgcn_readfirstlane(int(nxt)));
+      if (cand_lo + nxt >= cand_hi) flush = true;
+      else {
+        cl = nxt;
+        q_at = 0;
+        float T[12];
+        load_rows(K.T + size_t(K.t_stride) * (cand_lo + cl), T);
+        X = locating_xf<QLDS>(g, K, T);
+      }
     }
-    if (t != 0u) {                                        // consume step t-1
-      push(pc0, pw0, pi); push(pc1, pw1, pi + 64u);
-      lds_fence();
-    }
-    pc0 = c0; pc1 = c1; pw0 = w0; pw1 = w1; pi = i0;
-    // full batches as they become available (the queue holds 63 + 2 * 64 entries), the partial one after the last step
-    while (qn >= 64u || (!more && qn != 0u)) drain(min(qn, 64u));
-    if (!more) break;
-  }
-#else
-  // Four chunks per step: four query loads, then four reach-word gathers in flight.
-  const uint32_t last = n_q - 1u;
-  for (uint32_t base = 0;; base += 256u) {
-    const bool more = base < n_q;                        // wave-uniform
-    if (more) {
-      const uint32_t i0 = base + lane, i1 = i0 + 64u, i2 = i0 + 128u, i3 = i0 + 192u;
-      const float4 q0 = q4[min(i0, last)];
-      const float4 q1 = q4[min(i1, last)];
-      const float4 q2 = q4[min(i2, last)];
-      const float4 q3 = q4[min(i3, last)];
-      const uint32_t c0 = locate(q0, i0), c1 = locate(q1, i1), c2 = locate(q2, i2), c3 = locate(q3, i3);
+    if (!flush) {                                        // one step: two chunks, their reach gathers in flight together
+      const uint32_t last = K.n_q - 1u;
+      const uint32_t i0 = q_at + lane, i1 = i0 + 64u;
+      const float4 q0 = sweep_query<QLDS>(K, s_q, min(i0, last));
+      const float4 q1 = sweep_query<QLDS>(K, s_q, min(i1, last));
+      const uint32_t c0 = locate(q0, i0), c1 = locate(q1, i1);
       // reach words of the L0 survivors; rejected lanes read word 0 (one broadcast line)
       const uint2 w0 = g.reach[c0 == kNone ? 0u : c0 >> 5];
       const uint2 w1 = g.reach[c1 == kNone ? 0u : c1 >> 5];
-      const uint2 w2 = g.reach[c2 == kNone ? 0u : c2 >> 5];
-      const uint2 w3 = g.reach[c3 == kNone ? 0u : c3 >> 5];
-      push(c0, w0, i0); push(c1, w1, i1); push(c2, w2, i2); push(c3, w3, i3);
+      push(c0, w0, i0); push(c1, w1, i1);
+      lds_fence();
+      q_at += 128u;
+    }
+    // exact stage: full batches as they become available (the queue holds 63 + 2 * 64 entries), the rest at the very end
+    while (qn >= 64u || (flush && qn != 0u)) {
+      const uint32_t n = min(qn, 64u);
+      const bool valid = lane < n;
+      const uint2 e = s_queue[qn - n + min(lane, n - 1u)];
+      if (!SKIP_FINE) exact_batch<COUNT, QLDS>(g, K, s_q, valid, e.x & 0xFFFFu, cand_lo + (e.x >> 16), e.y);
+      qn -= n;
       lds_fence();
     }
-    // full batches as they become available (the queue holds 63 + 4 * 64 entries), the partial one after the last chunk
-    while (qn >= 64u || (!more && qn != 0u)) drain(min(qn, 64u));
-    if (!more) break;
+    if (flush) break;
   }
-#endif
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
-  __builtin_amdgcn_wave_barrier();
-  return cnt;
+}
+
+// Global -> LDS copy of the quantised queries (8 B each), padded to a multiple of 128 with the last entry
+__device__ __forceinline__ void stage_queries(const LcpTask& K, uint2* s_q) {
+  const uint32_t n_pad = (K.n_q + 127u) & ~127u;
+  for (uint32_t w = threadIdx.x; w < n_pad; w += blockDim.x) s_q[w] = K.qq.packed[min(w, K.n_q - 1u)];
 }
 
 // Global -> LDS copy of the coarse bitmap: 16 B per lane and four independent loads in flight per thread (a
@@ -808,7 +734,7 @@ __global__ __launch_bounds__(256) void k_prep(PrepParams P1, PrepParams P2) {
 // its slot range.  As the reference does, a primitive first tests the leaf BOX (:205) and only the points of leaves
 // its sphere touches are examined (:208-220), so the work is (primitives x touched leaves x their points), not n_Q^2.
 // One wave64 per primitive pId.  Leaves are taken 64 at a time (lane = leaf): box test, then the (leaf, point) slots of
-// the touched leaves are flattened with a prefix over the leaf sizes -- the same owner search as fine_batch -- so every
+// the touched leaves are flattened with a prefix over the leaf sizes -- a binary search for the owning leaf over that prefix -- so every
 // round of 64 lanes tests 64 real points.  Accepted (i = pId, j) are compacted by ballot/prefix into the wave's private
 // LDS stage (no LDS atomics) and appended with ONE global atomic per workgroup at the end (per wave if its stage
 // fills up first): (j,i) then (i,j) with order keys 2*(pId*n_seq + slot) + {0,1}, monotone in the reference's
@@ -1007,6 +933,7 @@ struct GateParams {
   BaseFrame base;
   uint32_t* counts;                                     // per quad: kGateFailed, later the inlier count
   uint32_t* cand_idx; float4* cand_T;                   // gated candidates: quad index + 3x4 transform
+  uint32_t* cand_cnt;                                   // ... and their inlier counters (cleared here, accumulated by k_verify)
   uint32_t* C_dev;
 };
 __device__ __forceinline__ bool gate_quad(const GateParams& G, const int4 qd, float T[12]) {
@@ -1017,6 +944,7 @@ __device__ __forceinline__ bool gate_quad(const GateParams& G, const int4 qd, fl
 }
 __device__ __forceinline__ void store_candidate(const GateParams& G, const uint32_t at, const uint32_t k, const float T[12]) {
   G.cand_idx[at] = k;
+  G.cand_cnt[at] = 0u;
   float4* dst = G.cand_T + 3 * size_t(at);
   dst[0] = make_float4(T[0], T[1], T[2], T[3]);
   dst[1] = make_float4(T[4], T[5], T[6], T[7]);
@@ -1171,10 +1099,12 @@ struct VerifyParams {
   LcpGrid grid;
   const float4* q4;                                     // sampled Q (centred), packed (x,y,z,0), original order (quad indices)
   const float4* q4v;                                    // the same points in Morton order, for the LCP sweep
+  QuantQ qq;                                            // ... and their 16-bit quantisation (QLDS kernels)
   uint32_t n_q;
   BaseFrame base;
   const int4* quads; const unsigned long long* tags; uint32_t* counts;
   const uint32_t* cand_idx; const float4* cand_T;       // gated candidates: quad index + 3x4 transform
+  uint32_t* cand_cnt;                                   // ... and their inlier counters (cleared by the gate)
   DevCounters* ctr;                                     // live counters of the base (reset by the last workgroup)
   DevCounters* res;                                     // result record of the base (copied to the host)
   uint4* slots;                                         // per workgroup: {best count, its candidate, tag lo, tag hi}
@@ -1187,48 +1117,65 @@ __device__ __forceinline__ bool slot_better(const uint32_t ca, const unsigned lo
   return !b_valid || ca > cb || (ca == cb && ta < tb);
 }
 
-template <bool COUNT>
+template <bool COUNT, bool QLDS>
 __global__ __launch_bounds__(kVerifyThreads, 8) void k_verify(VerifyParams P) {   // 8 waves/SIMD: two 1024-thread workgroups per CU
   extern __shared__ uint32_t s_mem[];
-  uint32_t* s_coarse = s_mem;
-  uint2* s_queue = reinterpret_cast<uint2*>(s_mem + P.grid.coarse_words) + (threadIdx.x >> 6) * (kQueueWordsPerWave / 2);
+  uint32_t* s_coarse = s_mem;                              // LDS: coarse bitmap | quantised queries (QLDS) | 16 survivor queues
+  uint2* s_q = reinterpret_cast<uint2*>(s_mem + P.grid.coarse_words);
+  uint2* s_queue = s_q + (QLDS ? ((P.n_q + 127u) & ~127u) : 0u) + (threadIdx.x >> 6) * (kQueueWordsPerWave / 2);
   __shared__ uint32_t s_next, s_last;
   __shared__ uint32_t s_wcnt[kVerifyThreads / 64], s_wcand[kVerifyThreads / 64];
   __shared__ unsigned long long s_wtag[kVerifyThreads / 64];
   const uint32_t C = P.ctr->C;
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   // Work split: every workgroup owns a contiguous slice of the gated candidate list (static: a single-address global
-  // cursor caps at ~90 dequeues/us, MI355X_MICROARCH "dequeue"); inside the slice its 16 waves take candidates from an
-  // LDS counter, so a wave that drew cheap candidates (few L0 survivors) simply takes more.  Slices differ by at most
-  // one candidate, against "one or two candidates per wave" for a static stride over waves.
+  // cursor caps at ~90 dequeues/us, MI355X_MICROARCH "dequeue"); inside the slice its 16 waves draw candidates from an
+  // LDS counter, so a wave that drew cheap candidates simply takes more.  (Slices hold < 65536 candidates: the grid is
+  // sized for that on the host, the queue entries carry the candidate's offset in 16 bits.)
   const uint32_t lo = uint32_t((uint64_t(C) * blockIdx.x) / gridDim.x), hi = uint32_t((uint64_t(C) * (blockIdx.x + 1u)) / gridDim.x);
-  uint32_t b_cnt = 0, b_cand = kNil; unsigned long long b_tag = ~0ull;      // this wave's best (wave-uniform)
-  if (lo < hi) {                                           // (uniform) otherwise: more workgroups than candidates
-    if (threadIdx.x == 0) s_next = lo;
+  if (lo < hi && P.ablate != 2) {                          // (uniform) otherwise: more workgroups than candidates
+    if (threadIdx.x == 0) s_next = 0;
+    LcpTask K;
+    K.q4 = P.q4v; K.n_q = P.n_q; K.qq = P.qq; K.T = P.cand_T; K.t_stride = 3u; K.cand_cnt = P.cand_cnt; K.point_tests = &P.ctr->point_tests;
+    if (QLDS) stage_queries(K, s_q);
     stage_coarse(P.grid, s_coarse);                        // ends with a workgroup barrier
-    while (true) {
-      uint32_t i = 0;
-      if (lane == 0) i = atomicAdd(&s_next, 1u);
-      i = uint32_t(__builtin_amdgcn_readfirstlane(int(i)));
-      if (i >= hi) break;
-      const float4* src = P.cand_T + 3 * size_t(i);         // one candidate per wave
-      uint32_t cnt = 0;
-      if (P.ablate == 2) cnt = uint32_t(src[0].w > 1e30f);
-      else if (P.ablate == 1) cnt = wave_lcp_count<COUNT, true>(P.grid, s_coarse, s_queue, P.q4v, P.n_q, src, &P.ctr->point_tests);
-      else cnt = wave_lcp_count<COUNT, false>(P.grid, s_coarse, s_queue, P.q4v, P.n_q, src, &P.ctr->point_tests);
-      const uint32_t k = uint32_t(__builtin_amdgcn_readfirstlane(int(P.cand_idx[i])));
-      const unsigned long long tag = P.tags[k];
-      if (lane == 0) P.counts[k] = cnt;
-      if (slot_better(cnt, tag, b_cnt, b_tag, b_cand != kNil)) { b_cnt = cnt; b_tag = tag; b_cand = i; }
-    }
+    if (P.ablate == 1) wave_score<COUNT, true, QLDS>(P.grid, K, s_coarse, s_q, s_queue, &s_next, lo, hi);
+    else wave_score<COUNT, false, QLDS>(P.grid, K, s_coarse, s_q, s_queue, &s_next, lo, hi);
   }
-  // ---- selection: wave bests -> workgroup best -> slot; the last workgroup to finish reduces the slots ----
-  if (lane == 0) { s_wcnt[wave] = b_cnt; s_wcand[wave] = b_cand; s_wtag[wave] = b_tag; }
+  // The workgroup's count atomics are performed at its XCD's L2 and the barrier's workgroup-scope fence waits for this
+  // wave's outstanding ones; the loads below are agent-scope atomics served by the same L2.  (An agent-scope
+  // __threadfence() here -- one L2 write-back per wave, 8192 per launch -- made the kernel 2.4x slower.)
   __syncthreads();
+  // ---- selection: the workgroup's candidates are final; thread bests -> wave bests -> workgroup best -> slot ----
+  uint32_t bc = 0, bi = kNil; unsigned long long bt = ~0ull;
+  for (uint32_t c = lo + threadIdx.x; c < hi; c += blockDim.x) {
+    const uint32_t cnt = __hip_atomic_load(P.cand_cnt + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t k = P.cand_idx[c];
+    P.counts[k] = cnt;                                     // per-quad record (s4p_last_candidates / visitors)
+    const unsigned long long tag = P.tags[k];
+    if (slot_better(cnt, tag, bc, bt, bi != kNil)) { bc = cnt; bt = tag; bi = c; }
+  }
+  auto wave_reduce = [&]() {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const uint32_t oc = uint32_t(__shfl_xor(int(bc), o)), oi = uint32_t(__shfl_xor(int(bi), o));
+      const uint32_t tl = uint32_t(__shfl_xor(int(uint32_t(bt)), o)), th = uint32_t(__shfl_xor(int(uint32_t(bt >> 32)), o));
+      const unsigned long long ot = (unsigned long long)tl | ((unsigned long long)th << 32);
+      if (oi != kNil && slot_better(oc, ot, bc, bt, bi != kNil)) { bc = oc; bt = ot; bi = oi; }
+    }
+  };
+  auto block_reduce = [&]() {                              // result valid in thread 0
+    wave_reduce();
+    if (lane == 0) { s_wcnt[wave] = bc; s_wcand[wave] = bi; s_wtag[wave] = bt; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      bc = 0; bi = kNil; bt = ~0ull;
+      for (uint32_t w = 0; w < uint32_t(kVerifyThreads / 64); ++w)
+        if (s_wcand[w] != kNil && slot_better(s_wcnt[w], s_wtag[w], bc, bt, bi != kNil)) { bc = s_wcnt[w]; bt = s_wtag[w]; bi = s_wcand[w]; }
+    }
+  };
+  block_reduce();
   if (threadIdx.x == 0) {
-    uint32_t bc = 0, bi = kNil; unsigned long long bt = ~0ull;
-    for (uint32_t w = 0; w < uint32_t(kVerifyThreads / 64); ++w)
-      if (s_wcand[w] != kNil && slot_better(s_wcnt[w], s_wtag[w], bc, bt, bi != kNil)) { bc = s_wcnt[w]; bt = s_wtag[w]; bi = s_wcand[w]; }
     P.slots[blockIdx.x] = make_uint4(bc, bi, uint32_t(bt), uint32_t(bt >> 32));
     __threadfence();                                       // release (agent scope): the slot is visible before the ticket
     const uint32_t ticket = atomicAdd(&P.ctr->done, 1u);
@@ -1237,26 +1184,14 @@ __global__ __launch_bounds__(kVerifyThreads, 8) void k_verify(VerifyParams P) { 
   __syncthreads();
   if (s_last == 0u) return;
   __threadfence();                                         // acquire: the other workgroups' slots
-  // (the arrays of the wave-level reduction are reused for the slot-level one: one entry per wave)
-  uint32_t bc = 0, bi = kNil; unsigned long long bt = ~0ull;
-  for (uint32_t b = threadIdx.x; b < gridDim.x; b += blockDim.x) {
-    const uint4 s = P.slots[b];
-    const unsigned long long t = (unsigned long long)s.z | ((unsigned long long)s.w << 32);
-    if (s.y != kNil && slot_better(s.x, t, bc, bt, bi != kNil)) { bc = s.x; bt = t; bi = s.y; }
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {                       // wave reduction
-    const uint32_t oc = uint32_t(__shfl_xor(int(bc), o)), oi = uint32_t(__shfl_xor(int(bi), o));
-    const uint32_t tl = uint32_t(__shfl_xor(int(uint32_t(bt)), o)), th = uint32_t(__shfl_xor(int(uint32_t(bt >> 32)), o));
-    const unsigned long long ot = (unsigned long long)tl | ((unsigned long long)th << 32);
-    if (oi != kNil && slot_better(oc, ot, bc, bt, bi != kNil)) { bc = oc; bt = ot; bi = oi; }
-  }
-  if (lane == 0) { s_wcnt[wave] = bc; s_wcand[wave] = bi; s_wtag[wave] = bt; }
-  __syncthreads();
-  if (threadIdx.x != 0) return;
   bc = 0; bi = kNil; bt = ~0ull;
-  for (uint32_t w = 0; w < uint32_t(kVerifyThreads / 64); ++w)
-    if (s_wcand[w] != kNil && slot_better(s_wcnt[w], s_wtag[w], bc, bt, bi != kNil)) { bc = s_wcnt[w]; bt = s_wtag[w]; bi = s_wcand[w]; }
+  for (uint32_t b = threadIdx.x; b < gridDim.x; b += blockDim.x) {
+    const uint4 sl = P.slots[b];
+    const unsigned long long t = (unsigned long long)sl.z | ((unsigned long long)sl.w << 32);
+    if (sl.y != kNil && slot_better(sl.x, t, bc, bt, bi != kNil)) { bc = sl.x; bt = t; bi = sl.y; }
+  }
+  block_reduce();
+  if (threadIdx.x != 0) return;
   DevCounters* c = P.ctr;
   DevCounters* r = P.res;
   r->m1 = c->m1; r->m2 = c->m2; r->K = c->K; r->C = C; r->overflow = c->overflow;
@@ -1282,25 +1217,27 @@ __global__ __launch_bounds__(kVerifyThreads, 8) void k_verify(VerifyParams P) { 
   c->done = 0;
 }
 
-// k_verify_T: Verify() for explicit transforms (one wave per transform).
+// k_verify_T: Verify() for explicit row-major 4x4 transforms; counts[] must be zero on entry (accumulated atomically).
 struct VerifyTParams {
-  LcpGrid grid; const float4* q4; uint32_t n_q;
+  LcpGrid grid; const float4* q4; QuantQ qq; uint32_t n_q;
   const float* T; uint32_t B; uint32_t* counts; DevCounters* ctr;
 };
-template <bool COUNT>
+template <bool COUNT, bool QLDS>
 __global__ __launch_bounds__(kVerifyThreads) void k_verify_T(VerifyTParams P) {
   extern __shared__ uint32_t s_mem[];
   uint32_t* s_coarse = s_mem;
-  uint2* s_queue = reinterpret_cast<uint2*>(s_mem + P.grid.coarse_words) + (threadIdx.x >> 6) * (kQueueWordsPerWave / 2);
+  uint2* s_q = reinterpret_cast<uint2*>(s_mem + P.grid.coarse_words);
+  uint2* s_queue = s_q + (QLDS ? ((P.n_q + 127u) & ~127u) : 0u) + (threadIdx.x >> 6) * (kQueueWordsPerWave / 2);
+  __shared__ uint32_t s_next;
+  const uint32_t lo = uint32_t((uint64_t(P.B) * blockIdx.x) / gridDim.x), hi = uint32_t((uint64_t(P.B) * (blockIdx.x + 1u)) / gridDim.x);
+  if (lo >= hi) return;
+  if (threadIdx.x == 0) s_next = 0;
+  LcpTask K;
+  K.q4 = P.q4; K.n_q = P.n_q; K.qq = P.qq; K.T = reinterpret_cast<const float4*>(P.T); K.t_stride = 4u; K.cand_cnt = P.counts;
+  K.point_tests = COUNT ? &P.ctr->point_tests : nullptr;
+  if (QLDS) stage_queries(K, s_q);
   stage_coarse(P.grid, s_coarse);
-  const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
-  for (uint32_t k = wave; k < P.B; k += nwaves) {
-    const uint32_t cnt = wave_lcp_count<COUNT, false>(P.grid, s_coarse, s_queue, P.q4, P.n_q,
-                                                      reinterpret_cast<const float4*>(P.T + 16 * size_t(k)), COUNT ? &P.ctr->point_tests : nullptr);
-    if (lane == 0) P.counts[k] = cnt;
-  }
+  wave_score<COUNT, false, QLDS>(P.grid, K, s_coarse, s_q, s_queue, &s_next, lo, hi);
 }
 
 // ---------------------------------------------------------------------------
