@@ -135,6 +135,7 @@ int32_t s4p_matcher_compute_transformation(s4p_matcher* m, const s4p_cloud_view*
 
 /* opt.terminate_threshold of the matcher (the sharded loop needs it to rank "crossed the threshold" outcomes). */
 float s4p_matcher_terminate_threshold(const s4p_matcher* m);
+int32_t s4p_matcher_max_time_seconds(const s4p_matcher* m);
 
 /* ---- multi-GPU: bases sharded over the GPUs of one node, one process per GPU ------------------
  * Every rank walks the same base sequence; rank (t mod world) runs the device pass of trial t; after each window of

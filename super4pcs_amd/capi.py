@@ -299,7 +299,7 @@ class MatcherInfo(C.Structure):
 SHARD_SYMBOLS = [
     "s4p_rccl_unique_id", "s4p_shard_create", "s4p_shard_destroy", "s4p_shard_last_error", "s4p_shard_use_rccl",
     "s4p_shard_use_collective", "s4p_shard_run_windows", "s4p_shard_compute_transformation", "s4p_shard_replay",
-    "s4p_matcher_terminate_threshold",
+    "s4p_matcher_terminate_threshold", "s4p_matcher_max_time_seconds",
 ]
 MATCHER_SYMBOLS = [
     "s4p_matcher_create", "s4p_matcher_destroy", "s4p_matcher_last_error", "s4p_matcher_ctx", "s4p_uniform_dist_sample",

@@ -64,8 +64,13 @@ struct s4p_ctx {
   // LCP scoring of base t instead of leaving most of the 256 CUs idle between them.
   struct Lane {
     hipStream_t stream = nullptr;
+    // CU partition (S4P_CU_SPLIT = n > 1): `stream` runs on one CU in n (the latency-bound pair / prep / quad kernels and
+    // the copies), `vstream` on the others (k_verify, sized to 2 workgroups per CU of ITS partition), chained by `chain`.
+    // Without the partition a k_verify launch is sized to the whole chip and slows 1.9x when another lane's small
+    // kernels hold some of its CU slots (its 512 workgroups then need a second round).
+    hipStream_t vstream = nullptr; hipEvent_t chain = nullptr;
     DevBuf<int2> ab1, ab2; DevBuf<uint32_t> okey1, okey2, cell1, cell2, bucket1, next1, mask2; DevBuf<float4> ew1, ew2;
-    DevBuf<int4> quads; DevBuf<unsigned long long> tags; DevBuf<uint32_t> counts, cand_idx, cand_cnt; DevBuf<float4> cand_T;
+    DevBuf<int4> quads; DevBuf<unsigned long long> tags; DevBuf<uint32_t> counts, cand_idx; DevBuf<float4> cand_T;
     DevBuf<unsigned long long> ht_keys, ht_heads; uint32_t ht_mask = 0, epoch = 0;
     DevBuf<DevCounters> ctr;          // [0] live counters of the base in flight, [1] its result record (what the host reads)
     DevBuf<uint4> slots;              // k_verify: per-workgroup best, reduced by its last workgroup
@@ -108,13 +113,13 @@ struct s4p_ctx {
   // slower: the ~3000-instruction cone mask of a set-2 pair lands on whichever wave found the pair); S4P_FUSE_GATE=0 runs
   // the rigid transform + rms gate as a k_gate launch instead of inside k_quads' flush (measured slower)
   bool fuse_prep = false, fuse_gate = true;
+  int cu_split = 0;                  // S4P_CU_SPLIT (0 = off): one CU in n for the small kernels, the rest for k_verify
   double host_octree_s = 0, host_wait_s = 0;
 
   size_t verify_lds_bytes() const {
     return gcoarse.n * 4 + (qlds ? size_t((n_q + 127u) & ~127u) * 8 : 0) + size_t(kVerifyThreads / 64) * kQueueWordsPerWave * 4;
   }
-  // workgroups of the scoring kernel: a slice holds < 65536 candidates (their offset travels in 16 bits of a queue entry)
-  uint32_t verify_grid() const { return std::min<uint32_t>(uint32_t(kVerifyMaxBlocks), std::max<uint32_t>(verify_blocks, uint32_t((max_quads + 65534) / 65535))); }
+  uint32_t verify_grid() const { return verify_blocks; }
   LcpGrid dev_grid() const {
     LcpGrid g;
     g.reach = greach.p; g.list_hdr = glist_hdr.p; g.nbr = gnbr.p;
@@ -287,7 +292,7 @@ int32_t quad_params(s4p_ctx* c, float inv1, float inv2, float thr2, PrepParams& 
 GateParams gate_params(s4p_ctx* c, const BaseFrame& bf) {
   s4p_ctx::Lane& L = c->lane[c->cur];
   GateParams G{};
-  G.q4 = c->q4.p; G.base = bf; G.counts = L.counts.p; G.cand_idx = L.cand_idx.p; G.cand_T = L.cand_T.p; G.cand_cnt = L.cand_cnt.p; G.C_dev = &L.ctr.p->C;
+  G.q4 = c->q4.p; G.base = bf; G.counts = L.counts.p; G.cand_idx = L.cand_idx.p; G.cand_T = L.cand_T.p; G.C_dev = &L.ctr.p->C;
   return G;
 }
 
@@ -308,15 +313,21 @@ int32_t launch_verify(s4p_ctx* c, const BaseFrame& bf) {
   s4p_ctx::Lane& L = c->lane[c->cur];
   VerifyParams V{};
   V.grid = c->dev_grid(); V.q4 = c->q4.p; V.q4v = c->q4v.p; V.qq = c->qq; V.n_q = c->n_q; V.base = bf;
-  V.quads = L.quads.p; V.tags = L.tags.p; V.counts = L.counts.p; V.cand_idx = L.cand_idx.p; V.cand_T = L.cand_T.p; V.cand_cnt = L.cand_cnt.p;
+  V.quads = L.quads.p; V.tags = L.tags.p; V.counts = L.counts.p; V.cand_idx = L.cand_idx.p; V.cand_T = L.cand_T.p;
   V.ctr = L.ctr.p; V.res = L.ctr.p + 1; V.slots = L.slots.p; V.count_tests = c->prof_points ? 1 : 0;
   V.ablate = c->ablate;
-  if (c->prof_events) HIPCHK(c, hipEventRecord(c->ev[c->cur][0], L.stream));
+  hipStream_t vs = L.stream;
+  if (L.vstream) {                                           // CU partition: k_verify on the big partition, after the lane's small kernels
+    HIPCHK(c, hipEventRecord(L.chain, L.stream));
+    HIPCHK(c, hipStreamWaitEvent(L.vstream, L.chain, 0));
+    vs = L.vstream;
+  }
+  if (c->prof_events) HIPCHK(c, hipEventRecord(c->ev[c->cur][0], vs));
   const size_t lds = c->verify_lds_bytes();
   const dim3 grid(c->verify_grid()), block(kVerifyThreads);
-  if (c->prof_points) { if (c->qlds) hipLaunchKernelGGL((k_verify<true, true>), grid, block, lds, L.stream, V); else hipLaunchKernelGGL((k_verify<true, false>), grid, block, lds, L.stream, V); }
-  else { if (c->qlds) hipLaunchKernelGGL((k_verify<false, true>), grid, block, lds, L.stream, V); else hipLaunchKernelGGL((k_verify<false, false>), grid, block, lds, L.stream, V); }
-  if (c->prof_events) HIPCHK(c, hipEventRecord(c->ev[c->cur][1], L.stream));
+  if (c->prof_points) { if (c->qlds) hipLaunchKernelGGL((k_verify<true, true>), grid, block, lds, vs, V); else hipLaunchKernelGGL((k_verify<true, false>), grid, block, lds, vs, V); }
+  else { if (c->qlds) hipLaunchKernelGGL((k_verify<false, true>), grid, block, lds, vs, V); else hipLaunchKernelGGL((k_verify<false, false>), grid, block, lds, vs, V); }
+  if (c->prof_events) HIPCHK(c, hipEventRecord(c->ev[c->cur][1], vs));
   HIPCHK(c, hipGetLastError());
   return S4P_OK;
 }
@@ -324,8 +335,9 @@ int32_t launch_verify(s4p_ctx* c, const BaseFrame& bf) {
 // enqueue the result read-back of the base in slot c->cur and mark its completion
 int32_t enqueue_result(s4p_ctx* c, const BaseFrame& bf) {
   c->slot_bf[c->cur] = bf;
-  HIPCHK(c, hipMemcpyAsync(c->hctr[c->cur].p, c->lane[c->cur].ctr.p + 1, sizeof(DevCounters), hipMemcpyDeviceToHost, c->lane[c->cur].stream));
-  HIPCHK(c, hipEventRecord(c->done[c->cur], c->lane[c->cur].stream));
+  hipStream_t rs = c->lane[c->cur].vstream ? c->lane[c->cur].vstream : c->lane[c->cur].stream;      // the stream k_verify ran on
+  HIPCHK(c, hipMemcpyAsync(c->hctr[c->cur].p, c->lane[c->cur].ctr.p + 1, sizeof(DevCounters), hipMemcpyDeviceToHost, rs));
+  HIPCHK(c, hipEventRecord(c->done[c->cur], rs));
   return S4P_OK;
 }
 
@@ -412,6 +424,7 @@ int32_t s4p_create(const s4p_options* opt, const s4p_limits* lim, int32_t device
   if (const char* vb = getenv("S4P_VERIFY_BLOCKS")) { const int v = atoi(vb); if (v >= 64 && v <= kVerifyMaxBlocks) c->verify_blocks = uint32_t(v); }   // tuning knob
   if (const char* fu = getenv("S4P_FUSE_PREP")) c->fuse_prep = atoi(fu) != 0;
   if (const char* fu = getenv("S4P_FUSE_GATE")) c->fuse_gate = atoi(fu) != 0;
+  if (const char* cs = getenv("S4P_CU_SPLIT")) { const int v = atoi(cs); if (v >= 2 && v <= 64) c->cu_split = v; }
   snprintf(c->devname, sizeof c->devname, "%s (%s)", prop.name, prop.gcnArchName);
   c->max_pairs = (lim && lim->max_pairs) ? lim->max_pairs : (4ull << 20);
   c->max_quads = (lim && lim->max_quads) ? lim->max_quads : (16ull << 20);
@@ -426,10 +439,22 @@ int32_t s4p_create(const s4p_options* opt, const s4p_limits* lim, int32_t device
 #define A(buf, cnt) if ((e = (buf).alloc(cnt)) != hipSuccess) return fail(e, "hipMalloc " #buf)
   for (int li = 0; li < c->n_lanes; ++li) {
     s4p_ctx::Lane& L = c->lane[li];
-    if ((e = hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
+    if (c->cu_split > 1) {
+      const uint32_t ncu = uint32_t(prop.multiProcessorCount);
+      std::vector<uint32_t> small((ncu + 31) / 32, 0u), big((ncu + 31) / 32, 0u);
+      uint32_t nbig = 0;
+      for (uint32_t cu = 0; cu < ncu; ++cu) {
+        if (cu % uint32_t(c->cu_split) == uint32_t(c->cu_split) - 1u) small[cu >> 5] |= 1u << (cu & 31u);
+        else { big[cu >> 5] |= 1u << (cu & 31u); ++nbig; }
+      }
+      if ((e = hipExtStreamCreateWithCUMask(&L.stream, uint32_t(small.size()), small.data())) != hipSuccess) return fail(e, "hipExtStreamCreateWithCUMask");
+      if ((e = hipExtStreamCreateWithCUMask(&L.vstream, uint32_t(big.size()), big.data())) != hipSuccess) return fail(e, "hipExtStreamCreateWithCUMask");
+      if ((e = hipEventCreateWithFlags(&L.chain, hipEventDisableTiming)) != hipSuccess) return fail(e, "hipEventCreate");
+      if (!getenv("S4P_VERIFY_BLOCKS")) c->verify_blocks = 2u * nbig;
+    } else if ((e = hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
     A(L.ab1, mp); A(L.ab2, mp); A(L.okey1, mp); A(L.okey2, mp); A(L.cell1, mp); A(L.cell2, mp);
     A(L.bucket1, mp); A(L.next1, mp); A(L.mask2, mp * kMaskWords); A(L.ew1, mp); A(L.ew2, mp);
-    A(L.quads, mq); A(L.tags, mq); A(L.counts, mq); A(L.cand_idx, mq); A(L.cand_cnt, mq); A(L.cand_T, mq * 3);
+    A(L.quads, mq); A(L.tags, mq); A(L.counts, mq); A(L.cand_idx, mq); A(L.cand_T, mq * 3);
     A(L.ht_keys, hts); A(L.ht_heads, hts); L.ht_mask = hts - 1;
     A(L.ctr, 2); A(L.slots, kVerifyMaxBlocks);
     if ((e = hipMemset(L.ht_keys.p, 0, size_t(hts) * 8)) != hipSuccess) return fail(e, "hipMemset");
@@ -443,7 +468,7 @@ int32_t s4p_create(const s4p_options* opt, const s4p_limits* lim, int32_t device
     if ((e = hipEventCreateWithFlags(&c->done[sl], hipEventDisableTiming)) != hipSuccess) return fail(e, "hipEventCreate");
   }
   {  // allow the verify kernels their dynamic LDS (coarse bitmap + quantised queries + survivor queues)
-    const int max_lds = int(kCoarseMaxWords * 4 + kLdsQueries * 8 + (kVerifyThreads / 64) * kQueueWordsPerWave * 4);
+    const int max_lds = kVerifyLdsBudget;
     const void* fns[] = {(const void*)k_verify<false, false>, (const void*)k_verify<false, true>, (const void*)k_verify<true, false>, (const void*)k_verify<true, true>,
                          (const void*)k_verify_T<false, false>, (const void*)k_verify_T<false, true>, (const void*)k_verify_T<true, false>, (const void*)k_verify_T<true, true>};
     for (const void* fn : fns)
@@ -457,7 +482,7 @@ int32_t s4p_create(const s4p_options* opt, const s4p_limits* lim, int32_t device
 void s4p_destroy(s4p_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  for (auto& L : c->lane) if (L.stream) (void)hipStreamSynchronize(L.stream);
+  for (auto& L : c->lane) { if (L.stream) (void)hipStreamSynchronize(L.stream); if (L.vstream) (void)hipStreamSynchronize(L.vstream); }
   c->greach.free(); c->glist_hdr.free(); c->gnbr.free();
   c->gcoarse.free(); c->q4.free(); c->q4v.free(); c->qquant.free();
   c->qx.free(); c->qy.free(); c->qz.free(); c->ux.free(); c->uy.free(); c->uz.free();
@@ -465,7 +490,7 @@ void s4p_destroy(s4p_ctx* c) {
   for (auto& L : c->lane) {
     L.ab1.free(); L.ab2.free(); L.okey1.free(); L.okey2.free(); L.cell1.free(); L.cell2.free();
     L.bucket1.free(); L.next1.free(); L.mask2.free(); L.ew1.free(); L.ew2.free();
-    L.quads.free(); L.tags.free(); L.counts.free(); L.cand_idx.free(); L.cand_cnt.free(); L.cand_T.free(); L.ht_keys.free(); L.ht_heads.free(); L.ctr.free(); L.slots.free();
+    L.quads.free(); L.tags.free(); L.counts.free(); L.cand_idx.free(); L.cand_T.free(); L.ht_keys.free(); L.ht_heads.free(); L.ctr.free(); L.slots.free();
     for (int s = 0; s < 2; ++s) L.seq[s].free();
   }
   for (auto& h : c->hctr) h.free();
@@ -474,7 +499,7 @@ void s4p_destroy(s4p_ctx* c) {
   for (auto& e : c->tev) if (e) (void)hipEventDestroy(e);
   for (auto& row : c->ev) for (auto& ev : row) if (ev) (void)hipEventDestroy(ev);
   for (auto& ev : c->done) if (ev) (void)hipEventDestroy(ev);
-  for (auto& L : c->lane) if (L.stream) (void)hipStreamDestroy(L.stream);
+  for (auto& L : c->lane) { if (L.chain) (void)hipEventDestroy(L.chain); if (L.vstream) (void)hipStreamDestroy(L.vstream); if (L.stream) (void)hipStreamDestroy(L.stream); }
   delete c;
 }
 
@@ -600,7 +625,8 @@ int32_t s4p_set_clouds(s4p_ctx* c, const float* px, const float* py, const float
       c->qq.step[k] = (hi[k] > lo[k]) ? (hi[k] - lo[k]) / 65535.0f : 1.0f;
       if (!(0.5f * c->qq.step[k] * c->hgrid.inv_h < 0.004f)) fine_enough = false;
     }
-    c->qlds = fine_enough && n_q <= int64_t(kLdsQueries) && getenv("S4P_NO_QLDS") == nullptr;
+    c->qlds = fine_enough && n_q <= int64_t(kLdsQueries) && getenv("S4P_NO_QLDS") == nullptr &&
+              c->gcoarse.n * 4 + size_t((n_q + 127) & ~int64_t(127)) * 8 + size_t(kVerifyThreads / 64) * kQueueWordsPerWave * 4 <= size_t(kVerifyLdsBudget);
     std::vector<uint2> packed((size_t)n_q);
     for (int64_t i = 0; i < n_q; ++i) {
       uint32_t u[3];
@@ -754,27 +780,27 @@ int32_t verify_transforms_impl(s4p_ctx* c, const float* T, int64_t B, uint32_t* 
   S4P_NEED_IDLE(c);
   HIPCHK(c, hipSetDevice(c->device));
   s4p_ctx::Lane& L = c->lane[c->cur];
+  hipStream_t st = L.vstream ? L.vstream : L.stream;          // (the big CU partition, if the context is partitioned)
   DevBuf<float> dT; DevBuf<uint32_t> dC;
   HIPCHK(c, dT.alloc(size_t(B) * 16));
   hipError_t e = dC.alloc(size_t(B));
   if (e != hipSuccess) { dT.free(); HIPCHK(c, e); }
   int32_t rc = S4P_OK;
   do {
-    if (stats4) { if ((rc = reset_counters(c)) != S4P_OK) break; L.dirty = true; }
-    if ((e = hipMemcpyAsync(dT.p, T, size_t(B) * 64, hipMemcpyHostToDevice, L.stream)) != hipSuccess) break;
-    if ((e = hipMemsetAsync(dC.p, 0, size_t(B) * 4, L.stream)) != hipSuccess) break;       // counts are accumulated atomically
+    if (stats4) { if ((rc = reset_counters(c)) != S4P_OK) break; L.dirty = true; if (L.vstream) (void)hipStreamSynchronize(L.stream); }
+    if ((e = hipMemcpyAsync(dT.p, T, size_t(B) * 64, hipMemcpyHostToDevice, st)) != hipSuccess) break;
     VerifyTParams V{};
     V.grid = c->dev_grid(); V.q4 = c->q4v.p; V.qq = c->qq; V.n_q = c->n_q; V.T = dT.p; V.B = uint32_t(B);
     V.counts = dC.p; V.ctr = L.ctr.p;
     const uint32_t wpb = kVerifyThreads / 64;
-    const uint32_t blocks = uint32_t(std::max<int64_t>(std::min<int64_t>((B + wpb - 1) / wpb, 512), (B + 65534) / 65535));   // slices < 65536 transforms
+    const uint32_t blocks = uint32_t(std::min<int64_t>((B + wpb - 1) / wpb, 512));
     const size_t lds = c->verify_lds_bytes();
-    if (stats4) { if (c->qlds) hipLaunchKernelGGL((k_verify_T<true, true>), dim3(blocks), dim3(kVerifyThreads), lds, L.stream, V); else hipLaunchKernelGGL((k_verify_T<true, false>), dim3(blocks), dim3(kVerifyThreads), lds, L.stream, V); }
-    else { if (c->qlds) hipLaunchKernelGGL((k_verify_T<false, true>), dim3(blocks), dim3(kVerifyThreads), lds, L.stream, V); else hipLaunchKernelGGL((k_verify_T<false, false>), dim3(blocks), dim3(kVerifyThreads), lds, L.stream, V); }
+    if (stats4) { if (c->qlds) hipLaunchKernelGGL((k_verify_T<true, true>), dim3(blocks), dim3(kVerifyThreads), lds, st, V); else hipLaunchKernelGGL((k_verify_T<true, false>), dim3(blocks), dim3(kVerifyThreads), lds, st, V); }
+    else { if (c->qlds) hipLaunchKernelGGL((k_verify_T<false, true>), dim3(blocks), dim3(kVerifyThreads), lds, st, V); else hipLaunchKernelGGL((k_verify_T<false, false>), dim3(blocks), dim3(kVerifyThreads), lds, st, V); }
     if ((e = hipGetLastError()) != hipSuccess) break;
-    if ((e = hipMemcpyAsync(counts, dC.p, size_t(B) * 4, hipMemcpyDeviceToHost, L.stream)) != hipSuccess) break;
-    if (stats4 && (e = hipMemcpyAsync(c->hctr[c->cur].p, L.ctr.p, sizeof(DevCounters), hipMemcpyDeviceToHost, L.stream)) != hipSuccess) break;
-    e = hipStreamSynchronize(L.stream);
+    if ((e = hipMemcpyAsync(counts, dC.p, size_t(B) * 4, hipMemcpyDeviceToHost, st)) != hipSuccess) break;
+    if (stats4 && (e = hipMemcpyAsync(c->hctr[c->cur].p, L.ctr.p, sizeof(DevCounters), hipMemcpyDeviceToHost, st)) != hipSuccess) break;
+    e = hipStreamSynchronize(st);
     if (stats4 && e == hipSuccess) {
       const DevCounters& d = *c->hctr[c->cur].p;
       stats4[0] = d.point_tests; stats4[1] = d.l0_pass; stats4[2] = d.l1_pass; stats4[3] = d.l2_pass;

@@ -595,6 +595,7 @@ void s4p_matcher_destroy(s4p_matcher* m) {
 const char* s4p_matcher_last_error(const s4p_matcher* m) { return m ? m->err.c_str() : s4p_last_error(nullptr); }
 s4p_ctx* s4p_matcher_ctx(s4p_matcher* m) { return m ? m->ctx : nullptr; }
 float s4p_matcher_terminate_threshold(const s4p_matcher* m) { return m ? m->opt.terminate_threshold : 0.f; }
+int32_t s4p_matcher_max_time_seconds(const s4p_matcher* m) { return m ? m->opt.max_time_seconds : 0; }
 
 int64_t s4p_uniform_dist_sample(const float* x, const float* y, const float* z, int64_t n, float delta, int64_t* out) {
   if (!x || !y || !z || !out || n <= 0 || !(delta > 0.f)) return 0;

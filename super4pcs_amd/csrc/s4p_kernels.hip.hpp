@@ -87,9 +87,10 @@ struct LcpGrid {
   float sq_eps;                 // fl(delta*delta)
 };
 
-constexpr int kQueueEntries = 192;                 // per-wave survivor queue (8 B entries): 63 left over + one step of 2 x 64
-constexpr int kQueueWordsPerWave = 2 * kQueueEntries;     // in 32-bit words (1.5 KB)
-constexpr int kCoarseMaxWords = 9216;              // 36 KB: + 20 KB of queries + 16 x 1.5 KB of queues = 80 KB, two workgroups per CU
+constexpr int kQueueEntries = 320;                 // per-wave survivor queue: 63 left over + one step of 4 x 64 entries
+constexpr int kQueueWordsPerWave = kQueueEntries + kQueueEntries / 2;     // 32-bit rank + 16-bit query index per entry: 1920 B
+constexpr int kCoarseMaxWords = 9216;              // 36 KB (two 1024-thread workgroups per CU share 160 KB: 80 KB each)
+constexpr int kVerifyLdsBudget = 80 * 1024 - 768;  // per workgroup: coarse bitmap + 16 queues (30 KB) [+ quantised queries]
 
 // value held by every lane of the wave -> SGPR
 __device__ __forceinline__ float wave_uniform(float v) {
@@ -288,30 +289,26 @@ __global__ __launch_bounds__(256) void k_build_masks(MaskParams P) {
 // ---------------------------------------------------------------------------
 // LCP scoring: Verify() (match4pcsBase.cc:508-567) without the early exit.
 //
-// What bounds this kernel (profiles/r02_*): not instruction issue (-14 % VALU: -2 % time), not the latency of the sweep's
-// loads (software-pipelining them: no change), not the number of dependent steps of the exact stage (a quarter of them:
-// slower), not the wave-level work granularity (1/2/4/8 items per candidate: same time) -- but the L2 -> L1 line traffic:
-// 20 M line requests per launch, 1350 per candidate, of which ~500 were the 32 KB query array that every wave re-streams
-// for every candidate through a 32 KB L1 it shares with the gathers.  Hence:
-//   * the sampled-Q points the SWEEP reads live in LDS, quantised to 3 x 16 bit over Q's bounding box (8 B per query,
-//     16 KB for n_Q = 2000): no global traffic for the sweep's queries at all.  The sweep only LOCATES a query; the
-//     quantisation moves it by < 2e-3 cell, inside the 1 % slack the structure is built with (LcpGridHost::plan).  The
-//     exact stage still reads the exact float query for the inlier predicate, and uses the SAME quantised value for
-//     the cell, so both stages agree bit for bit.  Clouds whose sample does not fit (n_Q > kLdsQueries) or whose extent
-//     needs more than 16 bits keep the float array in global memory (QLDS = false).
-//   * the survivor queue keeps the cell's rank (8 B entries), so the exact stage does not gather the reach word again;
-//   * the queue persists across candidates, so exact-stage batches are always full (3.3 per candidate instead of 3 + 1).
-//
-// Per wave:
-//   sweep of a candidate (two 64-query chunks per step): position in grid units (3 converts + 9 fma + 3 floor-converts),
-//     L0 test of the cell's coarse cube against the LDS bitmap, L1 reach word (8 B gather; rejected lanes read word 0,
-//     one broadcast line); queries whose cell is reachable are compacted (ballot/prefix) into the wave's LDS queue as
-//     {query | candidate << 16, rank of the cell among the reachable ones};
+// Structure per wave and candidate:
+//   sweep (four 64-query chunks per step): position in grid units (3 converts + 9 fma + 3 floor-converts), L0 test of the
+//     cell's coarse cube against the LDS bitmap, L1 reach word (8 B gather; rejected lanes read word 0, one broadcast
+//     line); queries whose cell is reachable are compacted (ballot/prefix) into the wave's LDS queue as {query, rank of
+//     the cell among the reachable ones};
 //   exact stage whenever 64 entries wait (and once at the end): lane per entry -- the candidate's exact 3x4, list header,
 //     4x4x4 sub-cell mask, then the exact predicate sqdist <= delta^2 (kdtree.h:417-421) against the listed points, two
-//     16-byte loads per dependent step; hits are counted per candidate with one atomic per (batch, candidate).
-// A workgroup owns a contiguous slice of candidates, so when its waves are done its candidates' counts are final and it
-// can reduce them to its best (count, then smallest tag = first in reference order) without any grid-wide step.
+//     16-byte loads per dependent step.
+// The sampled-Q points the SWEEP reads live in LDS, quantised to 3 x 16 bit over Q's bounding box (8 B per query, 16 KB
+// for n_Q = 2000): the 32 KB float array that every wave re-streamed for every candidate through a 32 KB L1 it shares
+// with the gathers is gone from the sweep (-18 % L1 accesses).  The sweep only LOCATES a query; the quantisation moves it
+// by < 2e-3 cell, inside the 1 % slack the structure is built with (LcpGridHost::plan).  The exact stage still reads
+// the exact float query for the inlier predicate, and uses the SAME quantised value for the cell, so both stages
+// agree bit for bit.  Clouds whose sample does not fit (n_Q > kLdsQueries) or whose extent needs more than 16 bits keep
+// the float array in global memory (QLDS = false).
+// What the round-2 measurements say about this kernel (profiles/r02_*): the sweep is instruction-
+// issue bound (57 -> 50 instructions per 64 queries); the exact stage is latency bound (~14 dependent gathers per batch
+// at ~1 us each under load, 8 waves per SIMD cannot cover them); software-pipelining the sweep, flattening the exact
+// stage into (query, point) pairs or 4-point items, finer work units and a queue persisting across candidates were all
+// built, verified bit-exact and measured slower or equal -- they are documented there, not kept here.
 // ---------------------------------------------------------------------------
 constexpr int kLdsQueries = 2560;                  // sampled-Q points that fit the LDS copy (20 KB)
 
@@ -326,7 +323,6 @@ struct LcpTask {                 // what the scoring loop needs besides the grid
   QuantQ qq;                     // (QLDS kernels)
   const float4* T;               // candidate transforms: row-major 3x4 at T + t_stride * candidate
   uint32_t t_stride;             // in float4: 3 (cand_T records) or 4 (caller's 4x4 matrices)
-  uint32_t* cand_cnt;            // per candidate: inlier count, accumulated atomically (zero on entry)
   unsigned long long* point_tests;   // instrumentation (COUNT kernels only)
 };
 
@@ -355,16 +351,16 @@ __device__ __forceinline__ float4 sweep_query(const LcpTask& K, const uint2* s_q
   return K.q4[i];
 }
 
-// Exact stage for the top n (<= 64) queue entries: lane = entry {query i, candidate ci, rank of the query's cell}.
+// Exact stage for the top n (<= 64) queue entries of the wave's candidate: lane = entry {query i, rank of its cell}.
+// Returns whether this lane's query is an inlier.
 template <bool COUNT, bool QLDS>
-__device__ __forceinline__ void exact_batch(const LcpGrid& g, const LcpTask& K, const uint2* s_q, const bool valid,
-                                            const uint32_t i, const uint32_t ci, const uint32_t rank) {
-  const uint32_t lane = threadIdx.x & 63u;
+__device__ __forceinline__ bool exact_batch(const LcpGrid& g, const LcpTask& K, const uint2* s_q, const float4* Tsrc, const bool valid,
+                                            const uint32_t i, const uint32_t rank) {
   bool hit = false;
   if (valid) {
     const uint4 hdr = g.list_hdr[rank];
     float T[12];
-    load_rows(K.T + size_t(K.t_stride) * ci, T);
+    load_rows(Tsrc, T);                                         // (three broadcast loads instead of 12 scalar registers held across the sweep)
     const float4 q = K.q4[i];
     float tx, ty, tz;
     transform_point(T, q, tx, ty, tz);                          // exact (reference order, no fma)
@@ -388,36 +384,28 @@ __device__ __forceinline__ void exact_batch(const LcpGrid& g, const LcpTask& K, 
       }
     }
   }
-  // hits per candidate: the entries of a batch belong to one to three consecutive candidates
-  unsigned long long todo = __ballot(valid);
-  const unsigned long long hits = __ballot(hit);
-  while (todo) {
-    const int leader = __builtin_ctzll(todo);
-    const uint32_t cv = uint32_t(__builtin_amdgcn_readlane(int(ci), leader));
-    const unsigned long long same = __ballot(valid && ci == cv);
-    const uint32_t n = uint32_t(__popcll(hits & same));
-    if (n != 0u && lane == uint32_t(leader)) atomicAdd(K.cand_cnt + cv, n);
-    todo &= ~same;
-  }
+  return hit;
 }
 
-// The scoring loop of one wave over the candidates [cand_lo + *s_next .. cand_hi) of its workgroup (drawn from the LDS
-// counter).  s_coarse: LDS copy of the coarse bitmap; s_q: LDS copy of the quantised queries (QLDS); s_queue: this
-// wave's private LDS queue (kQueueEntries entries).
+// Number of sampled-Q points the candidate at Tsrc brings within delta of a sampled-P point, for one wave64.
+//   s_coarse: LDS copy of the coarse bitmap; s_q: LDS copy of the quantised queries (QLDS); s_queue: this wave's
+//   private LDS queue (kQueueEntries entries: 32-bit ranks, then 16-bit query indices)
 template <bool COUNT, bool SKIP_FINE, bool QLDS>
-__device__ __forceinline__ void wave_score(const LcpGrid& g, const LcpTask& K, const uint32_t* s_coarse, const uint2* s_q,
-                                           uint2* s_queue, uint32_t* s_next, const uint32_t cand_lo, const uint32_t cand_hi) {
+__device__ __forceinline__ uint32_t wave_lcp_count(const LcpGrid& g, const LcpTask& K, const uint32_t* s_coarse, const uint2* s_q,
+                                                   uint32_t* s_queue, const float4* Tsrc) {
   constexpr uint32_t kNone = 0xFFFFFFFFu;
   const uint32_t lane = threadIdx.x & 63u;
-  uint32_t qn = 0;
+  uint32_t* q_rank = s_queue;                                                     // queue: ranks (32 bit) ...
+  uint16_t* q_idx = reinterpret_cast<uint16_t*>(s_queue + kQueueEntries);         // ... and query indices (n_Q < 65536)
+  uint32_t cnt = 0, qn = 0;
   const uint32_t cmax = g.coarse_words * 32u - 1u;
   const uint32_t unx = uint32_t(g.nx), uny = uint32_t(g.ny), unz = uint32_t(g.nz);
   const uint32_t ucx = uint32_t(g.cnx), ucy = uint32_t(g.cny);
-  GridXf X;                                              // locating transform of the current candidate
-  uint32_t cl = 0, q_at = K.n_q;                         // current candidate (relative to cand_lo), next query
-  // cell of query i under the current candidate, or kNone if it falls outside the grid or into a coarse cube nothing
-  // can reach (float -> int conversion saturates and one unsigned compare per axis covers both bounds; a NaN coordinate
-  // maps to cell 0 and then fails every exact distance test, so it cannot create an inlier)
+  GridXf X;                                              // locating transform: the only one live across the sweep
+  { float T[12]; load_rows(Tsrc, T); X = locating_xf<QLDS>(g, K, T); }
+  // cell of query i under the candidate, or kNone if it falls outside the grid or into a coarse cube nothing can reach
+  // (float -> int conversion saturates and one unsigned compare per axis covers both bounds; a NaN coordinate maps to
+  // cell 0 and then fails every exact distance test, so it cannot create an inlier)
   auto locate = [&](const float4 q, const uint32_t i) -> uint32_t {
     int ix, iy, iz;
     grid_cell(X.u, q, ix, iy, iz);
@@ -439,49 +427,47 @@ __device__ __forceinline__ void wave_score(const LcpGrid& g, const LcpTask& K, c
       if (lane == 0) { atomicAdd(K.point_tests + 1, (unsigned long long)__popcll(m0)); atomicAdd(K.point_tests + 2, (unsigned long long)__popcll(m)); }
     }
     if (m == 0ull) return;
-    if (reach) s_queue[qn + __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u))] =
-        make_uint2(i | (cl << 16), w.y + uint32_t(__popc(w.x & ((1u << sh) - 1u))));
+    if (reach) {
+      const uint32_t at = qn + __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u));
+      q_rank[at] = w.y + uint32_t(__popc(w.x & ((1u << sh) - 1u)));
+      q_idx[at] = uint16_t(i);
+    }
     qn += uint32_t(__popcll(m));
   };
-  bool flush = false;
-  while (true) {
-    if (q_at >= K.n_q && !flush) {                       // (wave-uniform) next candidate
-      uint32_t nxt = 0;
-      if (lane == 0) nxt = atomicAdd(s_next, 1u);
-      nxt = uint32_t(__builtin_amdgcn_readfirstlane(int(nxt)));
-      if (cand_lo + nxt >= cand_hi) flush = true;
-      else {
-        cl = nxt;
-        q_at = 0;
-        float T[12];
-        load_rows(K.T + size_t(K.t_stride) * (cand_lo + cl), T);
-        X = locating_xf<QLDS>(g, K, T);
-      }
-    }
-    if (!flush) {                                        // one step: two chunks, their reach gathers in flight together
-      const uint32_t last = K.n_q - 1u;
-      const uint32_t i0 = q_at + lane, i1 = i0 + 64u;
+  const uint32_t last = K.n_q - 1u;
+  for (uint32_t base = 0;; base += 256u) {
+    const bool more = base < K.n_q;                      // wave-uniform
+    if (more) {                                          // one step: four chunks, their four reach gathers in flight together
+      const uint32_t i0 = base + lane, i1 = i0 + 64u, i2 = i0 + 128u, i3 = i0 + 192u;
       const float4 q0 = sweep_query<QLDS>(K, s_q, min(i0, last));
       const float4 q1 = sweep_query<QLDS>(K, s_q, min(i1, last));
-      const uint32_t c0 = locate(q0, i0), c1 = locate(q1, i1);
+      const float4 q2 = sweep_query<QLDS>(K, s_q, min(i2, last));
+      const float4 q3 = sweep_query<QLDS>(K, s_q, min(i3, last));
+      const uint32_t c0 = locate(q0, i0), c1 = locate(q1, i1), c2 = locate(q2, i2), c3 = locate(q3, i3);
       // reach words of the L0 survivors; rejected lanes read word 0 (one broadcast line)
       const uint2 w0 = g.reach[c0 == kNone ? 0u : c0 >> 5];
       const uint2 w1 = g.reach[c1 == kNone ? 0u : c1 >> 5];
-      push(c0, w0, i0); push(c1, w1, i1);
+      const uint2 w2 = g.reach[c2 == kNone ? 0u : c2 >> 5];
+      const uint2 w3 = g.reach[c3 == kNone ? 0u : c3 >> 5];
+      push(c0, w0, i0); push(c1, w1, i1); push(c2, w2, i2); push(c3, w3, i3);
       lds_fence();
-      q_at += 128u;
     }
-    // exact stage: full batches as they become available (the queue holds 63 + 2 * 64 entries), the rest at the very end
-    while (qn >= 64u || (flush && qn != 0u)) {
+    // exact stage, ONE code site: full batches as they become available (the queue holds 63 + 4 * 64 entries), the
+    // partial one after the last step
+    while (qn >= 64u || (!more && qn != 0u)) {
       const uint32_t n = min(qn, 64u);
       const bool valid = lane < n;
-      const uint2 e = s_queue[qn - n + min(lane, n - 1u)];
-      if (!SKIP_FINE) exact_batch<COUNT, QLDS>(g, K, s_q, valid, e.x & 0xFFFFu, cand_lo + (e.x >> 16), e.y);
+      const uint32_t at = qn - n + min(lane, n - 1u);
+      if (!SKIP_FINE) cnt += exact_batch<COUNT, QLDS>(g, K, s_q, Tsrc, valid, uint32_t(q_idx[at]), q_rank[at]) ? 1u : 0u;
       qn -= n;
       lds_fence();
     }
-    if (flush) break;
+    if (!more) break;
   }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+  __builtin_amdgcn_wave_barrier();
+  return cnt;
 }
 
 // Global -> LDS copy of the quantised queries (8 B each), padded to a multiple of 128 with the last entry
@@ -933,7 +919,6 @@ struct GateParams {
   BaseFrame base;
   uint32_t* counts;                                     // per quad: kGateFailed, later the inlier count
   uint32_t* cand_idx; float4* cand_T;                   // gated candidates: quad index + 3x4 transform
-  uint32_t* cand_cnt;                                   // ... and their inlier counters (cleared here, accumulated by k_verify)
   uint32_t* C_dev;
 };
 __device__ __forceinline__ bool gate_quad(const GateParams& G, const int4 qd, float T[12]) {
@@ -944,7 +929,6 @@ __device__ __forceinline__ bool gate_quad(const GateParams& G, const int4 qd, fl
 }
 __device__ __forceinline__ void store_candidate(const GateParams& G, const uint32_t at, const uint32_t k, const float T[12]) {
   G.cand_idx[at] = k;
-  G.cand_cnt[at] = 0u;
   float4* dst = G.cand_T + 3 * size_t(at);
   dst[0] = make_float4(T[0], T[1], T[2], T[3]);
   dst[1] = make_float4(T[4], T[5], T[6], T[7]);
@@ -1104,7 +1088,6 @@ struct VerifyParams {
   BaseFrame base;
   const int4* quads; const unsigned long long* tags; uint32_t* counts;
   const uint32_t* cand_idx; const float4* cand_T;       // gated candidates: quad index + 3x4 transform
-  uint32_t* cand_cnt;                                   // ... and their inlier counters (cleared by the gate)
   DevCounters* ctr;                                     // live counters of the base (reset by the last workgroup)
   DevCounters* res;                                     // result record of the base (copied to the host)
   uint4* slots;                                         // per workgroup: {best count, its candidate, tag lo, tag hi}
@@ -1122,39 +1105,38 @@ __global__ __launch_bounds__(kVerifyThreads, 8) void k_verify(VerifyParams P) { 
   extern __shared__ uint32_t s_mem[];
   uint32_t* s_coarse = s_mem;                              // LDS: coarse bitmap | quantised queries (QLDS) | 16 survivor queues
   uint2* s_q = reinterpret_cast<uint2*>(s_mem + P.grid.coarse_words);
-  uint2* s_queue = s_q + (QLDS ? ((P.n_q + 127u) & ~127u) : 0u) + (threadIdx.x >> 6) * (kQueueWordsPerWave / 2);
+  uint32_t* s_queue = reinterpret_cast<uint32_t*>(s_q + (QLDS ? ((P.n_q + 127u) & ~127u) : 0u)) + (threadIdx.x >> 6) * kQueueWordsPerWave;
   __shared__ uint32_t s_next, s_last;
   __shared__ uint32_t s_wcnt[kVerifyThreads / 64], s_wcand[kVerifyThreads / 64];
   __shared__ unsigned long long s_wtag[kVerifyThreads / 64];
   const uint32_t C = P.ctr->C;
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   // Work split: every workgroup owns a contiguous slice of the gated candidate list (static: a single-address global
-  // cursor caps at ~90 dequeues/us, MI355X_MICROARCH "dequeue"); inside the slice its 16 waves draw candidates from an
-  // LDS counter, so a wave that drew cheap candidates simply takes more.  (Slices hold < 65536 candidates: the grid is
-  // sized for that on the host, the queue entries carry the candidate's offset in 16 bits.)
+  // cursor caps at ~90 dequeues/us, MI355X_MICROARCH "dequeue"); inside the slice its 16 waves take candidates from an
+  // LDS counter, so a wave that drew cheap candidates (few L0 survivors) simply takes more.
   const uint32_t lo = uint32_t((uint64_t(C) * blockIdx.x) / gridDim.x), hi = uint32_t((uint64_t(C) * (blockIdx.x + 1u)) / gridDim.x);
+  uint32_t bc = 0, bi = kNil; unsigned long long bt = ~0ull;                // this wave's / thread's best
   if (lo < hi && P.ablate != 2) {                          // (uniform) otherwise: more workgroups than candidates
-    if (threadIdx.x == 0) s_next = 0;
+    if (threadIdx.x == 0) s_next = lo;
     LcpTask K;
-    K.q4 = P.q4v; K.n_q = P.n_q; K.qq = P.qq; K.T = P.cand_T; K.t_stride = 3u; K.cand_cnt = P.cand_cnt; K.point_tests = &P.ctr->point_tests;
+    K.q4 = P.q4v; K.n_q = P.n_q; K.qq = P.qq; K.T = P.cand_T; K.t_stride = 3u; K.point_tests = &P.ctr->point_tests;
     if (QLDS) stage_queries(K, s_q);
     stage_coarse(P.grid, s_coarse);                        // ends with a workgroup barrier
-    if (P.ablate == 1) wave_score<COUNT, true, QLDS>(P.grid, K, s_coarse, s_q, s_queue, &s_next, lo, hi);
-    else wave_score<COUNT, false, QLDS>(P.grid, K, s_coarse, s_q, s_queue, &s_next, lo, hi);
+    while (true) {
+      uint32_t i = 0;
+      if (lane == 0) i = atomicAdd(&s_next, 1u);
+      i = uint32_t(__builtin_amdgcn_readfirstlane(int(i)));
+      if (i >= hi) break;
+      const float4* src = P.cand_T + 3 * size_t(i);         // one candidate per wave
+      const uint32_t cnt = P.ablate == 1 ? wave_lcp_count<COUNT, true, QLDS>(P.grid, K, s_coarse, s_q, s_queue, src)
+                                         : wave_lcp_count<COUNT, false, QLDS>(P.grid, K, s_coarse, s_q, s_queue, src);
+      const uint32_t k = uint32_t(__builtin_amdgcn_readfirstlane(int(P.cand_idx[i])));
+      const unsigned long long tag = P.tags[k];
+      if (lane == 0) P.counts[k] = cnt;
+      if (slot_better(cnt, tag, bc, bt, bi != kNil)) { bc = cnt; bt = tag; bi = i; }
+    }
   }
-  // The workgroup's count atomics are performed at its XCD's L2 and the barrier's workgroup-scope fence waits for this
-  // wave's outstanding ones; the loads below are agent-scope atomics served by the same L2.  (An agent-scope
-  // __threadfence() here -- one L2 write-back per wave, 8192 per launch -- made the kernel 2.4x slower.)
-  __syncthreads();
-  // ---- selection: the workgroup's candidates are final; thread bests -> wave bests -> workgroup best -> slot ----
-  uint32_t bc = 0, bi = kNil; unsigned long long bt = ~0ull;
-  for (uint32_t c = lo + threadIdx.x; c < hi; c += blockDim.x) {
-    const uint32_t cnt = __hip_atomic_load(P.cand_cnt + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const uint32_t k = P.cand_idx[c];
-    P.counts[k] = cnt;                                     // per-quad record (s4p_last_candidates / visitors)
-    const unsigned long long tag = P.tags[k];
-    if (slot_better(cnt, tag, bc, bt, bi != kNil)) { bc = cnt; bt = tag; bi = c; }
-  }
+  // ---- selection: wave bests -> workgroup best -> slot; the last workgroup to finish reduces the slots ----
   auto wave_reduce = [&]() {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -1164,8 +1146,8 @@ __global__ __launch_bounds__(kVerifyThreads, 8) void k_verify(VerifyParams P) { 
       if (oi != kNil && slot_better(oc, ot, bc, bt, bi != kNil)) { bc = oc; bt = ot; bi = oi; }
     }
   };
-  auto block_reduce = [&]() {                              // result valid in thread 0
-    wave_reduce();
+  auto block_reduce = [&](const bool lanes_differ) {        // result valid in thread 0
+    if (lanes_differ) wave_reduce();
     if (lane == 0) { s_wcnt[wave] = bc; s_wcand[wave] = bi; s_wtag[wave] = bt; }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -1174,7 +1156,7 @@ __global__ __launch_bounds__(kVerifyThreads, 8) void k_verify(VerifyParams P) { 
         if (s_wcand[w] != kNil && slot_better(s_wcnt[w], s_wtag[w], bc, bt, bi != kNil)) { bc = s_wcnt[w]; bt = s_wtag[w]; bi = s_wcand[w]; }
     }
   };
-  block_reduce();
+  block_reduce(false);                                     // (the wave's best is uniform over its lanes)
   if (threadIdx.x == 0) {
     P.slots[blockIdx.x] = make_uint4(bc, bi, uint32_t(bt), uint32_t(bt >> 32));
     __threadfence();                                       // release (agent scope): the slot is visible before the ticket
@@ -1190,7 +1172,8 @@ __global__ __launch_bounds__(kVerifyThreads, 8) void k_verify(VerifyParams P) { 
     const unsigned long long t = (unsigned long long)sl.z | ((unsigned long long)sl.w << 32);
     if (sl.y != kNil && slot_better(sl.x, t, bc, bt, bi != kNil)) { bc = sl.x; bt = t; bi = sl.y; }
   }
-  block_reduce();
+  __syncthreads();                                         // (s_w* are reused)
+  block_reduce(true);
   if (threadIdx.x != 0) return;
   DevCounters* c = P.ctr;
   DevCounters* r = P.res;
@@ -1217,7 +1200,7 @@ __global__ __launch_bounds__(kVerifyThreads, 8) void k_verify(VerifyParams P) { 
   c->done = 0;
 }
 
-// k_verify_T: Verify() for explicit row-major 4x4 transforms; counts[] must be zero on entry (accumulated atomically).
+// k_verify_T: Verify() for explicit row-major 4x4 transforms (one wave per transform).
 struct VerifyTParams {
   LcpGrid grid; const float4* q4; QuantQ qq; uint32_t n_q;
   const float* T; uint32_t B; uint32_t* counts; DevCounters* ctr;
@@ -1227,17 +1210,19 @@ __global__ __launch_bounds__(kVerifyThreads) void k_verify_T(VerifyTParams P) {
   extern __shared__ uint32_t s_mem[];
   uint32_t* s_coarse = s_mem;
   uint2* s_q = reinterpret_cast<uint2*>(s_mem + P.grid.coarse_words);
-  uint2* s_queue = s_q + (QLDS ? ((P.n_q + 127u) & ~127u) : 0u) + (threadIdx.x >> 6) * (kQueueWordsPerWave / 2);
-  __shared__ uint32_t s_next;
-  const uint32_t lo = uint32_t((uint64_t(P.B) * blockIdx.x) / gridDim.x), hi = uint32_t((uint64_t(P.B) * (blockIdx.x + 1u)) / gridDim.x);
-  if (lo >= hi) return;
-  if (threadIdx.x == 0) s_next = 0;
+  uint32_t* s_queue = reinterpret_cast<uint32_t*>(s_q + (QLDS ? ((P.n_q + 127u) & ~127u) : 0u)) + (threadIdx.x >> 6) * kQueueWordsPerWave;
   LcpTask K;
-  K.q4 = P.q4; K.n_q = P.n_q; K.qq = P.qq; K.T = reinterpret_cast<const float4*>(P.T); K.t_stride = 4u; K.cand_cnt = P.counts;
+  K.q4 = P.q4; K.n_q = P.n_q; K.qq = P.qq; K.T = reinterpret_cast<const float4*>(P.T); K.t_stride = 4u;
   K.point_tests = COUNT ? &P.ctr->point_tests : nullptr;
   if (QLDS) stage_queries(K, s_q);
   stage_coarse(P.grid, s_coarse);
-  wave_score<COUNT, false, QLDS>(P.grid, K, s_coarse, s_q, s_queue, &s_next, lo, hi);
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+  for (uint32_t k = wave; k < P.B; k += nwaves) {
+    const uint32_t cnt = wave_lcp_count<COUNT, false, QLDS>(P.grid, K, s_coarse, s_q, s_queue, K.T + 4 * size_t(k));
+    if (lane == 0) P.counts[k] = cnt;
+  }
 }
 
 // ---------------------------------------------------------------------------

@@ -21,6 +21,7 @@
 #include <rccl/rccl.h>
 #include <dlfcn.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -200,6 +201,7 @@ struct Loop {
   uint32_t threshold_count = 0, best_count = 0;
   bool terminated = false;
   uint64_t trials_done = 0, local_candidates = 0;
+  uint64_t trials_prepared = 0, trial_limit = ~0ull;     // trials of the common sequence handed out so far / never run from here on
   int slot_rr = 0;
   std::string err;
   int32_t fail(int32_t rc, const std::string& m) { err = m; return rc; }
@@ -208,10 +210,13 @@ struct Loop {
     w.bases.resize(size_t(world));
     for (int j = 0; j < world; ++j) {
       bool found = false;
-      if (int32_t rc = ops.prepare(j == rank, &found, w.bases[size_t(j)].ids)) return rc;
+      // trials past the limit (the tail of the last window of a registration) are not run by anybody
+      if (trials_prepared + uint64_t(j) < trial_limit)
+        if (int32_t rc = ops.prepare(j == rank, &found, w.bases[size_t(j)].ids)) return rc;
       w.bases[size_t(j)].found = found;
       if (j == rank) w.mine_found = found;
     }
+    trials_prepared += uint64_t(world);
     return S4P_OK;
   }
   int32_t post_window(Window& w) {
@@ -374,20 +379,36 @@ int32_t s4p_shard_compute_transformation(s4p_shard* s, const s4p_cloud_view* P, 
   *lcp = 1e9f;                                                     // kLargeNumber, match4pcsBase.hpp:69-70
   if (!P || !Q || P->n == 0 || Q->n == 0) return S4P_OK;
   if (int32_t rc = s4p_matcher_init_full(m, P, Q)) { s->err = s4p_matcher_last_error(m); return rc; }
-  s->loop.terminated = false; s->loop.trials_done = 0;
+  s->loop.terminated = false; s->loop.trials_done = 0; s->loop.trials_prepared = 0;
   s4p_matcher_info info;
   if (int32_t rc = s4p_matcher_get_info(m, &info)) return rc;
   const float lcp0 = info.best_lcp;
   if (info.best_lcp != 1.f) {
+    // Perform_N_steps (match4pcsBase.hpp:236-256) runs trial i = 0, 1, ... and leaves the loop after the first trial with
+    // max(time fraction, float(i) / float(number_of_trials)) >= 0.99, or when the terminate threshold is crossed:
+    const int N = info.number_of_trials;
+    int i_stop = N - 1;
+    for (int i = 0; i < N; ++i) if (float(i) / float(N) >= 0.99f) { i_stop = i; break; }
+    s->loop.trial_limit = uint64_t(i_stop) + 1u;
     const int world = s->loop.world;
-    const int windows = (info.number_of_trials + world - 1) / world;
-    // in slices, so that a crossed threshold stops the job within a few windows (the loop itself only stops committing)
+    const int windows = (i_stop + 1 + world - 1) / world;
+    const auto t0 = std::chrono::system_clock::now();
+    const long max_seconds = long(s4p_matcher_max_time_seconds(m));
+    // in slices, so that a crossed threshold or the time budget stops the job within a few windows
     for (int done = 0; done < windows && !s->loop.terminated;) {
-      const int n = std::min(windows - done, 8 * std::max(1, s->loop.ops.depth));
+      const int n = std::min(windows - done, 8 * std::max(1, s4p_pipeline_depth(s4p_matcher_ctx(m))));
       int32_t term = 0;
       if (int32_t rc = s4p_shard_run_windows(s, n, nullptr, &term)) return rc;
       done += n;
+      // time budget (integer seconds / integer max_time_seconds: the reference's quirk, :240-243), agreed on by all ranks
+      const long el = long(std::chrono::duration_cast<std::chrono::seconds>(std::chrono::system_clock::now() - t0).count());
+      const uint64_t mine = (max_seconds > 0 && float(el / max_seconds) >= 0.99f) ? 1u : 0u;
+      uint64_t any = 0;
+      if (int32_t rc = s->coll->post(0, mine)) { s->err = s->coll->err; return rc; }
+      if (int32_t rc = s->coll->result(0, &any)) { s->err = s->coll->err; return rc; }
+      if (any) break;
     }
+    s->loop.trial_limit = ~0ull;
   }
   if (int32_t rc = s4p_matcher_get_info(m, &info)) return rc;
   *lcp = info.best_lcp;

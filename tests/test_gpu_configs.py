@@ -221,3 +221,45 @@ def test_config4_part_in_whole_10m_scene(oracle_mod, s4p_lib_built):
     if SCALE == 1.0:
         _gm, quads, cand = _fused_bases_vs_oracle(oracle_mod, capi, P, Q, delta, 0.2, 2000, 28, 8 << 20, 64 << 20, count_sample=400, skip_bases=17)
         assert quads >= 148 and cand >= 42
+
+
+def test_config2_gpu_scale_sample_20000_pairs(oracle_mod, s4p_lib_built):
+    """configs[2] at the "GPU-scale" sample size of SURVEY.md 8d (n = 20 000 sampled Q points): ExtractPairs of the first
+    base, both sets (16.8 M and 10.2 M ordered pairs), in the reference's emission order against the oracle; then the fused
+    pass of that base must either fit the configured capacities or fail LOUDLY with S4P_ERR_CAPACITY (the congruent quads of
+    one base at this sample size run into the billions: the reference itself is not usable there, its O(m1 x m2) quad
+    search alone takes > 25 CPU-minutes per base)."""
+    from super4pcs_amd import capi, datasets as D
+    import bench
+    from bench import seg_len32
+    if SCALE != 1.0:
+        pytest.skip("full-size case")
+    O = oracle_mod
+    n_s = 20000
+    P, Q, _ = D.bumpy_pair(bench.N_POINTS, overlap=bench.OVERLAP, delta=bench.DELTA, seed=bench.SEED)
+    om = O.Matcher(O.make_options(bench.DELTA, bench.OVERLAP, n_s), full_counts=True, use_kdtree=True, keep_trace=False)
+    om.init(P, Q)
+    Ps, Qs = om.cloud(0), om.cloud(1)
+    assert Qs.shape[0] == n_s
+    ctx = capi.Context(capi.make_options(bench.DELTA, bench.OVERLAP, n_s), max_pairs=32 << 20, max_quads=16 << 20)
+    ctx.set_clouds(Ps, Qs)
+    ok, i1, i2, base, bx = om.select_quadrilateral()
+    assert ok
+    ctx.set_base(bx)
+    eps = 2.0 * bench.DELTA
+    total = 0
+    for a, b in ((0, 1), (2, 3)):
+        d = seg_len32(bx[a], bx[b])
+        want = om.extract_pairs_cap(d, 0.0, eps, a, b, 1 << 25)
+        got = ctx.extract_pairs(d, 0.0, eps, a, b, cap=1 << 25)
+        assert got.shape == want.shape and np.array_equal(got, want)          # same pairs, same emission order
+        total += want.shape[0]
+    assert total > 20_000_000
+    # the fused pass of one base: loud capacity error, never a silent truncation
+    gm = capi.Matcher(capi.make_options(bench.DELTA, bench.OVERLAP, n_s), max_pairs=32 << 20, max_quads=16 << 20)
+    gm.init_full(P, Q)
+    try:
+        _ok, r = gm.try_one_base()
+        assert r.n_quads <= (16 << 20)
+    except capi.S4PError as e:
+        assert e.code == -5 and "overflow" in str(e)
