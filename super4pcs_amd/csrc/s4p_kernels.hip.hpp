@@ -87,7 +87,13 @@ struct LcpGrid {
   float sq_eps;                 // fl(delta*delta)
 };
 
-constexpr int kQueueEntries = 320;                 // per-wave survivor queue: 63 left over + one step of 4 x 64 entries
+// S4P_EXACT_DUAL = 1: the exact stage takes 128 queued queries at a time, two per lane, so that two point lists are in
+// flight per lane (the stage is latency bound: ~14 dependent gathers per batch); the sweep then
+// takes two chunks per step so that the longer queue still fits the LDS budget.
+#ifndef S4P_EXACT_DUAL
+#define S4P_EXACT_DUAL 0
+#endif
+constexpr int kQueueEntries = S4P_EXACT_DUAL ? 256 : 320;   // per-wave survivor queue: (63 | 127) left over + one step of (4 | 2) x 64 entries
 constexpr int kQueueWordsPerWave = kQueueEntries + kQueueEntries / 2;     // 32-bit rank + 16-bit query index per entry: 1920 B
 constexpr int kCoarseMaxWords = 9216;              // 36 KB (two 1024-thread workgroups per CU share 160 KB: 80 KB each)
 constexpr int kVerifyLdsBudget = 80 * 1024 - 768;  // per workgroup: coarse bitmap + 16 queues (30 KB) [+ quantised queries]
@@ -387,6 +393,56 @@ __device__ __forceinline__ bool exact_batch(const LcpGrid& g, const LcpTask& K, 
   return hit;
 }
 
+// One queue entry prepared for the point loop: the exact transformed query and its list range (empty if the entry is
+// not valid or its sub-cell cannot be reached).
+struct ExactEntry { float tx, ty, tz; uint32_t p, e; };
+template <bool COUNT, bool QLDS>
+__device__ __forceinline__ ExactEntry exact_setup(const LcpGrid& g, const LcpTask& K, const uint2* s_q, const float* T, const float* XU,
+                                                  const bool valid, const uint32_t i, const uint32_t rank) {
+  ExactEntry E;
+  E.tx = E.ty = E.tz = 0.f; E.p = E.e = 0u;
+  if (valid) {
+    const uint4 hdr = g.list_hdr[rank];
+    const float4 q = K.q4[i];
+    transform_point(T, q, E.tx, E.ty, E.tz);                    // exact (reference order, no fma)
+    int ix, iy, iz;
+    grid_cell(XU, sweep_query<QLDS>(K, s_q, i), ix, iy, iz);
+    const float rx = (E.tx - g.ox) * g.inv_h - float(ix), ry = (E.ty - g.oy) * g.inv_h - float(iy), rz = (E.tz - g.oz) * g.inv_h - float(iz);
+    const uint32_t sx = uint32_t(min(max(int(rx * 4.f), 0), 3)), sy = uint32_t(min(max(int(ry * 4.f), 0), 3)),
+                   sz = uint32_t(min(max(int(rz * 4.f), 0), 3));
+    const uint32_t sb = sz * 16u + sy * 4u + sx;
+    const uint32_t mword = sb < 32u ? hdr.z : hdr.w;
+    if ((mword >> (sb & 31u)) & 1u) {
+      if (COUNT) { atomicAdd(K.point_tests + 3, 1ull); atomicAdd(K.point_tests, (unsigned long long)hdr.y); }
+      E.p = hdr.x; E.e = hdr.x + hdr.y;
+    }
+  }
+  return E;
+}
+// Exact stage for up to 128 queue entries, two per lane (A, B): both lists advance together, four 16-byte loads in
+// flight per lane and step.  Returns the number of inliers among this lane's two queries.
+template <bool COUNT, bool QLDS>
+__device__ __forceinline__ uint32_t exact_pair(const LcpGrid& g, const LcpTask& K, const uint2* s_q, const float4* Tsrc, const float* XU,
+                                               const bool validA, const uint32_t iA, const uint32_t rankA,
+                                               const bool validB, const uint32_t iB, const uint32_t rankB) {
+  ExactEntry A, B;
+  { float T[12]; load_rows(Tsrc, T);
+    A = exact_setup<COUNT, QLDS>(g, K, s_q, T, XU, validA, iA, rankA);
+    B = exact_setup<COUNT, QLDS>(g, K, s_q, T, XU, validB, iB, rankB); }
+  uint32_t hits = 0;
+  while (A.p < A.e || B.p < B.e) {
+    const bool la = A.p < A.e, lb = B.p < B.e;
+    const float4 a0 = g.nbr[la ? A.p : 0u], a1 = g.nbr[la ? min(A.p + 1u, A.e - 1u) : 0u];
+    const float4 b0 = g.nbr[lb ? B.p : 0u], b1 = g.nbr[lb ? min(B.p + 1u, B.e - 1u) : 0u];
+    const bool ha0 = sqn3(A.tx - a0.x, A.ty - a0.y, A.tz - a0.z) <= g.sq_eps, ha1 = sqn3(A.tx - a1.x, A.ty - a1.y, A.tz - a1.z) <= g.sq_eps;
+    const bool hb0 = sqn3(B.tx - b0.x, B.ty - b0.y, B.tz - b0.z) <= g.sq_eps, hb1 = sqn3(B.tx - b1.x, B.ty - b1.y, B.tz - b1.z) <= g.sq_eps;
+    const bool ha = la && (ha0 || ha1), hb = lb && (hb0 || hb1);
+    if (ha) { ++hits; A.p = A.e; } else if (la) A.p += 2u;
+    if (hb) { ++hits; B.p = B.e; } else if (lb) B.p += 2u;
+  }
+  return hits;
+}
+
 // Number of sampled-Q points the candidate at Tsrc brings within delta of a sampled-P point, for one wave64.
 //   s_coarse: LDS copy of the coarse bitmap; s_q: LDS copy of the quantised queries (QLDS); s_queue: this wave's
 //   private LDS queue (kQueueEntries entries: 32-bit ranks, then 16-bit query indices)
@@ -435,6 +491,32 @@ __device__ __forceinline__ uint32_t wave_lcp_count(const LcpGrid& g, const LcpTa
     qn += uint32_t(__popcll(m));
   };
   const uint32_t last = K.n_q - 1u;
+#if S4P_EXACT_DUAL
+  for (uint32_t base = 0;; base += 128u) {
+    const bool more = base < K.n_q;                      // wave-uniform
+    if (more) {                                          // one step: two chunks
+      const uint32_t i0 = base + lane, i1 = i0 + 64u;
+      const float4 q0 = sweep_query<QLDS>(K, s_q, min(i0, last));
+      const float4 q1 = sweep_query<QLDS>(K, s_q, min(i1, last));
+      const uint32_t c0 = locate(q0, i0), c1 = locate(q1, i1);
+      const uint2 w0 = g.reach[c0 == kNone ? 0u : c0 >> 5];
+      const uint2 w1 = g.reach[c1 == kNone ? 0u : c1 >> 5];
+      push(c0, w0, i0); push(c1, w1, i1);
+      lds_fence();
+    }
+    // exact stage, ONE code site: 128 entries at a time (the queue holds 127 + 2 * 64), the rest after the last step
+    // (the locating transform X is already in registers: the exact stage reuses it for the cells)
+    while (qn >= 128u || (!more && qn != 0u)) {
+      const uint32_t n = min(qn, 128u);
+      const bool va = lane < n, vb = lane + 64u < n;
+      const uint32_t aa = qn - n + min(lane, n - 1u), ab = qn - n + min(lane + 64u, n - 1u);
+      if (!SKIP_FINE) cnt += exact_pair<COUNT, QLDS>(g, K, s_q, Tsrc, X.u, va, uint32_t(q_idx[aa]), q_rank[aa], vb, uint32_t(q_idx[ab]), q_rank[ab]);
+      qn -= n;
+      lds_fence();
+    }
+    if (!more) break;
+  }
+#else
   for (uint32_t base = 0;; base += 256u) {
     const bool more = base < K.n_q;                      // wave-uniform
     if (more) {                                          // one step: four chunks, their four reach gathers in flight together
@@ -464,6 +546,7 @@ __device__ __forceinline__ uint32_t wave_lcp_count(const LcpGrid& g, const LcpTa
     }
     if (!more) break;
   }
+#endif
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
   __builtin_amdgcn_wave_barrier();
