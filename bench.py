@@ -446,6 +446,22 @@ def main():
         except Exception as e:                                  # noqa: BLE001
             hbm_point = {"error": "%s: %s" % (type(e).__name__, e)}
 
+    apply_row = None
+    if rank == 0 and world == 1 and args.hbm_point:
+        # final apply (match4pcsBase.hpp:265-267) on device-resident points: the product's VALU kernel against its MFMA
+        # formulation, GB/s = 24 B per point (12 in, 12 out) / HIP-event time; DESIGN.md section 5.2
+        try:
+            actx = capi.Context(opt, device=local_rank, max_pairs=1 << 16, max_quads=1 << 16)
+            apply_row = {}
+            for n in (1_000_000, 10_000_000):
+                ms_valu, ms_mfma, mism, maxabs = actx.apply_bench(n, 20)
+                apply_row["n=%d" % n] = {"valu_ms": ms_valu, "valu_GBps": 24.0 * n / (ms_valu * 1e-3) / 1e9,
+                                         "mfma_ms": ms_mfma, "mfma_GBps": 24.0 * n / (ms_mfma * 1e-3) / 1e9,
+                                         "coordinates_differing_from_valu": mism, "of": 3 * n, "max_abs_difference": maxabs}
+            actx.close()
+        except Exception as e:                                  # noqa: BLE001
+            apply_row = {"error": "%s: %s" % (type(e).__name__, e)}
+
     if rank == 0:
         launches = max(prof.verify_launches, 1)
         avg_ms = prof.verify_ms_total / launches
@@ -489,6 +505,7 @@ def main():
                                             "replaced; kept for reference, not a roofline fraction"},
                 "hbm_bound_point": hbm_point,
             },
+            "k_apply": apply_row,
             "stage_ms_per_step": {"pairs_and_prep": prof.pairs_ms_total / max(prof.quads_launches, 1),
                                   "quads_and_gate": prof.quads_ms_total / max(prof.quads_launches, 1), "verify_and_select": avg_ms},
         }

@@ -91,7 +91,7 @@ struct LcpGrid {
 // flight per lane (the stage is latency bound: ~14 dependent gathers per batch); the sweep then
 // takes two chunks per step so that the longer queue still fits the LDS budget.
 #ifndef S4P_EXACT_DUAL
-#define S4P_EXACT_DUAL 0
+#define S4P_EXACT_DUAL 1          // measured: k_verify 0.161 -> 0.151 ms alone, 69.5 -> 70.7 M candidates/s with three lanes
 #endif
 constexpr int kQueueEntries = S4P_EXACT_DUAL ? 256 : 320;   // per-wave survivor queue: (63 | 127) left over + one step of (4 | 2) x 64 entries
 constexpr int kQueueWordsPerWave = kQueueEntries + kQueueEntries / 2;     // 32-bit rank + 16-bit query index per entry: 1920 B
@@ -296,13 +296,14 @@ __global__ __launch_bounds__(256) void k_build_masks(MaskParams P) {
 // LCP scoring: Verify() (match4pcsBase.cc:508-567) without the early exit.
 //
 // Structure per wave and candidate:
-//   sweep (four 64-query chunks per step): position in grid units (3 converts + 9 fma + 3 floor-converts), L0 test of the
+//   sweep (two 64-query chunks per step): position in grid units (3 converts + 9 fma + 3 floor-converts), L0 test of the
 //     cell's coarse cube against the LDS bitmap, L1 reach word (8 B gather; rejected lanes read word 0, one broadcast
 //     line); queries whose cell is reachable are compacted (ballot/prefix) into the wave's LDS queue as {query, rank of
 //     the cell among the reachable ones};
-//   exact stage whenever 64 entries wait (and once at the end): lane per entry -- the candidate's exact 3x4, list header,
-//     4x4x4 sub-cell mask, then the exact predicate sqdist <= delta^2 (kdtree.h:417-421) against the listed points, two
-//     16-byte loads per dependent step.
+//   exact stage whenever 128 entries wait (and once at the end): TWO entries per lane -- the candidate's exact 3x4, list
+//     headers, 4x4x4 sub-cell masks, then the exact predicate sqdist <= delta^2 (kdtree.h:417-421) against the listed
+//     points, both lists advancing together with four 16-byte loads in flight per lane and dependent step (the stage is
+//     latency bound; two lists per lane halve its dependent steps per query).
 // The sampled-Q points the SWEEP reads live in LDS, quantised to 3 x 16 bit over Q's bounding box (8 B per query, 16 KB
 // for n_Q = 2000): the 32 KB float array that every wave re-streamed for every candidate through a 32 KB L1 it shares
 // with the gathers is gone from the sweep (-18 % L1 accesses).  The sweep only LOCATES a query; the quantisation moves it
