@@ -178,6 +178,18 @@ int32_t s4p_last_candidates(s4p_ctx* ctx, int32_t* quads, int32_t* counts, int64
  * by the base whose s4p_try_base_wait returned last, in reference order.  Valid until that lane is reused. */
 int32_t s4p_last_verified(s4p_ctx* ctx, uint32_t* counts, float* transforms16, int64_t cap, int64_t* n_out);
 
+/* ---- base selection: Match4PCSBase::SelectRandomTriangle + the 4th-point scan of SelectQuadrilateral
+ * (match4pcsBase.cc:185-218, 279-338) as device reductions over the sampled P resident in HBM: ONE attempt.
+ * draws: the 2001 indices (first, then 1000 x (second, third)) of `rand() % n_P` the reference would draw for this
+ * attempt -- the random stream stays with the caller; limit_sq = max_base_diameter^2, too_small = (0.2 * max_base_diameter)^2.
+ * ids[4] / xyz[12]: the three triangle points and the 4th point (sampling-order indices, -1 where none; centred
+ * coordinates).  status: 0 found, 1 no wide triangle (SelectRandomTriangle returned false), 2 coplanar-with-origin
+ * triangle (denominator 0: the reference retries), 3 no admissible 4th point (retries).  The winner of either search is
+ * the reference's: first strictly wider triangle / first strictly closer point in index order.
+ * May be called from a thread of its own while bases are in flight. */
+int32_t s4p_select_base_points(s4p_ctx* ctx, const uint32_t* draws, float limit_sq, float too_small,
+                               int32_t* ids, float* xyz, int32_t* status);
+
 /* ---- final apply: Match4PCSBase::Perform_N_steps tail (match4pcsBase.hpp:265-267) */
 /* xyz SoA in place: p <- (M * [p;1]).head<3>() for n points. */
 int32_t s4p_transform_points(s4p_ctx* ctx, const float* M, float* x, float* y, float* z, int64_t n);

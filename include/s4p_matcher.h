@@ -123,6 +123,14 @@ int32_t s4p_matcher_perform_n_steps(s4p_matcher* m, int32_t n, s4p_visitor_fn vi
  * lower for candidates that cannot win).  Costs a device read-back per trial; off by default. */
 int32_t s4p_matcher_visit_candidates(s4p_matcher* m, int32_t enable);
 
+/* Where SelectQuadrilateral's two searches run (match4pcsBase.cc:185-218 wide triangle, :321-338 4th point): mode 1 =
+ * device reductions over the sampled P resident in HBM (s4p_select_base_points), 0 = the host search structures, -1
+ * (default) = by size: device from 2^20 sampled P points (the S4P_DEVICE_SELECT environment variable overrides the
+ * default).  Same draws, same bases either way.  Takes effect at the next init; s4p_matcher_device_selection reports
+ * what the initialised matcher uses. */
+int32_t s4p_matcher_set_device_selection(s4p_matcher* m, int32_t mode);
+int32_t s4p_matcher_device_selection(const s4p_matcher* m);
+
 /* getGlobalTransform (match4pcsBase.hpp:224-229). */
 int32_t s4p_matcher_global_transform(s4p_matcher* m, float* transformation);
 

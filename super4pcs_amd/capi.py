@@ -19,7 +19,7 @@ ERR_NAMES = {0: "OK", -1: "BAD_ARG", -2: "NO_DEVICE", -3: "HIP", -4: "OOM", -5: 
 EXPORTED_SYMBOLS = [
     "s4p_create", "s4p_destroy", "s4p_last_error", "s4p_device_name", "s4p_set_clouds", "s4p_set_base",
     "s4p_extract_pairs", "s4p_find_congruent", "s4p_try_congruent_set", "s4p_verify_transforms", "s4p_verify_transforms_counted",
-    "s4p_transform_points_device", "s4p_apply_bench", "s4p_try_base", "s4p_last_verified", "s4p_try_base_async", "s4p_try_base_wait", "s4p_pair_state_words", "s4p_pair_state_save", "s4p_pair_state_restore", "s4p_stage_slots", "s4p_pipeline_depth", "s4p_stage_base", "s4p_try_base_staged_async", "s4p_skip_base", "s4p_last_candidates", "s4p_transform_points", "s4p_profile_enable", "s4p_profile_get",
+    "s4p_transform_points_device", "s4p_apply_bench", "s4p_select_base_points", "s4p_try_base", "s4p_last_verified", "s4p_try_base_async", "s4p_try_base_wait", "s4p_pair_state_words", "s4p_pair_state_save", "s4p_pair_state_restore", "s4p_stage_slots", "s4p_pipeline_depth", "s4p_stage_base", "s4p_try_base_staged_async", "s4p_skip_base", "s4p_last_candidates", "s4p_transform_points", "s4p_profile_enable", "s4p_profile_get",
     "s4p_selftest_ieee",
 ]
 
@@ -112,6 +112,9 @@ def load_library():
         L.s4p_transform_points_device.argtypes = [vp, fp, vp, vp, vp, C.c_int64]
         L.s4p_apply_bench.restype = C.c_int32
         L.s4p_apply_bench.argtypes = [vp, C.c_int64, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_float)]
+    if hasattr(L, "s4p_select_base_points"):
+        L.s4p_select_base_points.restype = C.c_int32
+        L.s4p_select_base_points.argtypes = [vp, C.POINTER(C.c_uint32), C.c_float, C.c_float, ip, fp, ip]
     L.s4p_profile_enable.restype = C.c_int32
     L.s4p_profile_enable.argtypes = [vp, C.c_int32, C.c_int32]
     L.s4p_profile_get.restype = C.c_int32
@@ -263,6 +266,14 @@ class Context:
         self._chk(self.L.s4p_apply_bench(self.h, int(n), int(reps), ms, C.byref(mm), C.byref(mx)))
         return ms[0], ms[1], int(mm.value), float(mx.value)
 
+    def select_base_points(self, draws, limit_sq, too_small):
+        """One attempt of the device base selection: (status, ids[4], xyz[4, 3]); see s4p_select_base_points."""
+        d = np.ascontiguousarray(draws, np.uint32)
+        assert d.shape == (2001,)
+        ids = np.empty(4, np.int32); xyz = np.empty(12, np.float32); st = C.c_int32()
+        self._chk(self.L.s4p_select_base_points(self.h, d.ctypes.data_as(C.POINTER(C.c_uint32)), float(limit_sq), float(too_small), _i(ids), _f(xyz), C.byref(st)))
+        return int(st.value), ids, xyz.reshape(4, 3)
+
     def profile_enable(self, events=True, point_tests=False):
         self._chk(self.L.s4p_profile_enable(self.h, int(events), int(point_tests)))
 
@@ -304,7 +315,7 @@ SHARD_SYMBOLS = [
 MATCHER_SYMBOLS = [
     "s4p_matcher_create", "s4p_matcher_destroy", "s4p_matcher_last_error", "s4p_matcher_ctx", "s4p_uniform_dist_sample",
     "s4p_matcher_init", "s4p_matcher_init_full", "s4p_matcher_get_info", "s4p_matcher_get_sampled",
-    "s4p_matcher_get_sampled_attrs", "s4p_matcher_select_quadrilateral", "s4p_matcher_try_one_base", "s4p_matcher_next_base", "s4p_matcher_next_base_async", "s4p_matcher_wait_base", "s4p_matcher_set_sharding", "s4p_matcher_visit_candidates", "s4p_matcher_commit", "s4p_matcher_perform_n_steps",
+    "s4p_matcher_get_sampled_attrs", "s4p_matcher_select_quadrilateral", "s4p_matcher_try_one_base", "s4p_matcher_next_base", "s4p_matcher_next_base_async", "s4p_matcher_wait_base", "s4p_matcher_set_sharding", "s4p_matcher_visit_candidates", "s4p_matcher_commit", "s4p_matcher_perform_n_steps", "s4p_matcher_set_device_selection", "s4p_matcher_device_selection",
     "s4p_matcher_global_transform", "s4p_matcher_compute_transformation",
 ]
 VISITOR_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_float, C.c_float, C.POINTER(C.c_float))
@@ -453,6 +464,13 @@ class Matcher:
         x = np.empty(n, np.float32); y = np.empty(n, np.float32); z = np.empty(n, np.float32)
         self._chk(self.L.s4p_matcher_get_sampled(self.h, which, _f(x), _f(y), _f(z)))
         return np.stack([x, y, z], axis=1)
+
+    def set_device_selection(self, mode):
+        """-1 by size (default), 0 host search structures, 1 device reductions; before init."""
+        self._chk(self.L.s4p_matcher_set_device_selection(self.h, int(mode)))
+
+    def device_selection(self):
+        return bool(self.L.s4p_matcher_device_selection(self.h))
 
     def select_quadrilateral(self):
         found = C.c_int32(); i1 = C.c_float(); i2 = C.c_float()

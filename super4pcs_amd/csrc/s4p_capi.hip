@@ -101,6 +101,10 @@ struct s4p_ctx {
   hipEvent_t done[4] = {nullptr, nullptr, nullptr, nullptr};
   DevBuf<float> tbuf; size_t tbuf_cap = 0;      // s4p_transform_points: two device + two pinned staging chunks
   PinBuf<float> tpin; hipEvent_t tev[2] = {nullptr, nullptr};
+  // base selection on the device (s4p_select_base_points): the sampled P as float4 records in sampling order, one
+  // attempt's 2001 draws and its result record; a stream of its own, so a selector thread never queues behind a lane
+  DevBuf<float4> p4o; DevBuf<uint32_t> sel_draws; DevBuf<SelectRecord> sel_rec;
+  PinBuf<uint32_t> sel_hdraws; PinBuf<SelectRecord> sel_hrec; hipStream_t sel_stream = nullptr;
 
   // profiling
   bool prof_events = false, prof_points = false;
@@ -475,6 +479,9 @@ int32_t s4p_create(const s4p_options* opt, const s4p_limits* lim, int32_t device
       if ((e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds)) != hipSuccess) return fail(e, "hipFuncSetAttribute");
   }
   for (auto& row : c->ev) for (auto& ev : row) if ((e = hipEventCreate(&ev)) != hipSuccess) return fail(e, "hipEventCreate");
+  if ((e = hipStreamCreateWithFlags(&c->sel_stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
+  if ((e = c->sel_draws.alloc(kSelectDraws)) != hipSuccess || (e = c->sel_rec.alloc(1)) != hipSuccess) return fail(e, "hipMalloc selection buffers");
+  if ((e = c->sel_hdraws.alloc(kSelectDraws)) != hipSuccess || (e = c->sel_hrec.alloc(1)) != hipSuccess) return fail(e, "hipHostMalloc selection buffers");
   *out = c;
   return S4P_OK;
 }
@@ -496,6 +503,8 @@ void s4p_destroy(s4p_ctx* c) {
   for (auto& h : c->hctr) h.free();
   for (auto& st : c->stage) for (int s = 0; s < 2; ++s) st.seq[s].free();
   c->tbuf.free(); c->tpin.free();
+  if (c->sel_stream) { (void)hipStreamSynchronize(c->sel_stream); (void)hipStreamDestroy(c->sel_stream); }
+  c->p4o.free(); c->sel_draws.free(); c->sel_rec.free(); c->sel_hdraws.free(); c->sel_hrec.free();
   for (auto& e : c->tev) if (e) (void)hipEventDestroy(e);
   for (auto& row : c->ev) for (auto& ev : row) if (ev) (void)hipEventDestroy(ev);
   for (auto& ev : c->done) if (ev) (void)hipEventDestroy(ev);
@@ -545,6 +554,8 @@ int32_t s4p_set_clouds(s4p_ctx* c, const float* px, const float* py, const float
       step(hipMemsetAsync(cell_count.p, 0, nc * 4, st));
       step(hipMemsetAsync(c->gcoarse.p, 0, size_t(c->hgrid.coarse_words) * 4, st));
       if (e != hipSuccess) break;
+      if (!step(c->p4o.alloc(size_t(n_p)))) break;
+      hipLaunchKernelGGL(k_pack_points, dim3(1024), dim3(256), 0, st, dpx.p, dpy.p, dpz.p, uint32_t(n_p), c->p4o.p);
       GridBuildParams G{};
       G.px = dpx.p; G.py = dpy.p; G.pz = dpz.p; G.n_p = uint32_t(n_p);
       G.ox = c->hgrid.ox; G.oy = c->hgrid.oy; G.oz = c->hgrid.oz; G.h = c->hgrid.h; G.inv_h = c->hgrid.inv_h;
@@ -1040,6 +1051,32 @@ int32_t s4p_transform_points(s4p_ctx* c, const float* M, float* x, float* y, flo
 // per variant (0 = VALU, the product path; 1 = v_mfma_f32_4x4x1 chain).  out_ms[variant] = mean HIP-event time per
 // launch; *mismatch = coordinates where the MFMA result is not bit-identical to the VALU result; *max_abs = their
 // largest absolute difference.
+// SelectRandomTriangle + the 4th-point scan of SelectQuadrilateral as device reductions (k_select_*): one attempt.
+// Safe to call from a thread of its own while bases are in flight: it touches only the selection buffers and stream.
+int32_t s4p_select_base_points(s4p_ctx* c, const uint32_t* draws, float limit_sq, float too_small,
+                               int32_t* ids, float* xyz, int32_t* status) {
+  if (!c || !draws || !ids || !xyz || !status) return S4P_ERR_BAD_ARG;
+  if (!c->clouds_set || !c->p4o.p) S4P_FAIL(c, S4P_ERR_STATE, "s4p_select_base_points: call s4p_set_clouds first");
+  for (int k = 0; k < kSelectDraws; ++k)
+    if (draws[k] >= c->n_p) S4P_FAIL(c, S4P_ERR_BAD_ARG, "s4p_select_base_points: draw outside the sampled P");
+  HIPCHK(c, hipSetDevice(c->device));
+  hipStream_t st = c->sel_stream;
+  std::memcpy(c->sel_hdraws.p, draws, sizeof(uint32_t) * kSelectDraws);
+  HIPCHK(c, hipMemcpyAsync(c->sel_draws.p, c->sel_hdraws.p, sizeof(uint32_t) * kSelectDraws, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(k_select_triangle, dim3(1), dim3(1024), 0, st, c->p4o.p, c->sel_draws.p, limit_sq, c->sel_rec.p);
+  const uint32_t blocks = std::min<uint32_t>(2048u, (c->n_p + 1023u) / 1024u);
+  hipLaunchKernelGGL(k_select_fourth, dim3(blocks ? blocks : 1u), dim3(256), 0, st, c->p4o.p, c->n_p, too_small, c->sel_rec.p);
+  hipLaunchKernelGGL(k_select_finish, dim3(1), dim3(64), 0, st, c->p4o.p, c->sel_rec.p);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(c->sel_hrec.p, c->sel_rec.p, sizeof(SelectRecord), hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipStreamSynchronize(st));
+  const SelectRecord& r = *c->sel_hrec.p;
+  for (int k = 0; k < 4; ++k) ids[k] = r.ids[k];
+  for (int k = 0; k < 12; ++k) xyz[k] = r.xyz[k];
+  *status = r.status;
+  return S4P_OK;
+}
+
 int32_t s4p_apply_bench(s4p_ctx* c, int64_t n, int32_t reps, double* out_ms, uint64_t* mismatch, float* max_abs) {
   if (!c || n <= 0 || reps <= 0 || !out_ms || !mismatch || !max_abs) return S4P_ERR_BAD_ARG;
   HIPCHK(c, hipSetDevice(c->device));

@@ -105,7 +105,10 @@ struct s4p_matcher {
   float centroid_p[3] = {0, 0, 0}, centroid_q[3] = {0, 0, 0};
   float p_diameter = 0.f, max_base_diameter = -1.f;
   std::vector<float> P4;                 // sampled P as (x, y, z, 0) records: one cache line per random draw of the base search
-  s4p::FourthPointIndex fourth;          // block-pruned 4th-point search over the sampled P
+  s4p::FourthPointIndex fourth;          // block-pruned 4th-point search over the sampled P (host selection mode)
+  // Where SelectQuadrilateral's two searches run: -1 = by size (device from kDeviceSelectMin sampled P points), 0 = host
+  // structures above, 1 = device reductions over the resident P (s4p_select_base_points); fixed by init.
+  int select_mode = -1; bool device_select = false;
   int number_of_trials = 0, current_trial = 0;
   float best_lcp = 0.f; uint32_t best_count = 0;
   float transform[16];
@@ -116,6 +119,7 @@ struct s4p_matcher {
   uint64_t candidates_verified = 0, quads_total = 0, pairs_total = 0, bases_tried = 0;
   double seconds_select = 0, seconds_device = 0;
   bool ready = false;
+  std::atomic<bool> select_failed{false}; std::string select_err;   // a device selection attempt returned an error (possibly on the selector thread)
   bool visit_candidates = false;         // issue the reference's per-candidate visitor calls (fraction == -1)
   // pipelined trials: bases whose device pass is in flight (at most two)
   struct Prepared {
@@ -249,7 +253,7 @@ bool pick_triangle(s4p_matcher* m, int& b1, int& b2, int& b3) {
 }
 
 // match4pcsBase.cc:225-274: best of the 12 segment pairings; reorders ids.
-bool order_quadrilateral(s4p_matcher* m, int ids[4], float& inv1, float& inv2) {
+bool order_quadrilateral(const V3 pts[4], int ids[4], float& inv1, float& inv2) {
   float best = std::numeric_limits<float>::max();
   int pick[4] = {-1, -1, -1, -1};
   for (int i = 0; i < 4; ++i)
@@ -258,7 +262,7 @@ bool order_quadrilateral(s4p_matcher* m, int ids[4], float& inv1, float& inv2) {
       int k = 0; while (k == i || k == j) k++;
       int l = 0; while (l == i || l == j || l == k) l++;
       double a, b;
-      const float dist = float(segment_segment(m->P(ids[i]), m->P(ids[j]), m->P(ids[k]), m->P(ids[l]), a, b));
+      const float dist = float(segment_segment(pts[i], pts[j], pts[k], pts[l], a, b));
       if (dist < best) { best = dist; pick[0] = i; pick[1] = j; pick[2] = k; pick[3] = l; inv1 = float(a); inv2 = float(b); }
     }
   if (pick[0] < 0 || pick[1] < 0 || pick[2] < 0 || pick[3] < 0) return false;
@@ -267,10 +271,39 @@ bool order_quadrilateral(s4p_matcher* m, int ids[4], float& inv1, float& inv2) {
   return true;
 }
 
+// Device selection: the draws of one attempt are made here, the searches run in k_select_*.
+// Returns the status of s4p_select_base_points, or -1 on a device error (m->err set).
+constexpr size_t kDeviceSelectMin = size_t(1) << 20;
+int device_attempt(s4p_matcher* m, int ids[4], V3 pts[4]) {
+  const uint32_t n = uint32_t(m->Ps.size());
+  if (n == 0) return 1;
+  const uint64_t magic = ~0ull / n + 1ull;
+  uint32_t idx[2001];
+  for (int t = 0; t < 2001; ++t) {
+    const uint32_t a = uint32_t(m->rng());
+    idx[t] = uint32_t((static_cast<unsigned __int128>(magic * a) * n) >> 64);
+  }
+  const float kBaseTooSmall = 0.2f;
+  const float limit = m->max_base_diameter * m->max_base_diameter;
+  const float too_small = float(std::pow(double(m->max_base_diameter * kBaseTooSmall), 2));
+  int32_t got[4], status = -1; float xyz[12];
+  if (s4p_select_base_points(m->ctx, idx, limit, too_small, got, xyz, &status) != S4P_OK) { m->select_err = s4p_last_error(m->ctx); return -1; }
+  for (int t = 0; t < 4; ++t) { ids[t] = got[t]; pts[t] = V3{xyz[3 * t], xyz[3 * t + 1], xyz[3 * t + 2]}; }
+  return status;
+}
+
 // match4pcsBase.cc:279-351
 bool select_quadrilateral(s4p_matcher* m, float& inv1, float& inv2, int ids[4]) {
   const float kBaseTooSmall = 0.2f;
   for (int attempt = 0; attempt < 1000; ++attempt) {
+    if (m->device_select) {
+      V3 pts[4];
+      const int st = device_attempt(m, ids, pts);
+      if (st < 0) { m->select_failed.store(true, std::memory_order_release); return false; }
+      if (st == 1) return false;                    // SelectRandomTriangle failed: the reference gives up (:285-287)
+      if (st == 0 && order_quadrilateral(pts, ids, inv1, inv2)) return true;
+      continue;
+    }
     int b1, b2, b3;
     if (!pick_triangle(m, b1, b2, b3)) return false;
     const V3 A = m->P(b1), B = m->P(b2), C = m->P(b3);
@@ -292,7 +325,8 @@ bool select_quadrilateral(s4p_matcher* m, float& inv1, float& inv2, int ids[4]) 
       b4 = m->fourth.query(pa, pb, pc, pA, pB, pC, too_small);
       if (b4 != -1) {
         ids[0] = b1; ids[1] = b2; ids[2] = b3; ids[3] = b4;
-        if (order_quadrilateral(m, ids, inv1, inv2)) return true;
+        const V3 pts[4] = {A, B, C, m->P(b4)};
+        if (order_quadrilateral(pts, ids, inv1, inv2)) return true;
       }
     }
   }
@@ -455,6 +489,7 @@ int32_t next_base(s4p_matcher* m, bool run_device, bool& found, int ids[4], s4p_
   auto t0 = clk::now();
   found = select_quadrilateral(m, inv1, inv2, ids);
   m->seconds_select += std::chrono::duration<double>(clk::now() - t0).count();
+  if (m->select_failed.load(std::memory_order_acquire)) return m->fail(S4P_ERR_HIP, "device base selection failed: " + m->select_err);
   if (!found) return S4P_OK;                                     // :313-316
   float bx[12], bn[12], bc[12];
   fill_base_arrays(m, ids, bx, bn, bc);
@@ -478,6 +513,7 @@ int32_t next_base_async(s4p_matcher* m, bool run_device, bool snapshot, s4p_matc
   if (m->prod.enabled) {
     s4p_matcher::Trial t;
     producer_pop(m, t);
+    if (m->select_failed.load(std::memory_order_acquire)) { if (t.slot >= 0) producer_release_slot(m, t.slot); return m->fail(S4P_ERR_HIP, "device base selection failed: " + m->select_err); }
     if (t.owned != run_device) return m->fail(S4P_ERR_STATE, "sharding mismatch: the producer and the caller disagree on who owns this trial");
     pr.found = t.found; pr.device = false; pr.slot = -1;
     for (int k = 0; k < 4; ++k) pr.ids[k] = t.ids[k];
@@ -499,6 +535,7 @@ int32_t next_base_async(s4p_matcher* m, bool run_device, bool snapshot, s4p_matc
   auto t0 = clk::now();
   pr.found = select_quadrilateral(m, inv1, inv2, pr.ids);
   m->seconds_select += std::chrono::duration<double>(clk::now() - t0).count();
+  if (m->select_failed.load(std::memory_order_acquire)) return m->fail(S4P_ERR_HIP, "device base selection failed: " + m->select_err);
   pr.device = false;
   if (!pr.found) return S4P_OK;
   float bx[12], bn[12], bc[12];
@@ -648,8 +685,13 @@ int32_t s4p_matcher_init(s4p_matcher* m, const s4p_cloud_view* p, const s4p_clou
   m->best_lcp = 0.f; m->best_count = 0;
   for (int t = 0; t < 4; ++t) { m->base[t] = 0; m->congruent[t] = 0; }
   m->set_identity();
-  // host-side search structures of SelectQuadrilateral, built while the device builds its own
+  // SelectQuadrilateral's searches: device reductions for large sampled P (or when asked for), else the host-side
+  // search structures, built while the device builds its own
+  if (const char* e = std::getenv("S4P_DEVICE_SELECT")) { if (m->select_mode < 0) m->select_mode = std::atoi(e) != 0 ? 1 : 0; }
+  m->device_select = m->select_mode >= 0 ? m->select_mode != 0 : Ps.size() >= kDeviceSelectMin;
+  m->select_failed.store(false);
   std::thread host_index([m, &Ps] {
+    if (m->device_select) { m->P4.clear(); m->P4.shrink_to_fit(); m->fourth = s4p::FourthPointIndex(); return; }
     const size_t np = Ps.size();
     m->P4.resize(4 * np);
     for (size_t i = 0; i < np; ++i) { m->P4[4 * i] = Ps.x[i]; m->P4[4 * i + 1] = Ps.y[i]; m->P4[4 * i + 2] = Ps.z[i]; m->P4[4 * i + 3] = 0.f; }
@@ -742,6 +784,7 @@ int32_t s4p_matcher_select_quadrilateral(s4p_matcher* m, int32_t* found, float* 
   if (!m->ready) return m->fail(S4P_ERR_STATE, "matcher not initialised");
   int ids[4] = {0, 0, 0, 0};
   *found = select_quadrilateral(m, *inv1, *inv2, ids) ? 1 : 0;
+  if (m->select_failed.load(std::memory_order_acquire)) return m->fail(S4P_ERR_HIP, "device base selection failed: " + m->select_err);
   for (int t = 0; t < 4; ++t) base_ids[t] = ids[t];
   if (base_xyz && *found) { float bn[12], bc[12]; fill_base_arrays(m, ids, base_xyz, bn, bc); }
   return S4P_OK;
@@ -765,6 +808,14 @@ int32_t s4p_matcher_next_base(s4p_matcher* m, int32_t run_device, int32_t* found
   for (int t = 0; t < 4; ++t) base_ids[t] = ids[t];
   return rc;
 }
+
+int32_t s4p_matcher_set_device_selection(s4p_matcher* m, int32_t mode) {
+  if (!m || mode < -1 || mode > 1) return S4P_ERR_BAD_ARG;
+  m->select_mode = mode;                  // takes effect at the next init
+  return S4P_OK;
+}
+
+int32_t s4p_matcher_device_selection(const s4p_matcher* m) { return m && m->device_select ? 1 : 0; }
 
 int32_t s4p_matcher_visit_candidates(s4p_matcher* m, int32_t enable) {
   if (!m) return S4P_ERR_BAD_ARG;

@@ -1348,6 +1348,105 @@ __global__ __launch_bounds__(256) void k_apply_mfma(ApplyParams P) {
   }
 }
 
+// ---------------------------------------------------------------------------
+// Base selection on the device: SelectRandomTriangle's 1000-draw search (match4pcsBase.cc:185-218) and the
+// 4th-point scan of SelectQuadrilateral (match4pcsBase.cc:303-338) as reductions over the sampled P resident in HBM
+// (float4 records in sampling order).  The random stream stays on the host (std::mt19937, 2001 draws per attempt, none
+// of them depends on a point); everything that reads points runs here.  Both loops of the reference keep "the first
+// strictly better item", i.e. the lexicographic optimum of (value, position): packed into 64-bit keys
+//   triangle:  max over  bits(area) << 32 | (0xFFFFFFFF - draw)      area = |u x w| > 0, both edges below the limit
+//   4th point: min over  bits(dist) << 32 | index                     dist = |a x + b y + c z - 1| < FLT_MAX
+// (non-negative floats order like their bit patterns).
+// ---------------------------------------------------------------------------
+struct SelectRecord {
+  unsigned long long tri_key, fourth_key;
+  int32_t ids[4];
+  int32_t status;                 // kSelect*
+  float pa, pb, pc;
+  float xyz[12];
+};
+constexpr int32_t kSelectFound = 0, kSelectNoTriangle = 1, kSelectDegenerate = 2, kSelectNoFourth = 3;
+constexpr int kSelectTriangles = 1000;      // kNumberOfDiameterTrials, match4pcsBase.cc:58
+constexpr int kSelectDraws = 1 + 2 * kSelectTriangles;
+
+__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int o) {
+  const uint32_t lo = uint32_t(__shfl_xor(int(uint32_t(v)), o)), hi = uint32_t(__shfl_xor(int(uint32_t(v >> 32)), o));
+  return (static_cast<unsigned long long>(hi) << 32) | lo;
+}
+
+__global__ __launch_bounds__(1024) void k_select_triangle(const float4* __restrict__ p4, const uint32_t* __restrict__ draws,
+                                                          float limit_sq, SelectRecord* rec) {
+  __shared__ unsigned long long s_key[16];
+  const uint32_t t = threadIdx.x;
+  unsigned long long key = 0;
+  const float4 o = p4[draws[0]];
+  if (t < uint32_t(kSelectTriangles)) {
+    const float4 ps = p4[draws[1 + 2 * t]], pt = p4[draws[2 + 2 * t]];
+    const float ux = ps.x - o.x, uy = ps.y - o.y, uz = ps.z - o.z;
+    const float wx = pt.x - o.x, wy = pt.y - o.y, wz = pt.z - o.z;
+    const float cx = uy * wz - uz * wy, cy = uz * wx - ux * wz, cz = ux * wy - uy * wx;
+    const float wide = sqrtf(sqn3(cx, cy, cz));
+    if (sqn3(ux, uy, uz) < limit_sq && sqn3(wx, wy, wz) < limit_sq && wide > 0.f)
+      key = (static_cast<unsigned long long>(__float_as_uint(wide)) << 32) | (0xFFFFFFFFu - t);
+  }
+  for (int s = 32; s > 0; s >>= 1) { const unsigned long long k2 = shfl_xor_u64(key, s); key = k2 > key ? k2 : key; }
+  if ((t & 63u) == 0) s_key[t >> 6] = key;
+  __syncthreads();
+  if (t != 0) return;
+  for (int w = 1; w < 16; ++w) key = s_key[w] > key ? s_key[w] : key;
+  rec->tri_key = key;
+  rec->fourth_key = ~0ull;
+  rec->ids[0] = rec->ids[1] = rec->ids[2] = rec->ids[3] = -1;
+  rec->pa = rec->pb = rec->pc = 0.f;
+  if (key == 0) { rec->status = kSelectNoTriangle; return; }
+  const uint32_t win = 0xFFFFFFFFu - uint32_t(key);
+  const uint32_t b1 = draws[0], b2 = draws[1 + 2 * win], b3 = draws[2 + 2 * win];
+  rec->ids[0] = int32_t(b1); rec->ids[1] = int32_t(b2); rec->ids[2] = int32_t(b3);
+  // plane through the three points, a x + b y + c z = 1, in double as match4pcsBase.cc:303-316 writes it
+  const float4 A = p4[b1], B = p4[b2], Cc = p4[b3];
+  const double x1 = A.x, y1 = A.y, z1 = A.z, x2 = B.x, y2 = B.y, z2 = B.z, x3 = Cc.x, y3 = Cc.y, z3 = Cc.z;
+  const float denom = float(-x3 * y2 * z1 + x2 * y3 * z1 + x3 * y1 * z2 - x1 * y3 * z2 - x2 * y1 * z3 + x1 * y2 * z3);
+  if (!(denom != 0)) { rec->status = kSelectDegenerate; return; }
+  rec->pa = float((-y2 * z1 + y3 * z1 + y1 * z2 - y3 * z2 - y1 * z3 + y2 * z3) / denom);
+  rec->pb = float((x2 * z1 - x3 * z1 - x1 * z2 + x3 * z2 + x1 * z3 - x2 * z3) / denom);
+  rec->pc = float((-x2 * y1 + x3 * y1 + x1 * y2 - x3 * y2 - x1 * y3 + x2 * y3) / denom);
+  rec->status = kSelectNoFourth;                // until k_select_fourth finds one
+}
+
+__global__ __launch_bounds__(256) void k_select_fourth(const float4* __restrict__ p4, uint32_t n_p, float too_small, SelectRecord* rec) {
+  if (rec->status != kSelectNoFourth) return;
+  const float pa = rec->pa, pb = rec->pb, pc = rec->pc;
+  const float4 A = p4[rec->ids[0]], B = p4[rec->ids[1]], Cc = p4[rec->ids[2]];
+  unsigned long long key = ~0ull;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_p; i += gridDim.x * blockDim.x) {
+    const float4 p = p4[i];
+    const float d = fabsf(((pa * p.x + pb * p.y) + pc * p.z) - 1.0f);
+    if (!(d < 3.402823466e+38f)) continue;
+    if (!(sqn3(p.x - A.x, p.y - A.y, p.z - A.z) >= too_small)) continue;
+    if (!(sqn3(p.x - B.x, p.y - B.y, p.z - B.z) >= too_small)) continue;
+    if (!(sqn3(p.x - Cc.x, p.y - Cc.y, p.z - Cc.z) >= too_small)) continue;
+    const unsigned long long k2 = (static_cast<unsigned long long>(__float_as_uint(d)) << 32) | i;
+    key = k2 < key ? k2 : key;
+  }
+  for (int s = 32; s > 0; s >>= 1) { const unsigned long long k2 = shfl_xor_u64(key, s); key = k2 < key ? k2 : key; }
+  if ((threadIdx.x & 63u) == 0 && key != ~0ull) atomicMin(&rec->fourth_key, key);
+}
+
+__global__ void k_select_finish(const float4* __restrict__ p4, SelectRecord* rec) {
+  const uint32_t t = threadIdx.x;
+  int32_t id = t < 3 ? rec->ids[t] : -1;
+  if (t == 3 && rec->status == kSelectNoFourth && rec->fourth_key != ~0ull) id = int32_t(uint32_t(rec->fourth_key));
+  if (t < 4) {
+    const float4 p = id >= 0 ? p4[id] : make_float4(0.f, 0.f, 0.f, 0.f);
+    rec->xyz[3 * t] = p.x; rec->xyz[3 * t + 1] = p.y; rec->xyz[3 * t + 2] = p.z;
+  }
+  if (t == 3 && id >= 0) { rec->ids[3] = id; rec->status = kSelectFound; }
+}
+
+__global__ void k_pack_points(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, uint32_t n, float4* __restrict__ out) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = make_float4(x[i], y[i], z[i], 0.f);
+}
+
 __global__ void k_selftest(const float* a, const float* b, uint64_t n, float* o_sqrt, float* o_div, float* o_ma) {
   for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
     const float x = a[i], y = b[i];

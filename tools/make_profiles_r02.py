@@ -3,6 +3,7 @@
   profiles/r02_ab_runs.json          every A/B arm of tools/gpu_run*.sh (tools/ab_one.py lines), per run script
   profiles/r02_pmc_k_verify.json     rocprofv3 --pmc means per k_verify launch, per variant / counter set
   profiles/r02_kernel_stats_*.csv    rocprofv3 --kernel-trace --stats summaries (1 and 3 lanes)
+  profiles/r02_final_kernel_stats_bench_*.csv   the same for the bench.py command of the final pass
   profiles/r02_bench*.json           bench.py lines
 Run from the repo root after the GPU passes."""
 import collections
@@ -47,6 +48,10 @@ json.dump({"note": "rocprofv3 --pmc <set> --kernel-trace -- python tools/ab_one.
 for f in glob.glob(os.path.join(G, "r2stats_l*", "**", "r_kernel_stats.csv"), recursive=True):
     lanes = os.path.relpath(f, G).split(os.sep)[0].replace("r2stats_", "")
     shutil.copy(f, os.path.join(P, "r02_kernel_stats_%s.csv" % lanes))
+# rocprofv3 --kernel-trace --stats of the bench.py command itself (tools/gpu_run12.sh): default lanes and S4P_LANES=1
+for tag, name in (("r2stats_bench", "r02_final_kernel_stats_bench_3lanes.csv"), ("r2stats_bench_l1", "r02_final_kernel_stats_bench_1lane.csv")):
+    for f in glob.glob(os.path.join(G, tag, "**", "r_kernel_stats.csv"), recursive=True):
+        shutil.copy(f, os.path.join(P, name))
 for f in glob.glob(os.path.join(G, "r2_bench*.json")):
     shutil.copy(f, os.path.join(P, os.path.basename(f).replace("r2_", "r02_")))
 print("profiles updated:", sorted(x for x in os.listdir(P) if x.startswith("r02_")))
