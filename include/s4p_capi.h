@@ -215,6 +215,7 @@ typedef struct {
   uint64_t pairs_launches, quads_launches;
   double   host_octree_s;        /* host time in the pair-octree builds (loop 1 of IntersectionFunctor)   */
   double   host_wait_s;          /* host time blocked in stream synchronisation                           */
+  uint64_t verify_settled;       /* packed point lists: queries settled by the float records (undecided quantised distance), if enabled */
 } s4p_profile;
 int32_t s4p_profile_enable(s4p_ctx* ctx, int32_t enable_events, int32_t count_point_tests);
 int32_t s4p_profile_get(s4p_ctx* ctx, s4p_profile* out, int32_t reset);

@@ -60,7 +60,7 @@ class Profile(C.Structure):
         ("verify_l0_pass", C.c_uint64), ("verify_l1_pass", C.c_uint64), ("verify_l2_pass", C.c_uint64),
         ("pairs_ms_total", C.c_double), ("quads_ms_total", C.c_double),
         ("pairs_launches", C.c_uint64), ("quads_launches", C.c_uint64),
-        ("host_octree_s", C.c_double), ("host_wait_s", C.c_double),
+        ("host_octree_s", C.c_double), ("host_wait_s", C.c_double), ("verify_settled", C.c_uint64),
     ]
 
 
@@ -362,6 +362,11 @@ def _declare_matcher(L):
     L.s4p_matcher_perform_n_steps.argtypes = [vp, C.c_int32, VISITOR_FN, vp, C.c_int32, fp, ip, ip]
     L.s4p_matcher_global_transform.restype = C.c_int32
     L.s4p_matcher_global_transform.argtypes = [vp, fp]
+    if hasattr(L, "s4p_matcher_set_device_selection"):
+        L.s4p_matcher_set_device_selection.restype = C.c_int32
+        L.s4p_matcher_set_device_selection.argtypes = [vp, C.c_int32]
+        L.s4p_matcher_device_selection.restype = C.c_int32
+        L.s4p_matcher_device_selection.argtypes = [vp]
     L.s4p_matcher_compute_transformation.restype = C.c_int32
     L.s4p_matcher_compute_transformation.argtypes = [vp, cv, cv, fp, fp, fp, fp, fp]
     _MATCHER_DECLARED = True

@@ -57,6 +57,7 @@ struct s4p_ctx {
 
   // device state
   DevBuf<uint2> greach; DevBuf<uint4> glist_hdr; DevBuf<uint32_t> gcoarse; DevBuf<float4> gnbr; DevBuf<float4> q4, q4v;
+  DevBuf<uint32_t> gpk; double pk_pad = 0, pk_scale = 0, pk_quant_err = 0;      // 4-byte packed copies of the point lists (LcpGrid::pk)
   DevBuf<uint2> qquant; QuantQ qq{}; bool qlds = false;      // 16-bit copy of the Morton-ordered queries for the LDS-resident sweep
   DevBuf<float> qx, qy, qz, ux, uy, uz, qnx, qny, qnz, qcr, qcg, qcb;
   // Two lanes = two HIP streams with private per-base device buffers.  Consecutive bases alternate lanes, so the
@@ -132,6 +133,19 @@ struct s4p_ctx {
     g.ox = hgrid.ox; g.oy = hgrid.oy; g.oz = hgrid.oz; g.inv_h = hgrid.inv_h;
     g.nx = hgrid.nx; g.ny = hgrid.ny; g.nz = hgrid.nz;
     g.sq_eps = opt.delta * opt.delta;     // match4pcsBase.cc:517,522
+    // Packed lists: thresholds on the quantised squared distance (in packed units).  With r = sqrt(sq_eps) / h in grid
+    // units and m = the largest difference between a quantised and an exact distance -- sqrt(3) half steps of the 10-bit
+    // records, the float rounding of a query's cell-relative position (a few ulp at the grid's size) and of the exact
+    // predicate itself -- a quantised distance <= r - m is an inlier of the exact predicate and one > r + m is not.
+    g.pk = gpk.p;
+    g.pk_pad = float(pk_pad); g.pk_scale = float(pk_scale);
+    {
+      const double r = std::sqrt(double(g.sq_eps)) / double(hgrid.h);
+      const double dims = double(hgrid.nx) + double(hgrid.ny) + double(hgrid.nz);
+      const double m = 1.7320508075688772 * (0.5 / pk_scale) * 1.0001 + 4.0 * 1.2e-7 * dims + 2e-5;
+      const double lo = std::max(0.0, (r - m) * pk_scale), hi = (r + m) * pk_scale;
+      g.pk_lo2 = float(lo * lo * (1.0 - 1e-6)); g.pk_hi2 = float(hi * hi * (1.0 + 1e-6));
+    }
     return g;
   }
 };
@@ -372,7 +386,7 @@ int32_t finish_result(s4p_ctx* c, s4p_base_result* r, bool fused) {
       if (hipEventElapsedTime(&ms, c->ev[c->cur][3], c->ev[c->cur][4]) == hipSuccess) { c->prof.quads_ms_total += ms; c->prof.quads_launches += 1; }
     }
   }
-  if (c->prof_points) { c->prof.verify_point_tests += d.point_tests; c->prof.verify_l0_pass += d.l0_pass; c->prof.verify_l1_pass += d.l1_pass; c->prof.verify_l2_pass += d.l2_pass; }
+  if (c->prof_points) { c->prof.verify_point_tests += d.point_tests; c->prof.verify_l0_pass += d.l0_pass; c->prof.verify_l1_pass += d.l1_pass; c->prof.verify_l2_pass += d.l2_pass; c->prof.verify_settled += d.settled; }
   return S4P_OK;
 }
 
@@ -490,7 +504,7 @@ void s4p_destroy(s4p_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   for (auto& L : c->lane) { if (L.stream) (void)hipStreamSynchronize(L.stream); if (L.vstream) (void)hipStreamSynchronize(L.vstream); }
-  c->greach.free(); c->glist_hdr.free(); c->gnbr.free();
+  c->greach.free(); c->glist_hdr.free(); c->gnbr.free(); c->gpk.free();
   c->gcoarse.free(); c->q4.free(); c->q4v.free(); c->qquant.free();
   c->qx.free(); c->qy.free(); c->qz.free(); c->ux.free(); c->uy.free(); c->uz.free();
   c->qnx.free(); c->qny.free(); c->qnz.free(); c->qcr.free(); c->qcg.free(); c->qcb.free();
@@ -541,7 +555,7 @@ int32_t s4p_set_clouds(s4p_ctx* c, const float* px, const float* py, const float
     hipStream_t st = c->lane[0].stream;
     const uint64_t nc = c->hgrid.ncell();
     const uint32_t nwords = uint32_t((nc + 31) / 32);
-    DevBuf<float> dpx, dpy, dpz; DevBuf<uint32_t> cell_count, word_pop, hdr_count, cell_id, cursor, totals;
+    DevBuf<float> dpx, dpy, dpz; DevBuf<uint32_t> cell_count, word_pop, hdr_count, cell_id, cursor, totals, pk_err;
     hipError_t e = hipSuccess;
     int32_t rc = S4P_OK;
     auto step = [&](hipError_t r) { if (e == hipSuccess) e = r; return e == hipSuccess; };
@@ -576,11 +590,13 @@ int32_t s4p_set_clouds(s4p_ctx* c, const float* px, const float* py, const float
       DevBuf<uint32_t> starts;
       if (!step(starts.alloc(n_reach))) break;
       step(hipMemcpyAsync(starts.p, hdr_count.p, size_t(n_reach) * 4, hipMemcpyDeviceToDevice, st));
+      hipLaunchKernelGGL(k_round_up4, dim3(1024), dim3(256), 0, st, starts.p, n_reach);      // every list starts on a 16-byte packed record
       hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, st, starts.p, n_reach, totals.p + 1);
       uint32_t n_entries = 0;
       step(hipMemcpyAsync(&n_entries, totals.p + 1, 4, hipMemcpyDeviceToHost, st));
       if (!step(hipStreamSynchronize(st))) { starts.free(); break; }
-      if (!step(c->gnbr.alloc(n_entries))) { starts.free(); break; }
+      if (!step(c->gnbr.alloc(n_entries)) || !step(c->gpk.alloc(n_entries)) || !step(pk_err.alloc(1))) { starts.free(); break; }
+      step(hipMemsetAsync(pk_err.p, 0, 4, st));
       G.nbr = c->gnbr.p;
       hipLaunchKernelGGL(k_grid_hdr_pack, dim3(1024), dim3(256), 0, st, G, starts.p, hdr_count.p, n_reach);
       hipLaunchKernelGGL(k_grid_fill, dim3(2048), dim3(256), 0, st, G);
@@ -588,12 +604,24 @@ int32_t s4p_set_clouds(s4p_ctx* c, const float* px, const float* py, const float
       M.list_hdr = c->glist_hdr.p; M.nbr = c->gnbr.p; M.cell_id = cell_id.p; M.n_reach = n_reach;
       M.ox = c->hgrid.ox; M.oy = c->hgrid.oy; M.oz = c->hgrid.oz; M.h = c->hgrid.h; M.nx = c->hgrid.nx; M.ny = c->hgrid.ny;
       M.reach2 = G.reach2;
+      // packed copies: position relative to the cell in grid units, [-pad, 1 + pad] -> [0, 1023]
+      c->pk_pad = c->hgrid.reach / double(c->hgrid.h) + 2e-3;
+      c->pk_scale = 1023.0 / (1.0 + 2.0 * c->pk_pad);
+      M.pk = c->gpk.p; M.pk_pad = c->pk_pad; M.pk_scale = c->pk_scale; M.pk_err = pk_err.p;
       hipLaunchKernelGGL(k_build_masks, dim3((n_reach + 255) / 256), dim3(256), 0, st, M);
       step(hipGetLastError());
+      uint32_t err_bits = 0;
+      step(hipMemcpyAsync(&err_bits, pk_err.p, 4, hipMemcpyDeviceToHost, st));
       step(hipStreamSynchronize(st));
       starts.free();
+      if (e == hipSuccess) {
+        float worst; std::memcpy(&worst, &err_bits, 4);
+        c->pk_quant_err = double(worst);
+        // every listed point lies inside the quantised range by construction (reach + one cell); half a step is the bound
+        if (!(c->pk_quant_err <= 0.5 / c->pk_scale * 1.0001)) { c->err = "LCP grid: packed point lists exceed their quantisation bound"; rc = S4P_ERR_STATE; break; }
+      }
     } while (0);
-    dpx.free(); dpy.free(); dpz.free(); cell_count.free(); word_pop.free(); hdr_count.free(); cell_id.free(); cursor.free(); totals.free();
+    dpx.free(); dpy.free(); dpz.free(); cell_count.free(); word_pop.free(); hdr_count.free(); cell_id.free(); cursor.free(); totals.free(); pk_err.free();
     if (rc != S4P_OK) return rc;
     HIPCHK(c, e);
   }

@@ -54,6 +54,7 @@ struct DevCounters {
   unsigned long long best_tag;      // min tag among candidates with best_count
   unsigned long long point_tests;   // optional instrumentation (COUNT kernels only)
   unsigned long long l0_pass, l1_pass, l2_pass;
+  unsigned long long settled;       // packed lists: queries whose undecided points went to the float records
   uint32_t done;                    // k_verify: workgroups that have published their best (last one selects the winner)
   // winner record
   int32_t best_quad[4];
@@ -85,6 +86,11 @@ struct LcpGrid {
   float ox, oy, oz, inv_h;
   int nx, ny, nz;
   float sq_eps;                 // fl(delta*delta)
+  // packed point lists (S4P_PACKED_LISTS): one 32-bit record per list entry, 3 x 10 bit, position relative to the
+  // cell in grid units: u = round((rel + pk_pad) * pk_scale); a squared distance in these units at most pk_lo2 is an
+  // inlier for certain, above pk_hi2 a miss for certain; in between the float record decides
+  const uint32_t* pk;
+  float pk_pad, pk_scale, pk_lo2, pk_hi2;
 };
 
 // S4P_EXACT_DUAL = 1: the exact stage takes 128 queued queries at a time, two per lane, so that two point lists are in
@@ -92,6 +98,12 @@ struct LcpGrid {
 // takes two chunks per step so that the longer queue still fits the LDS budget.
 #ifndef S4P_EXACT_DUAL
 #define S4P_EXACT_DUAL 1          // measured: k_verify 0.161 -> 0.151 ms alone, 69.5 -> 70.7 M candidates/s with three lanes
+#endif
+// S4P_PACKED_LISTS = 1: the exact stage walks 4-byte quantised copies of the point lists, four points per 16-byte load
+// (the stage is bound by dependent gathers and by cache-line lookups, one per lane and load); the float records are
+// read only for the rare point whose quantised distance falls inside the quantisation band around delta.
+#ifndef S4P_PACKED_LISTS
+#define S4P_PACKED_LISTS 1
 #endif
 constexpr int kQueueEntries = S4P_EXACT_DUAL ? 256 : 320;   // per-wave survivor queue: (63 | 127) left over + one step of (4 | 2) x 64 entries
 constexpr int kQueueWordsPerWave = kQueueEntries + kQueueEntries / 2;     // 32-bit rank + 16-bit query index per entry: 1920 B
@@ -243,6 +255,9 @@ __global__ __launch_bounds__(256) void k_grid_headers(GridBuildParams P, const u
     }
   }
 }
+__global__ __launch_bounds__(256) void k_round_up4(uint32_t* v, uint32_t n) {          // list lengths -> multiples of four entries
+  for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) v[r] = (v[r] + 3u) & ~3u;
+}
 __global__ __launch_bounds__(256) void k_grid_hdr_pack(GridBuildParams P, const uint32_t* list_start, const uint32_t* hdr_count, uint32_t n_reach) {
   for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n_reach; r += gridDim.x * blockDim.x) {
     P.list_hdr[r] = make_uint4(list_start[r], hdr_count[r], 0u, 0u);
@@ -266,8 +281,9 @@ __global__ __launch_bounds__(256) void k_grid_fill(GridBuildParams P) {
 // Fills hdr.z/.w, the 4x4x4 sub-cell reach masks, from the point lists.
 // bit(sx,sy,sz) = some listed point lies within `reach` of the sub-box; double precision, same slack as the lists.
 struct MaskParams {
-  uint4* list_hdr; const float4* nbr; const uint32_t* cell_id; uint32_t n_reach;
+  uint4* list_hdr; float4* nbr; const uint32_t* cell_id; uint32_t n_reach;
   float ox, oy, oz, h; int nx, ny; double reach2;
+  uint32_t* pk; double pk_pad, pk_scale; uint32_t* pk_err;      // packed copies; *pk_err = max |dequantised - true| (float bits), any axis
 };
 __global__ __launch_bounds__(256) void k_build_masks(MaskParams P) {
   const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -290,6 +306,25 @@ __global__ __launch_bounds__(256) void k_build_masks(MaskParams P) {
   }
   hdr.z = uint32_t(mask); hdr.w = uint32_t(mask >> 32);
   P.list_hdr[r] = hdr;
+  // lists start at multiples of four entries: pad with copies of the last point (a duplicate cannot change "some listed
+  // point within delta"), then the packed copy of every entry
+  const uint32_t padded = (hdr.y + 3u) & ~3u;
+  float worst = 0.f;
+  for (uint32_t k = 0; k < padded; ++k) {
+    const float4 pp = P.nbr[hdr.x + min(k, hdr.y - 1u)];
+    if (k >= hdr.y) P.nbr[hdr.x + k] = pp;
+    const double rel[3] = {(double(pp.x) - bx) / double(P.h), (double(pp.y) - by) / double(P.h), (double(pp.z) - bz) / double(P.h)};
+    uint32_t u[3];
+    for (int a = 0; a < 3; ++a) {
+      const double v = (rel[a] + P.pk_pad) * P.pk_scale;
+      const double c = v < 0.0 ? 0.0 : (v > 1023.0 ? 1023.0 : v);
+      u[a] = uint32_t(c + 0.5);
+      const float err = float(fabs((double(u[a]) / P.pk_scale - P.pk_pad) - rel[a]));
+      worst = err > worst ? err : worst;
+    }
+    P.pk[hdr.x + k] = u[0] | (u[1] << 10) | (u[2] << 20);
+  }
+  atomicMax(P.pk_err, __float_as_uint(worst));
 }
 
 // ---------------------------------------------------------------------------
@@ -444,6 +479,94 @@ __device__ __forceinline__ uint32_t exact_pair(const LcpGrid& g, const LcpTask& 
   return hits;
 }
 
+// --- packed lists ------------------------------------------------------------------------------------------------
+// The same two-entries-per-lane exact stage over the 4-byte copies: one 16-byte load brings four points of a list, so a
+// list of ten points takes three dependent steps instead of five, and a third of the cache-line lookups.  The quantised
+// squared distance classifies a point as inlier / miss for certain, or as undecided (inside the quantisation band around
+// delta); the undecided points of a query without a certain inlier are then settled by the float records with the exact
+// predicate, so the count is the exact stage's bit for bit.
+struct PackedEntry { float qx, qy, qz; uint32_t p, e, start, unc, i; };
+template <bool COUNT, bool QLDS>
+__device__ __forceinline__ PackedEntry packed_setup(const LcpGrid& g, const LcpTask& K, const uint2* s_q, const float* T, const float* XU,
+                                                    const bool valid, const uint32_t i, const uint32_t rank) {
+  PackedEntry E;
+  E.qx = E.qy = E.qz = 0.f; E.p = E.e = E.start = E.unc = 0u; E.i = i;
+  if (valid) {
+    const uint4 hdr = g.list_hdr[rank];
+    const float4 q = K.q4[i];
+    float tx, ty, tz;
+    transform_point(T, q, tx, ty, tz);                          // exact (reference order, no fma)
+    int ix, iy, iz;
+    grid_cell(XU, sweep_query<QLDS>(K, s_q, i), ix, iy, iz);
+    const float rx = (tx - g.ox) * g.inv_h - float(ix), ry = (ty - g.oy) * g.inv_h - float(iy), rz = (tz - g.oz) * g.inv_h - float(iz);
+    const uint32_t sx = uint32_t(min(max(int(rx * 4.f), 0), 3)), sy = uint32_t(min(max(int(ry * 4.f), 0), 3)),
+                   sz = uint32_t(min(max(int(rz * 4.f), 0), 3));
+    const uint32_t sb = sz * 16u + sy * 4u + sx;
+    const uint32_t mword = sb < 32u ? hdr.z : hdr.w;
+    if ((mword >> (sb & 31u)) & 1u) {
+      if (COUNT) { atomicAdd(K.point_tests + 3, 1ull); atomicAdd(K.point_tests, (unsigned long long)hdr.y); }
+      E.start = E.p = hdr.x; E.e = hdr.x + hdr.y;
+      E.qx = (rx + g.pk_pad) * g.pk_scale; E.qy = (ry + g.pk_pad) * g.pk_scale; E.qz = (rz + g.pk_pad) * g.pk_scale;
+    }
+  }
+  return E;
+}
+// four packed points against one query: bit k of the result = certain inlier, bit 4 + k = undecided
+__device__ __forceinline__ uint32_t packed_quad(const LcpGrid& g, const PackedEntry& E, const uint4 w) {
+  uint32_t r = 0;
+  const uint32_t v[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float dx = E.qx - float(v[k] & 1023u), dy = E.qy - float((v[k] >> 10) & 1023u), dz = E.qz - float(v[k] >> 20);
+    const float d2 = __builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, dz * dz));
+    r |= (d2 <= g.pk_lo2 ? 1u : 0u) << k;
+    r |= (d2 <= g.pk_hi2 ? 1u : 0u) << (4 + k);
+  }
+  return r;       // certain inliers are also flagged undecided: callers look at the low nibble first
+}
+template <bool COUNT, bool QLDS>
+__device__ __forceinline__ uint32_t exact_pair_packed(const LcpGrid& g, const LcpTask& K, const uint2* s_q, const float4* Tsrc, const float* XU,
+                                                      const bool validA, const uint32_t iA, const uint32_t rankA,
+                                                      const bool validB, const uint32_t iB, const uint32_t rankB) {
+  PackedEntry A, B;
+  { float T[12]; load_rows(Tsrc, T);
+    A = packed_setup<COUNT, QLDS>(g, K, s_q, T, XU, validA, iA, rankA);
+    B = packed_setup<COUNT, QLDS>(g, K, s_q, T, XU, validB, iB, rankB); }
+  const uint4* pk4 = reinterpret_cast<const uint4*>(g.pk);
+  uint32_t hits = 0;
+  while (A.p < A.e || B.p < B.e) {
+    const bool la = A.p < A.e, lb = B.p < B.e;
+    const uint4 wa = pk4[la ? A.p >> 2 : 0u], wb = pk4[lb ? B.p >> 2 : 0u];
+    const uint32_t ra = la ? packed_quad(g, A, wa) : 0u, rb = lb ? packed_quad(g, B, wb) : 0u;
+    if (ra & 15u) { ++hits; A.p = A.e; A.unc = 0u; }
+    else if (la) { const uint32_t sh = A.p - A.start; A.unc |= sh < 28u ? (ra >> 4) << sh : ((ra >> 4) ? 0x80000000u : 0u); A.p += 4u; }
+    if (rb & 15u) { ++hits; B.p = B.e; B.unc = 0u; }
+    else if (lb) { const uint32_t sh = B.p - B.start; B.unc |= sh < 28u ? (rb >> 4) << sh : ((rb >> 4) ? 0x80000000u : 0u); B.p += 4u; }
+  }
+  // undecided points of queries without a certain inlier: the float records and the exact predicate (rare: the band is
+  // +-0.3 % of delta wide).  Bit b < 31 = entry start + b; bit 31 = "somewhere from entry 28 on": those are all re-tested.
+  if (__any((A.unc | B.unc) != 0u)) {
+    float T[12]; load_rows(Tsrc, T);
+    auto settle = [&](PackedEntry& E) -> uint32_t {
+      if (E.unc == 0u) return 0u;
+      if (COUNT) atomicAdd(K.point_tests + 4, 1ull);
+      float tx, ty, tz;
+      transform_point(T, K.q4[E.i], tx, ty, tz);
+      const uint32_t n = E.e - E.start;
+      for (uint32_t b = 0; b < n; ++b) {
+        const bool test = b < 31u ? ((E.unc >> b) & 1u) != 0u : (E.unc >> 31) != 0u;
+        if (!test) continue;
+        const float4 pt = g.nbr[E.start + b];
+        if (sqn3(tx - pt.x, ty - pt.y, tz - pt.z) <= g.sq_eps) return 1u;
+      }
+      return 0u;
+    };
+    hits += settle(A);
+    hits += settle(B);
+  }
+  return hits;
+}
+
 // Number of sampled-Q points the candidate at Tsrc brings within delta of a sampled-P point, for one wave64.
 //   s_coarse: LDS copy of the coarse bitmap; s_q: LDS copy of the quantised queries (QLDS); s_queue: this wave's
 //   private LDS queue (kQueueEntries entries: 32-bit ranks, then 16-bit query indices)
@@ -511,7 +634,11 @@ __device__ __forceinline__ uint32_t wave_lcp_count(const LcpGrid& g, const LcpTa
       const uint32_t n = min(qn, 128u);
       const bool va = lane < n, vb = lane + 64u < n;
       const uint32_t aa = qn - n + min(lane, n - 1u), ab = qn - n + min(lane + 64u, n - 1u);
+#if S4P_PACKED_LISTS
+      if (!SKIP_FINE) cnt += exact_pair_packed<COUNT, QLDS>(g, K, s_q, Tsrc, X.u, va, uint32_t(q_idx[aa]), q_rank[aa], vb, uint32_t(q_idx[ab]), q_rank[ab]);
+#else
       if (!SKIP_FINE) cnt += exact_pair<COUNT, QLDS>(g, K, s_q, Tsrc, X.u, va, uint32_t(q_idx[aa]), q_rank[aa], vb, uint32_t(q_idx[ab]), q_rank[ab]);
+#endif
       qn -= n;
       lds_fence();
     }
@@ -1263,7 +1390,7 @@ __global__ __launch_bounds__(kVerifyThreads, 8) void k_verify(VerifyParams P) { 
   DevCounters* r = P.res;
   r->m1 = c->m1; r->m2 = c->m2; r->K = c->K; r->C = C; r->overflow = c->overflow;
   r->best_count = bc; r->best_tag = bt; r->has_best = 0u;
-  if (COUNT || P.count_tests) { r->point_tests = c->point_tests; r->l0_pass = c->l0_pass; r->l1_pass = c->l1_pass; r->l2_pass = c->l2_pass; }
+  if (COUNT || P.count_tests) { r->point_tests = c->point_tests; r->l0_pass = c->l0_pass; r->l1_pass = c->l1_pass; r->l2_pass = c->l2_pass; r->settled = c->settled; }
   if (bi != kNil) {                                        // recompute the winner's 4x4 (ComputeRigidTransformation)
     const uint32_t k = P.cand_idx[bi];
     const int4 qd = P.quads[k];
@@ -1279,7 +1406,7 @@ __global__ __launch_bounds__(kVerifyThreads, 8) void k_verify(VerifyParams P) { 
   }
   // the live counters are ready for the next base on this lane (no separate reset launch)
   c->m1 = 0; c->m2 = 0; c->K = 0; c->C = 0; c->best_count = 0; c->overflow = 0; c->best_tag = ~0ull; c->has_best = 0;
-  c->point_tests = 0; c->l0_pass = 0; c->l1_pass = 0; c->l2_pass = 0;
+  c->point_tests = 0; c->l0_pass = 0; c->l1_pass = 0; c->l2_pass = 0; c->settled = 0;
   __threadfence();
   c->done = 0;
 }
@@ -1461,7 +1588,7 @@ __global__ void k_selftest(const float* a, const float* b, uint64_t n, float* o_
 __global__ void k_reset_counters(DevCounters* c) {
   c->m1 = 0; c->m2 = 0; c->K = 0; c->C = 0; c->best_count = 0; c->overflow = 0;
   c->best_tag = ~0ull; c->has_best = 0; c->done = 0;
-  c->point_tests = 0; c->l0_pass = 0; c->l1_pass = 0; c->l2_pass = 0;
+  c->point_tests = 0; c->l0_pass = 0; c->l1_pass = 0; c->l2_pass = 0; c->settled = 0;
 }
 
 }  // namespace s4p
