@@ -151,7 +151,8 @@ int32_t s4p_try_base_wait(s4p_ctx* ctx, s4p_base_result* result);
  *                    thread than the one that owns the context, provided bases are staged in trial order.
  *   s4p_try_base_staged_async   uploads slot `slot` and enqueues the device pass (base set by s4p_set_base).
  * A slot may be re-staged once the s4p_try_base_wait of the base that used it has returned.
- * s4p_try_base_async itself uses slots 0..5 round-robin; a threaded driver uses slots 6 and up. */
+ * s4p_try_base_async itself uses the lower half of the slots round-robin; a threaded driver uses the upper half
+ * (s4p_stage_slots() / 2 and up). */
 int32_t s4p_stage_slots(const s4p_ctx* ctx);
 int32_t s4p_stage_base(s4p_ctx* ctx, const float* base_xyz, const float* base_nrm, int32_t want_device_data, int32_t slot);
 int32_t s4p_try_base_staged_async(s4p_ctx* ctx, int32_t slot, const int32_t* base_ids, float invariant1, float invariant2);
@@ -215,7 +216,6 @@ typedef struct {
   uint64_t pairs_launches, quads_launches;
   double   host_octree_s;        /* host time in the pair-octree builds (loop 1 of IntersectionFunctor)   */
   double   host_wait_s;          /* host time blocked in stream synchronisation                           */
-  uint64_t verify_settled;       /* packed point lists: queries settled by the float records (undecided quantised distance), if enabled */
 } s4p_profile;
 int32_t s4p_profile_enable(s4p_ctx* ctx, int32_t enable_events, int32_t count_point_tests);
 int32_t s4p_profile_get(s4p_ctx* ctx, s4p_profile* out, int32_t reset);

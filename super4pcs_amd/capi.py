@@ -60,7 +60,7 @@ class Profile(C.Structure):
         ("verify_l0_pass", C.c_uint64), ("verify_l1_pass", C.c_uint64), ("verify_l2_pass", C.c_uint64),
         ("pairs_ms_total", C.c_double), ("quads_ms_total", C.c_double),
         ("pairs_launches", C.c_uint64), ("quads_launches", C.c_uint64),
-        ("host_octree_s", C.c_double), ("host_wait_s", C.c_double), ("verify_settled", C.c_uint64),
+        ("host_octree_s", C.c_double), ("host_wait_s", C.c_double),
     ]
 
 

@@ -35,6 +35,11 @@ struct PinBuf {
   void free() { if (p) { (void)hipHostFree(p); p = nullptr; } n = 0; }
 };
 uint32_t next_pow2(uint64_t v) { uint64_t p = 1; while (p < v) p <<= 1; return uint32_t(p); }
+// k_pairs: waves per primitive (PairParams::split), so that a set has about 4000 work items whatever the sample size
+uint32_t pair_split(uint32_t n_q) {
+  static const uint32_t target = getenv("S4P_PAIR_ITEMS") ? uint32_t(atoi(getenv("S4P_PAIR_ITEMS"))) : 4096u;      // tuning aid
+  return std::min<uint32_t>(8u, std::max<uint32_t>(1u, target / std::max<uint32_t>(n_q, 1u)));
+}
 }  // namespace
 
 struct s4p_ctx {
@@ -57,10 +62,9 @@ struct s4p_ctx {
 
   // device state
   DevBuf<uint2> greach; DevBuf<uint4> glist_hdr; DevBuf<uint32_t> gcoarse; DevBuf<float4> gnbr; DevBuf<float4> q4, q4v;
-  DevBuf<uint32_t> gpk; double pk_pad = 0, pk_scale = 0, pk_quant_err = 0;      // 4-byte packed copies of the point lists (LcpGrid::pk)
   DevBuf<uint2> qquant; QuantQ qq{}; bool qlds = false;      // 16-bit copy of the Morton-ordered queries for the LDS-resident sweep
   DevBuf<float> qx, qy, qz, ux, uy, uz, qnx, qny, qnz, qcr, qcg, qcb;
-  // Two lanes = two HIP streams with private per-base device buffers.  Consecutive bases alternate lanes, so the
+  // Lanes = HIP streams with private per-base device buffers.  Consecutive bases rotate over the lanes, so the
   // small latency-bound kernels of base t+1 (pairs, hash build, quad enumeration) run concurrently with the
   // LCP scoring of base t instead of leaving most of the 256 CUs idle between them.
   struct Lane {
@@ -78,9 +82,9 @@ struct s4p_ctx {
     bool dirty = false;               // a stage-level call left the live counters non-zero: clear before a fused pass
     DevBuf<uint32_t> seq[2];          // device copy of a staged sequence blob (layout: StageSlot)
   };
-  static constexpr int kMaxLanes = 4;
+  static constexpr int kMaxLanes = 8;
   Lane lane[kMaxLanes];
-  int n_lanes = 3;                   // S4P_LANES (1..4): bases in flight
+  int n_lanes = 6;                   // S4P_LANES (1..8): bases in flight (measured 3: 66, 4: 72, 5: 77.5, 6: 81, 8: 79 M candidates/s)
   PinBuf<DevCounters> hctr[kMaxLanes];      // [pipeline slot == lane]
   // Staging ring: host-built octree sequences of the two pair sets of a base, in pinned memory.  A slot is
   // written by whoever stages the base (the caller thread, or the engine's octree thread through s4p_stage_base)
@@ -93,13 +97,13 @@ struct s4p_ctx {
     static size_t blob_words(size_t n_q) { return 2 * n_q + 8 + 4 * n_q; }      // n_leaf <= n_seq <= n_q
     float eps_unit[2] = {0, 0}, n_radius[2] = {0, 0}, distance[2] = {0, 0}, normal_angle[2] = {0, 0};
   };
-  static constexpr int kStageSlots = 12;   // 0..5: self-staging of s4p_try_base_async; 6..11: a threaded driver
+  static constexpr int kStageSlots = 24;   // 0..11: self-staging of s4p_try_base_async; 12..23: a threaded driver
   StageSlot stage[kStageSlots];
   uint32_t stage_rr = 0;             // round-robin slot for the self-staging (single-thread) paths
   int cur = 0;                       // slot used by the call in progress
   uint32_t q_head = 0, q_tail = 0;   // async FIFO of s4p_try_base_async (depth 2)
-  BaseFrame slot_bf[4];
-  hipEvent_t done[4] = {nullptr, nullptr, nullptr, nullptr};
+  BaseFrame slot_bf[kMaxLanes];
+  hipEvent_t done[kMaxLanes] = {};
   DevBuf<float> tbuf; size_t tbuf_cap = 0;      // s4p_transform_points: two device + two pinned staging chunks
   PinBuf<float> tpin; hipEvent_t tev[2] = {nullptr, nullptr};
   // base selection on the device (s4p_select_base_points): the sampled P as float4 records in sampling order, one
@@ -109,20 +113,21 @@ struct s4p_ctx {
 
   // profiling
   bool prof_events = false, prof_points = false;
-  hipEvent_t ev[4][6] = {};
+  hipEvent_t ev[kMaxLanes][6] = {};
   s4p_profile prof{};
   uint64_t last_K = 0;
   uint32_t verify_blocks = 512;
+  int verify_threads = kVerifyThreadsCached;      // per set_clouds: kVerifyMaxThreads when the point lists exceed the Infinity Cache; S4P_VERIFY_THREADS overrides
   int ablate = 0;                    // S4P_ABLATE (profiling aid, read once at creation)
-  // A/B aids: S4P_FUSE_PREP=1 prepares every pair inside k_pairs instead of a k_prep launch (measured
-  // slower: the ~3000-instruction cone mask of a set-2 pair lands on whichever wave found the pair); S4P_FUSE_GATE=0 runs
-  // the rigid transform + rms gate as a k_gate launch instead of inside k_quads' flush (measured slower)
-  bool fuse_prep = false, fuse_gate = true;
+  // A/B aid: S4P_FUSE_GATE=0 runs the rigid transform + rms gate as a k_gate launch instead of
+  // inside k_quads' flush (measured slower)
+  bool fuse_gate = true;
+  int list_align = 8;                // S4P_LIST_ALIGN (1, 2, 4, 8): point lists start on multiples of this many 16-byte records
   int cu_split = 0;                  // S4P_CU_SPLIT (0 = off): one CU in n for the small kernels, the rest for k_verify
   double host_octree_s = 0, host_wait_s = 0;
 
   size_t verify_lds_bytes() const {
-    return gcoarse.n * 4 + (qlds ? size_t((n_q + 127u) & ~127u) * 8 : 0) + size_t(kVerifyThreads / 64) * kQueueWordsPerWave * 4;
+    return gcoarse.n * 4 + (qlds ? size_t((n_q + 127u) & ~127u) * 8 : 0) + size_t(verify_threads / 64) * kQueueWordsPerWave * 4;
   }
   uint32_t verify_grid() const { return verify_blocks; }
   LcpGrid dev_grid() const {
@@ -133,19 +138,6 @@ struct s4p_ctx {
     g.ox = hgrid.ox; g.oy = hgrid.oy; g.oz = hgrid.oz; g.inv_h = hgrid.inv_h;
     g.nx = hgrid.nx; g.ny = hgrid.ny; g.nz = hgrid.nz;
     g.sq_eps = opt.delta * opt.delta;     // match4pcsBase.cc:517,522
-    // Packed lists: thresholds on the quantised squared distance (in packed units).  With r = sqrt(sq_eps) / h in grid
-    // units and m = the largest difference between a quantised and an exact distance -- sqrt(3) half steps of the 10-bit
-    // records, the float rounding of a query's cell-relative position (a few ulp at the grid's size) and of the exact
-    // predicate itself -- a quantised distance <= r - m is an inlier of the exact predicate and one > r + m is not.
-    g.pk = gpk.p;
-    g.pk_pad = float(pk_pad); g.pk_scale = float(pk_scale);
-    {
-      const double r = std::sqrt(double(g.sq_eps)) / double(hgrid.h);
-      const double dims = double(hgrid.nx) + double(hgrid.ny) + double(hgrid.nz);
-      const double m = 1.7320508075688772 * (0.5 / pk_scale) * 1.0001 + 4.0 * 1.2e-7 * dims + 2e-5;
-      const double lo = std::max(0.0, (r - m) * pk_scale), hi = (r + m) * pk_scale;
-      g.pk_lo2 = float(lo * lo * (1.0 - 1e-6)); g.pk_hi2 = float(hi * hi * (1.0 + 1e-6));
-    }
     return g;
   }
 };
@@ -208,14 +200,15 @@ int32_t upload_pairs_staged(s4p_ctx* c, int slot, int set, float pair_distance_e
   P.ab = set == 0 ? L.ab1.p : L.ab2.p; P.okey = set == 0 ? L.okey1.p : L.okey2.p;
   P.counter = set == 0 ? &L.ctr.p->m1 : &L.ctr.p->m2;
   P.cap = uint32_t(c->max_pairs); P.overflow = &L.ctr.p->overflow; P.overflow_bit = set == 0 ? 1u : 2u;
-  P.do_prep = 0;
+  P.split = pair_split(c->n_q);
   return S4P_OK;
 }
 
-// loop 2 + the pair filters (k_pairs) for one set, or for both sets of a base in one launch: one wave per primitive,
-// a few primitives per wave so that the end-of-workgroup append is one atomic per ~8 primitives
+// loop 2 + the pair filters (k_pairs) for one set, or for both sets of a base in one launch: one wave per (primitive,
+// part); about 4000 work items per set fill the chip once with both sets in flight
 int32_t launch_pairs_kernel(s4p_ctx* c, const PairParams2& PP, int n_sets) {
-  const uint32_t wgs = std::min<uint32_t>(std::max<uint32_t>((c->n_q + 2u * kPairWaves - 1u) / (2u * kPairWaves), 1u), 1024u);
+  const uint32_t items = c->n_q * pair_split(c->n_q);
+  const uint32_t wgs = std::min<uint32_t>(std::max<uint32_t>((items + kPairWaves - 1u) / kPairWaves, 1u), 4096u);
   hipLaunchKernelGGL(k_pairs, dim3(wgs, uint32_t(n_sets)), dim3(64 * kPairWaves), 0, c->lane[c->cur].stream, PP);
   HIPCHK(c, hipGetLastError());
   return S4P_OK;
@@ -287,7 +280,7 @@ int32_t quad_params(s4p_ctx* c, float inv1, float inv2, float thr2, PrepParams& 
     HIPCHK(c, hipMemsetAsync(L.ht_heads.p, 0, L.ht_heads.n * 8, L.stream));
     L.epoch = 1;
   }
-  HashTable ht{L.ht_keys.p, L.ht_heads.p, L.ht_mask, L.epoch};
+  HashTable ht{L.ht_keys.p, L.ht_heads.p, L.ht_mask, L.epoch, &L.ctr.p->m1, uint32_t(c->max_pairs)};
   P1 = PrepParams{};
   P1.ux = c->ux.p; P1.uy = c->uy.p; P1.uz = c->uz.p; P1.qx = c->qx.p; P1.qy = c->qy.p; P1.qz = c->qz.p;
   P1.ab = L.ab1.p; P1.m_dev = &L.ctr.p->m1; P1.cap = uint32_t(c->max_pairs); P1.invariant = inv1; P1.qg = qg;
@@ -315,10 +308,18 @@ GateParams gate_params(s4p_ctx* c, const BaseFrame& bf) {
 }
 
 void launch_prep_kernel(s4p_ctx* c, const PrepParams& P1, const PrepParams& P2) {
-  hipLaunchKernelGGL(k_prep, dim3(1024, 2), dim3(256), 0, c->lane[c->cur].stream, P1, P2);
+  static const bool split = getenv("S4P_PREP_SPLIT") != nullptr;       // profiling aid: one launch per set, so a kernel trace times them apart
+  if (split) {
+    hipLaunchKernelGGL(k_prep, dim3(1024, 1), dim3(256), 0, c->lane[c->cur].stream, P1, P2, 0);
+    hipLaunchKernelGGL(k_prep, dim3(1024, 1), dim3(256), 0, c->lane[c->cur].stream, P1, P2, 1);
+  } else {
+    hipLaunchKernelGGL(k_prep, dim3(1024, 2), dim3(256), 0, c->lane[c->cur].stream, P1, P2, 0);
+  }
 }
 void launch_quads_kernel(s4p_ctx* c, const QuadParams& Q) {
-  hipLaunchKernelGGL(k_quads, dim3(512), dim3(256), 0, c->lane[c->cur].stream, Q);
+  // one set-2 entry per thread in ONE pass for up to 512 k entries (a second grid-stride pass doubles the chain of
+  // dependent gathers of the workgroups that get one); idle workgroups leave after reading the count
+  hipLaunchKernelGGL(k_quads, dim3(2048), dim3(256), 0, c->lane[c->cur].stream, Q);
 }
 void launch_gate_kernel(s4p_ctx* c, const GateParams& G) {
   s4p_ctx::Lane& L = c->lane[c->cur];
@@ -342,7 +343,7 @@ int32_t launch_verify(s4p_ctx* c, const BaseFrame& bf) {
   }
   if (c->prof_events) HIPCHK(c, hipEventRecord(c->ev[c->cur][0], vs));
   const size_t lds = c->verify_lds_bytes();
-  const dim3 grid(c->verify_grid()), block(kVerifyThreads);
+  const dim3 grid(c->verify_grid()), block(c->verify_threads);
   if (c->prof_points) { if (c->qlds) hipLaunchKernelGGL((k_verify<true, true>), grid, block, lds, vs, V); else hipLaunchKernelGGL((k_verify<true, false>), grid, block, lds, vs, V); }
   else { if (c->qlds) hipLaunchKernelGGL((k_verify<false, true>), grid, block, lds, vs, V); else hipLaunchKernelGGL((k_verify<false, false>), grid, block, lds, vs, V); }
   if (c->prof_events) HIPCHK(c, hipEventRecord(c->ev[c->cur][1], vs));
@@ -386,7 +387,7 @@ int32_t finish_result(s4p_ctx* c, s4p_base_result* r, bool fused) {
       if (hipEventElapsedTime(&ms, c->ev[c->cur][3], c->ev[c->cur][4]) == hipSuccess) { c->prof.quads_ms_total += ms; c->prof.quads_launches += 1; }
     }
   }
-  if (c->prof_points) { c->prof.verify_point_tests += d.point_tests; c->prof.verify_l0_pass += d.l0_pass; c->prof.verify_l1_pass += d.l1_pass; c->prof.verify_l2_pass += d.l2_pass; c->prof.verify_settled += d.settled; }
+  if (c->prof_points) { c->prof.verify_point_tests += d.point_tests; c->prof.verify_l0_pass += d.l0_pass; c->prof.verify_l1_pass += d.l1_pass; c->prof.verify_l2_pass += d.l2_pass; }
   return S4P_OK;
 }
 
@@ -440,8 +441,8 @@ int32_t s4p_create(const s4p_options* opt, const s4p_limits* lim, int32_t device
     if (c->ablate) fprintf(stderr, "super4pcs_amd: S4P_ABLATE=%d is set: k_verify skips work, every result of this context is invalid\n", c->ablate);
   }
   if (const char* vb = getenv("S4P_VERIFY_BLOCKS")) { const int v = atoi(vb); if (v >= 64 && v <= kVerifyMaxBlocks) c->verify_blocks = uint32_t(v); }   // tuning knob
-  if (const char* fu = getenv("S4P_FUSE_PREP")) c->fuse_prep = atoi(fu) != 0;
   if (const char* fu = getenv("S4P_FUSE_GATE")) c->fuse_gate = atoi(fu) != 0;
+  if (const char* la = getenv("S4P_LIST_ALIGN")) { const int v = atoi(la); if (v == 1 || v == 2 || v == 4 || v == 8) c->list_align = v; }
   if (const char* cs = getenv("S4P_CU_SPLIT")) { const int v = atoi(cs); if (v >= 2 && v <= 64) c->cu_split = v; }
   snprintf(c->devname, sizeof c->devname, "%s (%s)", prop.name, prop.gcnArchName);
   c->max_pairs = (lim && lim->max_pairs) ? lim->max_pairs : (4ull << 20);
@@ -504,7 +505,7 @@ void s4p_destroy(s4p_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   for (auto& L : c->lane) { if (L.stream) (void)hipStreamSynchronize(L.stream); if (L.vstream) (void)hipStreamSynchronize(L.vstream); }
-  c->greach.free(); c->glist_hdr.free(); c->gnbr.free(); c->gpk.free();
+  c->greach.free(); c->glist_hdr.free(); c->gnbr.free();
   c->gcoarse.free(); c->q4.free(); c->q4v.free(); c->qquant.free();
   c->qx.free(); c->qy.free(); c->qz.free(); c->ux.free(); c->uy.free(); c->uz.free();
   c->qnx.free(); c->qny.free(); c->qnz.free(); c->qcr.free(); c->qcg.free(); c->qcb.free();
@@ -555,7 +556,7 @@ int32_t s4p_set_clouds(s4p_ctx* c, const float* px, const float* py, const float
     hipStream_t st = c->lane[0].stream;
     const uint64_t nc = c->hgrid.ncell();
     const uint32_t nwords = uint32_t((nc + 31) / 32);
-    DevBuf<float> dpx, dpy, dpz; DevBuf<uint32_t> cell_count, word_pop, hdr_count, cell_id, cursor, totals, pk_err;
+    DevBuf<float> dpx, dpy, dpz; DevBuf<uint32_t> cell_count, word_pop, hdr_count, cell_id, cursor, totals;
     hipError_t e = hipSuccess;
     int32_t rc = S4P_OK;
     auto step = [&](hipError_t r) { if (e == hipSuccess) e = r; return e == hipSuccess; };
@@ -590,38 +591,30 @@ int32_t s4p_set_clouds(s4p_ctx* c, const float* px, const float* py, const float
       DevBuf<uint32_t> starts;
       if (!step(starts.alloc(n_reach))) break;
       step(hipMemcpyAsync(starts.p, hdr_count.p, size_t(n_reach) * 4, hipMemcpyDeviceToDevice, st));
-      hipLaunchKernelGGL(k_round_up4, dim3(1024), dim3(256), 0, st, starts.p, n_reach);      // every list starts on a 16-byte packed record
+      if (c->list_align > 1) hipLaunchKernelGGL(k_round_up, dim3(1024), dim3(256), 0, st, starts.p, n_reach, uint32_t(c->list_align));
       hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, st, starts.p, n_reach, totals.p + 1);
       uint32_t n_entries = 0;
       step(hipMemcpyAsync(&n_entries, totals.p + 1, 4, hipMemcpyDeviceToHost, st));
       if (!step(hipStreamSynchronize(st))) { starts.free(); break; }
-      if (!step(c->gnbr.alloc(n_entries)) || !step(c->gpk.alloc(n_entries)) || !step(pk_err.alloc(1))) { starts.free(); break; }
-      step(hipMemsetAsync(pk_err.p, 0, 4, st));
+      if (!step(c->gnbr.alloc(n_entries))) { starts.free(); break; }
       G.nbr = c->gnbr.p;
+      { // k_verify block size: see kVerifyThreadsCached (s4p_kernels.hip.hpp)
+        const char* vt = getenv("S4P_VERIFY_THREADS");
+        const int v = vt ? atoi(vt) : 0;
+        c->verify_threads = (v >= 256 && v <= kVerifyMaxThreads && v % 64 == 0) ? v
+                          : (size_t(n_entries) * sizeof(float4) > (size_t(192) << 20) ? kVerifyMaxThreads : kVerifyThreadsCached); }
       hipLaunchKernelGGL(k_grid_hdr_pack, dim3(1024), dim3(256), 0, st, G, starts.p, hdr_count.p, n_reach);
       hipLaunchKernelGGL(k_grid_fill, dim3(2048), dim3(256), 0, st, G);
       MaskParams M{};
       M.list_hdr = c->glist_hdr.p; M.nbr = c->gnbr.p; M.cell_id = cell_id.p; M.n_reach = n_reach;
       M.ox = c->hgrid.ox; M.oy = c->hgrid.oy; M.oz = c->hgrid.oz; M.h = c->hgrid.h; M.nx = c->hgrid.nx; M.ny = c->hgrid.ny;
       M.reach2 = G.reach2;
-      // packed copies: position relative to the cell in grid units, [-pad, 1 + pad] -> [0, 1023]
-      c->pk_pad = c->hgrid.reach / double(c->hgrid.h) + 2e-3;
-      c->pk_scale = 1023.0 / (1.0 + 2.0 * c->pk_pad);
-      M.pk = c->gpk.p; M.pk_pad = c->pk_pad; M.pk_scale = c->pk_scale; M.pk_err = pk_err.p;
       hipLaunchKernelGGL(k_build_masks, dim3((n_reach + 255) / 256), dim3(256), 0, st, M);
       step(hipGetLastError());
-      uint32_t err_bits = 0;
-      step(hipMemcpyAsync(&err_bits, pk_err.p, 4, hipMemcpyDeviceToHost, st));
       step(hipStreamSynchronize(st));
       starts.free();
-      if (e == hipSuccess) {
-        float worst; std::memcpy(&worst, &err_bits, 4);
-        c->pk_quant_err = double(worst);
-        // every listed point lies inside the quantised range by construction (reach + one cell); half a step is the bound
-        if (!(c->pk_quant_err <= 0.5 / c->pk_scale * 1.0001)) { c->err = "LCP grid: packed point lists exceed their quantisation bound"; rc = S4P_ERR_STATE; break; }
-      }
     } while (0);
-    dpx.free(); dpy.free(); dpz.free(); cell_count.free(); word_pop.free(); hdr_count.free(); cell_id.free(); cursor.free(); totals.free(); pk_err.free();
+    dpx.free(); dpy.free(); dpz.free(); cell_count.free(); word_pop.free(); hdr_count.free(); cell_id.free(); cursor.free(); totals.free();
     if (rc != S4P_OK) return rc;
     HIPCHK(c, e);
   }
@@ -665,7 +658,7 @@ int32_t s4p_set_clouds(s4p_ctx* c, const float* px, const float* py, const float
       if (!(0.5f * c->qq.step[k] * c->hgrid.inv_h < 0.004f)) fine_enough = false;
     }
     c->qlds = fine_enough && n_q <= int64_t(kLdsQueries) && getenv("S4P_NO_QLDS") == nullptr &&
-              c->gcoarse.n * 4 + size_t((n_q + 127) & ~int64_t(127)) * 8 + size_t(kVerifyThreads / 64) * kQueueWordsPerWave * 4 <= size_t(kVerifyLdsBudget);
+              c->gcoarse.n * 4 + size_t((n_q + 127) & ~int64_t(127)) * 8 + size_t(kVerifyMaxThreads / 64) * kQueueWordsPerWave * 4 <= size_t(kVerifyLdsBudget);
     std::vector<uint2> packed((size_t)n_q);
     for (int64_t i = 0; i < n_q; ++i) {
       uint32_t u[3];
@@ -831,11 +824,11 @@ int32_t verify_transforms_impl(s4p_ctx* c, const float* T, int64_t B, uint32_t* 
     VerifyTParams V{};
     V.grid = c->dev_grid(); V.q4 = c->q4v.p; V.qq = c->qq; V.n_q = c->n_q; V.T = dT.p; V.B = uint32_t(B);
     V.counts = dC.p; V.ctr = L.ctr.p;
-    const uint32_t wpb = kVerifyThreads / 64;
+    const uint32_t wpb = uint32_t(c->verify_threads) / 64u;
     const uint32_t blocks = uint32_t(std::min<int64_t>((B + wpb - 1) / wpb, 512));
     const size_t lds = c->verify_lds_bytes();
-    if (stats4) { if (c->qlds) hipLaunchKernelGGL((k_verify_T<true, true>), dim3(blocks), dim3(kVerifyThreads), lds, st, V); else hipLaunchKernelGGL((k_verify_T<true, false>), dim3(blocks), dim3(kVerifyThreads), lds, st, V); }
-    else { if (c->qlds) hipLaunchKernelGGL((k_verify_T<false, true>), dim3(blocks), dim3(kVerifyThreads), lds, st, V); else hipLaunchKernelGGL((k_verify_T<false, false>), dim3(blocks), dim3(kVerifyThreads), lds, st, V); }
+    if (stats4) { if (c->qlds) hipLaunchKernelGGL((k_verify_T<true, true>), dim3(blocks), dim3(c->verify_threads), lds, st, V); else hipLaunchKernelGGL((k_verify_T<true, false>), dim3(blocks), dim3(c->verify_threads), lds, st, V); }
+    else { if (c->qlds) hipLaunchKernelGGL((k_verify_T<false, true>), dim3(blocks), dim3(c->verify_threads), lds, st, V); else hipLaunchKernelGGL((k_verify_T<false, false>), dim3(blocks), dim3(c->verify_threads), lds, st, V); }
     if ((e = hipGetLastError()) != hipSuccess) break;
     if ((e = hipMemcpyAsync(counts, dC.p, size_t(B) * 4, hipMemcpyDeviceToHost, st)) != hipSuccess) break;
     if (stats4 && (e = hipMemcpyAsync(c->hctr[c->cur].p, L.ctr.p, sizeof(DevCounters), hipMemcpyDeviceToHost, st)) != hipSuccess) break;
@@ -897,11 +890,9 @@ int32_t s4p_try_base_staged_async(s4p_ctx* c, int32_t slot, const int32_t* base_
   { PairParams2 PP{};
     if (int32_t rc = upload_pairs_staged(c, slot, 0, eps, 0, 1, PP.set[0].pair)) return rc;
     if (int32_t rc = upload_pairs_staged(c, slot, 1, eps, 2, 3, PP.set[1].pair)) return rc;
-    PP.set[0].prep = P1; PP.set[1].prep = P2;
-    PP.set[0].pair.do_prep = PP.set[1].pair.do_prep = c->fuse_prep ? 1 : 0;
     if (int32_t rc = launch_pairs_kernel(c, PP, 2)) return rc; }
   if (c->prof_events) HIPCHK(c, hipEventRecord(c->ev[c->cur][3], L.stream));
-  if (!c->fuse_prep) launch_prep_kernel(c, P1, P2);
+  launch_prep_kernel(c, P1, P2);
   if (c->fuse_gate) { Q.do_gate = 1; Q.gate = gate_params(c, bf); }
   launch_quads_kernel(c, Q);
   if (!c->fuse_gate) launch_gate_kernel(c, gate_params(c, bf));

@@ -424,7 +424,7 @@ void producer_start(s4p_matcher* m) {
   P.stop = false; P.stop_flag.store(false);
   P.free_slots.clear();
   const int nslots = s4p_stage_slots(m->ctx);
-  for (int sl = 6; sl < nslots; ++sl) P.free_slots.push_back(sl);      // 0..5 belong to s4p_try_base_async
+  for (int sl = nslots / 2; sl < nslots; ++sl) P.free_slots.push_back(sl);      // the lower half belongs to s4p_try_base_async
   P.next_index = P.consumed;
   P.sel = std::thread(selector_main, m);
   P.tree = std::thread(tree_main, m);

@@ -54,7 +54,6 @@ struct DevCounters {
   unsigned long long best_tag;      // min tag among candidates with best_count
   unsigned long long point_tests;   // optional instrumentation (COUNT kernels only)
   unsigned long long l0_pass, l1_pass, l2_pass;
-  unsigned long long settled;       // packed lists: queries whose undecided points went to the float records
   uint32_t done;                    // k_verify: workgroups that have published their best (last one selects the winner)
   // winner record
   int32_t best_quad[4];
@@ -86,11 +85,6 @@ struct LcpGrid {
   float ox, oy, oz, inv_h;
   int nx, ny, nz;
   float sq_eps;                 // fl(delta*delta)
-  // packed point lists (S4P_PACKED_LISTS): one 32-bit record per list entry, 3 x 10 bit, position relative to the
-  // cell in grid units: u = round((rel + pk_pad) * pk_scale); a squared distance in these units at most pk_lo2 is an
-  // inlier for certain, above pk_hi2 a miss for certain; in between the float record decides
-  const uint32_t* pk;
-  float pk_pad, pk_scale, pk_lo2, pk_hi2;
 };
 
 // S4P_EXACT_DUAL = 1: the exact stage takes 128 queued queries at a time, two per lane, so that two point lists are in
@@ -99,15 +93,9 @@ struct LcpGrid {
 #ifndef S4P_EXACT_DUAL
 #define S4P_EXACT_DUAL 1          // measured: k_verify 0.161 -> 0.151 ms alone, 69.5 -> 70.7 M candidates/s with three lanes
 #endif
-// S4P_PACKED_LISTS = 1: the exact stage walks 4-byte quantised copies of the point lists, four points per 16-byte load
-// (the stage is bound by dependent gathers and by cache-line lookups, one per lane and load); the float records are
-// read only for the rare point whose quantised distance falls inside the quantisation band around delta.
-#ifndef S4P_PACKED_LISTS
-#define S4P_PACKED_LISTS 1
-#endif
 constexpr int kQueueEntries = S4P_EXACT_DUAL ? 256 : 320;   // per-wave survivor queue: (63 | 127) left over + one step of (4 | 2) x 64 entries
 constexpr int kQueueWordsPerWave = kQueueEntries + kQueueEntries / 2;     // 32-bit rank + 16-bit query index per entry: 1920 B
-constexpr int kCoarseMaxWords = 9216;              // 36 KB (two 1024-thread workgroups per CU share 160 KB: 80 KB each)
+constexpr int kCoarseMaxWords = 9216;              // 36 KB (two k_verify workgroups per CU share 160 KB: 80 KB each)
 constexpr int kVerifyLdsBudget = 80 * 1024 - 768;  // per workgroup: coarse bitmap + 16 queues (30 KB) [+ quantised queries]
 
 // value held by every lane of the wave -> SGPR
@@ -255,8 +243,9 @@ __global__ __launch_bounds__(256) void k_grid_headers(GridBuildParams P, const u
     }
   }
 }
-__global__ __launch_bounds__(256) void k_round_up4(uint32_t* v, uint32_t n) {          // list lengths -> multiples of four entries
-  for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) v[r] = (v[r] + 3u) & ~3u;
+// list lengths -> multiples of `align` entries (a power of two), so that every list STARTS on an align * 16-byte boundary
+__global__ __launch_bounds__(256) void k_round_up(uint32_t* v, uint32_t n, uint32_t align) {
+  for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) v[r] = (v[r] + align - 1u) & ~(align - 1u);
 }
 __global__ __launch_bounds__(256) void k_grid_hdr_pack(GridBuildParams P, const uint32_t* list_start, const uint32_t* hdr_count, uint32_t n_reach) {
   for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n_reach; r += gridDim.x * blockDim.x) {
@@ -281,9 +270,8 @@ __global__ __launch_bounds__(256) void k_grid_fill(GridBuildParams P) {
 // Fills hdr.z/.w, the 4x4x4 sub-cell reach masks, from the point lists.
 // bit(sx,sy,sz) = some listed point lies within `reach` of the sub-box; double precision, same slack as the lists.
 struct MaskParams {
-  uint4* list_hdr; float4* nbr; const uint32_t* cell_id; uint32_t n_reach;
+  uint4* list_hdr; const float4* nbr; const uint32_t* cell_id; uint32_t n_reach;
   float ox, oy, oz, h; int nx, ny; double reach2;
-  uint32_t* pk; double pk_pad, pk_scale; uint32_t* pk_err;      // packed copies; *pk_err = max |dequantised - true| (float bits), any axis
 };
 __global__ __launch_bounds__(256) void k_build_masks(MaskParams P) {
   const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -306,25 +294,6 @@ __global__ __launch_bounds__(256) void k_build_masks(MaskParams P) {
   }
   hdr.z = uint32_t(mask); hdr.w = uint32_t(mask >> 32);
   P.list_hdr[r] = hdr;
-  // lists start at multiples of four entries: pad with copies of the last point (a duplicate cannot change "some listed
-  // point within delta"), then the packed copy of every entry
-  const uint32_t padded = (hdr.y + 3u) & ~3u;
-  float worst = 0.f;
-  for (uint32_t k = 0; k < padded; ++k) {
-    const float4 pp = P.nbr[hdr.x + min(k, hdr.y - 1u)];
-    if (k >= hdr.y) P.nbr[hdr.x + k] = pp;
-    const double rel[3] = {(double(pp.x) - bx) / double(P.h), (double(pp.y) - by) / double(P.h), (double(pp.z) - bz) / double(P.h)};
-    uint32_t u[3];
-    for (int a = 0; a < 3; ++a) {
-      const double v = (rel[a] + P.pk_pad) * P.pk_scale;
-      const double c = v < 0.0 ? 0.0 : (v > 1023.0 ? 1023.0 : v);
-      u[a] = uint32_t(c + 0.5);
-      const float err = float(fabs((double(u[a]) / P.pk_scale - P.pk_pad) - rel[a]));
-      worst = err > worst ? err : worst;
-    }
-    P.pk[hdr.x + k] = u[0] | (u[1] << 10) | (u[2] << 20);
-  }
-  atomicMax(P.pk_err, __float_as_uint(worst));
 }
 
 // ---------------------------------------------------------------------------
@@ -479,94 +448,6 @@ __device__ __forceinline__ uint32_t exact_pair(const LcpGrid& g, const LcpTask& 
   return hits;
 }
 
-// --- packed lists ------------------------------------------------------------------------------------------------
-// The same two-entries-per-lane exact stage over the 4-byte copies: one 16-byte load brings four points of a list, so a
-// list of ten points takes three dependent steps instead of five, and a third of the cache-line lookups.  The quantised
-// squared distance classifies a point as inlier / miss for certain, or as undecided (inside the quantisation band around
-// delta); the undecided points of a query without a certain inlier are then settled by the float records with the exact
-// predicate, so the count is the exact stage's bit for bit.
-struct PackedEntry { float qx, qy, qz; uint32_t p, e, start, unc, i; };
-template <bool COUNT, bool QLDS>
-__device__ __forceinline__ PackedEntry packed_setup(const LcpGrid& g, const LcpTask& K, const uint2* s_q, const float* T, const float* XU,
-                                                    const bool valid, const uint32_t i, const uint32_t rank) {
-  PackedEntry E;
-  E.qx = E.qy = E.qz = 0.f; E.p = E.e = E.start = E.unc = 0u; E.i = i;
-  if (valid) {
-    const uint4 hdr = g.list_hdr[rank];
-    const float4 q = K.q4[i];
-    float tx, ty, tz;
-    transform_point(T, q, tx, ty, tz);                          // exact (reference order, no fma)
-    int ix, iy, iz;
-    grid_cell(XU, sweep_query<QLDS>(K, s_q, i), ix, iy, iz);
-    const float rx = (tx - g.ox) * g.inv_h - float(ix), ry = (ty - g.oy) * g.inv_h - float(iy), rz = (tz - g.oz) * g.inv_h - float(iz);
-    const uint32_t sx = uint32_t(min(max(int(rx * 4.f), 0), 3)), sy = uint32_t(min(max(int(ry * 4.f), 0), 3)),
-                   sz = uint32_t(min(max(int(rz * 4.f), 0), 3));
-    const uint32_t sb = sz * 16u + sy * 4u + sx;
-    const uint32_t mword = sb < 32u ? hdr.z : hdr.w;
-    if ((mword >> (sb & 31u)) & 1u) {
-      if (COUNT) { atomicAdd(K.point_tests + 3, 1ull); atomicAdd(K.point_tests, (unsigned long long)hdr.y); }
-      E.start = E.p = hdr.x; E.e = hdr.x + hdr.y;
-      E.qx = (rx + g.pk_pad) * g.pk_scale; E.qy = (ry + g.pk_pad) * g.pk_scale; E.qz = (rz + g.pk_pad) * g.pk_scale;
-    }
-  }
-  return E;
-}
-// four packed points against one query: bit k of the result = certain inlier, bit 4 + k = undecided
-__device__ __forceinline__ uint32_t packed_quad(const LcpGrid& g, const PackedEntry& E, const uint4 w) {
-  uint32_t r = 0;
-  const uint32_t v[4] = {w.x, w.y, w.z, w.w};
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const float dx = E.qx - float(v[k] & 1023u), dy = E.qy - float((v[k] >> 10) & 1023u), dz = E.qz - float(v[k] >> 20);
-    const float d2 = __builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, dz * dz));
-    r |= (d2 <= g.pk_lo2 ? 1u : 0u) << k;
-    r |= (d2 <= g.pk_hi2 ? 1u : 0u) << (4 + k);
-  }
-  return r;       // certain inliers are also flagged undecided: callers look at the low nibble first
-}
-template <bool COUNT, bool QLDS>
-__device__ __forceinline__ uint32_t exact_pair_packed(const LcpGrid& g, const LcpTask& K, const uint2* s_q, const float4* Tsrc, const float* XU,
-                                                      const bool validA, const uint32_t iA, const uint32_t rankA,
-                                                      const bool validB, const uint32_t iB, const uint32_t rankB) {
-  PackedEntry A, B;
-  { float T[12]; load_rows(Tsrc, T);
-    A = packed_setup<COUNT, QLDS>(g, K, s_q, T, XU, validA, iA, rankA);
-    B = packed_setup<COUNT, QLDS>(g, K, s_q, T, XU, validB, iB, rankB); }
-  const uint4* pk4 = reinterpret_cast<const uint4*>(g.pk);
-  uint32_t hits = 0;
-  while (A.p < A.e || B.p < B.e) {
-    const bool la = A.p < A.e, lb = B.p < B.e;
-    const uint4 wa = pk4[la ? A.p >> 2 : 0u], wb = pk4[lb ? B.p >> 2 : 0u];
-    const uint32_t ra = la ? packed_quad(g, A, wa) : 0u, rb = lb ? packed_quad(g, B, wb) : 0u;
-    if (ra & 15u) { ++hits; A.p = A.e; A.unc = 0u; }
-    else if (la) { const uint32_t sh = A.p - A.start; A.unc |= sh < 28u ? (ra >> 4) << sh : ((ra >> 4) ? 0x80000000u : 0u); A.p += 4u; }
-    if (rb & 15u) { ++hits; B.p = B.e; B.unc = 0u; }
-    else if (lb) { const uint32_t sh = B.p - B.start; B.unc |= sh < 28u ? (rb >> 4) << sh : ((rb >> 4) ? 0x80000000u : 0u); B.p += 4u; }
-  }
-  // undecided points of queries without a certain inlier: the float records and the exact predicate (rare: the band is
-  // +-0.3 % of delta wide).  Bit b < 31 = entry start + b; bit 31 = "somewhere from entry 28 on": those are all re-tested.
-  if (__any((A.unc | B.unc) != 0u)) {
-    float T[12]; load_rows(Tsrc, T);
-    auto settle = [&](PackedEntry& E) -> uint32_t {
-      if (E.unc == 0u) return 0u;
-      if (COUNT) atomicAdd(K.point_tests + 4, 1ull);
-      float tx, ty, tz;
-      transform_point(T, K.q4[E.i], tx, ty, tz);
-      const uint32_t n = E.e - E.start;
-      for (uint32_t b = 0; b < n; ++b) {
-        const bool test = b < 31u ? ((E.unc >> b) & 1u) != 0u : (E.unc >> 31) != 0u;
-        if (!test) continue;
-        const float4 pt = g.nbr[E.start + b];
-        if (sqn3(tx - pt.x, ty - pt.y, tz - pt.z) <= g.sq_eps) return 1u;
-      }
-      return 0u;
-    };
-    hits += settle(A);
-    hits += settle(B);
-  }
-  return hits;
-}
-
 // Number of sampled-Q points the candidate at Tsrc brings within delta of a sampled-P point, for one wave64.
 //   s_coarse: LDS copy of the coarse bitmap; s_q: LDS copy of the quantised queries (QLDS); s_queue: this wave's
 //   private LDS queue (kQueueEntries entries: 32-bit ranks, then 16-bit query indices)
@@ -634,11 +515,7 @@ __device__ __forceinline__ uint32_t wave_lcp_count(const LcpGrid& g, const LcpTa
       const uint32_t n = min(qn, 128u);
       const bool va = lane < n, vb = lane + 64u < n;
       const uint32_t aa = qn - n + min(lane, n - 1u), ab = qn - n + min(lane + 64u, n - 1u);
-#if S4P_PACKED_LISTS
-      if (!SKIP_FINE) cnt += exact_pair_packed<COUNT, QLDS>(g, K, s_q, Tsrc, X.u, va, uint32_t(q_idx[aa]), q_rank[aa], vb, uint32_t(q_idx[ab]), q_rank[ab]);
-#else
       if (!SKIP_FINE) cnt += exact_pair<COUNT, QLDS>(g, K, s_q, Tsrc, X.u, va, uint32_t(q_idx[aa]), q_rank[aa], vb, uint32_t(q_idx[ab]), q_rank[ab]);
-#endif
       qn -= n;
       lds_fence();
     }
@@ -805,9 +682,20 @@ __device__ __forceinline__ uint32_t hash_cell(uint32_t c) {
 struct HashTable {
   unsigned long long* keys;    // (epoch << 32) | cell
   unsigned long long* heads;   // (epoch << 32) | entry index
-  uint32_t mask;               // size - 1 (power of two)
+  uint32_t mask;               // allocated size - 1 (power of two; sized for the pair capacity: 128 MB + 128 MB at 8 M pairs)
   uint32_t epoch;
+  const uint32_t* m1_dev;      // device count of the set-1 pairs of this base (final when k_prep / k_quads run)
+  uint32_t cap1;
 };
+// Slots a base really uses: 4 x its set-1 pairs, rounded up to a power of two (>= 4096) -- a few MB that stay in L2 instead
+// of random probes over the whole allocation (HBM + TLB misses on every hop).  Builder (k_prep) and reader (k_quads)
+// derive the same mask from the same device counter; entries of earlier epochs, wherever they lie, read as empty.
+__device__ __forceinline__ uint32_t hash_mask(const HashTable& ht) {
+  const uint32_t m = min(*ht.m1_dev, ht.cap1);
+  const uint32_t want = max(4u * m, 4096u);
+  const uint32_t size = 1u << (32 - __clz(int(want - 1u)));
+  return min(size - 1u, ht.mask);
+}
 
 // Per-set preparation parameters.  `ab`/`m_dev`/`cap` are only read by the stand-alone k_prep (stage-level entry
 // points); the fused pair kernel hands every pair over in registers.
@@ -839,7 +727,8 @@ __device__ __forceinline__ void prep1_item(const PrepParams& P, const uint32_t e
                         w1z + (w2z - w1z) * P.invariant, 0.f);                                            // :157
   // insert into the cell hash (find-or-claim slot, then push on the chain)
   const unsigned long long mykey = ((unsigned long long)P.ht.epoch << 32) | cell;
-  uint32_t h = hash_cell(cell) & P.ht.mask;
+  const uint32_t hmask = hash_mask(P.ht);
+  uint32_t h = hash_cell(cell) & hmask;
   while (true) {
     const unsigned long long k = __hip_atomic_load(&P.ht.keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (k == mykey) break;
@@ -848,7 +737,7 @@ __device__ __forceinline__ void prep1_item(const PrepParams& P, const uint32_t e
       if (old == k || old == mykey) break;
       continue;   // somebody claimed it for another cell: re-read the same slot
     }
-    h = (h + 1u) & P.ht.mask;
+    h = (h + 1u) & hmask;
   }
   const unsigned long long prev = atomicExch(&P.ht.heads[h], ((unsigned long long)P.ht.epoch << 32) | e);
   P.next[e] = (uint32_t(prev >> 32) == P.ht.epoch) ? uint32_t(prev) : kNil;
@@ -913,13 +802,86 @@ __device__ __forceinline__ void prep2_item(const PrepParams& P, const uint32_t e
 
 // Stand-alone preparation of two uploaded pair lists (s4p_find_congruent): blockIdx.y == 0 -> set 1, 1 -> set 2.
 // The fused path (s4p_try_base*) prepares every pair inside k_pairs, where it is produced.
-__global__ __launch_bounds__(256) void k_prep(PrepParams P1, PrepParams P2) {
-  __shared__ uint32_t smask[256 * kMaskWords];
-  const PrepParams& P = blockIdx.y == 0 ? P1 : P2;
+// set 2, EIGHT lanes per pair: the <= 56 cone samples of a pair (normalset.hpp:186-196) are independent, lane s of the
+// group takes samples s, s + 8, ...; the 343-bit mask is OR-ed together in the group's 11 LDS words.  Same arithmetic per
+// sample as prep2_item, so the same mask.  Why eight: a thread per pair ran the 56 samples (~150 instructions each, with
+// their square roots and divisions) as one dependent chain on ~400 waves -- 43 us for ~25 k pairs with most SIMDs empty; a
+// wave per pair would repeat the ~450-instruction set-up 64 times over; groups of eight keep the total work where it was
+// and put ~3 waves on every SIMD.
+constexpr uint32_t kPrepGroup = 8;
+__device__ __forceinline__ void prep2_group(const PrepParams& P, const uint32_t e, const bool live, const int2 ab, uint32_t* gmask) {
+  const uint32_t sub = threadIdx.x & (kPrepGroup - 1u);
+  float q[4] = {1.f, 0.f, 0.f, 0.f};
+  if (live) {
+    const float p1x = P.ux[ab.x], p1y = P.uy[ab.x], p1z = P.uz[ab.x];
+    const float p2x = P.ux[ab.y], p2y = P.uy[ab.y], p2z = P.uz[ab.y];
+    const float nx = p2x - p1x, ny = p2y - p1y, nz = p2z - p1z;
+    if (sub == 0) {
+      const float qx_ = p1x + P.invariant * nx, qy_ = p1y + P.invariant * ny, qz_ = p1z + P.invariant * nz;   // super4pcs.cc:141
+      P.cell[e] = index_pos(qx_, qy_, qz_, P.qg);
+      const float w1x = P.qx[ab.x], w1y = P.qy[ab.x], w1z = P.qz[ab.x];
+      const float w2x = P.qx[ab.y], w2y = P.qy[ab.y], w2z = P.qz[ab.y];
+      P.ew[e] = make_float4(w1x + P.invariant * (w2x - w1x), w1y + P.invariant * (w2y - w1y),
+                            w1z + P.invariant * (w2z - w1z), 0.f);                                          // :142
+    }
+    float qnx = nx, qny = ny, qnz = nz;
+    normalize3(qnx, qny, qnz);                          // queryn = (p2-p1).normalized()            super4pcs.cc:144
+    quat_from_z_to(qnx, qny, qnz, q);                   // setFromTwoVectors normalises it again    normalset.hpp:181
+  }
+  const float inv_neps = 1.0f / P.qg.nepsilon;
+  gmask[sub] = 0u; gmask[sub + kPrepGroup] = 0u;        // 16 words per group, 11 used
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+  if (live) {
+    for (int a = int(sub); a < P.cone.nb; a += int(kPrepGroup)) {
+      const float vx = P.cone.v[a][0], vy = P.cone.v[a][1], vz = P.cone.v[a][2];
+      float ux_, uy_, uz_;
+      cross3(q[1], q[2], q[3], vx, vy, vz, ux_, uy_, uz_);            // QuaternionBase::_transformVector
+      ux_ += ux_; uy_ += uy_; uz_ += uz_;
+      float cx, cy, cz;
+      cross3(q[1], q[2], q[3], ux_, uy_, uz_, cx, cy, cz);
+      float dx = (vx + q[0] * ux_) + cx, dy = (vy + q[0] * uy_) + cy, dz = (vz + q[0] * uz_) + cz;
+      // Only the bucket of the normalised direction is needed: int((x / 2 + 0.5) / neps) per axis after x /= |d| -- a
+      // square root and six correctly rounded divisions, 2/3 of the sample's instructions.  The rotated vector is unit
+      // to rounding already, so the bucket coordinates are first computed WITHOUT normalising and with one multiply by
+      // 1/neps: with | |d|^2 - 1 | < 1e-4 they differ from the exact ones by < 2e-4, so if every coordinate lies further
+      // than 4e-4 from an integer the truncations agree; otherwise (0.2 % of the samples) the exact sequence runs.
+      uint32_t id;
+      const float t0 = __builtin_fmaf(dx, 0.5f, 0.5f) * inv_neps, t1 = __builtin_fmaf(dy, 0.5f, 0.5f) * inv_neps,
+                  t2 = __builtin_fmaf(dz, 0.5f, 0.5f) * inv_neps;
+      const float f0 = __builtin_amdgcn_fractf(t0), f1 = __builtin_amdgcn_fractf(t1), f2 = __builtin_amdgcn_fractf(t2);
+      const float edge = fminf(fminf(fminf(f0, 1.f - f0), fminf(f1, 1.f - f1)), fminf(f2, 1.f - f2));
+      const float n2 = __builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, dz * dz));
+      if (fabsf(n2 - 1.f) < 1e-4f && edge > 4e-4f) {
+        id = uint32_t(int(t2) * 49 + int(t1) * 7 + int(t0));
+      } else {
+        normalize3(dx, dy, dz);
+        id = index_normal(dx, dy, dz, P.qg.nepsilon);
+      }
+      if (id < 343u) atomicOr(&gmask[id >> 5], 1u << (id & 31u));
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+  if (live) {
+    P.mask[size_t(e) * kMaskWords + sub] = gmask[sub];
+    if (sub + kPrepGroup < uint32_t(kMaskWords)) P.mask[size_t(e) * kMaskWords + sub + kPrepGroup] = gmask[sub + kPrepGroup];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+}
+
+__global__ __launch_bounds__(256) void k_prep(PrepParams P1, PrepParams P2, int first_set) {
+  __shared__ uint32_t smask[(256 / kPrepGroup) * 16];
+  const uint32_t set = blockIdx.y + uint32_t(first_set);           // one launch for both sets (gridDim.y = 2), or one per set
+  const PrepParams& P = set == 0 ? P1 : P2;
   const uint32_t m = min(*P.m_dev, P.cap);
-  for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < m; e += gridDim.x * blockDim.x) {
-    if (blockIdx.y == 0) prep1_item(P, e, P.ab[e]);
-    else prep2_item(P, e, P.ab[e], smask + threadIdx.x * kMaskWords);
+  if (set == 0) {
+    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < m; e += gridDim.x * blockDim.x) prep1_item(P, e, P.ab[e]);
+  } else {
+    const uint32_t group = threadIdx.x / kPrepGroup, groups = blockDim.x / kPrepGroup;       // 32 pairs per workgroup and pass
+    for (uint32_t e0 = blockIdx.x * groups; e0 < m; e0 += gridDim.x * groups) {               // uniform trip count per workgroup
+      const uint32_t e = e0 + group;
+      const bool live = e < m;
+      prep2_group(P, e, live, live ? P.ab[e] : make_int2(0, 0), smask + group * 16u);
+    }
   }
 }
 
@@ -950,7 +912,7 @@ struct PairParams {
   float max_normal_difference, max_color_distance, max_translation_distance, norm_threshold;
   float b1pos[3], b2pos[3], b1rgb[3], b2rgb[3];
   int2* ab; uint32_t* okey; uint32_t* counter; uint32_t cap; uint32_t* overflow; uint32_t overflow_bit;
-  int do_prep;                                             // fused path: prepare each pair for k_quads as it is appended
+  uint32_t split;                                          // waves per primitive: wave `part` takes the leaf tiles part, part + split, ...
 };
 
 __device__ __forceinline__ bool sphere_box(float cx, float cy, float cz, float r, float4 leaf) {
@@ -1003,26 +965,23 @@ __device__ __forceinline__ bool pair_filters(const PairParams& P, const uint32_t
   return acc;
 }
 
-constexpr int kPairStageW = 448;   // accepted (pId, j, slot) per wave between two flushes (12 B each)
+constexpr int kPairStageW = 192;   // accepted (pId, j, slot) per wave between two flushes (12 B each)
 constexpr int kPairWaves = 4;      // waves per workgroup
 
-struct PairSet { PairParams pair; PrepParams prep; };
+struct PairSet { PairParams pair; };
 struct PairParams2 { PairSet set[2]; };
 
 // The two pair sets of a base are independent: one launch, blockIdx.y picks the set (gridDim.y = 1 for a single set).
 __global__ __launch_bounds__(64 * kPairWaves) void k_pairs(PairParams2 PP) {
   const PairParams& P = PP.set[blockIdx.y].pair;
-  const PrepParams& R = PP.set[blockIdx.y].prep;
   __shared__ uint32_t st_j[kPairWaves][kPairStageW];
   __shared__ uint32_t st_s[kPairWaves][kPairStageW];
   __shared__ uint32_t st_p[kPairWaves][kPairStageW];
-  __shared__ uint32_t smask[64 * kPairWaves * kMaskWords];
   __shared__ uint32_t s_cnt[kPairWaves], s_base;
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  uint32_t* my_mask = smask + threadIdx.x * kMaskWords;
   uint32_t n_st = 0;                                     // staged entries of this wave (wave-uniform)
   // writes the wave's n_st staged entries at pair positions base, base + 2, ...: two ordered pairs per entry, one
-  // pair per lane (the set-2 preparation is ~3000 instructions per pair, so pairs, not entries, are spread over lanes)
+  // pair per lane
   auto write_out = [&](const uint32_t base) {
     for (uint32_t pe = lane; pe < 2u * n_st; pe += 64u) {
       const uint32_t e = pe >> 1, second = pe & 1u;
@@ -1033,10 +992,6 @@ __global__ __launch_bounds__(64 * kPairWaves) void k_pairs(PairParams2 PP) {
         // pairs->emplace_back(j, i) then pairs->emplace_back(i, j)   pairCreationFunctor.h:214-215
         const int2 pr = second ? make_int2(int(pId), int(j)) : make_int2(int(j), int(pId));
         P.ab[at] = pr; P.okey[at] = ok;
-        if (P.do_prep) {
-          if (blockIdx.y == 0) prep1_item(R, at, pr);
-          else prep2_item(R, at, pr, my_mask);
-        }
       } else {
         atomicOr(P.overflow, P.overflow_bit);
       }
@@ -1044,11 +999,15 @@ __global__ __launch_bounds__(64 * kPairWaves) void k_pairs(PairParams2 PP) {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
   };
+  // work item = (primitive, part): a primitive's leaf tiles are dealt out to `split` waves, so that a 2000-point sample
+  // puts ~8000 short waves on the chip instead of 2000 long ones (the walk is a chain of dependent L2 gathers); the
+  // emission order is carried by the order keys, not by who appends first
   const uint32_t gw = blockIdx.x * kPairWaves + wave, nw = gridDim.x * kPairWaves;
-  for (uint32_t pId = gw; pId < P.n_q; pId += nw) {
+  for (uint32_t item = gw; item < P.n_q * P.split; item += nw) {
+    const uint32_t pId = item / P.split, part = item - pId * P.split;
     const float cx = P.ux[pId], cy = P.uy[pId], cz = P.uz[pId];
     const float wxi = P.qx[pId], wyi = P.qy[pId], wzi = P.qz[pId];
-    for (uint32_t tile = 0; tile < P.n_leaf; tile += 64u) {
+    for (uint32_t tile = part * 64u; tile < P.n_leaf; tile += 64u * P.split) {
       const uint32_t l = tile + lane;
       uint32_t beg = 0, len = 0;
       if (l < P.n_leaf && sphere_box(cx, cy, cz, P.nRadius, P.leaves[l])) {     // intersect, intersectionPrimitive.h:117-142
@@ -1183,7 +1142,10 @@ struct QuadParams {
   int do_gate; GateParams gate;                          // fused path: gate every quad as it is appended
 };
 
-constexpr int kQuadStage = 1536;   // quads per workgroup between two flushes (24 B each)
+#ifndef S4P_QUAD_STAGE
+#define S4P_QUAD_STAGE 512           // 23 KB of LDS per workgroup: fits next to two resident k_verify workgroups (48 KB at 1536 did not)
+#endif
+constexpr int kQuadStage = S4P_QUAD_STAGE;   // quads per workgroup between two flushes (24 B each)
 
 // One thread per pairs2 entry: hash lookup of its euclidean cell, walk of the set-1 chain (super4pcs.cc:151-163).
 // Matches are staged in LDS and flushed with one global atomic per workgroup round; on the fused path the flush also
@@ -1194,7 +1156,9 @@ __global__ __launch_bounds__(256) void k_quads(QuadParams P) {
   __shared__ int4 st_q[kQuadStage];
   __shared__ unsigned long long st_t[kQuadStage];
   __shared__ uint32_t st_n, st_base, s_wc[4], s_cbase;
+  __shared__ uint32_t s_mask[256 * kMaskWords];            // each thread's copy of its entry's direction mask (row stride 11: conflict-free)
   const uint32_t m2 = min(*P.m2_dev, P.cap2);
+  const uint32_t hmask = hash_mask(P.ht);
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   if (threadIdx.x == 0) st_n = 0;
   __syncthreads();
@@ -1203,44 +1167,49 @@ __global__ __launch_bounds__(256) void k_quads(QuadParams P) {
     if (i < m2) {
       const uint32_t cell = P.cell2[i];
       const unsigned long long mykey = ((unsigned long long)P.ht.epoch << 32) | cell;
-      uint32_t h = hash_cell(cell) & P.ht.mask;
+      uint32_t h = hash_cell(cell) & hmask;
       uint32_t e = kNil;
       while (true) {
         const unsigned long long k = P.ht.keys[h];
         if (k == mykey) { const unsigned long long hd = P.ht.heads[h]; e = (uint32_t(hd >> 32) == P.ht.epoch) ? uint32_t(hd) : kNil; break; }
         if (uint32_t(k >> 32) != P.ht.epoch) break;
-        h = (h + 1u) & P.ht.mask;
+        h = (h + 1u) & hmask;
       }
       if (e != kNil) {
+        // The walk is a chain of dependent gathers (one set-1 pair per hop), so each hop is ONE round trip: the hop's
+        // direction bucket, world point and successor are requested together, and the 343-bit mask of this entry was
+        // copied to LDS up front (a global load indexed by the bucket would be a second dependent gather per hop).
         const float4 eq = P.ew2[i];
         const uint32_t* mk = P.mask2 + size_t(i) * kMaskWords;
+        uint32_t* row = s_mask + threadIdx.x * kMaskWords;
+#pragma unroll
+        for (int w = 0; w < kMaskWords; ++w) row[w] = mk[w];
         const int2 ab2 = P.ab2[i];
         const uint32_t ok2 = P.okey2[i];
         while (e != kNil) {
           const uint32_t b = P.bucket1[e];
-          if ((mk[b >> 5] >> (b & 31u)) & 1u) {
-            const float4 ep = P.ew1[e];
-            const float dx = eq.x - ep.x, dy = eq.y - ep.y, dz = eq.z - ep.z;
-            if (sqn3(dx, dy, dz) <= P.thr) {                                           // super4pcs.cc:160
-              const int2 ab1 = P.ab1[e];
-              const int4 quad = make_int4(ab1.x, ab1.y, ab2.x, ab2.y);                 // :171-172
-              const unsigned long long tag = ((unsigned long long)P.okey1[e] << 32) | ok2;
-              const uint32_t slot = atomicAdd(&st_n, 1u);
-              if (slot < uint32_t(kQuadStage)) { st_q[slot] = quad; st_t[slot] = tag; }
-              else {                                                                    // stage full (rare): direct append
-                const uint32_t at = atomicAdd(P.K_dev, 1u);
-                if (at < P.K_cap) {
-                  P.quads[at] = quad; P.tags[at] = tag;
-                  if (P.do_gate) {
-                    float T[12];
-                    if (gate_quad(P.gate, quad, T)) store_candidate(P.gate, atomicAdd(P.gate.C_dev, 1u), at, T);
-                    else P.gate.counts[at] = kGateFailed;
-                  }
-                } else atomicOr(P.overflow, 4u);
-              }
+          const float4 ep = P.ew1[e];
+          const uint32_t nxt = P.next1[e];
+          const float dx = eq.x - ep.x, dy = eq.y - ep.y, dz = eq.z - ep.z;
+          if (((row[b >> 5] >> (b & 31u)) & 1u) && sqn3(dx, dy, dz) <= P.thr) {       // super4pcs.cc:160
+            const int2 ab1 = P.ab1[e];
+            const int4 quad = make_int4(ab1.x, ab1.y, ab2.x, ab2.y);                 // :171-172
+            const unsigned long long tag = ((unsigned long long)P.okey1[e] << 32) | ok2;
+            const uint32_t slot = atomicAdd(&st_n, 1u);
+            if (slot < uint32_t(kQuadStage)) { st_q[slot] = quad; st_t[slot] = tag; }
+            else {                                                                    // stage full (rare): direct append
+              const uint32_t at = atomicAdd(P.K_dev, 1u);
+              if (at < P.K_cap) {
+                P.quads[at] = quad; P.tags[at] = tag;
+                if (P.do_gate) {
+                  float T[12];
+                  if (gate_quad(P.gate, quad, T)) store_candidate(P.gate, atomicAdd(P.gate.C_dev, 1u), at, T);
+                  else P.gate.counts[at] = kGateFailed;
+                }
+              } else atomicOr(P.overflow, 4u);
             }
           }
-          e = P.next1[e];
+          e = nxt;
         }
       }
     }
@@ -1288,7 +1257,13 @@ __global__ __launch_bounds__(256) void k_quads(QuadParams P) {
 // Persistent 1024-thread workgroups, one wave64 per gated candidate; the length of the gated list lives in device
 // memory (no host round trip).  LDS per workgroup: coarse bitmap (<= 34 KB) + 16 x 2.75 KB private survivor queues / item tables.
 // ---------------------------------------------------------------------------
-constexpr int kVerifyThreads = 1024;
+// k_verify / k_verify_T are launched with kVerifyThreadsCached (structure inside the Infinity Cache: the kernel is VALU-issue
+// bound, six waves per SIMD contend less; measured 0.1496 / 0.1443 / 0.1424 / 0.1433 / 0.1458 ms at 512 / 640 / 768 / 896 /
+// 1024 threads, tools/gpu_run19.sh) or with kVerifyMaxThreads (point lists beyond the cache: HBM bound, more waves in
+// flight win: 3.3 vs 4.1 TB/s on the configs[4] structure).  The block size is a launch parameter; the kernels only
+// assume blockDim.x <= kVerifyMaxThreads.
+constexpr int kVerifyMaxThreads = 1024;
+constexpr int kVerifyThreadsCached = 768;
 constexpr int kVerifyMaxBlocks = 4096;
 struct VerifyParams {
   LcpGrid grid;
@@ -1312,14 +1287,14 @@ __device__ __forceinline__ bool slot_better(const uint32_t ca, const unsigned lo
 }
 
 template <bool COUNT, bool QLDS>
-__global__ __launch_bounds__(kVerifyThreads, 8) void k_verify(VerifyParams P) {   // 8 waves/SIMD: two 1024-thread workgroups per CU
+__global__ __launch_bounds__(kVerifyMaxThreads, 8) void k_verify(VerifyParams P) {   // <= 64 VGPRs; two workgroups per CU (LDS)
   extern __shared__ uint32_t s_mem[];
   uint32_t* s_coarse = s_mem;                              // LDS: coarse bitmap | quantised queries (QLDS) | 16 survivor queues
   uint2* s_q = reinterpret_cast<uint2*>(s_mem + P.grid.coarse_words);
   uint32_t* s_queue = reinterpret_cast<uint32_t*>(s_q + (QLDS ? ((P.n_q + 127u) & ~127u) : 0u)) + (threadIdx.x >> 6) * kQueueWordsPerWave;
   __shared__ uint32_t s_next, s_last;
-  __shared__ uint32_t s_wcnt[kVerifyThreads / 64], s_wcand[kVerifyThreads / 64];
-  __shared__ unsigned long long s_wtag[kVerifyThreads / 64];
+  __shared__ uint32_t s_wcnt[kVerifyMaxThreads / 64], s_wcand[kVerifyMaxThreads / 64];
+  __shared__ unsigned long long s_wtag[kVerifyMaxThreads / 64];
   const uint32_t C = P.ctr->C;
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   // Work split: every workgroup owns a contiguous slice of the gated candidate list (static: a single-address global
@@ -1363,7 +1338,7 @@ __global__ __launch_bounds__(kVerifyThreads, 8) void k_verify(VerifyParams P) { 
     __syncthreads();
     if (threadIdx.x == 0) {
       bc = 0; bi = kNil; bt = ~0ull;
-      for (uint32_t w = 0; w < uint32_t(kVerifyThreads / 64); ++w)
+      for (uint32_t w = 0; w < (blockDim.x >> 6); ++w)
         if (s_wcand[w] != kNil && slot_better(s_wcnt[w], s_wtag[w], bc, bt, bi != kNil)) { bc = s_wcnt[w]; bt = s_wtag[w]; bi = s_wcand[w]; }
     }
   };
@@ -1390,7 +1365,7 @@ __global__ __launch_bounds__(kVerifyThreads, 8) void k_verify(VerifyParams P) { 
   DevCounters* r = P.res;
   r->m1 = c->m1; r->m2 = c->m2; r->K = c->K; r->C = C; r->overflow = c->overflow;
   r->best_count = bc; r->best_tag = bt; r->has_best = 0u;
-  if (COUNT || P.count_tests) { r->point_tests = c->point_tests; r->l0_pass = c->l0_pass; r->l1_pass = c->l1_pass; r->l2_pass = c->l2_pass; r->settled = c->settled; }
+  if (COUNT || P.count_tests) { r->point_tests = c->point_tests; r->l0_pass = c->l0_pass; r->l1_pass = c->l1_pass; r->l2_pass = c->l2_pass; }
   if (bi != kNil) {                                        // recompute the winner's 4x4 (ComputeRigidTransformation)
     const uint32_t k = P.cand_idx[bi];
     const int4 qd = P.quads[k];
@@ -1406,7 +1381,7 @@ __global__ __launch_bounds__(kVerifyThreads, 8) void k_verify(VerifyParams P) { 
   }
   // the live counters are ready for the next base on this lane (no separate reset launch)
   c->m1 = 0; c->m2 = 0; c->K = 0; c->C = 0; c->best_count = 0; c->overflow = 0; c->best_tag = ~0ull; c->has_best = 0;
-  c->point_tests = 0; c->l0_pass = 0; c->l1_pass = 0; c->l2_pass = 0; c->settled = 0;
+  c->point_tests = 0; c->l0_pass = 0; c->l1_pass = 0; c->l2_pass = 0;
   __threadfence();
   c->done = 0;
 }
@@ -1417,7 +1392,7 @@ struct VerifyTParams {
   const float* T; uint32_t B; uint32_t* counts; DevCounters* ctr;
 };
 template <bool COUNT, bool QLDS>
-__global__ __launch_bounds__(kVerifyThreads) void k_verify_T(VerifyTParams P) {
+__global__ __launch_bounds__(kVerifyMaxThreads) void k_verify_T(VerifyTParams P) {
   extern __shared__ uint32_t s_mem[];
   uint32_t* s_coarse = s_mem;
   uint2* s_q = reinterpret_cast<uint2*>(s_mem + P.grid.coarse_words);
@@ -1588,7 +1563,7 @@ __global__ void k_selftest(const float* a, const float* b, uint64_t n, float* o_
 __global__ void k_reset_counters(DevCounters* c) {
   c->m1 = 0; c->m2 = 0; c->K = 0; c->C = 0; c->best_count = 0; c->overflow = 0;
   c->best_tag = ~0ull; c->has_best = 0; c->done = 0;
-  c->point_tests = 0; c->l0_pass = 0; c->l1_pass = 0; c->l2_pass = 0; c->settled = 0;
+  c->point_tests = 0; c->l0_pass = 0; c->l1_pass = 0; c->l2_pass = 0;
 }
 
 }  // namespace s4p
