@@ -81,6 +81,13 @@ void    s4p_destroy(s4p_ctx* ctx);
 const char* s4p_last_error(const s4p_ctx* ctx);   /* ctx may be NULL: last create error */
 int32_t s4p_device_name(const s4p_ctx* ctx, char* buf, int32_t buflen);
 
+/* Raises the pair / quad capacities to at least min_pairs / min_quads (0 = the counts of the base whose overflow was
+ * reported last) with head-room, reallocating the per-base device buffers of every lane; nothing may be in flight.
+ * Refused with S4P_ERR_CAPACITY (limits unchanged) if the buffers would take more than 60 % of the device memory.
+ * s4p_get_limits reports the capacities in force. */
+int32_t s4p_grow_limits(s4p_ctx* ctx, uint64_t min_pairs, uint64_t min_quads);
+int32_t s4p_get_limits(const s4p_ctx* ctx, s4p_limits* out);
+
 /* ---- state ---------------------------------------------------------------- */
 /* Uploads the sampled, centred clouds and builds the device structures.
  * Replaces Match4PCSBase::initKdTree (match4pcsBase.cc:353-363; the kd-tree becomes

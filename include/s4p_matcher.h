@@ -131,6 +131,15 @@ int32_t s4p_matcher_visit_candidates(s4p_matcher* m, int32_t enable);
 int32_t s4p_matcher_set_device_selection(s4p_matcher* m, int32_t mode);
 int32_t s4p_matcher_device_selection(const s4p_matcher* m);
 
+/* Device buffer capacities (s4p_limits) inside s4p_matcher_perform_n_steps / _compute_transformation: when a base has more
+ * pairs or quads than the buffers hold, the speculation is rolled back to just before that base, the buffers are grown to
+ * what the base's own counters ask for (s4p_grow_limits) and the loop resumes with the same base -- same trials and
+ * results as with limits that were large enough from the start (the reference's std::vector simply grows).  On by default;
+ * with enable == 0, or when the growth is refused (more than 60 % of the device memory), the call fails with
+ * S4P_ERR_CAPACITY as the stage-level entry points always do.  s4p_matcher_capacity_growths counts the regrowths. */
+int32_t s4p_matcher_grow_on_overflow(s4p_matcher* m, int32_t enable);
+int32_t s4p_matcher_capacity_growths(const s4p_matcher* m);
+
 /* getGlobalTransform (match4pcsBase.hpp:224-229). */
 int32_t s4p_matcher_global_transform(s4p_matcher* m, float* transformation);
 

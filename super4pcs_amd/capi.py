@@ -14,12 +14,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("S4P_LIB") or os.path.join(_HERE, "lib", "libsuper4pcs_amd.so")
 
 S4P_OK = 0
+S4P_ERR_CAPACITY = -5
 ERR_NAMES = {0: "OK", -1: "BAD_ARG", -2: "NO_DEVICE", -3: "HIP", -4: "OOM", -5: "CAPACITY", -6: "UNSUPPORTED", -7: "STATE"}
 
 EXPORTED_SYMBOLS = [
     "s4p_create", "s4p_destroy", "s4p_last_error", "s4p_device_name", "s4p_set_clouds", "s4p_set_base",
     "s4p_extract_pairs", "s4p_find_congruent", "s4p_try_congruent_set", "s4p_verify_transforms", "s4p_verify_transforms_counted",
-    "s4p_transform_points_device", "s4p_apply_bench", "s4p_select_base_points", "s4p_try_base", "s4p_last_verified", "s4p_try_base_async", "s4p_try_base_wait", "s4p_pair_state_words", "s4p_pair_state_save", "s4p_pair_state_restore", "s4p_stage_slots", "s4p_pipeline_depth", "s4p_stage_base", "s4p_try_base_staged_async", "s4p_skip_base", "s4p_last_candidates", "s4p_transform_points", "s4p_profile_enable", "s4p_profile_get",
+    "s4p_transform_points_device", "s4p_apply_bench", "s4p_select_base_points", "s4p_grow_limits", "s4p_get_limits", "s4p_try_base", "s4p_last_verified", "s4p_try_base_async", "s4p_try_base_wait", "s4p_pair_state_words", "s4p_pair_state_save", "s4p_pair_state_restore", "s4p_stage_slots", "s4p_pipeline_depth", "s4p_stage_base", "s4p_try_base_staged_async", "s4p_skip_base", "s4p_last_candidates", "s4p_transform_points", "s4p_profile_enable", "s4p_profile_get",
     "s4p_selftest_ieee",
 ]
 
@@ -315,7 +316,7 @@ SHARD_SYMBOLS = [
 MATCHER_SYMBOLS = [
     "s4p_matcher_create", "s4p_matcher_destroy", "s4p_matcher_last_error", "s4p_matcher_ctx", "s4p_uniform_dist_sample",
     "s4p_matcher_init", "s4p_matcher_init_full", "s4p_matcher_get_info", "s4p_matcher_get_sampled",
-    "s4p_matcher_get_sampled_attrs", "s4p_matcher_select_quadrilateral", "s4p_matcher_try_one_base", "s4p_matcher_next_base", "s4p_matcher_next_base_async", "s4p_matcher_wait_base", "s4p_matcher_set_sharding", "s4p_matcher_visit_candidates", "s4p_matcher_commit", "s4p_matcher_perform_n_steps", "s4p_matcher_set_device_selection", "s4p_matcher_device_selection",
+    "s4p_matcher_get_sampled_attrs", "s4p_matcher_select_quadrilateral", "s4p_matcher_try_one_base", "s4p_matcher_next_base", "s4p_matcher_next_base_async", "s4p_matcher_wait_base", "s4p_matcher_set_sharding", "s4p_matcher_visit_candidates", "s4p_matcher_commit", "s4p_matcher_perform_n_steps", "s4p_matcher_set_device_selection", "s4p_matcher_device_selection", "s4p_matcher_grow_on_overflow", "s4p_matcher_capacity_growths",
     "s4p_matcher_global_transform", "s4p_matcher_compute_transformation",
 ]
 VISITOR_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_float, C.c_float, C.POINTER(C.c_float))
@@ -362,6 +363,15 @@ def _declare_matcher(L):
     L.s4p_matcher_perform_n_steps.argtypes = [vp, C.c_int32, VISITOR_FN, vp, C.c_int32, fp, ip, ip]
     L.s4p_matcher_global_transform.restype = C.c_int32
     L.s4p_matcher_global_transform.argtypes = [vp, fp]
+    if hasattr(L, "s4p_matcher_grow_on_overflow"):
+        L.s4p_matcher_grow_on_overflow.restype = C.c_int32
+        L.s4p_matcher_grow_on_overflow.argtypes = [vp, C.c_int32]
+        L.s4p_matcher_capacity_growths.restype = C.c_int32
+        L.s4p_matcher_capacity_growths.argtypes = [vp]
+        L.s4p_get_limits.restype = C.c_int32
+        L.s4p_get_limits.argtypes = [vp, C.POINTER(Limits)]
+        L.s4p_grow_limits.restype = C.c_int32
+        L.s4p_grow_limits.argtypes = [vp, C.c_uint64, C.c_uint64]
     if hasattr(L, "s4p_matcher_set_device_selection"):
         L.s4p_matcher_set_device_selection.restype = C.c_int32
         L.s4p_matcher_set_device_selection.argtypes = [vp, C.c_int32]
@@ -469,6 +479,19 @@ class Matcher:
         x = np.empty(n, np.float32); y = np.empty(n, np.float32); z = np.empty(n, np.float32)
         self._chk(self.L.s4p_matcher_get_sampled(self.h, which, _f(x), _f(y), _f(z)))
         return np.stack([x, y, z], axis=1)
+
+    def grow_on_overflow(self, enable):
+        self._chk(self.L.s4p_matcher_grow_on_overflow(self.h, int(enable)))
+
+    def capacity_growths(self):
+        return int(self.L.s4p_matcher_capacity_growths(self.h))
+
+    def limits(self):
+        lim = Limits()
+        rc = self.L.s4p_get_limits(self.ctx_handle(), C.byref(lim))
+        if rc != S4P_OK:
+            raise S4PError(rc, "s4p_get_limits")
+        return int(lim.max_pairs), int(lim.max_quads)
 
     def set_device_selection(self, mode):
         """-1 by size (default), 0 host search structures, 1 device reductions; before init."""

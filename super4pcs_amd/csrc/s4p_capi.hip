@@ -47,6 +47,7 @@ struct s4p_ctx {
   std::string err;
   s4p_options opt{};
   uint64_t max_pairs = 0, max_quads = 0, max_grid_cells = 0;
+  uint64_t need_pairs = 0, need_quads = 0;      // counts of the base that overflowed last (s4p_grow_limits)
   char devname[256] = {0};
 
   // host mirrors
@@ -149,8 +150,12 @@ struct s4p_ctx {
 
 namespace {
 
-int32_t check_overflow(s4p_ctx* c, uint32_t ov) {
+int32_t check_overflow(s4p_ctx* c, const DevCounters& d) {
+  const uint32_t ov = d.overflow;
   if (!ov) return S4P_OK;
+  // the device counters keep counting past the capacity, so they say what this base needs (the quads only once the
+  // pairs fit: with truncated pair lists K is a lower bound)
+  c->need_pairs = std::max<uint64_t>(d.m1, d.m2); c->need_quads = d.K;
   char b[160];
   snprintf(b, sizeof b, "device buffer overflow (bits=%u: 1=pairs1 2=pairs2 4=quads); raise s4p_limits (max_pairs=%llu max_quads=%llu)",
            ov, (unsigned long long)c->max_pairs, (unsigned long long)c->max_quads);
@@ -367,7 +372,7 @@ int32_t finish_result(s4p_ctx* c, s4p_base_result* r, bool fused) {
     c->host_wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
   const DevCounters& d = *c->hctr[c->cur].p;
   const BaseFrame& bf = c->slot_bf[c->cur];
-  if (int32_t rc = check_overflow(c, d.overflow)) return rc;
+  if (int32_t rc = check_overflow(c, d)) return rc;
   std::memset(r, 0, sizeof(*r));
   r->n_pairs1 = d.m1; r->n_pairs2 = d.m2; r->n_quads = d.K; r->n_verified = d.C;
   r->best_count = d.C ? d.best_count : 0u; r->has_best = d.C ? 1 : 0;
@@ -403,6 +408,27 @@ int32_t reset_counters(s4p_ctx* c) {
   HIPCHK(c, hipGetLastError());
   c->lane[c->cur].dirty = false;
   return S4P_OK;
+}
+
+// Per-lane buffers sized by the limits (pairs: 11 arrays, quads: 5, the cell hash): at creation and when the limits grow.
+hipError_t alloc_lane_buffers(s4p_ctx* c, s4p_ctx::Lane& L, const char** what) {
+  const size_t mp = c->max_pairs, mq = c->max_quads;
+  const uint32_t hts = next_pow2(2 * mp);
+  hipError_t e = hipSuccess;
+#define A(buf, cnt) if ((e = (buf).alloc(cnt)) != hipSuccess) { *what = "hipMalloc " #buf; return e; }
+  A(L.ab1, mp); A(L.ab2, mp); A(L.okey1, mp); A(L.okey2, mp); A(L.cell1, mp); A(L.cell2, mp);
+  A(L.bucket1, mp); A(L.next1, mp); A(L.mask2, mp * kMaskWords); A(L.ew1, mp); A(L.ew2, mp);
+  A(L.quads, mq); A(L.tags, mq); A(L.counts, mq); A(L.cand_idx, mq); A(L.cand_T, mq * 3);
+  A(L.ht_keys, hts); A(L.ht_heads, hts); L.ht_mask = hts - 1;
+#undef A
+  *what = "hipMemset";
+  if ((e = hipMemset(L.ht_keys.p, 0, size_t(hts) * 8)) != hipSuccess) return e;
+  if ((e = hipMemset(L.ht_heads.p, 0, size_t(hts) * 8)) != hipSuccess) return e;
+  L.epoch = 0; L.dirty = true;                          // first use of a lane starts with an explicit clear (best_tag = ~0)
+  return hipSuccess;
+}
+size_t lane_bytes(uint64_t mp, uint64_t mq) {            // what alloc_lane_buffers takes per lane
+  return size_t(mp) * (8 + 8 + 4 * 6 + 4 * kMaskWords + 16 * 2) + size_t(mq) * (16 + 8 + 4 + 4 + 48) + size_t(next_pow2(2 * mp)) * 16;
 }
 
 }  // namespace
@@ -453,8 +479,6 @@ int32_t s4p_create(const s4p_options* opt, const s4p_limits* lim, int32_t device
   auto fail = [&](hipError_t e, const char* what) { g_create_error = std::string(what) + ": " + hipGetErrorString(e); s4p_destroy(c); return e == hipErrorOutOfMemory ? S4P_ERR_OOM : S4P_ERR_HIP; };
   hipError_t e;
   if ((e = hipSetDevice(device)) != hipSuccess) return fail(e, "hipSetDevice");
-  const size_t mp = c->max_pairs, mq = c->max_quads;
-  const uint32_t hts = next_pow2(2 * mp);
 #define A(buf, cnt) if ((e = (buf).alloc(cnt)) != hipSuccess) return fail(e, "hipMalloc " #buf)
   for (int li = 0; li < c->n_lanes; ++li) {
     s4p_ctx::Lane& L = c->lane[li];
@@ -471,15 +495,10 @@ int32_t s4p_create(const s4p_options* opt, const s4p_limits* lim, int32_t device
       if ((e = hipEventCreateWithFlags(&L.chain, hipEventDisableTiming)) != hipSuccess) return fail(e, "hipEventCreate");
       if (!getenv("S4P_VERIFY_BLOCKS")) c->verify_blocks = 2u * nbig;
     } else if ((e = hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
-    A(L.ab1, mp); A(L.ab2, mp); A(L.okey1, mp); A(L.okey2, mp); A(L.cell1, mp); A(L.cell2, mp);
-    A(L.bucket1, mp); A(L.next1, mp); A(L.mask2, mp * kMaskWords); A(L.ew1, mp); A(L.ew2, mp);
-    A(L.quads, mq); A(L.tags, mq); A(L.counts, mq); A(L.cand_idx, mq); A(L.cand_T, mq * 3);
-    A(L.ht_keys, hts); A(L.ht_heads, hts); L.ht_mask = hts - 1;
     A(L.ctr, 2); A(L.slots, kVerifyMaxBlocks);
-    if ((e = hipMemset(L.ht_keys.p, 0, size_t(hts) * 8)) != hipSuccess) return fail(e, "hipMemset");
-    if ((e = hipMemset(L.ht_heads.p, 0, size_t(hts) * 8)) != hipSuccess) return fail(e, "hipMemset");
     if ((e = hipMemset(L.ctr.p, 0, 2 * sizeof(DevCounters))) != hipSuccess) return fail(e, "hipMemset");
-    L.epoch = 0; L.dirty = true;                        // first use of a lane starts with an explicit clear (best_tag = ~0)
+    const char* what = nullptr;
+    if ((e = alloc_lane_buffers(c, L, &what)) != hipSuccess) return fail(e, what);
   }
 #undef A
   for (int sl = 0; sl < s4p_ctx::kMaxLanes; ++sl) {
@@ -498,6 +517,49 @@ int32_t s4p_create(const s4p_options* opt, const s4p_limits* lim, int32_t device
   if ((e = c->sel_draws.alloc(kSelectDraws)) != hipSuccess || (e = c->sel_rec.alloc(1)) != hipSuccess) return fail(e, "hipMalloc selection buffers");
   if ((e = c->sel_hdraws.alloc(kSelectDraws)) != hipSuccess || (e = c->sel_hrec.alloc(1)) != hipSuccess) return fail(e, "hipHostMalloc selection buffers");
   *out = c;
+  return S4P_OK;
+}
+
+// Raises the pair / quad capacities to at least the given numbers (the counts of the base that overflowed, if 0) with
+// 25 % head-room, at least doubling what overflowed; every lane is reallocated.  Nothing may be in flight.  Refuses
+// (S4P_ERR_CAPACITY, limits unchanged) when the lanes would then take more than 60 % of the device memory.
+int32_t s4p_grow_limits(s4p_ctx* c, uint64_t min_pairs, uint64_t min_quads) {
+  if (!c) return S4P_ERR_BAD_ARG;
+  if (c->q_head != c->q_tail) S4P_FAIL(c, S4P_ERR_STATE, "s4p_grow_limits: bases in flight");
+  HIPCHK(c, hipSetDevice(c->device));
+  if (!min_pairs) min_pairs = c->need_pairs;
+  if (!min_quads) min_quads = c->need_quads;
+  uint64_t mp = c->max_pairs, mq = c->max_quads;
+  if (min_pairs > mp) mp = std::max<uint64_t>(2 * mp, min_pairs + min_pairs / 4);
+  if (min_quads > mq) mq = std::max<uint64_t>(2 * mq, min_quads + min_quads / 4);
+  if (mp == c->max_pairs && mq == c->max_quads) return S4P_OK;
+  size_t free_b = 0, total_b = 0;
+  HIPCHK(c, hipMemGetInfo(&free_b, &total_b));
+  if (mp > 0x7FFFFFFFull || mq > 0x7FFFFFFFull || double(lane_bytes(mp, mq)) * c->n_lanes > 0.6 * double(total_b)) {
+    char b[200];
+    snprintf(b, sizeof b, "device buffers would have to grow to max_pairs=%llu max_quads=%llu (%.1f GB in %d lanes): refused",
+             (unsigned long long)mp, (unsigned long long)mq, double(lane_bytes(mp, mq)) * c->n_lanes / 1e9, c->n_lanes);
+    c->err = b;
+    return S4P_ERR_CAPACITY;
+  }
+  for (int li = 0; li < c->n_lanes; ++li) {
+    s4p_ctx::Lane& L = c->lane[li];
+    HIPCHK(c, hipStreamSynchronize(L.stream));
+    if (L.vstream) HIPCHK(c, hipStreamSynchronize(L.vstream));
+  }
+  c->max_pairs = mp; c->max_quads = mq;
+  for (int li = 0; li < c->n_lanes; ++li) {
+    const char* what = nullptr;
+    const hipError_t e = alloc_lane_buffers(c, c->lane[li], &what);       // DevBuf::alloc frees the old buffer first
+    if (e != hipSuccess) { c->err = std::string(what) + ": " + hipGetErrorString(e); return e == hipErrorOutOfMemory ? S4P_ERR_OOM : S4P_ERR_HIP; }
+  }
+  c->need_pairs = c->need_quads = 0;
+  return S4P_OK;
+}
+
+int32_t s4p_get_limits(const s4p_ctx* c, s4p_limits* out) {
+  if (!c || !out) return S4P_ERR_BAD_ARG;
+  out->max_pairs = c->max_pairs; out->max_quads = c->max_quads; out->max_grid_cells = c->max_grid_cells;
   return S4P_OK;
 }
 
@@ -710,7 +772,7 @@ int32_t s4p_extract_pairs(s4p_ctx* c, float pair_distance, float pair_normals_an
   if (int32_t rc = launch_pairs(c, 0, pair_distance, pair_normals_angle, pair_distance_epsilon, bp1, bp2)) return rc;
   HIPCHK(c, hipMemcpyAsync(c->hctr[c->cur].p, c->lane[c->cur].ctr.p, sizeof(DevCounters), hipMemcpyDeviceToHost, c->lane[c->cur].stream));
   HIPCHK(c, hipStreamSynchronize(c->lane[c->cur].stream));
-  if (int32_t rc = check_overflow(c, c->hctr[c->cur].p->overflow)) return rc;
+  if (int32_t rc = check_overflow(c, *c->hctr[c->cur].p)) return rc;
   const uint32_t m = c->hctr[c->cur].p->m1;
   *n_out = m;
   if (m == 0) return S4P_OK;
@@ -755,7 +817,7 @@ int32_t s4p_find_congruent(s4p_ctx* c, float inv1, float inv2, float /*thr1*/, f
     HIPCHK(c, hipGetLastError()); }
   HIPCHK(c, hipMemcpyAsync(c->hctr[c->cur].p, c->lane[c->cur].ctr.p, sizeof(DevCounters), hipMemcpyDeviceToHost, c->lane[c->cur].stream));
   HIPCHK(c, hipStreamSynchronize(c->lane[c->cur].stream));
-  if (int32_t rc = check_overflow(c, c->hctr[c->cur].p->overflow)) return rc;
+  if (int32_t rc = check_overflow(c, *c->hctr[c->cur].p)) return rc;
   const uint32_t K = c->hctr[c->cur].p->K;
   *n_out = K;
   if (K == 0) return S4P_OK;

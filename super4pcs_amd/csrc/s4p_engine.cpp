@@ -119,6 +119,8 @@ struct s4p_matcher {
   uint64_t candidates_verified = 0, quads_total = 0, pairs_total = 0, bases_tried = 0;
   double seconds_select = 0, seconds_device = 0;
   bool ready = false;
+  bool grow_on_overflow = true;          // Perform_N_steps: grow the device buffers and redo the base instead of failing
+  uint32_t capacity_growths = 0;
   std::atomic<bool> select_failed{false}; std::string select_err;   // a device selection attempt returned an error (possibly on the selector thread)
   bool visit_candidates = false;         // issue the reference's per-candidate visitor calls (fraction == -1)
   // pipelined trials: bases whose device pass is in flight (at most two)
@@ -817,6 +819,14 @@ int32_t s4p_matcher_set_device_selection(s4p_matcher* m, int32_t mode) {
 
 int32_t s4p_matcher_device_selection(const s4p_matcher* m) { return m && m->device_select ? 1 : 0; }
 
+int32_t s4p_matcher_grow_on_overflow(s4p_matcher* m, int32_t enable) {
+  if (!m) return S4P_ERR_BAD_ARG;
+  m->grow_on_overflow = enable != 0;
+  return S4P_OK;
+}
+
+int32_t s4p_matcher_capacity_growths(const s4p_matcher* m) { return m ? int32_t(m->capacity_growths) : 0; }
+
 int32_t s4p_matcher_visit_candidates(s4p_matcher* m, int32_t enable) {
   if (!m) return S4P_ERR_BAD_ARG;
   m->visit_candidates = enable != 0;
@@ -868,6 +878,24 @@ int32_t s4p_matcher_global_transform(s4p_matcher* m, float* M) {
   return S4P_OK;
 }
 
+// Undoes everything that ran ahead of the committed trials: the producer threads are stopped (which rewinds to the first
+// trial not handed to this thread), the bases handed over but not committed are waited for and dropped, and the RNG
+// stream and the octree permutation go back to what they were before the first of them.
+static void rewind_speculation(s4p_matcher* m) {
+  std::vector<s4p_matcher::Prepared>& fifo = m->inflight;
+  if (m->prod.enabled) producer_stop(m);
+  if (fifo.empty()) return;
+  m->rng = fifo.front().rng_before;
+  std::vector<uint32_t> st = fifo.front().pair_state_before;
+  for (auto& pr : fifo) {
+    s4p_base_result dummy;
+    if (pr.device) { (void)s4p_try_base_wait(m->ctx, &dummy); producer_release_slot(m, pr.slot); }
+  }
+  if (!st.empty()) s4p_pair_state_restore(m->ctx, st.data());
+  if (m->prod.enabled) m->prod.consumed -= long(fifo.size());
+  fifo.clear();
+}
+
 int32_t s4p_matcher_perform_n_steps(s4p_matcher* m, int32_t n, s4p_visitor_fn visitor, void* user, int32_t needs_global,
                                     float* transformation, int32_t* improved, int32_t* done) {
   if (!m || !transformation || !improved || !done) return S4P_ERR_BAD_ARG;
@@ -895,7 +923,21 @@ int32_t s4p_matcher_perform_n_steps(s4p_matcher* m, int32_t n, s4p_visitor_fn vi
     s4p_matcher::Prepared pr = std::move(fifo.front());
     fifo.erase(fifo.begin());
     s4p_base_result r;
-    if ((rc = wait_base(m, pr, r)) != S4P_OK) break;
+    rc = wait_base(m, pr, r);
+    if (rc == S4P_ERR_CAPACITY && m->grow_on_overflow) {
+      // A device pair / quad buffer was too small for this base.  Bases never read results, so the speculation is rolled
+      // back to just before this base (RNG stream, octree permutation, producer threads), the buffers are grown to what
+      // the base's own counters ask for, and the loop resumes with the same base: same trials, same results, as if the
+      // limits had been large enough from the start.  Refused growth (device memory) stays the loud capacity error.
+      fifo.insert(fifo.begin(), std::move(pr));
+      fifo.front().device = false; fifo.front().slot = -1;  // its wait has returned (with the error) and released its slot
+      rewind_speculation(m);
+      if (s4p_grow_limits(m->ctx, 0, 0) != S4P_OK) { rc = m->ctx_fail(S4P_ERR_CAPACITY); break; }
+      m->capacity_growths++;
+      rc = S4P_OK; next_prep = i; --i;
+      continue;
+    }
+    if (rc != S4P_OK) break;
     if (visitor && m->visit_candidates && pr.device && r.n_verified) {     // match4pcsBase.hpp:458-465
       std::vector<uint32_t> cnt(size_t(r.n_verified)); std::vector<float> Ts(size_t(r.n_verified) * 16);
       int64_t nv = 0;
@@ -923,15 +965,7 @@ int32_t s4p_matcher_perform_n_steps(s4p_matcher* m, int32_t n, s4p_visitor_fn vi
     if (ok || i > m->number_of_trials || fraction >= 0.99 || m->best_lcp == 1.0) break;
   }
   // drain speculative work and put the host state back where the sequential loop stopped
-  if (m->prod.enabled) producer_stop(m);           // rewinds to the first trial not handed to this thread ...
-  if (!fifo.empty()) {                             // ... and these were handed over but not committed
-    m->rng = fifo.front().rng_before;
-    std::vector<uint32_t> st = fifo.front().pair_state_before;
-    for (auto& pr : fifo) { s4p_base_result dummy; if (pr.device) { (void)s4p_try_base_wait(m->ctx, &dummy); producer_release_slot(m, pr.slot); } }
-    if (!st.empty()) s4p_pair_state_restore(m->ctx, st.data());
-    if (m->prod.enabled) m->prod.consumed -= long(fifo.size());
-    fifo.clear();
-  }
+  rewind_speculation(m);
   if (rc != S4P_OK) return rc;
   m->current_trial += n;
   *improved = m->best_lcp > last_best ? 1 : 0;

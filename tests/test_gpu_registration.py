@@ -327,3 +327,31 @@ def test_early_termination_is_exact(oracle_mod, s4p_lib_built, producer):
         g_ok, _r = gm.try_one_base()
         assert g_ok == o_ok
     assert gm.info().candidates_verified == om.stats().n_verified and gm.info().best_lcp == om.stats().best_lcp
+
+
+@pytest.mark.parametrize("producer", [False, True])
+def test_capacity_growth_replays_the_overflowing_base(oracle_mod, s4p_lib_built, producer):
+    """Device buffers far too small for a base (256 pairs / 256 quads): ComputeTransformation rolls the speculation back
+    to just before the overflowing base, grows the buffers to what the base's counters ask for and resumes -- the same
+    registration as the oracle's (whose std::vectors simply grow), to the candidate.  With growth switched off the
+    same run fails loudly."""
+    from super4pcs_amd import capi
+    O = oracle_mod
+    delta, overlap, n_s = 0.01, 0.6, 200
+    P, Q, _ = H.small_pair(20000, delta=delta, seed=3)
+    om = O.Matcher(O.make_options(delta, overlap, n_s), full_counts=False, use_kdtree=True)
+    o_lcp, o_M, _ = om.compute_transformation(P, Q)
+    gm = capi.Matcher(capi.make_options(delta, overlap, n_s), max_pairs=256, max_quads=256)
+    if producer:
+        gm.set_sharding(0, 1, True)
+    g_lcp, g_M, _ = gm.compute_transformation(P, Q)
+    assert g_lcp == o_lcp and np.max(np.abs(g_M - o_M)) <= 1e-4
+    assert gm.info().candidates_verified == om.stats().n_verified
+    assert gm.capacity_growths() >= 1
+    mp, mq = gm.limits()
+    assert mp > 256 and mq > 256
+    strict = capi.Matcher(capi.make_options(delta, overlap, n_s), max_pairs=256, max_quads=256)
+    strict.grow_on_overflow(False)
+    with pytest.raises(capi.S4PError) as e:
+        strict.compute_transformation(P, Q)
+    assert e.value.code == capi.S4P_ERR_CAPACITY
