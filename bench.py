@@ -462,6 +462,32 @@ def main():
         except Exception as e:                                  # noqa: BLE001
             apply_row = {"error": "%s: %s" % (type(e).__name__, e)}
 
+    # k_verify with the chip to itself: the same bases with ONE base in flight (S4P_LANES is read at context creation).
+    # With the default number of lanes every launch shares the CUs with the launches of the other lanes, so its HIP-event
+    # duration is not the kernel's own time.
+    exclusive = None
+    if world == 1 and rank == 0:
+        saved = os.environ.get("S4P_LANES")
+        os.environ["S4P_LANES"] = "1"
+        try:
+            m1 = capi.Matcher(opt, device=local_rank, max_pairs=MAX_PAIRS, max_quads=MAX_QUADS)
+            m1.init_full(P, Q)
+            m1.set_sharding(0, 1, True)
+            m1.perform_n_steps(args.warmup)
+            m1.profile_enable(True, False)
+            m1.profile_get(reset=True)
+            m1.perform_n_steps(min(args.steps, 60))
+            p1 = m1.profile_get(reset=True)
+            m1.close()
+            if p1.verify_launches:
+                exclusive = {"avg_launch_ms": p1.verify_ms_total / p1.verify_launches, "launches": int(p1.verify_launches),
+                             "candidates_per_launch": p1.verify_candidates / p1.verify_launches}
+        finally:
+            if saved is None:
+                os.environ.pop("S4P_LANES", None)
+            else:
+                os.environ["S4P_LANES"] = saved
+
     if rank == 0:
         launches = max(prof.verify_launches, 1)
         avg_ms = prof.verify_ms_total / launches
@@ -504,6 +530,14 @@ def main():
                                     "note": "SURVEY.md 8d figure (27 cells x 8 B per query, no cache credit): a cell-probing kernel this one "
                                             "replaced; kept for reference, not a roofline fraction"},
                 "hbm_bound_point": hbm_point,
+                "exclusive": None if exclusive is None else dict(
+                    exclusive, achieved=exclusive["candidates_per_launch"] * gather_b / (exclusive["avg_launch_ms"] * 1e-3) / 1e9,
+                    frac=exclusive["candidates_per_launch"] * gather_b / (exclusive["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    note="same bases with one base in flight (S4P_LANES=1): k_verify's own launch time; achieved/frac above use the "
+                         "launch time of the default configuration, where every launch shares the chip with the other lanes' kernels"),
+                "aggregate": {"achieved": value * gather_b / 1e9, "frac": value * gather_b / 1e9 / HBM_PEAK_GBS,
+                              "note": "value (candidates/s of the whole pipeline) x algorithmic bytes per candidate: what the chip "
+                                      "sustains per unit of time with the default lanes"},
             },
             "k_apply": apply_row,
             "stage_ms_per_step": {"pairs_and_prep": prof.pairs_ms_total / max(prof.quads_launches, 1),

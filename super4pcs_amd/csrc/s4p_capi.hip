@@ -66,7 +66,7 @@ struct s4p_ctx {
   DevBuf<uint2> qquant; QuantQ qq{}; bool qlds = false;      // 16-bit copy of the Morton-ordered queries for the LDS-resident sweep
   DevBuf<float> qx, qy, qz, ux, uy, uz, qnx, qny, qnz, qcr, qcg, qcb;
   // Lanes = HIP streams with private per-base device buffers.  Consecutive bases rotate over the lanes, so the
-  // small latency-bound kernels of base t+1 (pairs, hash build, quad enumeration) run concurrently with the
+  // small kernels of base t+1 (pairs, hash build, quad enumeration) run concurrently with the
   // LCP scoring of base t instead of leaving most of the 256 CUs idle between them.
   struct Lane {
     hipStream_t stream = nullptr;

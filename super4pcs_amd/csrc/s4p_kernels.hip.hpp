@@ -88,8 +88,9 @@ struct LcpGrid {
 };
 
 // S4P_EXACT_DUAL = 1: the exact stage takes 128 queued queries at a time, two per lane, so that two point lists are in
-// flight per lane (the stage is latency bound: ~14 dependent gathers per batch); the sweep then
-// takes two chunks per step so that the longer queue still fits the LDS budget.
+// flight per lane (every batch runs for as many dependent steps as its longest list; two lists per lane halve the steps
+// per query); the sweep then takes two chunks per step so that the longer queue still fits the
+// LDS budget.
 #ifndef S4P_EXACT_DUAL
 #define S4P_EXACT_DUAL 1          // measured: k_verify 0.161 -> 0.151 ms alone, 69.5 -> 70.7 M candidates/s with three lanes
 #endif
@@ -306,8 +307,7 @@ __global__ __launch_bounds__(256) void k_build_masks(MaskParams P) {
 //     the cell among the reachable ones};
 //   exact stage whenever 128 entries wait (and once at the end): TWO entries per lane -- the candidate's exact 3x4, list
 //     headers, 4x4x4 sub-cell masks, then the exact predicate sqdist <= delta^2 (kdtree.h:417-421) against the listed
-//     points, both lists advancing together with four 16-byte loads in flight per lane and dependent step (the stage is
-//     latency bound; two lists per lane halve its dependent steps per query).
+//     points, both lists advancing together with four 16-byte loads in flight per lane and dependent step.
 // The sampled-Q points the SWEEP reads live in LDS, quantised to 3 x 16 bit over Q's bounding box (8 B per query, 16 KB
 // for n_Q = 2000): the 32 KB float array that every wave re-streamed for every candidate through a 32 KB L1 it shares
 // with the gathers is gone from the sweep (-18 % L1 accesses).  The sweep only LOCATES a query; the quantisation moves it
@@ -315,11 +315,13 @@ __global__ __launch_bounds__(256) void k_build_masks(MaskParams P) {
 // the exact float query for the inlier predicate, and uses the SAME quantised value for the cell, so both stages
 // agree bit for bit.  Clouds whose sample does not fit (n_Q > kLdsQueries) or whose extent needs more than 16 bits keep
 // the float array in global memory (QLDS = false).
-// What the round-2 measurements say about this kernel (profiles/r02_*): the sweep is instruction-
-// issue bound (57 -> 50 instructions per 64 queries); the exact stage is latency bound (~14 dependent gathers per batch
-// at ~1 us each under load, 8 waves per SIMD cannot cover them); software-pipelining the sweep, flattening the exact
-// stage into (query, point) pairs or 4-point items, finer work units and a queue persisting across candidates were all
-// built, verified bit-exact and measured slower or equal -- they are documented there, not kept here.
+// What the round-2 measurements say about this kernel (profiles/r02_*): it is VALU-issue bound first
+// (the vector pipes are busy 55 % of a launch: ~3200 instructions per candidate, half of them the sweep at 50 per 64
+// queries, most of the rest the exact stage at ~70 per step of four point tests) and waits on its gathers second.
+// Software-pipelining the sweep, flattening the exact stage into (query, point) pairs or 4-point items, finer work units,
+// a queue persisting across candidates and 4-byte packed point records (a third of the walk's loads, more instructions
+// per point) were all built, verified bit-exact and measured slower or equal -- they are documented there, not kept
+// here.  What did help: list starts on 128-byte lines, 768-thread workgroups, two lists per lane.
 // ---------------------------------------------------------------------------
 constexpr int kLdsQueries = 2560;                  // sampled-Q points that fit the LDS copy (20 KB)
 
