@@ -804,13 +804,13 @@ __device__ __forceinline__ void prep2_item(const PrepParams& P, const uint32_t e
 
 // Stand-alone preparation of two uploaded pair lists (s4p_find_congruent): blockIdx.y == 0 -> set 1, 1 -> set 2.
 // The fused path (s4p_try_base*) prepares every pair inside k_pairs, where it is produced.
-// set 2, EIGHT lanes per pair: the <= 56 cone samples of a pair (normalset.hpp:186-196) are independent, lane s of the
-// group takes samples s, s + 8, ...; the 343-bit mask is OR-ed together in the group's 11 LDS words.  Same arithmetic per
-// sample as prep2_item, so the same mask.  Why eight: a thread per pair ran the 56 samples (~150 instructions each, with
-// their square roots and divisions) as one dependent chain on ~400 waves -- 43 us for ~25 k pairs with most SIMDs empty; a
-// wave per pair would repeat the ~450-instruction set-up 64 times over; groups of eight keep the total work where it was
-// and put ~3 waves on every SIMD.
-constexpr uint32_t kPrepGroup = 8;
+// set 2, FOUR lanes per pair: the <= 56 cone samples of a pair (normalset.hpp:186-196) are independent, lane s of the
+// group takes samples s, s + 4, ...; the 343-bit mask is OR-ed together in the group's 11 LDS words.  Same buckets as
+// prep2_item, so the same mask.  Why a small group: a thread per pair runs the 56 samples as one dependent chain on too
+// few waves (43 us per base, most SIMDs empty); a wave per pair repeats the ~450-instruction set-up 64 times over.  With
+// a base's ~150 k pairs the launch is VALU-throughput bound, and per pair a group of g lanes costs (450 + 57/g x sample) / (64/g)
+// wave-instructions: four lanes keep that within a quarter of the one-lane minimum and still put 9 k waves on the chip.
+constexpr uint32_t kPrepGroup = 4;
 __device__ __forceinline__ void prep2_group(const PrepParams& P, const uint32_t e, const bool live, const int2 ab, uint32_t* gmask) {
   const uint32_t sub = threadIdx.x & (kPrepGroup - 1u);
   float q[4] = {1.f, 0.f, 0.f, 0.f};
@@ -830,32 +830,43 @@ __device__ __forceinline__ void prep2_group(const PrepParams& P, const uint32_t 
     normalize3(qnx, qny, qnz);                          // queryn = (p2-p1).normalized()            super4pcs.cc:144
     quat_from_z_to(qnx, qny, qnz, q);                   // setFromTwoVectors normalises it again    normalset.hpp:181
   }
+  // Only the BUCKET of a rotated, normalised cone sample is needed: int((x / 2 + 0.5) / neps) per axis.  The exact
+  // sequence -- the quaternion product as Eigen writes it, a square root and six correctly rounded divisions -- is ~150
+  // instructions per sample.  The fast path rotates with the quaternion's 3x3 matrix (9 fma; equal to the exact product
+  // to ~1e-7), does not normalise (the rotated vector is unit to rounding) and multiplies by 1/neps: with
+  // | |d|^2 - 1 | < 1e-4 its bucket coordinates differ from the exact ones by < 2e-4 (measured < 2e-5,
+  // tests/test_prep_bucket_fast_path.py), so if every coordinate lies further than 4e-4 from an integer the truncations
+  // agree; otherwise (0.2 % of the samples) the exact sequence runs.
   const float inv_neps = 1.0f / P.qg.nepsilon;
-  gmask[sub] = 0u; gmask[sub + kPrepGroup] = 0u;        // 16 words per group, 11 used
+  float R[9];
+  { const float w = q[0], x = q[1], y = q[2], z = q[3];
+    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, xz = x * z, yz = y * z, wx = w * x, wy = w * y, wz = w * z;
+    R[0] = 1.f - 2.f * (yy + zz); R[1] = 2.f * (xy - wz); R[2] = 2.f * (xz + wy);
+    R[3] = 2.f * (xy + wz); R[4] = 1.f - 2.f * (xx + zz); R[5] = 2.f * (yz - wx);
+    R[6] = 2.f * (xz - wy); R[7] = 2.f * (yz + wx); R[8] = 1.f - 2.f * (xx + yy); }
+#pragma unroll
+  for (uint32_t w = sub; w < 16u; w += kPrepGroup) gmask[w] = 0u;        // 16 words per group, 11 used
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
   if (live) {
     for (int a = int(sub); a < P.cone.nb; a += int(kPrepGroup)) {
       const float vx = P.cone.v[a][0], vy = P.cone.v[a][1], vz = P.cone.v[a][2];
-      float ux_, uy_, uz_;
-      cross3(q[1], q[2], q[3], vx, vy, vz, ux_, uy_, uz_);            // QuaternionBase::_transformVector
-      ux_ += ux_; uy_ += uy_; uz_ += uz_;
-      float cx, cy, cz;
-      cross3(q[1], q[2], q[3], ux_, uy_, uz_, cx, cy, cz);
-      float dx = (vx + q[0] * ux_) + cx, dy = (vy + q[0] * uy_) + cy, dz = (vz + q[0] * uz_) + cz;
-      // Only the bucket of the normalised direction is needed: int((x / 2 + 0.5) / neps) per axis after x /= |d| -- a
-      // square root and six correctly rounded divisions, 2/3 of the sample's instructions.  The rotated vector is unit
-      // to rounding already, so the bucket coordinates are first computed WITHOUT normalising and with one multiply by
-      // 1/neps: with | |d|^2 - 1 | < 1e-4 they differ from the exact ones by < 2e-4, so if every coordinate lies further
-      // than 4e-4 from an integer the truncations agree; otherwise (0.2 % of the samples) the exact sequence runs.
-      uint32_t id;
-      const float t0 = __builtin_fmaf(dx, 0.5f, 0.5f) * inv_neps, t1 = __builtin_fmaf(dy, 0.5f, 0.5f) * inv_neps,
-                  t2 = __builtin_fmaf(dz, 0.5f, 0.5f) * inv_neps;
+      const float fx = __builtin_fmaf(R[0], vx, __builtin_fmaf(R[1], vy, R[2] * vz)), fy = __builtin_fmaf(R[3], vx, __builtin_fmaf(R[4], vy, R[5] * vz)),
+                  fz = __builtin_fmaf(R[6], vx, __builtin_fmaf(R[7], vy, R[8] * vz));
+      const float t0 = __builtin_fmaf(fx, 0.5f, 0.5f) * inv_neps, t1 = __builtin_fmaf(fy, 0.5f, 0.5f) * inv_neps,
+                  t2 = __builtin_fmaf(fz, 0.5f, 0.5f) * inv_neps;
       const float f0 = __builtin_amdgcn_fractf(t0), f1 = __builtin_amdgcn_fractf(t1), f2 = __builtin_amdgcn_fractf(t2);
       const float edge = fminf(fminf(fminf(f0, 1.f - f0), fminf(f1, 1.f - f1)), fminf(f2, 1.f - f2));
-      const float n2 = __builtin_fmaf(dx, dx, __builtin_fmaf(dy, dy, dz * dz));
+      const float n2 = __builtin_fmaf(fx, fx, __builtin_fmaf(fy, fy, fz * fz));
+      uint32_t id;
       if (fabsf(n2 - 1.f) < 1e-4f && edge > 4e-4f) {
         id = uint32_t(int(t2) * 49 + int(t1) * 7 + int(t0));
       } else {
+        float ux_, uy_, uz_;
+        cross3(q[1], q[2], q[3], vx, vy, vz, ux_, uy_, uz_);            // QuaternionBase::_transformVector
+        ux_ += ux_; uy_ += uy_; uz_ += uz_;
+        float cx, cy, cz;
+        cross3(q[1], q[2], q[3], ux_, uy_, uz_, cx, cy, cz);
+        float dx = (vx + q[0] * ux_) + cx, dy = (vy + q[0] * uy_) + cy, dz = (vz + q[0] * uz_) + cz;
         normalize3(dx, dy, dz);
         id = index_normal(dx, dy, dz, P.qg.nepsilon);
       }
@@ -864,8 +875,8 @@ __device__ __forceinline__ void prep2_group(const PrepParams& P, const uint32_t 
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
   if (live) {
-    P.mask[size_t(e) * kMaskWords + sub] = gmask[sub];
-    if (sub + kPrepGroup < uint32_t(kMaskWords)) P.mask[size_t(e) * kMaskWords + sub + kPrepGroup] = gmask[sub + kPrepGroup];
+#pragma unroll
+    for (uint32_t w = sub; w < uint32_t(kMaskWords); w += kPrepGroup) P.mask[size_t(e) * kMaskWords + w] = gmask[w];
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
 }

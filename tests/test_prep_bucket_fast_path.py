@@ -31,9 +31,20 @@ def test_fast_bucket_equals_exact_bucket_wherever_it_is_taken():
     # exact sequence: normalize3, then index_normal
     s = np.sqrt(dx * dx + (dy * dy + dz * dz))
     ex = [((c / s) / F(2.0) + F(0.5)) / neps for c in (dx, dy, dz)]
-    # fast sequence: one fused multiply-add and one multiply by 1 / neps
+    # fast sequence: rotation by the quaternion's 3x3 matrix (float32 entries, fused multiply-adds), one fused
+    # multiply-add and one multiply by 1 / neps
     inv = F(1.0) / neps
-    fa = [(c.astype(np.float64) * 0.5 + 0.5).astype(F) * inv for c in (dx, dy, dz)]
+    w_, x_, y_, z_ = q0, q1, q2, q3
+    xx, yy, zz, xy, xz, yz, wx, wy, wz = x_ * x_, y_ * y_, z_ * z_, x_ * y_, x_ * z_, y_ * z_, w_ * x_, w_ * y_, w_ * z_
+    R = [F(1) - F(2) * (yy + zz), F(2) * (xy - wz), F(2) * (xz + wy),
+         F(2) * (xy + wz), F(1) - F(2) * (xx + zz), F(2) * (yz - wx),
+         F(2) * (xz - wy), F(2) * (yz + wx), F(1) - F(2) * (xx + yy)]
+
+    def fma(a, b, c):
+        return (a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64)).astype(F)
+    fx = fma(R[0], vx, fma(R[1], vy, R[2] * vz)); fy = fma(R[3], vx, fma(R[4], vy, R[5] * vz)); fz = fma(R[6], vx, fma(R[7], vy, R[8] * vz))
+    fa = [(c.astype(np.float64) * 0.5 + 0.5).astype(F) * inv for c in (fx, fy, fz)]
+    dx, dy, dz = fx, fy, fz                                       # (the norm check below is on the fast vector)
     worst = max(float(np.max(np.abs(a.astype(np.float64) - b.astype(np.float64)))) for a, b in zip(ex, fa))
     assert worst < 2e-5, worst                                   # the kernel's margin assumes < 2e-4
     n2 = (dx.astype(np.float64) ** 2 + dy.astype(np.float64) ** 2 + dz.astype(np.float64) ** 2)
