@@ -611,7 +611,7 @@ int32_t s4p_set_clouds(s4p_ctx* c, const float* px, const float* py, const float
   c->hqx.assign(qx, qx + n_q); c->hqy.assign(qy, qy + n_q); c->hqz.assign(qz, qz + n_q);
   c->frame.build(c->hqx, c->hqy, c->hqz, c->hux, c->huy, c->huz);
   c->tree.reset(c->n_q);
-  float cell_factor = 1.002f;
+  float cell_factor = LcpGridHost::kMinCellFactor;
   if (const char* cf = getenv("S4P_CELL_FACTOR")) cell_factor = float(atof(cf));      // tuning knob: LCP cell edge / delta
   if (!c->hgrid.plan(c->hpx, c->hpy, c->hpz, c->opt.delta, c->max_grid_cells, kCoarseMaxWords, cell_factor)) S4P_FAIL(c, S4P_ERR_STATE, "LCP grid planning failed");
   {  // device build of the LCP structure (counting formulation, see k_grid_* in s4p_kernels.hip.hpp)

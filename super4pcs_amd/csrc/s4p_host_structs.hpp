@@ -400,6 +400,7 @@ class FourthPointIndex {
 // ---------------------------------------------------------------------------
 // Dimensioning of the LCP grid (the structure itself is built on the device, s4p_kernels.hip.hpp k_grid_*).
 struct LcpGridHost {
+  static constexpr float kMinCellFactor = 1.02f;
   float ox = 0, oy = 0, oz = 0, h = 1, inv_h = 1;
   int nx = 1, ny = 1, nz = 1;
   int cshift = 0, cnx = 1, cny = 1, cnz = 1;
@@ -407,11 +408,16 @@ struct LcpGridHost {
   double reach = 0;                         // 1.01 * delta
   uint64_t ncell() const { return uint64_t(nx) * uint64_t(ny) * uint64_t(nz); }
 
-  // Cell edge h >= 1.002*delta.  A query q is mapped to cell floor((q-o)*inv_h) in float; a P point p with
-  // |q-p| <= delta then satisfies dist(p, box(cell)) <= delta + rounding slack, so it is listed for that cell by the
-  // 1.01*delta reach test (slack 1e-2*delta >> float rounding of the cell map).  One cell of padding on every side.
+  // Cell edge h >= 1.02 * delta.  The sweep LOCATES a query approximately: cell = floor of a fused-multiply-add transform
+  // of the query quantised to 16 bit (at most 0.004 cell per axis, s4p_set_clouds), i.e. up to e = 0.007 cell away from
+  // the cell of the exactly transformed query.  A P point p with |q - p| <= delta must still be in the list of the LOCATED
+  // cell c.  (i) Lists hold the points within 1.01 * delta of the cell's box: dist(p, box(c)) <= delta + e h < 1.0072
+  // delta.  (ii) The lists are built from each point's 27-cell neighbourhood only, so p's own cell must be a neighbour of c:
+  // p is at most delta + e h from box(c), which is less than one cell iff h (1 - e) >= delta, i.e. h >= 1.007 delta.
+  // With the former 1.002 an inlier at distance ~delta straight across a cell face could land two cells from the located
+  // cell and be missed (8 of 127 902 in tools/probe_locate_slack.py; tests/test_gpu_kernels.py holds that case now).
   bool plan(const std::vector<float>& px, const std::vector<float>& py, const std::vector<float>& pz,
-            float delta, uint64_t max_cells, uint32_t max_coarse_words, float cell_factor = 1.002f) {
+            float delta, uint64_t max_cells, uint32_t max_coarse_words, float cell_factor = kMinCellFactor) {
     const size_t n = px.size();
     if (n == 0) return false;
     float lo[3] = {px[0], py[0], pz[0]}, hi[3] = {px[0], py[0], pz[0]};
@@ -420,7 +426,7 @@ struct LcpGridHost {
       lo[1] = std::min(lo[1], py[i]); hi[1] = std::max(hi[1], py[i]);
       lo[2] = std::min(lo[2], pz[i]); hi[2] = std::max(hi[2], pz[i]);
     }
-    h = delta * (cell_factor >= 1.002f ? cell_factor : 1.002f);
+    h = delta * (cell_factor >= kMinCellFactor ? cell_factor : kMinCellFactor);
     if (!(h > 0.f)) return false;
     while (true) {
       const double ex = (double(hi[0]) - lo[0]) / h, ey = (double(hi[1]) - lo[1]) / h, ez = (double(hi[2]) - lo[2]) / h;

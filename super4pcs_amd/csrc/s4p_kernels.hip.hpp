@@ -64,7 +64,7 @@ struct DevCounters {
 
 // ---------------------------------------------------------------------------
 // LCP structure over sampled P  (replaces kd_tree_, match4pcsBase.cc:353-363).
-// Uniform grid of edge h >= 1.002*delta, three levels, all conservative supersets of the
+// Uniform grid of edge h >= 1.02*delta (LcpGridHost::plan says why), three levels, all conservative supersets of the
 // exact predicate "some P point with fl(dx^2+(dy^2+dz^2)) <= fl(delta^2)" (kdtree.h:417-421):
 //   L0  coarse bitmap (OR of 2^s-cubes of the reach bitmap), <= 48 KB, staged in LDS;
 //   L1  reach bitmap: bit(c) = some P point lies within 1.01*delta of the box of cell c,

@@ -216,3 +216,46 @@ def test_gpu_sampler_equals_host_and_oracle(oracle_mod, s4p_lib_built, monkeypat
     # coordinates whose voxel index does not fit the 21-bit device key fall back to the host path, same answer
     Y = (X[:40000] * np.float32(1e7)).astype(np.float32)
     assert np.array_equal(Y[capi.uniform_dist_sample(Y, 0.004)], oracle_mod.sample(Y, 0.004))
+
+
+def test_quantised_locate_cannot_lose_an_inlier_at_distance_delta(s4p_lib_built):
+    """Adversarial case for the LCP structure's locating slack (LcpGridHost::plan): queries quantised to 16 bit over a long
+    bounding box (half a quantisation step = 0.0039 cell, the largest the LDS path accepts), every query exactly one P point
+    at distance delta (1 - 1e-6) straight along -x, 64 transforms that move the pairs across the cell faces.  A query that
+    the quantised locate puts into the cell next to its true one must still find its point: counts equal a brute-force
+    float32 count.  (With cells of 1.002 delta this lost 8 inliers of 127 902.)"""
+    from super4pcs_amd import capi
+    F = np.float32
+    delta, n = 1.0, 2000
+    rng = np.random.default_rng(5)
+    h = 1.002 * delta
+    ext = 0.0078 * h * 65535.0
+    Q = np.stack([rng.uniform(0, ext, n), rng.uniform(0, 3, n), rng.uniform(0, 3, n)], axis=1).astype(F)
+    Q[0, 0], Q[1, 0] = 0.0, ext
+    Ts, Ps = [], []
+    for k in range(64):
+        T = np.eye(4, dtype=F)
+        T[0, 3] = F(0.0137 * k); T[1, 3] = F(5.0 * k)
+        Ts.append(T)
+        Pk = Q.astype(np.float64).copy()
+        Pk[:, 0] += float(T[0, 3]) - delta * (1 - 1e-6)
+        Pk[:, 1] += float(T[1, 3])
+        Ps.append(Pk.astype(F))
+    Ts = np.stack(Ts)
+    P = np.concatenate(Ps)
+    want = []
+    for T in Ts:
+        tx = ((T[0, 0] * Q[:, 0] + T[0, 1] * Q[:, 1]) + T[0, 2] * Q[:, 2]) + T[0, 3]
+        ty = ((T[1, 0] * Q[:, 0] + T[1, 1] * Q[:, 1]) + T[1, 2] * Q[:, 2]) + T[1, 3]
+        tz = ((T[2, 0] * Q[:, 0] + T[2, 1] * Q[:, 1]) + T[2, 2] * Q[:, 2]) + T[2, 3]
+        near = P[np.abs(P[:, 1] - T[1, 3] - 1.5) < 4.0]
+        cnt = 0
+        for i in range(n):
+            dx, dy, dz = tx[i] - near[:, 0], ty[i] - near[:, 1], tz[i] - near[:, 2]
+            cnt += bool(((dx * dx + (dy * dy + dz * dz)) <= F(delta) * F(delta)).any())
+        want.append(cnt)
+    ctx = capi.Context(capi.make_options(delta, 0.5, n), max_pairs=1 << 16, max_quads=1 << 16)
+    ctx.set_clouds(P, Q)
+    got = ctx.verify_transforms(Ts)
+    assert sum(want) > 120000
+    assert np.array_equal(got.astype(np.int64), np.array(want, np.int64))
