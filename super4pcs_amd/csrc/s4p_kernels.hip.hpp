@@ -694,6 +694,7 @@ struct HashTable {
 // derive the same mask from the same device counter; entries of earlier epochs, wherever they lie, read as empty.
 __device__ __forceinline__ uint32_t hash_mask(const HashTable& ht) {
   const uint32_t m = min(*ht.m1_dev, ht.cap1);
+  if (m > (ht.mask >> 2)) return ht.mask;                 // (also keeps 4 * m inside 32 bits)
   const uint32_t want = max(4u * m, 4096u);
   const uint32_t size = 1u << (32 - __clz(int(want - 1u)));
   return min(size - 1u, ht.mask);
