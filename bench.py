@@ -404,6 +404,7 @@ def main():
     kbar = pk.verify_point_tests / queries
     f_l0, f_l1, f_l2 = pk.verify_l0_pass / queries, pk.verify_l1_pass / queries, pk.verify_l2_pass / queries
     m.profile_enable(False, False)
+    final_info = m.info()                       # state after the last repeat's windows (N > 1: compared across ranks below)
     m.close()
 
     # time-to-register (the metric's second half): one whole ComputeTransformation on the same pair, wall time from
@@ -435,6 +436,38 @@ def main():
             if recount != ttr["best_count"]:
                 parity["mismatches"] += 1
                 parity.setdefault("failed", []).append("time-to-register: final LCP %d != oracle recount %d" % (ttr["best_count"], recount))
+
+    # N > 1: the sharded loop must leave every rank with the state the sequential loop reaches after the same trials.
+    # All ranks' states are compared with each other and with a sequential single-GPU replay on rank 0 (which is the
+    # path the N = 1 parity gate checks against the oracle).
+    if world > 1 and args.parity:
+        gi = final_info
+        mine = np.concatenate([[gi.current_trial, gi.best_count], np.frombuffer(np.float32(gi.best_lcp).tobytes(), np.uint32),
+                               np.frombuffer(np.array(gi.transform, np.float32).tobytes(), np.uint32),
+                               np.array(gi.base, np.int64), np.array(gi.congruent, np.int64)]).astype(np.int64)
+        mt = torch.tensor(mine, dtype=torch.int64, device=dev)
+        allt = [torch.zeros_like(mt) for _ in range(world)]
+        dist.all_gather(allt, mt)
+        if rank == 0:
+            states = [t.cpu().numpy() for t in allt]
+            failed = ["rank %d ends in a different state than rank 0" % r for r in range(1, world) if not np.array_equal(states[r], states[0])]
+            trials = (args.warmup + args.steps + 2) * world      # the last repeat's windows + the two instrumented ones above
+            seq = capi.Matcher(opt, device=local_rank, max_pairs=MAX_PAIRS, max_quads=MAX_QUADS)
+            seq.init_full(P, Q)
+            for _ in range(trials):                               # TryOneBase, one after the other: no stop rule, like run_windows
+                seq.try_one_base()
+            si = seq.info()
+            same = (si.best_count == gi.best_count and si.best_lcp == gi.best_lcp
+                    and list(si.transform) == list(gi.transform) and list(si.base) == list(gi.base) and list(si.congruent) == list(gi.congruent))
+            if not same:
+                failed.append("sharded state != sequential single-GPU replay of %d trials (LCP %r vs %r)" % (trials, gi.best_lcp, si.best_lcp))
+            seq.close()
+            parity = {"what": "N > 1: every rank's final state (trial count, best LCP, 4x4, winning base and quad) equal across ranks and "
+                              "equal to a sequential single-GPU replay of the same %d trials on rank 0; the sequential path is the one the "
+                              "N = 1 gate checks against the oracle" % trials,
+                      "trials": trials, "ranks": world, "mismatches": len(failed)}
+            if failed:
+                parity["failed"] = failed
 
     traffic, traffic_note = None, "skipped"
     if rank == 0 and world == 1 and args.pmc:
