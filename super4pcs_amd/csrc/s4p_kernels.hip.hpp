@@ -1311,10 +1311,15 @@ __global__ __launch_bounds__(kVerifyMaxThreads, 8) void k_verify(VerifyParams P)
   __shared__ unsigned long long s_wtag[kVerifyMaxThreads / 64];
   const uint32_t C = P.ctr->C;
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  // Work split: every workgroup owns a contiguous slice of the gated candidate list (static: a single-address global
-  // cursor caps at ~90 dequeues/us, MI355X_MICROARCH "dequeue"); inside the slice its 16 waves take candidates from an
-  // LDS counter, so a wave that drew cheap candidates (few L0 survivors) simply takes more.
-  const uint32_t lo = uint32_t((uint64_t(C) * blockIdx.x) / gridDim.x), hi = uint32_t((uint64_t(C) * (blockIdx.x + 1u)) / gridDim.x);
+  // Work split: every workgroup owns a fixed share of the gated candidate list (static: a single-address global cursor
+  // caps at ~90 dequeues/us, MI355X_MICROARCH "dequeue"); inside the share its waves take candidates from an LDS
+  // counter, so a wave that drew cheap candidates (few L0 survivors) simply takes more.
+  // Share of this workgroup: candidates blockIdx.x, blockIdx.x + gridDim.x, ...  Neighbours in the candidate order are
+  // neighbours in quad order and cost about the same, so contiguous slices made some workgroups consistently slower than
+  // others, and the launch ends with its slowest workgroup (0.145 -> 0.136 ms alone with the strided share).  A global
+  // counter for the tail of the list was tried on top and is not here: even ~8000 single-address atomics per launch cost
+  // more than the imbalance they remove (0.136 -> 0.172 ms).
+  const uint32_t lo = 0u, hi = blockIdx.x < C ? (C - blockIdx.x + gridDim.x - 1u) / gridDim.x : 0u;
   uint32_t bc = 0, bi = kNil; unsigned long long bt = ~0ull;                // this wave's / thread's best
   if (lo < hi && P.ablate != 2) {                          // (uniform) otherwise: more workgroups than candidates
     if (threadIdx.x == 0) s_next = lo;
@@ -1327,6 +1332,7 @@ __global__ __launch_bounds__(kVerifyMaxThreads, 8) void k_verify(VerifyParams P)
       if (lane == 0) i = atomicAdd(&s_next, 1u);
       i = uint32_t(__builtin_amdgcn_readfirstlane(int(i)));
       if (i >= hi) break;
+      i = blockIdx.x + i * gridDim.x;
       const float4* src = P.cand_T + 3 * size_t(i);         // one candidate per wave
       const uint32_t cnt = P.ablate == 1 ? wave_lcp_count<COUNT, true, QLDS>(P.grid, K, s_coarse, s_q, s_queue, src)
                                          : wave_lcp_count<COUNT, false, QLDS>(P.grid, K, s_coarse, s_q, s_queue, src);

@@ -1,0 +1,35 @@
+#!/bin/bash
+# round 2, pass 41: final pass of round 2 (strided k_verify shares)
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+R=$PWD
+echo "== full pytest -m gpu"
+timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -8 | tee gpurun_out/r2_pytest41.log
+echo "== smoke"
+timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
+echo "== bench"
+timeout 1200 python bench.py > gpurun_out/r2_bench41.json 2> gpurun_out/r2_bench41.err
+tail -c 600 gpurun_out/r2_bench41.err
+echo "== rocprof stats of the bench command"
+cd /tmp
+timeout 900 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/r2stats41_bench -o r --output-format csv -- python $R/bench.py --repeats 1 --cpu-seconds 0 --no-parity --no-pmc --no-hbm-point --no-time-to-register > $R/gpurun_out/r2stats41_bench.log 2>&1
+S4P_LANES=1 timeout 900 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/r2stats41_bench_l1 -o r --output-format csv -- python $R/bench.py --repeats 1 --cpu-seconds 0 --no-parity --no-pmc --no-hbm-point --no-time-to-register > $R/gpurun_out/r2stats41_bench_l1.log 2>&1
+cd $R
+python - <<'PY'
+import json, csv, glob
+try:
+    d=json.load(open('gpurun_out/r2_bench41.json'))
+    print({k:d[k] for k in ('value','ms_per_step','spread')}, d['parity']['mismatches'])
+    r=d['roofline']; print({k:r[k] for k in ('achieved','frac','traffic','avg_launch_ms')}, r['hbm_bound_point'].get('frac'))
+    print(d['k_apply'])
+    print(d['config']['time_to_register'])
+except Exception as e:
+    print('bench json unreadable', e)
+for f in sorted(glob.glob('gpurun_out/r2stats41_bench*/**/r_kernel_stats.csv', recursive=True)):
+    print(f)
+    for r in list(csv.DictReader(open(f)))[:6]:
+        print('  ', r['Name'][:44], r['Calls'], r['AverageNs'], r['Percentage'])
+for f in ('gpurun_out/r2stats41_bench.log','gpurun_out/r2stats41_bench_l1.log'):
+    print(open(f).read()[-400:])
+PY
