@@ -350,11 +350,30 @@ def main():
             if one_gpu:
                 sh.use_collective(capi.torch_collective(dist))          # single-GPU dry run: gloo through the callback provider
             else:
-                idt = torch.zeros(128, dtype=torch.uint8, device=dev)
-                if rank == 0:
-                    idt.copy_(torch.frombuffer(bytearray(capi.rccl_unique_id()), dtype=torch.uint8))
-                dist.broadcast(idt, src=0)
-                sh.use_rccl(local_rank, idt.cpu().numpy().tobytes())
+                # the library's own communicator (ncclCommInitRank from the id rank 0 made); should RCCL not bind or not
+                # initialise on some rank, every rank falls back to the process group torch already has (same 8-byte
+                # all-reduce per window, through the callback provider)
+                ok = 1
+                try:
+                    idt = torch.zeros(128, dtype=torch.uint8, device=dev)
+                    if rank == 0:
+                        idt.copy_(torch.frombuffer(bytearray(capi.rccl_unique_id()), dtype=torch.uint8))
+                except Exception as e:                          # noqa: BLE001
+                    print("rank %d: ncclGetUniqueId through the library failed (%s)" % (rank, e), file=sys.stderr)
+                    ok = 0
+                flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if int(flag.item()):
+                    dist.broadcast(idt, src=0)
+                    try:
+                        sh.use_rccl(local_rank, idt.cpu().numpy().tobytes())
+                    except Exception as e:                      # noqa: BLE001
+                        print("rank %d: s4p_shard_use_rccl failed (%s)" % (rank, e), file=sys.stderr)
+                        ok = 0
+                    flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+                    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if not int(flag.item()):
+                    sh.use_collective(capi.torch_collective(dist, dev))
         else:
             sh = sharding.ShardedRansac(m, rank, world, dist, dev)      # world 1: the engine's own pipelined Perform_N_steps
         sh.run_windows(warmup)

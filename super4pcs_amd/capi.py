@@ -617,13 +617,14 @@ def _declare_shard(L):
     _SHARD_DECLARED = True
 
 
-def torch_collective(dist):
-    """An s4p_collective whose two operations run over a torch.distributed process group with CPU tensors (gloo): the
-    provider the CPU tests and single-GPU dry runs plug into the C++ loop.  Keep the returned object alive."""
+def torch_collective(dist, device=None):
+    """An s4p_collective whose two operations run over a torch.distributed process group: CPU tensors (gloo) by default --
+    the provider the CPU tests and single-GPU dry runs plug into the C++ loop -- or tensors on `device` for a group whose
+    backend needs them there ("nccl" = RCCL).  Keep the returned object alive."""
     import torch
 
     def allreduce(user, keyp):
-        t = torch.tensor([keyp[0]], dtype=torch.int64)           # keys stay below 2^63
+        t = torch.tensor([keyp[0]], dtype=torch.int64, device=device)           # keys stay below 2^63
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         keyp[0] = int(t.item())
         return 0
@@ -631,8 +632,10 @@ def torch_collective(dist):
     def broadcast(user, buf, nbytes, root):
         arr = (C.c_uint8 * nbytes).from_address(buf)
         t = torch.frombuffer(arr, dtype=torch.uint8).clone()
+        if device is not None:
+            t = t.to(device)
         dist.broadcast(t, src=root)
-        C.memmove(buf, t.numpy().ctypes.data, nbytes)
+        C.memmove(buf, t.cpu().numpy().ctypes.data, nbytes)
         return 0
 
     coll = Collective()
