@@ -298,6 +298,9 @@ def main():
     ap.add_argument("--parity-bases", type=int, default=2)
     ap.add_argument("--no-pmc", dest="pmc", action="store_false", default=True, help="skip the rocprofv3 --pmc passes (roofline.traffic = null)")
     ap.add_argument("--no-hbm-point", dest="hbm_point", action="store_false", default=True)
+    ap.add_argument("--no-exclusive", dest="exclusive", action="store_false", default=True,
+                    help="skip the one-base-in-flight re-run (roofline.exclusive); used for the rocprofv3 kernel-stats run, so "
+                         "that its k_verify rows are the default configuration's launches only")
     ap.add_argument("--inner", action="store_true", help="(used by the --pmc passes) timed region only, no JSON")
     ap.add_argument("--points", type=int, default=N_POINTS)
     ap.add_argument("--sample", type=int, default=SAMPLE)
@@ -518,7 +521,7 @@ def main():
     # With the default number of lanes every launch shares the CUs with the launches of the other lanes, so its HIP-event
     # duration is not the kernel's own time.
     exclusive = None
-    if world == 1 and rank == 0:
+    if world == 1 and rank == 0 and args.exclusive:
         saved = os.environ.get("S4P_LANES")
         os.environ["S4P_LANES"] = "1"
         try:
