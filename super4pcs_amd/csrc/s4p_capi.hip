@@ -471,8 +471,10 @@ int32_t s4p_create(const s4p_options* opt, const s4p_limits* lim, int32_t device
   if (const char* la = getenv("S4P_LIST_ALIGN")) { const int v = atoi(la); if (v == 1 || v == 2 || v == 4 || v == 8) c->list_align = v; }
   if (const char* cs = getenv("S4P_CU_SPLIT")) { const int v = atoi(cs); if (v >= 2 && v <= 64) c->cu_split = v; }
   snprintf(c->devname, sizeof c->devname, "%s (%s)", prop.name, prop.gcnArchName);
-  c->max_pairs = (lim && lim->max_pairs) ? lim->max_pairs : (4ull << 20);
-  c->max_quads = (lim && lim->max_quads) ? lim->max_quads : (16ull << 20);
+  // defaults: 1 Mi pairs per set, 4 Mi quads per base -- 0.45 GB per lane, a context in ~20 ms (4 Mi / 16 Mi took 0.3-0.6 s to
+  // allocate and clear); Perform_N_steps grows them when a base needs more (s4p_grow_limits)
+  c->max_pairs = (lim && lim->max_pairs) ? lim->max_pairs : (1ull << 20);
+  c->max_quads = (lim && lim->max_quads) ? lim->max_quads : (4ull << 20);
   c->max_grid_cells = (lim && lim->max_grid_cells) ? lim->max_grid_cells : (1ull << 27);
   if (c->max_pairs > 0x7FFFFFFFull || c->max_quads > 0x7FFFFFFFull) { g_create_error = "limits exceed 2^31 entries"; delete c; return S4P_ERR_BAD_ARG; }
   for (int k = 0; k < 12; ++k) c->base_rgb[k] = -1.f;
