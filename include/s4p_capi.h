@@ -73,7 +73,15 @@ typedef struct {
   float    best_transform[16];  /* row-major, centred frame (transform_)                  */
   float    best_centroid2[3];   /* qcentroid2_                                            */
   float    centroid1[3];        /* qcentroid1_                                            */
+  /* Order-independent checksums of the fused device pass: sum over every congruent quad (a,b,c,d) of s4p_quad_mix(a,b,c,d)
+   * mod 2^64, and the same sum over the quads that passed the rms gate (the verified candidates).  They let a base be
+   * compared with the reference at sizes where the lists themselves (10^9 quads at a 20 000-point sample) cannot be. */
+  uint64_t quad_checksum;
+  uint64_t cand_checksum;
 } s4p_base_result;
+
+/* The checksum term: a 64-bit mix of the four sampled-Q indices of a quad (host-callable; tests and the oracle use it). */
+uint64_t s4p_quad_mix(int32_t a, int32_t b, int32_t c, int32_t d);
 
 /* ---- lifecycle ------------------------------------------------------------ */
 int32_t s4p_create(const s4p_options* opt, const s4p_limits* limits /*nullable*/, int32_t device, s4p_ctx** out);
@@ -81,12 +89,29 @@ void    s4p_destroy(s4p_ctx* ctx);
 const char* s4p_last_error(const s4p_ctx* ctx);   /* ctx may be NULL: last create error */
 int32_t s4p_device_name(const s4p_ctx* ctx, char* buf, int32_t buflen);
 
-/* Raises the pair / quad capacities to at least min_pairs / min_quads (0 = the counts of the base whose overflow was
- * reported last) with head-room, reallocating the per-base device buffers of every lane; nothing may be in flight.
- * Refused with S4P_ERR_CAPACITY (limits unchanged) if the buffers would take more than 60 % of the device memory.
- * s4p_get_limits reports the capacities in force. */
+/* Device buffer capacities follow the data, as the reference's std::vectors do (super4pcs.cc:166-174, :196,
+ * match4pcsBase.hpp:340-351):
+ *  - a fused pass (s4p_try_base*, and everything built on it) whose PAIR lists overflow a lane's buffers grows that lane
+ *    to what the base's own counters ask for (+25 %, at least double) and runs the base again, inside the wait -- no other
+ *    lane and no host state is involved;
+ *  - a base whose congruent QUADS do not fit (at the "GPU-scale" sample of 20 000 points a base has ~10^9) is processed in
+ *    CHUNKS: ranges of the second pair set are enumerated into the quad buffers, gated, LCP-scored and folded one after
+ *    the other with the reference's first-maximum rule, so winner, best count, n_quads, n_verified and the checksums are
+ *    those of an unbounded pass; afterwards the lane's quad buffers grow towards grow_cap_quads (default 32 Mi entries)
+ *    so that later bases of that size take one pass.  Only the per-candidate records (s4p_last_candidates /
+ *    s4p_last_verified) are not available for a chunked base (S4P_ERR_UNSUPPORTED).
+ * Growth is refused (S4P_ERR_CAPACITY, loudly) when the lanes together would take more than 60 % of the device memory.
+ * s4p_set_auto_grow(0) / s4p_set_quad_chunking(0, ..) restore the strict contract of the stage-level entry points: an
+ * overflowing base fails with S4P_ERR_CAPACITY.  s4p_chunk_stats: {chunked bases, chunk passes, range splits, quads of
+ * chunked bases}; s4p_lane_growths: regrowths so far; s4p_get_limits: the largest capacities in force on any lane.
+ * s4p_grow_limits raises every lane to at least min_pairs / min_quads (0 = what the last overflow reported) up front;
+ * nothing may be in flight. */
 int32_t s4p_grow_limits(s4p_ctx* ctx, uint64_t min_pairs, uint64_t min_quads);
 int32_t s4p_get_limits(const s4p_ctx* ctx, s4p_limits* out);
+int32_t s4p_set_auto_grow(s4p_ctx* ctx, int32_t enable);
+int64_t s4p_lane_growths(const s4p_ctx* ctx);
+int32_t s4p_set_quad_chunking(s4p_ctx* ctx, int32_t enable, uint64_t grow_cap_quads);
+int32_t s4p_chunk_stats(const s4p_ctx* ctx, uint64_t* out4);
 
 /* ---- state ---------------------------------------------------------------- */
 /* Uploads the sampled, centred clouds and builds the device structures.

@@ -131,12 +131,13 @@ int32_t s4p_matcher_visit_candidates(s4p_matcher* m, int32_t enable);
 int32_t s4p_matcher_set_device_selection(s4p_matcher* m, int32_t mode);
 int32_t s4p_matcher_device_selection(const s4p_matcher* m);
 
-/* Device buffer capacities (s4p_limits) inside s4p_matcher_perform_n_steps / _compute_transformation: when a base has more
- * pairs or quads than the buffers hold, the speculation is rolled back to just before that base, the buffers are grown to
- * what the base's own counters ask for (s4p_grow_limits) and the loop resumes with the same base -- same trials and
- * results as with limits that were large enough from the start (the reference's std::vector simply grows).  On by default;
- * with enable == 0, or when the growth is refused (more than 60 % of the device memory), the call fails with
- * S4P_ERR_CAPACITY as the stage-level entry points always do.  s4p_matcher_capacity_growths counts the regrowths. */
+/* Device buffer capacities (s4p_limits): when a base has more pairs than a lane's buffers hold, that lane grows them to
+ * what the base's own counters ask for and runs the base again inside the wait; a base with more congruent quads than fit
+ * is processed in chunks (s4p_capi.h, "Device buffer capacities follow the data") -- same trials and results as with
+ * limits that were large enough from the start (the reference's std::vector simply grows).  On by default, in the
+ * sequential and in the sharded loops; with enable == 0, or when growth is refused (more than 60 % of the device memory),
+ * the call fails with S4P_ERR_CAPACITY as the stage-level entry points always do.  s4p_matcher_capacity_growths counts
+ * the regrowths. */
 int32_t s4p_matcher_grow_on_overflow(s4p_matcher* m, int32_t enable);
 int32_t s4p_matcher_capacity_growths(const s4p_matcher* m);
 
@@ -153,6 +154,9 @@ int32_t s4p_matcher_compute_transformation(s4p_matcher* m, const s4p_cloud_view*
 /* opt.terminate_threshold of the matcher (the sharded loop needs it to rank "crossed the threshold" outcomes). */
 float s4p_matcher_terminate_threshold(const s4p_matcher* m);
 int32_t s4p_matcher_max_time_seconds(const s4p_matcher* m);
+/* Number of s4p_matcher_init / _init_full calls so far: drivers that keep per-registration state (the sharded loop's
+ * "terminated" flag, trial counters) reset it when this changes. */
+int64_t s4p_matcher_init_generation(const s4p_matcher* m);
 
 /* ---- multi-GPU: bases sharded over the GPUs of one node, one process per GPU ------------------
  * Every rank walks the same base sequence; rank (t mod world) runs the device pass of trial t; after each window of
@@ -183,7 +187,9 @@ int32_t s4p_shard_run_windows(s4p_shard* s, int32_t n_windows, uint64_t* candida
  * called by every rank with the same clouds. */
 int32_t s4p_shard_compute_transformation(s4p_shard* s, const s4p_cloud_view* P, const s4p_cloud_view* Q,
                                          float* qx_out, float* qy_out, float* qz_out, float* transformation, float* lcp);
-/* Host-only self-check of the window loop on recorded outcomes (no matcher, no GPU): the CPU tests drive it over gloo. */
+/* Host-only self-check of the window loop on recorded outcomes (no matcher, no GPU): the CPU tests drive it over gloo.
+ * A recorded result with n_quads == UINT64_MAX stands for a device pass that FAILED on this rank: the rank returns the
+ * error after posting the error key, and every other rank must leave the loop with S4P_ERR_STATE in the same window. */
 int32_t s4p_shard_replay(int32_t rank, int32_t world, const s4p_collective* coll, int32_t n_windows, int32_t depth,
                          uint32_t threshold_count, uint32_t start_best_count, const int32_t* found,
                          const s4p_base_result* results, int32_t* commit_trials, uint32_t* commit_counts, int32_t commit_cap,

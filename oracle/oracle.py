@@ -73,6 +73,11 @@ def lib():
         L.s4po_get_ids.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
         L.s4po_find_congruent.restype = C.c_int64
         L.s4po_find_congruent.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, ip, C.c_int64, ip, C.c_int64, ip, C.c_int64]
+        L.s4po_count_congruent.restype = None
+        L.s4po_count_congruent.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, ip, C.c_int64, ip, C.c_int64, ip, C.c_int32,
+                                           C.POINTER(C.c_uint64), C.c_uint64, ip, C.c_int64, C.POINTER(C.c_int64)]
+        L.s4po_quad_mix.restype = C.c_uint64
+        L.s4po_quad_mix.argtypes = [C.c_int32] * 4
         L.s4po_try_congruent_set.restype = C.c_int64
         L.s4po_try_congruent_set.argtypes = [C.c_void_p, ip, ip, C.c_int64, ip, C.POINTER(C.c_uint32), ip]
         L.s4po_compute_rigid.restype = C.c_int32
@@ -226,6 +231,20 @@ class Matcher:
         if K > cap:
             raise RuntimeError("quad capacity exceeded: %d > %d" % (K, cap))
         return out[:K].copy()
+
+    def count_congruent(self, inv1, inv2, thr, pairs1, pairs2, base=None, threads=0, sample_mod=0, sample_cap=1 << 16):
+        """Streaming FindCongruentQuadrilaterals (+ rms gate if `base` is given): dict(K, quad_sum, C, cand_sum, sample)."""
+        p1 = np.ascontiguousarray(pairs1, np.int32); p2 = np.ascontiguousarray(pairs2, np.int32)
+        out = (C.c_uint64 * 4)(); ns = C.c_int64()
+        b = None if base is None else np.ascontiguousarray(base, np.int32)
+        smp = np.empty((sample_cap, 4), np.int32) if sample_mod else None
+        self.L.s4po_count_congruent(self.h, inv1, inv2, thr, _i(p1), p1.shape[0], _i(p2), p2.shape[0],
+                                    None if b is None else _i(b), int(threads) or (os.cpu_count() or 1), out, int(sample_mod),
+                                    None if smp is None else _i(smp), sample_cap, C.byref(ns))
+        if sample_mod and ns.value > sample_cap:
+            raise RuntimeError("sample capacity exceeded: %d > %d" % (ns.value, sample_cap))
+        return {"K": int(out[0]), "quad_sum": int(out[1]), "C": int(out[2]), "cand_sum": int(out[3]),
+                "sample": None if smp is None else smp[:ns.value].copy()}
 
     def try_congruent_set(self, base, quads):
         base = np.ascontiguousarray(base, np.int32); quads = np.ascontiguousarray(quads, np.int32)

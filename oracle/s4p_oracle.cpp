@@ -788,6 +788,121 @@ struct Matcher {
     return !quads.empty();
   }
 
+  // ---- the same enumeration, streaming: COUNTS and order-independent CHECKSUMS instead of the sorted list -------------
+  // For sizes where FindCongruentQuadrilaterals' std::set cannot be built (a base of a 20 000-point sample has ~10^9
+  // congruent quads): per set-2 pair the same invariant point, cell, cone rasterisation (normalset.hpp:162-210) and
+  // distance test (super4pcs.cc:151-163) as find_congruent above -- checked against it on small cases
+  // (tests/test_oracle.py) -- with the IndexedNormalSet held as a sorted (cell * 343 + bucket, pair) array and the loop
+  // over set 2 under OpenMP.  Every quad found also goes through ComputeRigidTransformation + the rms gate of
+  // TryCongruentSet (match4pcsBase.hpp:436-439) when a base is given.
+  //   out[0] = #quads, out[1] = sum of quad_mix over them, out[2] = #quads that pass the gate, out[3] = their quad_mix sum
+  // Gated quads whose quad_mix % sample_mod == 0 are returned (lexicographically sorted) as a deterministic subsample.
+  static inline uint64_t quad_mix(int a, int b, int c, int d) {      // == s4p_quad_mix (include/s4p_capi.h)
+    uint64_t x = (uint64_t(uint32_t(a)) << 32) | uint32_t(b);
+    uint64_t y = (uint64_t(uint32_t(c)) << 32) | uint32_t(d);
+    x *= 0x9E3779B97F4A7C15ull; x ^= x >> 29;
+    y *= 0xC2B2AE3D27D4EB4Full; y ^= y >> 31;
+    const uint64_t h = (x + y) * 0xD6E8FEB86659FD93ull;
+    return h ^ (h >> 32);
+  }
+  void count_congruent(float invariant1, float invariant2, float distance_threshold2,
+                       const std::vector<std::pair<int, int>>& P_pairs, const std::vector<std::pair<int, int>>& Q_pairs,
+                       const int* base /* 4 sampled-P ids or nullptr */, int threads, uint64_t out[4],
+                       uint64_t sample_mod, std::vector<std::array<int, 4>>* sample) const {
+    float s01[3], s23[3];
+    sub3(base3D[1].pos, base3D[0].pos, s01); normalize3(s01);
+    sub3(base3D[3].pos, base3D[2].pos, s23); normalize3(s23);
+    const float cosAlpha = dot3(s01, s23);                                      // :109-111
+    const float eps = distance_threshold2 / ratio;                              // :114
+    const float nepsilon = float(double(1.f / 7.f) + 0.00001);
+    const int gridDepth = int(-std::log2(eps));
+    const int egSize = int(std::pow(2, gridDepth));
+    const float gepsilon = 1.f / float(egSize);
+    auto index_pos = [&](const float* p) -> int64_t {
+      int c0 = int(p[0] / gepsilon), c1 = int(p[1] / gepsilon), c2 = int(p[2] / gepsilon);
+      return int64_t(c2) * egSize * egSize + int64_t(c1) * egSize + int64_t(c0);
+    };
+    const size_t m1 = P_pairs.size();
+    std::vector<std::pair<uint64_t, unsigned>> keyed(m1);                         // (cell * 343 + bucket, set-1 pair)
+#pragma omp parallel for schedule(static) num_threads(threads)
+    for (long long i = 0; i < (long long)m1; ++i) {                             // :118-124
+      const float* p1 = upts[P_pairs[i].first].data();
+      const float* p2 = upts[P_pairs[i].second].data();
+      float nrm[3]; sub3(p2, p1, nrm); normalize3(nrm);
+      float pos[3]; for (int k = 0; k < 3; ++k) pos[k] = p1[k] + invariant1 * (p2[k] - p1[k]);
+      keyed[size_t(i)] = {uint64_t(index_pos(pos)) * 343u + unsigned(index_normal(nrm, nepsilon)), unsigned(i)};
+    }
+    std::sort(keyed.begin(), keyed.end());
+    const float ang = std::acos(cosAlpha);                                       // normalset.hpp:174-179
+    const float perimeter = float(double(2.f) * M_PI * double(std::atan(ang)));
+    const unsigned nbSample = unsigned(2 * std::ceil(perimeter * 7.f / 2.f));
+    const float angleStep = float(double(2.f) * M_PI / double(float(nbSample)));
+    const float sinAlpha = std::sin(ang);
+    P3 cbase[4]; float centroid1[3] = {0, 0, 0};
+    if (base) {
+      for (int k = 0; k < 4; ++k) cbase[k] = Ps[base[k]];
+      for (int k = 0; k < 3; ++k) centroid1[k] = ((cbase[0].pos[k] + cbase[1].pos[k]) + cbase[2].pos[k]) / 3.f;
+    }
+    const double pi = std::acos(-1);
+    const float max_angle_rad = float(double(opt.max_angle) * pi / 180.0);
+    uint64_t K = 0, ksum = 0, C = 0, csum = 0;
+    std::vector<std::array<int, 4>> picked;
+    auto lower = [&](uint64_t key) { return std::lower_bound(keyed.begin(), keyed.end(), std::make_pair(key, 0u)); };
+#pragma omp parallel num_threads(threads) reduction(+ : K, ksum, C, csum)
+    {
+      std::vector<std::array<int, 4>> mine;
+#pragma omp for schedule(dynamic, 256)
+      for (long long i = 0; i < (long long)Q_pairs.size(); ++i) {                  // :132-164
+        const float* p1 = upts[Q_pairs[i].first].data();
+        const float* p2 = upts[Q_pairs[i].second].data();
+        const float* pq1 = Qs[Q_pairs[i].first].pos;
+        const float* pq2 = Qs[Q_pairs[i].second].pos;
+        float query[3], queryQ[3], queryn[3];
+        for (int k = 0; k < 3; ++k) query[k] = p1[k] + invariant2 * (p2[k] - p1[k]);
+        for (int k = 0; k < 3; ++k) queryQ[k] = pq1[k] + invariant2 * (pq2[k] - pq1[k]);
+        sub3(p2, p1, queryn); normalize3(queryn);
+        const uint64_t cell = uint64_t(index_pos(query));
+        auto c_lo = lower(cell * 343u), c_hi = lower(cell * 343u + 343u);
+        if (c_lo == c_hi) continue;                                               // no set-1 pair in this cell
+        float q[4]; quat_from_z_to(queryn, q);
+        bool colored[343] = {false};
+        for (unsigned a = 0; a != nbSample; a++) {
+          float theta = float(a) * angleStep;
+          float v[3] = {sinAlpha * std::cos(theta), sinAlpha * std::sin(theta), cosAlpha};
+          float dir[3]; quat_rotate(q, v, dir); normalize3(dir);
+          const int id = index_normal(dir, nepsilon);
+          if (id >= 0 && id < 343) colored[id] = true;
+        }
+        for (auto it = c_lo; it != c_hi; ++it) {
+          if (!colored[it->first - cell * 343u]) continue;
+          const int id = int(it->second);
+          const float* pp1 = Qs[P_pairs[id].first].pos;
+          const float* pp2 = Qs[P_pairs[id].second].pos;
+          float d[3];
+          for (int t = 0; t < 3; ++t) { float inv = pp1[t] + (pp2[t] - pp1[t]) * invariant1; d[t] = queryQ[t] - inv; }
+          if (!(sqn3(d) <= distance_threshold2)) continue;                          // quirk :160
+          const int a = P_pairs[id].first, b = P_pairs[id].second, cq = Q_pairs[i].first, dq = Q_pairs[i].second;
+          const uint64_t mix = quad_mix(a, b, cq, dq);
+          ++K; ksum += mix;
+          if (!base) continue;
+          const P3 cc[4] = {Qs[a], Qs[b], Qs[cq], Qs[dq]};
+          float centroid2[3];
+          for (int k = 0; k < 3; ++k) centroid2[k] = ((cc[0].pos[k] + cc[1].pos[k]) + cc[2].pos[k]) / 3.f;
+          float rms = -1; float T[16];
+          const bool ok = compute_rigid(cbase, cc, centroid1, centroid2, max_angle_rad, T, rms);
+          if (ok && rms >= 0.f && rms < 2.0f * opt.delta) {
+            ++C; csum += mix;
+            if (sample && sample_mod && mix % sample_mod == 0) mine.push_back({a, b, cq, dq});
+          }
+        }
+      }
+#pragma omp critical
+      picked.insert(picked.end(), mine.begin(), mine.end());
+    }
+    out[0] = K; out[1] = ksum; out[2] = C; out[3] = csum;
+    if (sample) { std::sort(picked.begin(), picked.end()); *sample = std::move(picked); }
+  }
+
   // ---- match4pcsBase.cc:365-500  ComputeRigidTransformation (computeScale=false) ----
   // returns: 0 = false, 1 = true ; rms output. T row-major.
   bool compute_rigid(const P3* ref, const P3* cand, const float* centroid1, const float* centroid2,
@@ -1231,6 +1346,26 @@ int64_t s4po_find_congruent(void* h, float inv1, float inv2, float thr, const in
   for (int64_t i = 0; i < K && i < cap; ++i) for (int k = 0; k < 4; ++k) out_quads[4 * i + k] = quads[i][k];
   return K;
 }
+
+// Streaming counterpart of s4po_find_congruent (+ the rms gate of TryCongruentSet when base != NULL): counts and
+// checksums only, OpenMP over set 2.  out4 = {quads, quad checksum, gated quads, their checksum}; gated quads with
+// quad_mix % sample_mod == 0 are written to sample_quads (sorted), *n_sample = how many there are.
+void s4po_count_congruent(void* h, float inv1, float inv2, float thr, const int32_t* pairs1, int64_t m1,
+                          const int32_t* pairs2, int64_t m2, const int32_t* base, int32_t threads, uint64_t* out4,
+                          uint64_t sample_mod, int32_t* sample_quads, int64_t sample_cap, int64_t* n_sample) {
+  Matcher* m = static_cast<Matcher*>(h);
+  std::vector<std::pair<int, int>> p1(m1), p2(m2);
+  for (int64_t i = 0; i < m1; ++i) p1[i] = {pairs1[2 * i], pairs1[2 * i + 1]};
+  for (int64_t i = 0; i < m2; ++i) p2[i] = {pairs2[2 * i], pairs2[2 * i + 1]};
+  std::vector<std::array<int, 4>> sample;
+  int b4[4] = {0, 0, 0, 0};
+  if (base) for (int k = 0; k < 4; ++k) b4[k] = base[k];
+  m->count_congruent(inv1, inv2, thr, p1, p2, base ? b4 : nullptr, threads < 1 ? 1 : threads, out4, sample_mod,
+                     sample_quads ? &sample : nullptr);
+  if (n_sample) *n_sample = int64_t(sample.size());
+  for (int64_t i = 0; i < int64_t(sample.size()) && i < sample_cap; ++i) for (int k = 0; k < 4; ++k) sample_quads[4 * i + k] = sample[size_t(i)][k];
+}
+uint64_t s4po_quad_mix(int32_t a, int32_t b, int32_t c, int32_t d) { return Matcher::quad_mix(a, b, c, d); }
 
 // TryCongruentSet on explicit quads.  per_cand[i] = -1 (gate failed) or inlier count.  Updates best state.
 int64_t s4po_try_congruent_set(void* h, const int32_t* base, const int32_t* quads, int64_t K, int32_t* per_cand,

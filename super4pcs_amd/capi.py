@@ -21,7 +21,7 @@ EXPORTED_SYMBOLS = [
     "s4p_create", "s4p_destroy", "s4p_last_error", "s4p_device_name", "s4p_set_clouds", "s4p_set_base",
     "s4p_extract_pairs", "s4p_find_congruent", "s4p_try_congruent_set", "s4p_verify_transforms", "s4p_verify_transforms_counted",
     "s4p_transform_points_device", "s4p_apply_bench", "s4p_select_base_points", "s4p_grow_limits", "s4p_get_limits", "s4p_try_base", "s4p_last_verified", "s4p_try_base_async", "s4p_try_base_wait", "s4p_pair_state_words", "s4p_pair_state_save", "s4p_pair_state_restore", "s4p_stage_slots", "s4p_pipeline_depth", "s4p_stage_base", "s4p_try_base_staged_async", "s4p_skip_base", "s4p_last_candidates", "s4p_transform_points", "s4p_profile_enable", "s4p_profile_get",
-    "s4p_selftest_ieee",
+    "s4p_selftest_ieee", "s4p_set_quad_chunking", "s4p_chunk_stats", "s4p_set_auto_grow", "s4p_lane_growths", "s4p_quad_mix",
 ]
 
 
@@ -51,6 +51,7 @@ class BaseResult(C.Structure):
         ("best_count", C.c_uint32), ("has_best", C.c_int32), ("best_rank", C.c_uint64),
         ("best_quad", C.c_int32 * 4), ("best_transform", C.c_float * 16),
         ("best_centroid2", C.c_float * 3), ("centroid1", C.c_float * 3),
+        ("quad_checksum", C.c_uint64), ("cand_checksum", C.c_uint64),
     ]
 
 
@@ -122,6 +123,17 @@ def load_library():
     L.s4p_profile_get.argtypes = [vp, C.POINTER(Profile), C.c_int32]
     L.s4p_selftest_ieee.restype = C.c_int32
     L.s4p_selftest_ieee.argtypes = [vp, fp, fp, C.c_int64, fp, fp, fp]
+    if hasattr(L, "s4p_set_quad_chunking"):
+        L.s4p_set_quad_chunking.restype = C.c_int32
+        L.s4p_set_quad_chunking.argtypes = [vp, C.c_int32, C.c_uint64]
+        L.s4p_chunk_stats.restype = C.c_int32
+        L.s4p_chunk_stats.argtypes = [vp, C.POINTER(C.c_uint64)]
+        L.s4p_set_auto_grow.restype = C.c_int32
+        L.s4p_set_auto_grow.argtypes = [vp, C.c_int32]
+        L.s4p_lane_growths.restype = C.c_int64
+        L.s4p_lane_growths.argtypes = [vp]
+        L.s4p_quad_mix.restype = C.c_uint64
+        L.s4p_quad_mix.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32]
     _LIB = L
     return L
 
@@ -283,6 +295,14 @@ class Context:
         self._chk(self.L.s4p_profile_get(self.h, C.byref(p), int(reset)))
         return p
 
+    def set_quad_chunking(self, enable=True, grow_cap_quads=0):
+        self._chk(self.L.s4p_set_quad_chunking(self.h, int(enable), int(grow_cap_quads)))
+
+    def chunk_stats(self):
+        o = (C.c_uint64 * 4)()
+        self._chk(self.L.s4p_chunk_stats(self.h, o))
+        return {"bases": int(o[0]), "passes": int(o[1]), "splits": int(o[2]), "quads": int(o[3])}
+
     def selftest_ieee(self, a, b):
         a = np.ascontiguousarray(a, np.float32); b = np.ascontiguousarray(b, np.float32)
         o1 = np.empty_like(a); o2 = np.empty_like(a); o3 = np.empty_like(a)
@@ -311,7 +331,7 @@ class MatcherInfo(C.Structure):
 SHARD_SYMBOLS = [
     "s4p_rccl_unique_id", "s4p_shard_create", "s4p_shard_destroy", "s4p_shard_last_error", "s4p_shard_use_rccl",
     "s4p_shard_use_collective", "s4p_shard_run_windows", "s4p_shard_compute_transformation", "s4p_shard_replay",
-    "s4p_matcher_terminate_threshold", "s4p_matcher_max_time_seconds",
+    "s4p_matcher_terminate_threshold", "s4p_matcher_max_time_seconds", "s4p_matcher_init_generation",
 ]
 MATCHER_SYMBOLS = [
     "s4p_matcher_create", "s4p_matcher_destroy", "s4p_matcher_last_error", "s4p_matcher_ctx", "s4p_uniform_dist_sample",
@@ -448,6 +468,16 @@ class Matcher:
         p = Profile()
         self._chk(self.L.s4p_profile_get(self.ctx_handle(), C.byref(p), int(reset)))
         return p
+
+    def set_quad_chunking(self, enable=True, grow_cap_quads=0):
+        rc = self.L.s4p_set_quad_chunking(self.ctx_handle(), int(enable), int(grow_cap_quads))
+        if rc != S4P_OK:
+            raise S4PError(rc, self.L.s4p_last_error(self.ctx_handle()).decode())
+
+    def chunk_stats(self):
+        o = (C.c_uint64 * 4)()
+        self.L.s4p_chunk_stats(self.ctx_handle(), o)
+        return {"bases": int(o[0]), "passes": int(o[1]), "splits": int(o[2]), "quads": int(o[3])}
 
     def last_candidates(self, cap):
         """Quads (reference order) and per-candidate inlier counts (-1 = rms gate failed) of the base whose device pass

@@ -68,20 +68,32 @@ struct s4p_ctx {
   // Lanes = HIP streams with private per-base device buffers.  Consecutive bases rotate over the lanes, so the
   // small kernels of base t+1 (pairs, hash build, quad enumeration) run concurrently with the
   // LCP scoring of base t instead of leaving most of the 256 CUs idle between them.
-  struct Lane {
+  // per-base buffers sized by the limits (pairs: 11 arrays, quads: 5, the cell hash): allocated as a set, so that a
+  // growth can build the new set first and swap it in only when every allocation of every lane has succeeded
+  struct LaneBufs {
+    DevBuf<int2> ab1, ab2; DevBuf<uint32_t> okey1, okey2, cell1, cell2, bucket1, next1, mask2; DevBuf<float4> ew1, ew2;
+    DevBuf<int4> quads; DevBuf<unsigned long long> tags; DevBuf<uint32_t> counts, cand_idx; DevBuf<float4> cand_T;
+    DevBuf<unsigned long long> ht_keys, ht_heads; uint32_t ht_mask = 0, epoch = 0;
+    uint64_t cap_pairs = 0, cap_quads = 0;    // entries these buffers hold (a lane whose base needed more has grown on its own)
+    void free_all() {
+      cap_pairs = cap_quads = 0;
+      ab1.free(); ab2.free(); okey1.free(); okey2.free(); cell1.free(); cell2.free(); bucket1.free(); next1.free(); mask2.free();
+      ew1.free(); ew2.free(); quads.free(); tags.free(); counts.free(); cand_idx.free(); cand_T.free(); ht_keys.free(); ht_heads.free();
+    }
+  };
+  struct Lane : LaneBufs {
     hipStream_t stream = nullptr;
     // CU partition (S4P_CU_SPLIT = n > 1): `stream` runs on one CU in n (the latency-bound pair / prep / quad kernels and
     // the copies), `vstream` on the others (k_verify, sized to 2 workgroups per CU of ITS partition), chained by `chain`.
     // Without the partition a k_verify launch is sized to the whole chip and slows 1.9x when another lane's small
     // kernels hold some of its CU slots (its 512 workgroups then need a second round).
     hipStream_t vstream = nullptr; hipEvent_t chain = nullptr;
-    DevBuf<int2> ab1, ab2; DevBuf<uint32_t> okey1, okey2, cell1, cell2, bucket1, next1, mask2; DevBuf<float4> ew1, ew2;
-    DevBuf<int4> quads; DevBuf<unsigned long long> tags; DevBuf<uint32_t> counts, cand_idx; DevBuf<float4> cand_T;
-    DevBuf<unsigned long long> ht_keys, ht_heads; uint32_t ht_mask = 0, epoch = 0;
     DevBuf<DevCounters> ctr;          // [0] live counters of the base in flight, [1] its result record (what the host reads)
     DevBuf<uint4> slots;              // k_verify: per-workgroup best, reduced by its last workgroup
     bool dirty = false;               // a stage-level call left the live counters non-zero: clear before a fused pass
     DevBuf<uint32_t> seq[2];          // device copy of a staged sequence blob (layout: StageSlot)
+    // launch record of the base in flight: what a relaunch after a buffer growth needs (finish_result)
+    int sv_slot = -1; int32_t sv_ids[4] = {0, 0, 0, 0}; float sv_inv1 = 0.f, sv_inv2 = 0.f; float sv_bx[12] = {0}, sv_brgb[12] = {0};
   };
   static constexpr int kMaxLanes = 8;
   Lane lane[kMaxLanes];
@@ -104,7 +116,22 @@ struct s4p_ctx {
   int cur = 0;                       // slot used by the call in progress
   uint32_t q_head = 0, q_tail = 0;   // async FIFO of s4p_try_base_async (depth 2)
   BaseFrame slot_bf[kMaxLanes];
+  QuadParams slot_q[kMaxLanes];      // enumeration record of the base in flight on each lane (the chunk loop relaunches it per range)
+  PinBuf<uint32_t> hmm[kMaxLanes];   // pinned {m1, m2} of a chunked base: restored before every chunk pass
   hipEvent_t done[kMaxLanes] = {};
+  // Bases whose congruent quads do not fit max_quads are processed in CHUNKS (run_chunked): quads of a range of set-2
+  // entries -> gate -> score -> fold, range after range, instead of failing with S4P_ERR_CAPACITY.  The reference's
+  // std::vector<Quadrilateral> simply grows (super4pcs.cc:166-174, match4pcsBase.hpp:340-351); at the 20 000-point sample
+  // of SURVEY 8d a base has ~10^9 quads.  quad_grow_cap: the quad capacity never grows beyond this many entries.
+  bool chunking = true; uint64_t quad_grow_cap = 32ull << 20;
+  // A lane whose base overflowed a PAIR buffer (or, without chunking, the quad buffers) grows its own buffers to what the
+  // base's counters ask for and runs the base again, inside the wait (finish_result): what the reference's std::vectors do.
+  // No other lane, no host state (RNG stream, octree permutation) is involved, so single-GPU and sharded loops alike go on
+  // as if the buffers had been large enough.  Off: S4P_ERR_CAPACITY, the stage-level contract.
+  bool auto_grow = true; uint64_t lane_growths = 0;
+  bool last_chunked = false;         // the per-candidate records of the last base were overwritten chunk by chunk
+  bool broken = false;               // a growth failed half-way: the lane buffers are inconsistent, every pass is refused
+  uint64_t chunk_bases = 0, chunk_passes = 0, chunk_splits = 0, chunk_quads = 0;
   DevBuf<float> tbuf; size_t tbuf_cap = 0;      // s4p_transform_points: two device + two pinned staging chunks
   PinBuf<float> tpin; hipEvent_t tev[2] = {nullptr, nullptr};
   // base selection on the device (s4p_select_base_points): the sampled P as float4 records in sampling order, one
@@ -156,9 +183,10 @@ int32_t check_overflow(s4p_ctx* c, const DevCounters& d) {
   // the device counters keep counting past the capacity, so they say what this base needs (the quads only once the
   // pairs fit: with truncated pair lists K is a lower bound)
   c->need_pairs = std::max<uint64_t>(d.m1, d.m2); c->need_quads = d.K;
+  if (!(ov & 3u)) c->need_pairs = 0;                      // the pair lists fitted: only the quads ask for more
   char b[160];
   snprintf(b, sizeof b, "device buffer overflow (bits=%u: 1=pairs1 2=pairs2 4=quads); raise s4p_limits (max_pairs=%llu max_quads=%llu)",
-           ov, (unsigned long long)c->max_pairs, (unsigned long long)c->max_quads);
+           ov, (unsigned long long)c->lane[c->cur].cap_pairs, (unsigned long long)c->lane[c->cur].cap_quads);
   c->err = b;
   return S4P_ERR_CAPACITY;
 }
@@ -204,7 +232,7 @@ int32_t upload_pairs_staged(s4p_ctx* c, int slot, int set, float pair_distance_e
   }
   P.ab = set == 0 ? L.ab1.p : L.ab2.p; P.okey = set == 0 ? L.okey1.p : L.okey2.p;
   P.counter = set == 0 ? &L.ctr.p->m1 : &L.ctr.p->m2;
-  P.cap = uint32_t(c->max_pairs); P.overflow = &L.ctr.p->overflow; P.overflow_bit = set == 0 ? 1u : 2u;
+  P.cap = uint32_t(L.cap_pairs); P.overflow = &L.ctr.p->overflow; P.overflow_bit = set == 0 ? 1u : 2u;
   P.split = pair_split(c->n_q);
   return S4P_OK;
 }
@@ -285,22 +313,23 @@ int32_t quad_params(s4p_ctx* c, float inv1, float inv2, float thr2, PrepParams& 
     HIPCHK(c, hipMemsetAsync(L.ht_heads.p, 0, L.ht_heads.n * 8, L.stream));
     L.epoch = 1;
   }
-  HashTable ht{L.ht_keys.p, L.ht_heads.p, L.ht_mask, L.epoch, &L.ctr.p->m1, uint32_t(c->max_pairs)};
+  HashTable ht{L.ht_keys.p, L.ht_heads.p, L.ht_mask, L.epoch, &L.ctr.p->m1, uint32_t(L.cap_pairs)};
   P1 = PrepParams{};
   P1.ux = c->ux.p; P1.uy = c->uy.p; P1.uz = c->uz.p; P1.qx = c->qx.p; P1.qy = c->qy.p; P1.qz = c->qz.p;
-  P1.ab = L.ab1.p; P1.m_dev = &L.ctr.p->m1; P1.cap = uint32_t(c->max_pairs); P1.invariant = inv1; P1.qg = qg;
+  P1.ab = L.ab1.p; P1.m_dev = &L.ctr.p->m1; P1.cap = uint32_t(L.cap_pairs); P1.invariant = inv1; P1.qg = qg;
   P1.cell = L.cell1.p; P1.bucket = L.bucket1.p; P1.ew = L.ew1.p; P1.next = L.next1.p; P1.mask = nullptr; P1.ht = ht;
   P1.cone.nb = 0;
   P2 = PrepParams{};
   P2.ux = c->ux.p; P2.uy = c->uy.p; P2.uz = c->uz.p; P2.qx = c->qx.p; P2.qy = c->qy.p; P2.qz = c->qz.p;
-  P2.ab = L.ab2.p; P2.m_dev = &L.ctr.p->m2; P2.cap = uint32_t(c->max_pairs); P2.invariant = inv2; P2.qg = qg;
+  P2.ab = L.ab2.p; P2.m_dev = &L.ctr.p->m2; P2.cap = uint32_t(L.cap_pairs); P2.invariant = inv2; P2.qg = qg;
   P2.cell = L.cell2.p; P2.bucket = nullptr; P2.ew = L.ew2.p; P2.next = nullptr; P2.mask = L.mask2.p; P2.ht = ht;
   P2.cone = cone;
   Q = QuadParams{};
   Q.ab1 = L.ab1.p; Q.okey1 = L.okey1.p; Q.bucket1 = L.bucket1.p; Q.ew1 = L.ew1.p; Q.next1 = L.next1.p;
   Q.ab2 = L.ab2.p; Q.okey2 = L.okey2.p; Q.cell2 = L.cell2.p; Q.ew2 = L.ew2.p; Q.mask2 = L.mask2.p;
-  Q.m2_dev = &L.ctr.p->m2; Q.cap2 = uint32_t(c->max_pairs); Q.ht = ht; Q.thr = thr2;
-  Q.quads = L.quads.p; Q.tags = L.tags.p; Q.K_dev = &L.ctr.p->K; Q.K_cap = uint32_t(c->max_quads); Q.overflow = &L.ctr.p->overflow;
+  Q.m2_dev = &L.ctr.p->m2; Q.cap2 = uint32_t(L.cap_pairs); Q.ht = ht; Q.thr = thr2;
+  Q.quads = L.quads.p; Q.tags = L.tags.p; Q.K_dev = &L.ctr.p->K; Q.K_cap = uint32_t(L.cap_quads); Q.overflow = &L.ctr.p->overflow;
+  Q.r0 = 0u; Q.r1 = 0xFFFFFFFFu; Q.qsum_dev = &L.ctr.p->quad_sum; Q.csum_dev = &L.ctr.p->cand_sum;
   Q.do_gate = 0;
   return S4P_OK;
 }
@@ -324,11 +353,13 @@ void launch_prep_kernel(s4p_ctx* c, const PrepParams& P1, const PrepParams& P2) 
 void launch_quads_kernel(s4p_ctx* c, const QuadParams& Q) {
   // one set-2 entry per thread in ONE pass for up to 512 k entries (a second grid-stride pass doubles the chain of
   // dependent gathers of the workgroups that get one); idle workgroups leave after reading the count
-  hipLaunchKernelGGL(k_quads, dim3(2048), dim3(256), 0, c->lane[c->cur].stream, Q);
+  const uint32_t span = Q.r1 - Q.r0;                        // (the whole set: 2^32 - 1)
+  const uint32_t blocks = std::min<uint32_t>(2048u, std::max<uint32_t>(1u, (span + 255u) / 256u));
+  hipLaunchKernelGGL(k_quads, dim3(blocks), dim3(256), 0, c->lane[c->cur].stream, Q);
 }
 void launch_gate_kernel(s4p_ctx* c, const GateParams& G) {
   s4p_ctx::Lane& L = c->lane[c->cur];
-  GateKernelParams K{G, L.quads.p, &L.ctr.p->K, uint32_t(c->max_quads)};
+  GateKernelParams K{G, L.quads.p, &L.ctr.p->K, uint32_t(L.cap_quads)};   // (K: 64-bit counter)
   hipLaunchKernelGGL(k_gate, dim3(1024), dim3(256), 0, L.stream, K);
 }
 
@@ -365,27 +396,58 @@ int32_t enqueue_result(s4p_ctx* c, const BaseFrame& bf) {
   return S4P_OK;
 }
 
-// wait for slot c->cur and turn its counters into an s4p_base_result
-int32_t finish_result(s4p_ctx* c, s4p_base_result* r, bool fused) {
-  { auto t0 = std::chrono::steady_clock::now();
-    HIPCHK(c, hipEventSynchronize(c->done[c->cur]));
-    c->host_wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
-  const DevCounters& d = *c->hctr[c->cur].p;
-  const BaseFrame& bf = c->slot_bf[c->cur];
-  if (int32_t rc = check_overflow(c, d)) return rc;
-  std::memset(r, 0, sizeof(*r));
-  r->n_pairs1 = d.m1; r->n_pairs2 = d.m2; r->n_quads = d.K; r->n_verified = d.C;
-  r->best_count = d.C ? d.best_count : 0u; r->has_best = d.C ? 1 : 0;
-  r->best_rank = d.C ? d.best_tag : ~0ull;
-  for (int i = 0; i < 4; ++i) r->best_quad[i] = d.C ? d.best_quad[i] : 0;
-  for (int i = 0; i < 16; ++i) r->best_transform[i] = d.C ? d.best_T[i] : ((i % 5 == 0) ? 1.f : 0.f);
-  for (int k = 0; k < 3; ++k) { r->best_centroid2[k] = d.C ? d.best_c2[k] : 0.f; r->centroid1[k] = bf.c1[k]; }
-  c->last_K = d.K;
+size_t lane_bytes(uint64_t mp, uint64_t mq);
+
+hipError_t alloc_lane_buffers(uint64_t mp_, uint64_t mq_, s4p_ctx::LaneBufs& L, const char** what);
+
+// Replaces the per-base buffers of ONE idle lane by a set for mp pairs / mq quads.  The lanes together may take 60 % of
+// the device memory.  The new set is allocated before the old one is released whenever the device has room for both;
+// otherwise the old set goes first, is re-created if the new one cannot be had, and only if that fails too is the context
+// left refusing further passes (`broken`).
+int32_t grow_lane(s4p_ctx* c, int li, uint64_t mp, uint64_t mq) {
+  s4p_ctx::Lane& L = c->lane[li];
+  auto refuse = [&]() {
+    char b[220];
+    snprintf(b, sizeof b, "a base needs device buffers of max_pairs=%llu max_quads=%llu (%.1f GB for this lane, %d lanes): refused",
+             (unsigned long long)mp, (unsigned long long)mq, double(lane_bytes(mp, mq)) / 1e9, c->n_lanes);
+    c->err = b;
+    return S4P_ERR_CAPACITY;
+  };
+  if (mp > 0x7FFFFFFFull || mq > 0x7FFFFFFFull) return refuse();
+  size_t free_b = 0, total_b = 0;
+  HIPCHK(c, hipMemGetInfo(&free_b, &total_b));
+  double all = double(lane_bytes(mp, mq));
+  for (int j = 0; j < c->n_lanes; ++j) if (j != li) all += double(lane_bytes(c->lane[j].cap_pairs, c->lane[j].cap_quads));
+  if (all > 0.6 * double(total_b)) return refuse();
+  const uint64_t old_p = L.cap_pairs, old_q = L.cap_quads;
+  const bool both_fit = double(lane_bytes(mp, mq)) < 0.9 * double(free_b);
+  if (!both_fit && double(lane_bytes(mp, mq)) - double(lane_bytes(old_p, old_q)) > 0.9 * double(free_b)) return refuse();
+  s4p_ctx::LaneBufs fresh;
+  const char* what = nullptr;
+  if (!both_fit) L.free_all();
+  hipError_t e = alloc_lane_buffers(mp, mq, fresh, &what);
+  if (e != hipSuccess) {
+    fresh.free_all();
+    c->err = std::string(what ? what : "hipMalloc") + ": " + hipGetErrorString(e);
+    if (!both_fit) {
+      s4p_ctx::LaneBufs back;
+      if (alloc_lane_buffers(old_p, old_q, back, &what) == hipSuccess) static_cast<s4p_ctx::LaneBufs&>(L) = back;
+      else { back.free_all(); c->broken = true; c->err += " (context unusable)"; }
+    }
+    return e == hipErrorOutOfMemory ? S4P_ERR_OOM : S4P_ERR_HIP;
+  }
+  L.free_all();
+  static_cast<s4p_ctx::LaneBufs&>(L) = fresh;              // (DevBuf holds plain pointers: the set moves as a whole)
+  c->lane_growths++;
+  return S4P_OK;
+}
+
+void account_profile(s4p_ctx* c, const DevCounters& d, bool fused) {
   if (c->prof_events) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, c->ev[c->cur][0], c->ev[c->cur][1]) == hipSuccess) {
       c->prof.verify_launches++; c->prof.verify_ms_total += ms;
-      c->prof.verify_candidates += d.C; c->prof.verify_quads += d.K; c->prof.verify_queries += uint64_t(d.C) * c->n_q;
+      c->prof.verify_candidates += d.C; c->prof.verify_quads += std::min<uint64_t>(d.K, c->lane[c->cur].cap_quads); c->prof.verify_queries += uint64_t(d.C) * c->n_q;
     }
     if (fused) {
       if (hipEventElapsedTime(&ms, c->ev[c->cur][2], c->ev[c->cur][3]) == hipSuccess) { c->prof.pairs_ms_total += ms; c->prof.pairs_launches += 2; }
@@ -393,7 +455,171 @@ int32_t finish_result(s4p_ctx* c, s4p_base_result* r, bool fused) {
     }
   }
   if (c->prof_points) { c->prof.verify_point_tests += d.point_tests; c->prof.verify_l0_pass += d.l0_pass; c->prof.verify_l1_pass += d.l1_pass; c->prof.verify_l2_pass += d.l2_pass; }
+}
+
+// winner record of a device pass -> s4p_base_result (counts are filled in by the caller)
+void fill_winner(const DevCounters& d, bool have, const BaseFrame& bf, s4p_base_result* r) {
+  r->best_count = have ? d.best_count : 0u; r->has_best = have ? 1 : 0;
+  r->best_rank = have ? d.best_tag : ~0ull;
+  for (int i = 0; i < 4; ++i) r->best_quad[i] = have ? d.best_quad[i] : 0;
+  for (int i = 0; i < 16; ++i) r->best_transform[i] = have ? d.best_T[i] : ((i % 5 == 0) ? 1.f : 0.f);
+  for (int k = 0; k < 3; ++k) { r->best_centroid2[k] = have ? d.best_c2[k] : 0.f; r->centroid1[k] = bf.c1[k]; }
+}
+
+int32_t launch_verify(s4p_ctx* c, const BaseFrame& bf);
+int32_t enqueue_result(s4p_ctx* c, const BaseFrame& bf);
+void launch_quads_kernel(s4p_ctx* c, const QuadParams& Q);
+void launch_gate_kernel(s4p_ctx* c, const GateParams& G);
+GateParams gate_params(s4p_ctx* c, const BaseFrame& bf);
+
+// A base whose congruent quads do not fit the quad buffers (first.overflow == 4, first.K = how many there are):
+// FindCongruentQuadrilaterals + TryCongruentSet (super4pcs.cc:132-174, match4pcsBase.hpp:363-497) over RANGES of the
+// set-2 pairs.  The pair sets, their preparation and the cell hash of the base are still on the lane; every range is
+// enumerated into the (reused) quad buffers, gated and scored by the same kernels, and its best is folded with the rule
+// of the single pass -- greatest count, then smallest tag = earliest in the reference's std::set order -- so the winner
+// is the first maximum of the whole base (match4pcsBase.hpp:467-484) whatever the chunking.  A range that still
+// overflows is halved.  The per-range quad counts and checksums must add up to those of the counting pass.
+int32_t run_chunked(s4p_ctx* c, const DevCounters& first, s4p_base_result* r) {
+  const int li = c->cur;
+  s4p_ctx::Lane& L = c->lane[li];
+  QuadParams Q = c->slot_q[li];
+  const BaseFrame bf = c->slot_bf[li];
+  const uint32_t m1 = first.m1, m2 = first.m2;            // exact: the pair lists fitted
+  const uint64_t Ktot = first.K;
+  const uint64_t target = std::max<uint64_t>(L.cap_quads * 6 / 10, 1);          // entries are in append order, i.e. shuffled: ranges are even
+  const uint64_t nch = (Ktot + target - 1) / target;
+  const uint32_t step = uint32_t(std::max<uint64_t>(1, (uint64_t(m2) + nch - 1) / nch));
+  std::vector<std::pair<uint32_t, uint32_t>> todo;
+  for (uint64_t a = 0; a < m2; a += step) todo.emplace_back(uint32_t(a), uint32_t(std::min<uint64_t>(a + step, m2)));
+  std::reverse(todo.begin(), todo.end());
+  uint64_t Ksum = 0, Csum = 0, qsum = 0, csum = 0;
+  DevCounters best{}; bool have = false;
+  c->chunk_bases++; c->chunk_quads += Ktot;
+  if (!c->hmm[li].p) HIPCHK(c, c->hmm[li].alloc(2));
+  while (!todo.empty()) {
+    const std::pair<uint32_t, uint32_t> rg = todo.back(); todo.pop_back();
+    c->hmm[li].p[0] = m1; c->hmm[li].p[1] = m2;            // k_verify cleared the live counters: the pair counts come back
+    HIPCHK(c, hipMemcpyAsync(&L.ctr.p->m1, c->hmm[li].p, 8, hipMemcpyHostToDevice, L.stream));
+    Q.r0 = rg.first; Q.r1 = rg.second;
+    launch_quads_kernel(c, Q);
+    if (!Q.do_gate) launch_gate_kernel(c, gate_params(c, bf));
+    HIPCHK(c, hipGetLastError());
+    if (int32_t rc = launch_verify(c, bf)) return rc;
+    if (int32_t rc = enqueue_result(c, bf)) return rc;
+    HIPCHK(c, hipEventSynchronize(c->done[li]));
+    const DevCounters d = *c->hctr[li].p;
+    if (d.overflow & 4u) {
+      if (rg.second - rg.first < 2u) S4P_FAIL(c, S4P_ERR_CAPACITY, "one set-2 pair has more congruent quads than max_quads: raise s4p_limits.max_quads");
+      const uint32_t mid = rg.first + (rg.second - rg.first) / 2u;
+      todo.emplace_back(mid, rg.second); todo.emplace_back(rg.first, mid);
+      c->chunk_splits++;
+      continue;
+    }
+    if (d.overflow) S4P_FAIL(c, S4P_ERR_STATE, "chunk pass: unexpected overflow bits");
+    c->chunk_passes++;
+    account_profile(c, d, false);
+    Ksum += d.K; Csum += d.C; qsum += d.quad_sum; csum += d.cand_sum;
+    if (d.C && (!have || d.best_count > best.best_count || (d.best_count == best.best_count && d.best_tag < best.best_tag))) { best = d; have = true; }
+  }
+  if (Ksum != Ktot || qsum != first.quad_sum) {
+    char b[200];
+    snprintf(b, sizeof b, "chunked enumeration disagrees with the counting pass (quads %llu vs %llu, checksum %016llx vs %016llx)",
+             (unsigned long long)Ksum, (unsigned long long)Ktot, (unsigned long long)qsum, (unsigned long long)first.quad_sum);
+    c->err = b;
+    return S4P_ERR_STATE;
+  }
+  std::memset(r, 0, sizeof(*r));
+  r->n_pairs1 = m1; r->n_pairs2 = m2; r->n_quads = Ksum; r->n_verified = Csum;
+  r->quad_checksum = qsum; r->cand_checksum = csum;
+  fill_winner(best, have, bf, r);
+  c->last_K = 0; c->last_chunked = true;
+  c->need_quads = Ktot; c->need_pairs = 0;
   return S4P_OK;
+}
+
+int32_t launch_base(s4p_ctx* c, int32_t slot, const int32_t* base_ids, float inv1, float inv2);
+int32_t reset_counters(s4p_ctx* c);
+
+// The base of lane c->cur once more, after the lane's buffers have grown: same staged sequences (the staging slot is
+// recycled only after the wait has returned), same base points, same parameters.
+int32_t relaunch_base(s4p_ctx* c) {
+  s4p_ctx::Lane& L = c->lane[c->cur];
+  float kx[12], kc[12];
+  std::memcpy(kx, c->base_xyz, sizeof kx); std::memcpy(kc, c->base_rgb, sizeof kc);
+  std::memcpy(c->base_xyz, L.sv_bx, sizeof kx); std::memcpy(c->base_rgb, L.sv_brgb, sizeof kc);
+  const int32_t rc = launch_base(c, L.sv_slot, L.sv_ids, L.sv_inv1, L.sv_inv2);
+  std::memcpy(c->base_xyz, kx, sizeof kx); std::memcpy(c->base_rgb, kc, sizeof kc);
+  if (rc) return rc;
+  HIPCHK(c, hipEventSynchronize(c->done[c->cur]));
+  return S4P_OK;
+}
+
+// wait for slot c->cur and turn its counters into an s4p_base_result
+int32_t finish_result(s4p_ctx* c, s4p_base_result* r, bool fused) {
+  { auto t0 = std::chrono::steady_clock::now();
+    HIPCHK(c, hipEventSynchronize(c->done[c->cur]));
+    c->host_wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+  const int li = c->cur;
+  for (int attempt = 0;; ++attempt) {
+    const DevCounters d = *c->hctr[li].p;                  // (a copy: relaunches and chunk passes reuse the pinned record)
+    const BaseFrame& bf = c->slot_bf[li];
+    if (attempt == 0) account_profile(c, d, fused);
+    if (!d.overflow) {
+      std::memset(r, 0, sizeof(*r));
+      r->n_pairs1 = d.m1; r->n_pairs2 = d.m2; r->n_quads = d.K; r->n_verified = d.C;
+      r->quad_checksum = d.quad_sum; r->cand_checksum = d.cand_sum;
+      fill_winner(d, d.C != 0, bf, r);
+      c->last_K = d.K; c->last_chunked = false;
+      return S4P_OK;
+    }
+    s4p_ctx::Lane& L = c->lane[li];
+    const bool pairs_over = (d.overflow & 3u) != 0u;
+    if (fused && !pairs_over && c->chunking) {              // only the quads did not fit: chunk the base, then widen the lane
+      if (int32_t rc = run_chunked(c, d, r)) return rc;
+      if (c->auto_grow && L.cap_quads < c->quad_grow_cap) {
+        const uint64_t want = std::min<uint64_t>(c->quad_grow_cap, std::max<uint64_t>(2 * L.cap_quads, d.K + d.K / 4));
+        std::string keep = c->err;
+        if (grow_lane(c, li, L.cap_pairs, want) != S4P_OK) c->err = keep;      // no room: later bases are chunked as well
+      }
+      return S4P_OK;
+    }
+    if (!fused || !c->auto_grow || attempt >= 4) return check_overflow(c, d);
+    // a pair list (or, without chunking, the quad list) did not fit: the counters kept counting, so they say what the
+    // base needs (the quads only once the pairs fit)
+    uint64_t mp = L.cap_pairs, mq = L.cap_quads;
+    const uint64_t need_p = std::max<uint64_t>(d.m1, d.m2);
+    if (need_p > mp) mp = std::max<uint64_t>(2 * mp, need_p + need_p / 4);
+    if (!pairs_over && d.K > mq) mq = std::max<uint64_t>(2 * mq, d.K + d.K / 4);
+    if (int32_t rc = grow_lane(c, li, mp, mq)) return rc;
+    if (int32_t rc = relaunch_base(c)) return rc;
+  }
+}
+
+// The device pass of one base on lane c->cur: 2 uploads and 4 launches (k_pairs: both pair sets; k_prep: their
+// preparation; k_quads: enumeration + rigid transform + rms gate; k_verify: LCP of every candidate + winner + result record
+// + counters cleared for the lane's next base), then the read-back of the result record.
+int32_t launch_base(s4p_ctx* c, int32_t slot, const int32_t* base_ids, float inv1, float inv2) {
+  s4p_ctx::Lane& L = c->lane[c->cur];
+  if (L.dirty) { if (int32_t rc = reset_counters(c)) return rc; }
+  const float eps = 2.0f * c->opt.delta;
+  const BaseFrame bf = make_base_frame(c, base_ids);
+  PrepParams P1, P2; QuadParams Q;
+  if (int32_t rc = quad_params(c, inv1, inv2, eps, P1, P2, Q)) return rc;
+  if (c->prof_events) HIPCHK(c, hipEventRecord(c->ev[c->cur][2], L.stream));
+  { PairParams2 PP{};
+    if (int32_t rc = upload_pairs_staged(c, slot, 0, eps, 0, 1, PP.set[0].pair)) return rc;
+    if (int32_t rc = upload_pairs_staged(c, slot, 1, eps, 2, 3, PP.set[1].pair)) return rc;
+    if (int32_t rc = launch_pairs_kernel(c, PP, 2)) return rc; }
+  if (c->prof_events) HIPCHK(c, hipEventRecord(c->ev[c->cur][3], L.stream));
+  launch_prep_kernel(c, P1, P2);
+  if (c->fuse_gate) { Q.do_gate = 1; Q.gate = gate_params(c, bf); }
+  c->slot_q[c->cur] = Q;                                  // (the chunk loop relaunches it range by range if the quads do not fit)
+  launch_quads_kernel(c, Q);
+  if (!c->fuse_gate) launch_gate_kernel(c, gate_params(c, bf));
+  HIPCHK(c, hipGetLastError());
+  if (c->prof_events) HIPCHK(c, hipEventRecord(c->ev[c->cur][4], L.stream));
+  if (int32_t rc = launch_verify(c, bf)) return rc;
+  return enqueue_result(c, bf);
 }
 
 int32_t fetch_result(s4p_ctx* c, const BaseFrame& bf, s4p_base_result* r) {
@@ -411,8 +637,8 @@ int32_t reset_counters(s4p_ctx* c) {
 }
 
 // Per-lane buffers sized by the limits (pairs: 11 arrays, quads: 5, the cell hash): at creation and when the limits grow.
-hipError_t alloc_lane_buffers(s4p_ctx* c, s4p_ctx::Lane& L, const char** what) {
-  const size_t mp = c->max_pairs, mq = c->max_quads;
+hipError_t alloc_lane_buffers(uint64_t mp_, uint64_t mq_, s4p_ctx::LaneBufs& L, const char** what) {
+  const size_t mp = mp_, mq = mq_;
   const uint32_t hts = next_pow2(2 * mp);
   hipError_t e = hipSuccess;
 #define A(buf, cnt) if ((e = (buf).alloc(cnt)) != hipSuccess) { *what = "hipMalloc " #buf; return e; }
@@ -424,7 +650,7 @@ hipError_t alloc_lane_buffers(s4p_ctx* c, s4p_ctx::Lane& L, const char** what) {
   *what = "hipMemset";
   if ((e = hipMemset(L.ht_keys.p, 0, size_t(hts) * 8)) != hipSuccess) return e;
   if ((e = hipMemset(L.ht_heads.p, 0, size_t(hts) * 8)) != hipSuccess) return e;
-  L.epoch = 0; L.dirty = true;                          // first use of a lane starts with an explicit clear (best_tag = ~0)
+  L.epoch = 0; L.cap_pairs = mp_; L.cap_quads = mq_;
   return hipSuccess;
 }
 size_t lane_bytes(uint64_t mp, uint64_t mq) {            // what alloc_lane_buffers takes per lane
@@ -435,6 +661,8 @@ size_t lane_bytes(uint64_t mp, uint64_t mq) {            // what alloc_lane_buff
 
 // ============================================================================
 extern "C" {
+
+uint64_t s4p_quad_mix(int32_t a, int32_t b, int32_t c, int32_t d) { return quad_mix(a, b, c, d); }
 
 const char* s4p_last_error(const s4p_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
@@ -470,6 +698,7 @@ int32_t s4p_create(const s4p_options* opt, const s4p_limits* lim, int32_t device
   if (const char* fu = getenv("S4P_FUSE_GATE")) c->fuse_gate = atoi(fu) != 0;
   if (const char* la = getenv("S4P_LIST_ALIGN")) { const int v = atoi(la); if (v == 1 || v == 2 || v == 4 || v == 8) c->list_align = v; }
   if (const char* cs = getenv("S4P_CU_SPLIT")) { const int v = atoi(cs); if (v >= 2 && v <= 64) c->cu_split = v; }
+  if (const char* qc = getenv("S4P_QUAD_GROW_CAP")) { const long long v = atoll(qc); if (v > 0 && v <= 0x7FFFFFFFll) c->quad_grow_cap = uint64_t(v); }
   snprintf(c->devname, sizeof c->devname, "%s (%s)", prop.name, prop.gcnArchName);
   // defaults: 1 Mi pairs per set, 4 Mi quads per base -- 0.45 GB per lane, a context in ~20 ms (4 Mi / 16 Mi took 0.3-0.6 s to
   // allocate and clear); Perform_N_steps grows them when a base needs more (s4p_grow_limits)
@@ -500,7 +729,8 @@ int32_t s4p_create(const s4p_options* opt, const s4p_limits* lim, int32_t device
     A(L.ctr, 2); A(L.slots, kVerifyMaxBlocks);
     if ((e = hipMemset(L.ctr.p, 0, 2 * sizeof(DevCounters))) != hipSuccess) return fail(e, "hipMemset");
     const char* what = nullptr;
-    if ((e = alloc_lane_buffers(c, L, &what)) != hipSuccess) return fail(e, what);
+    if ((e = alloc_lane_buffers(c->max_pairs, c->max_quads, L, &what)) != hipSuccess) return fail(e, what);
+    L.dirty = true;                                       // first use of a lane starts with an explicit clear (best_tag = ~0)
   }
 #undef A
   for (int sl = 0; sl < s4p_ctx::kMaxLanes; ++sl) {
@@ -522,9 +752,11 @@ int32_t s4p_create(const s4p_options* opt, const s4p_limits* lim, int32_t device
   return S4P_OK;
 }
 
-// Raises the pair / quad capacities to at least the given numbers (the counts of the base that overflowed, if 0) with
-// 25 % head-room, at least doubling what overflowed; every lane is reallocated.  Nothing may be in flight.  Refuses
-// (S4P_ERR_CAPACITY, limits unchanged) when the lanes would then take more than 60 % of the device memory.
+// Raises the pair / quad capacities of EVERY lane to at least the given numbers (the counts of the base that overflowed
+// last, if 0) with 25 % head-room, at least doubling what overflowed.  Nothing may be in flight.  Refused
+// (S4P_ERR_CAPACITY, nothing changed) when the lanes would then take more than 60 % of the device memory.  The fused
+// path does not need this call: a lane whose base overflows grows on its own (finish_result); it serves the stage-level
+// entry points and callers that want to size the buffers up front.
 int32_t s4p_grow_limits(s4p_ctx* c, uint64_t min_pairs, uint64_t min_quads) {
   if (!c) return S4P_ERR_BAD_ARG;
   if (c->q_head != c->q_tail) S4P_FAIL(c, S4P_ERR_STATE, "s4p_grow_limits: bases in flight");
@@ -534,13 +766,14 @@ int32_t s4p_grow_limits(s4p_ctx* c, uint64_t min_pairs, uint64_t min_quads) {
   uint64_t mp = c->max_pairs, mq = c->max_quads;
   if (min_pairs > mp) mp = std::max<uint64_t>(2 * mp, min_pairs + min_pairs / 4);
   if (min_quads > mq) mq = std::max<uint64_t>(2 * mq, min_quads + min_quads / 4);
-  if (mp == c->max_pairs && mq == c->max_quads) return S4P_OK;
   size_t free_b = 0, total_b = 0;
   HIPCHK(c, hipMemGetInfo(&free_b, &total_b));
-  if (mp > 0x7FFFFFFFull || mq > 0x7FFFFFFFull || double(lane_bytes(mp, mq)) * c->n_lanes > 0.6 * double(total_b)) {
+  double all = 0;
+  for (int li = 0; li < c->n_lanes; ++li) all += double(lane_bytes(std::max(mp, c->lane[li].cap_pairs), std::max(mq, c->lane[li].cap_quads)));
+  if (mp > 0x7FFFFFFFull || mq > 0x7FFFFFFFull || all > 0.6 * double(total_b)) {
     char b[200];
     snprintf(b, sizeof b, "device buffers would have to grow to max_pairs=%llu max_quads=%llu (%.1f GB in %d lanes): refused",
-             (unsigned long long)mp, (unsigned long long)mq, double(lane_bytes(mp, mq)) * c->n_lanes / 1e9, c->n_lanes);
+             (unsigned long long)mp, (unsigned long long)mq, all / 1e9, c->n_lanes);
     c->err = b;
     return S4P_ERR_CAPACITY;
   }
@@ -548,20 +781,41 @@ int32_t s4p_grow_limits(s4p_ctx* c, uint64_t min_pairs, uint64_t min_quads) {
     s4p_ctx::Lane& L = c->lane[li];
     HIPCHK(c, hipStreamSynchronize(L.stream));
     if (L.vstream) HIPCHK(c, hipStreamSynchronize(L.vstream));
+    if (L.cap_pairs >= mp && L.cap_quads >= mq) continue;
+    if (int32_t rc = grow_lane(c, li, std::max(mp, L.cap_pairs), std::max(mq, L.cap_quads))) return rc;
   }
   c->max_pairs = mp; c->max_quads = mq;
-  for (int li = 0; li < c->n_lanes; ++li) {
-    const char* what = nullptr;
-    const hipError_t e = alloc_lane_buffers(c, c->lane[li], &what);       // DevBuf::alloc frees the old buffer first
-    if (e != hipSuccess) { c->err = std::string(what) + ": " + hipGetErrorString(e); return e == hipErrorOutOfMemory ? S4P_ERR_OOM : S4P_ERR_HIP; }
-  }
   c->need_pairs = c->need_quads = 0;
   return S4P_OK;
 }
 
+// Chunked processing of bases whose congruent quads exceed the quad buffers (on by default).  grow_cap_quads = the
+// largest quad capacity s4p_grow_limits may reach (0 keeps the current value); enable = 0 restores the loud
+// S4P_ERR_CAPACITY of the stage-level contract for such bases.
+int32_t s4p_set_quad_chunking(s4p_ctx* c, int32_t enable, uint64_t grow_cap_quads) {
+  if (!c) return S4P_ERR_BAD_ARG;
+  if (grow_cap_quads > 0x7FFFFFFFull) S4P_FAIL(c, S4P_ERR_BAD_ARG, "quad capacity beyond 2^31 entries");
+  c->chunking = enable != 0;
+  if (grow_cap_quads) c->quad_grow_cap = grow_cap_quads;
+  return S4P_OK;
+}
+// out4 = {bases processed in chunks, chunk passes, range splits after an overflowing chunk, quads enumerated by chunked bases}
+int32_t s4p_chunk_stats(const s4p_ctx* c, uint64_t* out4) {
+  if (!c || !out4) return S4P_ERR_BAD_ARG;
+  out4[0] = c->chunk_bases; out4[1] = c->chunk_passes; out4[2] = c->chunk_splits; out4[3] = c->chunk_quads;
+  return S4P_OK;
+}
+// Lanes growing their own buffers when a base overflows (on by default); s4p_lane_growths counts the regrowths.
+int32_t s4p_set_auto_grow(s4p_ctx* c, int32_t enable) { if (!c) return S4P_ERR_BAD_ARG; c->auto_grow = enable != 0; return S4P_OK; }
+int64_t s4p_lane_growths(const s4p_ctx* c) { return c ? int64_t(c->lane_growths) : 0; }
+
 int32_t s4p_get_limits(const s4p_ctx* c, s4p_limits* out) {
   if (!c || !out) return S4P_ERR_BAD_ARG;
   out->max_pairs = c->max_pairs; out->max_quads = c->max_quads; out->max_grid_cells = c->max_grid_cells;
+  for (int li = 0; li < c->n_lanes; ++li) {                // lanes grow on their own: report the largest buffers in force
+    out->max_pairs = std::max<uint64_t>(out->max_pairs, c->lane[li].cap_pairs);
+    out->max_quads = std::max<uint64_t>(out->max_quads, c->lane[li].cap_quads);
+  }
   return S4P_OK;
 }
 
@@ -574,12 +828,11 @@ void s4p_destroy(s4p_ctx* c) {
   c->qx.free(); c->qy.free(); c->qz.free(); c->ux.free(); c->uy.free(); c->uz.free();
   c->qnx.free(); c->qny.free(); c->qnz.free(); c->qcr.free(); c->qcg.free(); c->qcb.free();
   for (auto& L : c->lane) {
-    L.ab1.free(); L.ab2.free(); L.okey1.free(); L.okey2.free(); L.cell1.free(); L.cell2.free();
-    L.bucket1.free(); L.next1.free(); L.mask2.free(); L.ew1.free(); L.ew2.free();
-    L.quads.free(); L.tags.free(); L.counts.free(); L.cand_idx.free(); L.cand_T.free(); L.ht_keys.free(); L.ht_heads.free(); L.ctr.free(); L.slots.free();
+    L.free_all(); L.ctr.free(); L.slots.free();
     for (int s = 0; s < 2; ++s) L.seq[s].free();
   }
   for (auto& h : c->hctr) h.free();
+  for (auto& h : c->hmm) h.free();
   for (auto& st : c->stage) for (int s = 0; s < 2; ++s) st.seq[s].free();
   c->tbuf.free(); c->tpin.free();
   if (c->sel_stream) { (void)hipStreamSynchronize(c->sel_stream); (void)hipStreamDestroy(c->sel_stream); }
@@ -797,7 +1050,7 @@ int32_t s4p_find_congruent(s4p_ctx* c, float inv1, float inv2, float /*thr1*/, f
   *n_out = 0;
   if (m1 <= 0 || m2 <= 0) return S4P_OK;
   if (!pairs1 || !pairs2) S4P_FAIL(c, S4P_ERR_BAD_ARG, "null pair list");
-  if (uint64_t(m1) > c->max_pairs || uint64_t(m2) > c->max_pairs) S4P_FAIL(c, S4P_ERR_CAPACITY, "pair list longer than max_pairs");
+  if (uint64_t(m1) > c->lane[0].cap_pairs || uint64_t(m2) > c->lane[0].cap_pairs) S4P_FAIL(c, S4P_ERR_CAPACITY, "pair list longer than max_pairs");
   for (int64_t i = 0; i < 2 * m1; ++i) if (pairs1[i] < 0 || uint32_t(pairs1[i]) >= c->n_q) S4P_FAIL(c, S4P_ERR_BAD_ARG, "pair index out of range");
   for (int64_t i = 0; i < 2 * m2; ++i) if (pairs2[i] < 0 || uint32_t(pairs2[i]) >= c->n_q) S4P_FAIL(c, S4P_ERR_BAD_ARG, "pair index out of range");
   S4P_NEED_IDLE(c);
@@ -842,7 +1095,7 @@ int32_t s4p_try_congruent_set(s4p_ctx* c, const int32_t* base_ids, const int32_t
   if (!c || !base_ids || !result) return S4P_ERR_BAD_ARG;
   if (!c->clouds_set) S4P_FAIL(c, S4P_ERR_STATE, "s4p_set_clouds not called");
   for (int i = 0; i < 4; ++i) if (base_ids[i] < 0 || uint32_t(base_ids[i]) >= c->n_p) S4P_FAIL(c, S4P_ERR_BAD_ARG, "base id out of range");
-  if (K < 0 || uint64_t(K) > c->max_quads) S4P_FAIL(c, S4P_ERR_CAPACITY, "more quads than max_quads");
+  if (K < 0 || uint64_t(K) > c->lane[0].cap_quads) S4P_FAIL(c, S4P_ERR_CAPACITY, "more quads than max_quads");
   if (K > 0 && !quads) S4P_FAIL(c, S4P_ERR_BAD_ARG, "null quads");
   for (int64_t i = 0; i < 4 * K; ++i) if (quads[i] < 0 || uint32_t(quads[i]) >= c->n_q) S4P_FAIL(c, S4P_ERR_BAD_ARG, "quad index out of range");
   S4P_NEED_IDLE(c);
@@ -855,8 +1108,8 @@ int32_t s4p_try_congruent_set(s4p_ctx* c, const int32_t* base_ids, const int32_t
     HIPCHK(c, hipMemcpyAsync(c->lane[c->cur].quads.p, quads, size_t(K) * 16, hipMemcpyHostToDevice, c->lane[c->cur].stream));
     HIPCHK(c, hipMemcpyAsync(c->lane[c->cur].tags.p, tg.data(), size_t(K) * 8, hipMemcpyHostToDevice, c->lane[c->cur].stream));
   }
-  const uint32_t k32 = uint32_t(K);
-  HIPCHK(c, hipMemcpyAsync(&c->lane[c->cur].ctr.p->K, &k32, 4, hipMemcpyHostToDevice, c->lane[c->cur].stream));
+  const unsigned long long k64 = (unsigned long long)K;
+  HIPCHK(c, hipMemcpyAsync(&c->lane[c->cur].ctr.p->K, &k64, 8, hipMemcpyHostToDevice, c->lane[c->cur].stream));
   launch_gate_kernel(c, gate_params(c, bf));
   if (int32_t rc = launch_verify(c, bf)) return rc;
   if (int32_t rc = fetch_result(c, bf, result)) return rc;
@@ -937,33 +1190,16 @@ int32_t s4p_try_base_staged_async(s4p_ctx* c, int32_t slot, const int32_t* base_
   if (!c || !base_ids) return S4P_ERR_BAD_ARG;
   if (!c->clouds_set) S4P_FAIL(c, S4P_ERR_STATE, "s4p_set_clouds not called");
   if (slot < 0 || slot >= s4p_ctx::kStageSlots) S4P_FAIL(c, S4P_ERR_BAD_ARG, "bad staging slot");
+  if (c->broken) S4P_FAIL(c, S4P_ERR_STATE, "context unusable: a buffer growth failed half-way");
   for (int i = 0; i < 4; ++i) if (base_ids[i] < 0 || uint32_t(base_ids[i]) >= c->n_p) S4P_FAIL(c, S4P_ERR_BAD_ARG, "base id out of range");
   if (c->q_tail - c->q_head >= uint32_t(c->n_lanes)) S4P_FAIL(c, S4P_ERR_STATE, "all lanes busy: call s4p_try_base_wait first");
   HIPCHK(c, hipSetDevice(c->device));
   c->cur = int(c->q_tail % uint32_t(c->n_lanes));
   s4p_ctx::Lane& L = c->lane[c->cur];
-  // The device pass of one base: 2 uploads and 4 launches (k_pairs: both pair sets; k_prep: their preparation; k_quads:
-  // enumeration + rigid transform + rms gate; k_verify: LCP of every candidate + winner + result record + counters
-  // cleared for the lane's next base), then the read-back of the result record.
-  if (L.dirty) { if (int32_t rc = reset_counters(c)) return rc; }
-  const float eps = 2.0f * c->opt.delta;
-  const BaseFrame bf = make_base_frame(c, base_ids);
-  PrepParams P1, P2; QuadParams Q;
-  if (int32_t rc = quad_params(c, inv1, inv2, eps, P1, P2, Q)) return rc;
-  if (c->prof_events) HIPCHK(c, hipEventRecord(c->ev[c->cur][2], L.stream));
-  { PairParams2 PP{};
-    if (int32_t rc = upload_pairs_staged(c, slot, 0, eps, 0, 1, PP.set[0].pair)) return rc;
-    if (int32_t rc = upload_pairs_staged(c, slot, 1, eps, 2, 3, PP.set[1].pair)) return rc;
-    if (int32_t rc = launch_pairs_kernel(c, PP, 2)) return rc; }
-  if (c->prof_events) HIPCHK(c, hipEventRecord(c->ev[c->cur][3], L.stream));
-  launch_prep_kernel(c, P1, P2);
-  if (c->fuse_gate) { Q.do_gate = 1; Q.gate = gate_params(c, bf); }
-  launch_quads_kernel(c, Q);
-  if (!c->fuse_gate) launch_gate_kernel(c, gate_params(c, bf));
-  HIPCHK(c, hipGetLastError());
-  if (c->prof_events) HIPCHK(c, hipEventRecord(c->ev[c->cur][4], L.stream));
-  if (int32_t rc = launch_verify(c, bf)) return rc;
-  if (int32_t rc = enqueue_result(c, bf)) return rc;
+  L.sv_slot = slot; L.sv_inv1 = inv1; L.sv_inv2 = inv2;
+  for (int i = 0; i < 4; ++i) L.sv_ids[i] = base_ids[i];
+  std::memcpy(L.sv_bx, c->base_xyz, sizeof L.sv_bx); std::memcpy(L.sv_brgb, c->base_rgb, sizeof L.sv_brgb);
+  if (int32_t rc = launch_base(c, slot, base_ids, inv1, inv2)) return rc;
   c->q_tail++;
   return S4P_OK;
 }
@@ -1014,6 +1250,7 @@ int32_t s4p_skip_base(s4p_ctx* c) {
 
 int32_t s4p_last_candidates(s4p_ctx* c, int32_t* quads, int32_t* counts, int64_t cap, int64_t* n_out) {
   if (!c || !n_out) return S4P_ERR_BAD_ARG;
+  if (c->last_chunked) S4P_FAIL(c, S4P_ERR_UNSUPPORTED, "the last base was processed in chunks: its per-candidate records were not kept");
   const uint64_t K = c->last_K;
   *n_out = int64_t(K);
   if (K == 0) return S4P_OK;
@@ -1038,6 +1275,7 @@ int32_t s4p_last_candidates(s4p_ctx* c, int32_t* quads, int32_t* counts, int64_t
 // inlier count and the 3x4 transform each was scored with (cand_T, kept in HBM by k_gate).
 int32_t s4p_last_verified(s4p_ctx* c, uint32_t* counts, float* transforms16, int64_t cap, int64_t* n_out) {
   if (!c || !n_out) return S4P_ERR_BAD_ARG;
+  if (c->last_chunked) S4P_FAIL(c, S4P_ERR_UNSUPPORTED, "the last base was processed in chunks: its per-candidate records were not kept");
   HIPCHK(c, hipSetDevice(c->device));
   const s4p_ctx::Lane& L = c->lane[c->cur];
   const uint32_t C = c->hctr[c->cur].p->C;

@@ -119,8 +119,8 @@ struct s4p_matcher {
   uint64_t candidates_verified = 0, quads_total = 0, pairs_total = 0, bases_tried = 0;
   double seconds_select = 0, seconds_device = 0;
   bool ready = false;
-  bool grow_on_overflow = true;          // Perform_N_steps: grow the device buffers and redo the base instead of failing
-  uint32_t capacity_growths = 0;
+  int64_t init_generation = 0;           // counts s4p_matcher_init calls (drivers keep per-registration state)
+  bool grow_on_overflow = true;          // a lane whose base overflows grows its buffers and redoes the base (s4p_set_auto_grow)
   std::atomic<bool> select_failed{false}; std::string select_err;   // a device selection attempt returned an error (possibly on the selector thread)
   bool visit_candidates = false;         // issue the reference's per-candidate visitor calls (fraction == -1)
   // pipelined trials: bases whose device pass is in flight (at most two)
@@ -635,6 +635,7 @@ const char* s4p_matcher_last_error(const s4p_matcher* m) { return m ? m->err.c_s
 s4p_ctx* s4p_matcher_ctx(s4p_matcher* m) { return m ? m->ctx : nullptr; }
 float s4p_matcher_terminate_threshold(const s4p_matcher* m) { return m ? m->opt.terminate_threshold : 0.f; }
 int32_t s4p_matcher_max_time_seconds(const s4p_matcher* m) { return m ? m->opt.max_time_seconds : 0; }
+int64_t s4p_matcher_init_generation(const s4p_matcher* m) { return m ? m->init_generation : -1; }
 
 int64_t s4p_uniform_dist_sample(const float* x, const float* y, const float* z, int64_t n, float delta, int64_t* out) {
   if (!x || !y || !z || !out || n <= 0 || !(delta > 0.f)) return 0;
@@ -647,7 +648,7 @@ int32_t s4p_matcher_init(s4p_matcher* m, const s4p_cloud_view* p, const s4p_clou
   producer_stop(m);
   drain_inflight(m);
   m->prod.consumed = 0; m->prod.next_index = 0;
-  m->ready = false;
+  m->ready = false; m->init_generation++;
   Cloud& Ps = m->Ps; Cloud& Qs = m->Qs;
   Ps = Cloud(); Qs = Cloud();
   Ps.init_flags(*p); Qs.init_flags(*q);
@@ -822,10 +823,10 @@ int32_t s4p_matcher_device_selection(const s4p_matcher* m) { return m && m->devi
 int32_t s4p_matcher_grow_on_overflow(s4p_matcher* m, int32_t enable) {
   if (!m) return S4P_ERR_BAD_ARG;
   m->grow_on_overflow = enable != 0;
-  return S4P_OK;
+  return s4p_set_auto_grow(m->ctx, enable);
 }
 
-int32_t s4p_matcher_capacity_growths(const s4p_matcher* m) { return m ? int32_t(m->capacity_growths) : 0; }
+int32_t s4p_matcher_capacity_growths(const s4p_matcher* m) { return m ? int32_t(s4p_lane_growths(m->ctx)) : 0; }
 
 int32_t s4p_matcher_visit_candidates(s4p_matcher* m, int32_t enable) {
   if (!m) return S4P_ERR_BAD_ARG;
@@ -924,20 +925,8 @@ int32_t s4p_matcher_perform_n_steps(s4p_matcher* m, int32_t n, s4p_visitor_fn vi
     fifo.erase(fifo.begin());
     s4p_base_result r;
     rc = wait_base(m, pr, r);
-    if (rc == S4P_ERR_CAPACITY && m->grow_on_overflow) {
-      // A device pair / quad buffer was too small for this base.  Bases never read results, so the speculation is rolled
-      // back to just before this base (RNG stream, octree permutation, producer threads), the buffers are grown to what
-      // the base's own counters ask for, and the loop resumes with the same base: same trials, same results, as if the
-      // limits had been large enough from the start.  Refused growth (device memory) stays the loud capacity error.
-      fifo.insert(fifo.begin(), std::move(pr));
-      fifo.front().device = false; fifo.front().slot = -1;  // its wait has returned (with the error) and released its slot
-      rewind_speculation(m);
-      if (s4p_grow_limits(m->ctx, 0, 0) != S4P_OK) { rc = m->ctx_fail(S4P_ERR_CAPACITY); break; }
-      m->capacity_growths++;
-      rc = S4P_OK; next_prep = i; --i;
-      continue;
-    }
     if (rc != S4P_OK) break;
+    // (a base whose quads were processed in chunks keeps no per-candidate records: s4p_last_verified then fails loudly)
     if (visitor && m->visit_candidates && pr.device && r.n_verified) {     // match4pcsBase.hpp:458-465
       std::vector<uint32_t> cnt(size_t(r.n_verified)); std::vector<float> Ts(size_t(r.n_verified) * 16);
       int64_t nv = 0;

@@ -405,14 +405,17 @@ struct LcpGridHost {
   int nx = 1, ny = 1, nz = 1;
   int cshift = 0, cnx = 1, cny = 1, cnz = 1;
   uint32_t coarse_words = 0;
-  double reach = 0;                         // 1.01 * delta
+  double reach = 0;                         // delta + 0.01 * h
   uint64_t ncell() const { return uint64_t(nx) * uint64_t(ny) * uint64_t(nz); }
 
   // Cell edge h >= 1.02 * delta.  The sweep LOCATES a query approximately: cell = floor of a fused-multiply-add transform
   // of the query quantised to 16 bit (at most 0.004 cell per axis, s4p_set_clouds), i.e. up to e = 0.007 cell away from
   // the cell of the exactly transformed query.  A P point p with |q - p| <= delta must still be in the list of the LOCATED
-  // cell c.  (i) Lists hold the points within 1.01 * delta of the cell's box: dist(p, box(c)) <= delta + e h < 1.0072
-  // delta.  (ii) The lists are built from each point's 27-cell neighbourhood only, so p's own cell must be a neighbour of c:
+  // cell c.  (i) Lists (and sub-cell masks) hold the points within reach = delta + 0.01 h of the cell's box, and
+  // dist(p, box(c)) <= delta + e h: the slack is a fraction of the CELL, like the locate error, so it also covers the
+  // cells enlarged by the loop below (x 1.25 per step when the grid would exceed max_cells or the 2^24 index limits) or by
+  // S4P_CELL_FACTOR -- with the former fixed 1.01 delta the condition e h <= 0.01 delta failed from h ~ 1.4 delta on.
+  // (ii) The lists are built from each point's 27-cell neighbourhood only, so p's own cell must be a neighbour of c:
   // p is at most delta + e h from box(c), which is less than one cell iff h (1 - e) >= delta, i.e. h >= 1.007 delta.
   // With the former 1.002 an inlier at distance ~delta straight across a cell face could land two cells from the located
   // cell and be missed (8 of 127 902 in tools/probe_locate_slack.py; tests/test_gpu_kernels.py holds that case now).
@@ -439,7 +442,7 @@ struct LcpGridHost {
     }
     inv_h = 1.0f / h;
     ox = lo[0] - 1.5f * h; oy = lo[1] - 1.5f * h; oz = lo[2] - 1.5f * h;
-    reach = double(delta) * 1.01;
+    reach = double(delta) + 0.01 * double(h);
     cshift = 0;      // coarse level: smallest shift whose bitmap fits the LDS budget (padded to 16 B for the staging)
     while (true) {
       cnx = ((nx - 1) >> cshift) + 1; cny = ((ny - 1) >> cshift) + 1; cnz = ((nz - 1) >> cshift) + 1;

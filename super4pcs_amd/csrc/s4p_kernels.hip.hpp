@@ -44,14 +44,31 @@ __device__ __forceinline__ void cross3(float ax, float ay, float az, float bx, f
   oz = ax * by - ay * bx;
 }
 
+// 64-bit mix of a congruent quad (indices into the sampled Q): the term of the order-independent checksums the fused
+// path keeps per base (DevCounters::quad_sum / cand_sum).  Exported as s4p_quad_mix so that a checker can form the same sums.
+__host__ __device__ inline unsigned long long quad_mix(int a, int b, int c, int d) {
+  unsigned long long x = (static_cast<unsigned long long>(uint32_t(a)) << 32) | uint32_t(b);
+  unsigned long long y = (static_cast<unsigned long long>(uint32_t(c)) << 32) | uint32_t(d);
+  x *= 0x9E3779B97F4A7C15ull; x ^= x >> 29;
+  y *= 0xC2B2AE3D27D4EB4Full; y ^= y >> 31;
+  const unsigned long long h = (x + y) * 0xD6E8FEB86659FD93ull;
+  return h ^ (h >> 32);
+}
+
 // ---------------------------------------------------------------------------
 // device-resident per-base counters / result
 // ---------------------------------------------------------------------------
 struct DevCounters {
-  uint32_t m1, m2, K, C;            // appended pairs1 / pairs2 / quads, verified candidates
+  uint32_t m1, m2;                  // appended pairs1 / pairs2 (contiguous: restored with one 8-byte copy by the chunk loop)
+  uint32_t C;                       // verified candidates
   uint32_t best_count;              // max inlier count (verified candidates only)
+  unsigned long long K;             // congruent quads FOUND: keeps counting past the capacity (64 bit: a base of a 20 000-point
+                                    // sample has ~10^9), so an overflowing pass reports what the base needs
   uint32_t overflow;                // bit0 pairs1, bit1 pairs2, bit2 quads
+  uint32_t pad_;
   unsigned long long best_tag;      // min tag among candidates with best_count
+  unsigned long long quad_sum;      // order-independent checksums (sum of quad_mix mod 2^64) over all quads found ...
+  unsigned long long cand_sum;      // ... and over the quads that passed the rms gate (fused path): parity at sizes where lists cannot be compared
   unsigned long long point_tests;   // optional instrumentation (COUNT kernels only)
   unsigned long long l0_pass, l1_pass, l2_pass;
   uint32_t done;                    // k_verify: workgroups that have published their best (last one selects the winner)
@@ -67,7 +84,7 @@ struct DevCounters {
 // Uniform grid of edge h >= 1.02*delta (LcpGridHost::plan says why), three levels, all conservative supersets of the
 // exact predicate "some P point with fl(dx^2+(dy^2+dz^2)) <= fl(delta^2)" (kdtree.h:417-421):
 //   L0  coarse bitmap (OR of 2^s-cubes of the reach bitmap), <= 48 KB, staged in LDS;
-//   L1  reach bitmap: bit(c) = some P point lies within 1.01*delta of the box of cell c,
+//   L1  reach bitmap: bit(c) = some P point lies within delta + 0.01 h of the box of cell c,
 //       stored as {bits, rank-prefix} records (one 8 B load gives the bit and the rank);
 //   L2  per reachable cell, a 16 B header {list start, count, 64-bit mask of the 4x4x4 sub-cells (edge h/4) that
 //       some listed point can reach} and the contiguous list of exactly those P points (float4 copies): one
@@ -115,7 +132,7 @@ __device__ __forceinline__ void transform_point(const float* T, const float4 q, 
 // transformed query.  Evaluated with fused multiply-adds: nine instructions per query instead of the 30 of "exact
 // transform, subtract origin, scale", and that is what stage 1 spends most of its time on.  It only LOCATES the query:
 // the result may differ from the exactly rounded cell coordinate by ~1e-5 cell, which the structure absorbs by
-// construction (a cell lists every P point within 1.01*delta of its box, LcpGridHost::plan; the 4x4x4 sub-cell masks
+// construction (a cell lists every P point within delta + 0.01 h of its box, LcpGridHost::plan; the 4x4x4 sub-cell masks
 // carry the same 1 % slack).  The inlier predicate itself (exact_batch) uses the exact, un-fused transform_point.
 // Only the coarse copy lives across the query loop (12 registers); the exact 3x4 and the fine-unit transform are
 // re-derived from the candidate's record where the dense stages need them -- keeping all 36 values live cost ~25 % of
@@ -1122,9 +1139,9 @@ __device__ __forceinline__ void store_candidate(const GateParams& G, const uint3
 // k_gate: one thread per congruent quad (s4p_try_congruent_set, where the quads come from the caller).  Passing
 // candidates are compacted (wave-aggregated append) into cand_idx / cand_T so that the scoring kernel sees a dense,
 // perfectly balanceable list; failing ones get counts[k] = kGateFailed.
-struct GateKernelParams { GateParams g; const int4* quads; const uint32_t* K_dev; uint32_t K_cap; };
+struct GateKernelParams { GateParams g; const int4* quads; const unsigned long long* K_dev; uint32_t K_cap; };
 __global__ __launch_bounds__(256) void k_gate(GateKernelParams P) {
-  const uint32_t K = min(*P.K_dev, P.K_cap);
+  const uint32_t K = uint32_t(min(*P.K_dev, (unsigned long long)P.K_cap));
   const uint32_t lane = threadIdx.x & 63u;
   for (uint32_t k0 = (blockIdx.x * blockDim.x + threadIdx.x) & ~63u; k0 < K; k0 += gridDim.x * blockDim.x) {
     const uint32_t k = k0 + lane;
@@ -1152,7 +1169,9 @@ struct QuadParams {
   const uint32_t* m2_dev; uint32_t cap2;
   HashTable ht;
   float thr;                   // distance_threshold2 (compared against a SQUARED norm: quirk super4pcs.cc:160)
-  int4* quads; unsigned long long* tags; uint32_t* K_dev; uint32_t K_cap; uint32_t* overflow;
+  int4* quads; unsigned long long* tags; unsigned long long* K_dev; uint32_t K_cap; uint32_t* overflow;
+  uint32_t r0, r1;                                       // set-2 entries [r0, min(r1, m2)): the whole set, or one chunk of a base whose quads do not fit
+  unsigned long long* qsum_dev; unsigned long long* csum_dev;   // checksums (DevCounters::quad_sum / cand_sum)
   int do_gate; GateParams gate;                          // fused path: gate every quad as it is appended
 };
 
@@ -1166,19 +1185,29 @@ constexpr int kQuadStage = S4P_QUAD_STAGE;   // quads per workgroup between two 
 // runs ComputeRigidTransformation + the rms gate on the staged quads -- one thread per quad, all 256 lanes busy,
 // instead of a separate launch that re-reads them -- and appends the survivors to the candidate list (one more
 // atomic per 256 quads).
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const uint32_t lo = uint32_t(__shfl_xor(int(uint32_t(v)), o)), hi = uint32_t(__shfl_xor(int(uint32_t(v >> 32)), o));
+    v += (static_cast<unsigned long long>(hi) << 32) | lo;
+  }
+  return v;
+}
+
 __global__ __launch_bounds__(256) void k_quads(QuadParams P) {
   __shared__ int4 st_q[kQuadStage];
   __shared__ unsigned long long st_t[kQuadStage];
-  __shared__ uint32_t st_n, st_base, s_wc[4], s_cbase;
+  __shared__ unsigned long long st_base, s_qsum, s_csum;
+  __shared__ uint32_t st_n, s_wc[4], s_cbase;
   __shared__ uint32_t s_mask[256 * kMaskWords];            // each thread's copy of its entry's direction mask (row stride 11: conflict-free)
-  const uint32_t m2 = min(*P.m2_dev, P.cap2);
+  const uint32_t end = min(min(*P.m2_dev, P.cap2), P.r1);
   const uint32_t hmask = hash_mask(P.ht);
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  if (threadIdx.x == 0) st_n = 0;
+  if (threadIdx.x == 0) { st_n = 0; s_qsum = 0ull; s_csum = 0ull; }
   __syncthreads();
-  for (uint32_t i0 = blockIdx.x * blockDim.x; i0 < m2; i0 += gridDim.x * blockDim.x) {
+  for (uint32_t i0 = P.r0 + blockIdx.x * blockDim.x; i0 < end; i0 += gridDim.x * blockDim.x) {
     const uint32_t i = i0 + threadIdx.x;
-    if (i < m2) {
+    if (i < end) {
       const uint32_t cell = P.cell2[i];
       const unsigned long long mykey = ((unsigned long long)P.ht.epoch << 32) | cell;
       uint32_t h = hash_cell(cell) & hmask;
@@ -1212,12 +1241,14 @@ __global__ __launch_bounds__(256) void k_quads(QuadParams P) {
             const uint32_t slot = atomicAdd(&st_n, 1u);
             if (slot < uint32_t(kQuadStage)) { st_q[slot] = quad; st_t[slot] = tag; }
             else {                                                                    // stage full (rare): direct append
-              const uint32_t at = atomicAdd(P.K_dev, 1u);
+              const unsigned long long at = atomicAdd(P.K_dev, 1ull);
+              const unsigned long long mix = quad_mix(quad.x, quad.y, quad.z, quad.w);
+              atomicAdd(&s_qsum, mix);
               if (at < P.K_cap) {
                 P.quads[at] = quad; P.tags[at] = tag;
                 if (P.do_gate) {
                   float T[12];
-                  if (gate_quad(P.gate, quad, T)) store_candidate(P.gate, atomicAdd(P.gate.C_dev, 1u), at, T);
+                  if (gate_quad(P.gate, quad, T)) { store_candidate(P.gate, atomicAdd(P.gate.C_dev, 1u), uint32_t(at), T); atomicAdd(&s_csum, mix); }
                   else P.gate.counts[at] = kGateFailed;
                 }
               } else atomicOr(P.overflow, 4u);
@@ -1230,21 +1261,25 @@ __global__ __launch_bounds__(256) void k_quads(QuadParams P) {
     __syncthreads();
     const uint32_t n = min(st_n, uint32_t(kQuadStage));
     if (n) {                                                   // uniform
-      if (threadIdx.x == 0) st_base = atomicAdd(P.K_dev, n);
+      if (threadIdx.x == 0) st_base = atomicAdd(P.K_dev, (unsigned long long)n);
       __syncthreads();
-      const uint32_t base = st_base;
+      const unsigned long long base = st_base;
       for (uint32_t c0 = 0; c0 < n; c0 += blockDim.x) {        // uniform trip count
         const uint32_t e = c0 + threadIdx.x;
-        const uint32_t at = base + e;
+        const unsigned long long at = base + e;
         const bool live = e < n && at < P.K_cap;
         if (e < n && at >= P.K_cap) atomicOr(P.overflow, 4u);
         int4 quad = make_int4(0, 0, 0, 0);
-        if (live) { quad = st_q[e]; P.quads[at] = quad; P.tags[at] = st_t[e]; }
+        unsigned long long mix = 0ull;
+        if (e < n) { quad = st_q[e]; mix = quad_mix(quad.x, quad.y, quad.z, quad.w); }   // counted (and summed) even when it does not fit
+        if (live) { P.quads[at] = quad; P.tags[at] = st_t[e]; }
+        { const unsigned long long ws = wave_sum_u64(mix); if (lane == 0 && ws) atomicAdd(&s_qsum, ws); }
         if (P.do_gate) {                                        // uniform
           float T[12];
           const bool ok = live && gate_quad(P.gate, quad, T);
           if (live && !ok) P.gate.counts[at] = kGateFailed;
           const unsigned long long pass = __ballot(ok);
+          { const unsigned long long ws = wave_sum_u64(ok ? mix : 0ull); if (lane == 0 && ws) atomicAdd(&s_csum, ws); }
           if (lane == 0) s_wc[wave] = uint32_t(__popcll(pass));
           __syncthreads();
           if (threadIdx.x == 0) { const uint32_t tot = s_wc[0] + s_wc[1] + s_wc[2] + s_wc[3]; s_cbase = tot ? atomicAdd(P.gate.C_dev, tot) : 0u; }
@@ -1252,7 +1287,7 @@ __global__ __launch_bounds__(256) void k_quads(QuadParams P) {
           if (ok) {
             uint32_t before = 0;
             for (uint32_t w = 0; w < wave; ++w) before += s_wc[w];
-            store_candidate(P.gate, s_cbase + before + uint32_t(__popcll(pass & ((1ull << lane) - 1ull))), at, T);
+            store_candidate(P.gate, s_cbase + before + uint32_t(__popcll(pass & ((1ull << lane) - 1ull))), uint32_t(at), T);
           }
           __syncthreads();                                      // s_wc / s_cbase are rewritten by the next chunk
         }
@@ -1261,6 +1296,10 @@ __global__ __launch_bounds__(256) void k_quads(QuadParams P) {
     __syncthreads();
     if (threadIdx.x == 0) st_n = 0;
     __syncthreads();
+  }
+  if (threadIdx.x == 0) {                                      // one pair of global atomics per workgroup that found anything
+    if (s_qsum) atomicAdd(P.qsum_dev, s_qsum);
+    if (s_csum) atomicAdd(P.csum_dev, s_csum);
   }
 }
 
@@ -1384,6 +1423,7 @@ __global__ __launch_bounds__(kVerifyMaxThreads, 8) void k_verify(VerifyParams P)
   DevCounters* c = P.ctr;
   DevCounters* r = P.res;
   r->m1 = c->m1; r->m2 = c->m2; r->K = c->K; r->C = C; r->overflow = c->overflow;
+  r->quad_sum = c->quad_sum; r->cand_sum = c->cand_sum;
   r->best_count = bc; r->best_tag = bt; r->has_best = 0u;
   if (COUNT || P.count_tests) { r->point_tests = c->point_tests; r->l0_pass = c->l0_pass; r->l1_pass = c->l1_pass; r->l2_pass = c->l2_pass; }
   if (bi != kNil) {                                        // recompute the winner's 4x4 (ComputeRigidTransformation)
@@ -1401,6 +1441,7 @@ __global__ __launch_bounds__(kVerifyMaxThreads, 8) void k_verify(VerifyParams P)
   }
   // the live counters are ready for the next base on this lane (no separate reset launch)
   c->m1 = 0; c->m2 = 0; c->K = 0; c->C = 0; c->best_count = 0; c->overflow = 0; c->best_tag = ~0ull; c->has_best = 0;
+  c->quad_sum = 0; c->cand_sum = 0;
   c->point_tests = 0; c->l0_pass = 0; c->l1_pass = 0; c->l2_pass = 0;
   __threadfence();
   c->done = 0;
@@ -1582,7 +1623,7 @@ __global__ void k_selftest(const float* a, const float* b, uint64_t n, float* o_
 // leaves them cleared for the next base of the lane.
 __global__ void k_reset_counters(DevCounters* c) {
   c->m1 = 0; c->m2 = 0; c->K = 0; c->C = 0; c->best_count = 0; c->overflow = 0;
-  c->best_tag = ~0ull; c->has_best = 0; c->done = 0;
+  c->best_tag = ~0ull; c->has_best = 0; c->done = 0; c->quad_sum = 0; c->cand_sum = 0;
   c->point_tests = 0; c->l0_pass = 0; c->l1_pass = 0; c->l2_pass = 0;
 }
 

@@ -35,6 +35,10 @@
 namespace {
 
 constexpr uint64_t kCrossBit = 1ull << 62;
+// A rank that failed locally (device error, refused buffer growth, ...) still owes the other ranks its all-reduce of the
+// window: it posts this key, which outranks every real one, so that every rank sees the failure in the same window and
+// leaves the loop together instead of blocking in a collective for ever.
+constexpr uint64_t kErrorKey = 0x7FFFFFFFFFFFFFFFull;      // (below 2^63: providers may carry keys as signed 64-bit integers)
 
 // Packs one trial's outcome so that max() over the window reproduces the sequential reference.
 // usable: pairs1, pairs2 and quads all non-empty (otherwise TryOneBase returned before TryCongruentSet).  A trial whose
@@ -97,7 +101,7 @@ static_assert(sizeof(ncclUniqueId) == 128, "s4p_rccl_unique_id hands out 128 byt
 // ---- collective providers: post() / result() are split so that the RCCL one can be asynchronous ---------------------
 struct Collective {
   virtual ~Collective() {}
-  virtual int32_t post(int slot, uint64_t key) = 0;          // all-reduce(MAX) of one key; slot in {0, 1}
+  virtual int32_t post(int slot, uint64_t key) = 0;          // all-reduce(MAX) of one key; slot in {0, 1, 2}
   virtual int32_t result(int slot, uint64_t* key) = 0;
   virtual int32_t broadcast(void* buf, size_t bytes, int root) = 0;
   std::string err;
@@ -105,7 +109,7 @@ struct Collective {
 
 struct CallbackCollective : Collective {                     // caller-supplied, synchronous
   s4p_collective c;
-  uint64_t val[2] = {0, 0};
+  uint64_t val[3] = {0, 0, 0};
   explicit CallbackCollective(const s4p_collective& cc) : c(cc) {}
   int32_t post(int slot, uint64_t key) override {
     val[slot] = key;
@@ -125,10 +129,10 @@ struct RcclCollective : Collective {                         // RCCL over xGMI, 
   int device = 0, rank = 0, world = 1;
   ncclComm_t comm = nullptr;
   hipStream_t stream = nullptr;
-  hipEvent_t ev[2] = {nullptr, nullptr};
-  uint64_t* host = nullptr;                                  // pinned: [0..1] keys, then a 256-byte record
+  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+  uint64_t* host = nullptr;                                  // pinned: [0..2] keys (two window slots + the time-budget vote), then a 256-byte record
   uint64_t* dev = nullptr;
-  static constexpr size_t kRecBytes = 256, kBytes = 16 + kRecBytes;
+  static constexpr size_t kRecBytes = 256, kKeyBytes = 32, kBytes = kKeyBytes + kRecBytes;
   bool hip_ok(hipError_t e, const char* what) { if (e != hipSuccess) { err = std::string(what) + ": " + hipGetErrorString(e); return false; } return true; }
   bool nccl_ok(ncclResult_t r, const char* what) {
     if (r != ncclSuccess) { err = std::string(what) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "rccl error"); return false; }
@@ -171,8 +175,8 @@ struct RcclCollective : Collective {                         // RCCL over xGMI, 
   }
   int32_t broadcast(void* buf, size_t bytes, int root) override {
     if (bytes > kRecBytes) { err = "broadcast record too large"; return S4P_ERR_BAD_ARG; }
-    char* hrec = reinterpret_cast<char*>(host) + 16;
-    char* drec = reinterpret_cast<char*>(dev) + 16;
+    char* hrec = reinterpret_cast<char*>(host) + kKeyBytes;
+    char* drec = reinterpret_cast<char*>(dev) + kKeyBytes;
     if (rank == root) std::memcpy(hrec, buf, bytes);
     if (!hip_ok(hipMemcpyAsync(drec, hrec, bytes, hipMemcpyHostToDevice, stream), "hipMemcpyAsync")) return S4P_ERR_HIP;
     if (!nccl_ok(g_rccl.Broadcast(drec, drec, bytes, ncclChar, root, comm, stream), "ncclBroadcast")) return S4P_ERR_STATE;
@@ -236,9 +240,11 @@ struct Loop {
   }
   int32_t complete_window(Window& w) {
     trials_done += uint64_t(world);
-    if (w.slot < 0 || terminated) return S4P_OK;
+    if (w.slot < 0) return S4P_OK;
     uint64_t key = 0;
-    if (int32_t rc = coll->result(w.slot, &key)) return fail(rc, coll->err);
+    if (int32_t rc = coll->result(w.slot, &key)) return fail(rc, coll->err);      // always consumed: the slot is reused
+    if (key == kErrorKey) return fail(S4P_ERR_STATE, "a rank of the sharded job failed in this window (see that rank's error)");
+    if (terminated) return S4P_OK;                           // a window posted before the threshold was crossed: not committed
     const Decoded d = decode_key(key);
     if (d.any && d.count > best_count) {                     // the window improved the best LCP: fetch the winner's record
       if (d.trial >= uint32_t(world)) return fail(S4P_ERR_STATE, "corrupt window key");
@@ -257,22 +263,39 @@ struct Loop {
   int32_t run(int n) {
     std::deque<Window> prepared;
     Window posted; bool have_posted = false;
+    int posted_n = 0;                                        // windows of this call whose key this rank has posted
+    bool remote_error = false;
     auto advance = [&]() -> int32_t {
       Window nxt = std::move(prepared.front());
       prepared.pop_front();
       if (int32_t rc = post_window(nxt)) return rc;
-      if (have_posted) if (int32_t rc = complete_window(posted)) return rc;
+      if (nxt.slot >= 0) ++posted_n;
+      if (have_posted) if (int32_t rc = complete_window(posted)) { remote_error = true; return rc; }
       posted = std::move(nxt);
       have_posted = true;
       return S4P_OK;
     };
+    // A LOCAL failure: the other ranks post one window ahead of the one they complete, so they are (or will be) inside the
+    // all-reduce of the next window this rank has not posted, and of the one after it: post the error key for both.
+    auto leave = [&](int32_t rc) -> int32_t {
+      if (rc == S4P_OK || remote_error || terminated || !coll) return rc;
+      const std::string keep = err;
+      for (int k = 0; k < 2 && posted_n < n; ++k, ++posted_n) {
+        const int slot = slot_rr; slot_rr ^= 1;
+        uint64_t dummy = 0;
+        if (coll->post(slot, kErrorKey) != S4P_OK || coll->result(slot, &dummy) != S4P_OK) break;
+      }
+      err = keep;
+      return rc;
+    };
     for (int w = 0; w < n; ++w) {
+      if (terminated) break;                                 // threshold crossed: no further bases are selected or launched
       prepared.emplace_back();
-      if (int32_t rc = prepare_window(prepared.back())) return rc;
-      if (int(prepared.size()) >= ops.depth) if (int32_t rc = advance()) return rc;
+      if (int32_t rc = prepare_window(prepared.back())) return leave(rc);
+      if (int(prepared.size()) >= ops.depth) if (int32_t rc = advance()) return leave(rc);
     }
-    while (!prepared.empty()) if (int32_t rc = advance()) return rc;
-    if (have_posted) if (int32_t rc = complete_window(posted)) return rc;
+    while (!prepared.empty()) if (int32_t rc = advance()) return leave(rc);
+    if (have_posted) if (int32_t rc = complete_window(posted)) { remote_error = true; return rc; }
     return S4P_OK;
   }
 };
@@ -281,6 +304,7 @@ struct Loop {
 
 struct s4p_shard {
   s4p_matcher* m = nullptr;
+  int64_t init_generation = -1;        // the matcher initialisation the loop state belongs to
   Loop loop;
   Collective* coll = nullptr;
   std::string err;
@@ -336,6 +360,10 @@ int32_t s4p_shard_run_windows(s4p_shard* s, int32_t n_windows, uint64_t* candida
   s4p_matcher_info info;
   if (int32_t rc = s4p_matcher_get_info(m, &info)) { s->err = s4p_matcher_last_error(m); return rc; }
   Loop& L = s->loop;
+  if (s->init_generation != s4p_matcher_init_generation(m)) {      // the matcher was (re-)initialised: a new registration
+    s->init_generation = s4p_matcher_init_generation(m);
+    L.terminated = false; L.trials_done = 0; L.trials_prepared = 0; L.slot_rr = 0;
+  }
   L.coll = s->coll;
   L.best_count = info.best_count;
   L.threshold_count = threshold_count_for(uint32_t(info.n_sampled_q), s4p_matcher_terminate_threshold(m));
@@ -379,7 +407,8 @@ int32_t s4p_shard_compute_transformation(s4p_shard* s, const s4p_cloud_view* P, 
   *lcp = 1e9f;                                                     // kLargeNumber, match4pcsBase.hpp:69-70
   if (!P || !Q || P->n == 0 || Q->n == 0) return S4P_OK;
   if (int32_t rc = s4p_matcher_init_full(m, P, Q)) { s->err = s4p_matcher_last_error(m); return rc; }
-  s->loop.terminated = false; s->loop.trials_done = 0; s->loop.trials_prepared = 0;
+  s->init_generation = s4p_matcher_init_generation(m);
+  s->loop.terminated = false; s->loop.trials_done = 0; s->loop.trials_prepared = 0; s->loop.slot_rr = 0;
   s4p_matcher_info info;
   if (int32_t rc = s4p_matcher_get_info(m, &info)) return rc;
   const float lcp0 = info.best_lcp;
@@ -404,8 +433,8 @@ int32_t s4p_shard_compute_transformation(s4p_shard* s, const s4p_cloud_view* P, 
       const long el = long(std::chrono::duration_cast<std::chrono::seconds>(std::chrono::system_clock::now() - t0).count());
       const uint64_t mine = (max_seconds > 0 && float(el / max_seconds) >= 0.99f) ? 1u : 0u;
       uint64_t any = 0;
-      if (int32_t rc = s->coll->post(0, mine)) { s->err = s->coll->err; return rc; }
-      if (int32_t rc = s->coll->result(0, &any)) { s->err = s->coll->err; return rc; }
+      if (int32_t rc = s->coll->post(2, mine)) { s->err = s->coll->err; return rc; }      // a slot of its own: never a window's
+      if (int32_t rc = s->coll->result(2, &any)) { s->err = s->coll->err; return rc; }
       if (any) break;
     }
     s->loop.trial_limit = ~0ull;
@@ -453,6 +482,7 @@ int32_t s4p_shard_replay(int32_t rank, int32_t world, const s4p_collective* coll
     if (own.empty()) return S4P_ERR_STATE;
     *r = results[own.front()];
     own.pop_front(); ++waited;
+    if (r->n_quads == ~0ull) { L.err = "injected failure of this rank's device pass"; return S4P_ERR_CAPACITY; }   // (tests: the collective abort)
     return S4P_OK;
   };
   L.ops.commit = [&](const int32_t ids[4], const s4p_base_result* r, bool* ok) -> int32_t {

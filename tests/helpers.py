@@ -44,3 +44,22 @@ def attributes_for(P, Q, T_gt, seed=0):
     Pc = col(P.astype(np.float64)) + 0.01 * rng.normal(size=P.shape)
     Qc = col(Qp) + 0.01 * rng.normal(size=Q.shape)
     return Pn.astype(np.float32), np.clip(Pc, 0, 1).astype(np.float32), Qn.astype(np.float32), np.clip(Qc, 0, 1).astype(np.float32)
+
+
+def quad_mix(quads):
+    """numpy form of s4p_quad_mix (include/s4p_capi.h): uint64 per quad; checksums are sums mod 2^64."""
+    q = np.asarray(quads, np.int64).reshape(-1, 4)
+    m = np.uint64(0xFFFFFFFF)
+    a, b, c, d = [(q[:, k].astype(np.uint64) & m) for k in range(4)]
+    x = (a << np.uint64(32)) | b
+    y = (c << np.uint64(32)) | d
+    with np.errstate(over="ignore"):
+        x = x * np.uint64(0x9E3779B97F4A7C15); x ^= x >> np.uint64(29)
+        y = y * np.uint64(0xC2B2AE3D27D4EB4F); y ^= y >> np.uint64(31)
+        h = (x + y) * np.uint64(0xD6E8FEB86659FD93)
+    return h ^ (h >> np.uint64(32))
+
+
+def checksum(quads):
+    with np.errstate(over="ignore"):
+        return int(np.sum(quad_mix(quads), dtype=np.uint64)) if len(quads) else 0

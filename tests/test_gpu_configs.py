@@ -223,12 +223,16 @@ def test_config4_part_in_whole_10m_scene(oracle_mod, s4p_lib_built):
         assert quads >= 148 and cand >= 42
 
 
-def test_config2_gpu_scale_sample_20000_pairs(oracle_mod, s4p_lib_built):
-    """configs[2] at the "GPU-scale" sample size of SURVEY.md 8d (n = 20 000 sampled Q points): ExtractPairs of the first
-    base, both sets (16.8 M and 10.2 M ordered pairs), in the reference's emission order against the oracle; then the fused
-    pass of that base must either fit the configured capacities or fail LOUDLY with S4P_ERR_CAPACITY (the congruent quads of
-    one base at this sample size run into the billions: the reference itself is not usable there, its O(m1 x m2) quad
-    search alone takes > 25 CPU-minutes per base)."""
+def test_config2_gpu_scale_sample_20000(oracle_mod, s4p_lib_built):
+    """configs[2] at the "GPU-scale" sample size of SURVEY.md 8d (n = 20 000 sampled Q points), first base of the seeded
+    sequence.  ExtractPairs, both sets (16.8 M and 10.2 M ordered pairs), in the reference's emission order against the
+    oracle; then the FUSED pass of that base to completion.  Its ~10^9 congruent quads exceed any quad buffer, so the base
+    is chunked (ranges of the second pair set -> enumerate -> gate -> score -> fold).  Lists of that size cannot be compared
+    (the reference's own std::set would need ~50 GB); the oracle's streaming enumeration (OpenMP over set 2, pinned to the
+    list form on small cases, tests/test_oracle.py) gives the number of quads, the number that pass the rms gate and the
+    order-independent checksums of both, plus a deterministic subsample of the gated quads whose inlier counts the
+    stage-level entry point and the oracle's kd-tree Verify must agree on; the winner's gate and count are recomputed by
+    the oracle and no sampled candidate may beat it."""
     from super4pcs_amd import capi, datasets as D
     import bench
     from bench import seg_len32
@@ -247,19 +251,29 @@ def test_config2_gpu_scale_sample_20000_pairs(oracle_mod, s4p_lib_built):
     assert ok
     ctx.set_base(bx)
     eps = 2.0 * bench.DELTA
-    total = 0
+    sets = []
     for a, b in ((0, 1), (2, 3)):
         d = seg_len32(bx[a], bx[b])
-        want = om.extract_pairs_cap(d, 0.0, eps, a, b, 1 << 25)
-        got = ctx.extract_pairs(d, 0.0, eps, a, b, cap=1 << 25)
-        assert got.shape == want.shape and np.array_equal(got, want)          # same pairs, same emission order
-        total += want.shape[0]
-    assert total > 20_000_000
-    # the fused pass of one base: loud capacity error, never a silent truncation
-    gm = capi.Matcher(capi.make_options(bench.DELTA, bench.OVERLAP, n_s), max_pairs=32 << 20, max_quads=16 << 20)
+        want_p = om.extract_pairs_cap(d, 0.0, eps, a, b, 1 << 25)
+        got_p = ctx.extract_pairs(d, 0.0, eps, a, b, cap=1 << 25)
+        assert got_p.shape == want_p.shape and np.array_equal(got_p, want_p)          # same pairs, same emission order
+        sets.append(want_p)
+    assert sets[0].shape[0] + sets[1].shape[0] > 20_000_000
+    want = om.count_congruent(i1, i2, eps, sets[0], sets[1], base=base, sample_mod=1 << 18, sample_cap=1 << 14)
+    # default limits (1 Mi pairs, 4 Mi quads): the lane grows its pair buffers and redoes the base, then chunks its quads
+    gm = capi.Matcher(capi.make_options(bench.DELTA, bench.OVERLAP, n_s))
     gm.init_full(P, Q)
-    try:
-        _ok, r = gm.try_one_base()
-        assert r.n_quads <= (16 << 20)
-    except capi.S4PError as e:
-        assert e.code == -5 and "overflow" in str(e)
+    _ok, r = gm.try_one_base()
+    assert (r.n_pairs1, r.n_pairs2) == (sets[0].shape[0], sets[1].shape[0])
+    assert (r.n_quads, r.quad_checksum) == (want["K"], want["quad_sum"])
+    assert (r.n_verified, r.cand_checksum) == (want["C"], want["cand_sum"])
+    st = gm.chunk_stats()
+    assert r.n_quads > (200 << 20) and st["bases"] == 1 and st["passes"] >= 8 and gm.capacity_growths() >= 1
+    smp = want["sample"]
+    assert len(smp) >= 100
+    _nb, w_per, _bc, _bi = om.try_congruent_set(base, np.array([list(r.best_quad)], np.int32))
+    assert w_per[0] == r.best_count
+    _nb, o_per, _bc, _bi = om.try_congruent_set(base, smp[:300])
+    _gr, g_per = ctx.try_congruent_set(base, smp[:300])
+    assert np.array_equal(g_per, o_per) and (o_per >= 0).all()
+    assert o_per.max() <= r.best_count

@@ -218,17 +218,22 @@ def test_gpu_sampler_equals_host_and_oracle(oracle_mod, s4p_lib_built, monkeypat
     assert np.array_equal(Y[capi.uniform_dist_sample(Y, 0.004)], oracle_mod.sample(Y, 0.004))
 
 
-def test_quantised_locate_cannot_lose_an_inlier_at_distance_delta(s4p_lib_built):
+@pytest.mark.parametrize("cell_factor", [None, 1.6, 2.5])
+def test_quantised_locate_cannot_lose_an_inlier_at_distance_delta(s4p_lib_built, cell_factor, monkeypatch):
     """Adversarial case for the LCP structure's locating slack (LcpGridHost::plan): queries quantised to 16 bit over a long
     bounding box (half a quantisation step = 0.0039 cell, the largest the LDS path accepts), every query exactly one P point
     at distance delta (1 - 1e-6) straight along -x, 64 transforms that move the pairs across the cell faces.  A query that
     the quantised locate puts into the cell next to its true one must still find its point: counts equal a brute-force
-    float32 count.  (With cells of 1.002 delta this lost 8 inliers of 127 902.)"""
+    float32 count.  (With cells of 1.002 delta this lost 8 inliers of 127 902.)  cell_factor 1.6 / 2.5: the same with the
+    enlarged cells LcpGridHost::plan falls back to for huge extents -- the locate error is a fraction of the CELL, so the
+    reach of the lists must be too (delta + 0.01 h; a fixed 1.01 delta stops covering it from h ~ 1.4 delta on)."""
     from super4pcs_amd import capi
     F = np.float32
     delta, n = 1.0, 2000
     rng = np.random.default_rng(5)
-    h = 1.002 * delta
+    h = (cell_factor or 1.002) * delta
+    if cell_factor:
+        monkeypatch.setenv("S4P_CELL_FACTOR", str(cell_factor))
     ext = 0.0078 * h * 65535.0
     Q = np.stack([rng.uniform(0, ext, n), rng.uniform(0, 3, n), rng.uniform(0, 3, n)], axis=1).astype(F)
     Q[0, 0], Q[1, 0] = 0.0, ext

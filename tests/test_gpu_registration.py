@@ -355,3 +355,64 @@ def test_capacity_growth_replays_the_overflowing_base(oracle_mod, s4p_lib_built,
     with pytest.raises(capi.S4PError) as e:
         strict.compute_transformation(P, Q)
     assert e.value.code == capi.S4P_ERR_CAPACITY
+
+
+def test_chunked_bases_equal_the_unbounded_registration(oracle_mod, s4p_lib_built):
+    """Quad buffers of 1500 entries that may not grow (chunk cap = 1500) against bases with tens of thousands of congruent
+    quads: every such base is enumerated, gated and scored in CHUNKS (ranges of the second pair set), the chunk bests folded
+    with the first-maximum rule -- and the registration equals the oracle's (whose std::vectors simply grow) to the
+    candidate, as do the per-base quad / candidate counts and their order-independent checksums."""
+    from super4pcs_amd import capi
+    from bench import seg_len32
+    O = oracle_mod
+    delta, overlap, n_s = 0.01, 0.6, 200
+    P, Q, _ = H.small_pair(20000, delta=delta, seed=3)
+    om = O.Matcher(O.make_options(delta, overlap, n_s), full_counts=False, use_kdtree=True)
+    o_lcp, o_M, _ = om.compute_transformation(P, Q)
+    gm = capi.Matcher(capi.make_options(delta, overlap, n_s), max_quads=1500)
+    gm.set_quad_chunking(True, 1500)
+    g_lcp, g_M, _ = gm.compute_transformation(P, Q)
+    assert g_lcp == o_lcp and np.array_equal(g_M, o_M)
+    gi, os_ = gm.info(), om.stats()
+    assert (gi.pairs_total, gi.quads_total, gi.candidates_verified) == (os_.n_pairs, os_.n_quads, os_.n_verified)
+    st = gm.chunk_stats()
+    assert st["bases"] > 10 and st["passes"] >= 2 * st["bases"] and gm.limits()[1] == 1500
+    # base by base: counts and checksums of chunked bases against the oracle's lists
+    of = O.Matcher(O.make_options(delta, overlap, n_s), full_counts=True, use_kdtree=True)
+    of.init(P, Q)
+    g2 = capi.Matcher(capi.make_options(delta, overlap, n_s), max_quads=1500)
+    g2.set_quad_chunking(True, 1500)
+    g2.init_full(P, Q)
+    eps = 2.0 * delta
+    chunked = 0
+    for _ in range(12):
+        before = g2.chunk_stats()["bases"]
+        _ok, r = g2.try_one_base()
+        ok, i1, i2, base, bx = of.select_quadrilateral()
+        if not ok:
+            continue
+        p1 = of.extract_pairs(seg_len32(bx[0], bx[1]), 0.0, eps, 0, 1)
+        p2 = of.extract_pairs(seg_len32(bx[2], bx[3]), 0.0, eps, 2, 3)
+        assert (r.n_pairs1, r.n_pairs2) == (len(p1), len(p2))
+        if not (len(p1) and len(p2)):
+            continue
+        quads = of.find_congruent(i1, i2, eps, p1, p2)
+        _nb, per, _bc, _bi = of.try_congruent_set(base, quads)
+        assert (r.n_quads, r.quad_checksum) == (len(quads), H.checksum(quads))
+        assert (r.n_verified, r.cand_checksum) == (int((per >= 0).sum()), H.checksum(quads[per >= 0]))
+        if r.n_verified:
+            k = int(np.flatnonzero(per == per.max())[0])           # first maximum in std::set order
+            assert r.best_count == per.max() and list(r.best_quad) == quads[k].tolist()
+        if g2.chunk_stats()["bases"] > before:
+            chunked += 1
+            with pytest.raises(capi.S4PError) as e:
+                g2.last_candidates(16)
+            assert e.value.code == -6
+    assert chunked >= 3
+    # chunking off: the same base fails loudly
+    strict = capi.Matcher(capi.make_options(delta, overlap, n_s), max_quads=1500)
+    strict.set_quad_chunking(False)
+    strict.grow_on_overflow(False)
+    with pytest.raises(capi.S4PError) as e:
+        strict.compute_transformation(P, Q)
+    assert e.value.code == capi.S4P_ERR_CAPACITY

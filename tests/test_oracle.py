@@ -156,3 +156,36 @@ def test_config1_hippo_fixture_is_what_the_oracle_computes(oracle_mod):
     assert lcp == np.float32(g["lcp"]) and m.stats().n_verified == int(g["n_candidates"])
     T, l2, base, cong, _, _ = m.best()
     assert np.array_equal(T, g["transform"]) and np.array_equal(base, g["base"]) and np.array_equal(cong, g["congruent"])
+
+
+def test_streaming_quad_count_equals_the_list_enumeration(oracle_mod):
+    """oracle.count_congruent (OpenMP, counts + order-independent checksums: the checker for bases whose ~10^9 quads cannot
+    be listed) against find_congruent / try_congruent_set, which are pinned to the reference's own sources: same number of
+    quads, same checksum, same gate decisions, and the subsample is exactly the gated quads whose mix is 0 mod sample_mod."""
+    O = oracle_mod
+    delta, overlap, n_s = 0.01, 0.6, 300
+    P, Q, _ = H.small_pair(20000, delta=delta, seed=11)
+    om = H.init_oracle(O, P, Q, delta, overlap, n_s)
+    eps = 2.0 * delta
+    seen = 0
+    for _ in range(6):
+        ok, i1, i2, base, bx = om.select_quadrilateral()
+        if not ok:
+            continue
+        p1 = om.extract_pairs(float(np.float32(np.linalg.norm(bx[0] - bx[1]))), 0.0, eps, 0, 1)
+        p2 = om.extract_pairs(float(np.float32(np.linalg.norm(bx[2] - bx[3]))), 0.0, eps, 2, 3)
+        if not (len(p1) and len(p2)):
+            continue
+        quads = om.find_congruent(i1, i2, eps, p1, p2)
+        _nb, per, _bc, _bi = om.try_congruent_set(base, quads)
+        gated = quads[per >= 0]
+        for threads in (1, 4):
+            got = om.count_congruent(i1, i2, eps, p1, p2, base=base, threads=threads, sample_mod=7)
+            assert (got["K"], got["quad_sum"]) == (len(quads), H.checksum(quads))
+            assert (got["C"], got["cand_sum"]) == (len(gated), H.checksum(gated))
+            want = gated[H.quad_mix(gated) % np.uint64(7) == 0] if len(gated) else gated
+            want = want[np.lexsort(want.T[::-1])] if len(want) else want
+            assert np.array_equal(got["sample"], want)
+        assert om.L.s4po_quad_mix(1, 2, 3, 4) == int(H.quad_mix([[1, 2, 3, 4]])[0]) == 6837720401966776326
+        seen += len(quads)
+    assert seen > 1000

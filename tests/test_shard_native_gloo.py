@@ -33,7 +33,7 @@ def sequential_commits(table, start_best, threshold_count):
     return commits
 
 
-def _worker(rank, world, port, seed, n_windows, threshold_count, depth, q):
+def _worker(rank, world, port, seed, n_windows, threshold_count, depth, q, fail_at=None):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     from super4pcs_amd import capi
@@ -49,11 +49,17 @@ def _worker(rank, world, port, seed, n_windows, threshold_count, depth, q):
             r.best_count = count
             r.has_best = 1
             r.best_quad[0] = w * world + rank
+        if fail_at == (rank, w):
+            f = True
+            r.n_quads = 2 ** 64 - 1                     # this rank's device pass of window w "fails"
         found.append(f)
         results.append(r)
     coll = capi.torch_collective(dist)
-    commits, terminated, trials_done = capi.shard_replay(rank, world, coll, found, results, depth, threshold_count, 3)
-    q.put((rank, commits, terminated, trials_done))
+    try:
+        commits, terminated, trials_done = capi.shard_replay(rank, world, coll, found, results, depth, threshold_count, 3)
+        q.put((rank, commits, terminated, trials_done))
+    except capi.S4PError as e:
+        q.put((rank, "error", e.code, 0))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -66,12 +72,12 @@ def _free_port():
     return p
 
 
-def _run(world, seed, n_windows, threshold_count, depth):
+def _run(world, seed, n_windows, threshold_count, depth, fail_at=None):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, seed, n_windows, threshold_count, depth, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, seed, n_windows, threshold_count, depth, q, fail_at)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=180) for _ in range(world))
@@ -111,3 +117,16 @@ def test_native_loop_stops_committing_at_the_first_crossing_trial(world, seed, s
         for t, c in want:
             seq_by_window[t // world] = (t, c)
         assert commits == [seq_by_window[w] for w in sorted(seq_by_window)]
+
+
+@pytest.mark.parametrize("world,fail_rank,fail_window,depth", [(2, 1, 5, 3), (2, 0, 0, 1), (4, 2, 11, 3), (4, 3, 7, 2)])
+def test_a_failing_rank_takes_every_rank_out_of_the_loop(world, fail_rank, fail_window, depth, s4p_lib_built):
+    """One rank's device pass fails (a refused buffer growth, a HIP error): it still owes the others its all-reduce of that
+    window.  It posts the error key, so every rank returns an error from the same window instead of blocking in a
+    collective for ever (the run would hit this test's 180 s queue timeout)."""
+    n_windows = 12
+    res = _run(world, 1, n_windows, N_Q, depth, fail_at=(fail_rank, fail_window))
+    assert len(res) == world
+    for rank, tag, code, _ in res:
+        assert tag == "error"
+        assert code == (-5 if rank == fail_rank else -7)        # the failing rank keeps its own error; the others: S4P_ERR_STATE
