@@ -113,6 +113,14 @@ int64_t s4p_lane_growths(const s4p_ctx* ctx);
 int32_t s4p_set_quad_chunking(s4p_ctx* ctx, int32_t enable, uint64_t grow_cap_quads);
 int32_t s4p_chunk_stats(const s4p_ctx* ctx, uint64_t* out4);
 
+/* options.max_angle (shared4pcs.h:160).  > 0: the segment-angle pair filter acosf(segment1 . segment2) <= max_angle
+ * (pairCreationFunctor.h:203-212) runs on the device as an exact cosine threshold (the smallest float whose libm acosf
+ * passes, found with libm at s4p_create).  >= 0: the Euler-angle bound of ComputeRigidTransformation
+ * (match4pcsBase.cc:457-472) is decided on the device up to a margin of 1e-6 rad; the about one candidate in 10^6 inside
+ * the margin is scored on the device but admitted or rejected by the HOST with the reference's own libm expression, so
+ * the set of verified candidates is the reference's.  s4p_border_stats: {candidates settled by the host, rejected}. */
+int32_t s4p_border_stats(const s4p_ctx* ctx, uint64_t* out2);
+
 /* ---- state ---------------------------------------------------------------- */
 /* Uploads the sampled, centred clouds and builds the device structures.
  * Replaces Match4PCSBase::initKdTree (match4pcsBase.cc:353-363; the kd-tree becomes

@@ -40,6 +40,25 @@ uint32_t pair_split(uint32_t n_q) {
   static const uint32_t target = getenv("S4P_PAIR_ITEMS") ? uint32_t(atoi(getenv("S4P_PAIR_ITEMS"))) : 4096u;      // tuning aid
   return std::min<uint32_t>(8u, std::max<uint32_t>(1u, target / std::max<uint32_t>(n_q, 1u)));
 }
+// Smallest float x with acosf(x) <= theta, acosf being libm's (what the reference's std::acos(float) calls): the
+// segment-angle filter "acos(d) <= theta" (pairCreationFunctor.h:205,209) then is "d >= x && d <= 1" exactly, provided
+// acosf is monotone around x -- checked over +-512 neighbouring floats (its error is < 1 ulp while 512 ulps of the
+// argument move the result by hundreds of ulps, so a violation further out is impossible).
+uint32_t float_key(float f) { uint32_t b; std::memcpy(&b, &f, 4); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
+float key_float(uint32_t k) { const uint32_t b = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k; float f; std::memcpy(&f, &b, 4); return f; }
+float angle_threshold(double theta, bool* monotone) {
+  auto pass = [&](float x) { return double(std::acos(x)) <= theta; };
+  *monotone = true;
+  if (!pass(1.0f)) return 2.0f;                            // nothing passes (theta < 0)
+  if (pass(-1.0f)) return -1.0f;                           // everything in [-1, 1] passes (theta >= pi)
+  uint32_t lo = float_key(-1.0f), hi = float_key(1.0f);    // lo fails, hi passes
+  while (hi - lo > 1u) { const uint32_t mid = lo + (hi - lo) / 2u; if (pass(key_float(mid))) hi = mid; else lo = mid; }
+  for (uint32_t d = 0; d < 512u; ++d) {
+    if (hi + d <= float_key(1.0f) && !pass(key_float(hi + d))) *monotone = false;
+    if (lo - d >= float_key(-1.0f) && lo >= d && pass(key_float(lo - d))) *monotone = false;
+  }
+  return key_float(hi);
+}
 }  // namespace
 
 struct s4p_ctx {
@@ -90,6 +109,7 @@ struct s4p_ctx {
     hipStream_t vstream = nullptr; hipEvent_t chain = nullptr;
     DevBuf<DevCounters> ctr;          // [0] live counters of the base in flight, [1] its result record (what the host reads)
     DevBuf<uint4> slots;              // k_verify: per-workgroup best, reduced by its last workgroup
+    DevBuf<uint32_t> border;          // k_verify: candidates whose Euler-angle gate the host settles (max_angle >= 0), kBorderCap entries
     bool dirty = false;               // a stage-level call left the live counters non-zero: clear before a fused pass
     DevBuf<uint32_t> seq[2];          // device copy of a staged sequence blob (layout: StageSlot)
     // launch record of the base in flight: what a relaunch after a buffer growth needs (finish_result)
@@ -129,6 +149,11 @@ struct s4p_ctx {
   // No other lane, no host state (RNG stream, octree permutation) is involved, so single-GPU and sharded loops alike go on
   // as if the buffers had been large enough.  Off: S4P_ERR_CAPACITY, the stage-level contract.
   bool auto_grow = true; uint64_t lane_growths = 0;
+  // max_angle (shared4pcs.h:160): > 0 -> the segment-angle pair filter through an exact cosine threshold; >= 0 -> the
+  // Euler-angle bound of ComputeRigidTransformation, decided on the device up to a margin and settled on the host
+  float cos_min = -1.f; bool angle_pairs = false;
+  uint64_t border_settled = 0, border_rejected = 0;
+  std::vector<uint32_t> border_failed;   // quads of the last pass whose undecided gate the host rejected (per-candidate outputs say -1 for them)
   bool last_chunked = false;         // the per-candidate records of the last base were overwritten chunk by chunk
   bool broken = false;               // a growth failed half-way: the lane buffers are inconsistent, every pass is refused
   uint64_t chunk_bases = 0, chunk_passes = 0, chunk_splits = 0, chunk_quads = 0;
@@ -234,6 +259,10 @@ int32_t upload_pairs_staged(s4p_ctx* c, int slot, int set, float pair_distance_e
   P.counter = set == 0 ? &L.ctr.p->m1 : &L.ctr.p->m2;
   P.cap = uint32_t(L.cap_pairs); P.overflow = &L.ctr.p->overflow; P.overflow_bit = set == 0 ? 1u : 2u;
   P.split = pair_split(c->n_q);
+  { float sx = c->base_xyz[3 * bp2] - c->base_xyz[3 * bp1], sy = c->base_xyz[3 * bp2 + 1] - c->base_xyz[3 * bp1 + 1],
+          sz = c->base_xyz[3 * bp2 + 2] - c->base_xyz[3 * bp1 + 2];                 // setBase, pairCreationFunctor.h:135-143
+    normalize3(sx, sy, sz);
+    P.seg1[0] = sx; P.seg1[1] = sy; P.seg1[2] = sz; P.cos_min = c->cos_min; }
   return S4P_OK;
 }
 
@@ -242,7 +271,8 @@ int32_t upload_pairs_staged(s4p_ctx* c, int slot, int set, float pair_distance_e
 int32_t launch_pairs_kernel(s4p_ctx* c, const PairParams2& PP, int n_sets) {
   const uint32_t items = c->n_q * pair_split(c->n_q);
   const uint32_t wgs = std::min<uint32_t>(std::max<uint32_t>((items + kPairWaves - 1u) / kPairWaves, 1u), 4096u);
-  hipLaunchKernelGGL(k_pairs, dim3(wgs, uint32_t(n_sets)), dim3(64 * kPairWaves), 0, c->lane[c->cur].stream, PP);
+  if (c->angle_pairs) hipLaunchKernelGGL(k_pairs<true>, dim3(wgs, uint32_t(n_sets)), dim3(64 * kPairWaves), 0, c->lane[c->cur].stream, PP);
+  else hipLaunchKernelGGL(k_pairs<false>, dim3(wgs, uint32_t(n_sets)), dim3(64 * kPairWaves), 0, c->lane[c->cur].stream, PP);
   HIPCHK(c, hipGetLastError());
   return S4P_OK;
 }
@@ -297,6 +327,10 @@ BaseFrame make_base_frame(const s4p_ctx* c, const int32_t* base_ids) {
   for (int i = 0; i < 3; ++i) { b.p[i][0] = c->hpx[base_ids[i]]; b.p[i][1] = c->hpy[base_ids[i]]; b.p[i][2] = c->hpz[base_ids[i]]; }
   for (int k = 0; k < 3; ++k) b.c1[k] = ((b.p[0][k] + b.p[1][k]) + b.p[2][k]) / 3.f;   // match4pcsBase.hpp:385
   b.gate = 2.0f * c->opt.delta;                                                        // distance_factor * delta
+  b.max_angle_rad = float(double(c->opt.max_angle) * std::acos(-1.0) / 180.0);         // match4pcsBase.hpp:392,426
+  b.angle_gate = c->opt.max_angle >= 0.f ? 1 : 0;                                      // match4pcsBase.cc:457
+  static const float tol = getenv("S4P_ANGLE_TOL") ? float(atof(getenv("S4P_ANGLE_TOL"))) : 1e-6f;
+  b.angle_tol = tol > 1e-6f ? tol : 1e-6f;
   return b;
 }
 
@@ -369,7 +403,7 @@ int32_t launch_verify(s4p_ctx* c, const BaseFrame& bf) {
   VerifyParams V{};
   V.grid = c->dev_grid(); V.q4 = c->q4.p; V.q4v = c->q4v.p; V.qq = c->qq; V.n_q = c->n_q; V.base = bf;
   V.quads = L.quads.p; V.tags = L.tags.p; V.counts = L.counts.p; V.cand_idx = L.cand_idx.p; V.cand_T = L.cand_T.p;
-  V.ctr = L.ctr.p; V.res = L.ctr.p + 1; V.slots = L.slots.p; V.count_tests = c->prof_points ? 1 : 0;
+  V.ctr = L.ctr.p; V.res = L.ctr.p + 1; V.slots = L.slots.p; V.border = L.border.p; V.count_tests = c->prof_points ? 1 : 0;
   V.ablate = c->ablate;
   hipStream_t vs = L.stream;
   if (L.vstream) {                                           // CU partition: k_verify on the big partition, after the lane's small kernels
@@ -466,6 +500,50 @@ void fill_winner(const DevCounters& d, bool have, const BaseFrame& bf, s4p_base_
   for (int k = 0; k < 3; ++k) { r->best_centroid2[k] = have ? d.best_c2[k] : 0.f; r->centroid1[k] = bf.c1[k]; }
 }
 
+// Candidates of the pass that just finished on lane c->cur whose Euler-angle bound (match4pcsBase.cc:457-472) the device
+// could not decide (euler_verdict == 2): they were scored but kept out of the selection.  Here the reference's own
+// expression (libm, host) decides each one; those that pass are folded into the pass's record with the rule of the
+// selection (greater count, then smaller tag), those that fail leave the candidate count and checksum and get the
+// "gate failed" mark in the per-quad count array.  d: the pass's record, updated in place.
+int32_t settle_borderline(s4p_ctx* c, DevCounters& d, const BaseFrame& bf) {
+  c->border_failed.clear();
+  if (!d.n_border) return S4P_OK;
+  if (d.n_border > kBorderCap) S4P_FAIL(c, S4P_ERR_STATE, "more candidates with an undecided Euler-angle gate than the device hands over (kBorderCap)");
+  s4p_ctx::Lane& L = c->lane[c->cur];
+  std::vector<uint32_t> pos(d.n_border);
+  HIPCHK(c, hipMemcpy(pos.data(), L.border.p, size_t(d.n_border) * 4, hipMemcpyDeviceToHost));
+  bool have = d.C > d.n_border;                            // the device selected among the decided candidates only
+  for (const uint32_t i : pos) {
+    uint32_t kraw = 0, count = 0; int4 qd; unsigned long long tag = 0;
+    HIPCHK(c, hipMemcpy(&kraw, L.cand_idx.p + i, 4, hipMemcpyDeviceToHost));
+    const uint32_t k = kraw & ~kBorderFlag;
+    HIPCHK(c, hipMemcpy(&qd, L.quads.p + k, sizeof qd, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(&tag, L.tags.p + k, 8, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(&count, L.counts.p + k, 4, hipMemcpyDeviceToHost));
+    const int ids[3] = {qd.x, qd.y, qd.z};
+    float q[3][3], T[12], c2[3];
+    for (int a = 0; a < 3; ++a) { q[a][0] = c->hqx[size_t(ids[a])]; q[a][1] = c->hqy[size_t(ids[a])]; q[a][2] = c->hqz[size_t(ids[a])]; }
+    c->border_settled++;
+    if (rigid_verdict(bf, q, T, c2) != 0) {                // host: the exact expression
+      if (!have || count > d.best_count || (count == d.best_count && tag < d.best_tag)) {
+        have = true; d.best_count = count; d.best_tag = tag; d.has_best = 1u;
+        d.best_quad[0] = qd.x; d.best_quad[1] = qd.y; d.best_quad[2] = qd.z; d.best_quad[3] = qd.w;
+        for (int t = 0; t < 12; ++t) d.best_T[t] = T[t];
+        d.best_T[12] = 0.f; d.best_T[13] = 0.f; d.best_T[14] = 0.f; d.best_T[15] = 1.f;
+        for (int t = 0; t < 3; ++t) d.best_c2[t] = c2[t];
+      }
+    } else {
+      c->border_rejected++;
+      d.C -= 1u; d.cand_sum -= quad_mix(qd.x, qd.y, qd.z, qd.w);
+      const uint32_t failed = kGateFailed;
+      HIPCHK(c, hipMemcpy(L.counts.p + k, &failed, 4, hipMemcpyHostToDevice));
+      c->border_failed.push_back(k);
+    }
+  }
+  d.n_border = 0;
+  return S4P_OK;
+}
+
 int32_t launch_verify(s4p_ctx* c, const BaseFrame& bf);
 int32_t enqueue_result(s4p_ctx* c, const BaseFrame& bf);
 void launch_quads_kernel(s4p_ctx* c, const QuadParams& Q);
@@ -507,7 +585,7 @@ int32_t run_chunked(s4p_ctx* c, const DevCounters& first, s4p_base_result* r) {
     if (int32_t rc = launch_verify(c, bf)) return rc;
     if (int32_t rc = enqueue_result(c, bf)) return rc;
     HIPCHK(c, hipEventSynchronize(c->done[li]));
-    const DevCounters d = *c->hctr[li].p;
+    DevCounters d = *c->hctr[li].p;
     if (d.overflow & 4u) {
       if (rg.second - rg.first < 2u) S4P_FAIL(c, S4P_ERR_CAPACITY, "one set-2 pair has more congruent quads than max_quads: raise s4p_limits.max_quads");
       const uint32_t mid = rg.first + (rg.second - rg.first) / 2u;
@@ -516,6 +594,7 @@ int32_t run_chunked(s4p_ctx* c, const DevCounters& first, s4p_base_result* r) {
       continue;
     }
     if (d.overflow) S4P_FAIL(c, S4P_ERR_STATE, "chunk pass: unexpected overflow bits");
+    if (int32_t rc = settle_borderline(c, d, bf)) return rc;
     c->chunk_passes++;
     account_profile(c, d, false);
     Ksum += d.K; Csum += d.C; qsum += d.quad_sum; csum += d.cand_sum;
@@ -561,10 +640,11 @@ int32_t finish_result(s4p_ctx* c, s4p_base_result* r, bool fused) {
     c->host_wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
   const int li = c->cur;
   for (int attempt = 0;; ++attempt) {
-    const DevCounters d = *c->hctr[li].p;                  // (a copy: relaunches and chunk passes reuse the pinned record)
+    DevCounters d = *c->hctr[li].p;                        // (a copy: relaunches and chunk passes reuse the pinned record)
     const BaseFrame& bf = c->slot_bf[li];
     if (attempt == 0) account_profile(c, d, fused);
     if (!d.overflow) {
+      if (int32_t rc = settle_borderline(c, d, bf)) return rc;
       std::memset(r, 0, sizeof(*r));
       r->n_pairs1 = d.m1; r->n_pairs2 = d.m2; r->n_quads = d.K; r->n_verified = d.C;
       r->quad_checksum = d.quad_sum; r->cand_checksum = d.cand_sum;
@@ -676,11 +756,6 @@ int32_t s4p_create(const s4p_options* opt, const s4p_limits* lim, int32_t device
   }
   if (device < 0 || device >= ndev) { g_create_error = "bad device index"; return S4P_ERR_BAD_ARG; }
   if (!(opt->delta > 0.f)) { g_create_error = "delta must be > 0"; return S4P_ERR_BAD_ARG; }
-  if (opt->max_angle >= 0.f) {
-    g_create_error = "max_angle >= 0 (Euler-angle gate / segment-angle pair filter use libm acos/atan2 and are not "
-                     "bit-reproducible on device): unsupported on the device path";
-    return S4P_ERR_UNSUPPORTED;
-  }
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) != hipSuccess) { g_create_error = "hipGetDeviceProperties failed"; return S4P_ERR_HIP; }
   if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos) {
@@ -707,6 +782,12 @@ int32_t s4p_create(const s4p_options* opt, const s4p_limits* lim, int32_t device
   c->max_grid_cells = (lim && lim->max_grid_cells) ? lim->max_grid_cells : (1ull << 27);
   if (c->max_pairs > 0x7FFFFFFFull || c->max_quads > 0x7FFFFFFFull) { g_create_error = "limits exceed 2^31 entries"; delete c; return S4P_ERR_BAD_ARG; }
   for (int k = 0; k < 12; ++k) c->base_rgb[k] = -1.f;
+  if (opt->max_angle > 0.f) {
+    bool monotone = false;
+    c->cos_min = angle_threshold(double(opt->max_angle) * M_PI / 180.0, &monotone);     // pairCreationFunctor.h:205
+    c->angle_pairs = true;
+    if (!monotone) { g_create_error = "libm acosf is not monotone around the max_angle threshold: the segment-angle pair filter cannot be reproduced"; delete c; return S4P_ERR_UNSUPPORTED; }
+  }
   auto fail = [&](hipError_t e, const char* what) { g_create_error = std::string(what) + ": " + hipGetErrorString(e); s4p_destroy(c); return e == hipErrorOutOfMemory ? S4P_ERR_OOM : S4P_ERR_HIP; };
   hipError_t e;
   if ((e = hipSetDevice(device)) != hipSuccess) return fail(e, "hipSetDevice");
@@ -726,7 +807,7 @@ int32_t s4p_create(const s4p_options* opt, const s4p_limits* lim, int32_t device
       if ((e = hipEventCreateWithFlags(&L.chain, hipEventDisableTiming)) != hipSuccess) return fail(e, "hipEventCreate");
       if (!getenv("S4P_VERIFY_BLOCKS")) c->verify_blocks = 2u * nbig;
     } else if ((e = hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
-    A(L.ctr, 2); A(L.slots, kVerifyMaxBlocks);
+    A(L.ctr, 2); A(L.slots, kVerifyMaxBlocks); A(L.border, kBorderCap);
     if ((e = hipMemset(L.ctr.p, 0, 2 * sizeof(DevCounters))) != hipSuccess) return fail(e, "hipMemset");
     const char* what = nullptr;
     if ((e = alloc_lane_buffers(c->max_pairs, c->max_quads, L, &what)) != hipSuccess) return fail(e, what);
@@ -805,6 +886,12 @@ int32_t s4p_chunk_stats(const s4p_ctx* c, uint64_t* out4) {
   out4[0] = c->chunk_bases; out4[1] = c->chunk_passes; out4[2] = c->chunk_splits; out4[3] = c->chunk_quads;
   return S4P_OK;
 }
+// out2 = {candidates whose Euler-angle bound the host settled, how many of them it rejected} (max_angle >= 0)
+int32_t s4p_border_stats(const s4p_ctx* c, uint64_t* out2) {
+  if (!c || !out2) return S4P_ERR_BAD_ARG;
+  out2[0] = c->border_settled; out2[1] = c->border_rejected;
+  return S4P_OK;
+}
 // Lanes growing their own buffers when a base overflows (on by default); s4p_lane_growths counts the regrowths.
 int32_t s4p_set_auto_grow(s4p_ctx* c, int32_t enable) { if (!c) return S4P_ERR_BAD_ARG; c->auto_grow = enable != 0; return S4P_OK; }
 int64_t s4p_lane_growths(const s4p_ctx* c) { return c ? int64_t(c->lane_growths) : 0; }
@@ -828,7 +915,7 @@ void s4p_destroy(s4p_ctx* c) {
   c->qx.free(); c->qy.free(); c->qz.free(); c->ux.free(); c->uy.free(); c->uz.free();
   c->qnx.free(); c->qny.free(); c->qnz.free(); c->qcr.free(); c->qcg.free(); c->qcb.free();
   for (auto& L : c->lane) {
-    L.free_all(); L.ctr.free(); L.slots.free();
+    L.free_all(); L.ctr.free(); L.slots.free(); L.border.free();
     for (int s = 0; s < 2; ++s) L.seq[s].free();
   }
   for (auto& h : c->hctr) h.free();
@@ -1278,19 +1365,24 @@ int32_t s4p_last_verified(s4p_ctx* c, uint32_t* counts, float* transforms16, int
   if (c->last_chunked) S4P_FAIL(c, S4P_ERR_UNSUPPORTED, "the last base was processed in chunks: its per-candidate records were not kept");
   HIPCHK(c, hipSetDevice(c->device));
   const s4p_ctx::Lane& L = c->lane[c->cur];
-  const uint32_t C = c->hctr[c->cur].p->C;
-  *n_out = int64_t(C);
-  if (C == 0) return S4P_OK;
-  if (cap < int64_t(C) || !counts || !transforms16) S4P_FAIL(c, S4P_ERR_CAPACITY, "s4p_last_verified: output buffer too small");
-  std::vector<uint32_t> idx(C); std::vector<float4> T(size_t(C) * 3);
-  HIPCHK(c, hipMemcpy(idx.data(), L.cand_idx.p, size_t(C) * 4, hipMemcpyDeviceToHost));
-  HIPCHK(c, hipMemcpy(T.data(), L.cand_T.p, size_t(C) * 48, hipMemcpyDeviceToHost));
+  const uint32_t Cdev = c->hctr[c->cur].p->C;               // as the device counted them (incl. candidates the host rejected afterwards)
+  *n_out = 0;
+  if (Cdev == 0) return S4P_OK;
+  std::vector<uint32_t> idx(Cdev); std::vector<float4> T(size_t(Cdev) * 3);
+  HIPCHK(c, hipMemcpy(idx.data(), L.cand_idx.p, size_t(Cdev) * 4, hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(T.data(), L.cand_T.p, size_t(Cdev) * 48, hipMemcpyDeviceToHost));
+  for (auto& k : idx) k &= ~kBorderFlag;
   const uint64_t K = c->last_K;
   std::vector<unsigned long long> t(K); std::vector<uint32_t> cn(K);
   HIPCHK(c, hipMemcpy(t.data(), L.tags.p, K * 8, hipMemcpyDeviceToHost));
   HIPCHK(c, hipMemcpy(cn.data(), L.counts.p, K * 4, hipMemcpyDeviceToHost));
-  std::vector<uint32_t> order(C);
-  std::iota(order.begin(), order.end(), 0u);
+  std::vector<uint32_t> order;
+  order.reserve(Cdev);
+  for (uint32_t a = 0; a < Cdev; ++a) if (cn[idx[a]] != kGateFailed) order.push_back(a);   // (an undecided Euler-angle gate the host rejected)
+  const uint32_t C = uint32_t(order.size());
+  *n_out = int64_t(C);
+  if (C == 0) return S4P_OK;
+  if (cap < int64_t(C) || !counts || !transforms16) S4P_FAIL(c, S4P_ERR_CAPACITY, "s4p_last_verified: output buffer too small");
   std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return t[idx[a]] < t[idx[b]]; });
   for (uint32_t i = 0; i < C; ++i) {
     const uint32_t a = order[i];

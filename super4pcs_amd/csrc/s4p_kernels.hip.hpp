@@ -29,15 +29,15 @@ constexpr int kMaxConeSamples = 56;
 // ---------------------------------------------------------------------------
 // exact-order float helpers (Eigen 3-vector reductions: x + (y + z))
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz) {
+__host__ __device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz) {
   return ax * bx + (ay * by + az * bz);
 }
-__device__ __forceinline__ float sqn3(float x, float y, float z) { return x * x + (y * y + z * z); }
-__device__ __forceinline__ void normalize3(float& x, float& y, float& z) {
+__host__ __device__ __forceinline__ float sqn3(float x, float y, float z) { return x * x + (y * y + z * z); }
+__host__ __device__ __forceinline__ void normalize3(float& x, float& y, float& z) {
   const float s2 = sqn3(x, y, z);
   if (s2 > 0.f) { const float s = sqrtf(s2); x /= s; y /= s; z /= s; }
 }
-__device__ __forceinline__ void cross3(float ax, float ay, float az, float bx, float by, float bz,
+__host__ __device__ __forceinline__ void cross3(float ax, float ay, float az, float bx, float by, float bz,
                                        float& ox, float& oy, float& oz) {
   ox = ay * bz - az * by;
   oy = az * bx - ax * bz;
@@ -65,7 +65,7 @@ struct DevCounters {
   unsigned long long K;             // congruent quads FOUND: keeps counting past the capacity (64 bit: a base of a 20 000-point
                                     // sample has ~10^9), so an overflowing pass reports what the base needs
   uint32_t overflow;                // bit0 pairs1, bit1 pairs2, bit2 quads
-  uint32_t pad_;
+  uint32_t n_border;                // max_angle >= 0: candidates whose Euler-angle gate the device could not decide (scored, not selected; the host settles them)
   unsigned long long best_tag;      // min tag among candidates with best_count
   unsigned long long quad_sum;      // order-independent checksums (sum of quad_mix mod 2^64) over all quads found ...
   unsigned long long cand_sum;      // ... and over the quads that passed the rms gate (fused path): parity at sizes where lists cannot be compared
@@ -604,8 +604,7 @@ __device__ __forceinline__ void stage_coarse(const LcpGrid& g, uint32_t* s_coars
 }
 
 // ---------------------------------------------------------------------------
-// ComputeRigidTransformation (match4pcsBase.cc:365-500), computeScale == false,
-// max_angle < 0 (the Euler-angle gate is rejected at s4p_create).
+// ComputeRigidTransformation (match4pcsBase.cc:365-500), computeScale == false.
 // Returns true iff "ok && rms >= 0 && rms < 2*delta" (match4pcsBase.hpp:436-439).
 // T is row-major 3x4 (R | t).
 // ---------------------------------------------------------------------------
@@ -613,9 +612,12 @@ struct BaseFrame {          // per-base constants, computed once on the host sid
   float p[3][3];            // first three base points (sampled P, centred)
   float c1[3];              // centroid1 = ((b1+b2)+b3)/3
   float gate;               // distance_factor * delta = 2*delta
+  float max_angle_rad;      // options.max_angle * pi / 180 as a float (match4pcsBase.hpp:426)
+  int angle_gate;           // options.max_angle >= 0: the Euler-angle bound of match4pcsBase.cc:457-472 is in force
+  float angle_tol;          // device margin of that bound, 1e-6 rad (S4P_ANGLE_TOL widens it: a test aid that sends more candidates to the host)
 };
 
-__device__ __forceinline__ bool gs_frame(const float* a0, const float* a1, const float* a2, float e[3][3]) {
+__host__ __device__ __forceinline__ bool gs_frame(const float* a0, const float* a1, const float* a2, float e[3][3]) {
   e[0][0] = a1[0] - a0[0]; e[0][1] = a1[1] - a0[1]; e[0][2] = a1[2] - a0[2];
   if (sqn3(e[0][0], e[0][1], e[0][2]) == 0.f) return false;
   normalize3(e[0][0], e[0][1], e[0][2]);
@@ -630,11 +632,40 @@ __device__ __forceinline__ bool gs_frame(const float* a0, const float* a1, const
   return true;
 }
 
-__device__ __forceinline__ bool rigid_gate(const BaseFrame& b, const float q[3][3], float T[12], float c2[3]) {
+// The Euler-angle bound (match4pcsBase.cc:457-472):
+//   |atan2f(R21, R22)| <= a  &&  |atan2(-R20, sqrt(R21^2 + R22^2))| <= a (double)  &&  |atan2(R10, R00)| <= a (double).
+// Its outcome depends on libm's last bits, which device code cannot reproduce.  HOST: the reference's expression, libm --
+// exact.  DEVICE: the three angles in double with a margin of 1e-6 rad (libm's float atan2f is within 1.5 ulp of the true
+// angle: < 6e-7 at pi): 1 = passes for certain, 0 = fails for certain, 2 = within the margin -- such a candidate is
+// scored but left out of the device's selection, and the host settles it with the exact expression (s4p_capi.hip,
+// settle_borderline): about one candidate in 10^6.
+constexpr uint32_t kBorderFlag = 0x80000000u;      // in cand_idx: the gate of this candidate is undecided
+constexpr uint32_t kBorderCap = 1024;              // undecided candidates a pass can hand to the host
+__host__ __device__ inline int euler_verdict(const float R[3][3], const float max_angle, const float angle_tol) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const double m = double(max_angle), tol = double(angle_tol);
+  const double r21 = double(R[2][1]), r22 = double(R[2][2]);
+  const double a1 = fabs(atan2(r21, r22));
+  const double a2 = fabs(atan2(double(-R[2][0]), sqrt(r21 * r21 + r22 * r22)));
+  const double a3 = fabs(atan2(double(R[1][0]), double(R[0][0])));
+  const double hi = fmax(a1, fmax(a2, a3));
+  if (hi > m + tol) return 0;
+  return hi <= m - tol ? 1 : 2;
+#else
+  const bool ok = std::abs(std::atan2(R[2][1], R[2][2])) <= max_angle &&
+                  std::abs(std::atan2(double(-R[2][0]), std::sqrt(std::pow(double(R[2][1]), 2) + std::pow(double(R[2][2]), 2)))) <= double(max_angle) &&
+                  std::abs(::atan2(double(R[1][0]), double(R[0][0]))) <= double(max_angle);
+  return ok ? 1 : 0;
+#endif
+}
+
+// 0: rejected ("!ok || !(0 <= rms < 2 delta)", match4pcsBase.hpp:436-439); 1: a candidate; 2 (device only): a candidate if
+// the Euler-angle bound holds, which the host has to settle.
+__host__ __device__ __forceinline__ int rigid_verdict(const BaseFrame& b, const float q[3][3], float T[12], float c2[3]) {
   for (int k = 0; k < 3; ++k) c2[k] = ((q[0][k] + q[1][k]) + q[2][k]) / 3.f;    // match4pcsBase.hpp:415-417
   float vp[3][3], vq[3][3];
-  if (!gs_frame(b.p[0], b.p[1], b.p[2], vp)) return false;   // rms = 1e9 -> gate fails (quirk .cc:417-433)
-  if (!gs_frame(q[0], q[1], q[2], vq)) return false;
+  if (!gs_frame(b.p[0], b.p[1], b.p[2], vp)) return 0;       // rms = 1e9 -> gate fails (quirk .cc:417-433)
+  if (!gs_frame(q[0], q[1], q[2], vq)) return 0;
   float R[3][3];
 #pragma unroll
   for (int r = 0; r < 3; ++r)
@@ -643,7 +674,12 @@ __device__ __forceinline__ bool rigid_gate(const BaseFrame& b, const float q[3][
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     const float dg = R[i][0] * R[0][i] + (R[i][1] * R[1][i] + R[i][2] * R[2][i]);   // (R*R).diagonal() .cc:453
-    if (dg - 1.f > 1e-6f) return false;
+    if (dg - 1.f > 1e-6f) return 0;
+  }
+  int verdict = 1;
+  if (b.angle_gate) {                                                              // .cc:457-472 (uniform over the launch)
+    verdict = euler_verdict(R, b.max_angle_rad, b.angle_tol);
+    if (verdict == 0) return 0;
   }
   float rms = 0.f;
 #pragma unroll
@@ -658,14 +694,17 @@ __device__ __forceinline__ bool rigid_gate(const BaseFrame& b, const float q[3][
     rms += sqrtf(sqn3(d[0], d[1], d[2]));
   }
   rms /= 4.f;                                                                      // .cc:489 (quirk: /4 over 3 terms)
-  if (!(rms >= 0.f && rms < b.gate)) return false;
+  if (!(rms >= 0.f && rms < b.gate)) return 0;
 #pragma unroll
   for (int r = 0; r < 3; ++r) {
     const float rc = R[r][0] * (-c2[0]) + (R[r][1] * (-c2[1]) + R[r][2] * (-c2[2]));
     T[r * 4 + 0] = R[r][0]; T[r * 4 + 1] = R[r][1]; T[r * 4 + 2] = R[r][2];
     T[r * 4 + 3] = b.c1[r] + rc;
   }
-  return true;
+  return verdict;
+}
+__host__ __device__ __forceinline__ bool rigid_gate(const BaseFrame& b, const float q[3][3], float T[12], float c2[3]) {
+  return rigid_verdict(b, q, T, c2) != 0;
 }
 
 // ---------------------------------------------------------------------------
@@ -944,6 +983,11 @@ struct PairParams {
   float b1pos[3], b2pos[3], b1rgb[3], b2rgb[3];
   int2* ab; uint32_t* okey; uint32_t* counter; uint32_t cap; uint32_t* overflow; uint32_t overflow_bit;
   uint32_t split;                                          // waves per primitive: wave `part` takes the leaf tiles part, part + split, ...
+  // max_angle > 0 (pairCreationFunctor.h:203-212): (j,i) is emitted iff acosf(segment1 . segment2) <= max_angle * pi / 180,
+  // (i,j) iff the same holds for -segment2.  acosf is decreasing, so the test is d >= cos_min with cos_min = the smallest
+  // float whose libm acosf passes (found by the host with libm itself, s4p_capi.hip angle_threshold); |d| > 1 gives NaN in
+  // the reference, i.e. no pair.
+  float seg1[3]; float cos_min;
 };
 
 __device__ __forceinline__ bool sphere_box(float cx, float cy, float cz, float r, float4 leaf) {
@@ -1003,6 +1047,9 @@ struct PairSet { PairParams pair; };
 struct PairParams2 { PairSet set[2]; };
 
 // The two pair sets of a base are independent: one launch, blockIdx.y picks the set (gridDim.y = 1 for a single set).
+// ANGLE (options.max_angle > 0): the two ordered pairs of an accepted (i, j) are emitted independently, so the stage holds
+// ORDERED pairs (bit 31 of the slot word = the second of the two) instead of unordered ones.
+template <bool ANGLE>
 __global__ __launch_bounds__(64 * kPairWaves) void k_pairs(PairParams2 PP) {
   const PairParams& P = PP.set[blockIdx.y].pair;
   __shared__ uint32_t st_j[kPairWaves][kPairStageW];
@@ -1014,12 +1061,12 @@ __global__ __launch_bounds__(64 * kPairWaves) void k_pairs(PairParams2 PP) {
   // writes the wave's n_st staged entries at pair positions base, base + 2, ...: two ordered pairs per entry, one
   // pair per lane
   auto write_out = [&](const uint32_t base) {
-    for (uint32_t pe = lane; pe < 2u * n_st; pe += 64u) {
-      const uint32_t e = pe >> 1, second = pe & 1u;
+    for (uint32_t pe = lane; pe < (ANGLE ? n_st : 2u * n_st); pe += 64u) {
+      const uint32_t e = ANGLE ? pe : pe >> 1, second = ANGLE ? st_s[wave][e] >> 31 : pe & 1u;
       const uint32_t at = base + pe;
-      if ((at | 1u) < P.cap) {                             // both pairs of an entry fit, or neither is written
+      if ((ANGLE ? at : (at | 1u)) < P.cap) {              // both pairs of an entry fit, or neither is written
         const uint32_t j = st_j[wave][e], pId = st_p[wave][e];
-        const uint32_t ok = 2u * (pId * P.n_seq + st_s[wave][e]) + second;
+        const uint32_t ok = 2u * (pId * P.n_seq + (st_s[wave][e] & 0x7FFFFFFFu)) + second;
         // pairs->emplace_back(j, i) then pairs->emplace_back(i, j)   pairCreationFunctor.h:214-215
         const int2 pr = second ? make_int2(int(pId), int(j)) : make_int2(int(j), int(pId));
         P.ab[at] = pr; P.okey[at] = ok;
@@ -1077,18 +1124,37 @@ __global__ __launch_bounds__(64 * kPairWaves) void k_pairs(PairParams2 PP) {
               acc = pair_filters(P, pId, j, wxi, wyi, wzi);
           }
         }
-        const unsigned long long m = __ballot(acc);
-        if (m != 0ull) {
-          if (acc) {
+        bool emit_a = acc, emit_b = false;                // ANGLE: (j,i) / (i,j) separately
+        if (ANGLE) {
+          emit_a = false;
+          if (acc) {                                        // pairCreationFunctor.h:203-212
+            float sx = wxi - P.qx[j], sy = wyi - P.qy[j], sz = wzi - P.qz[j];     // segment2 = (q.pos() - p.pos()).normalized()
+            normalize3(sx, sy, sz);
+            const float d = dot3(P.seg1[0], P.seg1[1], P.seg1[2], sx, sy, sz), nd = -d;   // segment1.dot(-segment2) == -d exactly
+            emit_a = d >= P.cos_min && d <= 1.f;
+            emit_b = nd >= P.cos_min && nd <= 1.f;
+          }
+        }
+        const unsigned long long m = __ballot(emit_a);
+        const unsigned long long mb = ANGLE ? __ballot(emit_b) : 0ull;
+        if ((m | mb) != 0ull) {
+          if (emit_a) {
             const uint32_t e = n_st + __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u));
             st_j[wave][e] = j; st_s[wave][e] = s; st_p[wave][e] = pId;
           }
           n_st += uint32_t(__popcll(m));
+          if (ANGLE) {
+            if (emit_b) {
+              const uint32_t e = n_st + __builtin_amdgcn_mbcnt_hi(uint32_t(mb >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mb), 0u));
+              st_j[wave][e] = j; st_s[wave][e] = s | 0x80000000u; st_p[wave][e] = pId;
+            }
+            n_st += uint32_t(__popcll(mb));
+          }
           __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
           __builtin_amdgcn_wave_barrier();
-          if (n_st + 64u > uint32_t(kPairStageW)) {      // stage full before the end: this wave appends on its own
+          if (n_st + (ANGLE ? 128u : 64u) > uint32_t(kPairStageW)) {      // stage full before the end: this wave appends on its own
             uint32_t b = 0;
-            if (lane == 0) b = atomicAdd(P.counter, 2u * n_st);
+            if (lane == 0) b = atomicAdd(P.counter, ANGLE ? n_st : 2u * n_st);
             b = uint32_t(__builtin_amdgcn_readfirstlane(int(b)));
             write_out(b);
             n_st = 0;
@@ -1103,12 +1169,12 @@ __global__ __launch_bounds__(64 * kPairWaves) void k_pairs(PairParams2 PP) {
   if (threadIdx.x == 0) {
     uint32_t tot = 0;
     for (int w = 0; w < kPairWaves; ++w) tot += s_cnt[w];
-    s_base = tot ? atomicAdd(P.counter, 2u * tot) : 0u;
+    s_base = tot ? atomicAdd(P.counter, ANGLE ? tot : 2u * tot) : 0u;
   }
   __syncthreads();
   uint32_t before = 0;
   for (uint32_t w = 0; w < wave; ++w) before += s_cnt[w];
-  if (n_st) write_out(s_base + 2u * before);
+  if (n_st) write_out(s_base + (ANGLE ? before : 2u * before));
 }
 
 // ---------------------------------------------------------------------------
@@ -1122,12 +1188,14 @@ struct GateParams {
   uint32_t* cand_idx; float4* cand_T;                   // gated candidates: quad index + 3x4 transform
   uint32_t* C_dev;
 };
-__device__ __forceinline__ bool gate_quad(const GateParams& G, const int4 qd, float T[12]) {
+// 0 = rejected, 1 = candidate, 2 = candidate whose Euler-angle bound the host settles (rigid_verdict)
+__device__ __forceinline__ int gate_quad(const GateParams& G, const int4 qd, float T[12]) {
   const float4 a = G.q4[qd.x], b = G.q4[qd.y], c = G.q4[qd.z];
   const float q[3][3] = {{a.x, a.y, a.z}, {b.x, b.y, b.z}, {c.x, c.y, c.z}};
   float c2[3];
-  return rigid_gate(G.base, q, T, c2);
+  return rigid_verdict(G.base, q, T, c2);
 }
+// k: index of the quad, with kBorderFlag set if its gate is undecided
 __device__ __forceinline__ void store_candidate(const GateParams& G, const uint32_t at, const uint32_t k, const float T[12]) {
   G.cand_idx[at] = k;
   float4* dst = G.cand_T + 3 * size_t(at);
@@ -1146,18 +1214,19 @@ __global__ __launch_bounds__(256) void k_gate(GateKernelParams P) {
   for (uint32_t k0 = (blockIdx.x * blockDim.x + threadIdx.x) & ~63u; k0 < K; k0 += gridDim.x * blockDim.x) {
     const uint32_t k = k0 + lane;
     float T[12];
-    bool ok = false;
+    int vd = 0;
     if (k < K) {
-      ok = gate_quad(P.g, P.quads[k], T);
-      if (!ok) P.g.counts[k] = kGateFailed;
+      vd = gate_quad(P.g, P.quads[k], T);
+      if (!vd) P.g.counts[k] = kGateFailed;
     }
+    const bool ok = vd != 0;
     const unsigned long long pass = __ballot(ok);
     if (pass == 0ull) continue;
     const uint32_t leader = __ffsll((long long)pass) - 1;
     uint32_t base = 0;
     if (lane == leader) base = atomicAdd(P.g.C_dev, uint32_t(__popcll(pass)));
     base = __shfl(base, leader);
-    if (ok) store_candidate(P.g, base + uint32_t(__popcll(pass & ((1ull << lane) - 1ull))), k, T);
+    if (ok) store_candidate(P.g, base + uint32_t(__popcll(pass & ((1ull << lane) - 1ull))), k | (vd == 2 ? kBorderFlag : 0u), T);
   }
 }
 
@@ -1248,7 +1317,8 @@ __global__ __launch_bounds__(256) void k_quads(QuadParams P) {
                 P.quads[at] = quad; P.tags[at] = tag;
                 if (P.do_gate) {
                   float T[12];
-                  if (gate_quad(P.gate, quad, T)) { store_candidate(P.gate, atomicAdd(P.gate.C_dev, 1u), uint32_t(at), T); atomicAdd(&s_csum, mix); }
+                  const int vd = gate_quad(P.gate, quad, T);
+                  if (vd) { store_candidate(P.gate, atomicAdd(P.gate.C_dev, 1u), uint32_t(at) | (vd == 2 ? kBorderFlag : 0u), T); atomicAdd(&s_csum, mix); }
                   else P.gate.counts[at] = kGateFailed;
                 }
               } else atomicOr(P.overflow, 4u);
@@ -1276,7 +1346,8 @@ __global__ __launch_bounds__(256) void k_quads(QuadParams P) {
         { const unsigned long long ws = wave_sum_u64(mix); if (lane == 0 && ws) atomicAdd(&s_qsum, ws); }
         if (P.do_gate) {                                        // uniform
           float T[12];
-          const bool ok = live && gate_quad(P.gate, quad, T);
+          const int vd = live ? gate_quad(P.gate, quad, T) : 0;
+          const bool ok = vd != 0;
           if (live && !ok) P.gate.counts[at] = kGateFailed;
           const unsigned long long pass = __ballot(ok);
           { const unsigned long long ws = wave_sum_u64(ok ? mix : 0ull); if (lane == 0 && ws) atomicAdd(&s_csum, ws); }
@@ -1287,7 +1358,7 @@ __global__ __launch_bounds__(256) void k_quads(QuadParams P) {
           if (ok) {
             uint32_t before = 0;
             for (uint32_t w = 0; w < wave; ++w) before += s_wc[w];
-            store_candidate(P.gate, s_cbase + before + uint32_t(__popcll(pass & ((1ull << lane) - 1ull))), uint32_t(at), T);
+            store_candidate(P.gate, s_cbase + before + uint32_t(__popcll(pass & ((1ull << lane) - 1ull))), uint32_t(at) | (vd == 2 ? kBorderFlag : 0u), T);
           }
           __syncthreads();                                      // s_wc / s_cbase are rewritten by the next chunk
         }
@@ -1330,6 +1401,7 @@ struct VerifyParams {
   DevCounters* ctr;                                     // live counters of the base (reset by the last workgroup)
   DevCounters* res;                                     // result record of the base (copied to the host)
   uint4* slots;                                         // per workgroup: {best count, its candidate, tag lo, tag hi}
+  uint32_t* border;                                     // candidates (positions in cand_idx) with an undecided gate, kBorderCap entries
   int count_tests;                                      // instrumentation counters are live: carry them into res
   int ablate;                                           // S4P_ABLATE debugging only (0 = full kernel)
 };
@@ -1375,10 +1447,13 @@ __global__ __launch_bounds__(kVerifyMaxThreads, 8) void k_verify(VerifyParams P)
       const float4* src = P.cand_T + 3 * size_t(i);         // one candidate per wave
       const uint32_t cnt = P.ablate == 1 ? wave_lcp_count<COUNT, true, QLDS>(P.grid, K, s_coarse, s_q, s_queue, src)
                                          : wave_lcp_count<COUNT, false, QLDS>(P.grid, K, s_coarse, s_q, s_queue, src);
-      const uint32_t k = uint32_t(__builtin_amdgcn_readfirstlane(int(P.cand_idx[i])));
+      const uint32_t kraw = uint32_t(__builtin_amdgcn_readfirstlane(int(P.cand_idx[i])));
+      const uint32_t k = kraw & ~kBorderFlag;
       const unsigned long long tag = P.tags[k];
       if (lane == 0) P.counts[k] = cnt;
-      if (slot_better(cnt, tag, bc, bt, bi != kNil)) { bc = cnt; bt = tag; bi = i; }
+      if (kraw & kBorderFlag) {                              // scored, but the host decides whether it is a candidate at all
+        if (lane == 0) { const uint32_t n = atomicAdd(&P.ctr->n_border, 1u); if (n < kBorderCap) P.border[n] = i; }
+      } else if (slot_better(cnt, tag, bc, bt, bi != kNil)) { bc = cnt; bt = tag; bi = i; }
     }
   }
   // ---- selection: wave bests -> workgroup best -> slot; the last workgroup to finish reduces the slots ----
@@ -1423,11 +1498,11 @@ __global__ __launch_bounds__(kVerifyMaxThreads, 8) void k_verify(VerifyParams P)
   DevCounters* c = P.ctr;
   DevCounters* r = P.res;
   r->m1 = c->m1; r->m2 = c->m2; r->K = c->K; r->C = C; r->overflow = c->overflow;
-  r->quad_sum = c->quad_sum; r->cand_sum = c->cand_sum;
+  r->quad_sum = c->quad_sum; r->cand_sum = c->cand_sum; r->n_border = c->n_border;
   r->best_count = bc; r->best_tag = bt; r->has_best = 0u;
   if (COUNT || P.count_tests) { r->point_tests = c->point_tests; r->l0_pass = c->l0_pass; r->l1_pass = c->l1_pass; r->l2_pass = c->l2_pass; }
   if (bi != kNil) {                                        // recompute the winner's 4x4 (ComputeRigidTransformation)
-    const uint32_t k = P.cand_idx[bi];
+    const uint32_t k = P.cand_idx[bi] & ~kBorderFlag;
     const int4 qd = P.quads[k];
     const float4 a = P.q4[qd.x], b = P.q4[qd.y], cc = P.q4[qd.z];
     const float q[3][3] = {{a.x, a.y, a.z}, {b.x, b.y, b.z}, {cc.x, cc.y, cc.z}};
@@ -1441,7 +1516,7 @@ __global__ __launch_bounds__(kVerifyMaxThreads, 8) void k_verify(VerifyParams P)
   }
   // the live counters are ready for the next base on this lane (no separate reset launch)
   c->m1 = 0; c->m2 = 0; c->K = 0; c->C = 0; c->best_count = 0; c->overflow = 0; c->best_tag = ~0ull; c->has_best = 0;
-  c->quad_sum = 0; c->cand_sum = 0;
+  c->quad_sum = 0; c->cand_sum = 0; c->n_border = 0;
   c->point_tests = 0; c->l0_pass = 0; c->l1_pass = 0; c->l2_pass = 0;
   __threadfence();
   c->done = 0;
@@ -1623,7 +1698,7 @@ __global__ void k_selftest(const float* a, const float* b, uint64_t n, float* o_
 // leaves them cleared for the next base of the lane.
 __global__ void k_reset_counters(DevCounters* c) {
   c->m1 = 0; c->m2 = 0; c->K = 0; c->C = 0; c->best_count = 0; c->overflow = 0;
-  c->best_tag = ~0ull; c->has_best = 0; c->done = 0; c->quad_sum = 0; c->cand_sum = 0;
+  c->best_tag = ~0ull; c->has_best = 0; c->done = 0; c->quad_sum = 0; c->cand_sum = 0; c->n_border = 0;
   c->point_tests = 0; c->l0_pass = 0; c->l1_pass = 0; c->l2_pass = 0;
 }
 

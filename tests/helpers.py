@@ -63,3 +63,20 @@ def quad_mix(quads):
 def checksum(quads):
     with np.errstate(over="ignore"):
         return int(np.sum(quad_mix(quads), dtype=np.uint64)) if len(quads) else 0
+
+
+def small_rotation_pair(n_points=20000, delta=0.01, seed=31, degrees=(8.0, -11.0, 6.0)):
+    """A pair whose true motion has small Euler angles (for max_angle): P ~ R_s Q2 + t_s with R_s = Rz Ry Rx of `degrees`."""
+    P, Q, T = small_pair(n_points, delta=delta, seed=seed)
+    T = np.asarray(T, np.float64)
+    ax, ay, az = np.deg2rad(degrees)
+    Rx = np.array([[1, 0, 0], [0, np.cos(ax), -np.sin(ax)], [0, np.sin(ax), np.cos(ax)]])
+    Ry = np.array([[np.cos(ay), 0, np.sin(ay)], [0, 1, 0], [-np.sin(ay), 0, np.cos(ay)]])
+    Rz = np.array([[np.cos(az), -np.sin(az), 0], [np.sin(az), np.cos(az), 0], [0, 0, 1]])
+    Rs = Rz @ Ry @ Rx
+    Qp = Q.astype(np.float64) @ T[:3, :3].T + T[:3, 3]          # Q in P's frame
+    Q2 = (Qp - np.array([0.05, -0.03, 0.02])) @ Rs               # x = Rs^T (p - t_s)  <=>  p = Rs x + t_s
+    Tn = np.eye(4)
+    Tn[:3, :3] = Rs
+    Tn[:3, 3] = [0.05, -0.03, 0.02]
+    return P, Q2.astype(np.float32), Tn.astype(np.float32)

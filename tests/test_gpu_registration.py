@@ -82,10 +82,66 @@ def test_transform_points_matches_oracle_order(oracle_mod, s4p_lib_built):
 def test_options_rejected_loudly(s4p_lib_built):
     from super4pcs_amd import capi
     with pytest.raises(capi.S4PError) as e:
-        capi.Context(capi.make_options(0.01, 0.5, 200, max_angle=30.0))
-    assert e.value.code == -6
-    with pytest.raises(capi.S4PError):
         capi.Context(capi.make_options(-1.0, 0.5, 200))
+    assert e.value.code == -1
+
+
+@pytest.mark.parametrize("max_angle,tol", [(30.0, None), (12.0, None), (30.0, "0.02")])
+def test_max_angle_matches_oracle(oracle_mod, s4p_lib_built, max_angle, tol, monkeypatch):
+    """options.max_angle on the device path: the segment-angle pair filter (pairCreationFunctor.h:203-212; an exact cosine
+    threshold) and the Euler-angle bound of ComputeRigidTransformation (match4pcsBase.cc:457-472; decided on the device up
+    to a margin, settled by the host with libm inside it) -- ordered pair lists, per-quad gate decisions and inlier counts,
+    and the whole registration against the oracle, which is pinned to the reference's own code for this option
+    (tests/test_oracle_vs_reference.py::test_max_angle_matches_reference).  tol = 0.02: the device margin widened 20 000 x,
+    so that hundreds of candidates take the host route instead of one in a million -- same results."""
+    from super4pcs_amd import capi
+    if tol:
+        monkeypatch.setenv("S4P_ANGLE_TOL", tol)
+    O = oracle_mod
+    delta, overlap, n_s = 0.01, 0.6, 200
+    P, Q, _ = H.small_rotation_pair(20000, delta=delta, seed=31)
+    oopt = O.make_options(delta, overlap, n_s, max_angle=max_angle)
+    gopt = capi.make_options(delta, overlap, n_s, max_angle=max_angle)
+    om = O.Matcher(oopt, full_counts=True, use_kdtree=True)
+    om.init(P, Q)
+    ctx = capi.Context(gopt)
+    ctx.set_clouds(om.cloud(0), om.cloud(1))
+    eps = 2.0 * delta
+    n_pairs = n_gated = n_rejected = 0
+    for _ in range(10):
+        ok, i1, i2, base, bx = om.select_quadrilateral()
+        if not ok:
+            continue
+        ctx.set_base(bx)
+        sets = []
+        for a, b in ((0, 1), (2, 3)):
+            d = float(np.float32(np.linalg.norm(bx[a] - bx[b])))
+            want, got = om.extract_pairs(d, 0.0, eps, a, b), ctx.extract_pairs(d, 0.0, eps, a, b)
+            assert np.array_equal(got, want)                 # the filter drops ordered pairs one by one: same list, same order
+            sets.append(want)
+            n_pairs += len(want)
+        if not (len(sets[0]) and len(sets[1])):
+            continue
+        quads = om.find_congruent(i1, i2, eps, sets[0], sets[1])
+        assert np.array_equal(ctx.find_congruent(i1, i2, eps, sets[0], sets[1]), quads)
+        if len(quads):
+            _nb, per, _bc, _bi = om.try_congruent_set(base, quads)
+            r, g_per = ctx.try_congruent_set(base, quads)
+            assert np.array_equal(g_per, per)
+            assert r.n_verified == int((per >= 0).sum())
+            n_gated += int((per >= 0).sum()); n_rejected += int((per < 0).sum())
+    assert n_pairs > 0 and n_rejected > 0
+    om2 = O.Matcher(oopt)
+    o_lcp, o_M, _ = om2.compute_transformation(P, Q)
+    gm = capi.Matcher(gopt)
+    g_lcp, g_M, _ = gm.compute_transformation(P, Q)
+    assert g_lcp == o_lcp and np.array_equal(g_M, o_M)
+    gi, os_ = gm.info(), om2.stats()
+    assert (gi.pairs_total, gi.quads_total, gi.candidates_verified) == (os_.n_pairs, os_.n_quads, os_.n_verified)
+    assert os_.n_verified > 0
+    if tol:
+        settled, rejected = gm.border_stats()
+        assert settled > 20 and 0 < rejected < settled       # the host route was taken, both ways
 
 
 def test_empty_inputs_return_large_number(s4p_lib_built):

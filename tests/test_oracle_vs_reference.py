@@ -155,3 +155,48 @@ def test_attribute_filters_match_reference(oracle_mod, opts):
     o_lcp, o_M, o_Q = om2.compute_transformation(P, Q, Pn, Pc, Qn, Qc)
     assert r_lcp == o_lcp and r_n == om2.stats().n_verified
     assert np.array_equal(r_M[:3, :3], o_M[:3, :3]) and np.max(np.abs(r_M - o_M)) <= 1e-6
+
+
+@pytest.mark.parametrize("max_angle", [30.0, 12.0])
+def test_max_angle_matches_reference(oracle_mod, max_angle):
+    """options.max_angle: the segment-angle pair filter (pairCreationFunctor.h:203-212) and the Euler-angle bound of
+    ComputeRigidTransformation (match4pcsBase.cc:457-472), stage by stage and end to end against the reference's own code."""
+    O = oracle_mod
+    delta, overlap, n_s = 0.01, 0.6, 200
+    P, Q, _ = H.small_rotation_pair(20000, delta=delta, seed=31)
+    rm = reflib.RefMatcher(O.make_options(delta, overlap, n_s, max_angle=max_angle))
+    om = O.Matcher(O.make_options(delta, overlap, n_s, max_angle=max_angle), full_counts=True)
+    rm.init(P, Q)
+    om.init(P, Q)
+    eps = 2.0 * delta
+    pairs_seen = gated = 0
+    for _ in range(8):
+        r, o = rm.select_quadrilateral(), om.select_quadrilateral()
+        assert r[0] == o[0] and np.array_equal(r[3], o[3])
+        if not r[0]:
+            continue
+        bx = r[4]
+        sets = []
+        for a, b in ((0, 1), (2, 3)):
+            d = float(np.float32(np.linalg.norm(bx[a] - bx[b])))
+            rp, op = rm.extract_pairs(d, 0.0, eps, a, b), om.extract_pairs(d, 0.0, eps, a, b)
+            assert np.array_equal(rp, op)
+            sets.append(op)
+            pairs_seen += len(op)
+        if len(sets[0]) and len(sets[1]):
+            rq, oq = rm.find_congruent(r[1], r[2], eps, sets[0], sets[1]), om.find_congruent(r[1], r[2], eps, sets[0], sets[1])
+            assert np.array_equal(rq, oq)
+            if len(oq):
+                r_nb, _ = rm.try_congruent_set(r[3], oq)
+                o_nb, per, _, _ = om.try_congruent_set(o[3], oq)
+                assert r_nb == o_nb == int((per >= 0).sum())          # same gate decisions (incl. the Euler-angle bound)
+                gated += o_nb
+    assert pairs_seen > 0
+    rm2 = reflib.RefMatcher(O.make_options(delta, overlap, n_s, max_angle=max_angle))
+    om2 = O.Matcher(O.make_options(delta, overlap, n_s, max_angle=max_angle))
+    r_lcp, r_M, r_Q, r_n = rm2.compute_transformation(P, Q)
+    o_lcp, o_M, o_Q = om2.compute_transformation(P, Q)
+    assert r_lcp == o_lcp and r_n == om2.stats().n_verified and r_n > 0
+    assert np.array_equal(r_M[:3, :3], o_M[:3, :3]) and np.max(np.abs(r_M - o_M)) <= 1e-6
+    if max_angle == 30.0:
+        assert o_lcp > 0.5                                             # the small-rotation pose is found under the bound
