@@ -141,6 +141,10 @@ int32_t s4p_matcher_device_selection(const s4p_matcher* m);
 int32_t s4p_matcher_grow_on_overflow(s4p_matcher* m, int32_t enable);
 int32_t s4p_matcher_capacity_growths(const s4p_matcher* m);
 
+/* current_trial_ += n (match4pcsBase.hpp:258), for a driver that runs the trial loop itself through SelectQuadrilateral /
+ * ExtractPairs / FindCongruentQuadrilaterals / TryCongruentSet (the facade does when a subclass overrides the hooks). */
+int32_t s4p_matcher_advance_trials(s4p_matcher* m, int32_t n);
+
 /* getGlobalTransform (match4pcsBase.hpp:224-229). */
 int32_t s4p_matcher_global_transform(s4p_matcher* m, float* transformation);
 

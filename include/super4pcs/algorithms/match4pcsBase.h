@@ -6,7 +6,10 @@
 #ifndef S4P_FACADE_MATCH4PCSBASE_H_
 #define S4P_FACADE_MATCH4PCSBASE_H_
 
+#include <algorithm>
 #include <array>
+#include <chrono>
+#include <cmath>
 #include <stdexcept>
 #include <type_traits>
 #include <string>
@@ -107,19 +110,50 @@ class Match4PCSBase {
   }
 
   // ---- match4pcsBase.hpp:208-274 -----------------------------------------------------------------
+  // Two routes, same trials and results:
+  //  * the dynamic type uses the stock hooks (uses_stock_hooks()): the whole loop runs inside the engine, bases
+  //    pipelined, pairs -> quads -> candidates fused on the device (s4p_matcher_perform_n_steps);
+  //  * a subclass overrides ExtractPairs / FindCongruentQuadrilaterals (the plugin points of match4pcsBase.h:300-326, the
+  //    pattern of tests/testing.h:71-154): the loop below is the reference's own -- TryOneBase calls the VIRTUAL hooks
+  //    stage by stage, so the overrides see, and may change, every pair and quad list; the device still does the work
+  //    behind the stock implementations and behind TryCongruentSet.
   template <typename Visitor>
   bool Perform_N_steps(int n, MatrixRef transformation, std::vector<Point3D>* Q, const Visitor& v) {
     if (Q == nullptr) return false;
     float M[16];
     to_rowmajor(transformation, M);
-    VisitorThunk<Visitor> thunk{&v};
     int32_t improved = 0, done = 0;
-    // the reference also calls v(-1, lcp, T) once per verified candidate (:458-465); only pay for it when someone listens
-    check(s4p_matcher_visit_candidates(engine_, std::is_same<Visitor, DummyTransformVisitor>::value ? 0 : 1));
-    check(s4p_matcher_perform_n_steps(engine_, n, &VisitorThunk<Visitor>::call, &thunk, v.needsGlobalTransformation() ? 1 : 0,
-                                      M, &improved, &done));
-    from_rowmajor(M, transformation);
-    refresh();
+    if (uses_stock_hooks()) {
+      VisitorThunk<Visitor> thunk{&v};
+      // the reference also calls v(-1, lcp, T) once per verified candidate (:458-465); only pay for it when someone listens
+      check(s4p_matcher_visit_candidates(engine_, std::is_same<Visitor, DummyTransformVisitor>::value ? 0 : 1));
+      check(s4p_matcher_perform_n_steps(engine_, n, &VisitorThunk<Visitor>::call, &thunk, v.needsGlobalTransformation() ? 1 : 0,
+                                        M, &improved, &done));
+      from_rowmajor(M, transformation);
+      refresh();
+    } else {
+      using sclock = std::chrono::system_clock;
+      const Scalar last_best = best_LCP_;
+      v(0, best_LCP_, transformation);                                       // :232
+      bool ok = false;
+      const auto t0 = sclock::now();
+      for (int i = current_trial_; i < current_trial_ + n; ++i) {            // :236-256
+        ok = TryOneBase(v);
+        const Scalar fraction_try = Scalar(i) / Scalar(number_of_trials_);
+        const Scalar fraction_time = Scalar(std::chrono::duration_cast<std::chrono::seconds>(sclock::now() - t0).count() /
+                                            (long)options_.max_time_seconds);   // integer division: reference quirk, :240-243
+        const Scalar fraction = std::max(fraction_time, fraction_try);
+        current_transform(v.needsGlobalTransformation(), M);
+        from_rowmajor(M, transformation);
+        v(fraction, best_LCP_, transformation);
+        if (ok || i > number_of_trials_ || fraction >= 0.99 || best_LCP_ == 1.0) break;
+      }
+      check(s4p_matcher_advance_trials(engine_, n));                         // current_trial_ += n, :258
+      refresh();
+      improved = best_LCP_ > last_best ? 1 : 0;
+      if (improved) { current_transform(true, M); from_rowmajor(M, transformation); }      // getGlobalTransform, :259-262
+      done = (ok || current_trial_ >= number_of_trials_) ? 1 : 0;
+    }
     if (improved) {                                   // :259-268 -- the final apply runs on the GPU (k_apply)
       *Q = Q_copy_;
       const int64_t nq = int64_t(Q->size());
@@ -133,11 +167,29 @@ class Match4PCSBase {
 
   // ---- match4pcsBase.hpp:281-360 -----------------------------------------------------------------
   template <typename Visitor>
-  bool TryOneBase(const Visitor&) {
-    int32_t ok = 0;
-    check(s4p_matcher_try_one_base(engine_, &ok, nullptr));
-    refresh();
-    return ok != 0;
+  bool TryOneBase(const Visitor& v) {
+    if (uses_stock_hooks()) {
+      int32_t ok = 0;
+      check(s4p_matcher_try_one_base(engine_, &ok, nullptr));
+      refresh();
+      return ok != 0;
+    }
+    Scalar invariant1, invariant2;
+    int base_id1, base_id2, base_id3, base_id4;
+    if (!SelectQuadrilateral(invariant1, invariant2, base_id1, base_id2, base_id3, base_id4)) return false;      // :313-316
+    const Scalar distance1 = diff_norm(base_3D_[0].pos(), base_3D_[1].pos());                                     // :318-321
+    const Scalar distance2 = diff_norm(base_3D_[2].pos(), base_3D_[3].pos());
+    const Scalar normal_angle1 = diff_norm(base_3D_[0].normal(), base_3D_[1].normal());                           // :326-327
+    const Scalar normal_angle2 = diff_norm(base_3D_[2].normal(), base_3D_[3].normal());
+    PairsVector pairs1, pairs2;
+    std::vector<Quadrilateral> congruent_quads;
+    ExtractPairs(distance1, normal_angle1, distance_factor * options_.delta, 0, 1, &pairs1);                      // virtual
+    ExtractPairs(distance2, normal_angle2, distance_factor * options_.delta, 2, 3, &pairs2);
+    if (pairs1.size() == 0 || pairs2.size() == 0) return false;                                                   // :335-337
+    if (!FindCongruentQuadrilaterals(invariant1, invariant2, distance_factor * options_.delta, distance_factor * options_.delta,
+                                     pairs1, pairs2, &congruent_quads)) return false;                             // virtual, :340-347
+    size_t nb = 0;
+    return TryCongruentSet(base_id1, base_id2, base_id3, base_id4, congruent_quads, v, nb);
   }
 
   // ---- match4pcsBase.cc:279-351 ------------------------------------------------------------------
@@ -159,6 +211,11 @@ class Match4PCSBase {
   }
   const std::vector<Point3D>& base3D() const { return base_3D_; }
 
+  // True iff the object's ExtractPairs / FindCongruentQuadrilaterals are the stock device implementations, so that the
+  // trial loop may run fused inside the engine.  MatchSuper4PCS answers by dynamic type; a subclass that does not touch
+  // the hooks may override this to return true and keep the fused loop.
+  virtual bool uses_stock_hooks() const { return false; }
+
   // ---- virtual hooks (match4pcsBase.h:270-326); MatchSuper4PCS implements them on the GPU ------------
   virtual void Initialize(const std::vector<Point3D>& P, const std::vector<Point3D>& Q) = 0;
   virtual void ExtractPairs(Scalar pair_distance, Scalar pair_normals_angle, Scalar pair_distance_epsilon, int base_point1,
@@ -170,13 +227,29 @@ class Match4PCSBase {
   // ---- match4pcsBase.hpp:363-497 -----------------------------------------------------------------
   template <typename Visitor>
   bool TryCongruentSet(int base_id1, int base_id2, int base_id3, int base_id4, const std::vector<Quadrilateral>& congruent_quads,
-                       const Visitor&, size_t& nbCongruent) {
+                       const Visitor& v, size_t& nbCongruent) {
     const int32_t ids[4] = {base_id1, base_id2, base_id3, base_id4};
     std::vector<int32_t> q(congruent_quads.size() * 4);
     for (size_t i = 0; i < congruent_quads.size(); ++i) for (int k = 0; k < 4; ++k) q[4 * i + size_t(k)] = congruent_quads[i][k];
     s4p_base_result r;
     check(s4p_try_congruent_set(s4p_matcher_ctx(engine_), ids, q.data(), int64_t(congruent_quads.size()), nullptr, &r));
     nbCongruent = size_t(r.n_verified);
+    if (!std::is_same<Visitor, DummyTransformVisitor>::value && r.n_verified) {       // v(-1, lcp, T) per candidate, :458-465
+      std::vector<uint32_t> cnt(size_t(r.n_verified)); std::vector<float> Ts(size_t(r.n_verified) * 16);
+      int64_t nv = 0;
+      check(s4p_last_verified(s4p_matcher_ctx(engine_), cnt.data(), Ts.data(), int64_t(r.n_verified), &nv));
+      for (int64_t k = 0; k < nv; ++k) {
+        float* T = Ts.data() + 16 * size_t(k);
+        if (v.needsGlobalTransformation())                                            // getGlobalTransform, :446-456
+          for (int a = 0; a < 3; ++a) {
+            const float rq = T[4 * a] * centroid_Q_(0) + (T[4 * a + 1] * centroid_Q_(1) + T[4 * a + 2] * centroid_Q_(2));
+            T[4 * a + 3] = (T[4 * a + 3] + centroid_P_(a)) - rq;
+          }
+        MatrixType Tm;
+        from_rowmajor(T, Tm);
+        v(-1, float(cnt[size_t(k)]) / float(sampled_Q_3D_.size()), Tm);
+      }
+    }
     r.n_pairs1 = r.n_pairs2 = 1; r.n_quads = congruent_quads.size();
     int32_t ok = 0;
     check(s4p_matcher_commit(engine_, 1, ids, &r, &ok));
@@ -238,6 +311,19 @@ class Match4PCSBase {
   template <class Mat> static void to_rowmajor(const Mat& T, float* M) { for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) M[4 * r + c] = T(r, c); }
   template <class Mat> static void from_rowmajor(const float* M, Mat&& T) { for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) T(r, c) = M[4 * r + c]; }
 
+  // (a - b).norm() of two 3-vectors in Eigen's fixed-size evaluation order x + (y + z); written on coefficients so that it
+  // also serves the Eigen-free build
+  template <class V> static Scalar diff_norm(const V& a, const V& b) {
+    const Scalar d0 = a(0) - b(0), d1 = a(1) - b(1), d2 = a(2) - b(2);
+    return std::sqrt(d0 * d0 + (d1 * d1 + d2 * d2));
+  }
+  // transform_ (centred frame) or the global transform of the current best (match4pcsBase.hpp:224-229, 246-252), row-major
+  void current_transform(bool global, float* M) {
+    if (global) { check(s4p_matcher_global_transform(engine_, M)); return; }
+    s4p_matcher_info i;
+    check(s4p_matcher_get_info(engine_, &i));
+    for (int k = 0; k < 16; ++k) M[k] = i.transform[k];
+  }
   void refresh() {
     s4p_matcher_info i;
     check(s4p_matcher_get_info(engine_, &i));

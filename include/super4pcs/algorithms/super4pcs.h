@@ -4,6 +4,8 @@
 #ifndef S4P_FACADE_SUPER4PCS_H_
 #define S4P_FACADE_SUPER4PCS_H_
 
+#include <typeinfo>
+
 #include "super4pcs/algorithms/match4pcsBase.h"
 
 namespace GlobalRegistration {
@@ -18,6 +20,10 @@ class MatchSuper4PCS : public Match4PCSBase {
   ~MatchSuper4PCS() {}
 
  protected:
+  // The fused device loop only when the object IS a MatchSuper4PCS: any subclass may have overridden the hooks below
+  // (tests/testing.h:71-154 does), and then the trial loop must call them (match4pcsBase.hpp:328-347).
+  bool uses_stock_hooks() const override { return typeid(*this) == typeid(MatchSuper4PCS); }
+
   // super4pcs.cc:183-224
   void ExtractPairs(Scalar pair_distance, Scalar pair_normals_angle, Scalar pair_distance_epsilon, int base_point1,
                     int base_point2, PairsVector* pairs) const override {

@@ -339,7 +339,7 @@ MATCHER_SYMBOLS = [
     "s4p_matcher_create", "s4p_matcher_destroy", "s4p_matcher_last_error", "s4p_matcher_ctx", "s4p_uniform_dist_sample",
     "s4p_matcher_init", "s4p_matcher_init_full", "s4p_matcher_get_info", "s4p_matcher_get_sampled",
     "s4p_matcher_get_sampled_attrs", "s4p_matcher_select_quadrilateral", "s4p_matcher_try_one_base", "s4p_matcher_next_base", "s4p_matcher_next_base_async", "s4p_matcher_wait_base", "s4p_matcher_set_sharding", "s4p_matcher_visit_candidates", "s4p_matcher_commit", "s4p_matcher_perform_n_steps", "s4p_matcher_set_device_selection", "s4p_matcher_device_selection", "s4p_matcher_grow_on_overflow", "s4p_matcher_capacity_growths",
-    "s4p_matcher_global_transform", "s4p_matcher_compute_transformation",
+    "s4p_matcher_global_transform", "s4p_matcher_compute_transformation", "s4p_matcher_advance_trials",
 ]
 VISITOR_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_float, C.c_float, C.POINTER(C.c_float))
 _MATCHER_DECLARED = False

@@ -873,6 +873,14 @@ int32_t s4p_matcher_commit(s4p_matcher* m, int32_t found, const int32_t* base_id
   return S4P_OK;
 }
 
+// current_trial_ += n (match4pcsBase.hpp:258) for a driver that runs the trial loop itself through the stage-level calls
+// (the facade does when a subclass overrides the virtual hooks).
+int32_t s4p_matcher_advance_trials(s4p_matcher* m, int32_t n) {
+  if (!m || n < 0) return S4P_ERR_BAD_ARG;
+  m->current_trial += n;
+  return S4P_OK;
+}
+
 int32_t s4p_matcher_global_transform(s4p_matcher* m, float* M) {
   if (!m || !M) return S4P_ERR_BAD_ARG;
   global_transform(m, M);

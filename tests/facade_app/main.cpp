@@ -38,6 +38,34 @@ class TestMatcher : public BaseMatcher {
   }
 };
 
+// A subclass that USES the plugin points (match4pcsBase.h:300-326): its ExtractPairs drops some of the pairs the stock
+// implementation found, its FindCongruentQuadrilaterals records what it is handed.  The trial loop must route through
+// both (match4pcsBase.hpp:328-347) -- the fused device loop would silently ignore them.
+class FilteringMatcher : public MatchSuper4PCS {
+ public:
+  using MatchSuper4PCS::MatchSuper4PCS;
+  mutable long extract_calls = 0, pairs_found = 0, pairs_kept = 0, find_calls = 0, pairs_seen_by_find = 0;
+ protected:
+  void ExtractPairs(Scalar d, Scalar na, Scalar e, int p1, int p2, PairsVector* out) const override {
+    MatchSuper4PCS::ExtractPairs(d, na, e, p1, p2, out);
+    ++extract_calls; pairs_found += long(out->size());
+    PairsVector kept;
+    for (const auto& pr : *out) if ((pr.first + pr.second) % 4 != 0) kept.push_back(pr);
+    out->swap(kept);
+    pairs_kept += long(out->size());
+  }
+  bool FindCongruentQuadrilaterals(Scalar i1, Scalar i2, Scalar t1, Scalar t2, const PairsVector& a, const PairsVector& b,
+                                   std::vector<Quadrilateral>* q) const override {
+    ++find_calls; pairs_seen_by_find += long(a.size() + b.size());
+    return MatchSuper4PCS::FindCongruentQuadrilaterals(i1, i2, t1, t2, a, b, q);
+  }
+};
+
+static bool same_matrix(const Match4PCSBase::MatrixType& a, const Match4PCSBase::MatrixType& b) {
+  for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) if (!(a(r, c) == b(r, c))) return false;
+  return true;
+}
+
 int main(int argc, char** argv) {
   const bool expect_gpu = argc > 1 && std::atoi(argv[1]) != 0;
   Match4PCSOptions opt;
@@ -65,6 +93,33 @@ int main(int argc, char** argv) {
     std::printf("score %.4f visitor calls %d sampled %zu/%zu\n", score, vis.calls, matcher.getFirstSampled().size(),
                 matcher.getSecondSampled().size());
     if (!(score > 0.5f) || vis.calls < 2) return 4;
+    // The same registration through the stock class: TestMatcher overrides the hooks (by forwarding), so it ran the
+    // staged loop of the facade; MatchSuper4PCS itself runs the fused device loop.  Same trials, same candidates: the
+    // score, the 4x4 and the transformed cloud must agree bit for bit, and so must the number of visitor calls.
+    {
+      MatchSuper4PCS stock(opt, logger);
+      Match4PCSBase::MatrixType mat_s = Match4PCSBase::MatrixType::Identity();
+      CountingVisitor vis_s;
+      std::vector<Point3D> Q3 = Q;
+      const float score_s = stock.ComputeTransformation(P, &Q3, mat_s, Sampling::UniformDistSampler(), vis_s);
+      bool same_cloud = Q3.size() == Q2.size();
+      for (size_t i = 0; same_cloud && i < Q3.size(); ++i)
+        same_cloud = Q3[i].x() == Q2[i].x() && Q3[i].y() == Q2[i].y() && Q3[i].z() == Q2[i].z();
+      std::printf("routes: staged %.6f (%d visitor calls) fused %.6f (%d)\n", score, vis.calls, score_s, vis_s.calls);
+      if (score_s != score || !same_matrix(mat, mat_s) || !same_cloud || vis.calls != vis_s.calls) return 9;
+    }
+    // a subclass that filters pairs: its hooks must be called by the trial loop and must shape the result's inputs
+    {
+      FilteringMatcher fm(opt, logger);
+      Match4PCSBase::MatrixType mat_f = Match4PCSBase::MatrixType::Identity();
+      std::vector<Point3D> Q4 = Q;
+      const float score_f = fm.ComputeTransformation(P, &Q4, mat_f);
+      std::printf("filtering subclass: score %.4f extract calls %ld pairs %ld -> %ld, find calls %ld saw %ld pairs\n", score_f,
+                  fm.extract_calls, fm.pairs_found, fm.pairs_kept, fm.find_calls, fm.pairs_seen_by_find);
+      if (fm.extract_calls < 2 || fm.extract_calls % 2 != 0) return 10;          // two calls per trial (match4pcsBase.hpp:328-331)
+      if (!(fm.pairs_kept < fm.pairs_found) || fm.find_calls < 1) return 11;
+      if (fm.pairs_seen_by_find > fm.pairs_kept) return 12;                       // FindCongruentQuadrilaterals got the FILTERED lists
+    }
     // empty sets (tests/externalAppTest/main.cpp): kLargeNumber
     std::vector<Point3D> e1, e2;
     if (matcher.ComputeTransformation(e1, &e2, mat) != Match4PCSBase::kLargeNumber) return 5;

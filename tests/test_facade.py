@@ -33,3 +33,4 @@ def test_facade_registers_on_gpu(tmp_path, s4p_lib_built):
     out = subprocess.run([exe, "1"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "score" in out.stdout and "quads" in out.stdout
+    assert "routes: staged" in out.stdout and "filtering subclass" in out.stdout     # overridden hooks are honoured (main.cpp)
