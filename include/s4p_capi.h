@@ -133,6 +133,10 @@ int32_t s4p_set_clouds(s4p_ctx* ctx,
                        const float* qnx, const float* qny, const float* qnz,
                        const float* qr, const float* qg, const float* qb, int64_t n_q);
 
+/* Wall time of the last s4p_set_clouds in seconds: {host copies + unit frame + grid plan, device build of the LCP
+ * structure, Q-side uploads, total}.  Measurement aid, no reference counterpart. */
+int32_t s4p_set_clouds_timing(const s4p_ctx* ctx, double* out4);
+
 /* base_3D_ of the current RANSAC base (4 points, ordered as TryQuadrilateral left them):
  * positions, normals, rgb as float[12] each (normals/rgb nullable).
  * Replaces PairCreationFunctor::setBase (pairCreationFunctor.h:135-143). */

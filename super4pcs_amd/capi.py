@@ -21,7 +21,7 @@ EXPORTED_SYMBOLS = [
     "s4p_create", "s4p_destroy", "s4p_last_error", "s4p_device_name", "s4p_set_clouds", "s4p_set_base",
     "s4p_extract_pairs", "s4p_find_congruent", "s4p_try_congruent_set", "s4p_verify_transforms", "s4p_verify_transforms_counted",
     "s4p_transform_points_device", "s4p_apply_bench", "s4p_select_base_points", "s4p_grow_limits", "s4p_get_limits", "s4p_try_base", "s4p_last_verified", "s4p_try_base_async", "s4p_try_base_wait", "s4p_pair_state_words", "s4p_pair_state_save", "s4p_pair_state_restore", "s4p_stage_slots", "s4p_pipeline_depth", "s4p_stage_base", "s4p_try_base_staged_async", "s4p_skip_base", "s4p_last_candidates", "s4p_transform_points", "s4p_profile_enable", "s4p_profile_get",
-    "s4p_selftest_ieee", "s4p_set_quad_chunking", "s4p_chunk_stats", "s4p_set_auto_grow", "s4p_lane_growths", "s4p_border_stats", "s4p_quad_mix",
+    "s4p_selftest_ieee", "s4p_set_quad_chunking", "s4p_chunk_stats", "s4p_set_auto_grow", "s4p_lane_growths", "s4p_border_stats", "s4p_set_clouds_timing", "s4p_quad_mix",
 ]
 
 
@@ -134,6 +134,8 @@ def load_library():
         L.s4p_lane_growths.argtypes = [vp]
         L.s4p_border_stats.restype = C.c_int32
         L.s4p_border_stats.argtypes = [vp, C.POINTER(C.c_uint64)]
+        L.s4p_set_clouds_timing.restype = C.c_int32
+        L.s4p_set_clouds_timing.argtypes = [vp, C.POINTER(C.c_double)]
         L.s4p_quad_mix.restype = C.c_uint64
         L.s4p_quad_mix.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32]
     _LIB = L
@@ -480,6 +482,11 @@ class Matcher:
         o = (C.c_uint64 * 4)()
         self.L.s4p_chunk_stats(self.ctx_handle(), o)
         return {"bases": int(o[0]), "passes": int(o[1]), "splits": int(o[2]), "quads": int(o[3])}
+
+    def set_clouds_timing(self):
+        o = (C.c_double * 4)()
+        self.L.s4p_set_clouds_timing(self.ctx_handle(), o)
+        return {"host_prep_s": o[0], "device_build_s": o[1], "q_uploads_s": o[2], "total_s": o[3]}
 
     def border_stats(self):
         o = (C.c_uint64 * 2)()

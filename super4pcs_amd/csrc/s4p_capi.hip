@@ -151,7 +151,7 @@ struct s4p_ctx {
   bool auto_grow = true; uint64_t lane_growths = 0;
   // max_angle (shared4pcs.h:160): > 0 -> the segment-angle pair filter through an exact cosine threshold; >= 0 -> the
   // Euler-angle bound of ComputeRigidTransformation, decided on the device up to a margin and settled on the host
-  float cos_min = -1.f; bool angle_pairs = false;
+  float cos_min = -1.f; bool angle_pairs = false; float angle_tol = 1e-6f;   // S4P_ANGLE_TOL (read at creation) widens the device margin: a test aid
   uint64_t border_settled = 0, border_rejected = 0;
   std::vector<uint32_t> border_failed;   // quads of the last pass whose undecided gate the host rejected (per-candidate outputs say -1 for them)
   bool last_chunked = false;         // the per-candidate records of the last base were overwritten chunk by chunk
@@ -178,6 +178,7 @@ struct s4p_ctx {
   int list_align = 8;                // S4P_LIST_ALIGN (1, 2, 4, 8): point lists start on multiples of this many 16-byte records
   int cu_split = 0;                  // S4P_CU_SPLIT (0 = off): one CU in n for the small kernels, the rest for k_verify
   double host_octree_s = 0, host_wait_s = 0;
+  double set_clouds_s[4] = {0, 0, 0, 0};      // last s4p_set_clouds: host copies + unit frame + grid plan | device build of the LCP structure | Q-side uploads | total
 
   size_t verify_lds_bytes() const {
     return gcoarse.n * 4 + (qlds ? size_t((n_q + 127u) & ~127u) * 8 : 0) + size_t(verify_threads / 64) * kQueueWordsPerWave * 4;
@@ -329,8 +330,7 @@ BaseFrame make_base_frame(const s4p_ctx* c, const int32_t* base_ids) {
   b.gate = 2.0f * c->opt.delta;                                                        // distance_factor * delta
   b.max_angle_rad = float(double(c->opt.max_angle) * std::acos(-1.0) / 180.0);         // match4pcsBase.hpp:392,426
   b.angle_gate = c->opt.max_angle >= 0.f ? 1 : 0;                                      // match4pcsBase.cc:457
-  static const float tol = getenv("S4P_ANGLE_TOL") ? float(atof(getenv("S4P_ANGLE_TOL"))) : 1e-6f;
-  b.angle_tol = tol > 1e-6f ? tol : 1e-6f;
+  b.angle_tol = c->angle_tol;
   return b;
 }
 
@@ -387,14 +387,16 @@ void launch_prep_kernel(s4p_ctx* c, const PrepParams& P1, const PrepParams& P2) 
 void launch_quads_kernel(s4p_ctx* c, const QuadParams& Q) {
   // one set-2 entry per thread in ONE pass for up to 512 k entries (a second grid-stride pass doubles the chain of
   // dependent gathers of the workgroups that get one); idle workgroups leave after reading the count
-  const uint32_t span = Q.r1 - Q.r0;                        // (the whole set: 2^32 - 1)
-  const uint32_t blocks = std::min<uint32_t>(2048u, std::max<uint32_t>(1u, (span + 255u) / 256u));
-  hipLaunchKernelGGL(k_quads, dim3(blocks), dim3(256), 0, c->lane[c->cur].stream, Q);
+  const uint64_t span = uint64_t(Q.r1) - uint64_t(Q.r0);    // (the whole set: 2^32 - 1)
+  const uint32_t blocks = uint32_t(std::min<uint64_t>(2048u, std::max<uint64_t>(1u, (span + 255u) / 256u)));
+  if (c->opt.max_angle >= 0.f) hipLaunchKernelGGL(k_quads<true>, dim3(blocks), dim3(256), 0, c->lane[c->cur].stream, Q);
+  else hipLaunchKernelGGL(k_quads<false>, dim3(blocks), dim3(256), 0, c->lane[c->cur].stream, Q);
 }
 void launch_gate_kernel(s4p_ctx* c, const GateParams& G) {
   s4p_ctx::Lane& L = c->lane[c->cur];
   GateKernelParams K{G, L.quads.p, &L.ctr.p->K, uint32_t(L.cap_quads)};   // (K: 64-bit counter)
-  hipLaunchKernelGGL(k_gate, dim3(1024), dim3(256), 0, L.stream, K);
+  if (c->opt.max_angle >= 0.f) hipLaunchKernelGGL(k_gate<true>, dim3(1024), dim3(256), 0, L.stream, K);
+  else hipLaunchKernelGGL(k_gate<false>, dim3(1024), dim3(256), 0, L.stream, K);
 }
 
 // Verify of every gated candidate + winner selection + result record (k_verify), bracketed by the profiling events
@@ -524,7 +526,7 @@ int32_t settle_borderline(s4p_ctx* c, DevCounters& d, const BaseFrame& bf) {
     float q[3][3], T[12], c2[3];
     for (int a = 0; a < 3; ++a) { q[a][0] = c->hqx[size_t(ids[a])]; q[a][1] = c->hqy[size_t(ids[a])]; q[a][2] = c->hqz[size_t(ids[a])]; }
     c->border_settled++;
-    if (rigid_verdict(bf, q, T, c2) != 0) {                // host: the exact expression
+    if (rigid_verdict<true>(bf, q, T, c2) != 0) {          // host: the exact expression
       if (!have || count > d.best_count || (count == d.best_count && tag < d.best_tag)) {
         have = true; d.best_count = count; d.best_tag = tag; d.has_best = 1u;
         d.best_quad[0] = qd.x; d.best_quad[1] = qd.y; d.best_quad[2] = qd.z; d.best_quad[3] = qd.w;
@@ -773,6 +775,7 @@ int32_t s4p_create(const s4p_options* opt, const s4p_limits* lim, int32_t device
   if (const char* fu = getenv("S4P_FUSE_GATE")) c->fuse_gate = atoi(fu) != 0;
   if (const char* la = getenv("S4P_LIST_ALIGN")) { const int v = atoi(la); if (v == 1 || v == 2 || v == 4 || v == 8) c->list_align = v; }
   if (const char* cs = getenv("S4P_CU_SPLIT")) { const int v = atoi(cs); if (v >= 2 && v <= 64) c->cu_split = v; }
+  if (const char* at = getenv("S4P_ANGLE_TOL")) { const float v = float(atof(at)); if (v > 1e-6f) c->angle_tol = v; }
   if (const char* qc = getenv("S4P_QUAD_GROW_CAP")) { const long long v = atoll(qc); if (v > 0 && v <= 0x7FFFFFFFll) c->quad_grow_cap = uint64_t(v); }
   snprintf(c->devname, sizeof c->devname, "%s (%s)", prop.name, prop.gcnArchName);
   // defaults: 1 Mi pairs per set, 4 Mi quads per base -- 0.45 GB per lane, a context in ~20 ms (4 Mi / 16 Mi took 0.3-0.6 s to
@@ -937,6 +940,17 @@ int32_t s4p_device_name(const s4p_ctx* c, char* buf, int32_t buflen) {
   return S4P_OK;
 }
 
+namespace {
+// exclusive scan of v[0..n) in place on stream st, *total = the sum (k_scan_* in s4p_kernels.hip.hpp); tmp: >= n / kScanTile + 1 words
+void launch_scan(uint32_t* v, uint32_t n, uint32_t* total, uint32_t* tmp, hipStream_t st) {
+  if (n <= 4u * kScanTile) { hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, st, v, n, total); return; }
+  const uint32_t tiles = (n + kScanTile - 1u) / kScanTile;
+  hipLaunchKernelGGL(k_scan_tile_sums, dim3(tiles), dim3(1024), 0, st, v, n, tmp);
+  hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, st, tmp, tiles, total);
+  hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(1024), 0, st, v, n, tmp);
+}
+}  // namespace
+
 int32_t s4p_set_clouds(s4p_ctx* c, const float* px, const float* py, const float* pz, int64_t n_p,
                        const float* qx, const float* qy, const float* qz,
                        const float* qnx, const float* qny, const float* qnz,
@@ -947,6 +961,8 @@ int32_t s4p_set_clouds(s4p_ctx* c, const float* px, const float* py, const float
   if (n_p > 0x7FFFFFF0ll) S4P_FAIL(c, S4P_ERR_UNSUPPORTED, "sampled P too large");
   if (c->q_head != c->q_tail) S4P_FAIL(c, S4P_ERR_STATE, "s4p_set_clouds: asynchronous bases outstanding (their kernels read the buffers this call replaces): call s4p_try_base_wait first");
   HIPCHK(c, hipSetDevice(c->device));
+  const auto sc_t0 = std::chrono::steady_clock::now();
+  auto sc_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); };
   c->clouds_set = false;
   c->n_p = uint32_t(n_p); c->n_q = uint32_t(n_q);
   c->hpx.assign(px, px + n_p); c->hpy.assign(py, py + n_p); c->hpz.assign(pz, pz + n_p);
@@ -956,17 +972,19 @@ int32_t s4p_set_clouds(s4p_ctx* c, const float* px, const float* py, const float
   float cell_factor = LcpGridHost::kMinCellFactor;
   if (const char* cf = getenv("S4P_CELL_FACTOR")) cell_factor = float(atof(cf));      // tuning knob: LCP cell edge / delta
   if (!c->hgrid.plan(c->hpx, c->hpy, c->hpz, c->opt.delta, c->max_grid_cells, kCoarseMaxWords, cell_factor)) S4P_FAIL(c, S4P_ERR_STATE, "LCP grid planning failed");
+  c->set_clouds_s[0] = sc_since(sc_t0);
+  const auto sc_t1 = std::chrono::steady_clock::now();
   {  // device build of the LCP structure (counting formulation, see k_grid_* in s4p_kernels.hip.hpp)
     hipStream_t st = c->lane[0].stream;
     const uint64_t nc = c->hgrid.ncell();
     const uint32_t nwords = uint32_t((nc + 31) / 32);
-    DevBuf<float> dpx, dpy, dpz; DevBuf<uint32_t> cell_count, word_pop, hdr_count, cell_id, cursor, totals;
+    DevBuf<float> dpx, dpy, dpz; DevBuf<uint32_t> cell_count, word_pop, hdr_count, cell_id, cursor, totals, scan_tmp;
     hipError_t e = hipSuccess;
     int32_t rc = S4P_OK;
     auto step = [&](hipError_t r) { if (e == hipSuccess) e = r; return e == hipSuccess; };
     do {
       if (!step(dpx.alloc(n_p)) || !step(dpy.alloc(n_p)) || !step(dpz.alloc(n_p)) || !step(cell_count.alloc(nc)) ||
-          !step(word_pop.alloc(nwords)) || !step(totals.alloc(2)) || !step(c->greach.alloc(nwords)) || !step(c->gcoarse.alloc(c->hgrid.coarse_words))) break;
+          !step(word_pop.alloc(nwords)) || !step(totals.alloc(2)) || !step(scan_tmp.alloc(size_t(nc / kScanTile) + 8)) || !step(c->greach.alloc(nwords)) || !step(c->gcoarse.alloc(c->hgrid.coarse_words))) break;
       step(hipMemcpyAsync(dpx.p, c->hpx.data(), n_p * 4, hipMemcpyHostToDevice, st));
       step(hipMemcpyAsync(dpy.p, c->hpy.data(), n_p * 4, hipMemcpyHostToDevice, st));
       step(hipMemcpyAsync(dpz.p, c->hpz.data(), n_p * 4, hipMemcpyHostToDevice, st));
@@ -983,7 +1001,7 @@ int32_t s4p_set_clouds(s4p_ctx* c, const float* px, const float* py, const float
       G.coarse = c->gcoarse.p; G.cshift = c->hgrid.cshift; G.cnx = c->hgrid.cnx; G.cny = c->hgrid.cny;
       hipLaunchKernelGGL(k_grid_count, dim3(2048), dim3(256), 0, st, G);
       hipLaunchKernelGGL(k_grid_words, dim3(1024), dim3(256), 0, st, G, word_pop.p);
-      hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, st, word_pop.p, nwords, totals.p);
+      launch_scan(word_pop.p, nwords, totals.p, scan_tmp.p, st);
       uint32_t n_reach = 0;
       step(hipMemcpyAsync(&n_reach, totals.p, 4, hipMemcpyDeviceToHost, st));
       if (!step(hipStreamSynchronize(st))) break;
@@ -996,7 +1014,7 @@ int32_t s4p_set_clouds(s4p_ctx* c, const float* px, const float* py, const float
       if (!step(starts.alloc(n_reach))) break;
       step(hipMemcpyAsync(starts.p, hdr_count.p, size_t(n_reach) * 4, hipMemcpyDeviceToDevice, st));
       if (c->list_align > 1) hipLaunchKernelGGL(k_round_up, dim3(1024), dim3(256), 0, st, starts.p, n_reach, uint32_t(c->list_align));
-      hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, st, starts.p, n_reach, totals.p + 1);
+      launch_scan(starts.p, n_reach, totals.p + 1, scan_tmp.p, st);
       uint32_t n_entries = 0;
       step(hipMemcpyAsync(&n_entries, totals.p + 1, 4, hipMemcpyDeviceToHost, st));
       if (!step(hipStreamSynchronize(st))) { starts.free(); break; }
@@ -1013,15 +1031,17 @@ int32_t s4p_set_clouds(s4p_ctx* c, const float* px, const float* py, const float
       M.list_hdr = c->glist_hdr.p; M.nbr = c->gnbr.p; M.cell_id = cell_id.p; M.n_reach = n_reach;
       M.ox = c->hgrid.ox; M.oy = c->hgrid.oy; M.oz = c->hgrid.oz; M.h = c->hgrid.h; M.nx = c->hgrid.nx; M.ny = c->hgrid.ny;
       M.reach2 = G.reach2;
-      hipLaunchKernelGGL(k_build_masks, dim3((n_reach + 255) / 256), dim3(256), 0, st, M);
+      hipLaunchKernelGGL(k_build_masks, dim3(std::min<uint32_t>((n_reach + 3u) / 4u, 65536u)), dim3(256), 0, st, M);   // a wave per cell
       step(hipGetLastError());
       step(hipStreamSynchronize(st));
       starts.free();
     } while (0);
-    dpx.free(); dpy.free(); dpz.free(); cell_count.free(); word_pop.free(); hdr_count.free(); cell_id.free(); cursor.free(); totals.free();
+    dpx.free(); dpy.free(); dpz.free(); cell_count.free(); word_pop.free(); hdr_count.free(); cell_id.free(); cursor.free(); totals.free(); scan_tmp.free();
     if (rc != S4P_OK) return rc;
     HIPCHK(c, e);
   }
+  c->set_clouds_s[1] = sc_since(sc_t1);
+  const auto sc_t2 = std::chrono::steady_clock::now();
   {
     std::vector<float4> q4((size_t)n_q);
     for (int64_t i = 0; i < n_q; ++i) q4[size_t(i)] = make_float4(qx[i], qy[i], qz[i], 0.f);
@@ -1091,6 +1111,15 @@ int32_t s4p_set_clouds(s4p_ctx* c, const float* px, const float* py, const float
     for (auto& st : c->stage) HIPCHK(c, st.seq[s].alloc(s4p_ctx::StageSlot::blob_words(n_q)));
   }
   c->clouds_set = true;
+  c->set_clouds_s[2] = sc_since(sc_t2); c->set_clouds_s[3] = sc_since(sc_t0);
+  return S4P_OK;
+}
+
+// Wall time of the last s4p_set_clouds, seconds: {host copies + unit frame + grid plan, device build of the LCP structure,
+// Q-side uploads, total}.  Measurement aid.
+int32_t s4p_set_clouds_timing(const s4p_ctx* c, double* out4) {
+  if (!c || !out4) return S4P_ERR_BAD_ARG;
+  for (int k = 0; k < 4; ++k) out4[k] = c->set_clouds_s[k];
   return S4P_OK;
 }
 

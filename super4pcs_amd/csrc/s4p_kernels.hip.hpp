@@ -225,7 +225,47 @@ __global__ __launch_bounds__(256) void k_grid_words(GridBuildParams P, uint32_t*
     word_pop[w] = uint32_t(__popc(bits));
   }
 }
-// single-workgroup exclusive scan of n values (in place); *total = sum.  n up to a few million (one-off use).
+// Exclusive scan of n values (in place), *total = sum: three launches over tiles of kScanTile values -- per-tile sums,
+// a single-workgroup scan of those (<= a few thousand), per-tile scan seeded with the tile's offset.  (The former single
+// workgroup walked the whole array: 0.15 ms at 2 10^6 cells, linear in the grid; SURVEY 8 f1 sizes have 10^8 cells.)
+constexpr uint32_t kScanTile = 4096;                 // 1024 threads x 4 values
+__device__ __forceinline__ uint32_t block_exclusive_scan_1024(uint32_t v, uint32_t* s_wave, uint32_t* block_total) {
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  uint32_t incl = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const uint32_t up = uint32_t(__shfl_up(int(incl), o)); if (lane >= uint32_t(o)) incl += up; }
+  if (lane == 63u) s_wave[wave] = incl;
+  __syncthreads();
+  if (wave == 0) {
+    uint32_t w = lane < 16u ? s_wave[lane] : 0u, wi = w;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) { const uint32_t up = uint32_t(__shfl_up(int(wi), o)); if (lane >= uint32_t(o)) wi += up; }
+    if (lane < 16u) s_wave[lane] = wi - w;           // exclusive prefix of the wave sums
+    if (lane == 15u) *block_total = wi;
+  }
+  __syncthreads();
+  return s_wave[wave] + incl - v;
+}
+__global__ __launch_bounds__(1024) void k_scan_tile_sums(const uint32_t* v, uint32_t n, uint32_t* tile_sum) {
+  __shared__ uint32_t s_wave[16], s_total;
+  const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * 4u;
+  uint32_t sum = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < 4u; ++k) if (base + k < n) sum += v[base + k];
+  (void)block_exclusive_scan_1024(sum, s_wave, &s_total);
+  if (threadIdx.x == 0) tile_sum[blockIdx.x] = s_total;
+}
+__global__ __launch_bounds__(1024) void k_scan_tiles(uint32_t* v, uint32_t n, const uint32_t* tile_offset) {
+  __shared__ uint32_t s_wave[16], s_total;
+  const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * 4u;
+  uint32_t x[4], sum = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < 4u; ++k) { x[k] = base + k < n ? v[base + k] : 0u; sum += x[k]; }
+  uint32_t run = tile_offset[blockIdx.x] + block_exclusive_scan_1024(sum, s_wave, &s_total);
+#pragma unroll
+  for (uint32_t k = 0; k < 4u; ++k) { if (base + k < n) v[base + k] = run; run += x[k]; }
+}
+// single-workgroup exclusive scan of n values (in place); *total = sum: the tile sums of the scan above, small arrays
 __global__ __launch_bounds__(1024) void k_scan_exclusive(uint32_t* v, uint32_t n, uint32_t* total) {
   __shared__ uint32_t s_part[1024];
   const uint32_t per = (n + 1023u) / 1024u;
@@ -291,27 +331,32 @@ struct MaskParams {
   uint4* list_hdr; const float4* nbr; const uint32_t* cell_id; uint32_t n_reach;
   float ox, oy, oz, h; int nx, ny; double reach2;
 };
+// One wave per reachable cell, lane = one of its 64 sub-boxes: every lane walks the cell's list (the same address in all
+// lanes: one broadcast load per point) and tests its own sub-box; the mask is the ballot.  (A thread per cell ran
+// 64 x list length double-precision box tests serially and loaded its list uncoalesced: 0.37 ms at 1.4 10^5 cells.)
 __global__ __launch_bounds__(256) void k_build_masks(MaskParams P) {
-  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= P.n_reach) return;
-  uint4 hdr = P.list_hdr[r];
-  const uint32_t c = P.cell_id[r];
-  const int ix = int(c % uint32_t(P.nx)), iy = int((c / uint32_t(P.nx)) % uint32_t(P.ny)), iz = int(c / (uint32_t(P.nx) * uint32_t(P.ny)));
-  const double q = double(P.h) * 0.25;
-  const double bx = double(P.ox) + double(ix) * double(P.h), by = double(P.oy) + double(iy) * double(P.h), bz = double(P.oz) + double(iz) * double(P.h);
-  unsigned long long mask = 0ull;
-  for (uint32_t p = hdr.x; p < hdr.x + hdr.y; ++p) {
-    const float4 pp = P.nbr[p];
-    for (int s = 0; s < 64; ++s) {
-      const double lo[3] = {bx + (s & 3) * q, by + ((s >> 2) & 3) * q, bz + (s >> 4) * q};
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t waves = (gridDim.x * blockDim.x) >> 6;
+  for (uint32_t r = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; r < P.n_reach; r += waves) {
+    uint4 hdr = P.list_hdr[r];
+    const uint32_t c = P.cell_id[r];
+    const int ix = int(c % uint32_t(P.nx)), iy = int((c / uint32_t(P.nx)) % uint32_t(P.ny)), iz = int(c / (uint32_t(P.nx) * uint32_t(P.ny)));
+    const double q = double(P.h) * 0.25;
+    const double lo[3] = {double(P.ox) + double(ix) * double(P.h) + double(lane & 3u) * q,
+                          double(P.oy) + double(iy) * double(P.h) + double((lane >> 2) & 3u) * q,
+                          double(P.oz) + double(iz) * double(P.h) + double(lane >> 4) * q};
+    bool hit = false;
+    for (uint32_t p = hdr.x; p < hdr.x + hdr.y && !__all(hit); ++p) {
+      const float4 pp = P.nbr[p];
       const double v[3] = {double(pp.x), double(pp.y), double(pp.z)};
       double d2 = 0;
+#pragma unroll
       for (int k = 0; k < 3; ++k) { const double d = v[k] < lo[k] ? lo[k] - v[k] : (v[k] > lo[k] + q ? v[k] - (lo[k] + q) : 0.0); d2 += d * d; }
-      if (d2 <= P.reach2) mask |= (1ull << s);
+      hit = hit || d2 <= P.reach2;
     }
+    const unsigned long long mask = __ballot(hit);
+    if (lane == 0) { hdr.z = uint32_t(mask); hdr.w = uint32_t(mask >> 32); P.list_hdr[r] = hdr; }
   }
-  hdr.z = uint32_t(mask); hdr.w = uint32_t(mask >> 32);
-  P.list_hdr[r] = hdr;
 }
 
 // ---------------------------------------------------------------------------
@@ -661,6 +706,9 @@ __host__ __device__ inline int euler_verdict(const float R[3][3], const float ma
 
 // 0: rejected ("!ok || !(0 <= rms < 2 delta)", match4pcsBase.hpp:436-439); 1: a candidate; 2 (device only): a candidate if
 // the Euler-angle bound holds, which the host has to settle.
+// ANGLE: compiled with the Euler-angle bound (three double-precision atan2: ~70 extra registers in a kernel that inlines
+// it, so the variants without it stay the ones launched when options.max_angle < 0).
+template <bool ANGLE>
 __host__ __device__ __forceinline__ int rigid_verdict(const BaseFrame& b, const float q[3][3], float T[12], float c2[3]) {
   for (int k = 0; k < 3; ++k) c2[k] = ((q[0][k] + q[1][k]) + q[2][k]) / 3.f;    // match4pcsBase.hpp:415-417
   float vp[3][3], vq[3][3];
@@ -677,7 +725,7 @@ __host__ __device__ __forceinline__ int rigid_verdict(const BaseFrame& b, const 
     if (dg - 1.f > 1e-6f) return 0;
   }
   int verdict = 1;
-  if (b.angle_gate) {                                                              // .cc:457-472 (uniform over the launch)
+  if (ANGLE && b.angle_gate) {                                                     // .cc:457-472 (uniform over the launch)
     verdict = euler_verdict(R, b.max_angle_rad, b.angle_tol);
     if (verdict == 0) return 0;
   }
@@ -704,7 +752,7 @@ __host__ __device__ __forceinline__ int rigid_verdict(const BaseFrame& b, const 
   return verdict;
 }
 __host__ __device__ __forceinline__ bool rigid_gate(const BaseFrame& b, const float q[3][3], float T[12], float c2[3]) {
-  return rigid_verdict(b, q, T, c2) != 0;
+  return rigid_verdict<false>(b, q, T, c2) != 0;            // (without the Euler-angle bound: the transform of a candidate that is known to have passed)
 }
 
 // ---------------------------------------------------------------------------
@@ -1189,11 +1237,12 @@ struct GateParams {
   uint32_t* C_dev;
 };
 // 0 = rejected, 1 = candidate, 2 = candidate whose Euler-angle bound the host settles (rigid_verdict)
+template <bool ANGLE>
 __device__ __forceinline__ int gate_quad(const GateParams& G, const int4 qd, float T[12]) {
   const float4 a = G.q4[qd.x], b = G.q4[qd.y], c = G.q4[qd.z];
   const float q[3][3] = {{a.x, a.y, a.z}, {b.x, b.y, b.z}, {c.x, c.y, c.z}};
   float c2[3];
-  return rigid_verdict(G.base, q, T, c2);
+  return rigid_verdict<ANGLE>(G.base, q, T, c2);
 }
 // k: index of the quad, with kBorderFlag set if its gate is undecided
 __device__ __forceinline__ void store_candidate(const GateParams& G, const uint32_t at, const uint32_t k, const float T[12]) {
@@ -1208,6 +1257,7 @@ __device__ __forceinline__ void store_candidate(const GateParams& G, const uint3
 // candidates are compacted (wave-aggregated append) into cand_idx / cand_T so that the scoring kernel sees a dense,
 // perfectly balanceable list; failing ones get counts[k] = kGateFailed.
 struct GateKernelParams { GateParams g; const int4* quads; const unsigned long long* K_dev; uint32_t K_cap; };
+template <bool ANGLE>
 __global__ __launch_bounds__(256) void k_gate(GateKernelParams P) {
   const uint32_t K = uint32_t(min(*P.K_dev, (unsigned long long)P.K_cap));
   const uint32_t lane = threadIdx.x & 63u;
@@ -1216,7 +1266,7 @@ __global__ __launch_bounds__(256) void k_gate(GateKernelParams P) {
     float T[12];
     int vd = 0;
     if (k < K) {
-      vd = gate_quad(P.g, P.quads[k], T);
+      vd = gate_quad<ANGLE>(P.g, P.quads[k], T);
       if (!vd) P.g.counts[k] = kGateFailed;
     }
     const bool ok = vd != 0;
@@ -1263,6 +1313,7 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
   return v;
 }
 
+template <bool ANGLE>
 __global__ __launch_bounds__(256) void k_quads(QuadParams P) {
   __shared__ int4 st_q[kQuadStage];
   __shared__ unsigned long long st_t[kQuadStage];
@@ -1317,7 +1368,7 @@ __global__ __launch_bounds__(256) void k_quads(QuadParams P) {
                 P.quads[at] = quad; P.tags[at] = tag;
                 if (P.do_gate) {
                   float T[12];
-                  const int vd = gate_quad(P.gate, quad, T);
+                  const int vd = gate_quad<ANGLE>(P.gate, quad, T);
                   if (vd) { store_candidate(P.gate, atomicAdd(P.gate.C_dev, 1u), uint32_t(at) | (vd == 2 ? kBorderFlag : 0u), T); atomicAdd(&s_csum, mix); }
                   else P.gate.counts[at] = kGateFailed;
                 }
@@ -1346,7 +1397,7 @@ __global__ __launch_bounds__(256) void k_quads(QuadParams P) {
         { const unsigned long long ws = wave_sum_u64(mix); if (lane == 0 && ws) atomicAdd(&s_qsum, ws); }
         if (P.do_gate) {                                        // uniform
           float T[12];
-          const int vd = live ? gate_quad(P.gate, quad, T) : 0;
+          const int vd = live ? gate_quad<ANGLE>(P.gate, quad, T) : 0;
           const bool ok = vd != 0;
           if (live && !ok) P.gate.counts[at] = kGateFailed;
           const unsigned long long pass = __ballot(ok);
