@@ -175,7 +175,6 @@ struct s4p_ctx {
   // A/B aid: S4P_FUSE_GATE=0 runs the rigid transform + rms gate as a k_gate launch instead of
   // inside k_quads' flush (measured slower)
   bool fuse_gate = true;
-  int list_align = 8;                // S4P_LIST_ALIGN (1, 2, 4, 8): point lists start on multiples of this many 16-byte records
   int cu_split = 0;                  // S4P_CU_SPLIT (0 = off): one CU in n for the small kernels, the rest for k_verify
   double host_octree_s = 0, host_wait_s = 0;
   double set_clouds_s[4] = {0, 0, 0, 0};      // last s4p_set_clouds: host copies + unit frame + grid plan | device build of the LCP structure | Q-side uploads | total
@@ -773,7 +772,6 @@ int32_t s4p_create(const s4p_options* opt, const s4p_limits* lim, int32_t device
   }
   if (const char* vb = getenv("S4P_VERIFY_BLOCKS")) { const int v = atoi(vb); if (v >= 64 && v <= kVerifyMaxBlocks) c->verify_blocks = uint32_t(v); }   // tuning knob
   if (const char* fu = getenv("S4P_FUSE_GATE")) c->fuse_gate = atoi(fu) != 0;
-  if (const char* la = getenv("S4P_LIST_ALIGN")) { const int v = atoi(la); if (v == 1 || v == 2 || v == 4 || v == 8) c->list_align = v; }
   if (const char* cs = getenv("S4P_CU_SPLIT")) { const int v = atoi(cs); if (v >= 2 && v <= 64) c->cu_split = v; }
   if (const char* at = getenv("S4P_ANGLE_TOL")) { const float v = float(atof(at)); if (v > 1e-6f) c->angle_tol = v; }
   if (const char* qc = getenv("S4P_QUAD_GROW_CAP")) { const long long v = atoll(qc); if (v > 0 && v <= 0x7FFFFFFFll) c->quad_grow_cap = uint64_t(v); }
@@ -1006,25 +1004,27 @@ int32_t s4p_set_clouds(s4p_ctx* c, const float* px, const float* py, const float
       step(hipMemcpyAsync(&n_reach, totals.p, 4, hipMemcpyDeviceToHost, st));
       if (!step(hipStreamSynchronize(st))) break;
       if (n_reach == 0) { c->err = "LCP grid: no reachable cell"; rc = S4P_ERR_STATE; break; }
-      if (!step(hdr_count.alloc(n_reach)) || !step(cell_id.alloc(n_reach)) || !step(cursor.alloc(n_reach)) || !step(c->glist_hdr.alloc(n_reach))) break;
+      if (!step(hdr_count.alloc(n_reach)) || !step(cell_id.alloc(n_reach)) || !step(cursor.alloc(n_reach)) || !step(c->glist_hdr.alloc(size_t(n_reach) * 2u))) break;
       G.list_hdr = c->glist_hdr.p; G.cell_id = cell_id.p; G.cursor = cursor.p;
       hipLaunchKernelGGL(k_grid_headers, dim3(1024), dim3(256), 0, st, G, word_pop.p, hdr_count.p);
-      // list starts = exclusive scan of the per-cell counts (kept: hdr_count -> copy before scanning in place)
+      // first line of every list = exclusive scan of the per-cell LINE counts (8 points per 128-byte line)
       DevBuf<uint32_t> starts;
       if (!step(starts.alloc(n_reach))) break;
       step(hipMemcpyAsync(starts.p, hdr_count.p, size_t(n_reach) * 4, hipMemcpyDeviceToDevice, st));
-      if (c->list_align > 1) hipLaunchKernelGGL(k_round_up, dim3(1024), dim3(256), 0, st, starts.p, n_reach, uint32_t(c->list_align));
+      hipLaunchKernelGGL(k_lines_of, dim3(1024), dim3(256), 0, st, starts.p, n_reach);
       launch_scan(starts.p, n_reach, totals.p + 1, scan_tmp.p, st);
-      uint32_t n_entries = 0;
-      step(hipMemcpyAsync(&n_entries, totals.p + 1, 4, hipMemcpyDeviceToHost, st));
+      uint32_t n_lines = 0;
+      step(hipMemcpyAsync(&n_lines, totals.p + 1, 4, hipMemcpyDeviceToHost, st));
       if (!step(hipStreamSynchronize(st))) { starts.free(); break; }
-      if (!step(c->gnbr.alloc(n_entries))) { starts.free(); break; }
+      if (uint64_t(n_lines) * 8u >= (1ull << 31)) { c->err = "LCP grid: point lists beyond 2^31 records"; rc = S4P_ERR_CAPACITY; starts.free(); break; }
+      if (!step(c->gnbr.alloc(size_t(n_lines) * 8u))) { starts.free(); break; }
       G.nbr = c->gnbr.p;
       { // k_verify block size: see kVerifyThreadsCached (s4p_kernels.hip.hpp)
         const char* vt = getenv("S4P_VERIFY_THREADS");
         const int v = vt ? atoi(vt) : 0;
         c->verify_threads = (v >= 256 && v <= kVerifyMaxThreads && v % 64 == 0) ? v
-                          : (size_t(n_entries) * sizeof(float4) > (size_t(192) << 20) ? kVerifyMaxThreads : kVerifyThreadsCached); }
+                          : (size_t(n_lines) * 128u > (size_t(192) << 20) ? kVerifyMaxThreads : kVerifyThreadsCached); }
+      hipLaunchKernelGGL(k_lines_clear, dim3(2048), dim3(256), 0, st, c->gnbr.p, uint64_t(n_lines));
       hipLaunchKernelGGL(k_grid_hdr_pack, dim3(1024), dim3(256), 0, st, G, starts.p, hdr_count.p, n_reach);
       hipLaunchKernelGGL(k_grid_fill, dim3(2048), dim3(256), 0, st, G);
       MaskParams M{};

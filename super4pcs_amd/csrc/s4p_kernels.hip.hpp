@@ -86,16 +86,19 @@ struct DevCounters {
 //   L0  coarse bitmap (OR of 2^s-cubes of the reach bitmap), <= 48 KB, staged in LDS;
 //   L1  reach bitmap: bit(c) = some P point lies within delta + 0.01 h of the box of cell c,
 //       stored as {bits, rank-prefix} records (one 8 B load gives the bit and the rank);
-//   L2  per reachable cell, a 16 B header {list start, count, 64-bit mask of the 4x4x4 sub-cells (edge h/4) that
-//       some listed point can reach} and the contiguous list of exactly those P points (float4 copies): one
-//       header load, a sub-cell bit test that drops most near-misses, then one 16 B load per exact distance test.
+//   L2  per reachable cell, a 32 B header {first line, point count, 64-bit mask of the 4x4x4 sub-cells (edge h/4) that
+//       some listed point can reach | the cell's integer coordinates as floats} and the list of exactly those P points
+//       in 128-byte LINES of 8 points each: [x0..x3][y0..y3][z0..z3][x4..x7][y4..y7][z4..z7][32 B unused], unused slots
+//       hold a far-away point.  One header load (both halves arrive together), a sub-cell bit test that drops most
+//       near-misses, then per dependent step THREE 16 B loads = four points whose exact distance tests run on the
+//       packed FP32 pipe (v_pk_add/mul_f32: two points per instruction).
 // The reach records and range table (~2 MB per 10^5 points) are L2-cache resident; the
 // point lists (~400 B per P point) stream from Infinity Cache / HBM.
 // ---------------------------------------------------------------------------
 struct LcpGrid {
   const uint2* reach;           // per 32-cell word: {reach bits, number of reachable cells before this word}
-  const uint4* list_hdr;        // per reachable cell: {first entry in nbr, entry count, 4x4x4 sub-cell reach mask lo, hi}
-  const float4* nbr;            // P points (x,y,z,0) grouped by reachable cell
+  const uint4* list_hdr;        // per reachable cell TWO records: {first line, point count, sub-cell reach mask lo, hi}, {float(ix), float(iy), float(iz), -}
+  const float4* nbr;            // point lines: 8 float4 (128 B) per line, see above
   const uint32_t* coarse;       // coarse bitmap (global copy, staged to LDS by the kernels)
   uint32_t coarse_words;
   int cshift, cnx, cny;
@@ -104,14 +107,10 @@ struct LcpGrid {
   float sq_eps;                 // fl(delta*delta)
 };
 
-// S4P_EXACT_DUAL = 1: the exact stage takes 128 queued queries at a time, two per lane, so that two point lists are in
-// flight per lane (every batch runs for as many dependent steps as its longest list; two lists per lane halve the steps
-// per query); the sweep then takes two chunks per step so that the longer queue still fits the
-// LDS budget.
-#ifndef S4P_EXACT_DUAL
-#define S4P_EXACT_DUAL 1          // measured: k_verify 0.161 -> 0.151 ms alone, 69.5 -> 70.7 M candidates/s with three lanes
-#endif
-constexpr int kQueueEntries = S4P_EXACT_DUAL ? 256 : 320;   // per-wave survivor queue: (63 | 127) left over + one step of (4 | 2) x 64 entries
+// The exact stage takes 128 queued queries at a time, two per lane, so that two point lists are in flight per lane (every
+// batch runs for as many dependent steps as its longest list; two lists per lane halve the steps per query: round 2,
+// k_verify 0.161 -> 0.151 ms alone); the sweep takes two chunks per step so that the queue fits the LDS budget.
+constexpr int kQueueEntries = 256;                // per-wave survivor queue: 127 left over + one step of 2 x 64 entries
 constexpr int kQueueWordsPerWave = kQueueEntries + kQueueEntries / 2;     // 32-bit rank + 16-bit query index per entry: 1920 B
 constexpr int kCoarseMaxWords = 9216;              // 36 KB (two k_verify workgroups per CU share 160 KB: 80 KB each)
 constexpr int kVerifyLdsBudget = 80 * 1024 - 768;  // per workgroup: coarse bitmap + 16 queues (30 KB) [+ quantised queries]
@@ -133,7 +132,7 @@ __device__ __forceinline__ void transform_point(const float* T, const float4 q, 
 // transform, subtract origin, scale", and that is what stage 1 spends most of its time on.  It only LOCATES the query:
 // the result may differ from the exactly rounded cell coordinate by ~1e-5 cell, which the structure absorbs by
 // construction (a cell lists every P point within delta + 0.01 h of its box, LcpGridHost::plan; the 4x4x4 sub-cell masks
-// carry the same 1 % slack).  The inlier predicate itself (exact_batch) uses the exact, un-fused transform_point.
+// carry the same 1 % slack).  The inlier predicate itself (exact_setup) uses the exact, un-fused transform_point.
 // Only the coarse copy lives across the query loop (12 registers); the exact 3x4 and the fine-unit transform are
 // re-derived from the candidate's record where the dense stages need them -- keeping all 36 values live cost ~25 % of
 // the loop's instructions in scalar-register spills.
@@ -301,26 +300,42 @@ __global__ __launch_bounds__(256) void k_grid_headers(GridBuildParams P, const u
     }
   }
 }
-// list lengths -> multiples of `align` entries (a power of two), so that every list STARTS on an align * 16-byte boundary
-__global__ __launch_bounds__(256) void k_round_up(uint32_t* v, uint32_t n, uint32_t align) {
-  for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) v[r] = (v[r] + align - 1u) & ~(align - 1u);
+constexpr float kFarAway = 3.0e38f;             // unused slots of a point line: (t - 3e38)^2 = inf, never an inlier, never a NaN
+constexpr uint32_t kLinePoints = 8;              // points per 128-byte line
+// float index of point slot `slot` (0..7), axis `axis` (0..2) inside a line of 32 floats
+__host__ __device__ __forceinline__ uint32_t line_float(uint32_t slot, uint32_t axis) { return (slot >> 2) * 12u + axis * 4u + (slot & 3u); }
+
+// point counts -> line counts (the scan of these places the lists)
+__global__ __launch_bounds__(256) void k_lines_of(uint32_t* v, uint32_t n) {
+  for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) v[r] = (v[r] + kLinePoints - 1u) / kLinePoints;
+}
+// every point slot of every line: far away
+__global__ __launch_bounds__(256) void k_lines_clear(float4* nbr, uint64_t n_lines) {
+  const float4 far4 = make_float4(kFarAway, kFarAway, kFarAway, kFarAway);
+  for (uint64_t t = blockIdx.x * uint64_t(blockDim.x) + threadIdx.x; t < n_lines * 8u; t += uint64_t(gridDim.x) * blockDim.x) nbr[t] = far4;
 }
 __global__ __launch_bounds__(256) void k_grid_hdr_pack(GridBuildParams P, const uint32_t* list_start, const uint32_t* hdr_count, uint32_t n_reach) {
   for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n_reach; r += gridDim.x * blockDim.x) {
-    P.list_hdr[r] = make_uint4(list_start[r], hdr_count[r], 0u, 0u);
+    const uint32_t c = P.cell_id[r];
+    const int ix = int(c % uint32_t(P.nx)), iy = int((c / uint32_t(P.nx)) % uint32_t(P.ny)), iz = int(c / (uint32_t(P.nx) * uint32_t(P.ny)));
+    P.list_hdr[2u * r] = make_uint4(list_start[r], hdr_count[r], 0u, 0u);
+    P.list_hdr[2u * r + 1u] = make_uint4(__float_as_uint(float(ix)), __float_as_uint(float(iy)), __float_as_uint(float(iz)), 0u);
     P.cursor[r] = 0u;
   }
 }
 __global__ __launch_bounds__(256) void k_grid_fill(GridBuildParams P) {
   const uint64_t total = uint64_t(P.n_p) * 27u;
+  float* lines = reinterpret_cast<float*>(P.nbr);
   for (uint64_t t = blockIdx.x * uint64_t(blockDim.x) + threadIdx.x; t < total; t += uint64_t(gridDim.x) * blockDim.x) {
     uint32_t cell;
     const uint32_t i = uint32_t(t / 27u);
     if (grid_incidence(P, i, int(t % 27u), cell)) {
       const uint2 w = P.reach[cell >> 5];
       const uint32_t rank = w.y + uint32_t(__popc(w.x & ((1u << (cell & 31u)) - 1u)));
-      const uint32_t at = P.list_hdr[rank].x + atomicAdd(&P.cursor[rank], 1u);
-      P.nbr[at] = make_float4(P.px[i], P.py[i], P.pz[i], 0.f);
+      const uint32_t at = atomicAdd(&P.cursor[rank], 1u);
+      float* line = lines + (size_t(P.list_hdr[2u * rank].x) + at / kLinePoints) * 32u;
+      const uint32_t slot = at % kLinePoints;
+      line[line_float(slot, 0)] = P.px[i]; line[line_float(slot, 1)] = P.py[i]; line[line_float(slot, 2)] = P.pz[i];
     }
   }
 }
@@ -337,8 +352,9 @@ struct MaskParams {
 __global__ __launch_bounds__(256) void k_build_masks(MaskParams P) {
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t waves = (gridDim.x * blockDim.x) >> 6;
+  const float* lines = reinterpret_cast<const float*>(P.nbr);
   for (uint32_t r = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; r < P.n_reach; r += waves) {
-    uint4 hdr = P.list_hdr[r];
+    uint4 hdr = P.list_hdr[2u * r];
     const uint32_t c = P.cell_id[r];
     const int ix = int(c % uint32_t(P.nx)), iy = int((c / uint32_t(P.nx)) % uint32_t(P.ny)), iz = int(c / (uint32_t(P.nx) * uint32_t(P.ny)));
     const double q = double(P.h) * 0.25;
@@ -346,16 +362,17 @@ __global__ __launch_bounds__(256) void k_build_masks(MaskParams P) {
                           double(P.oy) + double(iy) * double(P.h) + double((lane >> 2) & 3u) * q,
                           double(P.oz) + double(iz) * double(P.h) + double(lane >> 4) * q};
     bool hit = false;
-    for (uint32_t p = hdr.x; p < hdr.x + hdr.y && !__all(hit); ++p) {
-      const float4 pp = P.nbr[p];
-      const double v[3] = {double(pp.x), double(pp.y), double(pp.z)};
+    for (uint32_t p = 0; p < hdr.y && !__all(hit); ++p) {
+      const float* line = lines + (size_t(hdr.x) + p / kLinePoints) * 32u;
+      const uint32_t slot = p % kLinePoints;
+      const double v[3] = {double(line[line_float(slot, 0)]), double(line[line_float(slot, 1)]), double(line[line_float(slot, 2)])};
       double d2 = 0;
 #pragma unroll
       for (int k = 0; k < 3; ++k) { const double d = v[k] < lo[k] ? lo[k] - v[k] : (v[k] > lo[k] + q ? v[k] - (lo[k] + q) : 0.0); d2 += d * d; }
       hit = hit || d2 <= P.reach2;
     }
     const unsigned long long mask = __ballot(hit);
-    if (lane == 0) { hdr.z = uint32_t(mask); hdr.w = uint32_t(mask >> 32); P.list_hdr[r] = hdr; }
+    if (lane == 0) { hdr.z = uint32_t(mask); hdr.w = uint32_t(mask >> 32); P.list_hdr[2u * r] = hdr; }
   }
 }
 
@@ -426,88 +443,64 @@ __device__ __forceinline__ float4 sweep_query(const LcpTask& K, const uint2* s_q
   return K.q4[i];
 }
 
-// Exact stage for the top n (<= 64) queue entries of the wave's candidate: lane = entry {query i, rank of its cell}.
-// Returns whether this lane's query is an inlier.
-template <bool COUNT, bool QLDS>
-__device__ __forceinline__ bool exact_batch(const LcpGrid& g, const LcpTask& K, const uint2* s_q, const float4* Tsrc, const bool valid,
-                                            const uint32_t i, const uint32_t rank) {
-  bool hit = false;
+// One queue entry prepared for the point loop: the exact transformed query and its range of point GROUPS (four points,
+// three 16-byte loads; group gi lives at float4 index (gi >> 1) * 8 + (gi & 1) * 3) -- empty if the entry is not valid or
+// its sub-cell cannot be reached.
+struct ExactEntry { float tx, ty, tz; uint32_t p, e; };
+template <bool COUNT>
+__device__ __forceinline__ ExactEntry exact_setup(const LcpGrid& g, const LcpTask& K, const float* T, const bool valid, const uint32_t i, const uint32_t rank) {
+  ExactEntry E;
+  E.tx = E.ty = E.tz = 0.f; E.p = E.e = 0u;
   if (valid) {
-    const uint4 hdr = g.list_hdr[rank];
-    float T[12];
-    load_rows(Tsrc, T);                                         // (three broadcast loads instead of 12 scalar registers held across the sweep)
+    const uint4 hdr = g.list_hdr[2u * rank], cel = g.list_hdr[2u * rank + 1u];     // one 32-byte record: both halves arrive together
     const float4 q = K.q4[i];
-    float tx, ty, tz;
-    transform_point(T, q, tx, ty, tz);                          // exact (reference order, no fma)
-    int ix, iy, iz;
-    grid_cell(locating_xf<QLDS>(g, K, T).u, sweep_query<QLDS>(K, s_q, i), ix, iy, iz);   // the cell the sweep put this query in
-    // sub-cell of the exact point inside THAT cell, clamped (the exact point can sit a few 1e-3 cell outside it)
-    const float rx = (tx - g.ox) * g.inv_h - float(ix), ry = (ty - g.oy) * g.inv_h - float(iy), rz = (tz - g.oz) * g.inv_h - float(iz);
+    transform_point(T, q, E.tx, E.ty, E.tz);                    // exact (reference order, no fma)
+    // sub-cell of the exact point inside the cell the sweep LOCATED (its coordinates travel in the header), clamped: the
+    // exact point can sit a few 1e-3 cell outside it, which the masks' slack covers (LcpGridHost::plan)
+    const float rx = (E.tx - g.ox) * g.inv_h - __uint_as_float(cel.x), ry = (E.ty - g.oy) * g.inv_h - __uint_as_float(cel.y),
+                rz = (E.tz - g.oz) * g.inv_h - __uint_as_float(cel.z);
     const uint32_t sx = uint32_t(min(max(int(rx * 4.f), 0), 3)), sy = uint32_t(min(max(int(ry * 4.f), 0), 3)),
                    sz = uint32_t(min(max(int(rz * 4.f), 0), 3));
     const uint32_t sb = sz * 16u + sy * 4u + sx;
     const uint32_t mword = sb < 32u ? hdr.z : hdr.w;
     if ((mword >> (sb & 31u)) & 1u) {
       if (COUNT) { atomicAdd(K.point_tests + 3, 1ull); atomicAdd(K.point_tests, (unsigned long long)hdr.y); }   // l2_pass, listed points
-      const uint32_t e = hdr.x + hdr.y;
-      for (uint32_t p = hdr.x; p < e; p += 2) {                 // two independent 16 B loads per dependent step (four: slower)
-        const float4 pa = g.nbr[p];
-        const float4 pb = g.nbr[min(p + 1u, e - 1u)];          // (predicating this load away on odd tails was measured slower)
-        const bool ha = sqn3(tx - pa.x, ty - pa.y, tz - pa.z) <= g.sq_eps;
-        const bool hb = sqn3(tx - pb.x, ty - pb.y, tz - pb.z) <= g.sq_eps;
-        if (ha | hb) { hit = true; break; }
-      }
-    }
-  }
-  return hit;
-}
-
-// One queue entry prepared for the point loop: the exact transformed query and its list range (empty if the entry is
-// not valid or its sub-cell cannot be reached).
-struct ExactEntry { float tx, ty, tz; uint32_t p, e; };
-template <bool COUNT, bool QLDS>
-__device__ __forceinline__ ExactEntry exact_setup(const LcpGrid& g, const LcpTask& K, const uint2* s_q, const float* T, const float* XU,
-                                                  const bool valid, const uint32_t i, const uint32_t rank) {
-  ExactEntry E;
-  E.tx = E.ty = E.tz = 0.f; E.p = E.e = 0u;
-  if (valid) {
-    const uint4 hdr = g.list_hdr[rank];
-    const float4 q = K.q4[i];
-    transform_point(T, q, E.tx, E.ty, E.tz);                    // exact (reference order, no fma)
-    int ix, iy, iz;
-    grid_cell(XU, sweep_query<QLDS>(K, s_q, i), ix, iy, iz);
-    const float rx = (E.tx - g.ox) * g.inv_h - float(ix), ry = (E.ty - g.oy) * g.inv_h - float(iy), rz = (E.tz - g.oz) * g.inv_h - float(iz);
-    const uint32_t sx = uint32_t(min(max(int(rx * 4.f), 0), 3)), sy = uint32_t(min(max(int(ry * 4.f), 0), 3)),
-                   sz = uint32_t(min(max(int(rz * 4.f), 0), 3));
-    const uint32_t sb = sz * 16u + sy * 4u + sx;
-    const uint32_t mword = sb < 32u ? hdr.z : hdr.w;
-    if ((mword >> (sb & 31u)) & 1u) {
-      if (COUNT) { atomicAdd(K.point_tests + 3, 1ull); atomicAdd(K.point_tests, (unsigned long long)hdr.y); }
-      E.p = hdr.x; E.e = hdr.x + hdr.y;
+      E.p = 2u * hdr.x; E.e = E.p + (hdr.y + 3u) / 4u;
     }
   }
   return E;
 }
-// Exact stage for up to 128 queue entries, two per lane (A, B): both lists advance together, four 16-byte loads in
-// flight per lane and step.  Returns the number of inliers among this lane's two queries.
-template <bool COUNT, bool QLDS>
-__device__ __forceinline__ uint32_t exact_pair(const LcpGrid& g, const LcpTask& K, const uint2* s_q, const float4* Tsrc, const float* XU,
+// sqdist <= delta^2 (kdtree.h:417-421) of one transformed query against the four points of a group: the reference's
+// x*x + (y*y + z*z) per point, two points per instruction on the packed FP32 pipe (separately rounded mul / add)
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ bool group_hit(const float4 X, const float4 Y, const float4 Z, const float tx, const float ty, const float tz, const float sq_eps) {
+  const v2f tx2 = {tx, tx}, ty2 = {ty, ty}, tz2 = {tz, tz};
+  const v2f dx0 = tx2 - v2f{X.x, X.y}, dx1 = tx2 - v2f{X.z, X.w};
+  const v2f dy0 = ty2 - v2f{Y.x, Y.y}, dy1 = ty2 - v2f{Y.z, Y.w};
+  const v2f dz0 = tz2 - v2f{Z.x, Z.y}, dz1 = tz2 - v2f{Z.z, Z.w};
+  const v2f s0 = dx0 * dx0 + (dy0 * dy0 + dz0 * dz0), s1 = dx1 * dx1 + (dy1 * dy1 + dz1 * dz1);
+  return (s0.x <= sq_eps) | (s0.y <= sq_eps) | (s1.x <= sq_eps) | (s1.y <= sq_eps);
+}
+// Exact stage for up to 128 queue entries, two per lane (A, B): both lists advance together, one group (four points) of
+// each per dependent step, six 16-byte loads in flight per lane.  Returns the number of inliers among this lane's two queries.
+template <bool COUNT>
+__device__ __forceinline__ uint32_t exact_pair(const LcpGrid& g, const LcpTask& K, const float4* Tsrc,
                                                const bool validA, const uint32_t iA, const uint32_t rankA,
                                                const bool validB, const uint32_t iB, const uint32_t rankB) {
   ExactEntry A, B;
   { float T[12]; load_rows(Tsrc, T);
-    A = exact_setup<COUNT, QLDS>(g, K, s_q, T, XU, validA, iA, rankA);
-    B = exact_setup<COUNT, QLDS>(g, K, s_q, T, XU, validB, iB, rankB); }
+    A = exact_setup<COUNT>(g, K, T, validA, iA, rankA);
+    B = exact_setup<COUNT>(g, K, T, validB, iB, rankB); }
   uint32_t hits = 0;
   while (A.p < A.e || B.p < B.e) {
     const bool la = A.p < A.e, lb = B.p < B.e;
-    const float4 a0 = g.nbr[la ? A.p : 0u], a1 = g.nbr[la ? min(A.p + 1u, A.e - 1u) : 0u];
-    const float4 b0 = g.nbr[lb ? B.p : 0u], b1 = g.nbr[lb ? min(B.p + 1u, B.e - 1u) : 0u];
-    const bool ha0 = sqn3(A.tx - a0.x, A.ty - a0.y, A.tz - a0.z) <= g.sq_eps, ha1 = sqn3(A.tx - a1.x, A.ty - a1.y, A.tz - a1.z) <= g.sq_eps;
-    const bool hb0 = sqn3(B.tx - b0.x, B.ty - b0.y, B.tz - b0.z) <= g.sq_eps, hb1 = sqn3(B.tx - b1.x, B.ty - b1.y, B.tz - b1.z) <= g.sq_eps;
-    const bool ha = la && (ha0 || ha1), hb = lb && (hb0 || hb1);
-    if (ha) { ++hits; A.p = A.e; } else if (la) A.p += 2u;
-    if (hb) { ++hits; B.p = B.e; } else if (lb) B.p += 2u;
+    const uint32_t ia = la ? (A.p >> 1) * 8u + (A.p & 1u) * 3u : 0u, ib = lb ? (B.p >> 1) * 8u + (B.p & 1u) * 3u : 0u;
+    const float4 ax = g.nbr[ia], ay = g.nbr[ia + 1u], az = g.nbr[ia + 2u];
+    const float4 bx = g.nbr[ib], by = g.nbr[ib + 1u], bz = g.nbr[ib + 2u];
+    const bool ha = la && group_hit(ax, ay, az, A.tx, A.ty, A.tz, g.sq_eps);
+    const bool hb = lb && group_hit(bx, by, bz, B.tx, B.ty, B.tz, g.sq_eps);
+    if (ha) { ++hits; A.p = A.e; } else if (la) A.p += 1u;
+    if (hb) { ++hits; B.p = B.e; } else if (lb) B.p += 1u;
   }
   return hits;
 }
@@ -560,7 +553,6 @@ __device__ __forceinline__ uint32_t wave_lcp_count(const LcpGrid& g, const LcpTa
     qn += uint32_t(__popcll(m));
   };
   const uint32_t last = K.n_q - 1u;
-#if S4P_EXACT_DUAL
   for (uint32_t base = 0;; base += 128u) {
     const bool more = base < K.n_q;                      // wave-uniform
     if (more) {                                          // one step: two chunks
@@ -574,48 +566,16 @@ __device__ __forceinline__ uint32_t wave_lcp_count(const LcpGrid& g, const LcpTa
       lds_fence();
     }
     // exact stage, ONE code site: 128 entries at a time (the queue holds 127 + 2 * 64), the rest after the last step
-    // (the locating transform X is already in registers: the exact stage reuses it for the cells)
     while (qn >= 128u || (!more && qn != 0u)) {
       const uint32_t n = min(qn, 128u);
       const bool va = lane < n, vb = lane + 64u < n;
       const uint32_t aa = qn - n + min(lane, n - 1u), ab = qn - n + min(lane + 64u, n - 1u);
-      if (!SKIP_FINE) cnt += exact_pair<COUNT, QLDS>(g, K, s_q, Tsrc, X.u, va, uint32_t(q_idx[aa]), q_rank[aa], vb, uint32_t(q_idx[ab]), q_rank[ab]);
+      if (!SKIP_FINE) cnt += exact_pair<COUNT>(g, K, Tsrc, va, uint32_t(q_idx[aa]), q_rank[aa], vb, uint32_t(q_idx[ab]), q_rank[ab]);
       qn -= n;
       lds_fence();
     }
     if (!more) break;
   }
-#else
-  for (uint32_t base = 0;; base += 256u) {
-    const bool more = base < K.n_q;                      // wave-uniform
-    if (more) {                                          // one step: four chunks, their four reach gathers in flight together
-      const uint32_t i0 = base + lane, i1 = i0 + 64u, i2 = i0 + 128u, i3 = i0 + 192u;
-      const float4 q0 = sweep_query<QLDS>(K, s_q, min(i0, last));
-      const float4 q1 = sweep_query<QLDS>(K, s_q, min(i1, last));
-      const float4 q2 = sweep_query<QLDS>(K, s_q, min(i2, last));
-      const float4 q3 = sweep_query<QLDS>(K, s_q, min(i3, last));
-      const uint32_t c0 = locate(q0, i0), c1 = locate(q1, i1), c2 = locate(q2, i2), c3 = locate(q3, i3);
-      // reach words of the L0 survivors; rejected lanes read word 0 (one broadcast line)
-      const uint2 w0 = g.reach[c0 == kNone ? 0u : c0 >> 5];
-      const uint2 w1 = g.reach[c1 == kNone ? 0u : c1 >> 5];
-      const uint2 w2 = g.reach[c2 == kNone ? 0u : c2 >> 5];
-      const uint2 w3 = g.reach[c3 == kNone ? 0u : c3 >> 5];
-      push(c0, w0, i0); push(c1, w1, i1); push(c2, w2, i2); push(c3, w3, i3);
-      lds_fence();
-    }
-    // exact stage, ONE code site: full batches as they become available (the queue holds 63 + 4 * 64 entries), the
-    // partial one after the last step
-    while (qn >= 64u || (!more && qn != 0u)) {
-      const uint32_t n = min(qn, 64u);
-      const bool valid = lane < n;
-      const uint32_t at = qn - n + min(lane, n - 1u);
-      if (!SKIP_FINE) cnt += exact_batch<COUNT, QLDS>(g, K, s_q, Tsrc, valid, uint32_t(q_idx[at]), q_rank[at]) ? 1u : 0u;
-      qn -= n;
-      lds_fence();
-    }
-    if (!more) break;
-  }
-#endif
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
   __builtin_amdgcn_wave_barrier();
@@ -1463,7 +1423,7 @@ __device__ __forceinline__ bool slot_better(const uint32_t ca, const unsigned lo
 }
 
 template <bool COUNT, bool QLDS>
-__global__ __launch_bounds__(kVerifyMaxThreads, 8) void k_verify(VerifyParams P) {   // <= 64 VGPRs; two workgroups per CU (LDS)
+__global__ __launch_bounds__(kVerifyMaxThreads, 6) void k_verify(VerifyParams P) {   // <= 80 VGPRs: six waves per SIMD (two 768-thread workgroups per CU)
   extern __shared__ uint32_t s_mem[];
   uint32_t* s_coarse = s_mem;                              // LDS: coarse bitmap | quantised queries (QLDS) | 16 survivor queues
   uint2* s_q = reinterpret_cast<uint2*>(s_mem + P.grid.coarse_words);
