@@ -5,12 +5,15 @@ Contract (driver): python bench.py --gpus N --steps K --warmup W ; for N>1 launc
 torch.distributed.run, one rank per GPU.  Rank 0 prints ONE JSON line.
 
 Metric (BASELINE.json): candidate transforms verified / s on the synthetic 1 M-point pair
-(configs[2]: 50 % overlap, Gaussian noise sigma = delta = 0.004, sample size 2000).
+(configs[2]: 50 % overlap, Gaussian noise sigma = delta = 0.004, sample size 2000; --sample 20000 gives the
+"GPU-scale" sample of SURVEY.md 8d as a second line).
 One "step" = one RANSAC base through the whole hot path on this rank's GPU:
    SelectQuadrilateral (host) -> ExtractPairs x2 -> FindCongruentQuadrilaterals ->
    ComputeRigidTransformation + Verify of every congruent candidate -> best selection,
 i.e. Match4PCSBase::TryOneBase (match4pcsBase.hpp:281-360).  A candidate counts when it passed the
-rms gate and was LCP-scored over all sampled Q points (reference counter nbCongruentAto, :441).
+rms gate and entered Verify (reference counter nbCongruentAto, :441); like the reference's Verify (match4pcsBase.cc:558-560)
+the device abandons a candidate once it can no longer exceed the best LCP of the registration so far -- the rate with
+every candidate scored over all sampled Q points is reported next to it (config.full_count_mode).
 Inputs (sampled clouds, LCP grid) are resident in HBM before the timed region.
 With N GPUs each rank owns every N-th base of the same sequence (weak scaling: K device steps per
 rank) and one 8-byte all-reduce(MAX) per window over RCCL picks the winner.
@@ -19,9 +22,21 @@ The timed region (W warm-up steps, then exactly K steps between barrier + device
 `--repeats` times on a fresh matcher with the same seed, i.e. over the SAME bases, so that the spread is timing noise and
 not workload variation; `value` / `ms_per_step` are the median repeat, `spread` holds min / median / max.
 
-Every measurement carries a parity gate: the first timed bases are replayed through the oracle
-(oracle/, CPU) and compared -- quads in reference order, per-candidate inlier counts, winner, best LCP, transform -- and the
-process exits non-zero on any mismatch.  The oracle is only ever the checker and the cpu_baseline, never the thing timed.
+Parity gate, non-zero exit on any mismatch.  The oracle (oracle/, CPU, OpenMP over candidates) runs the SAME
+W + K bases in the reference's mode (kd-tree Verify with early exit) and
+  * every repeat of the timed region must end in the oracle's state: best LCP, winning base + quad, 4x4, and must have
+    verified exactly the oracle's number of candidates over the K timed bases (parity.bases == steps);
+  * a replay of the same bases one by one on a fresh GPU matcher is compared base by base: pair / quad / candidate counts,
+    TryOneBase's return value, the running best;
+  * for the first `--parity-full-bases` bases the ordered quad list and the inlier count of EVERY candidate are compared with
+    the oracle in full-count mode.
+The oracle is only ever the checker and the cpu_baseline, never the thing timed.
+
+Roofline: the byte model's inputs (fractions of the queries that pass the three levels of the LCP
+structure, exact point tests per query) are measured by an instrumented replay of the TIMED bases; `frac` is the per-step
+figure (algorithmic bytes of the K timed bases / timed seconds / HBM peak), which does not depend on how many bases are in
+flight; rocprofv3 --pmc passes over an inner run of the same W + K bases give the HBM-side traffic, the L2 hit rate and the
+VALU issue utilisation of k_verify, and `binding` names the resource that is closest to its roof.
 """
 import argparse
 import csv
@@ -46,6 +61,7 @@ SAMPLE = 2000
 SEED = 20140814
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 L2_PEAK_GBS = 34500.0          # MI355X_MICROARCH.md: aggregate L2 bandwidth, ~34.5 TB/s
+N_SIMDS = 256 * 4              # 256 CUs x 4 SIMDs
 MAX_PAIRS, MAX_QUADS = 8 << 20, 64 << 20
 
 
@@ -54,15 +70,13 @@ def survey_bytes_per_candidate(n_q, kbar, cells=27):
     return 16 + 8 + n_q * (12 + cells * 8 + kbar * 12)
 
 
-def structure_bytes_per_candidate(n_q, f_l0, f_l1, kbar):
+def structure_bytes_per_candidate(n_q, f_l0, f_l1, f_l2, groups_per_query):
     """Bytes the three-level LCP structure REQUIRES per verified candidate:
-    query sweep 16 B/query (q4v, a 32 KB array every workgroup re-reads: served by L1/L2), reach word 8 B per L0 survivor,
-    list header 16 B + query re-read 16 B per L1 survivor, 16 B per exact point test, 48 B transform + 8 B tag + 4 B
-    index in, 4 B count out.  The first class never leaves the CU's L1/L2; the rest are dependent gathers into
-    structures (reach words 0.5 MB, headers 2.3 MB, point lists 19 MB on the bench workload) that live beyond the L2
-    of any single XCD."""
-    sweep = 16.0 * n_q
-    gathers = n_q * (8.0 * f_l0 + 32.0 * f_l1 + 16.0 * kbar) + 64.0
+    reach word 8 B per L0 survivor; 32 B list header + 16 B exact query per L1 survivor; 48 B (one group of four points:
+    three 16-byte loads) per group a sub-cell-mask survivor walks; 48 B transform + 8 B tag + 4 B index in, 4 B count out.
+    The sweep's own query reads (8 B per query out of the LDS copy) never leave the CU and are reported separately."""
+    sweep = 8.0 * n_q
+    gathers = n_q * (8.0 * f_l0 + 48.0 * f_l1 + 48.0 * groups_per_query) + 64.0
     return sweep, gathers
 
 
@@ -73,21 +87,25 @@ def seg_len32(a, b):
     return float(np.sqrt(np.float32(s)))
 
 
-def parity_gate(P, Q, T_gt, opt, warmup, n_bases, per_base_sample, device):
-    """Replays the first `n_bases` TIMED bases (the ones after `warmup`) of the seeded sequence on a fresh GPU matcher and
-    on the oracle and compares everything the reference's TryOneBase produces.  Returns the `parity` object."""
+def parity_gate(P, Q, opt, warmup, n_bases, full_bases, device, sample):
+    """The W warm-up + n_bases timed bases of the seeded sequence, one by one, on a fresh GPU matcher and on the oracle.
+    Returns (parity object, oracle state after the last base, oracle matcher for recounts)."""
     from oracle import oracle as O
     from super4pcs_amd import capi
     O.build()
-    oopt = O.make_options(DELTA, OVERLAP, int(opt.sample_size))
+    nproc = os.cpu_count() or 1
+    oopt = O.make_options(DELTA, OVERLAP, sample)
     om_ref = O.Matcher(oopt, full_counts=False, use_kdtree=True, keep_trace=True)    # reference semantics (early exit)
+    om_ref.set_threads(nproc)                                                         # candidates under OpenMP: same results as the serial loop
     om_full = O.Matcher(oopt, full_counts=True, use_kdtree=True, keep_trace=False)   # stage-wise, every inlier counted
+    om_full.set_threads(nproc)
     om_ref.init(P, Q)
     om_full.init(P, Q)
     gm = capi.Matcher(opt, device=device, max_pairs=MAX_PAIRS, max_quads=MAX_QUADS)
     gm.init_full(P, Q)
     mism = []
-    out = {"bases": 0, "quads": 0, "candidates": 0, "candidates_count_checked": 0}
+    out = {"bases": 0, "warmup_bases": warmup, "quads": 0, "candidates": 0, "bases_with_every_candidate_counted": 0,
+           "candidates_count_checked": 0}
 
     def check(ok, what):
         if not ok:
@@ -98,17 +116,13 @@ def parity_gate(P, Q, T_gt, opt, warmup, n_bases, per_base_sample, device):
     check((gi.n_sampled_p, gi.n_sampled_q, gi.number_of_trials) == (os_.n_P, os_.n_Q, os_.number_of_trials), "sizes / trial count")
     check(gi.best_lcp == os_.best_lcp, "initial LCP (Verify(identity))")
     eps = 2.0 * DELTA
-    # the warm-up bases: advance RNG + pair-octree permutation everywhere, score nothing
-    for _ in range(warmup):
-        for om in (om_ref, om_full):
-            ok, _i1, _i2, _b, bx = om.select_quadrilateral()
-            if ok:
-                om.extract_pairs(seg_len32(bx[0], bx[1]), 0.0, eps, 0, 1)
-                om.extract_pairs(seg_len32(bx[2], bx[3]), 0.0, eps, 2, 3)
-        gm.next_base(run_device=False)
-    for b in range(n_bases):
+    cand_before = 0
+    for b in range(warmup + n_bases):
+        timed = b >= warmup
         g_ok, r = gm.try_one_base()                                   # the fused device pass, as timed
-        g_quads, g_counts = gm.last_candidates(r.n_quads)
+        want_full = timed and out["bases_with_every_candidate_counted"] < full_bases and r.n_quads > 0
+        if want_full:
+            g_quads, g_counts = gm.last_candidates(r.n_quads)
         o_ok = om_ref.try_one_base()
         rec = om_ref.trace()[0][-1]
         check(g_ok == o_ok, "base %d: TryOneBase return value" % b)
@@ -121,49 +135,127 @@ def parity_gate(P, Q, T_gt, opt, warmup, n_bases, per_base_sample, device):
         check(gi.best_lcp == lcp, "base %d: best LCP" % b)
         check(list(gi.base) == base.tolist() and list(gi.congruent) == cong.tolist(), "base %d: winning base / quad" % b)
         check(np.array_equal(np.array(gi.transform, np.float32).reshape(4, 4), T), "base %d: transform" % b)
-        # stage-wise replay with full counts: ordered quads, per-candidate inlier counts
+        # the stage-wise oracle walks the same sequence (RNG + pair-octree permutation); full counts where asked for
         ok, i1, i2, obase, bx = om_full.select_quadrilateral()
         if ok:
             p1 = om_full.extract_pairs(seg_len32(bx[0], bx[1]), 0.0, eps, 0, 1)
             p2 = om_full.extract_pairs(seg_len32(bx[2], bx[3]), 0.0, eps, 2, 3)
-            o_quads = om_full.find_congruent(i1, i2, eps, p1, p2, cap=max(int(r.n_quads) + 16, 1 << 16)) if (len(p1) and len(p2)) else np.zeros((0, 4), np.int32)
-            same = o_quads.shape == g_quads.shape and np.array_equal(o_quads, g_quads)
-            check(same, "base %d: congruent quads (std::set order)" % b)
-            if same and len(o_quads):
-                K = len(o_quads)
-                stride = max(K // max(per_base_sample, 1), 1)
-                idx = np.unique(np.concatenate([np.arange(0, K, stride), np.arange(min(K, 256)),
-                                                np.flatnonzero(g_counts == g_counts.max())[:4]]))
-                _nb, per, _bc, _bi = om_full.try_congruent_set(obase, o_quads[idx])
-                check(np.array_equal(per, g_counts[idx]), "base %d: per-candidate inlier counts" % b)
-                out["candidates_count_checked"] += int((per >= 0).sum())
-            out["quads"] += int(len(o_quads))
-        out["candidates"] += int(r.n_verified)
-        out["bases"] += 1
+            if want_full:
+                o_quads = om_full.find_congruent(i1, i2, eps, p1, p2, cap=max(int(r.n_quads) + 16, 1 << 16)) if (len(p1) and len(p2)) else np.zeros((0, 4), np.int32)
+                same = o_quads.shape == g_quads.shape and np.array_equal(o_quads, g_quads)
+                check(same, "base %d: congruent quads (std::set order)" % b)
+                if same and len(o_quads):
+                    _nb, per, _bc, _bi = om_full.try_congruent_set(obase, o_quads)          # EVERY candidate, full counts
+                    check(np.array_equal(per, g_counts), "base %d: per-candidate inlier counts" % b)
+                    out["candidates_count_checked"] += int((per >= 0).sum())
+                    out["bases_with_every_candidate_counted"] += 1
+        if timed:
+            out["quads"] += int(r.n_quads); out["candidates"] += int(r.n_verified); out["bases"] += 1
+        else:
+            cand_before += int(r.n_verified)
+    T, lcp, base, cong, _c1, _c2 = om_ref.best()
+    state = {"best_lcp": lcp, "base": base.tolist(), "congruent": cong.tolist(), "transform": T.copy(),
+             "candidates_timed": int(om_ref.stats().n_verified) - cand_before}
+    check(state["candidates_timed"] == out["candidates"], "candidates over the timed bases: GPU replay %d vs oracle %d" % (out["candidates"], state["candidates_timed"]))
     out["mismatches"] = len(mism)
-    out["what"] = ("first %d timed bases (after %d warm-up bases) of the seeded sequence: pair/quad/candidate counts, ordered quad list, "
-                   "TryOneBase return value, best LCP, winning base+quad and 4x4 against the oracle in reference mode (early exit); "
-                   "per-candidate inlier counts of a deterministic subsample against the oracle in full-count mode" % (n_bases, warmup))
+    out["what"] = ("the %d warm-up + %d timed bases of the seeded sequence, base by base on a fresh GPU matcher and on the oracle in the "
+                   "reference's mode (kd-tree Verify with early exit, candidates under OpenMP): pair / quad / candidate counts, TryOneBase's "
+                   "return value, running best LCP, winning base + quad and 4x4; ordered quad list and the inlier count of EVERY candidate of "
+                   "%d base(s) against the oracle in full-count mode; the final state and the candidate total of every timed repeat "
+                   "against the oracle's" % (warmup, n_bases, out["bases_with_every_candidate_counted"]))
     if mism:
-        out["failed"] = mism
+        out["failed"] = mism[:20]
     del gm
-    return out, om_full
+    return out, state, om_full
 
 
-def cpu_baseline(P, Q, budget_s):
+def parity_gate_scale(P, Q, opt, warmup, n_bases, device, sample, sample_mod=1 << 18):
+    """Parity at the "GPU-scale" sample (n = 20 000): a base has ~10^9 congruent quads, which neither the reference's
+    std::set nor the oracle's list form can hold.  Per base the oracle's STREAMING enumeration (OpenMP over the second pair
+    set; pinned to the list form on small cases by tests/test_oracle.py) gives the number of quads, the number that pass
+    the rms gate and order-independent checksums of both, plus a deterministic subsample of the gated quads; the GPU's fused
+    (chunked) pass must reproduce all four numbers, its winner's gate + inlier count are recomputed by the oracle's kd-tree
+    Verify, no sampled candidate may beat it, and the sampled candidates' counts through the stage-level entry point equal
+    the oracle's."""
+    from oracle import oracle as O
+    from super4pcs_amd import capi
+    O.build()
+    om = O.Matcher(O.make_options(DELTA, OVERLAP, sample), full_counts=True, use_kdtree=True, keep_trace=False)
+    om.set_threads(os.cpu_count() or 1)
+    om.init(P, Q)
+    gm = capi.Matcher(opt, device=device)
+    gm.init_full(P, Q)
+    ctx = capi.Context(opt, device=device, max_pairs=32 << 20, max_quads=1 << 20)
+    ctx.set_clouds(om.cloud(0), om.cloud(1))
+    mism = []
+    out = {"bases": 0, "warmup_bases": warmup, "quads": 0, "candidates": 0, "candidates_count_checked": 0}
+
+    def check(ok, what):
+        if not ok:
+            mism.append(what)
+
+    check(np.array_equal(gm.sampled(0), om.cloud(0)) and np.array_equal(gm.sampled(1), om.cloud(1)), "sampled clouds")
+    eps = 2.0 * DELTA
+    bm = {"tests": 0, "l0": 0, "l1": 0, "l2": 0, "queries": 0}
+    for b in range(warmup + n_bases):
+        g_ok, r = gm.try_one_base()
+        ok, i1, i2, base, bx = om.select_quadrilateral()
+        if not ok:
+            check(r.n_pairs1 == 0 and r.n_quads == 0, "base %d: no base found by the oracle" % b)
+            continue
+        p1 = om.extract_pairs_cap(seg_len32(bx[0], bx[1]), 0.0, eps, 0, 1, 1 << 25)
+        p2 = om.extract_pairs_cap(seg_len32(bx[2], bx[3]), 0.0, eps, 2, 3, 1 << 25)
+        check((r.n_pairs1, r.n_pairs2) == (len(p1), len(p2)), "base %d: pair counts" % b)
+        if not (len(p1) and len(p2)):
+            continue
+        want = om.count_congruent(i1, i2, eps, p1, p2, base=base, sample_mod=sample_mod, sample_cap=1 << 15)
+        check((r.n_quads, r.quad_checksum) == (want["K"], want["quad_sum"]), "base %d: quads %d / checksum vs oracle %d" % (b, r.n_quads, want["K"]))
+        check((r.n_verified, r.cand_checksum) == (want["C"], want["cand_sum"]), "base %d: candidates %d / checksum vs oracle %d" % (b, r.n_verified, want["C"]))
+        if r.n_verified:
+            _nb, w_per, _bc, _bi = om.try_congruent_set(base, np.array([list(r.best_quad)], np.int32))
+            check(int(w_per[0]) == int(r.best_count), "base %d: winner's inlier count %d vs oracle %d" % (b, r.best_count, int(w_per[0])))
+            smp = want["sample"][:256]
+            if len(smp):
+                ctx.set_base(bx)
+                _nb, o_per, _bc, _bi = om.try_congruent_set(base, smp)
+                _gr, g_per = ctx.try_congruent_set(base, smp)
+                check(np.array_equal(g_per, o_per), "base %d: inlier counts of %d sampled candidates" % (b, len(smp)))
+                check(int(o_per.max()) <= int(r.best_count), "base %d: a sampled candidate beats the reported winner" % b)
+                out["candidates_count_checked"] += int(len(smp))
+                if b >= warmup:          # the byte model's inputs on this deterministic subsample of the base's candidates
+                    Ts = np.stack([om.compute_rigid(base, q)[2] for q in smp])
+                    st = ctx.verify_stats(Ts)
+                    for k in ("tests", "l0", "l1", "l2"):
+                        bm[k] += st[k]
+                    bm["queries"] += len(smp) * int(om.cloud(1).shape[0])
+        if b >= warmup:
+            out["quads"] += int(r.n_quads); out["candidates"] += int(r.n_verified); out["bases"] += 1
+    out["chunk_stats"] = gm.chunk_stats()
+    out["mismatches"] = len(mism)
+    out["what"] = ("%d timed bases at sample size %d: pair counts, number of congruent quads and of gated candidates with their "
+                   "order-independent checksums against the oracle's streaming enumeration; the winner's gate and inlier count and the counts "
+                   "of a deterministic subsample of the candidates against the oracle's kd-tree Verify" % (n_bases, sample))
+    if mism:
+        out["failed"] = mism[:20]
+    state = {"candidates_timed": out["candidates"], "byte_model": bm}
+    return out, state, None
+
+
+def cpu_baseline(P, Q, budget_s, sample, ttr_candidates):
     """CPU path on the same workload, bounded samples.
     A (reference-faithful): 1 thread -- what MatchSuper4PCS does (super4pcs.cc:68-73), kd-tree Verify with early exit.
        kind "reference": the reference's own sources (oracle/_ref/libs4p_ref.so) run ComputeTransformation and are cut by a
        visitor exception after budget_s of RANSAC time; kind "port" (the oracle) if the prebuilt library is absent.
-    B (best-effort CPU): the oracle with its candidate loop under `omp parallel for` on all host
-       cores, as the legacy Match4PCS does by default (match4pcsBase.h:190-192); also gives the per-stage split."""
+    B (best-effort CPU): the oracle with its CANDIDATE LOOP ONLY under `omp parallel for` on all host
+       cores, as the legacy Match4PCS does by default (match4pcsBase.h:190-192) -- pair extraction and quad enumeration
+       stay serial, as in the reference; also gives the per-stage split."""
     from oracle import oracle as O
     from oracle import reflib
     O.build()
     nproc = os.cpu_count() or 1
 
     def port_run(threads, seconds):
-        om = O.Matcher(O.make_options(DELTA, OVERLAP, SAMPLE), full_counts=False, use_kdtree=True, keep_trace=False)
+        om = O.Matcher(O.make_options(DELTA, OVERLAP, sample), full_counts=False, use_kdtree=True, keep_trace=False)
         om.set_threads(threads)
         om.init(P, Q)
         om.set_budget(seconds)
@@ -181,7 +273,7 @@ def cpu_baseline(P, Q, budget_s):
                 "stage_seconds": {"select": s.t_select, "pairs": s.t_pairs, "quads": s.t_quads, "verify": s.t_verify}}
 
     if reflib.available():
-        rm = reflib.RefMatcher(O.make_options(DELTA, OVERLAP, SAMPLE))
+        rm = reflib.RefMatcher(O.make_options(DELTA, OVERLAP, sample))
         cut, n, sec = rm.bench(P, Q, budget_s)
         a = {"value": n / max(sec, 1e-9), "unit": "candidates/s", "cores": 1, "kind": "reference",
              "sample": "reference ComputeTransformation (kd-tree Verify with early exit) on the same clouds/seed, "
@@ -192,55 +284,68 @@ def cpu_baseline(P, Q, budget_s):
     a["host_cores"] = nproc
     a["note"] = ("the GPU scores every candidate over all n_Q points (no early exit); the CPU loops stop a candidate as soon as it "
                  "cannot beat the running best (match4pcsBase.cc:558-560), so work per candidate differs: a reported baseline")
-    a["openmp_all_cores"] = port_run(nproc, max(budget_s * 0.6, 3.0))
+    b = port_run(nproc, max(budget_s * 0.6, 3.0))
+    b["label"] = "candidate loop only under OpenMP (pairs and quads serial, as in the reference)"
+    a["openmp_all_cores"] = b
+    if ttr_candidates:
+        # time-to-register on the CPU (BASELINE.md section 3 "Reported"; the reference's tests allow 600 s): the whole
+        # registration verifies ttr_candidates candidates (counted by the GPU run above, equal to the oracle's by the parity
+        # tests); at the sampled rates that is an EXTRAPOLATION, not a run -- a measured run is in profiles/ (README there)
+        a["time_to_register"] = {"measured": False, "candidates_of_the_registration": int(ttr_candidates),
+                                 "extrapolated_seconds_1_core": ttr_candidates / max(a["value"], 1e-9),
+                                 "extrapolated_seconds_all_cores": ttr_candidates / max(b["value"], 1e-9),
+                                 "cap_seconds": 600,
+                                 "note": "candidates of the whole registration / sampled candidates-per-second; both exceed the 600 s the "
+                                         "reference's own tests allow when > 600"}
     return a
 
 
-def pmc_traffic(args, timeout_s=150):
-    """HBM-side traffic of the dominant kernel (k_verify) in THIS configuration: two `rocprofv3 --pmc` passes
-    (FETCH_SIZE, WRITE_SIZE: they do not fit one pass, MI355X_MICROARCH.md) over a short inner run of this script with
-    the default lanes.  Returns (bytes per launch or None, note)."""
+def pmc_passes(args, timeout_s=240):
+    """rocprofv3 --pmc passes over an inner run of this script with the SAME warm-up + timed bases and the default lanes
+    (counters serialise the launches: per-kernel numbers are the kernel's own).  Three passes -- the TCC slots do not hold
+    FETCH_SIZE and WRITE_SIZE together (MI355X_MICROARCH.md "rocprofv3 PMC slots").  Returns {counter: (mean per k_verify
+    launch, launches)} and notes."""
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
-        return None, "rocprofv3 not found"
-    got = {}
-    note = []
-    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        return {}, ["rocprofv3 not found"]
+    got, note = {}, []
+    for ctrs in (["FETCH_SIZE", "GRBM_GUI_ACTIVE", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY"],
+                 ["WRITE_SIZE"], ["TCC_HIT_sum", "TCC_MISS_sum"]):
         d = tempfile.mkdtemp(prefix="s4p_pmc_", dir="/tmp")
-        cmd = [exe, "--pmc", ctr, "--kernel-trace", "-d", d, "-o", "p", "--output-format", "csv", "--",
-               sys.executable, os.path.abspath(__file__), "--inner", "--steps", "30", "--warmup", "3",
+        cmd = [exe, "--pmc"] + ctrs + ["--kernel-trace", "-d", d, "-o", "p", "--output-format", "csv", "--",
+               sys.executable, os.path.abspath(__file__), "--inner", "--steps", str(args.steps), "--warmup", str(args.warmup),
                "--points", str(args.points), "--sample", str(args.sample)]
         env = dict(os.environ, TMPDIR="/tmp")
         try:
             subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=True)
-            vals = []
+            vals = {}
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
-                    if "k_verify<" in row.get("Kernel_Name", "") and row.get("Counter_Name") == ctr:
-                        vals.append(float(row["Counter_Value"]))
-            if vals:
-                got[ctr] = (float(np.mean(vals)), len(vals))
+                    if "k_verify<" in row.get("Kernel_Name", "") and row.get("Counter_Name") in ctrs:
+                        vals.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+            # the inner run launches warm-up + timed bases: keep the timed ones (the last `steps` launches)
+            for k, v in vals.items():
+                v = v[-args.steps:] if len(v) >= args.steps else v
+                got[k] = (float(np.mean(v)), len(v))
+            if args.profile_dir:
+                os.makedirs(args.profile_dir, exist_ok=True)
+                for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                    rows = [r for r in csv.DictReader(open(f)) if "k_verify<" in r.get("Kernel_Name", "")]
+                    if rows:
+                        with open(os.path.join(args.profile_dir, "pmc_%s_k_verify.csv" % "_".join(ctrs)[:60]), "w", newline="") as fo:
+                            w = csv.DictWriter(fo, fieldnames=["Dispatch_Id", "Kernel_Name", "Counter_Name", "Counter_Value"], extrasaction="ignore")
+                            w.writeheader(); w.writerows(rows)
         except Exception as e:                                  # noqa: BLE001 -- the bench line must still be printed
-            note.append("%s pass failed: %s" % (ctr, type(e).__name__))
+            note.append("%s pass failed: %s" % ("+".join(ctrs), type(e).__name__))
         finally:
             shutil.rmtree(d, ignore_errors=True)
-    if "FETCH_SIZE" not in got or "WRITE_SIZE" not in got:
-        return None, "; ".join(note) or "no k_verify rows in the counter output"
-    # FETCH_SIZE / WRITE_SIZE are in KiB-like units of 1 KB? rocprofv3 reports them in kilobytes (derived from 64 B / 32 B
-    # requests); gfx950 tallies 128-B read requests at 64 B, hence the factor 2 on FETCH_SIZE (MI355X_MICROARCH.md, HBM).
-    fetch_b = got["FETCH_SIZE"][0] * 1024.0 * 2.0
-    write_b = got["WRITE_SIZE"][0] * 1024.0
-    return fetch_b + write_b, ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, this run's binary and default lanes, "
-                              "30 timed bases; mean per k_verify launch over %d / %d launches; FETCH_SIZE doubled (gfx950 tallies 128-B "
-                              "requests at 64 B), uncalibrated for 16-B gathers; counts L2->fabric requests including Infinity-Cache hits"
-                              % (got["FETCH_SIZE"][1], got["WRITE_SIZE"][1]))
+    return got, note
 
 
-def hbm_bound_point(device, budget_transforms=4096):
-    """One HBM-bound operating point of the same scoring code: BASELINE configs[4] (100 k-point query in a 10 M-point scene),
-    n_P ~ 4.2 M sampled scene points -> ~1.4 GB of point lists (>> 256 MB Infinity Cache).  A batch of transforms near the
-    ground truth (so that most queries reach the exact stage) is scored with s4p_verify_transforms; the bytes the
-    structure requires come from the instrumented kernel's own counters."""
+def part_in_whole_structure(device, n_transforms, seed=11):
+    """BASELINE configs[4]'s structure (100 k-point query in a 10 M-point scene: n_P ~ 4.2 M sampled scene points -> ~1.4 GB
+    of point lines, >> the 256 MB Infinity Cache) and a batch of transforms that slide the query over the WHOLE scene
+    (uniform over the ground's extent, any yaw), so that consecutive transforms do not share cache lines."""
     from super4pcs_amd import capi, datasets
     delta = 0.05
     P, Q, T_gt = datasets.part_in_whole_pair(10_000_000, 100_000, delta=delta)
@@ -249,6 +354,7 @@ def hbm_bound_point(device, budget_transforms=4096):
     m.init_full(P, Q)
     i = m.info()
     Ps, Qs = m.sampled(0), m.sampled(1)
+    m.close()
     ctx = capi.Context(opt, device=device, max_pairs=1 << 20, max_quads=1 << 20)
     ctx.set_clouds(Ps, Qs)
     cP, cQ = np.array(i.centroid_p, np.float64), np.array(i.centroid_q, np.float64)
@@ -256,34 +362,95 @@ def hbm_bound_point(device, budget_transforms=4096):
     Tc = np.eye(4)
     Tc[:3, :3] = Tg[:3, :3]
     Tc[:3, 3] = Tg[:3, :3] @ cQ + Tg[:3, 3] - cP
-    rng = np.random.default_rng(11)
+    lo, hi = Ps.min(axis=0).astype(np.float64), Ps.max(axis=0).astype(np.float64)
+    rng = np.random.default_rng(seed)
     Ts = []
-    for _ in range(budget_transforms):
+    for _ in range(n_transforms):
         Tp = np.eye(4)
-        Tp[:3, 3] = rng.uniform(-6.0, 6.0, 3) * np.array([1.0, 1.0, 0.05])       # slide the query over the scene's ground
         a = rng.uniform(-np.pi, np.pi)
         Tp[:3, :3] = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]])
+        Tp[:3, 3] = [rng.uniform(0.8 * lo[0], 0.8 * hi[0]), rng.uniform(0.8 * lo[1], 0.8 * hi[1]), rng.uniform(-0.05, 0.05)]
         Ts.append((Tp @ Tc).astype(np.float32))
-    Ts = np.stack(Ts)
-    ctx.verify_transforms(Ts[:64])
-    best = None
-    for _ in range(3):
-        t0 = time.perf_counter()
-        counts = ctx.verify_transforms(Ts)
-        dt = time.perf_counter() - t0
-        best = dt if best is None else min(best, dt)
-    stats = ctx.verify_stats(Ts)                     # instrumented pass: survivors per level, exact point tests
-    n_q = Qs.shape[0]
-    queries = float(len(Ts)) * n_q
-    sweep, gathers = structure_bytes_per_candidate(n_q, stats["l0"] / queries, stats["l1"] / queries, stats["tests"] / queries)
-    gb = len(Ts) * gathers / 1e9
-    return {"workload": "configs[4] structure: n_P=%d sampled scene points, n_Q=%d, %d transforms around the ground truth"
-                        % (Ps.shape[0], n_q, len(Ts)),
-            "seconds": best, "transforms_per_s": len(Ts) / best, "mean_inliers": float(np.mean(counts)),
-            "gather_bytes_per_transform": gathers, "achieved_GBps": gb / best, "peak_GBps": HBM_PEAK_GBS,
-            "frac": gb / best / HBM_PEAK_GBS,
-            "note": "wall time of s4p_verify_transforms incl. the upload of the 4x4s and the read-back of the counts (both < 1 MB); "
-                    "bytes = dependent gathers the structure requires (reach words, headers, query re-reads, 16-B point records)"}
+    return ctx, Ps, Qs, np.stack(Ts), opt
+
+
+def hbm_point_inner(device, n_transforms):
+    """(run under rocprofv3 by hbm_bound_point) ONE cold s4p_verify_transforms over the configs[4] structure; prints the counts."""
+    ctx, Ps, Qs, Ts, _ = part_in_whole_structure(device, n_transforms)
+    t0 = time.perf_counter()
+    counts = ctx.verify_transforms(Ts)               # first and only scoring launch of this process: nothing is warm
+    dt = time.perf_counter() - t0
+    print(json.dumps({"seconds_wall": dt, "n_P": int(Ps.shape[0]), "n_Q": int(Qs.shape[0]), "counts_head": counts[:128].tolist(),
+                      "mean_inliers": float(np.mean(counts))}))
+
+
+def hbm_bound_point(args, device, n_transforms=4096, timeout_s=300):
+    """One HBM-bound operating point of the same scoring code, measured by rocprofv3 in a process of its own: kernel
+    duration from --kernel-trace and FETCH_SIZE from --pmc of the SINGLE, cold k_verify_T launch; the first 64 counts are
+    recomputed by the oracle's kd-tree Verify on the same sampled clouds (parity of the timed launch itself)."""
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return {"error": "rocprofv3 not found"}
+    d = tempfile.mkdtemp(prefix="s4p_hbm_", dir="/tmp")
+    cmd = [exe, "--pmc", "FETCH_SIZE", "--kernel-trace", "-d", d, "-o", "h", "--output-format", "csv", "--",
+           sys.executable, os.path.abspath(__file__), "--hbm-point-inner", "--hbm-transforms", str(n_transforms)]
+    out = {}
+    try:
+        pr = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=timeout_s, check=True)
+        inner = json.loads([l for l in pr.stdout.splitlines() if l.startswith("{")][-1])
+        dur_ns, fetch = None, None
+        for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
+            for row in csv.DictReader(open(f)):
+                if "k_verify_T<" in row.get("Kernel_Name", ""):
+                    dur_ns = float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
+        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            for row in csv.DictReader(open(f)):
+                if "k_verify_T<" in row.get("Kernel_Name", "") and row.get("Counter_Name") == "FETCH_SIZE":
+                    fetch = float(row["Counter_Value"])
+            if args.profile_dir:
+                os.makedirs(args.profile_dir, exist_ok=True)
+                shutil.copy(f, os.path.join(args.profile_dir, "hbm_point_counter_collection.csv"))
+        if args.profile_dir:
+            for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
+                shutil.copy(f, os.path.join(args.profile_dir, "hbm_point_kernel_trace.csv"))
+        if dur_ns is None or fetch is None:
+            return {"error": "no k_verify_T row in the rocprofv3 output"}
+        # the byte model's inputs for this structure: an instrumented pass over the same transforms
+        from oracle import oracle as O
+        ctx, Ps, Qs, Ts, _ = part_in_whole_structure(device, n_transforms)
+        stats = ctx.verify_stats(Ts)                 # survivors per level, exact point tests
+        n_q = Qs.shape[0]
+        queries = float(len(Ts)) * n_q
+        groups = stats["tests"] / 4.0 / queries      # (listed points of mask survivors / 4: an upper bound of the groups walked)
+        _sweep, gathers = structure_bytes_per_candidate(n_q, stats["l0"] / queries, stats["l1"] / queries, stats["l2"] / queries, groups)
+        fetch_b = fetch * 1024.0 * 2.0               # KB -> B, x2: gfx950 tallies 128-B read requests at 64 B (MI355X_MICROARCH.md, HBM)
+        t = dur_ns * 1e-9
+        out = {"workload": "configs[4] structure: n_P=%d sampled scene points, n_Q=%d, %d transforms spread over the whole scene, ONE cold launch"
+                           % (inner["n_P"], n_q, len(Ts)),
+               "kernel_ms": dur_ns * 1e-6, "transforms_per_s": len(Ts) / t, "mean_inliers": inner["mean_inliers"],
+               "fetch_bytes": fetch_b, "measured_GBps": fetch_b / t / 1e9, "measured_frac": fetch_b / t / 1e9 / HBM_PEAK_GBS,
+               "algorithmic_bytes": len(Ts) * gathers, "achieved_GBps": len(Ts) * gathers / t / 1e9, "peak_GBps": HBM_PEAK_GBS,
+               "frac": len(Ts) * gathers / t / 1e9 / HBM_PEAK_GBS,
+               "counts_checked_by_oracle": 0, "count_mismatches": None,
+               "note": "kernel duration and FETCH_SIZE (doubled: gfx950 tallies 128-B requests at 64 B) of the single cold k_verify_T launch, "
+                       "rocprofv3 --kernel-trace --pmc FETCH_SIZE in a process of its own; algorithmic bytes = dependent gathers the structure "
+                       "requires (reach words, 32-B headers, query re-reads, 48-B point groups) from the instrumented kernel's counters"}
+        # parity of the TIMED launch: the oracle's kd-tree Verify recounts the first 64 transforms on exactly the sampled,
+        # centred clouds the context was given (the inner process builds them the same way: same seeds)
+        try:
+            om = O.Matcher(O.make_options(0.05, 0.2, 5000), full_counts=True, use_kdtree=True)
+            om.set_sampled(Ps, Qs)
+            want = om.verify_batch(Ts[:64])
+            got = np.array(inner["counts_head"][:64], np.int64)
+            out["counts_checked_by_oracle"] = 64
+            out["count_mismatches"] = int((want.astype(np.int64) != got).sum())
+        except Exception as e:                                  # noqa: BLE001
+            out["count_mismatches"] = "oracle recount failed: %s" % e
+    except Exception as e:                                      # noqa: BLE001
+        out = {"error": "%s: %s" % (type(e).__name__, e)}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    return out
 
 
 def main():
@@ -295,17 +462,28 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the 1-core cpu_baseline sample (0 = skip)")
     ap.add_argument("--no-time-to-register", dest="time_to_register", action="store_false", default=True)
     ap.add_argument("--no-parity", dest="parity", action="store_false", default=True)
-    ap.add_argument("--parity-bases", type=int, default=2)
-    ap.add_argument("--no-pmc", dest="pmc", action="store_false", default=True, help="skip the rocprofv3 --pmc passes (roofline.traffic = null)")
+    ap.add_argument("--parity-bases", type=int, default=-1, help="timed bases replayed on the oracle (default: all of them up to 40)")
+    ap.add_argument("--parity-full-bases", type=int, default=2, help="bases whose EVERY candidate count is checked")
+    ap.add_argument("--no-pmc", dest="pmc", action="store_false", default=True, help="skip the rocprofv3 --pmc passes (traffic / valu / l2 = null)")
     ap.add_argument("--no-hbm-point", dest="hbm_point", action="store_false", default=True)
+    ap.add_argument("--no-full-count-mode", dest="full_count_mode", action="store_false", default=True,
+                    help="skip the extra timed region with the early exit off (config.full_count_mode)")
     ap.add_argument("--no-exclusive", dest="exclusive", action="store_false", default=True,
-                    help="skip the one-base-in-flight re-run (roofline.exclusive); used for the rocprofv3 kernel-stats run, so "
-                         "that its k_verify rows are the default configuration's launches only")
+                    help="skip the one-base-in-flight re-run (roofline.per_launch.exclusive)")
+    ap.add_argument("--profile-dir", default=None, help="keep the k_verify rows of the rocprofv3 outputs here (e.g. profiles/r03_bench)")
     ap.add_argument("--inner", action="store_true", help="(used by the --pmc passes) timed region only, no JSON")
+    ap.add_argument("--hbm-point-inner", action="store_true", help="(used by the HBM-bound point) one cold scoring launch")
+    ap.add_argument("--hbm-transforms", type=int, default=4096)
     ap.add_argument("--points", type=int, default=N_POINTS)
     ap.add_argument("--sample", type=int, default=SAMPLE)
     args = ap.parse_args()
 
+    scale_mode = args.sample > 5000          # the "GPU-scale" sample: bases of ~10^9 quads, seconds per base
+    if scale_mode:
+        # a whole registration, the CPU baselines and the per-launch profiling passes are out of reach at this size (the
+        # reference itself cannot finish ONE base); what remains: value, parity through counts + checksums, the byte model
+        args.time_to_register = False; args.pmc = False; args.hbm_point = False; args.exclusive = False; args.cpu_seconds = 0.0
+        args.repeats = min(args.repeats, 2)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -327,7 +505,6 @@ def main():
             dev = torch.device("cpu")
         else:
             dist.init_process_group(backend="nccl", device_id=dev)     # "nccl" is RCCL on ROCm
-
     from super4pcs_amd import build as B
     if rank == 0 and B.needs_build():
         B.build()
@@ -335,27 +512,30 @@ def main():
         dist.barrier()
     from super4pcs_amd import capi, datasets, sharding
 
+    if args.hbm_point_inner:
+        hbm_point_inner(local_rank, args.hbm_transforms)
+        return
+
     P, Q, T_gt = datasets.bumpy_pair(args.points, overlap=OVERLAP, delta=DELTA, seed=SEED)
     opt = capi.make_options(DELTA, OVERLAP, args.sample)
+    collective = {"kind": "none (one GPU: the engine's pipelined Perform_N_steps)"}
 
     def sync():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed_region(steps, warmup):
-        """Fresh matcher, same seed: W untimed steps, then exactly K timed steps between barrier + synchronize."""
-        m = capi.Matcher(opt, device=local_rank, max_pairs=MAX_PAIRS, max_quads=MAX_QUADS)
-        m.init_full(P, Q)                       # sampling, grid build, upload: outside the timed region
+    def make_driver(m):
         if world > 1:
             # the C++ sharded loop behind the C ABI (s4p_shard_*): RCCL all-reduce(max) of one 8-byte key per window
             sh = capi.Shard(m, rank, world, True)
             if one_gpu:
                 sh.use_collective(capi.torch_collective(dist))          # single-GPU dry run: gloo through the callback provider
+                collective["kind"] = "gloo through the callback provider (S4P_BENCH_ONE_GPU dry run)"
             else:
                 # the library's own communicator (ncclCommInitRank from the id rank 0 made); should RCCL not bind or not
                 # initialise on some rank, every rank falls back to the process group torch already has (same 8-byte
-                # all-reduce per window, through the callback provider)
+                # all-reduce per window, through the callback provider) -- and the JSON line says which one ran
                 ok = 1
                 try:
                     idt = torch.zeros(128, dtype=torch.uint8, device=dev)
@@ -375,10 +555,20 @@ def main():
                         ok = 0
                     flag = torch.tensor([ok], dtype=torch.int32, device=dev)
                     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-                if not int(flag.item()):
+                if int(flag.item()):
+                    collective["kind"] = "rccl: ncclAllReduce(uint64, max) per window from the C++ loop (s4p_shard_run_windows, own communicator)"
+                else:
                     sh.use_collective(capi.torch_collective(dist, dev))
-        else:
-            sh = sharding.ShardedRansac(m, rank, world, dist, dev)      # world 1: the engine's own pipelined Perform_N_steps
+                    collective["kind"] = "torch-fallback: torch.distributed all_reduce(max) on the nccl (= RCCL) process group through the callback provider"
+            return sh
+        return sharding.ShardedRansac(m, rank, world, dist, dev)      # world 1: the engine's own pipelined Perform_N_steps
+
+    def timed_region(steps, warmup, early_exit=True):
+        """Fresh matcher, same seed: W untimed steps, then exactly K timed steps between barrier + synchronize."""
+        m = capi.Matcher(opt, device=local_rank, max_pairs=(32 << 20) if scale_mode else MAX_PAIRS, max_quads=(32 << 20) if scale_mode else MAX_QUADS)
+        m.early_exit(early_exit)
+        m.init_full(P, Q)                       # sampling, grid build, upload: outside the timed region
+        sh = make_driver(m)
         sh.run_windows(warmup)
         m.profile_enable(True, False)
         m.profile_get(reset=True)
@@ -399,7 +589,7 @@ def main():
         timed_region(args.steps, args.warmup)
         return
 
-    runs = []
+    runs, finals = [], []
     m = sh = None
     for _ in range(max(args.repeats, 1)):
         if m is not None:
@@ -408,32 +598,54 @@ def main():
             m.close()
         m, sh, dt_max, cand_all, prof = timed_region(args.steps, args.warmup)
         runs.append((cand_all / dt_max, dt_max, cand_all, prof))
+        finals.append(m.info())
     order = sorted(range(len(runs)), key=lambda k: runs[k][0])
     med = order[len(order) // 2]
     value, dt_max, cand_all, prof = runs[med]
-    info = m.info()
+    info = finals[-1]
     n_q, n_p = info.n_sampled_q, info.n_sampled_p
-
-    # k-bar (mean P points distance-tested per query) and the pass fractions of the three levels, from two extra,
-    # untimed, instrumented bases
-    m.profile_enable(False, True)
-    m.profile_get(reset=True)
-    q_before = m.info().candidates_verified
-    sh.run_windows(2)
-    pk = m.profile_get(reset=True)
-    q_after = m.info().candidates_verified
-    queries = max((q_after - q_before) * n_q, 1)
-    kbar = pk.verify_point_tests / queries
-    f_l0, f_l1, f_l2 = pk.verify_l0_pass / queries, pk.verify_l1_pass / queries, pk.verify_l2_pass / queries
-    m.profile_enable(False, False)
-    final_info = m.info()                       # state after the last repeat's windows (N > 1: compared across ranks below)
+    final_info = info                           # state after the last repeat's windows (N > 1: compared across ranks below)
+    chunk_stats = m.chunk_stats()
+    lane_growths = m.capacity_growths()
+    if hasattr(sh, "close"):
+        sh.close()
     m.close()
+    # the same timed region with every candidate counted in full (no early exit): what rounds 1 and 2 reported as `value`
+    full_mode = None
+    if world == 1 and args.full_count_mode:
+        mf, shf, dt_f, cand_f, prof_f = timed_region(args.steps, args.warmup, early_exit=False)
+        fi = mf.info()
+        full_mode = {"value": cand_f / dt_f, "ms_per_step": dt_f / args.steps * 1e3, "candidates": cand_f,
+                     "same_result_as_default": bool(fi.best_lcp == info.best_lcp and list(fi.transform) == list(info.transform)
+                                                    and list(fi.base) == list(info.base) and list(fi.congruent) == list(info.congruent) and cand_f == cand_all),
+                     "note": "S4P early exit off: every candidate scored over all n_Q points; one repeat"}
+        mf.close()
+
+    # the byte model's inputs, measured on the TIMED bases: a fresh matcher runs the W warm-up bases, then the K timed bases
+    # again through the instrumented kernel (slower; untimed)
+    f_l0 = f_l1 = f_l2 = kbar = 0.0
+    groups_per_query = 0.0
+    if world == 1 and not scale_mode:
+        mi = capi.Matcher(opt, device=local_rank, max_pairs=(32 << 20) if scale_mode else MAX_PAIRS, max_quads=(32 << 20) if scale_mode else MAX_QUADS)
+        mi.init_full(P, Q)
+        shi = sharding.ShardedRansac(mi, 0, 1, None, dev)
+        shi.run_windows(args.warmup)
+        mi.profile_enable(False, True)
+        mi.profile_get(reset=True)
+        q_before = mi.info().candidates_verified
+        shi.run_windows(args.steps)
+        pk = mi.profile_get(reset=True)
+        queries = max((mi.info().candidates_verified - q_before) * n_q, 1)
+        kbar = pk.verify_point_tests / queries
+        f_l0, f_l1, f_l2 = pk.verify_l0_pass / queries, pk.verify_l1_pass / queries, pk.verify_l2_pass / queries
+        groups_per_query = kbar / 4.0 + 0.375 * f_l2        # listed points / 4, plus the part-filled last group of a list (mean 3/8 of a group)
+        mi.close()
 
     # time-to-register (the metric's second half): one whole ComputeTransformation on the same pair, wall time from
     # call to return with inputs in host memory (sampling of both 1 M-point clouds, grid build, upload, all trials,
     # final apply).  Reported, never part of `value`.
     ttr = None
-    M2 = None
+    T2c = None
     if world == 1 and args.time_to_register:
         m2 = capi.Matcher(opt, device=local_rank, max_pairs=MAX_PAIRS, max_quads=MAX_QUADS)
         m2.set_sharding(0, 1, True)
@@ -450,14 +662,48 @@ def main():
 
     parity = None
     if rank == 0 and world == 1 and args.parity:
-        parity, om_full = parity_gate(P, Q, T_gt, opt, args.warmup, args.parity_bases, 2500, local_rank)
+        n_par = args.parity_bases if args.parity_bases >= 0 else min(args.steps, 40)
+        n_par = min(n_par, args.steps)
+        if scale_mode:
+            parity, ostate, om_full = parity_gate_scale(P, Q, opt, args.warmup, n_par, local_rank, args.sample)
+        else:
+            parity, ostate, om_full = parity_gate(P, Q, opt, args.warmup, n_par, args.parity_full_bases, local_rank, args.sample)
+        failed = parity.setdefault("failed", [])
+        # every repeat of the timed region ended in the same state and verified the same number of candidates ...
+        for k, fi in enumerate(finals):
+            same = (fi.best_lcp == finals[0].best_lcp and list(fi.transform) == list(finals[0].transform) and list(fi.base) == list(finals[0].base)
+                    and list(fi.congruent) == list(finals[0].congruent) and runs[k][2] == runs[0][2])
+            if not same:
+                failed.append("timed repeat %d ends in a different state than repeat 0" % k)
+        # ... which is the oracle's after the same W + K bases (when all K were replayed)
+        parity["timed_repeats_checked_against_oracle"] = 0
+        if n_par == args.steps and scale_mode:
+            for k in range(len(finals)):
+                if runs[k][2] != ostate["candidates_timed"]:
+                    failed.append("timed repeat %d: %d candidates vs the oracle's %d over the same bases" % (k, runs[k][2], ostate["candidates_timed"]))
+                parity["timed_repeats_checked_against_oracle"] += 1
+        elif n_par == args.steps:
+            for k, fi in enumerate(finals):
+                ok = (fi.best_lcp == ostate["best_lcp"] and list(fi.base) == ostate["base"] and list(fi.congruent) == ostate["congruent"]
+                      and np.array_equal(np.array(fi.transform, np.float32).reshape(4, 4), ostate["transform"]) and runs[k][2] == ostate["candidates_timed"])
+                if not ok:
+                    failed.append("timed repeat %d: final state / candidate total differs from the oracle's after the same bases "
+                                  "(LCP %r vs %r, candidates %d vs %d)" % (k, fi.best_lcp, ostate["best_lcp"], runs[k][2], ostate["candidates_timed"]))
+                parity["timed_repeats_checked_against_oracle"] += 1
+        if scale_mode and ostate.get("byte_model", {}).get("queries"):
+            bmq = ostate["byte_model"]                # (instrumenting 10^8 candidates per base is out of reach: a subsample of them instead)
+            kbar = bmq["tests"] / bmq["queries"]
+            f_l0, f_l1, f_l2 = bmq["l0"] / bmq["queries"], bmq["l1"] / bmq["queries"], bmq["l2"] / bmq["queries"]
+            groups_per_query = kbar / 4.0 + 0.375 * f_l2
         if ttr is not None:
             # the registration's result, recounted by the oracle's kd-tree Verify on its own sampled clouds
             recount = int(om_full.verify_batch(T2c.reshape(1, 16))[0])
             ttr["oracle_recount_of_final_transform"] = recount
             if recount != ttr["best_count"]:
-                parity["mismatches"] += 1
-                parity.setdefault("failed", []).append("time-to-register: final LCP %d != oracle recount %d" % (ttr["best_count"], recount))
+                failed.append("time-to-register: final LCP %d != oracle recount %d" % (ttr["best_count"], recount))
+        parity["mismatches"] = len(failed) if not parity.get("mismatches") else max(parity["mismatches"], len(failed))
+        if not failed:
+            parity.pop("failed", None)
 
     # N > 1: the sharded loop must leave every rank with the state the sequential loop reaches after the same trials.
     # All ranks' states are compared with each other and with a sequential single-GPU replay on rank 0 (which is the
@@ -473,7 +719,7 @@ def main():
         if rank == 0:
             states = [t.cpu().numpy() for t in allt]
             failed = ["rank %d ends in a different state than rank 0" % r for r in range(1, world) if not np.array_equal(states[r], states[0])]
-            trials = (args.warmup + args.steps + 2) * world      # the last repeat's windows + the two instrumented ones above
+            trials = (args.warmup + args.steps) * world           # the last repeat's windows
             seq = capi.Matcher(opt, device=local_rank, max_pairs=MAX_PAIRS, max_quads=MAX_QUADS)
             seq.init_full(P, Q)
             for _ in range(trials):                               # TryOneBase, one after the other: no stop rule, like run_windows
@@ -491,15 +737,12 @@ def main():
             if failed:
                 parity["failed"] = failed
 
-    traffic, traffic_note = None, "skipped"
+    pmc, pmc_note = {}, ["skipped"]
     if rank == 0 and world == 1 and args.pmc:
-        traffic, traffic_note = pmc_traffic(args)
+        pmc, pmc_note = pmc_passes(args)
     hbm_point = None
     if rank == 0 and world == 1 and args.hbm_point:
-        try:
-            hbm_point = hbm_bound_point(local_rank)
-        except Exception as e:                                  # noqa: BLE001
-            hbm_point = {"error": "%s: %s" % (type(e).__name__, e)}
+        hbm_point = hbm_bound_point(args, local_rank)
 
     apply_row = None
     if rank == 0 and world == 1 and args.hbm_point:
@@ -531,7 +774,7 @@ def main():
             m1.perform_n_steps(args.warmup)
             m1.profile_enable(True, False)
             m1.profile_get(reset=True)
-            m1.perform_n_steps(min(args.steps, 60))
+            m1.perform_n_steps(args.steps)
             p1 = m1.profile_get(reset=True)
             m1.close()
             if p1.verify_launches:
@@ -547,12 +790,42 @@ def main():
         launches = max(prof.verify_launches, 1)
         avg_ms = prof.verify_ms_total / launches
         cand_per_launch = prof.verify_candidates / launches
-        sweep_b, gather_b = structure_bytes_per_candidate(n_q, f_l0, f_l1, kbar)
-        t = avg_ms * 1e-3
-        achieved = cand_per_launch * gather_b / t / 1e9 if t > 0 else 0.0
-        sweep_gbps = cand_per_launch * sweep_b / t / 1e9 if t > 0 else 0.0
+        sweep_b, gather_b = structure_bytes_per_candidate(n_q, f_l0, f_l1, f_l2, groups_per_query)
+        achieved = value * gather_b / 1e9                       # per-step figure: bytes of the K timed bases / timed seconds
         survey_b = survey_bytes_per_candidate(n_q, kbar)
         vals = sorted(r[0] for r in runs)
+
+        def mean(name):
+            return pmc[name][0] if name in pmc else None
+
+        traffic = None
+        if mean("FETCH_SIZE") is not None and mean("WRITE_SIZE") is not None:
+            # FETCH_SIZE / WRITE_SIZE are reported in KB; gfx950 tallies 128-B read requests at 64 B, hence the factor 2 on
+            # FETCH_SIZE (MI355X_MICROARCH.md, HBM); counts L2 -> fabric requests including Infinity-Cache hits
+            traffic = mean("FETCH_SIZE") * 1024.0 * 2.0 + mean("WRITE_SIZE") * 1024.0
+        valu = None
+        if mean("SQ_ACTIVE_INST_VALU") is not None and mean("GRBM_GUI_ACTIVE"):
+            avail = N_SIMDS * mean("GRBM_GUI_ACTIVE") / 8.0 / 4.0     # SIMD quad-cycles of one launch (GRBM_GUI_ACTIVE is summed over the 8 XCDs)
+            valu = {"frac": mean("SQ_ACTIVE_INST_VALU") / avail, "active_quad_cycles": mean("SQ_ACTIVE_INST_VALU"), "available_quad_cycles": avail,
+                    "valu_instructions_per_candidate": (mean("SQ_INSTS_VALU") or 0) / max(cand_per_launch, 1),
+                    "wait_any_frac_of_wave_cycles": (mean("SQ_WAIT_ANY") or 0) / max(mean("SQ_WAVE_CYCLES") or 1, 1),
+                    "note": "SQ_ACTIVE_INST_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 / 4) of k_verify, launches serialised by the counter collection "
+                            "(the kernel alone), mean over the timed bases"}
+        l2 = None
+        if mean("TCC_HIT_sum") is not None and mean("TCC_MISS_sum") is not None:
+            req = mean("TCC_HIT_sum") + mean("TCC_MISS_sum")
+            ex_ms = exclusive["avg_launch_ms"] if exclusive else avg_ms
+            l2 = {"hit_rate": mean("TCC_HIT_sum") / max(req, 1), "requests_per_launch": req,
+                  "GBps_at_128B_per_request": req * 128.0 / (ex_ms * 1e-3) / 1e9, "peak_GBps": L2_PEAK_GBS,
+                  "frac": req * 128.0 / (ex_ms * 1e-3) / 1e9 / L2_PEAK_GBS,
+                  "note": "TCC_HIT_sum + TCC_MISS_sum per launch x 128 B (an upper bound: a 16-B gather moves at most one line) over the kernel's "
+                          "own launch time"}
+        fracs = {"hbm": achieved / HBM_PEAK_GBS}
+        if valu:
+            fracs["valu"] = valu["frac"]
+        if l2:
+            fracs["l2"] = l2["frac"]
+        binding = max(fracs, key=lambda k: fracs[k])
         out = {
             "metric": "candidate transforms verified/sec", "value": value, "unit": "candidates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -565,41 +838,51 @@ def main():
                                    % (args.points, DELTA, args.sample, n_p, n_q),
                        "n_P": n_p, "n_Q": n_q, "delta": DELTA, "overlap": OVERLAP, "seed": SEED,
                        "candidates_timed": cand_all, "point_queries_per_s": cand_all * n_q / dt_max,
-                       "parallelism": "bases sharded over %d GPU(s), one 8-byte ncclAllReduce(max) per window (C++ loop, s4p_shard_run_windows)" % world,
+                       "parallelism": "bases sharded over %d GPU(s), one 8-byte all-reduce(max) per window" % world,
+                       "collective": collective["kind"],
+                       "early_exit": {"on": True, "candidates_abandoned": int(prof.verify_pruned), "fraction": prof.verify_pruned / max(cand_all, 1),
+                                      "note": "candidates that can no longer EXCEED the registration's best inlier count are abandoned, as the reference's "
+                                              "Verify does (match4pcsBase.cc:520,558-560); they count as verified there and here; results identical"},
+                       "full_count_mode": full_mode,
+                       "chunked_bases": chunk_stats, "lane_growths": lane_growths,
                        "time_to_register": ttr},
             "parity": parity,
             "roofline": {
                 "bound": "hbm", "kernel": "k_verify", "unit": "GB/s", "peak": HBM_PEAK_GBS,
                 "achieved": achieved, "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic, "traffic_note": traffic_note,
-                "avg_launch_ms": avg_ms, "launches": int(prof.verify_launches), "candidates_per_launch": cand_per_launch,
+                "traffic": traffic, "traffic_note": "; ".join(pmc_note) if pmc_note else
+                           "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over an inner run of the same %d + %d bases, mean per k_verify "
+                           "launch of the timed bases; FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B), uncalibrated for 16-B gathers; "
+                           "counts L2 -> fabric requests including Infinity-Cache hits" % (args.warmup, args.steps),
                 "algorithmic_bytes_per_candidate": gather_b,
-                "definition": "achieved = gather bytes the three-level structure requires per candidate (8 B reach word per L0 survivor, "
-                              "16 B header + 16 B query per L1 survivor, 16 B per exact point test, 64 B candidate record) x candidates "
-                              "per launch / HIP-event launch time; these are dependent 8/16-B gathers into structures beyond one XCD's L2, "
-                              "priced against the HBM peak.  The 16 B/query sweep of the 32 KB query array is L1/L2-resident and reported "
-                              "separately (l2_sweep).  DESIGN.md section 7.",
-                "pass_fractions": {"coarse_bitmap_L0": f_l0, "reach_bit_L1": f_l1, "subcell_mask_L2": f_l2}, "kbar": kbar,
-                "l2_sweep": {"bytes_per_candidate": sweep_b, "achieved_GBps": sweep_gbps, "peak_GBps": L2_PEAK_GBS, "frac": sweep_gbps / L2_PEAK_GBS},
-                "survey_8d_model": {"bytes_per_candidate": survey_b, "GBps": cand_per_launch * survey_b / t / 1e9 if t > 0 else 0.0,
+                "definition": "achieved = gather bytes the three-level structure requires per candidate (8 B reach word per L0 survivor, 32 B header + "
+                              "16 B query per L1 survivor, 48 B per group of four points a mask survivor walks, 64 B candidate record; fractions measured "
+                              "by an instrumented replay of the timed bases) x candidates of the timed bases / timed seconds: the per-step figure, "
+                              "independent of how many bases are in flight.  The working set (point lines ~19 MB) is Infinity-Cache resident, so this is "
+                              "priced against a roof the kernel is NOT bound by -- `binding` names the resource closest to its roof.  DESIGN.md section 7.",
+                "binding": {"resource": binding, "fracs": fracs},
+                "valu": valu, "l2": l2,
+                "pass_fractions": {"coarse_bitmap_L0": f_l0, "reach_bit_L1": f_l1, "subcell_mask_L2": f_l2}, "kbar": kbar, "groups_per_query": groups_per_query,
+                "per_launch": {"avg_launch_ms": avg_ms, "launches": int(prof.verify_launches), "candidates_per_launch": cand_per_launch,
+                               "achieved": cand_per_launch * gather_b / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0,
+                               "note": "HIP-event duration of a launch in the default configuration: six bases in flight stretch every launch, so "
+                                       "this is not a per-step cost",
+                               "exclusive": None if exclusive is None else dict(
+                                   exclusive, achieved=exclusive["candidates_per_launch"] * gather_b / (exclusive["avg_launch_ms"] * 1e-3) / 1e9,
+                                   frac=exclusive["candidates_per_launch"] * gather_b / (exclusive["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                   note="same bases with one base in flight (S4P_LANES=1): k_verify's own launch time")},
+                "lds_sweep": {"bytes_per_candidate": sweep_b, "note": "8 B per query out of the workgroup's LDS copy of the quantised queries"},
+                "survey_8d_model": {"bytes_per_candidate": survey_b, "GBps": value * survey_b / 1e9,
                                     "note": "SURVEY.md 8d figure (27 cells x 8 B per query, no cache credit): a cell-probing kernel this one "
                                             "replaced; kept for reference, not a roofline fraction"},
                 "hbm_bound_point": hbm_point,
-                "exclusive": None if exclusive is None else dict(
-                    exclusive, achieved=exclusive["candidates_per_launch"] * gather_b / (exclusive["avg_launch_ms"] * 1e-3) / 1e9,
-                    frac=exclusive["candidates_per_launch"] * gather_b / (exclusive["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                    note="same bases with one base in flight (S4P_LANES=1): k_verify's own launch time; achieved/frac above use the "
-                         "launch time of the default configuration, where every launch shares the chip with the other lanes' kernels"),
-                "aggregate": {"achieved": value * gather_b / 1e9, "frac": value * gather_b / 1e9 / HBM_PEAK_GBS,
-                              "note": "value (candidates/s of the whole pipeline) x algorithmic bytes per candidate: what the chip "
-                                      "sustains per unit of time with the default lanes"},
             },
             "k_apply": apply_row,
             "stage_ms_per_step": {"pairs_and_prep": prof.pairs_ms_total / max(prof.quads_launches, 1),
                                   "quads_and_gate": prof.quads_ms_total / max(prof.quads_launches, 1), "verify_and_select": avg_ms},
         }
         if world == 1 and args.cpu_seconds > 0:
-            out["cpu_baseline"] = cpu_baseline(P, Q, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(P, Q, args.cpu_seconds, args.sample, ttr["candidates_verified"] if ttr else 0)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

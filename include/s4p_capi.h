@@ -113,6 +113,16 @@ int64_t s4p_lane_growths(const s4p_ctx* ctx);
 int32_t s4p_set_quad_chunking(s4p_ctx* ctx, int32_t enable, uint64_t grow_cap_quads);
 int32_t s4p_chunk_stats(const s4p_ctx* ctx, uint64_t* out4);
 
+/* Early abandonment of candidates that cannot win.  The reference's Verify stops scoring a candidate as soon as it cannot
+ * reach the best LCP found so far (match4pcsBase.cc:520,558-560).  s4p_set_best_hint(ctx, n) lets the fused pass do the
+ * same from the next launched base on, with a bound that does not depend on candidate order: a candidate is abandoned once
+ * (confirmed inliers + queries still waiting for their exact test + queries not swept yet) <= n, i.e. once it can no longer
+ * EXCEED n inliers and therefore cannot become the best (match4pcsBase.hpp:468).  n must not be larger than the best inlier
+ * count of the registration so far (the engine passes exactly that).  Unaffected: the winner and its count whenever it
+ * exceeds n, n_quads, n_verified (the reference counts abandoned candidates as verified too), the checksums.  Lower
+ * bounds only: the counts of abandoned candidates and a base's best_count when it does not exceed n.  0 = off (default). */
+int32_t s4p_set_best_hint(s4p_ctx* ctx, uint32_t best_count);
+
 /* options.max_angle (shared4pcs.h:160).  > 0: the segment-angle pair filter acosf(segment1 . segment2) <= max_angle
  * (pairCreationFunctor.h:203-212) runs on the device as an exact cosine threshold (the smallest float whose libm acosf
  * passes, found with libm at s4p_create).  >= 0: the Euler-angle bound of ComputeRigidTransformation
@@ -260,6 +270,7 @@ typedef struct {
   uint64_t pairs_launches, quads_launches;
   double   host_octree_s;        /* host time in the pair-octree builds (loop 1 of IntersectionFunctor)   */
   double   host_wait_s;          /* host time blocked in stream synchronisation                           */
+  uint64_t verify_pruned;        /* candidates abandoned because they could not exceed the best-count hint */
 } s4p_profile;
 int32_t s4p_profile_enable(s4p_ctx* ctx, int32_t enable_events, int32_t count_point_tests);
 int32_t s4p_profile_get(s4p_ctx* ctx, s4p_profile* out, int32_t reset);

@@ -123,6 +123,17 @@ int32_t s4p_matcher_perform_n_steps(s4p_matcher* m, int32_t n, s4p_visitor_fn vi
  * lower for candidates that cannot win).  Costs a device read-back per trial; off by default. */
 int32_t s4p_matcher_visit_candidates(s4p_matcher* m, int32_t enable);
 
+/* Early exit: inside the trial loops (s4p_matcher_perform_n_steps / _compute_transformation, the sharded loop) the device
+ * abandons candidates that can no longer EXCEED the best inlier count committed so far (s4p_set_best_hint) -- the
+ * reference's Verify does the same sequentially (match4pcsBase.cc:520,558-560).  Results are unaffected: best LCP, winner,
+ * transform, candidates_verified.  On by default; off automatically while a per-candidate visitor listens
+ * (s4p_matcher_visit_candidates) and never active for s4p_matcher_try_one_base / next_base outside a loop;
+ * s4p_matcher_set_early_exit(m, 0) or S4P_EARLY_EXIT=0 in the environment restore full counts everywhere.
+ * s4p_matcher_loop_begin / _end bracket a driver's own trial loop (the sharded loop uses them). */
+int32_t s4p_matcher_set_early_exit(s4p_matcher* m, int32_t enable);
+int32_t s4p_matcher_loop_begin(s4p_matcher* m);
+int32_t s4p_matcher_loop_end(s4p_matcher* m);
+
 /* Where SelectQuadrilateral's two searches run (match4pcsBase.cc:185-218 wide triangle, :321-338 4th point): mode 1 =
  * device reductions over the sampled P resident in HBM (s4p_select_base_points), 0 = the host search structures, -1
  * (default) = by size: device from 2^20 sampled P points (the S4P_DEVICE_SELECT environment variable overrides the

@@ -61,6 +61,7 @@ def lib():
         L.s4po_sample.restype = C.c_uint64
         L.s4po_sample.argtypes = [fp, C.c_uint64, C.c_float, fp]
         L.s4po_init.argtypes = [C.c_void_p, fp, fp, fp, C.c_uint64, fp, fp, fp, C.c_uint64]
+        L.s4po_set_sampled.argtypes = [C.c_void_p, fp, C.c_uint64, fp, C.c_uint64]
         L.s4po_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
         L.s4po_get_cloud.argtypes = [C.c_void_p, C.c_int, fp, fp, fp]
         L.s4po_get_frame.argtypes = [C.c_void_p, fp, fp, fp, fp]
@@ -168,6 +169,12 @@ class Matcher:
         Pn = None if Pn is None else _c32(Pn); Qn = None if Qn is None else _c32(Qn)
         Prgb = None if Prgb is None else _c32(Prgb); Qrgb = None if Qrgb is None else _c32(Qrgb)
         self.L.s4po_init(self.h, _f(P), _f(Pn), _f(Prgb), P.shape[0], _f(Q), _f(Qn), _f(Qrgb), Q.shape[0])
+
+    def set_sampled(self, Ps, Qs):
+        """Clouds that are already sampled and centred, taken as they are (kd-tree only): for recounting transforms that
+        were scored elsewhere on exactly these points (verify_batch)."""
+        Ps = _c32(Ps); Qs = _c32(Qs)
+        self.L.s4po_set_sampled(self.h, _f(Ps), Ps.shape[0], _f(Qs), Qs.shape[0])
 
     def stats(self):
         s = Stats()

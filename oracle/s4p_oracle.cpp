@@ -401,6 +401,16 @@ struct Matcher {
     full_counts = fc;
   }
 
+  // Checker-only entry: take clouds that are ALREADY sampled and centred exactly as they are (no sampling, no shuffle, no
+  // re-centring -- re-centring a centred cloud would move every coordinate by a rounding error) and build the kd-tree, so
+  // that Verify can recount transforms scored elsewhere on the very same points.  Not a reference code path.
+  void set_sampled(const std::vector<P3>& P, const std::vector<P3>& Q) {
+    for (int k = 0; k < 3; ++k) centroidP[k] = centroidQ[k] = 0.f;
+    Ps = P; Qs = Q;
+    kd.build(Ps);
+    best_LCP = 0.f;
+  }
+
   // ---- match4pcsBase.cc:158-182  MeanDistance (result stored, otherwise unused) ----
   float mean_distance() {
     const float kDiameterFraction = 0.2f;
@@ -1270,6 +1280,10 @@ void s4po_init(void* h, const float* Pxyz, const float* Pn, const float* Prgb, u
                const float* Qxyz, const float* Qn, const float* Qrgb, uint64_t nQ) {
   Matcher* m = static_cast<Matcher*>(h);
   m->init(make_cloud(Pxyz, Pn, Prgb, nP), make_cloud(Qxyz, Qn, Qrgb, nQ));
+}
+
+void s4po_set_sampled(void* h, const float* Pxyz, uint64_t nP, const float* Qxyz, uint64_t nQ) {
+  static_cast<Matcher*>(h)->set_sampled(make_cloud(Pxyz, nullptr, nullptr, nP), make_cloud(Qxyz, nullptr, nullptr, nQ));
 }
 
 void s4po_get_stats(void* h, s4po_stats* s) {

@@ -21,7 +21,7 @@ EXPORTED_SYMBOLS = [
     "s4p_create", "s4p_destroy", "s4p_last_error", "s4p_device_name", "s4p_set_clouds", "s4p_set_base",
     "s4p_extract_pairs", "s4p_find_congruent", "s4p_try_congruent_set", "s4p_verify_transforms", "s4p_verify_transforms_counted",
     "s4p_transform_points_device", "s4p_apply_bench", "s4p_select_base_points", "s4p_grow_limits", "s4p_get_limits", "s4p_try_base", "s4p_last_verified", "s4p_try_base_async", "s4p_try_base_wait", "s4p_pair_state_words", "s4p_pair_state_save", "s4p_pair_state_restore", "s4p_stage_slots", "s4p_pipeline_depth", "s4p_stage_base", "s4p_try_base_staged_async", "s4p_skip_base", "s4p_last_candidates", "s4p_transform_points", "s4p_profile_enable", "s4p_profile_get",
-    "s4p_selftest_ieee", "s4p_set_quad_chunking", "s4p_chunk_stats", "s4p_set_auto_grow", "s4p_lane_growths", "s4p_border_stats", "s4p_set_clouds_timing", "s4p_quad_mix",
+    "s4p_selftest_ieee", "s4p_set_quad_chunking", "s4p_chunk_stats", "s4p_set_auto_grow", "s4p_lane_growths", "s4p_border_stats", "s4p_set_clouds_timing", "s4p_set_best_hint", "s4p_quad_mix",
 ]
 
 
@@ -62,7 +62,7 @@ class Profile(C.Structure):
         ("verify_l0_pass", C.c_uint64), ("verify_l1_pass", C.c_uint64), ("verify_l2_pass", C.c_uint64),
         ("pairs_ms_total", C.c_double), ("quads_ms_total", C.c_double),
         ("pairs_launches", C.c_uint64), ("quads_launches", C.c_uint64),
-        ("host_octree_s", C.c_double), ("host_wait_s", C.c_double),
+        ("host_octree_s", C.c_double), ("host_wait_s", C.c_double), ("verify_pruned", C.c_uint64),
     ]
 
 
@@ -136,6 +136,8 @@ def load_library():
         L.s4p_border_stats.argtypes = [vp, C.POINTER(C.c_uint64)]
         L.s4p_set_clouds_timing.restype = C.c_int32
         L.s4p_set_clouds_timing.argtypes = [vp, C.POINTER(C.c_double)]
+        L.s4p_set_best_hint.restype = C.c_int32
+        L.s4p_set_best_hint.argtypes = [vp, C.c_uint32]
         L.s4p_quad_mix.restype = C.c_uint64
         L.s4p_quad_mix.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32]
     _LIB = L
@@ -299,6 +301,9 @@ class Context:
         self._chk(self.L.s4p_profile_get(self.h, C.byref(p), int(reset)))
         return p
 
+    def set_best_hint(self, best_count):
+        self._chk(self.L.s4p_set_best_hint(self.h, int(best_count)))
+
     def set_quad_chunking(self, enable=True, grow_cap_quads=0):
         self._chk(self.L.s4p_set_quad_chunking(self.h, int(enable), int(grow_cap_quads)))
 
@@ -341,7 +346,7 @@ MATCHER_SYMBOLS = [
     "s4p_matcher_create", "s4p_matcher_destroy", "s4p_matcher_last_error", "s4p_matcher_ctx", "s4p_uniform_dist_sample",
     "s4p_matcher_init", "s4p_matcher_init_full", "s4p_matcher_get_info", "s4p_matcher_get_sampled",
     "s4p_matcher_get_sampled_attrs", "s4p_matcher_select_quadrilateral", "s4p_matcher_try_one_base", "s4p_matcher_next_base", "s4p_matcher_next_base_async", "s4p_matcher_wait_base", "s4p_matcher_set_sharding", "s4p_matcher_visit_candidates", "s4p_matcher_commit", "s4p_matcher_perform_n_steps", "s4p_matcher_set_device_selection", "s4p_matcher_device_selection", "s4p_matcher_grow_on_overflow", "s4p_matcher_capacity_growths",
-    "s4p_matcher_global_transform", "s4p_matcher_compute_transformation", "s4p_matcher_advance_trials",
+    "s4p_matcher_global_transform", "s4p_matcher_compute_transformation", "s4p_matcher_advance_trials", "s4p_matcher_set_early_exit", "s4p_matcher_loop_begin", "s4p_matcher_loop_end",
 ]
 VISITOR_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_float, C.c_float, C.POINTER(C.c_float))
 _MATCHER_DECLARED = False
@@ -482,6 +487,13 @@ class Matcher:
         o = (C.c_uint64 * 4)()
         self.L.s4p_chunk_stats(self.ctx_handle(), o)
         return {"bases": int(o[0]), "passes": int(o[1]), "splits": int(o[2]), "quads": int(o[3])}
+
+    def early_exit(self, enable):
+        """Abandon candidates that cannot beat the registration's best (the reference's Verify early exit) in the trial loops;
+        on by default, S4P_EARLY_EXIT=0 in the environment turns it off globally."""
+        self.L.s4p_matcher_set_early_exit.restype = C.c_int32
+        self.L.s4p_matcher_set_early_exit.argtypes = [C.c_void_p, C.c_int32]
+        self._chk(self.L.s4p_matcher_set_early_exit(self.h, int(enable)))
 
     def set_clouds_timing(self):
         o = (C.c_double * 4)()

@@ -149,6 +149,8 @@ struct s4p_ctx {
   // No other lane, no host state (RNG stream, octree permutation) is involved, so single-GPU and sharded loops alike go on
   // as if the buffers had been large enough.  Off: S4P_ERR_CAPACITY, the stage-level contract.
   bool auto_grow = true; uint64_t lane_growths = 0;
+  // s4p_set_best_hint: candidates that cannot EXCEED this inlier count may be abandoned by k_verify (0 = count all in full)
+  uint32_t best_hint = 0;
   // max_angle (shared4pcs.h:160): > 0 -> the segment-angle pair filter through an exact cosine threshold; >= 0 -> the
   // Euler-angle bound of ComputeRigidTransformation, decided on the device up to a margin and settled on the host
   float cos_min = -1.f; bool angle_pairs = false; float angle_tol = 1e-6f;   // S4P_ANGLE_TOL (read at creation) widens the device margin: a test aid
@@ -405,6 +407,7 @@ int32_t launch_verify(s4p_ctx* c, const BaseFrame& bf) {
   V.grid = c->dev_grid(); V.q4 = c->q4.p; V.q4v = c->q4v.p; V.qq = c->qq; V.n_q = c->n_q; V.base = bf;
   V.quads = L.quads.p; V.tags = L.tags.p; V.counts = L.counts.p; V.cand_idx = L.cand_idx.p; V.cand_T = L.cand_T.p;
   V.ctr = L.ctr.p; V.res = L.ctr.p + 1; V.slots = L.slots.p; V.border = L.border.p; V.count_tests = c->prof_points ? 1 : 0;
+  V.prune = c->prof_points ? 0u : c->best_hint;            // (the instrumented kernel measures the full structure walk)
   V.ablate = c->ablate;
   hipStream_t vs = L.stream;
   if (L.vstream) {                                           // CU partition: k_verify on the big partition, after the lane's small kernels
@@ -489,6 +492,7 @@ void account_profile(s4p_ctx* c, const DevCounters& d, bool fused) {
       if (hipEventElapsedTime(&ms, c->ev[c->cur][3], c->ev[c->cur][4]) == hipSuccess) { c->prof.quads_ms_total += ms; c->prof.quads_launches += 1; }
     }
   }
+  c->prof.verify_pruned += d.pruned;
   if (c->prof_points) { c->prof.verify_point_tests += d.point_tests; c->prof.verify_l0_pass += d.l0_pass; c->prof.verify_l1_pass += d.l1_pass; c->prof.verify_l2_pass += d.l2_pass; }
 }
 
@@ -893,6 +897,12 @@ int32_t s4p_border_stats(const s4p_ctx* c, uint64_t* out2) {
   out2[0] = c->border_settled; out2[1] = c->border_rejected;
   return S4P_OK;
 }
+// Candidates that cannot EXCEED `best_count` inliers may be abandoned by the fused pass from the next base on: they cannot
+// become the registration's best (match4pcsBase.hpp:468), which is what the reference's Verify exits early for
+// (match4pcsBase.cc:520,558-560).  Winner, best count above the hint, n_quads and n_verified are unaffected; the counts of
+// abandoned candidates (s4p_last_candidates, s4p_last_verified) and a base's best_count AT OR BELOW the hint are lower
+// bounds.  0 (the default) = every candidate is counted in full.
+int32_t s4p_set_best_hint(s4p_ctx* c, uint32_t best_count) { if (!c) return S4P_ERR_BAD_ARG; c->best_hint = best_count; return S4P_OK; }
 // Lanes growing their own buffers when a base overflows (on by default); s4p_lane_growths counts the regrowths.
 int32_t s4p_set_auto_grow(s4p_ctx* c, int32_t enable) { if (!c) return S4P_ERR_BAD_ARG; c->auto_grow = enable != 0; return S4P_OK; }
 int64_t s4p_lane_growths(const s4p_ctx* c) { return c ? int64_t(c->lane_growths) : 0; }
@@ -1022,8 +1032,7 @@ int32_t s4p_set_clouds(s4p_ctx* c, const float* px, const float* py, const float
       { // k_verify block size: see kVerifyThreadsCached (s4p_kernels.hip.hpp)
         const char* vt = getenv("S4P_VERIFY_THREADS");
         const int v = vt ? atoi(vt) : 0;
-        c->verify_threads = (v >= 256 && v <= kVerifyMaxThreads && v % 64 == 0) ? v
-                          : (size_t(n_lines) * 128u > (size_t(192) << 20) ? kVerifyMaxThreads : kVerifyThreadsCached); }
+        c->verify_threads = (v >= 256 && v <= kVerifyMaxThreads && v % 64 == 0) ? v : kVerifyThreadsCached; }
       hipLaunchKernelGGL(k_lines_clear, dim3(2048), dim3(256), 0, st, c->gnbr.p, uint64_t(n_lines));
       hipLaunchKernelGGL(k_grid_hdr_pack, dim3(1024), dim3(256), 0, st, G, starts.p, hdr_count.p, n_reach);
       hipLaunchKernelGGL(k_grid_fill, dim3(2048), dim3(256), 0, st, G);
@@ -1082,7 +1091,7 @@ int32_t s4p_set_clouds(s4p_ctx* c, const float* px, const float* py, const float
       if (!(0.5f * c->qq.step[k] * c->hgrid.inv_h < 0.004f)) fine_enough = false;
     }
     c->qlds = fine_enough && n_q <= int64_t(kLdsQueries) && getenv("S4P_NO_QLDS") == nullptr &&
-              c->gcoarse.n * 4 + size_t((n_q + 127) & ~int64_t(127)) * 8 + size_t(kVerifyMaxThreads / 64) * kQueueWordsPerWave * 4 <= size_t(kVerifyLdsBudget);
+              c->gcoarse.n * 4 + size_t((n_q + 127) & ~int64_t(127)) * 8 + size_t(c->verify_threads / 64) * kQueueWordsPerWave * 4 <= size_t(kVerifyLdsBudget);
     std::vector<uint2> packed((size_t)n_q);
     for (int64_t i = 0; i < n_q; ++i) {
       uint32_t u[3];

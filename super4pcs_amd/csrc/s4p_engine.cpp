@@ -123,6 +123,11 @@ struct s4p_matcher {
   bool grow_on_overflow = true;          // a lane whose base overflows grows its buffers and redoes the base (s4p_set_auto_grow)
   std::atomic<bool> select_failed{false}; std::string select_err;   // a device selection attempt returned an error (possibly on the selector thread)
   bool visit_candidates = false;         // issue the reference's per-candidate visitor calls (fraction == -1)
+  // Early exit (s4p_set_best_hint): inside the trial loops (Perform_N_steps, the sharded loop) the device may abandon
+  // candidates that cannot exceed the best inlier count committed so far -- the reference's Verify early exit,
+  // match4pcsBase.cc:520,558-560.  Never while a per-candidate visitor listens, never for the stage-level calls.
+  bool early_exit = true;                // s4p_matcher_set_early_exit / S4P_EARLY_EXIT=0
+  bool in_loop = false;                  // a trial loop is running: commits refresh the hint
   // pipelined trials: bases whose device pass is in flight (at most two)
   struct Prepared {
     bool found = false, device = false;
@@ -580,6 +585,7 @@ bool commit_base(s4p_matcher* m, bool found, const int ids[4], const s4p_base_re
       m->best_lcp = lcp; m->best_count = r.best_count;
       std::memcpy(m->transform, r.best_transform, sizeof(float) * 16);
       for (int k = 0; k < 3; ++k) { m->qc1[k] = r.centroid1[k]; m->qc2[k] = r.best_centroid2[k]; }
+      if (m->in_loop) (void)s4p_set_best_hint(m->ctx, m->best_count);          // bases launched from now on may abandon what cannot beat this
     }
   }
   return m->best_lcp > m->opt.terminate_threshold;               // :496
@@ -828,6 +834,22 @@ int32_t s4p_matcher_grow_on_overflow(s4p_matcher* m, int32_t enable) {
 
 int32_t s4p_matcher_capacity_growths(const s4p_matcher* m) { return m ? int32_t(s4p_lane_growths(m->ctx)) : 0; }
 
+// Trial loops call this around themselves: inside, every commit refreshes the device's best-count hint.
+static void loop_hint(s4p_matcher* m, bool enter) {
+  static const bool env_off = std::getenv("S4P_EARLY_EXIT") && std::atoi(std::getenv("S4P_EARLY_EXIT")) == 0;
+  m->in_loop = enter && m->early_exit && !env_off && !m->visit_candidates;
+  (void)s4p_set_best_hint(m->ctx, m->in_loop ? m->best_count : 0u);
+}
+
+int32_t s4p_matcher_set_early_exit(s4p_matcher* m, int32_t enable) {
+  if (!m) return S4P_ERR_BAD_ARG;
+  m->early_exit = enable != 0;
+  return S4P_OK;
+}
+// (the sharded loop of s4p_shard.cpp brackets its windows with these)
+int32_t s4p_matcher_loop_begin(s4p_matcher* m) { if (!m) return S4P_ERR_BAD_ARG; loop_hint(m, true); return S4P_OK; }
+int32_t s4p_matcher_loop_end(s4p_matcher* m) { if (!m) return S4P_ERR_BAD_ARG; loop_hint(m, false); return S4P_OK; }
+
 int32_t s4p_matcher_visit_candidates(s4p_matcher* m, int32_t enable) {
   if (!m) return S4P_ERR_BAD_ARG;
   m->visit_candidates = enable != 0;
@@ -921,6 +943,7 @@ int32_t s4p_matcher_perform_n_steps(s4p_matcher* m, int32_t n, s4p_visitor_fn vi
   int next_prep = m->current_trial;
   std::vector<s4p_matcher::Prepared>& fifo = m->inflight;
   drain_inflight(m);                       // leftovers of next_base_async calls the caller never waited for
+  loop_hint(m, true);
   int32_t rc = S4P_OK;
   for (int i = m->current_trial; i < end && rc == S4P_OK; ++i) {
     while (int(fifo.size()) < s4p_pipeline_depth(m->ctx) && next_prep < end) {
@@ -963,6 +986,7 @@ int32_t s4p_matcher_perform_n_steps(s4p_matcher* m, int32_t n, s4p_visitor_fn vi
   }
   // drain speculative work and put the host state back where the sequential loop stopped
   rewind_speculation(m);
+  loop_hint(m, false);
   if (rc != S4P_OK) return rc;
   m->current_trial += n;
   *improved = m->best_lcp > last_best ? 1 : 0;

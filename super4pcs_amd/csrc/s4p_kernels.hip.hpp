@@ -72,6 +72,7 @@ struct DevCounters {
   unsigned long long point_tests;   // optional instrumentation (COUNT kernels only)
   unsigned long long l0_pass, l1_pass, l2_pass;
   uint32_t done;                    // k_verify: workgroups that have published their best (last one selects the winner)
+  uint32_t pruned;                  // k_verify: candidates abandoned because they could not beat VerifyParams::prune
   // winner record
   int32_t best_quad[4];
   float best_T[16];
@@ -110,10 +111,11 @@ struct LcpGrid {
 // The exact stage takes 128 queued queries at a time, two per lane, so that two point lists are in flight per lane (every
 // batch runs for as many dependent steps as its longest list; two lists per lane halve the steps per query: round 2,
 // k_verify 0.161 -> 0.151 ms alone); the sweep takes two chunks per step so that the queue fits the LDS budget.
-constexpr int kQueueEntries = 256;                // per-wave survivor queue: 127 left over + one step of 2 x 64 entries
+constexpr int kQueueEntries = 384;                // per-wave survivor queue: up to 256 waiting + one step of 2 x 64 entries
+constexpr uint32_t kQueueHold = 256;              // an exact batch only runs once more than this many wait (or the sweep is over)
 constexpr int kQueueWordsPerWave = kQueueEntries + kQueueEntries / 2;     // 32-bit rank + 16-bit query index per entry: 1920 B
 constexpr int kCoarseMaxWords = 9216;              // 36 KB (two k_verify workgroups per CU share 160 KB: 80 KB each)
-constexpr int kVerifyLdsBudget = 80 * 1024 - 768;  // per workgroup: coarse bitmap + 16 queues (30 KB) [+ quantised queries]
+constexpr int kVerifyLdsBudget = 80 * 1024 - 768;  // per workgroup: coarse bitmap + survivor queues (2.25 KB per wave) [+ quantised queries]
 
 // value held by every lane of the wave -> SGPR
 __device__ __forceinline__ float wave_uniform(float v) {
@@ -416,6 +418,13 @@ struct LcpTask {                 // what the scoring loop needs besides the grid
   const float4* T;               // candidate transforms: row-major 3x4 at T + t_stride * candidate
   uint32_t t_stride;             // in float4: 3 (cand_T records) or 4 (caller's 4x4 matrices)
   unsigned long long* point_tests;   // instrumentation (COUNT kernels only)
+  // A candidate whose inlier count cannot EXCEED `prune` (the best count of the registration when the base was launched)
+  // cannot become the best (match4pcsBase.hpp:468: strictly greater wins) and may be abandoned -- what the reference's
+  // Verify does sequentially (match4pcsBase.cc:520,558-560), here with the stronger bound "confirmed inliers + queries
+  // still waiting for their exact test + queries not swept yet".  Its reported count is then a lower bound (as the
+  // reference's is for every candidate it abandons).  0 = every candidate is counted in full.
+  uint32_t prune;
+  uint32_t* pruned;                  // (k_verify) per-workgroup LDS counter of abandoned candidates, or nullptr
 };
 
 // The locating transform of a candidate: grid units, and for QLDS folded with the de-quantisation
@@ -482,7 +491,7 @@ __device__ __forceinline__ bool group_hit(const float4 X, const float4 Y, const 
   return (s0.x <= sq_eps) | (s0.y <= sq_eps) | (s1.x <= sq_eps) | (s1.y <= sq_eps);
 }
 // Exact stage for up to 128 queue entries, two per lane (A, B): both lists advance together, one group (four points) of
-// each per dependent step, six 16-byte loads in flight per lane.  Returns the number of inliers among this lane's two queries.
+// each per dependent step, six 16-byte loads in flight per lane.  Returns which of this lane's two queries are inliers.
 template <bool COUNT>
 __device__ __forceinline__ uint32_t exact_pair(const LcpGrid& g, const LcpTask& K, const float4* Tsrc,
                                                const bool validA, const uint32_t iA, const uint32_t rankA,
@@ -499,10 +508,10 @@ __device__ __forceinline__ uint32_t exact_pair(const LcpGrid& g, const LcpTask& 
     const float4 bx = g.nbr[ib], by = g.nbr[ib + 1u], bz = g.nbr[ib + 2u];
     const bool ha = la && group_hit(ax, ay, az, A.tx, A.ty, A.tz, g.sq_eps);
     const bool hb = lb && group_hit(bx, by, bz, B.tx, B.ty, B.tz, g.sq_eps);
-    if (ha) { ++hits; A.p = A.e; } else if (la) A.p += 1u;
-    if (hb) { ++hits; B.p = B.e; } else if (lb) B.p += 1u;
+    if (ha) { hits |= 1u; A.p = A.e; } else if (la) A.p += 1u;
+    if (hb) { hits |= 2u; B.p = B.e; } else if (lb) B.p += 1u;
   }
-  return hits;
+  return hits;                                           // bit 0: this lane's first query is an inlier, bit 1: its second
 }
 
 // Number of sampled-Q points the candidate at Tsrc brings within delta of a sampled-P point, for one wave64.
@@ -553,6 +562,7 @@ __device__ __forceinline__ uint32_t wave_lcp_count(const LcpGrid& g, const LcpTa
     qn += uint32_t(__popcll(m));
   };
   const uint32_t last = K.n_q - 1u;
+  bool abandoned = false;
   for (uint32_t base = 0;; base += 128u) {
     const bool more = base < K.n_q;                      // wave-uniform
     if (more) {                                          // one step: two chunks
@@ -564,22 +574,29 @@ __device__ __forceinline__ uint32_t wave_lcp_count(const LcpGrid& g, const LcpTa
       const uint2 w1 = g.reach[c1 == kNone ? 0u : c1 >> 5];
       push(c0, w0, i0); push(c1, w1, i1);
       lds_fence();
+      // upper bound of what this candidate can still reach: confirmed + waiting + not swept yet (all wave-uniform)
+      const uint32_t swept = min(base + 128u, K.n_q);
+      if (cnt + qn + (K.n_q - swept) <= K.prune) { abandoned = true; break; }
     }
-    // exact stage, ONE code site: 128 entries at a time (the queue holds 127 + 2 * 64), the rest after the last step
-    while (qn >= 128u || (!more && qn != 0u)) {
+    // exact stage, ONE code site: 128 entries at a time once more than kQueueHold wait (the queue then still takes a
+    // sweep step), the rest after the last step -- unless the waiting entries can no longer lift the candidate above the bound
+    while (qn > kQueueHold || (!more && qn != 0u)) {
+      if (!more && cnt + qn <= K.prune) { abandoned = true; break; }
       const uint32_t n = min(qn, 128u);
       const bool va = lane < n, vb = lane + 64u < n;
       const uint32_t aa = qn - n + min(lane, n - 1u), ab = qn - n + min(lane + 64u, n - 1u);
-      if (!SKIP_FINE) cnt += exact_pair<COUNT>(g, K, Tsrc, va, uint32_t(q_idx[aa]), q_rank[aa], vb, uint32_t(q_idx[ab]), q_rank[ab]);
+      if (!SKIP_FINE) {
+        const uint32_t h = exact_pair<COUNT>(g, K, Tsrc, va, uint32_t(q_idx[aa]), q_rank[aa], vb, uint32_t(q_idx[ab]), q_rank[ab]);
+        cnt += uint32_t(__popcll(__ballot((h & 1u) != 0u))) + uint32_t(__popcll(__ballot((h & 2u) != 0u)));
+      }
       qn -= n;
       lds_fence();
     }
-    if (!more) break;
+    if (!more || abandoned) break;
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+  if (abandoned && K.prune != 0u && K.pruned != nullptr && lane == 0) atomicAdd(K.pruned, 1u);
   __builtin_amdgcn_wave_barrier();
-  return cnt;
+  return cnt;                                            // wave-uniform
 }
 
 // Global -> LDS copy of the quantised queries (8 B each), padded to a multiple of 128 with the last entry
@@ -1413,6 +1430,7 @@ struct VerifyParams {
   DevCounters* res;                                     // result record of the base (copied to the host)
   uint4* slots;                                         // per workgroup: {best count, its candidate, tag lo, tag hi}
   uint32_t* border;                                     // candidates (positions in cand_idx) with an undecided gate, kBorderCap entries
+  uint32_t prune;                                       // best inlier count of the registration at launch (LcpTask::prune), 0 = count every candidate in full
   int count_tests;                                      // instrumentation counters are live: carry them into res
   int ablate;                                           // S4P_ABLATE debugging only (0 = full kernel)
 };
@@ -1428,7 +1446,7 @@ __global__ __launch_bounds__(kVerifyMaxThreads, 6) void k_verify(VerifyParams P)
   uint32_t* s_coarse = s_mem;                              // LDS: coarse bitmap | quantised queries (QLDS) | 16 survivor queues
   uint2* s_q = reinterpret_cast<uint2*>(s_mem + P.grid.coarse_words);
   uint32_t* s_queue = reinterpret_cast<uint32_t*>(s_q + (QLDS ? ((P.n_q + 127u) & ~127u) : 0u)) + (threadIdx.x >> 6) * kQueueWordsPerWave;
-  __shared__ uint32_t s_next, s_last;
+  __shared__ uint32_t s_next, s_last, s_pruned;
   __shared__ uint32_t s_wcnt[kVerifyMaxThreads / 64], s_wcand[kVerifyMaxThreads / 64];
   __shared__ unsigned long long s_wtag[kVerifyMaxThreads / 64];
   const uint32_t C = P.ctr->C;
@@ -1444,9 +1462,10 @@ __global__ __launch_bounds__(kVerifyMaxThreads, 6) void k_verify(VerifyParams P)
   const uint32_t lo = 0u, hi = blockIdx.x < C ? (C - blockIdx.x + gridDim.x - 1u) / gridDim.x : 0u;
   uint32_t bc = 0, bi = kNil; unsigned long long bt = ~0ull;                // this wave's / thread's best
   if (lo < hi && P.ablate != 2) {                          // (uniform) otherwise: more workgroups than candidates
-    if (threadIdx.x == 0) s_next = lo;
+    if (threadIdx.x == 0) { s_next = lo; s_pruned = 0u; }
     LcpTask K;
     K.q4 = P.q4v; K.n_q = P.n_q; K.qq = P.qq; K.T = P.cand_T; K.t_stride = 3u; K.point_tests = &P.ctr->point_tests;
+    K.prune = P.prune; K.pruned = &s_pruned;
     if (QLDS) stage_queries(K, s_q);
     stage_coarse(P.grid, s_coarse);                        // ends with a workgroup barrier
     while (true) {
@@ -1489,6 +1508,7 @@ __global__ __launch_bounds__(kVerifyMaxThreads, 6) void k_verify(VerifyParams P)
   };
   block_reduce(false);                                     // (the wave's best is uniform over its lanes)
   if (threadIdx.x == 0) {
+    if (lo < hi && P.ablate != 2 && s_pruned) atomicAdd(&P.ctr->pruned, s_pruned);
     P.slots[blockIdx.x] = make_uint4(bc, bi, uint32_t(bt), uint32_t(bt >> 32));
     __threadfence();                                       // release (agent scope): the slot is visible before the ticket
     const uint32_t ticket = atomicAdd(&P.ctr->done, 1u);
@@ -1509,7 +1529,7 @@ __global__ __launch_bounds__(kVerifyMaxThreads, 6) void k_verify(VerifyParams P)
   DevCounters* c = P.ctr;
   DevCounters* r = P.res;
   r->m1 = c->m1; r->m2 = c->m2; r->K = c->K; r->C = C; r->overflow = c->overflow;
-  r->quad_sum = c->quad_sum; r->cand_sum = c->cand_sum; r->n_border = c->n_border;
+  r->quad_sum = c->quad_sum; r->cand_sum = c->cand_sum; r->n_border = c->n_border; r->pruned = c->pruned;
   r->best_count = bc; r->best_tag = bt; r->has_best = 0u;
   if (COUNT || P.count_tests) { r->point_tests = c->point_tests; r->l0_pass = c->l0_pass; r->l1_pass = c->l1_pass; r->l2_pass = c->l2_pass; }
   if (bi != kNil) {                                        // recompute the winner's 4x4 (ComputeRigidTransformation)
@@ -1527,7 +1547,7 @@ __global__ __launch_bounds__(kVerifyMaxThreads, 6) void k_verify(VerifyParams P)
   }
   // the live counters are ready for the next base on this lane (no separate reset launch)
   c->m1 = 0; c->m2 = 0; c->K = 0; c->C = 0; c->best_count = 0; c->overflow = 0; c->best_tag = ~0ull; c->has_best = 0;
-  c->quad_sum = 0; c->cand_sum = 0; c->n_border = 0;
+  c->quad_sum = 0; c->cand_sum = 0; c->n_border = 0; c->pruned = 0;
   c->point_tests = 0; c->l0_pass = 0; c->l1_pass = 0; c->l2_pass = 0;
   __threadfence();
   c->done = 0;
@@ -1547,6 +1567,7 @@ __global__ __launch_bounds__(kVerifyMaxThreads) void k_verify_T(VerifyTParams P)
   LcpTask K;
   K.q4 = P.q4; K.n_q = P.n_q; K.qq = P.qq; K.T = reinterpret_cast<const float4*>(P.T); K.t_stride = 4u;
   K.point_tests = COUNT ? &P.ctr->point_tests : nullptr;
+  K.prune = 0u; K.pruned = nullptr;                        // explicit transforms are always counted in full
   if (QLDS) stage_queries(K, s_q);
   stage_coarse(P.grid, s_coarse);
   const uint32_t lane = threadIdx.x & 63u;
@@ -1709,7 +1730,7 @@ __global__ void k_selftest(const float* a, const float* b, uint64_t n, float* o_
 // leaves them cleared for the next base of the lane.
 __global__ void k_reset_counters(DevCounters* c) {
   c->m1 = 0; c->m2 = 0; c->K = 0; c->C = 0; c->best_count = 0; c->overflow = 0;
-  c->best_tag = ~0ull; c->has_best = 0; c->done = 0; c->quad_sum = 0; c->cand_sum = 0; c->n_border = 0;
+  c->best_tag = ~0ull; c->has_best = 0; c->done = 0; c->quad_sum = 0; c->cand_sum = 0; c->n_border = 0; c->pruned = 0;
   c->point_tests = 0; c->l0_pass = 0; c->l1_pass = 0; c->l2_pass = 0;
 }
 

@@ -390,7 +390,9 @@ int32_t s4p_shard_run_windows(s4p_shard* s, int32_t n_windows, uint64_t* candida
     return rc;
   };
   const uint64_t before = L.local_candidates;
+  (void)s4p_matcher_loop_begin(m);                          // commits refresh the device's best-count hint (early exit)
   const int32_t rc = L.run(n_windows);
+  (void)s4p_matcher_loop_end(m);
   if (rc && s->err.empty()) s->err = L.err;
   if (candidates_local) *candidates_local = L.local_candidates - before;
   if (terminated) *terminated = L.terminated ? 1 : 0;

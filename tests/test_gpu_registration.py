@@ -472,3 +472,44 @@ def test_chunked_bases_equal_the_unbounded_registration(oracle_mod, s4p_lib_buil
     with pytest.raises(capi.S4PError) as e:
         strict.compute_transformation(P, Q)
     assert e.value.code == capi.S4P_ERR_CAPACITY
+
+
+def test_early_exit_changes_no_result(oracle_mod, s4p_lib_built):
+    """The trial loops let the device abandon candidates that can no longer EXCEED the best inlier count so far (the reference's
+    Verify early exit, match4pcsBase.cc:520,558-560).  With it on (the default) and off: same best LCP, winner, transform and
+    number of verified candidates as the oracle -- and it really prunes.  Outside a loop (try_one_base) counts stay full."""
+    from super4pcs_amd import capi
+    O = oracle_mod
+    delta, overlap, n_s = 0.01, 0.6, 300
+    P, Q, _ = H.small_pair(20000, delta=delta, seed=5)
+    om = O.Matcher(O.make_options(delta, overlap, n_s), full_counts=False, use_kdtree=True)
+    o_lcp, o_M, _ = om.compute_transformation(P, Q)
+    res = {}
+    for on in (True, False):
+        gm = capi.Matcher(capi.make_options(delta, overlap, n_s))
+        gm.early_exit(on)
+        gm.profile_enable(True, False)
+        lcp, M, _ = gm.compute_transformation(P, Q)
+        i = gm.info()
+        res[on] = (lcp, M.tobytes(), tuple(i.base), tuple(i.congruent), i.candidates_verified, i.quads_total)
+        pruned = gm.profile_get().verify_pruned
+        assert (pruned > 0.3 * i.candidates_verified) if on else (pruned == 0)
+        assert lcp == o_lcp and np.array_equal(M, o_M) and i.candidates_verified == om.stats().n_verified
+    assert res[True] == res[False]
+    # stage-level / single-base calls are never pruned: full per-candidate counts against the oracle
+    of = O.Matcher(O.make_options(delta, overlap, n_s), full_counts=True, use_kdtree=True)
+    of.init(P, Q)
+    gm = capi.Matcher(capi.make_options(delta, overlap, n_s))
+    gm.init_full(P, Q)
+    gm.perform_n_steps(3)                                    # a loop ran (and left): the hint must be gone afterwards
+    for _ in range(3):
+        of.try_one_base()
+    _ok, r = gm.try_one_base()
+    g_quads, g_counts = gm.last_candidates(r.n_quads)
+    ok, i1, i2, base, bx = of.select_quadrilateral()
+    assert ok
+    from bench import seg_len32
+    p1 = of.extract_pairs(seg_len32(bx[0], bx[1]), 0.0, 2 * delta, 0, 1); p2 = of.extract_pairs(seg_len32(bx[2], bx[3]), 0.0, 2 * delta, 2, 3)
+    quads = of.find_congruent(i1, i2, 2 * delta, p1, p2)
+    _nb, per, _bc, _bi = of.try_congruent_set(base, quads)
+    assert np.array_equal(quads, g_quads) and np.array_equal(per, g_counts)
