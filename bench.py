@@ -282,8 +282,8 @@ def cpu_baseline(P, Q, budget_s, sample, ttr_candidates):
     else:
         a = port_run(1, budget_s)
     a["host_cores"] = nproc
-    a["note"] = ("the GPU scores every candidate over all n_Q points (no early exit); the CPU loops stop a candidate as soon as it "
-                 "cannot beat the running best (match4pcsBase.cc:558-560), so work per candidate differs: a reported baseline")
+    a["note"] = ("CPU and GPU both abandon a candidate that cannot beat the best LCP so far (match4pcsBase.cc:558-560; the GPU with an "
+                 "order-independent bound against the best at launch time, config.early_exit): a reported baseline, not a target")
     b = port_run(nproc, max(budget_s * 0.6, 3.0))
     b["label"] = "candidate loop only under OpenMP (pairs and quads serial, as in the reference)"
     a["openmp_all_cores"] = b
@@ -622,11 +622,11 @@ def main():
         mf.close()
 
     # the byte model's inputs, measured on the TIMED bases: a fresh matcher runs the W warm-up bases, then the K timed bases
-    # again through the instrumented kernel (slower; untimed)
-    f_l0 = f_l1 = f_l2 = kbar = 0.0
-    groups_per_query = 0.0
-    if world == 1 and not scale_mode:
+    # again through the instrumented kernel (slower; untimed) -- in the default mode (early exit: the structure walk the timed
+    # kernel really does) and with every candidate counted in full
+    def instrumented(early_exit):
         mi = capi.Matcher(opt, device=local_rank, max_pairs=(32 << 20) if scale_mode else MAX_PAIRS, max_quads=(32 << 20) if scale_mode else MAX_QUADS)
+        mi.early_exit(early_exit)
         mi.init_full(P, Q)
         shi = sharding.ShardedRansac(mi, 0, 1, None, dev)
         shi.run_windows(args.warmup)
@@ -636,10 +636,19 @@ def main():
         shi.run_windows(args.steps)
         pk = mi.profile_get(reset=True)
         queries = max((mi.info().candidates_verified - q_before) * n_q, 1)
-        kbar = pk.verify_point_tests / queries
-        f_l0, f_l1, f_l2 = pk.verify_l0_pass / queries, pk.verify_l1_pass / queries, pk.verify_l2_pass / queries
-        groups_per_query = kbar / 4.0 + 0.375 * f_l2        # listed points / 4, plus the part-filled last group of a list (mean 3/8 of a group)
         mi.close()
+        kb = pk.verify_point_tests / queries
+        fr = (pk.verify_l0_pass / queries, pk.verify_l1_pass / queries, pk.verify_l2_pass / queries)
+        return kb, fr, kb / 4.0 + 0.375 * fr[2]     # listed points / 4, plus the part-filled last group of a list (mean 3/8 of a group)
+
+    f_l0 = f_l1 = f_l2 = kbar = 0.0
+    groups_per_query = 0.0
+    full_walk = None
+    if world == 1 and not scale_mode:
+        kbar, (f_l0, f_l1, f_l2), groups_per_query = instrumented(True)
+        kb_f, fr_f, gq_f = instrumented(False)
+        full_walk = {"kbar": kb_f, "pass_fractions": {"coarse_bitmap_L0": fr_f[0], "reach_bit_L1": fr_f[1], "subcell_mask_L2": fr_f[2]},
+                     "groups_per_query": gq_f, "bytes_per_candidate": structure_bytes_per_candidate(n_q, fr_f[0], fr_f[1], fr_f[2], gq_f)[1]}
 
     # time-to-register (the metric's second half): one whole ComputeTransformation on the same pair, wall time from
     # call to return with inputs in host memory (sampling of both 1 M-point clouds, grid build, upload, all trials,
@@ -841,8 +850,10 @@ def main():
                        "parallelism": "bases sharded over %d GPU(s), one 8-byte all-reduce(max) per window" % world,
                        "collective": collective["kind"],
                        "early_exit": {"on": True, "candidates_abandoned": int(prof.verify_pruned), "fraction": prof.verify_pruned / max(cand_all, 1),
-                                      "note": "candidates that can no longer EXCEED the registration's best inlier count are abandoned, as the reference's "
-                                              "Verify does (match4pcsBase.cc:520,558-560); they count as verified there and here; results identical"},
+                                      "exact_point_tests_per_query": kbar, "exact_point_tests_per_query_full_counts": None if full_walk is None else full_walk["kbar"],
+                                      "note": "candidates that can no longer EXCEED the registration's best inlier count are abandoned (every candidate that "
+                                              "does not become the new best ends that way, most of them before their exact stage), as the reference's Verify "
+                                              "does (match4pcsBase.cc:520,558-560); they count as verified there and here; results identical"},
                        "full_count_mode": full_mode,
                        "chunked_bases": chunk_stats, "lane_growths": lane_growths,
                        "time_to_register": ttr},
@@ -857,12 +868,17 @@ def main():
                 "algorithmic_bytes_per_candidate": gather_b,
                 "definition": "achieved = gather bytes the three-level structure requires per candidate (8 B reach word per L0 survivor, 32 B header + "
                               "16 B query per L1 survivor, 48 B per group of four points a mask survivor walks, 64 B candidate record; fractions measured "
-                              "by an instrumented replay of the timed bases) x candidates of the timed bases / timed seconds: the per-step figure, "
+                              "by an instrumented replay of the timed bases IN THE TIMED MODE: with the early exit, queries a candidate never gets to are "
+                              "not counted) x candidates of the timed bases / timed seconds: the per-step figure, "
                               "independent of how many bases are in flight.  The working set (point lines ~19 MB) is Infinity-Cache resident, so this is "
                               "priced against a roof the kernel is NOT bound by -- `binding` names the resource closest to its roof.  DESIGN.md section 7.",
                 "binding": {"resource": binding, "fracs": fracs},
                 "valu": valu, "l2": l2,
                 "pass_fractions": {"coarse_bitmap_L0": f_l0, "reach_bit_L1": f_l1, "subcell_mask_L2": f_l2}, "kbar": kbar, "groups_per_query": groups_per_query,
+                "full_count_mode": None if (full_walk is None or full_mode is None) else dict(
+                    full_walk, achieved=full_mode["value"] * full_walk["bytes_per_candidate"] / 1e9,
+                    frac=full_mode["value"] * full_walk["bytes_per_candidate"] / 1e9 / HBM_PEAK_GBS,
+                    note="the same figure with the early exit off: every candidate walks the structure for all n_Q queries (what rounds 1-2 reported)"),
                 "per_launch": {"avg_launch_ms": avg_ms, "launches": int(prof.verify_launches), "candidates_per_launch": cand_per_launch,
                                "achieved": cand_per_launch * gather_b / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0,
                                "note": "HIP-event duration of a launch in the default configuration: six bases in flight stretch every launch, so "

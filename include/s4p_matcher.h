@@ -195,6 +195,9 @@ const char* s4p_shard_last_error(const s4p_shard* s);
 /* ncclCommInitRank on `device` (the matcher's GPU); collective = ncclAllReduce(uint64, max) / ncclBroadcast on a private stream. */
 int32_t s4p_shard_use_rccl(s4p_shard* s, int32_t device, const uint8_t* unique_id128);
 int32_t s4p_shard_use_collective(s4p_shard* s, const s4p_collective* coll);
+/* Measurement aid: the shard plays one rank of its world alone (reduction = own key, broadcast = no-op), so that the
+ * per-window cost of a rank at a given world size can be measured on one GPU (tools/sim_world.py). */
+int32_t s4p_shard_use_null_collective(s4p_shard* s);
 /* n_windows windows (n_windows * world trials of the common sequence) through the pipelined loop; *candidates_local = candidates
  * this rank verified, *terminated = the terminate threshold was crossed (later windows are drained, not committed). */
 int32_t s4p_shard_run_windows(s4p_shard* s, int32_t n_windows, uint64_t* candidates_local, int32_t* terminated);

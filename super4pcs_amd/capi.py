@@ -339,7 +339,7 @@ class MatcherInfo(C.Structure):
 
 SHARD_SYMBOLS = [
     "s4p_rccl_unique_id", "s4p_shard_create", "s4p_shard_destroy", "s4p_shard_last_error", "s4p_shard_use_rccl",
-    "s4p_shard_use_collective", "s4p_shard_run_windows", "s4p_shard_compute_transformation", "s4p_shard_replay",
+    "s4p_shard_use_collective", "s4p_shard_use_null_collective", "s4p_shard_run_windows", "s4p_shard_compute_transformation", "s4p_shard_replay",
     "s4p_matcher_terminate_threshold", "s4p_matcher_max_time_seconds", "s4p_matcher_init_generation",
 ]
 MATCHER_SYMBOLS = [
@@ -742,6 +742,11 @@ class Shard:
     def use_rccl(self, device, unique_id):
         buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
         self._chk(self.L.s4p_shard_use_rccl(self.h, device, buf))
+
+    def use_null_collective(self):
+        self.L.s4p_shard_use_null_collective.restype = C.c_int32
+        self.L.s4p_shard_use_null_collective.argtypes = [C.c_void_p]
+        self._chk(self.L.s4p_shard_use_null_collective(self.h))
 
     def use_collective(self, coll):
         self._coll = coll                       # the callbacks must outlive the shard

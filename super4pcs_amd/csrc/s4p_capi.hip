@@ -407,7 +407,7 @@ int32_t launch_verify(s4p_ctx* c, const BaseFrame& bf) {
   V.grid = c->dev_grid(); V.q4 = c->q4.p; V.q4v = c->q4v.p; V.qq = c->qq; V.n_q = c->n_q; V.base = bf;
   V.quads = L.quads.p; V.tags = L.tags.p; V.counts = L.counts.p; V.cand_idx = L.cand_idx.p; V.cand_T = L.cand_T.p;
   V.ctr = L.ctr.p; V.res = L.ctr.p + 1; V.slots = L.slots.p; V.border = L.border.p; V.count_tests = c->prof_points ? 1 : 0;
-  V.prune = c->prof_points ? 0u : c->best_hint;            // (the instrumented kernel measures the full structure walk)
+  V.prune = c->best_hint;
   V.ablate = c->ablate;
   hipStream_t vs = L.stream;
   if (L.vstream) {                                           // CU partition: k_verify on the big partition, after the lane's small kernels

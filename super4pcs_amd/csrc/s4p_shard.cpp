@@ -125,6 +125,17 @@ struct CallbackCollective : Collective {                     // caller-supplied,
   }
 };
 
+// Measurement aid (tools/sim_world.py): this process plays ONE rank of a `world`-rank job on one GPU -- it selects and
+// stages every trial of every window and runs its own device passes, as a real rank does; the reduction returns its own
+// key and the broadcast is a no-op.  What it measures is the per-window cost of a rank, i.e. whether the replicated host
+// chain or the GPU pass bounds a rank at that world size.  Never a product path.
+struct NullCollective : Collective {
+  uint64_t val[3] = {0, 0, 0};
+  int32_t post(int slot, uint64_t key) override { val[slot] = key; return S4P_OK; }
+  int32_t result(int slot, uint64_t* key) override { *key = val[slot]; return S4P_OK; }
+  int32_t broadcast(void*, size_t, int) override { return S4P_OK; }
+};
+
 struct RcclCollective : Collective {                         // RCCL over xGMI, one communicator per matcher
   int device = 0, rank = 0, world = 1;
   ncclComm_t comm = nullptr;
@@ -343,6 +354,13 @@ int32_t s4p_shard_use_rccl(s4p_shard* s, int32_t device, const uint8_t* unique_i
   if (rc) { s->err = c->err; delete c; return rc; }
   delete s->coll;
   s->coll = c;
+  return S4P_OK;
+}
+
+int32_t s4p_shard_use_null_collective(s4p_shard* s) {
+  if (!s) return S4P_ERR_BAD_ARG;
+  delete s->coll;
+  s->coll = new NullCollective();
   return S4P_OK;
 }
 
