@@ -468,6 +468,8 @@ def main():
     ap.add_argument("--no-hbm-point", dest="hbm_point", action="store_false", default=True)
     ap.add_argument("--no-full-count-mode", dest="full_count_mode", action="store_false", default=True,
                     help="skip the extra timed region with the early exit off (config.full_count_mode)")
+    ap.add_argument("--no-instrumented", dest="instrumented", action="store_false", default=True,
+                    help="skip the instrumented replays of the timed bases (byte model = null): for a clean rocprofv3 kernel trace of the command")
     ap.add_argument("--no-exclusive", dest="exclusive", action="store_false", default=True,
                     help="skip the one-base-in-flight re-run (roofline.per_launch.exclusive)")
     ap.add_argument("--profile-dir", default=None, help="keep the k_verify rows of the rocprofv3 outputs here (e.g. profiles/r03_bench)")
@@ -644,7 +646,7 @@ def main():
     f_l0 = f_l1 = f_l2 = kbar = 0.0
     groups_per_query = 0.0
     full_walk = None
-    if world == 1 and not scale_mode:
+    if world == 1 and not scale_mode and args.instrumented:
         kbar, (f_l0, f_l1, f_l2), groups_per_query = instrumented(True)
         kb_f, fr_f, gq_f = instrumented(False)
         full_walk = {"kbar": kb_f, "pass_fractions": {"coarse_bitmap_L0": fr_f[0], "reach_bit_L1": fr_f[1], "subcell_mask_L2": fr_f[2]},

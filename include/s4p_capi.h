@@ -244,6 +244,14 @@ int32_t s4p_last_verified(s4p_ctx* ctx, uint32_t* counts, float* transforms16, i
  * May be called from a thread of its own while bases are in flight. */
 int32_t s4p_select_base_points(s4p_ctx* ctx, const uint32_t* draws, float limit_sq, float too_small,
                                int32_t* ids, float* xyz, int32_t* status);
+/* The same for n_attempts (<= s4p_select_batch_max()) CONSECUTIVE attempts of the random stream in one set of launches and
+ * one synchronisation: draws = n_attempts x 2001 indices, ids / xyz / status = one record per attempt.  The stream does
+ * not depend on results, so a driver can draw ahead; which attempt ends which trial is decided from the statuses, in
+ * order, exactly as the reference's loop would (a failed attempt is followed by the next one; match4pcsBase.cc:283-349).
+ * At n_P = 4.2 M one attempt costs ~130 us of launches and synchronisation; eight attempts per call cost little more. */
+int32_t s4p_select_base_points_batch(s4p_ctx* ctx, const uint32_t* draws, int32_t n_attempts, float limit_sq, float too_small,
+                                     int32_t* ids, float* xyz, int32_t* status);
+int32_t s4p_select_batch_max(void);
 
 /* ---- final apply: Match4PCSBase::Perform_N_steps tail (match4pcsBase.hpp:265-267) */
 /* xyz SoA in place: p <- (M * [p;1]).head<3>() for n points. */

@@ -90,14 +90,14 @@ struct s4p_ctx {
   // per-base buffers sized by the limits (pairs: 11 arrays, quads: 5, the cell hash): allocated as a set, so that a
   // growth can build the new set first and swap it in only when every allocation of every lane has succeeded
   struct LaneBufs {
-    DevBuf<int2> ab1, ab2; DevBuf<uint32_t> okey1, okey2, cell1, cell2, bucket1, next1, mask2; DevBuf<float4> ew1, ew2;
+    DevBuf<int2> ab1, ab2; DevBuf<uint32_t> okey1, okey2, cell1, bucket1, next1; DevBuf<float4> ew1;
     DevBuf<int4> quads; DevBuf<unsigned long long> tags; DevBuf<uint32_t> counts, cand_idx; DevBuf<float4> cand_T;
     DevBuf<unsigned long long> ht_keys, ht_heads; uint32_t ht_mask = 0, epoch = 0;
     uint64_t cap_pairs = 0, cap_quads = 0;    // entries these buffers hold (a lane whose base needed more has grown on its own)
     void free_all() {
       cap_pairs = cap_quads = 0;
-      ab1.free(); ab2.free(); okey1.free(); okey2.free(); cell1.free(); cell2.free(); bucket1.free(); next1.free(); mask2.free();
-      ew1.free(); ew2.free(); quads.free(); tags.free(); counts.free(); cand_idx.free(); cand_T.free(); ht_keys.free(); ht_heads.free();
+      ab1.free(); ab2.free(); okey1.free(); okey2.free(); cell1.free(); bucket1.free(); next1.free();
+      ew1.free(); quads.free(); tags.free(); counts.free(); cand_idx.free(); cand_T.free(); ht_keys.free(); ht_heads.free();
     }
   };
   struct Lane : LaneBufs {
@@ -171,7 +171,7 @@ struct s4p_ctx {
   hipEvent_t ev[kMaxLanes][6] = {};
   s4p_profile prof{};
   uint64_t last_K = 0;
-  uint32_t verify_blocks = 512;
+  uint32_t verify_blocks = 256; bool verify_blocks_fixed = false;   // per set_clouds (see there); S4P_VERIFY_BLOCKS fixes it
   int verify_threads = kVerifyThreadsCached;      // per set_clouds: kVerifyMaxThreads when the point lists exceed the Infinity Cache; S4P_VERIFY_THREADS overrides
   int ablate = 0;                    // S4P_ABLATE (profiling aid, read once at creation)
   // A/B aid: S4P_FUSE_GATE=0 runs the rigid transform + rms gate as a k_gate launch instead of
@@ -337,7 +337,7 @@ BaseFrame make_base_frame(const s4p_ctx* c, const int32_t* base_ids) {
 
 // Parameters of FindCongruentQuadrilaterals for the lane's current base: a fresh hash epoch, the per-set preparation
 // records (consumed by k_pairs on the fused path, by k_prep otherwise) and the enumeration record.
-int32_t quad_params(s4p_ctx* c, float inv1, float inv2, float thr2, PrepParams& P1, PrepParams& P2, QuadParams& Q) {
+int32_t quad_params(s4p_ctx* c, float inv1, float inv2, float thr2, PrepParams& P1, QuadParams& Q) {
   s4p_ctx::Lane& L = c->lane[c->cur];
   QuadGrid qg; ConeTable cone;
   quad_setup(c, thr2, qg, cone);
@@ -352,16 +352,12 @@ int32_t quad_params(s4p_ctx* c, float inv1, float inv2, float thr2, PrepParams& 
   P1 = PrepParams{};
   P1.ux = c->ux.p; P1.uy = c->uy.p; P1.uz = c->uz.p; P1.qx = c->qx.p; P1.qy = c->qy.p; P1.qz = c->qz.p;
   P1.ab = L.ab1.p; P1.m_dev = &L.ctr.p->m1; P1.cap = uint32_t(L.cap_pairs); P1.invariant = inv1; P1.qg = qg;
-  P1.cell = L.cell1.p; P1.bucket = L.bucket1.p; P1.ew = L.ew1.p; P1.next = L.next1.p; P1.mask = nullptr; P1.ht = ht;
-  P1.cone.nb = 0;
-  P2 = PrepParams{};
-  P2.ux = c->ux.p; P2.uy = c->uy.p; P2.uz = c->uz.p; P2.qx = c->qx.p; P2.qy = c->qy.p; P2.qz = c->qz.p;
-  P2.ab = L.ab2.p; P2.m_dev = &L.ctr.p->m2; P2.cap = uint32_t(L.cap_pairs); P2.invariant = inv2; P2.qg = qg;
-  P2.cell = L.cell2.p; P2.bucket = nullptr; P2.ew = L.ew2.p; P2.next = nullptr; P2.mask = L.mask2.p; P2.ht = ht;
-  P2.cone = cone;
+  P1.cell = L.cell1.p; P1.bucket = L.bucket1.p; P1.ew = L.ew1.p; P1.next = L.next1.p; P1.ht = ht;
   Q = QuadParams{};
   Q.ab1 = L.ab1.p; Q.okey1 = L.okey1.p; Q.bucket1 = L.bucket1.p; Q.ew1 = L.ew1.p; Q.next1 = L.next1.p;
-  Q.ab2 = L.ab2.p; Q.okey2 = L.okey2.p; Q.cell2 = L.cell2.p; Q.ew2 = L.ew2.p; Q.mask2 = L.mask2.p;
+  Q.ab2 = L.ab2.p; Q.okey2 = L.okey2.p;
+  Q.ux = c->ux.p; Q.uy = c->uy.p; Q.uz = c->uz.p; Q.qx = c->qx.p; Q.qy = c->qy.p; Q.qz = c->qz.p;
+  Q.invariant2 = inv2; Q.qg = qg; Q.cone = cone;
   Q.m2_dev = &L.ctr.p->m2; Q.cap2 = uint32_t(L.cap_pairs); Q.ht = ht; Q.thr = thr2;
   Q.quads = L.quads.p; Q.tags = L.tags.p; Q.K_dev = &L.ctr.p->K; Q.K_cap = uint32_t(L.cap_quads); Q.overflow = &L.ctr.p->overflow;
   Q.r0 = 0u; Q.r1 = 0xFFFFFFFFu; Q.qsum_dev = &L.ctr.p->quad_sum; Q.csum_dev = &L.ctr.p->cand_sum;
@@ -376,14 +372,8 @@ GateParams gate_params(s4p_ctx* c, const BaseFrame& bf) {
   return G;
 }
 
-void launch_prep_kernel(s4p_ctx* c, const PrepParams& P1, const PrepParams& P2) {
-  static const bool split = getenv("S4P_PREP_SPLIT") != nullptr;       // profiling aid: one launch per set, so a kernel trace times them apart
-  if (split) {
-    hipLaunchKernelGGL(k_prep, dim3(1024, 1), dim3(256), 0, c->lane[c->cur].stream, P1, P2, 0);
-    hipLaunchKernelGGL(k_prep, dim3(1024, 1), dim3(256), 0, c->lane[c->cur].stream, P1, P2, 1);
-  } else {
-    hipLaunchKernelGGL(k_prep, dim3(1024, 2), dim3(256), 0, c->lane[c->cur].stream, P1, P2, 0);
-  }
+void launch_prep_kernel(s4p_ctx* c, const PrepParams& P1) {
+  hipLaunchKernelGGL(k_prep, dim3(1024), dim3(256), 0, c->lane[c->cur].stream, P1);      // set 1: hash build (set 2 is prepared inside k_quads)
 }
 void launch_quads_kernel(s4p_ctx* c, const QuadParams& Q) {
   // one set-2 entry per thread in ONE pass for up to 512 k entries (a second grid-stride pass doubles the chain of
@@ -688,15 +678,15 @@ int32_t launch_base(s4p_ctx* c, int32_t slot, const int32_t* base_ids, float inv
   if (L.dirty) { if (int32_t rc = reset_counters(c)) return rc; }
   const float eps = 2.0f * c->opt.delta;
   const BaseFrame bf = make_base_frame(c, base_ids);
-  PrepParams P1, P2; QuadParams Q;
-  if (int32_t rc = quad_params(c, inv1, inv2, eps, P1, P2, Q)) return rc;
+  PrepParams P1; QuadParams Q;
+  if (int32_t rc = quad_params(c, inv1, inv2, eps, P1, Q)) return rc;
   if (c->prof_events) HIPCHK(c, hipEventRecord(c->ev[c->cur][2], L.stream));
   { PairParams2 PP{};
     if (int32_t rc = upload_pairs_staged(c, slot, 0, eps, 0, 1, PP.set[0].pair)) return rc;
     if (int32_t rc = upload_pairs_staged(c, slot, 1, eps, 2, 3, PP.set[1].pair)) return rc;
     if (int32_t rc = launch_pairs_kernel(c, PP, 2)) return rc; }
   if (c->prof_events) HIPCHK(c, hipEventRecord(c->ev[c->cur][3], L.stream));
-  launch_prep_kernel(c, P1, P2);
+  launch_prep_kernel(c, P1);
   if (c->fuse_gate) { Q.do_gate = 1; Q.gate = gate_params(c, bf); }
   c->slot_q[c->cur] = Q;                                  // (the chunk loop relaunches it range by range if the quads do not fit)
   launch_quads_kernel(c, Q);
@@ -727,8 +717,8 @@ hipError_t alloc_lane_buffers(uint64_t mp_, uint64_t mq_, s4p_ctx::LaneBufs& L, 
   const uint32_t hts = next_pow2(2 * mp);
   hipError_t e = hipSuccess;
 #define A(buf, cnt) if ((e = (buf).alloc(cnt)) != hipSuccess) { *what = "hipMalloc " #buf; return e; }
-  A(L.ab1, mp); A(L.ab2, mp); A(L.okey1, mp); A(L.okey2, mp); A(L.cell1, mp); A(L.cell2, mp);
-  A(L.bucket1, mp); A(L.next1, mp); A(L.mask2, mp * kMaskWords); A(L.ew1, mp); A(L.ew2, mp);
+  A(L.ab1, mp); A(L.ab2, mp); A(L.okey1, mp); A(L.okey2, mp); A(L.cell1, mp);
+  A(L.bucket1, mp); A(L.next1, mp); A(L.ew1, mp);
   A(L.quads, mq); A(L.tags, mq); A(L.counts, mq); A(L.cand_idx, mq); A(L.cand_T, mq * 3);
   A(L.ht_keys, hts); A(L.ht_heads, hts); L.ht_mask = hts - 1;
 #undef A
@@ -739,7 +729,7 @@ hipError_t alloc_lane_buffers(uint64_t mp_, uint64_t mq_, s4p_ctx::LaneBufs& L, 
   return hipSuccess;
 }
 size_t lane_bytes(uint64_t mp, uint64_t mq) {            // what alloc_lane_buffers takes per lane
-  return size_t(mp) * (8 + 8 + 4 * 6 + 4 * kMaskWords + 16 * 2) + size_t(mq) * (16 + 8 + 4 + 4 + 48) + size_t(next_pow2(2 * mp)) * 16;
+  return size_t(mp) * (8 + 8 + 4 * 5 + 16) + size_t(mq) * (16 + 8 + 4 + 4 + 48) + size_t(next_pow2(2 * mp)) * 16;
 }
 
 }  // namespace
@@ -774,7 +764,7 @@ int32_t s4p_create(const s4p_options* opt, const s4p_limits* lim, int32_t device
     c->ablate = atoi(ab);
     if (c->ablate) fprintf(stderr, "super4pcs_amd: S4P_ABLATE=%d is set: k_verify skips work, every result of this context is invalid\n", c->ablate);
   }
-  if (const char* vb = getenv("S4P_VERIFY_BLOCKS")) { const int v = atoi(vb); if (v >= 64 && v <= kVerifyMaxBlocks) c->verify_blocks = uint32_t(v); }   // tuning knob
+  if (const char* vb = getenv("S4P_VERIFY_BLOCKS")) { const int v = atoi(vb); if (v >= 64 && v <= kVerifyMaxBlocks) { c->verify_blocks = uint32_t(v); c->verify_blocks_fixed = true; } }   // tuning knob
   if (const char* fu = getenv("S4P_FUSE_GATE")) c->fuse_gate = atoi(fu) != 0;
   if (const char* cs = getenv("S4P_CU_SPLIT")) { const int v = atoi(cs); if (v >= 2 && v <= 64) c->cu_split = v; }
   if (const char* at = getenv("S4P_ANGLE_TOL")) { const float v = float(atof(at)); if (v > 1e-6f) c->angle_tol = v; }
@@ -810,7 +800,7 @@ int32_t s4p_create(const s4p_options* opt, const s4p_limits* lim, int32_t device
       if ((e = hipExtStreamCreateWithCUMask(&L.stream, uint32_t(small.size()), small.data())) != hipSuccess) return fail(e, "hipExtStreamCreateWithCUMask");
       if ((e = hipExtStreamCreateWithCUMask(&L.vstream, uint32_t(big.size()), big.data())) != hipSuccess) return fail(e, "hipExtStreamCreateWithCUMask");
       if ((e = hipEventCreateWithFlags(&L.chain, hipEventDisableTiming)) != hipSuccess) return fail(e, "hipEventCreate");
-      if (!getenv("S4P_VERIFY_BLOCKS")) c->verify_blocks = 2u * nbig;
+      if (!getenv("S4P_VERIFY_BLOCKS")) { c->verify_blocks = 2u * nbig; c->verify_blocks_fixed = true; }
     } else if ((e = hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
     A(L.ctr, 2); A(L.slots, kVerifyMaxBlocks); A(L.border, kBorderCap);
     if ((e = hipMemset(L.ctr.p, 0, 2 * sizeof(DevCounters))) != hipSuccess) return fail(e, "hipMemset");
@@ -832,8 +822,8 @@ int32_t s4p_create(const s4p_options* opt, const s4p_limits* lim, int32_t device
   }
   for (auto& row : c->ev) for (auto& ev : row) if ((e = hipEventCreate(&ev)) != hipSuccess) return fail(e, "hipEventCreate");
   if ((e = hipStreamCreateWithFlags(&c->sel_stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
-  if ((e = c->sel_draws.alloc(kSelectDraws)) != hipSuccess || (e = c->sel_rec.alloc(1)) != hipSuccess) return fail(e, "hipMalloc selection buffers");
-  if ((e = c->sel_hdraws.alloc(kSelectDraws)) != hipSuccess || (e = c->sel_hrec.alloc(1)) != hipSuccess) return fail(e, "hipHostMalloc selection buffers");
+  if ((e = c->sel_draws.alloc(size_t(kSelectDraws) * kSelectBatch)) != hipSuccess || (e = c->sel_rec.alloc(kSelectBatch)) != hipSuccess) return fail(e, "hipMalloc selection buffers");
+  if ((e = c->sel_hdraws.alloc(size_t(kSelectDraws) * kSelectBatch)) != hipSuccess || (e = c->sel_hrec.alloc(kSelectBatch)) != hipSuccess) return fail(e, "hipHostMalloc selection buffers");
   *out = c;
   return S4P_OK;
 }
@@ -1032,7 +1022,12 @@ int32_t s4p_set_clouds(s4p_ctx* c, const float* px, const float* py, const float
       { // k_verify block size: see kVerifyThreadsCached (s4p_kernels.hip.hpp)
         const char* vt = getenv("S4P_VERIFY_THREADS");
         const int v = vt ? atoi(vt) : 0;
-        c->verify_threads = (v >= 256 && v <= kVerifyMaxThreads && v % 64 == 0) ? v : kVerifyThreadsCached; }
+        c->verify_threads = (v >= 256 && v <= kVerifyMaxThreads && v % 64 == 0) ? v : kVerifyThreadsCached;
+        // k_verify workgroups: one per CU while the point lines stay in the Infinity Cache -- with the early exit the kernel is
+        // short and the other lanes' pair / quad kernels need CU slots next to it (measured 256 / 384 / 512 / 768 workgroups:
+        // 115.4 / 113.5 / 112.2 / 105.3 M candidates/s, profiles/r03_lanes_blocks_sweep.log); two per CU when the lines
+        // stream from HBM, where more waves in flight carry the bandwidth
+        if (!c->verify_blocks_fixed) c->verify_blocks = size_t(n_lines) * 128u > (size_t(192) << 20) ? 512u : 256u; }
       hipLaunchKernelGGL(k_lines_clear, dim3(2048), dim3(256), 0, st, c->gnbr.p, uint64_t(n_lines));
       hipLaunchKernelGGL(k_grid_hdr_pack, dim3(1024), dim3(256), 0, st, G, starts.p, hdr_count.p, n_reach);
       hipLaunchKernelGGL(k_grid_fill, dim3(2048), dim3(256), 0, st, G);
@@ -1190,9 +1185,9 @@ int32_t s4p_find_congruent(s4p_ctx* c, float inv1, float inv2, float /*thr1*/, f
   const uint32_t mm[2] = {uint32_t(m1), uint32_t(m2)};
   HIPCHK(c, hipMemcpyAsync(&c->lane[c->cur].ctr.p->m1, mm, 8, hipMemcpyHostToDevice, c->lane[c->cur].stream));
   c->lane[c->cur].dirty = true;
-  { PrepParams P1, P2; QuadParams Q;
-    if (int32_t rc = quad_params(c, inv1, inv2, thr2, P1, P2, Q)) return rc;
-    launch_prep_kernel(c, P1, P2);
+  { PrepParams P1; QuadParams Q;
+    if (int32_t rc = quad_params(c, inv1, inv2, thr2, P1, Q)) return rc;
+    launch_prep_kernel(c, P1);
     launch_quads_kernel(c, Q);
     HIPCHK(c, hipGetLastError()); }
   HIPCHK(c, hipMemcpyAsync(c->hctr[c->cur].p, c->lane[c->cur].ctr.p, sizeof(DevCounters), hipMemcpyDeviceToHost, c->lane[c->cur].stream));
@@ -1504,29 +1499,39 @@ int32_t s4p_transform_points(s4p_ctx* c, const float* M, float* x, float* y, flo
 // largest absolute difference.
 // SelectRandomTriangle + the 4th-point scan of SelectQuadrilateral as device reductions (k_select_*): one attempt.
 // Safe to call from a thread of its own while bases are in flight: it touches only the selection buffers and stream.
-int32_t s4p_select_base_points(s4p_ctx* c, const uint32_t* draws, float limit_sq, float too_small,
-                               int32_t* ids, float* xyz, int32_t* status) {
-  if (!c || !draws || !ids || !xyz || !status) return S4P_ERR_BAD_ARG;
+int32_t s4p_select_base_points_batch(s4p_ctx* c, const uint32_t* draws, int32_t n_attempts, float limit_sq, float too_small,
+                                     int32_t* ids, float* xyz, int32_t* status) {
+  if (!c || !draws || !ids || !xyz || !status || n_attempts < 1 || n_attempts > kSelectBatch) return S4P_ERR_BAD_ARG;
   if (!c->clouds_set || !c->p4o.p) S4P_FAIL(c, S4P_ERR_STATE, "s4p_select_base_points: call s4p_set_clouds first");
-  for (int k = 0; k < kSelectDraws; ++k)
+  const size_t nd = size_t(kSelectDraws) * size_t(n_attempts);
+  for (size_t k = 0; k < nd; ++k)
     if (draws[k] >= c->n_p) S4P_FAIL(c, S4P_ERR_BAD_ARG, "s4p_select_base_points: draw outside the sampled P");
   HIPCHK(c, hipSetDevice(c->device));
   hipStream_t st = c->sel_stream;
-  std::memcpy(c->sel_hdraws.p, draws, sizeof(uint32_t) * kSelectDraws);
-  HIPCHK(c, hipMemcpyAsync(c->sel_draws.p, c->sel_hdraws.p, sizeof(uint32_t) * kSelectDraws, hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(k_select_triangle, dim3(1), dim3(1024), 0, st, c->p4o.p, c->sel_draws.p, limit_sq, c->sel_rec.p);
-  const uint32_t blocks = std::min<uint32_t>(2048u, (c->n_p + 1023u) / 1024u);
-  hipLaunchKernelGGL(k_select_fourth, dim3(blocks ? blocks : 1u), dim3(256), 0, st, c->p4o.p, c->n_p, too_small, c->sel_rec.p);
-  hipLaunchKernelGGL(k_select_finish, dim3(1), dim3(64), 0, st, c->p4o.p, c->sel_rec.p);
+  std::memcpy(c->sel_hdraws.p, draws, sizeof(uint32_t) * nd);
+  HIPCHK(c, hipMemcpyAsync(c->sel_draws.p, c->sel_hdraws.p, sizeof(uint32_t) * nd, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(k_select_triangle, dim3(uint32_t(n_attempts)), dim3(1024), 0, st, c->p4o.p, c->sel_draws.p, limit_sq, c->sel_rec.p);
+  const uint32_t blocks = std::max<uint32_t>(1u, std::min<uint32_t>(2048u / uint32_t(n_attempts) + 1u, (c->n_p + 1023u) / 1024u));
+  hipLaunchKernelGGL(k_select_fourth, dim3(blocks, uint32_t(n_attempts)), dim3(256), 0, st, c->p4o.p, c->n_p, too_small, c->sel_rec.p);
+  hipLaunchKernelGGL(k_select_finish, dim3(uint32_t(n_attempts)), dim3(64), 0, st, c->p4o.p, c->sel_rec.p);
   HIPCHK(c, hipGetLastError());
-  HIPCHK(c, hipMemcpyAsync(c->sel_hrec.p, c->sel_rec.p, sizeof(SelectRecord), hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipMemcpyAsync(c->sel_hrec.p, c->sel_rec.p, sizeof(SelectRecord) * size_t(n_attempts), hipMemcpyDeviceToHost, st));
   HIPCHK(c, hipStreamSynchronize(st));
-  const SelectRecord& r = *c->sel_hrec.p;
-  for (int k = 0; k < 4; ++k) ids[k] = r.ids[k];
-  for (int k = 0; k < 12; ++k) xyz[k] = r.xyz[k];
-  *status = r.status;
+  for (int32_t a = 0; a < n_attempts; ++a) {
+    const SelectRecord& r = c->sel_hrec.p[a];
+    for (int k = 0; k < 4; ++k) ids[4 * a + k] = r.ids[k];
+    for (int k = 0; k < 12; ++k) xyz[12 * a + k] = r.xyz[k];
+    status[a] = r.status;
+  }
   return S4P_OK;
 }
+
+int32_t s4p_select_base_points(s4p_ctx* c, const uint32_t* draws, float limit_sq, float too_small,
+                               int32_t* ids, float* xyz, int32_t* status) {
+  return s4p_select_base_points_batch(c, draws, 1, limit_sq, too_small, ids, xyz, status);
+}
+
+int32_t s4p_select_batch_max(void) { return kSelectBatch; }
 
 int32_t s4p_apply_bench(s4p_ctx* c, int64_t n, int32_t reps, double* out_ms, uint64_t* mismatch, float* max_abs) {
   if (!c || n <= 0 || reps <= 0 || !out_ms || !mismatch || !max_abs) return S4P_ERR_BAD_ARG;

@@ -18,6 +18,7 @@
 #include <cstring>
 #include <deque>
 #include <limits>
+#include <memory>
 #include <mutex>
 #include <atomic>
 #include <random>
@@ -156,7 +157,24 @@ struct s4p_matcher {
     int rank = 0, world = 1;
     long next_index = 0;                   // next trial the selector will draw
     long consumed = 0;                     // trials handed to the main thread
-    std::thread sel, tree;
+    std::thread tree;
+    // Base selection as a pipeline of its own: the DRAWER owns the random stream and draws the 2001 indices of one attempt
+    // after the other (match4pcsBase.cc:185-218 draws them unconditionally, so the stream never depends on a result);
+    // EVALUATORS (two on the host structures; one that batches attempts through s4p_select_base_points_batch when the
+    // searches run on the device) find the widest triangle, the fourth point and the ordering of an attempt, several
+    // attempts at a time; the ASSEMBLER consumes the attempts strictly in order and turns them into trials exactly as
+    // the reference's loop does (a failed attempt is followed by the next one, :283-349) and feeds qa.  The serial part of
+    // a trial drops from ~15 us (draw + evaluate) to the ~5 us of the draws, which is what bounds a rank that has to walk
+    // the bases of all `world` ranks.
+    struct Attempt { uint32_t idx[2001]; std::mt19937 rng_before; int status = -1; int ids[4] = {0, 0, 0, 0}; float inv1 = 0, inv2 = 0; };
+    static constexpr uint32_t kRing = 64;
+    std::unique_ptr<Attempt[]> ring;
+    std::atomic<uint32_t> ring_state[kRing];     // 0 free, 1 drawn, 2 evaluated
+    std::atomic<uint64_t> drawn{0}, claimed{0}, taken{0};
+    std::thread drawer, evals[2], assembler;
+    int n_eval = 2;
+    std::atomic<uint64_t> select_ns{0};
+    bool partial = false; std::mt19937 partial_rng;     // the assembler stopped inside a trial: where that trial's draws began
     std::mutex mu;
     // one condition per wait reason: a hand-off wakes only the thread that can use it, and a full queue's
     // producer is woken at the low-water mark (half empty), not once per item
@@ -229,19 +247,18 @@ double segment_segment(V3 p1, V3 p2, V3 q1, V3 q2, double& inv1, double& inv2) {
 //  * `rng() % n` through an exact multiply-high remainder (n is loop-invariant);
 //  * the area test on the squared cross product first -- sqrt is monotone, so a candidate whose squared area does
 //    not exceed the best one's cannot pass `wide > widest`; the square root is taken only for the few that can.
-bool pick_triangle(s4p_matcher* m, int& b1, int& b2, int& b3) {
-  const uint32_t n = uint32_t(m->Ps.size());
-  b1 = b2 = b3 = -1;
-  if (n == 0) return false;
+// the 2001 draws of one attempt: `first`, then 1000 x (second, third), each `rng() % n` (match4pcsBase.cc:192-199)
+void draw_attempt(std::mt19937& rng, uint32_t n, uint32_t idx[2001]) {
   const uint64_t magic = ~0ull / n + 1ull;                       // exact for every 32-bit dividend
-  auto draw = [&]() {
-    const uint32_t a = uint32_t(m->rng());                       // mt19937 yields 32-bit values
-    return uint32_t((static_cast<unsigned __int128>(magic * a) * n) >> 64);
-  };
-  // all 2001 draws first (the stream does not depend on the points), prefetching the records they address
-  uint32_t idx[2001];
+  for (int t = 0; t < 2001; ++t) {
+    const uint32_t a = uint32_t(rng());                          // mt19937 yields 32-bit values
+    idx[t] = uint32_t((static_cast<unsigned __int128>(magic * a) * n) >> 64);
+  }
+}
+bool eval_triangle(const s4p_matcher* m, const uint32_t idx[2001], int& b1, int& b2, int& b3) {
+  b1 = b2 = b3 = -1;
   const float* P = m->P4.data();
-  for (int t = 0; t < 2001; ++t) { idx[t] = draw(); __builtin_prefetch(P + 4 * size_t(idx[t])); }
+  for (int t = 0; t < 2001; ++t) __builtin_prefetch(P + 4 * size_t(idx[t]));       // the records the draws address
   const uint32_t first = idx[0];
   const float limit = m->max_base_diameter * m->max_base_diameter;
   float widest = 0.f, widest_sq = 0.f;
@@ -257,6 +274,14 @@ bool pick_triangle(s4p_matcher* m, int& b1, int& b2, int& b3) {
     if (wide > widest) { widest = wide; widest_sq = sq; b1 = int(first); b2 = int(second); b3 = int(third); }
   }
   return b1 != -1 && b2 != -1 && b3 != -1;
+}
+bool pick_triangle(s4p_matcher* m, int& b1, int& b2, int& b3) {
+  const uint32_t n = uint32_t(m->Ps.size());
+  b1 = b2 = b3 = -1;
+  if (n == 0) return false;
+  uint32_t idx[2001];
+  draw_attempt(m->rng, n, idx);
+  return eval_triangle(m, idx, b1, b2, b3);
 }
 
 // match4pcsBase.cc:225-274: best of the 12 segment pairings; reorders ids.
@@ -299,6 +324,29 @@ int device_attempt(s4p_matcher* m, int ids[4], V3 pts[4]) {
   return status;
 }
 
+constexpr int kAttemptFound = 0, kAttemptNoTriangle = 1, kAttemptRetry = 2;
+// One attempt of SelectQuadrilateral's loop on the host structures, given its draws (match4pcsBase.cc:283-349)
+int eval_attempt_host(const s4p_matcher* m, const uint32_t idx[2001], int ids[4], float& inv1, float& inv2) {
+  const float kBaseTooSmall = 0.2f;
+  int b1, b2, b3;
+  if (!eval_triangle(m, idx, b1, b2, b3)) return kAttemptNoTriangle;
+  const V3 A = m->P(b1), B = m->P(b2), C = m->P(b3);
+  const double x1 = A.x, y1 = A.y, z1 = A.z, x2 = B.x, y2 = B.y, z2 = B.z, x3 = C.x, y3 = C.y, z3 = C.z;
+  const float denom = float(-x3 * y2 * z1 + x2 * y3 * z1 + x3 * y1 * z2 - x1 * y3 * z2 - x2 * y1 * z3 + x1 * y2 * z3);
+  if (!(denom != 0)) return kAttemptRetry;
+  const float pa = float((-y2 * z1 + y3 * z1 + y1 * z2 - y3 * z2 - y1 * z3 + y2 * z3) / denom);
+  const float pb = float((x2 * z1 - x3 * z1 - x1 * z2 + x3 * z2 + x1 * z3 - x2 * z3) / denom);
+  const float pc = float((-x2 * y1 + x3 * y1 + x1 * y2 - x3 * y2 - x1 * y3 + x2 * y3) / denom);
+  const float too_small = float(std::pow(double(m->max_base_diameter * kBaseTooSmall), 2));
+  const float pA[3] = {A.x, A.y, A.z}, pB[3] = {B.x, B.y, B.z}, pC[3] = {C.x, C.y, C.z};
+  static thread_local std::vector<float> scratch;           // (two evaluator threads query the same index concurrently)
+  const int b4 = m->fourth.query(pa, pb, pc, pA, pB, pC, too_small, scratch);
+  if (b4 == -1) return kAttemptRetry;
+  ids[0] = b1; ids[1] = b2; ids[2] = b3; ids[3] = b4;
+  const V3 pts[4] = {A, B, C, m->P(b4)};
+  return order_quadrilateral(pts, ids, inv1, inv2) ? kAttemptFound : kAttemptRetry;
+}
+
 // match4pcsBase.cc:279-351
 bool select_quadrilateral(s4p_matcher* m, float& inv1, float& inv2, int ids[4]) {
   const float kBaseTooSmall = 0.2f;
@@ -329,7 +377,8 @@ bool select_quadrilateral(s4p_matcher* m, float& inv1, float& inv2, int ids[4]) 
       // FourthPointIndex, which skips the blocks of P whose bounding box lies further from the plane than the best
       // point found so far (s4p_host_structs.hpp).
       const float pA[3] = {A.x, A.y, A.z}, pB[3] = {B.x, B.y, B.z}, pC[3] = {C.x, C.y, C.z};
-      b4 = m->fourth.query(pa, pb, pc, pA, pB, pC, too_small);
+      static thread_local std::vector<float> scratch;
+      b4 = m->fourth.query(pa, pb, pc, pA, pB, pC, too_small, scratch);
       if (b4 != -1) {
         ids[0] = b1; ids[1] = b2; ids[2] = b3; ids[3] = b4;
         const V3 pts[4] = {A, B, C, m->P(b4)};
@@ -372,22 +421,109 @@ inline void spin_until_ready(const std::atomic<size_t>& ready, const std::atomic
     for (int k = 0; k < 16; ++k) __builtin_ia32_pause();
 }
 
-void selector_main(s4p_matcher* m) {
+// waits until `st` holds `want`; false if the producer is stopping.  Spins first (a streaming stage never sleeps), then
+// naps: when the GPU is the bottleneck the queues are full and the helpers idle cheaply.
+inline bool wait_state(const std::atomic<uint32_t>& st, uint32_t want, const std::atomic<bool>& stop) {
+  for (int spin = 0;; ++spin) {
+    if (st.load(std::memory_order_acquire) == want) return true;
+    if (stop.load(std::memory_order_relaxed)) return false;
+    if (spin < 4000) __builtin_ia32_pause();
+    else std::this_thread::sleep_for(std::chrono::microseconds(50));
+  }
+}
+
+void drawer_main(s4p_matcher* m) {
+  auto& P = m->prod;
+  const uint32_t n = uint32_t(m->Ps.size());
+  for (uint64_t seq = P.drawn.load();; ++seq) {
+    const uint32_t slot = uint32_t(seq % s4p_matcher::Producer::kRing);
+    if (!wait_state(P.ring_state[slot], 0u, P.stop_flag)) return;
+    s4p_matcher::Producer::Attempt& a = P.ring[slot];
+    a.rng_before = m->rng;
+    a.status = -1;
+    if (n) draw_attempt(m->rng, n, a.idx);
+    P.ring_state[slot].store(1u, std::memory_order_release);
+    P.drawn.store(seq + 1, std::memory_order_release);
+  }
+}
+
+void evaluator_main(s4p_matcher* m) {
+  auto& P = m->prod;
+  using clk = std::chrono::steady_clock;
+  const float kBaseTooSmall = 0.2f;
+  if (!m->device_select) {
+    while (true) {
+      const uint64_t seq = P.claimed.fetch_add(1);
+      const uint32_t slot = uint32_t(seq % s4p_matcher::Producer::kRing);
+      if (!wait_state(P.ring_state[slot], 1u, P.stop_flag)) return;
+      s4p_matcher::Producer::Attempt& a = P.ring[slot];
+      const auto t0 = clk::now();
+      a.status = m->Ps.size() ? eval_attempt_host(m, a.idx, a.ids, a.inv1, a.inv2) : kAttemptNoTriangle;
+      P.select_ns.fetch_add(uint64_t(std::chrono::duration_cast<std::chrono::nanoseconds>(clk::now() - t0).count()));
+      P.ring_state[slot].store(2u, std::memory_order_release);
+    }
+  }
+  // searches on the device: every attempt that has been drawn so far (up to the batch size) goes into ONE set of launches
+  const int bmax = std::min(8, s4p_select_batch_max());
+  std::vector<uint32_t> draws(size_t(bmax) * 2001);
+  std::vector<int32_t> got(size_t(bmax) * 4), st(static_cast<size_t>(bmax));
+  std::vector<float> xyz(size_t(bmax) * 12);
+  const float limit = m->max_base_diameter * m->max_base_diameter;
+  const float too_small = float(std::pow(double(m->max_base_diameter * kBaseTooSmall), 2));
+  while (true) {
+    const uint64_t seq0 = P.claimed.load();
+    if (!wait_state(P.ring_state[seq0 % s4p_matcher::Producer::kRing], 1u, P.stop_flag)) return;
+    int nb = 1;
+    while (nb < bmax && P.ring_state[(seq0 + uint64_t(nb)) % s4p_matcher::Producer::kRing].load(std::memory_order_acquire) == 1u) ++nb;
+    for (int k = 0; k < nb; ++k) std::memcpy(draws.data() + size_t(k) * 2001, P.ring[(seq0 + uint64_t(k)) % s4p_matcher::Producer::kRing].idx, 2001 * sizeof(uint32_t));
+    const auto t0 = clk::now();
+    const int32_t rc = m->Ps.size() ? s4p_select_base_points_batch(m->ctx, draws.data(), nb, limit, too_small, got.data(), xyz.data(), st.data()) : S4P_OK;
+    if (rc != S4P_OK) { m->select_err = s4p_last_error(m->ctx); m->select_failed.store(true, std::memory_order_release); }
+    for (int k = 0; k < nb; ++k) {
+      s4p_matcher::Producer::Attempt& a = P.ring[(seq0 + uint64_t(k)) % s4p_matcher::Producer::kRing];
+      a.status = kAttemptNoTriangle;                         // (also the answer after a device error: the trial finds no base, the loop reports the error)
+      if (rc == S4P_OK && m->Ps.size()) {
+        if (st[size_t(k)] == 1) a.status = kAttemptNoTriangle;
+        else if (st[size_t(k)] == 0) {
+          V3 pts[4];
+          for (int t = 0; t < 4; ++t) { a.ids[t] = got[size_t(4 * k + t)]; pts[t] = V3{xyz[size_t(12 * k + 3 * t)], xyz[size_t(12 * k + 3 * t + 1)], xyz[size_t(12 * k + 3 * t + 2)]}; }
+          a.status = order_quadrilateral(pts, a.ids, a.inv1, a.inv2) ? kAttemptFound : kAttemptRetry;
+        } else a.status = kAttemptRetry;
+      }
+    }
+    P.select_ns.fetch_add(uint64_t(std::chrono::duration_cast<std::chrono::nanoseconds>(clk::now() - t0).count()));
+    for (int k = 0; k < nb; ++k) P.ring_state[(seq0 + uint64_t(k)) % s4p_matcher::Producer::kRing].store(2u, std::memory_order_release);
+    P.claimed.store(seq0 + uint64_t(nb));
+  }
+}
+
+// attempts -> trials, strictly in order: SelectQuadrilateral's loop (match4pcsBase.cc:283-349) over evaluated attempts
+void assembler_main(s4p_matcher* m) {
   auto& P = m->prod;
   while (true) {
     { std::unique_lock<std::mutex> lk(P.mu);
       P.cv_a_space.wait(lk, [&] { return P.stop || P.qa.size() < P.cap_a; });
       if (P.stop) return; }
     s4p_matcher::Trial t;
-    t.rng_before = m->rng;
-    const auto t0 = std::chrono::steady_clock::now();
-    t.found = select_quadrilateral(m, t.inv1, t.inv2, t.ids);
-    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    t.found = false;
+    bool first = true;
+    for (int attempt = 0; attempt < 1000; ++attempt) {
+      const uint64_t seq = P.taken.load();
+      const uint32_t slot = uint32_t(seq % s4p_matcher::Producer::kRing);
+      if (!wait_state(P.ring_state[slot], 2u, P.stop_flag)) return;      // (P.partial tells producer_stop where this trial's draws began)
+      s4p_matcher::Producer::Attempt& a = P.ring[slot];
+      if (first) { t.rng_before = a.rng_before; P.partial_rng = a.rng_before; P.partial = true; first = false; }
+      const int status = a.status;
+      if (status == kAttemptFound) { t.found = true; t.inv1 = a.inv1; t.inv2 = a.inv2; for (int k = 0; k < 4; ++k) t.ids[k] = a.ids[k]; }
+      P.ring_state[slot].store(0u, std::memory_order_release);
+      P.taken.store(seq + 1, std::memory_order_release);
+      if (status != kAttemptRetry) break;                    // found, or SelectRandomTriangle failed: the reference gives up (:285-287)
+    }
     if (t.found) fill_base_arrays(m, t.ids, t.bx, t.bn, t.bc);
     { std::lock_guard<std::mutex> lk(P.mu);
+      P.partial = false;
       t.index = P.next_index++;
       t.owned = (t.index % P.world) == P.rank;
-      P.select_s += dt;
       P.qa.push_back(std::move(t));       // pushed even when stopping: nothing that advanced the RNG is ever dropped
       P.qa_ready.store(P.qa.size(), std::memory_order_release); }
     P.cv_a_item.notify_one();
@@ -433,7 +569,13 @@ void producer_start(s4p_matcher* m) {
   const int nslots = s4p_stage_slots(m->ctx);
   for (int sl = nslots / 2; sl < nslots; ++sl) P.free_slots.push_back(sl);      // the lower half belongs to s4p_try_base_async
   P.next_index = P.consumed;
-  P.sel = std::thread(selector_main, m);
+  if (!P.ring) P.ring.reset(new s4p_matcher::Producer::Attempt[s4p_matcher::Producer::kRing]);
+  for (auto& st : P.ring_state) st.store(0u);
+  P.drawn.store(0); P.claimed.store(0); P.taken.store(0); P.partial = false;
+  P.n_eval = m->device_select ? 1 : 2;
+  P.drawer = std::thread(drawer_main, m);
+  for (int k = 0; k < P.n_eval; ++k) P.evals[k] = std::thread(evaluator_main, m);
+  P.assembler = std::thread(assembler_main, m);
   P.tree = std::thread(tree_main, m);
   P.running = true;
 }
@@ -445,16 +587,24 @@ void producer_stop(s4p_matcher* m) {
   if (!P.running) return;
   { std::lock_guard<std::mutex> lk(P.mu); P.stop = true; P.stop_flag.store(true); }
   P.wake_all();
-  P.sel.join(); P.tree.join();
+  P.drawer.join();
+  for (int k = 0; k < P.n_eval; ++k) P.evals[k].join();
+  P.assembler.join(); P.tree.join();
   P.running = false;
+  // the random stream goes back to where the first trial that was not handed to the main thread began
   if (!P.qb.empty()) {
     m->rng = P.qb.front().rng_before;
     s4p_pair_state_restore(m->ctx, P.qb.front().pair_before.data());
   } else if (!P.qa.empty()) {
     m->rng = P.qa.front().rng_before;
+  } else if (P.partial) {
+    m->rng = P.partial_rng;                                  // the assembler was inside a trial
+  } else if (P.taken.load() < P.drawn.load()) {
+    m->rng = P.ring[P.taken.load() % s4p_matcher::Producer::kRing].rng_before;      // attempts drawn ahead, none of them consumed
   }
+  P.partial = false;
   P.qa.clear(); P.qb.clear(); P.qa_ready.store(0); P.qb_ready.store(0);
-  m->seconds_select += P.select_s; P.select_s = 0;
+  m->seconds_select += double(P.select_ns.exchange(0)) * 1e-9 + P.select_s; P.select_s = 0;
 }
 
 bool producer_pop(s4p_matcher* m, s4p_matcher::Trial& t) {

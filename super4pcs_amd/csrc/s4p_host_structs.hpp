@@ -342,18 +342,19 @@ class FourthPointIndex {
         }
       }
     }
-    lb_.resize(nb_);
   }
 
   // Returns the index (into the original arrays) or -1.  A, B, C: the base triangle; pa, pb, pc: the plane.
-  int query(float pa, float pb, float pc, const float* A, const float* B, const float* C, float too_small) {
+  // lb: the caller's scratch (one float per block; resized here) -- concurrent queries from several threads each bring their own
+  int query(float pa, float pb, float pc, const float* A, const float* B, const float* C, float too_small, std::vector<float>& lb) const {
+    if (lb.size() < nb_) lb.resize(nb_);
     const float margin = 4e-6f * (std::fabs(pa) * absmax_[0] + std::fabs(pb) * absmax_[1] + std::fabs(pc) * absmax_[2] + 1.0f);
     // interval of (a x + b y + c z - 1) over each block's box: the low end takes, per axis, the box face on the side
     // the coefficient's sign points away from
     const float* __restrict x0 = (pa >= 0.f ? blo_[0] : bhi_[0]).data(); const float* __restrict x1 = (pa >= 0.f ? bhi_[0] : blo_[0]).data();
     const float* __restrict y0 = (pb >= 0.f ? blo_[1] : bhi_[1]).data(); const float* __restrict y1 = (pb >= 0.f ? bhi_[1] : blo_[1]).data();
     const float* __restrict z0 = (pc >= 0.f ? blo_[2] : bhi_[2]).data(); const float* __restrict z1 = (pc >= 0.f ? bhi_[2] : blo_[2]).data();
-    float* __restrict lbp = lb_.data();
+    float* __restrict lbp = lb.data();
     for (size_t b = 0; b < nb_; ++b) {
       const float vmin = ((pa * x0[b] + pb * y0[b]) + pc * z0[b]) - 1.0f;
       const float vmax = ((pa * x1[b] + pb * y1[b]) + pc * z1[b]) - 1.0f;
@@ -381,8 +382,8 @@ class FourthPointIndex {
         if (i != 0xFFFFFFFFu && far_enough(p, A, too_small) && far_enough(p, B, too_small) && far_enough(p, C, too_small)) { best = d; best_i = i; }
       }
     };
-    for (size_t b = 0; b < nb_; ++b) if (lb_[b] <= 0.0f) visit(b);          // boxes the plane passes through
-    for (size_t b = 0; b < nb_; ++b) if (lb_[b] > 0.0f && lb_[b] <= best) visit(b);
+    for (size_t b = 0; b < nb_; ++b) if (lbp[b] <= 0.0f) visit(b);          // boxes the plane passes through
+    for (size_t b = 0; b < nb_; ++b) if (lbp[b] > 0.0f && lbp[b] <= best) visit(b);
     return best_i == 0xFFFFFFFFu ? -1 : int(best_i);
   }
 
@@ -393,7 +394,7 @@ class FourthPointIndex {
   }
   size_t n_ = 0, nb_ = 0;
   float absmax_[3] = {0, 0, 0};
-  std::vector<float> bx_, by_, bz_, blo_[3], bhi_[3], lb_;
+  std::vector<float> bx_, by_, bz_, blo_[3], bhi_[3];
   std::vector<uint32_t> bi_;
 };
 

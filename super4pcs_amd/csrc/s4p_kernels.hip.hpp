@@ -781,18 +781,15 @@ __device__ __forceinline__ uint32_t hash_mask(const HashTable& ht) {
   return min(size - 1u, ht.mask);
 }
 
-// Per-set preparation parameters.  `ab`/`m_dev`/`cap` are only read by the stand-alone k_prep (stage-level entry
-// points); the fused pair kernel hands every pair over in registers.
+// Preparation parameters of set 1 (k_prep).
 struct PrepParams {
   const float* ux; const float* uy; const float* uz;
   const float* qx; const float* qy; const float* qz;
   const int2* ab; const uint32_t* m_dev; uint32_t cap;
   float invariant;
   QuadGrid qg;
-  uint32_t* cell; uint32_t* bucket; float4* ew; uint32_t* next;   // set 1: bucket,next used; set 2: unused
-  uint32_t* mask;                                                  // set 2: kMaskWords per entry
+  uint32_t* cell; uint32_t* bucket; float4* ew; uint32_t* next;
   HashTable ht;
-  ConeTable cone;
 };
 
 // set 1, one pair (entry e = (ab.x, ab.y)): invariant point, cell, direction bucket, world point, hash insert
@@ -851,75 +848,21 @@ __device__ __forceinline__ void quat_from_z_to(float nx, float ny, float nz, flo
   q[0] = s * 0.5f;
 }
 
-// set 2, one pair: invariant point, cell, world point, 343-bit cone mask (built in the caller's LDS row `my`)
-__device__ __forceinline__ void prep2_item(const PrepParams& P, const uint32_t e, const int2 ab, uint32_t* my) {
-  const float p1x = P.ux[ab.x], p1y = P.uy[ab.x], p1z = P.uz[ab.x];
-  const float p2x = P.ux[ab.y], p2y = P.uy[ab.y], p2z = P.uz[ab.y];
-  const float nx = p2x - p1x, ny = p2y - p1y, nz = p2z - p1z;
-  const float qx_ = p1x + P.invariant * nx, qy_ = p1y + P.invariant * ny, qz_ = p1z + P.invariant * nz;   // super4pcs.cc:141
-  P.cell[e] = index_pos(qx_, qy_, qz_, P.qg);
-  const float w1x = P.qx[ab.x], w1y = P.qy[ab.x], w1z = P.qz[ab.x];
-  const float w2x = P.qx[ab.y], w2y = P.qy[ab.y], w2z = P.qz[ab.y];
-  P.ew[e] = make_float4(w1x + P.invariant * (w2x - w1x), w1y + P.invariant * (w2y - w1y),
-                        w1z + P.invariant * (w2z - w1z), 0.f);                                          // :142
+// The 343-bit cone mask of one set-2 pair (getNeighbors, normalset.hpp:174-196): the direction buckets hit by the nb cone
+// samples rotated onto the pair's direction (nx, ny, nz: p2 - p1 in unit coordinates, not normalised), OR-ed into the
+// caller's private row of kMaskWords words (zeroed here).
+// Only the BUCKET of a rotated, normalised cone sample is needed: int((x / 2 + 0.5) / neps) per axis.  The exact
+// sequence -- the quaternion product as Eigen writes it, a square root and six correctly rounded divisions -- is ~150
+// instructions per sample.  The fast path rotates with the quaternion's 3x3 matrix (9 fma; equal to the exact product
+// to ~1e-7), does not normalise (the rotated vector is unit to rounding) and multiplies by 1/neps: with
+// | |d|^2 - 1 | < 1e-4 its bucket coordinates differ from the exact ones by < 2e-4 (measured < 2e-5,
+// tests/test_prep_bucket_fast_path.py), so if every coordinate lies further than 4e-4 from an integer the truncations
+// agree; otherwise (0.2 % of the samples) the exact sequence runs.
+__device__ __forceinline__ void cone_mask_row(const ConeTable& cone, const float nepsilon, float nx, float ny, float nz, uint32_t* row) {
   float q[4];
-  float qnx = nx, qny = ny, qnz = nz;
-  normalize3(qnx, qny, qnz);                          // queryn = (p2-p1).normalized()            super4pcs.cc:144
-  quat_from_z_to(qnx, qny, qnz, q);                   // setFromTwoVectors normalises it again    normalset.hpp:181
-#pragma unroll
-  for (int w = 0; w < kMaskWords; ++w) my[w] = 0u;
-  for (int a = 0; a < P.cone.nb; ++a) {               // normalset.hpp:186-196
-    const float vx = P.cone.v[a][0], vy = P.cone.v[a][1], vz = P.cone.v[a][2];
-    float ux_, uy_, uz_;
-    cross3(q[1], q[2], q[3], vx, vy, vz, ux_, uy_, uz_);            // QuaternionBase::_transformVector
-    ux_ += ux_; uy_ += uy_; uz_ += uz_;
-    float cx, cy, cz;
-    cross3(q[1], q[2], q[3], ux_, uy_, uz_, cx, cy, cz);
-    float dx = (vx + q[0] * ux_) + cx, dy = (vy + q[0] * uy_) + cy, dz = (vz + q[0] * uz_) + cz;
-    normalize3(dx, dy, dz);
-    const uint32_t id = index_normal(dx, dy, dz, P.qg.nepsilon);
-    if (id < 343u) my[id >> 5] |= (1u << (id & 31u));
-  }
-#pragma unroll
-  for (int w = 0; w < kMaskWords; ++w) P.mask[size_t(e) * kMaskWords + w] = my[w];
-}
-
-// Stand-alone preparation of two uploaded pair lists (s4p_find_congruent): blockIdx.y == 0 -> set 1, 1 -> set 2.
-// The fused path (s4p_try_base*) prepares every pair inside k_pairs, where it is produced.
-// set 2, FOUR lanes per pair: the <= 56 cone samples of a pair (normalset.hpp:186-196) are independent, lane s of the
-// group takes samples s, s + 4, ...; the 343-bit mask is OR-ed together in the group's 11 LDS words.  Same buckets as
-// prep2_item, so the same mask.  Why a small group: a thread per pair runs the 56 samples as one dependent chain on too
-// few waves (43 us per base, most SIMDs empty); a wave per pair repeats the ~450-instruction set-up 64 times over.  With
-// a base's ~150 k pairs the launch is VALU-throughput bound, and per pair a group of g lanes costs (450 + 57/g x sample) / (64/g)
-// wave-instructions: four lanes keep that within a quarter of the one-lane minimum and still put 9 k waves on the chip.
-constexpr uint32_t kPrepGroup = 4;
-__device__ __forceinline__ void prep2_group(const PrepParams& P, const uint32_t e, const bool live, const int2 ab, uint32_t* gmask) {
-  const uint32_t sub = threadIdx.x & (kPrepGroup - 1u);
-  float q[4] = {1.f, 0.f, 0.f, 0.f};
-  if (live) {
-    const float p1x = P.ux[ab.x], p1y = P.uy[ab.x], p1z = P.uz[ab.x];
-    const float p2x = P.ux[ab.y], p2y = P.uy[ab.y], p2z = P.uz[ab.y];
-    const float nx = p2x - p1x, ny = p2y - p1y, nz = p2z - p1z;
-    if (sub == 0) {
-      const float qx_ = p1x + P.invariant * nx, qy_ = p1y + P.invariant * ny, qz_ = p1z + P.invariant * nz;   // super4pcs.cc:141
-      P.cell[e] = index_pos(qx_, qy_, qz_, P.qg);
-      const float w1x = P.qx[ab.x], w1y = P.qy[ab.x], w1z = P.qz[ab.x];
-      const float w2x = P.qx[ab.y], w2y = P.qy[ab.y], w2z = P.qz[ab.y];
-      P.ew[e] = make_float4(w1x + P.invariant * (w2x - w1x), w1y + P.invariant * (w2y - w1y),
-                            w1z + P.invariant * (w2z - w1z), 0.f);                                          // :142
-    }
-    float qnx = nx, qny = ny, qnz = nz;
-    normalize3(qnx, qny, qnz);                          // queryn = (p2-p1).normalized()            super4pcs.cc:144
-    quat_from_z_to(qnx, qny, qnz, q);                   // setFromTwoVectors normalises it again    normalset.hpp:181
-  }
-  // Only the BUCKET of a rotated, normalised cone sample is needed: int((x / 2 + 0.5) / neps) per axis.  The exact
-  // sequence -- the quaternion product as Eigen writes it, a square root and six correctly rounded divisions -- is ~150
-  // instructions per sample.  The fast path rotates with the quaternion's 3x3 matrix (9 fma; equal to the exact product
-  // to ~1e-7), does not normalise (the rotated vector is unit to rounding) and multiplies by 1/neps: with
-  // | |d|^2 - 1 | < 1e-4 its bucket coordinates differ from the exact ones by < 2e-4 (measured < 2e-5,
-  // tests/test_prep_bucket_fast_path.py), so if every coordinate lies further than 4e-4 from an integer the truncations
-  // agree; otherwise (0.2 % of the samples) the exact sequence runs.
-  const float inv_neps = 1.0f / P.qg.nepsilon;
+  normalize3(nx, ny, nz);                             // queryn = (p2-p1).normalized()            super4pcs.cc:144
+  quat_from_z_to(nx, ny, nz, q);                      // setFromTwoVectors normalises it again    normalset.hpp:181
+  const float inv_neps = 1.0f / nepsilon;
   float R[9];
   { const float w = q[0], x = q[1], y = q[2], z = q[3];
     const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, xz = x * z, yz = y * z, wx = w * x, wy = w * y, wz = w * z;
@@ -927,57 +870,38 @@ __device__ __forceinline__ void prep2_group(const PrepParams& P, const uint32_t 
     R[3] = 2.f * (xy + wz); R[4] = 1.f - 2.f * (xx + zz); R[5] = 2.f * (yz - wx);
     R[6] = 2.f * (xz - wy); R[7] = 2.f * (yz + wx); R[8] = 1.f - 2.f * (xx + yy); }
 #pragma unroll
-  for (uint32_t w = sub; w < 16u; w += kPrepGroup) gmask[w] = 0u;        // 16 words per group, 11 used
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
-  if (live) {
-    for (int a = int(sub); a < P.cone.nb; a += int(kPrepGroup)) {
-      const float vx = P.cone.v[a][0], vy = P.cone.v[a][1], vz = P.cone.v[a][2];
-      const float fx = __builtin_fmaf(R[0], vx, __builtin_fmaf(R[1], vy, R[2] * vz)), fy = __builtin_fmaf(R[3], vx, __builtin_fmaf(R[4], vy, R[5] * vz)),
-                  fz = __builtin_fmaf(R[6], vx, __builtin_fmaf(R[7], vy, R[8] * vz));
-      const float t0 = __builtin_fmaf(fx, 0.5f, 0.5f) * inv_neps, t1 = __builtin_fmaf(fy, 0.5f, 0.5f) * inv_neps,
-                  t2 = __builtin_fmaf(fz, 0.5f, 0.5f) * inv_neps;
-      const float f0 = __builtin_amdgcn_fractf(t0), f1 = __builtin_amdgcn_fractf(t1), f2 = __builtin_amdgcn_fractf(t2);
-      const float edge = fminf(fminf(fminf(f0, 1.f - f0), fminf(f1, 1.f - f1)), fminf(f2, 1.f - f2));
-      const float n2 = __builtin_fmaf(fx, fx, __builtin_fmaf(fy, fy, fz * fz));
-      uint32_t id;
-      if (fabsf(n2 - 1.f) < 1e-4f && edge > 4e-4f) {
-        id = uint32_t(int(t2) * 49 + int(t1) * 7 + int(t0));
-      } else {
-        float ux_, uy_, uz_;
-        cross3(q[1], q[2], q[3], vx, vy, vz, ux_, uy_, uz_);            // QuaternionBase::_transformVector
-        ux_ += ux_; uy_ += uy_; uz_ += uz_;
-        float cx, cy, cz;
-        cross3(q[1], q[2], q[3], ux_, uy_, uz_, cx, cy, cz);
-        float dx = (vx + q[0] * ux_) + cx, dy = (vy + q[0] * uy_) + cy, dz = (vz + q[0] * uz_) + cz;
-        normalize3(dx, dy, dz);
-        id = index_normal(dx, dy, dz, P.qg.nepsilon);
-      }
-      if (id < 343u) atomicOr(&gmask[id >> 5], 1u << (id & 31u));
+  for (int w = 0; w < kMaskWords; ++w) row[w] = 0u;
+  for (int a = 0; a < cone.nb; ++a) {
+    const float vx = cone.v[a][0], vy = cone.v[a][1], vz = cone.v[a][2];
+    const float fx = __builtin_fmaf(R[0], vx, __builtin_fmaf(R[1], vy, R[2] * vz)), fy = __builtin_fmaf(R[3], vx, __builtin_fmaf(R[4], vy, R[5] * vz)),
+                fz = __builtin_fmaf(R[6], vx, __builtin_fmaf(R[7], vy, R[8] * vz));
+    const float t0 = __builtin_fmaf(fx, 0.5f, 0.5f) * inv_neps, t1 = __builtin_fmaf(fy, 0.5f, 0.5f) * inv_neps,
+                t2 = __builtin_fmaf(fz, 0.5f, 0.5f) * inv_neps;
+    const float f0 = __builtin_amdgcn_fractf(t0), f1 = __builtin_amdgcn_fractf(t1), f2 = __builtin_amdgcn_fractf(t2);
+    const float edge = fminf(fminf(fminf(f0, 1.f - f0), fminf(f1, 1.f - f1)), fminf(f2, 1.f - f2));
+    const float n2 = __builtin_fmaf(fx, fx, __builtin_fmaf(fy, fy, fz * fz));
+    uint32_t id;
+    if (fabsf(n2 - 1.f) < 1e-4f && edge > 4e-4f) {
+      id = uint32_t(int(t2) * 49 + int(t1) * 7 + int(t0));
+    } else {
+      float ux_, uy_, uz_;
+      cross3(q[1], q[2], q[3], vx, vy, vz, ux_, uy_, uz_);            // QuaternionBase::_transformVector
+      ux_ += ux_; uy_ += uy_; uz_ += uz_;
+      float cx, cy, cz;
+      cross3(q[1], q[2], q[3], ux_, uy_, uz_, cx, cy, cz);
+      float dx = (vx + q[0] * ux_) + cx, dy = (vy + q[0] * uy_) + cy, dz = (vz + q[0] * uz_) + cz;
+      normalize3(dx, dy, dz);
+      id = index_normal(dx, dy, dz, nepsilon);
     }
+    if (id < 343u) row[id >> 5] |= (1u << (id & 31u));
   }
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
-  if (live) {
-#pragma unroll
-    for (uint32_t w = sub; w < uint32_t(kMaskWords); w += kPrepGroup) P.mask[size_t(e) * kMaskWords + w] = gmask[w];
-  }
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
 }
 
-__global__ __launch_bounds__(256) void k_prep(PrepParams P1, PrepParams P2, int first_set) {
-  __shared__ uint32_t smask[(256 / kPrepGroup) * 16];
-  const uint32_t set = blockIdx.y + uint32_t(first_set);           // one launch for both sets (gridDim.y = 2), or one per set
-  const PrepParams& P = set == 0 ? P1 : P2;
+// Preparation of set 1 (one thread per pair): invariant point, cell, direction bucket, world point, hash insert.  Set 2 is
+// prepared where it is consumed (k_quads): only the pairs whose cell holds a set-1 pair need their world point and cone mask.
+__global__ __launch_bounds__(256) void k_prep(PrepParams P) {
   const uint32_t m = min(*P.m_dev, P.cap);
-  if (set == 0) {
-    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < m; e += gridDim.x * blockDim.x) prep1_item(P, e, P.ab[e]);
-  } else {
-    const uint32_t group = threadIdx.x / kPrepGroup, groups = blockDim.x / kPrepGroup;       // 32 pairs per workgroup and pass
-    for (uint32_t e0 = blockIdx.x * groups; e0 < m; e0 += gridDim.x * groups) {               // uniform trip count per workgroup
-      const uint32_t e = e0 + group;
-      const bool live = e < m;
-      prep2_group(P, e, live, live ? P.ab[e] : make_int2(0, 0), smask + group * 16u);
-    }
-  }
+  for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < m; e += gridDim.x * blockDim.x) prep1_item(P, e, P.ab[e]);
 }
 
 // ---------------------------------------------------------------------------
@@ -1260,8 +1184,10 @@ __global__ __launch_bounds__(256) void k_gate(GateKernelParams P) {
 struct QuadParams {
   // set 1
   const int2* ab1; const uint32_t* okey1; const uint32_t* bucket1; const float4* ew1; const uint32_t* next1;
-  // set 2
-  const int2* ab2; const uint32_t* okey2; const uint32_t* cell2; const float4* ew2; const uint32_t* mask2;
+  // set 2: prepared here, and only where needed (cell with a set-1 pair): invariant point + cell, world point, cone mask
+  const int2* ab2; const uint32_t* okey2;
+  const float* ux; const float* uy; const float* uz; const float* qx; const float* qy; const float* qz;
+  float invariant2; QuadGrid qg; ConeTable cone;
   const uint32_t* m2_dev; uint32_t cap2;
   HashTable ht;
   float thr;                   // distance_threshold2 (compared against a SQUARED norm: quirk super4pcs.cc:160)
@@ -1295,65 +1221,92 @@ __global__ __launch_bounds__(256) void k_quads(QuadParams P) {
   __shared__ int4 st_q[kQuadStage];
   __shared__ unsigned long long st_t[kQuadStage];
   __shared__ unsigned long long st_base, s_qsum, s_csum;
-  __shared__ uint32_t st_n, s_wc[4], s_cbase;
-  __shared__ uint32_t s_mask[256 * kMaskWords];            // each thread's copy of its entry's direction mask (row stride 11: conflict-free)
+  __shared__ uint32_t st_n, s_wc[4], s_cbase, s_ic[4];
+  __shared__ uint32_t s_item_i[256], s_item_e[256];        // the tile's pairs whose cell holds a set-1 pair, compacted
+  __shared__ uint32_t s_mask[256 * kMaskWords];            // each thread's direction mask (row stride 11: conflict-free)
   const uint32_t end = min(min(*P.m2_dev, P.cap2), P.r1);
   const uint32_t hmask = hash_mask(P.ht);
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   if (threadIdx.x == 0) { st_n = 0; s_qsum = 0ull; s_csum = 0ull; }
   __syncthreads();
   for (uint32_t i0 = P.r0 + blockIdx.x * blockDim.x; i0 < end; i0 += gridDim.x * blockDim.x) {
-    const uint32_t i = i0 + threadIdx.x;
-    if (i < end) {
-      const uint32_t cell = P.cell2[i];
-      const unsigned long long mykey = ((unsigned long long)P.ht.epoch << 32) | cell;
-      uint32_t h = hash_cell(cell) & hmask;
+    // phase A, one thread per set-2 pair of the tile: invariant point -> cell -> head of the cell's set-1 chain (super4pcs.cc:141,
+    // normalset.hpp:162-171).  Typically well under half of the pairs fall into a cell that holds a set-1 pair; those are
+    // compacted (ballot + per-wave offsets) so that the expensive part below runs on DENSE waves.
+    {
+      const uint32_t i = i0 + threadIdx.x;
       uint32_t e = kNil;
-      while (true) {
-        const unsigned long long k = P.ht.keys[h];
-        if (k == mykey) { const unsigned long long hd = P.ht.heads[h]; e = (uint32_t(hd >> 32) == P.ht.epoch) ? uint32_t(hd) : kNil; break; }
-        if (uint32_t(k >> 32) != P.ht.epoch) break;
-        h = (h + 1u) & hmask;
-      }
-      if (e != kNil) {
-        // The walk is a chain of dependent gathers (one set-1 pair per hop), so each hop is ONE round trip: the hop's
-        // direction bucket, world point and successor are requested together, and the 343-bit mask of this entry was
-        // copied to LDS up front (a global load indexed by the bucket would be a second dependent gather per hop).
-        const float4 eq = P.ew2[i];
-        const uint32_t* mk = P.mask2 + size_t(i) * kMaskWords;
-        uint32_t* row = s_mask + threadIdx.x * kMaskWords;
-#pragma unroll
-        for (int w = 0; w < kMaskWords; ++w) row[w] = mk[w];
-        const int2 ab2 = P.ab2[i];
-        const uint32_t ok2 = P.okey2[i];
-        while (e != kNil) {
-          const uint32_t b = P.bucket1[e];
-          const float4 ep = P.ew1[e];
-          const uint32_t nxt = P.next1[e];
-          const float dx = eq.x - ep.x, dy = eq.y - ep.y, dz = eq.z - ep.z;
-          if (((row[b >> 5] >> (b & 31u)) & 1u) && sqn3(dx, dy, dz) <= P.thr) {       // super4pcs.cc:160
-            const int2 ab1 = P.ab1[e];
-            const int4 quad = make_int4(ab1.x, ab1.y, ab2.x, ab2.y);                 // :171-172
-            const unsigned long long tag = ((unsigned long long)P.okey1[e] << 32) | ok2;
-            const uint32_t slot = atomicAdd(&st_n, 1u);
-            if (slot < uint32_t(kQuadStage)) { st_q[slot] = quad; st_t[slot] = tag; }
-            else {                                                                    // stage full (rare): direct append
-              const unsigned long long at = atomicAdd(P.K_dev, 1ull);
-              const unsigned long long mix = quad_mix(quad.x, quad.y, quad.z, quad.w);
-              atomicAdd(&s_qsum, mix);
-              if (at < P.K_cap) {
-                P.quads[at] = quad; P.tags[at] = tag;
-                if (P.do_gate) {
-                  float T[12];
-                  const int vd = gate_quad<ANGLE>(P.gate, quad, T);
-                  if (vd) { store_candidate(P.gate, atomicAdd(P.gate.C_dev, 1u), uint32_t(at) | (vd == 2 ? kBorderFlag : 0u), T); atomicAdd(&s_csum, mix); }
-                  else P.gate.counts[at] = kGateFailed;
-                }
-              } else atomicOr(P.overflow, 4u);
-            }
-          }
-          e = nxt;
+      if (i < end) {
+        const int2 ab = P.ab2[i];
+        const float p1x = P.ux[ab.x], p1y = P.uy[ab.x], p1z = P.uz[ab.x];
+        const float p2x = P.ux[ab.y], p2y = P.uy[ab.y], p2z = P.uz[ab.y];
+        const float nx = p2x - p1x, ny = p2y - p1y, nz = p2z - p1z;
+        const uint32_t cell = index_pos(p1x + P.invariant2 * nx, p1y + P.invariant2 * ny, p1z + P.invariant2 * nz, P.qg);
+        const unsigned long long mykey = ((unsigned long long)P.ht.epoch << 32) | cell;
+        uint32_t h = hash_cell(cell) & hmask;
+        while (true) {
+          const unsigned long long k = P.ht.keys[h];
+          if (k == mykey) { const unsigned long long hd = P.ht.heads[h]; e = (uint32_t(hd >> 32) == P.ht.epoch) ? uint32_t(hd) : kNil; break; }
+          if (uint32_t(k >> 32) != P.ht.epoch) break;
+          h = (h + 1u) & hmask;
         }
+      }
+      const unsigned long long m = __ballot(e != kNil);
+      if (lane == 0) s_ic[wave] = uint32_t(__popcll(m));
+      __syncthreads();
+      uint32_t before = 0;
+      for (uint32_t w = 0; w < wave; ++w) before += s_ic[w];
+      if (e != kNil) {
+        const uint32_t at = before + __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u));
+        s_item_i[at] = i; s_item_e[at] = e;
+      }
+      __syncthreads();
+    }
+    const uint32_t n_items = s_ic[0] + s_ic[1] + s_ic[2] + s_ic[3];
+    if (threadIdx.x < n_items) {
+      // phase B, one thread per pair with a chain: world point (super4pcs.cc:142) and the cone mask of its direction
+      // (normalset.hpp:174-196) into the thread's LDS row -- what a separate preparation launch used to do for EVERY pair
+      const uint32_t i = s_item_i[threadIdx.x];
+      uint32_t e = s_item_e[threadIdx.x];
+      const int2 ab2 = P.ab2[i];
+      const uint32_t ok2 = P.okey2[i];
+      uint32_t* row = s_mask + threadIdx.x * kMaskWords;
+      float4 eq;
+      { const float p1x = P.ux[ab2.x], p1y = P.uy[ab2.x], p1z = P.uz[ab2.x];
+        const float p2x = P.ux[ab2.y], p2y = P.uy[ab2.y], p2z = P.uz[ab2.y];
+        const float w1x = P.qx[ab2.x], w1y = P.qy[ab2.x], w1z = P.qz[ab2.x];
+        const float w2x = P.qx[ab2.y], w2y = P.qy[ab2.y], w2z = P.qz[ab2.y];
+        eq = make_float4(w1x + P.invariant2 * (w2x - w1x), w1y + P.invariant2 * (w2y - w1y), w1z + P.invariant2 * (w2z - w1z), 0.f);
+        cone_mask_row(P.cone, P.qg.nepsilon, p2x - p1x, p2y - p1y, p2z - p1z, row); }
+      // phase C: the walk is a chain of dependent gathers (one set-1 pair per hop), so each hop is ONE round trip: the hop's
+      // direction bucket, world point and successor are requested together; the bucket test reads the LDS row.
+      while (e != kNil) {
+        const uint32_t b = P.bucket1[e];
+        const float4 ep = P.ew1[e];
+        const uint32_t nxt = P.next1[e];
+        const float dx = eq.x - ep.x, dy = eq.y - ep.y, dz = eq.z - ep.z;
+        if (((row[b >> 5] >> (b & 31u)) & 1u) && sqn3(dx, dy, dz) <= P.thr) {       // super4pcs.cc:160
+          const int2 ab1 = P.ab1[e];
+          const int4 quad = make_int4(ab1.x, ab1.y, ab2.x, ab2.y);                 // :171-172
+          const unsigned long long tag = ((unsigned long long)P.okey1[e] << 32) | ok2;
+          const uint32_t slot = atomicAdd(&st_n, 1u);
+          if (slot < uint32_t(kQuadStage)) { st_q[slot] = quad; st_t[slot] = tag; }
+          else {                                                                    // stage full (rare): direct append
+            const unsigned long long at = atomicAdd(P.K_dev, 1ull);
+            const unsigned long long mix = quad_mix(quad.x, quad.y, quad.z, quad.w);
+            atomicAdd(&s_qsum, mix);
+            if (at < P.K_cap) {
+              P.quads[at] = quad; P.tags[at] = tag;
+              if (P.do_gate) {
+                float T[12];
+                const int vd = gate_quad<ANGLE>(P.gate, quad, T);
+                if (vd) { store_candidate(P.gate, atomicAdd(P.gate.C_dev, 1u), uint32_t(at) | (vd == 2 ? kBorderFlag : 0u), T); atomicAdd(&s_csum, mix); }
+                else P.gate.counts[at] = kGateFailed;
+              }
+            } else atomicOr(P.overflow, 4u);
+          }
+        }
+        e = nxt;
       }
     }
     __syncthreads();
@@ -1638,15 +1591,19 @@ struct SelectRecord {
 constexpr int32_t kSelectFound = 0, kSelectNoTriangle = 1, kSelectDegenerate = 2, kSelectNoFourth = 3;
 constexpr int kSelectTriangles = 1000;      // kNumberOfDiameterTrials, match4pcsBase.cc:58
 constexpr int kSelectDraws = 1 + 2 * kSelectTriangles;
+constexpr int kSelectBatch = 16;            // attempts one s4p_select_base_points_batch call evaluates at most
 
 __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int o) {
   const uint32_t lo = uint32_t(__shfl_xor(int(uint32_t(v)), o)), hi = uint32_t(__shfl_xor(int(uint32_t(v >> 32)), o));
   return (static_cast<unsigned long long>(hi) << 32) | lo;
 }
 
-__global__ __launch_bounds__(1024) void k_select_triangle(const float4* __restrict__ p4, const uint32_t* __restrict__ draws,
-                                                          float limit_sq, SelectRecord* rec) {
+// One workgroup per ATTEMPT (blockIdx.x): a batch of attempts of consecutive draws is evaluated by one set of launches.
+__global__ __launch_bounds__(1024) void k_select_triangle(const float4* __restrict__ p4, const uint32_t* __restrict__ draws_all,
+                                                          float limit_sq, SelectRecord* rec_all) {
   __shared__ unsigned long long s_key[16];
+  const uint32_t* draws = draws_all + size_t(blockIdx.x) * kSelectDraws;
+  SelectRecord* rec = rec_all + blockIdx.x;
   const uint32_t t = threadIdx.x;
   unsigned long long key = 0;
   const float4 o = p4[draws[0]];
@@ -1683,7 +1640,8 @@ __global__ __launch_bounds__(1024) void k_select_triangle(const float4* __restri
   rec->status = kSelectNoFourth;                // until k_select_fourth finds one
 }
 
-__global__ __launch_bounds__(256) void k_select_fourth(const float4* __restrict__ p4, uint32_t n_p, float too_small, SelectRecord* rec) {
+__global__ __launch_bounds__(256) void k_select_fourth(const float4* __restrict__ p4, uint32_t n_p, float too_small, SelectRecord* rec_all) {
+  SelectRecord* rec = rec_all + blockIdx.y;                // attempt = blockIdx.y
   if (rec->status != kSelectNoFourth) return;
   const float pa = rec->pa, pb = rec->pb, pc = rec->pc;
   const float4 A = p4[rec->ids[0]], B = p4[rec->ids[1]], Cc = p4[rec->ids[2]];
@@ -1702,7 +1660,8 @@ __global__ __launch_bounds__(256) void k_select_fourth(const float4* __restrict_
   if ((threadIdx.x & 63u) == 0 && key != ~0ull) atomicMin(&rec->fourth_key, key);
 }
 
-__global__ void k_select_finish(const float4* __restrict__ p4, SelectRecord* rec) {
+__global__ void k_select_finish(const float4* __restrict__ p4, SelectRecord* rec_all) {
+  SelectRecord* rec = rec_all + blockIdx.x;
   const uint32_t t = threadIdx.x;
   int32_t id = t < 3 ? rec->ids[t] : -1;
   if (t == 3 && rec->status == kSelectNoFourth && rec->fourth_key != ~0ull) id = int32_t(uint32_t(rec->fourth_key));

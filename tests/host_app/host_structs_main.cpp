@@ -86,7 +86,8 @@ static int run_fourth(unsigned seed) {
       const float A[3] = {x[i1], y[i1], z[i1]}, B[3] = {x[i2], y[i2], z[i2]}, C[3] = {x[i3], y[i3], z[i3]};
       const float ts = r % 7 == 0 ? 4.0f : (r % 3 == 0 ? 0.25f : 0.01f);      // 4.0: nothing qualifies -> -1
       const int want = literal_fourth(x, y, z, pa, pb, pc, A, B, C, ts);
-      const int got = idx.query(pa, pb, pc, A, B, C, ts);
+      static std::vector<float> scratch;
+      const int got = idx.query(pa, pb, pc, A, B, C, ts, scratch);
       bad += want != got; ++queries;
     }
   }
