@@ -123,6 +123,14 @@ int32_t s4p_chunk_stats(const s4p_ctx* ctx, uint64_t* out4);
  * bounds only: the counts of abandoned candidates and a base's best_count when it does not exceed n.  0 = off (default). */
 int32_t s4p_set_best_hint(s4p_ctx* ctx, uint32_t best_count);
 
+/* One base over several GPUs (SURVEY.md 8e level 2).  After s4p_set_quad_slice(ctx, part, parts) every fused pass of this
+ * context enumerates, gates and scores only the part-th of `parts` equal shares of the base's SECOND pair set (both pair
+ * sets and the set-1 structure are still built in full: they are cheap next to the candidates); s4p_base_result then
+ * describes that share: its quads, candidates, checksums, and its best candidate with the order tag (best_rank) that lets a
+ * driver pick, among the shares, the greatest count and -- at equal counts -- the smallest tag, i.e. the reference's first
+ * maximum (match4pcsBase.hpp:467-484).  The sharded driver does (s4p_shard_set_mode, s4p_matcher.h). */
+int32_t s4p_set_quad_slice(s4p_ctx* ctx, uint32_t part, uint32_t parts);
+
 /* options.max_angle (shared4pcs.h:160).  > 0: the segment-angle pair filter acosf(segment1 . segment2) <= max_angle
  * (pairCreationFunctor.h:203-212) runs on the device as an exact cosine threshold (the smallest float whose libm acosf
  * passes, found with libm at s4p_create).  >= 0: the Euler-angle bound of ComputeRigidTransformation

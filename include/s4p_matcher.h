@@ -198,6 +198,13 @@ int32_t s4p_shard_use_collective(s4p_shard* s, const s4p_collective* coll);
 /* Measurement aid: the shard plays one rank of its world alone (reduction = own key, broadcast = no-op), so that the
  * per-window cost of a rank at a given world size can be measured on one GPU (tools/sim_world.py). */
 int32_t s4p_shard_use_null_collective(s4p_shard* s);
+/* How the job is spread over the ranks.  0 (default): trials sharded by base -- rank (t mod world) runs trial t, one
+ * all-reduce per window of `world` trials.  1: EVERY base over all ranks (SURVEY.md 8e level 2) -- each rank runs every
+ * trial on its share of the base's second pair set (s4p_set_quad_slice), two 8-byte all-reduce(MAX) per trial pick the
+ * base's first maximum among the shares, one broadcast carries the winner when it improves the best LCP.  For bases that
+ * take seconds each (the 20 000-point sample: ~10^9 quads per base) or jobs with fewer trials than GPUs; in this mode the
+ * "windows" of s4p_shard_run_windows are single trials.  Call after s4p_shard_create, before the matcher is initialised. */
+int32_t s4p_shard_set_mode(s4p_shard* s, int32_t mode);
 /* n_windows windows (n_windows * world trials of the common sequence) through the pipelined loop; *candidates_local = candidates
  * this rank verified, *terminated = the terminate threshold was crossed (later windows are drained, not committed). */
 int32_t s4p_shard_run_windows(s4p_shard* s, int32_t n_windows, uint64_t* candidates_local, int32_t* terminated);
@@ -212,6 +219,12 @@ int32_t s4p_shard_replay(int32_t rank, int32_t world, const s4p_collective* coll
                          uint32_t threshold_count, uint32_t start_best_count, const int32_t* found,
                          const s4p_base_result* results, int32_t* commit_trials, uint32_t* commit_counts, int32_t commit_cap,
                          int32_t* n_commits, int32_t* terminated, uint64_t* trials_done);
+
+/* The same self-check for the split-base mode: results[t] = THIS rank's share of trial t (best_rank = its order tag). */
+int32_t s4p_shard_replay_split(int32_t rank, int32_t world, const s4p_collective* coll, int32_t n_trials, int32_t depth,
+                               uint32_t threshold_count, uint32_t start_best_count, const int32_t* found,
+                               const s4p_base_result* results, int32_t* commit_trials, uint32_t* commit_counts, uint64_t* commit_tags,
+                               int32_t commit_cap, int32_t* n_commits, int32_t* terminated, uint64_t* trials_done);
 
 #ifdef __cplusplus
 }

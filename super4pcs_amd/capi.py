@@ -21,7 +21,7 @@ EXPORTED_SYMBOLS = [
     "s4p_create", "s4p_destroy", "s4p_last_error", "s4p_device_name", "s4p_set_clouds", "s4p_set_base",
     "s4p_extract_pairs", "s4p_find_congruent", "s4p_try_congruent_set", "s4p_verify_transforms", "s4p_verify_transforms_counted",
     "s4p_transform_points_device", "s4p_apply_bench", "s4p_select_base_points", "s4p_grow_limits", "s4p_get_limits", "s4p_try_base", "s4p_last_verified", "s4p_try_base_async", "s4p_try_base_wait", "s4p_pair_state_words", "s4p_pair_state_save", "s4p_pair_state_restore", "s4p_stage_slots", "s4p_pipeline_depth", "s4p_stage_base", "s4p_try_base_staged_async", "s4p_skip_base", "s4p_last_candidates", "s4p_transform_points", "s4p_profile_enable", "s4p_profile_get",
-    "s4p_selftest_ieee", "s4p_set_quad_chunking", "s4p_chunk_stats", "s4p_set_auto_grow", "s4p_lane_growths", "s4p_border_stats", "s4p_set_clouds_timing", "s4p_set_best_hint", "s4p_select_base_points_batch", "s4p_select_batch_max", "s4p_quad_mix",
+    "s4p_selftest_ieee", "s4p_set_quad_chunking", "s4p_chunk_stats", "s4p_set_auto_grow", "s4p_lane_growths", "s4p_border_stats", "s4p_set_clouds_timing", "s4p_set_best_hint", "s4p_select_base_points_batch", "s4p_select_batch_max", "s4p_set_quad_slice", "s4p_quad_mix",
 ]
 
 
@@ -339,7 +339,7 @@ class MatcherInfo(C.Structure):
 
 SHARD_SYMBOLS = [
     "s4p_rccl_unique_id", "s4p_shard_create", "s4p_shard_destroy", "s4p_shard_last_error", "s4p_shard_use_rccl",
-    "s4p_shard_use_collective", "s4p_shard_use_null_collective", "s4p_shard_run_windows", "s4p_shard_compute_transformation", "s4p_shard_replay",
+    "s4p_shard_use_collective", "s4p_shard_use_null_collective", "s4p_shard_set_mode", "s4p_shard_replay_split", "s4p_shard_run_windows", "s4p_shard_compute_transformation", "s4p_shard_replay",
     "s4p_matcher_terminate_threshold", "s4p_matcher_max_time_seconds", "s4p_matcher_init_generation",
 ]
 MATCHER_SYMBOLS = [
@@ -743,6 +743,12 @@ class Shard:
         buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
         self._chk(self.L.s4p_shard_use_rccl(self.h, device, buf))
 
+    def set_mode(self, split_bases):
+        """False: trials sharded by base (default).  True: every base over all ranks (SURVEY 8e level 2); before init."""
+        self.L.s4p_shard_set_mode.restype = C.c_int32
+        self.L.s4p_shard_set_mode.argtypes = [C.c_void_p, C.c_int32]
+        self._chk(self.L.s4p_shard_set_mode(self.h, int(bool(split_bases))))
+
     def use_null_collective(self):
         self.L.s4p_shard_use_null_collective.restype = C.c_int32
         self.L.s4p_shard_use_null_collective.argtypes = [C.c_void_p]
@@ -766,6 +772,27 @@ class Shard:
         lcp = C.c_float()
         self._chk(self.L.s4p_shard_compute_transformation(self.h, C.byref(vp.view), C.byref(vq.view), _f(qx), _f(qy), _f(qz), _f(M), C.byref(lcp)))
         return lcp.value, M.reshape(4, 4), np.stack([qx, qy, qz], axis=1)
+
+
+def shard_replay_split(rank, world, coll, found, results, depth, threshold_count, start_best):
+    """s4p_shard_replay_split: the C++ split-base loop on the recorded results of this rank's shares (host only)."""
+    L = load_library(); _declare_shard(L)
+    L.s4p_shard_replay_split.restype = C.c_int32
+    L.s4p_shard_replay_split.argtypes = [C.c_int32, C.c_int32, C.POINTER(Collective), C.c_int32, C.c_int32, C.c_uint32, C.c_uint32,
+                                         C.POINTER(C.c_int32), C.POINTER(BaseResult), C.POINTER(C.c_int32), C.POINTER(C.c_uint32),
+                                         C.POINTER(C.c_uint64), C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]
+    n = len(found)
+    f = (C.c_int32 * n)(*[int(x) for x in found])
+    r = (BaseResult * n)(*results)
+    cap = n + 4
+    ct = (C.c_int32 * cap)(); cc = (C.c_uint32 * cap)(); cg = (C.c_uint64 * cap)()
+    nc = C.c_int32(); term = C.c_int32(); td = C.c_uint64()
+    rc = L.s4p_shard_replay_split(rank, world, C.byref(coll), n, depth, threshold_count, start_best, f, r, ct, cc, cg, cap,
+                                  C.byref(nc), C.byref(term), C.byref(td))
+    if rc != S4P_OK:
+        raise S4PError(rc, "s4p_shard_replay_split failed")
+    k = min(nc.value, cap)
+    return [(ct[i], cc[i], cg[i]) for i in range(k)], bool(term.value), int(td.value)
 
 
 def shard_replay(rank, world, coll, found, results, depth, threshold_count, start_best):

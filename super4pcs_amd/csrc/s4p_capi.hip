@@ -151,6 +151,8 @@ struct s4p_ctx {
   bool auto_grow = true; uint64_t lane_growths = 0;
   // s4p_set_best_hint: candidates that cannot EXCEED this inlier count may be abandoned by k_verify (0 = count all in full)
   uint32_t best_hint = 0;
+  // s4p_set_quad_slice: this context enumerates only its share of every base's second pair set (SURVEY 8e level 2)
+  uint32_t slice_num = 0, slice_den = 0;
   // max_angle (shared4pcs.h:160): > 0 -> the segment-angle pair filter through an exact cosine threshold; >= 0 -> the
   // Euler-angle bound of ComputeRigidTransformation, decided on the device up to a margin and settled on the host
   float cos_min = -1.f; bool angle_pairs = false; float angle_tol = 1e-6f;   // S4P_ANGLE_TOL (read at creation) widens the device margin: a test aid
@@ -361,6 +363,7 @@ int32_t quad_params(s4p_ctx* c, float inv1, float inv2, float thr2, PrepParams& 
   Q.m2_dev = &L.ctr.p->m2; Q.cap2 = uint32_t(L.cap_pairs); Q.ht = ht; Q.thr = thr2;
   Q.quads = L.quads.p; Q.tags = L.tags.p; Q.K_dev = &L.ctr.p->K; Q.K_cap = uint32_t(L.cap_quads); Q.overflow = &L.ctr.p->overflow;
   Q.r0 = 0u; Q.r1 = 0xFFFFFFFFu; Q.qsum_dev = &L.ctr.p->quad_sum; Q.csum_dev = &L.ctr.p->cand_sum;
+  Q.slice_num = c->slice_num; Q.slice_den = c->slice_den;
   Q.do_gate = 0;
   return S4P_OK;
 }
@@ -561,9 +564,13 @@ int32_t run_chunked(s4p_ctx* c, const DevCounters& first, s4p_base_result* r) {
   const uint64_t Ktot = first.K;
   const uint64_t target = std::max<uint64_t>(L.cap_quads * 6 / 10, 1);          // entries are in append order, i.e. shuffled: ranges are even
   const uint64_t nch = (Ktot + target - 1) / target;
-  const uint32_t step = uint32_t(std::max<uint64_t>(1, (uint64_t(m2) + nch - 1) / nch));
+  const uint64_t share = Q.slice_den ? std::max<uint64_t>(1, uint64_t(m2) / Q.slice_den) : uint64_t(m2);
+  const uint32_t step = uint32_t(std::max<uint64_t>(1, (share + nch - 1) / nch));
   std::vector<std::pair<uint32_t, uint32_t>> todo;
-  for (uint64_t a = 0; a < m2; a += step) todo.emplace_back(uint32_t(a), uint32_t(std::min<uint64_t>(a + step, m2)));
+  uint64_t lo = 0, hi = m2;                                // this context's share of the set (s4p_set_quad_slice), as k_quads computes it
+  if (Q.slice_den) { lo = (uint64_t(m2) * Q.slice_num) / Q.slice_den; hi = (uint64_t(m2) * (Q.slice_num + 1u)) / Q.slice_den; }
+  Q.slice_den = 0u;                                        // the chunk passes carry explicit ranges
+  for (uint64_t a = lo; a < hi; a += step) todo.emplace_back(uint32_t(a), uint32_t(std::min<uint64_t>(a + step, hi)));
   std::reverse(todo.begin(), todo.end());
   uint64_t Ksum = 0, Csum = 0, qsum = 0, csum = 0;
   DevCounters best{}; bool have = false;
@@ -893,6 +900,13 @@ int32_t s4p_border_stats(const s4p_ctx* c, uint64_t* out2) {
 // abandoned candidates (s4p_last_candidates, s4p_last_verified) and a base's best_count AT OR BELOW the hint are lower
 // bounds.  0 (the default) = every candidate is counted in full.
 int32_t s4p_set_best_hint(s4p_ctx* c, uint32_t best_count) { if (!c) return S4P_ERR_BAD_ARG; c->best_hint = best_count; return S4P_OK; }
+// SURVEY 8e level 2: this context takes the `part`-th of `parts` equal shares of every base's second pair set (its quads,
+// candidates and their best); parts = 0 or 1 restores the whole set.  Pairs and the set-1 hash are still built in full.
+int32_t s4p_set_quad_slice(s4p_ctx* c, uint32_t part, uint32_t parts) {
+  if (!c || (parts && part >= parts)) return S4P_ERR_BAD_ARG;
+  c->slice_num = parts > 1 ? part : 0u; c->slice_den = parts > 1 ? parts : 0u;
+  return S4P_OK;
+}
 // Lanes growing their own buffers when a base overflows (on by default); s4p_lane_growths counts the regrowths.
 int32_t s4p_set_auto_grow(s4p_ctx* c, int32_t enable) { if (!c) return S4P_ERR_BAD_ARG; c->auto_grow = enable != 0; return S4P_OK; }
 int64_t s4p_lane_growths(const s4p_ctx* c) { return c ? int64_t(c->lane_growths) : 0; }

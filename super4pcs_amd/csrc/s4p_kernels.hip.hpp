@@ -1193,6 +1193,7 @@ struct QuadParams {
   float thr;                   // distance_threshold2 (compared against a SQUARED norm: quirk super4pcs.cc:160)
   int4* quads; unsigned long long* tags; unsigned long long* K_dev; uint32_t K_cap; uint32_t* overflow;
   uint32_t r0, r1;                                       // set-2 entries [r0, min(r1, m2)): the whole set, or one chunk of a base whose quads do not fit
+  uint32_t slice_num, slice_den;                         // slice_den != 0: only the slice_num-th of slice_den equal parts of the set (one GPU's share of a base)
   unsigned long long* qsum_dev; unsigned long long* csum_dev;   // checksums (DevCounters::quad_sum / cand_sum)
   int do_gate; GateParams gate;                          // fused path: gate every quad as it is appended
 };
@@ -1224,12 +1225,17 @@ __global__ __launch_bounds__(256) void k_quads(QuadParams P) {
   __shared__ uint32_t st_n, s_wc[4], s_cbase, s_ic[4];
   __shared__ uint32_t s_item_i[256], s_item_e[256];        // the tile's pairs whose cell holds a set-1 pair, compacted
   __shared__ uint32_t s_mask[256 * kMaskWords];            // each thread's direction mask (row stride 11: conflict-free)
-  const uint32_t end = min(min(*P.m2_dev, P.cap2), P.r1);
+  const uint32_t m2 = min(*P.m2_dev, P.cap2);
+  uint32_t begin = P.r0, end = min(m2, P.r1);
+  if (P.slice_den) {                                       // (m2 only exists on the device when the pass is enqueued)
+    begin = max(begin, uint32_t((uint64_t(m2) * P.slice_num) / P.slice_den));
+    end = min(end, uint32_t((uint64_t(m2) * (P.slice_num + 1u)) / P.slice_den));
+  }
   const uint32_t hmask = hash_mask(P.ht);
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   if (threadIdx.x == 0) { st_n = 0; s_qsum = 0ull; s_csum = 0ull; }
   __syncthreads();
-  for (uint32_t i0 = P.r0 + blockIdx.x * blockDim.x; i0 < end; i0 += gridDim.x * blockDim.x) {
+  for (uint32_t i0 = begin + blockIdx.x * blockDim.x; i0 < end; i0 += gridDim.x * blockDim.x) {
     // phase A, one thread per set-2 pair of the tile: invariant point -> cell -> head of the cell's set-1 chain (super4pcs.cc:141,
     // normalset.hpp:162-171).  Typically well under half of the pairs fall into a cell that holds a set-1 pair; those are
     // compacted (ballot + per-wave offsets) so that the expensive part below runs on DENSE waves.

@@ -311,10 +311,92 @@ struct Loop {
   }
 };
 
+// ---- SURVEY 8e level 2: every base over ALL ranks ---------------------------------------------------------------------
+// Every rank runs every trial, but enumerates, gates and scores only its share of the base's second pair set
+// (s4p_set_quad_slice).  Per trial two 8-byte all-reduce(MAX) pick the base's winner among the shares exactly as a single
+// pass would -- greatest inlier count, then smallest order tag (match4pcsBase.hpp:467-484):
+//   key A = (count + 1) << 32 | (0xFFFFFFFF - tag.hi)      (0 = this share verified nothing)
+//   key B = (0xFFFFFFFF - tag.lo) << 16 | (rank + 1)       from the ranks whose (count, tag.hi) won A, else 0
+// and one broadcast from the rank B names carries the winner's record when it improves the registration's best.  For
+// bases that take seconds (the 20 000-point sample) the three collectives are noise; for cheap bases sharding by base
+// (the window loop above) is the mode to use.
+struct SplitOps {
+  std::function<int32_t(bool* found, int32_t ids[4])> prepare;           // enqueue this rank's share of the next trial
+  std::function<int32_t(s4p_base_result*)> wait_own;
+  std::function<int32_t(const int32_t ids[4], const s4p_base_result*, bool* ok)> commit;
+  int depth = 2;
+};
+struct SplitLoop {
+  int rank = 0, world = 1;
+  Collective* coll = nullptr;
+  SplitOps ops;
+  uint32_t best_count = 0;
+  bool terminated = false;
+  uint64_t trials_done = 0, local_candidates = 0;
+  std::string err;
+  int32_t fail(int32_t rc, const std::string& m) { err = m; return rc; }
+
+  int32_t reduce_and_commit(const BaseId& b, const s4p_base_result& r) {
+    const bool usable = b.found && r.n_pairs1 && r.n_pairs2 && r.n_quads && r.has_best;
+    const uint32_t thi = uint32_t(r.best_rank >> 32), tlo = uint32_t(r.best_rank);
+    uint64_t a = usable ? ((uint64_t(r.best_count) + 1ull) << 32) | uint64_t(0xFFFFFFFFu - thi) : 0ull, ga = 0;
+    if (b.found && !usable && r.n_pairs1 == ~0ull) a = kErrorKey;             // (a rank whose pass failed: see run())
+    if (int32_t rc = coll->post(0, a)) return fail(rc, coll->err);
+    if (int32_t rc = coll->result(0, &ga)) return fail(rc, coll->err);
+    if (ga == kErrorKey) return fail(S4P_ERR_STATE, "a rank of the sharded job failed on this base (see that rank's error)");
+    const uint64_t kb = (ga != 0 && a == ga) ? (uint64_t(0xFFFFFFFFu - tlo) << 16) | uint64_t(rank + 1) : 0ull;
+    uint64_t gb = 0;
+    if (int32_t rc = coll->post(1, kb)) return fail(rc, coll->err);
+    if (int32_t rc = coll->result(1, &gb)) return fail(rc, coll->err);
+    if (ga == 0 || gb == 0) return S4P_OK;                                     // no share of this base verified a candidate
+    const uint32_t win_count = uint32_t(ga >> 32) - 1u;
+    const int root = int(gb & 0xFFFFull) - 1;
+    if (root < 0 || root >= world) return fail(S4P_ERR_STATE, "corrupt split-base key");
+    if (win_count > best_count) {                                              // only an improvement travels (and is committed)
+      s4p_base_result wr = r;
+      if (int32_t rc = coll->broadcast(&wr, sizeof wr, root)) return fail(rc, coll->err);
+      wr.n_quads = std::max<uint64_t>(wr.n_quads, 1);                          // (some share had quads: TryOneBase went on to TryCongruentSet)
+      bool ok = false;
+      if (int32_t rc = ops.commit(b.ids, &wr, &ok)) return rc;
+      best_count = wr.best_count;
+      terminated = terminated || ok;
+    }
+    return S4P_OK;
+  }
+  // n trials, `depth` of them in flight on the device; the reduction of trial t runs while t+1 .. t+depth-1 compute
+  int32_t run(int n) {
+    std::deque<BaseId> inflight;
+    auto drain_one = [&]() -> int32_t {
+      BaseId b = inflight.front(); inflight.pop_front();
+      s4p_base_result r; std::memset(&r, 0, sizeof r);
+      int32_t rc = S4P_OK;
+      if (b.found) rc = ops.wait_own(&r);
+      if (rc != S4P_OK) { std::memset(&r, 0, sizeof r); r.n_pairs1 = ~0ull; b.found = true; }     // tell the others, then leave
+      local_candidates += rc == S4P_OK ? r.n_verified : 0;
+      ++trials_done;
+      if (terminated) return rc;                            // drained, not committed (the sequential loop would not have run it)
+      const std::string keep = err;
+      const int32_t rc2 = reduce_and_commit(b, r);
+      if (rc != S4P_OK) { err = keep; return rc; }
+      return rc2;
+    };
+    for (int t = 0; t < n && !terminated; ++t) {
+      BaseId b;
+      if (int32_t rc = ops.prepare(&b.found, b.ids)) return rc;               // (a failed prepare is symmetric: every rank selects the same base)
+      inflight.push_back(b);
+      if (int(inflight.size()) >= ops.depth) if (int32_t rc = drain_one()) return rc;
+    }
+    while (!inflight.empty()) if (int32_t rc = drain_one()) return rc;
+    return S4P_OK;
+  }
+};
+
 }  // namespace
 
 struct s4p_shard {
   s4p_matcher* m = nullptr;
+  int mode = 0;                        // 0: trials sharded by base (window loop), 1: every base split over all ranks
+  SplitLoop split;
   int64_t init_generation = -1;        // the matcher initialisation the loop state belongs to
   Loop loop;
   Collective* coll = nullptr;
@@ -371,9 +453,58 @@ int32_t s4p_shard_use_collective(s4p_shard* s, const s4p_collective* coll) {
   return S4P_OK;
 }
 
+int32_t s4p_shard_set_mode(s4p_shard* s, int32_t mode) {
+  if (!s || (mode != 0 && mode != 1)) return S4P_ERR_BAD_ARG;
+  s4p_matcher* m = s->m;
+  // split mode: this rank runs EVERY trial (it owns them all as far as base selection and staging go) on its share of the quads
+  if (int32_t rc = s4p_matcher_set_sharding(m, mode ? 0 : s->loop.rank, mode ? 1 : s->loop.world, 1)) return rc;
+  if (int32_t rc = s4p_set_quad_slice(s4p_matcher_ctx(m), mode ? uint32_t(s->loop.rank) : 0u, mode ? uint32_t(s->loop.world) : 0u)) return rc;
+  s->mode = mode;
+  return S4P_OK;
+}
+
+static int32_t shard_run_split(s4p_shard* s, int32_t n_trials, uint64_t* candidates_local, int32_t* terminated) {
+  s4p_matcher* m = s->m;
+  s4p_matcher_info info;
+  if (int32_t rc = s4p_matcher_get_info(m, &info)) { s->err = s4p_matcher_last_error(m); return rc; }
+  SplitLoop& L = s->split;
+  if (s->init_generation != s4p_matcher_init_generation(m)) { s->init_generation = s4p_matcher_init_generation(m); L.terminated = false; L.trials_done = 0; }
+  L.rank = s->loop.rank; L.world = s->loop.world; L.coll = s->coll;
+  L.best_count = info.best_count;
+  L.ops.depth = std::max(1, s4p_pipeline_depth(s4p_matcher_ctx(m)));
+  L.ops.prepare = [m, s](bool* found, int32_t ids[4]) -> int32_t {
+    int32_t f = 0;
+    const int32_t rc = s4p_matcher_next_base_async(m, 1, &f, ids);
+    if (rc) s->err = s4p_matcher_last_error(m);
+    *found = f != 0;
+    return rc;
+  };
+  L.ops.wait_own = [m, s](s4p_base_result* r) -> int32_t {
+    const int32_t rc = s4p_matcher_wait_base(m, r);
+    if (rc) s->err = s4p_matcher_last_error(m);
+    return rc;
+  };
+  L.ops.commit = [m, s](const int32_t ids[4], const s4p_base_result* r, bool* ok) -> int32_t {
+    int32_t o = 0;
+    const int32_t rc = s4p_matcher_commit(m, 1, ids, r, &o);
+    if (rc) s->err = s4p_matcher_last_error(m);
+    *ok = o != 0;
+    return rc;
+  };
+  const uint64_t before = L.local_candidates;
+  (void)s4p_matcher_loop_begin(m);
+  const int32_t rc = L.run(n_trials);
+  (void)s4p_matcher_loop_end(m);
+  if (rc && s->err.empty()) s->err = L.err;
+  if (candidates_local) *candidates_local = L.local_candidates - before;
+  if (terminated) *terminated = L.terminated ? 1 : 0;
+  return rc;
+}
+
 int32_t s4p_shard_run_windows(s4p_shard* s, int32_t n_windows, uint64_t* candidates_local, int32_t* terminated) {
   if (!s || n_windows < 0) return S4P_ERR_BAD_ARG;
   if (!s->coll) { s->err = "no collective: call s4p_shard_use_rccl or s4p_shard_use_collective first"; return S4P_ERR_STATE; }
+  if (s->mode == 1) return shard_run_split(s, n_windows, candidates_local, terminated);      // (split mode: a "window" is one trial)
   s4p_matcher* m = s->m;
   s4p_matcher_info info;
   if (int32_t rc = s4p_matcher_get_info(m, &info)) { s->err = s4p_matcher_last_error(m); return rc; }
@@ -439,12 +570,13 @@ int32_t s4p_shard_compute_transformation(s4p_shard* s, const s4p_cloud_view* P, 
     int i_stop = N - 1;
     for (int i = 0; i < N; ++i) if (float(i) / float(N) >= 0.99f) { i_stop = i; break; }
     s->loop.trial_limit = uint64_t(i_stop) + 1u;
-    const int world = s->loop.world;
+    const int world = s->mode == 1 ? 1 : s->loop.world;       // split mode: one trial per "window", all ranks on it
     const int windows = (i_stop + 1 + world - 1) / world;
     const auto t0 = std::chrono::system_clock::now();
     const long max_seconds = long(s4p_matcher_max_time_seconds(m));
     // in slices, so that a crossed threshold or the time budget stops the job within a few windows
-    for (int done = 0; done < windows && !s->loop.terminated;) {
+    s->split.terminated = false; s->split.trials_done = 0;
+    for (int done = 0; done < windows && !s->loop.terminated && !s->split.terminated;) {
       const int n = std::min(windows - done, 8 * std::max(1, s4p_pipeline_depth(s4p_matcher_ctx(m))));
       int32_t term = 0;
       if (int32_t rc = s4p_shard_run_windows(s, n, nullptr, &term)) return rc;
@@ -512,6 +644,51 @@ int32_t s4p_shard_replay(int32_t rank, int32_t world, const s4p_collective* coll
     return S4P_OK;
   };
   const int32_t rc = L.run(n_windows);
+  if (terminated) *terminated = L.terminated ? 1 : 0;
+  if (trials_done) *trials_done = L.trials_done;
+  return rc;
+}
+
+// Host-only self-check of the split-base loop (no matcher, no GPU): this rank replays the recorded results of ITS share of
+// every trial (found[t], results[t]) through the same SplitLoop and the given collective, and logs every commit.
+int32_t s4p_shard_replay_split(int32_t rank, int32_t world, const s4p_collective* coll, int32_t n_trials, int32_t depth,
+                               uint32_t threshold_count, uint32_t start_best_count, const int32_t* found,
+                               const s4p_base_result* results, int32_t* commit_trials, uint32_t* commit_counts, uint64_t* commit_tags,
+                               int32_t commit_cap, int32_t* n_commits, int32_t* terminated, uint64_t* trials_done) {
+  if (!coll || !coll->allreduce_max_u64 || !coll->broadcast || world < 1 || rank < 0 || rank >= world || !found || !results || !n_commits)
+    return S4P_ERR_BAD_ARG;
+  CallbackCollective cc(*coll);
+  SplitLoop L;
+  L.rank = rank; L.world = world; L.coll = &cc; L.best_count = start_best_count;
+  L.ops.depth = std::max(1, depth);
+  int prepared = 0;
+  std::deque<int> own;
+  *n_commits = 0;
+  L.ops.prepare = [&](bool* f, int32_t ids[4]) -> int32_t {
+    ids[0] = prepared; ids[1] = ids[2] = ids[3] = 0;
+    *f = found[prepared] != 0;
+    if (*f) own.push_back(prepared);
+    ++prepared;
+    return S4P_OK;
+  };
+  L.ops.wait_own = [&](s4p_base_result* r) -> int32_t {
+    if (own.empty()) return S4P_ERR_STATE;
+    *r = results[own.front()];
+    own.pop_front();
+    if (r->n_quads == ~0ull) { L.err = "injected failure of this rank's device pass"; return S4P_ERR_CAPACITY; }
+    return S4P_OK;
+  };
+  L.ops.commit = [&](const int32_t ids[4], const s4p_base_result* r, bool* ok) -> int32_t {
+    if (*n_commits < commit_cap) {
+      if (commit_trials) commit_trials[*n_commits] = ids[0];
+      if (commit_counts) commit_counts[*n_commits] = r->best_count;
+      if (commit_tags) commit_tags[*n_commits] = r->best_rank;
+    }
+    ++*n_commits;
+    *ok = r->best_count > threshold_count;
+    return S4P_OK;
+  };
+  const int32_t rc = L.run(n_trials);
   if (terminated) *terminated = L.terminated ? 1 : 0;
   if (trials_done) *trials_done = L.trials_done;
   return rc;

@@ -182,3 +182,53 @@ def test_native_loop_over_rccl_whole_registration(oracle_mod, s4p_lib_built):
     o_lcp, o_M, _ = om.compute_transformation(P, Q)
     assert r[0] == o_lcp and np.max(np.abs(np.array(r[1], np.float32) - o_M)) <= 1e-4
     assert r[2] == om.stats().n_verified
+
+
+# ---- SURVEY 8e level 2: every base split over the ranks (s4p_shard_set_mode(1), s4p_set_quad_slice) ---------------------
+def _split_worker(rank, world, port, n_trials, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from super4pcs_amd import capi
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    P, Q, _ = H.small_pair(30000, delta=DELTA, seed=23)
+    m = capi.Matcher(capi.make_options(DELTA, OVERLAP, N_S), device=0, max_pairs=1 << 20, max_quads=4 << 20)
+    sh = capi.Shard(m, rank, world, producer_threads=True)
+    sh.set_mode(True)                                         # this rank: its share of every base's second pair set
+    m.init_full(P, Q)
+    sh.use_collective(capi.torch_collective(dist))
+    got = sh.run_windows(n_trials)                            # split mode: one trial per window
+    i = m.info()
+    q.put((rank, float(i.best_lcp), list(i.base), list(i.congruent), list(i.transform), int(got), int(i.quads_total)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_split_bases_over_ranks_match_the_sequential_oracle(oracle_mod, s4p_lib_built, world):
+    """Every base over all ranks: each rank enumerates, gates and scores its share of the base's second pair set, two
+    all-reduces pick the first maximum among the shares.  Every rank must end in the sequential oracle's state, every
+    candidate (and every quad) must have been handled on exactly one rank."""
+    import torch.multiprocessing as mp
+    n_trials = 16
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_split_worker, args=(r, world, port, n_trials, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    O = oracle_mod
+    P, Q, _ = H.small_pair(30000, delta=DELTA, seed=23)
+    om = O.Matcher(O.make_options(DELTA, OVERLAP, N_S))
+    om.init(P, Q)
+    for _ in range(n_trials):
+        om.try_one_base()
+    T, lcp, base, cong, _, _ = om.best()
+    for r in res:
+        assert r[1] == lcp and r[2] == base.tolist() and r[3] == cong.tolist()
+        assert np.array_equal(np.array(r[4], np.float32).reshape(4, 4), T)
+    assert sum(r[5] for r in res) == om.stats().n_verified and all(r[5] > 0 for r in res)
+    assert sum(r[6] for r in res) == om.stats().n_quads

@@ -130,3 +130,97 @@ def test_a_failing_rank_takes_every_rank_out_of_the_loop(world, fail_rank, fail_
     for rank, tag, code, _ in res:
         assert tag == "error"
         assert code == (-5 if rank == fail_rank else -7)        # the failing rank keeps its own error; the others: S4P_ERR_STATE
+
+
+# ---- SURVEY 8e level 2: every base split over all ranks (SplitLoop in s4p_shard.cpp) -------------------------------------
+def split_table(seed, n_trials, world):
+    """Per trial: found (same on every rank: all ranks select the same base) and, per rank, its share's (usable, count, tag)."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n_trials):
+        found = bool(rng.random() < 0.9)
+        shares = []
+        for _r in range(world):
+            usable = bool(rng.random() < 0.8)
+            count = int(rng.integers(0, 12 if rng.random() < 0.5 else N_Q))       # many ties on small counts: the tag decides
+            tag = (int(rng.integers(0, 1 << 12)) << 32) | int(rng.integers(0, 1 << 32))   # few distinct high words: the low word decides too
+            shares.append((usable, count, tag))
+        out.append((found, shares))
+    return out
+
+
+def split_sequential(table, start_best, threshold_count):
+    best, commits = start_best, []
+    for t, (found, shares) in enumerate(table):
+        cand = [(c, -tag) for (u, c, tag) in shares if found and u]
+        if cand:
+            c, ntag = max(cand)                                     # greatest count, then smallest tag: the base's first maximum
+            if c > best:
+                best = c
+                commits.append((t, c, -ntag))
+        if best > threshold_count:
+            break
+    return commits
+
+
+def _split_worker(rank, world, port, seed, n_trials, threshold_count, depth, q, fail_at=None):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from super4pcs_amd import capi
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    table = split_table(seed, n_trials, world)
+    found, results = [], []
+    for t, (f, shares) in enumerate(table):
+        usable, count, tag = shares[rank]
+        r = capi.BaseResult()
+        r.n_pairs1 = r.n_pairs2 = 10
+        if usable:
+            r.n_quads = 10; r.n_verified = 5; r.best_count = count; r.has_best = 1; r.best_rank = tag
+            r.best_quad[0] = t; r.best_quad[1] = rank
+        if fail_at == (rank, t):
+            f = True
+            r.n_quads = 2 ** 64 - 1
+        found.append(f)
+        results.append(r)
+    coll = capi.torch_collective(dist)
+    try:
+        commits, terminated, trials_done = capi.shard_replay_split(rank, world, coll, found, results, depth, threshold_count, 3)
+        q.put((rank, commits, terminated, trials_done))
+    except capi.S4PError as e:
+        q.put((rank, "error", e.code, 0))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_split(world, seed, n_trials, threshold_count, depth, fail_at=None):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_split_worker, args=(r, world, port, seed, n_trials, threshold_count, depth, q, fail_at)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return res
+
+
+@pytest.mark.parametrize("world,seed,depth,thr", [(2, 1, 3, N_Q), (4, 2, 1, N_Q), (4, 3, 3, 95), (2, 9, 2, 93)])
+def test_split_base_loop_commits_equal_the_sequential_loop(world, seed, depth, thr, s4p_lib_built):
+    """Every base split over all ranks: the two all-reduces must pick, per base, the greatest count and among equal counts the
+    smallest order tag over ALL shares (the reference's first maximum), commit it only when it improves the best, and stop at
+    the first base that crosses the terminate threshold -- on every rank alike."""
+    n_trials = 40
+    want = split_sequential(split_table(seed, n_trials, world), 3, thr)
+    assert len(want) >= 2, "seed produces no improvements; pick another"
+    for rank, commits, terminated, trials_done in _run_split(world, seed, n_trials, thr, depth):
+        assert commits == want
+        assert terminated == (want[-1][1] > thr)
+
+
+def test_split_base_loop_a_failing_rank_takes_every_rank_out(s4p_lib_built):
+    res = _run_split(3, 5, 20, N_Q, 2, fail_at=(1, 6))
+    for rank, tag, code, _ in res:
+        assert tag == "error" and code == (-5 if rank == 1 else -7)
