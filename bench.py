@@ -473,6 +473,9 @@ def main():
     ap.add_argument("--no-exclusive", dest="exclusive", action="store_false", default=True,
                     help="skip the one-base-in-flight re-run (roofline.per_launch.exclusive)")
     ap.add_argument("--profile-dir", default=None, help="keep the k_verify rows of the rocprofv3 outputs here (e.g. profiles/r03_bench)")
+    ap.add_argument("--shard-mode", choices=["auto", "base", "split"], default="auto",
+                    help="N > 1: trials sharded by base (one all-reduce per window), or every base split over all GPUs (SURVEY 8e "
+                         "level 2; auto = split at the GPU-scale sample, where a base takes seconds)")
     ap.add_argument("--inner", action="store_true", help="(used by the --pmc passes) timed region only, no JSON")
     ap.add_argument("--hbm-point-inner", action="store_true", help="(used by the HBM-bound point) one cold scoring launch")
     ap.add_argument("--hbm-transforms", type=int, default=4096)
@@ -531,6 +534,11 @@ def main():
         if world > 1:
             # the C++ sharded loop behind the C ABI (s4p_shard_*): RCCL all-reduce(max) of one 8-byte key per window
             sh = capi.Shard(m, rank, world, True)
+            split = args.shard_mode == "split" or (args.shard_mode == "auto" and scale_mode)
+            if split:
+                sh.set_mode(True)
+            collective["mode"] = "every base split over the GPUs (2 all-reduces per base)" if split else "trials sharded by base (1 all-reduce per window)"
+            collective["split"] = split
             if one_gpu:
                 sh.use_collective(capi.torch_collective(dist))          # single-GPU dry run: gloo through the callback provider
                 collective["kind"] = "gloo through the callback provider (S4P_BENCH_ONE_GPU dry run)"
@@ -840,7 +848,8 @@ def main():
         out = {
             "metric": "candidate transforms verified/sec", "value": value, "unit": "candidates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong" if collective.get("split") else "weak",     # split mode: the K bases are shared by all GPUs; by base: K bases per GPU
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "spread": {"repeats": len(runs), "min": vals[0], "median": vals[len(vals) // 2], "max": vals[-1],
                        "note": "each repeat: fresh matcher, same seed, same %d timed bases" % args.steps},
@@ -850,7 +859,7 @@ def main():
                        "n_P": n_p, "n_Q": n_q, "delta": DELTA, "overlap": OVERLAP, "seed": SEED,
                        "candidates_timed": cand_all, "point_queries_per_s": cand_all * n_q / dt_max,
                        "parallelism": "bases sharded over %d GPU(s), one 8-byte all-reduce(max) per window" % world,
-                       "collective": collective["kind"],
+                       "collective": collective["kind"], "shard_mode": collective.get("mode"),
                        "early_exit": {"on": True, "candidates_abandoned": int(prof.verify_pruned), "fraction": prof.verify_pruned / max(cand_all, 1),
                                       "exact_point_tests_per_query": kbar, "exact_point_tests_per_query_full_counts": None if full_walk is None else full_walk["kbar"],
                                       "note": "candidates that can no longer EXCEED the registration's best inlier count are abandoned (every candidate that "
