@@ -1362,11 +1362,13 @@ __global__ __launch_bounds__(256) void k_quads(QuadParams P) {
 }
 
 // ---------------------------------------------------------------------------
-// k_verify: Verify() (match4pcsBase.cc:508-567, no early exit) of every gated candidate, then -- in the same launch --
-// the selection of the base's winner (match4pcsBase.hpp:467-484: the first candidate in reference order with the
-// strictly greatest LCP), its transform, and the result record the host reads.
-// Persistent 1024-thread workgroups, one wave64 per gated candidate; the length of the gated list lives in device
-// memory (no host round trip).  LDS per workgroup: coarse bitmap (<= 34 KB) + 16 x 2.75 KB private survivor queues / item tables.
+// k_verify: Verify() (match4pcsBase.cc:508-567) of every gated candidate, then -- in the same launch -- the selection of
+// the base's winner (match4pcsBase.hpp:467-484: the first candidate in reference order with the strictly greatest LCP),
+// its transform, and the result record the host reads.  With VerifyParams::prune > 0 a candidate that can no longer
+// EXCEED that count is abandoned (the order-independent form of match4pcsBase.cc:558-560); with
+// prune == 0 every candidate is counted in full.
+// Persistent workgroups of up to 1024 threads, one wave64 per gated candidate; the length of the gated list lives in
+// device memory (no host round trip).  LDS per workgroup: coarse bitmap (<= 34 KB) + one private survivor queue per wave.
 // ---------------------------------------------------------------------------
 // k_verify / k_verify_T are launched with kVerifyThreadsCached (structure inside the Infinity Cache: the kernel is VALU-issue
 // bound, six waves per SIMD contend less; measured 0.1496 / 0.1443 / 0.1424 / 0.1433 / 0.1458 ms at 512 / 640 / 768 / 896 /
