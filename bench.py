@@ -570,6 +570,15 @@ def main():
                 else:
                     sh.use_collective(capi.torch_collective(dist, dev))
                     collective["kind"] = "torch-fallback: torch.distributed all_reduce(max) on the nccl (= RCCL) process group through the callback provider"
+            if not collective.get("warmed") and not collective["kind"].startswith("rccl"):
+                # a process group sets its connections up on first use of each collective (the library's own communicator
+                # does that inside s4p_shard_use_rccl): once, before any timed region
+                wt = torch.zeros(1, dtype=torch.int64, device=None if one_gpu else dev)
+                dist.all_reduce(wt, op=dist.ReduceOp.MAX)
+                wb = torch.zeros(256, dtype=torch.uint8, device=None if one_gpu else dev)
+                for root in range(world):
+                    dist.broadcast(wb, src=root)
+                collective["warmed"] = True
             return sh
         return sharding.ShardedRansac(m, rank, world, dist, dev)      # world 1: the engine's own pipelined Perform_N_steps
 
@@ -634,16 +643,19 @@ def main():
     # the byte model's inputs, measured on the TIMED bases: a fresh matcher runs the W warm-up bases, then the K timed bases
     # again through the instrumented kernel (slower; untimed) -- in the default mode (early exit: the structure walk the timed
     # kernel really does) and with every candidate counted in full
+    # (N > 1: rank 0 replays the trials of ALL ranks' timed windows one after the other -- the job's timed bases)
+    trials_per_window = 1 if (world == 1 or collective.get("split")) else world
+
     def instrumented(early_exit):
         mi = capi.Matcher(opt, device=local_rank, max_pairs=(32 << 20) if scale_mode else MAX_PAIRS, max_quads=(32 << 20) if scale_mode else MAX_QUADS)
         mi.early_exit(early_exit)
         mi.init_full(P, Q)
-        shi = sharding.ShardedRansac(mi, 0, 1, None, dev)
-        shi.run_windows(args.warmup)
+        shi = sharding.ShardedRansac(mi, 0, 1, None, torch.device("cuda", local_rank))
+        shi.run_windows(args.warmup * trials_per_window)
         mi.profile_enable(False, True)
         mi.profile_get(reset=True)
         q_before = mi.info().candidates_verified
-        shi.run_windows(args.steps)
+        shi.run_windows(args.steps * trials_per_window)
         pk = mi.profile_get(reset=True)
         queries = max((mi.info().candidates_verified - q_before) * n_q, 1)
         mi.close()
@@ -654,6 +666,8 @@ def main():
     f_l0 = f_l1 = f_l2 = kbar = 0.0
     groups_per_query = 0.0
     full_walk = None
+    if world > 1 and rank == 0 and not scale_mode and args.instrumented:
+        kbar, (f_l0, f_l1, f_l2), groups_per_query = instrumented(True)
     if world == 1 and not scale_mode and args.instrumented:
         kbar, (f_l0, f_l1, f_l2), groups_per_query = instrumented(True)
         kb_f, fr_f, gq_f = instrumented(False)

@@ -124,8 +124,9 @@ int32_t s4p_chunk_stats(const s4p_ctx* ctx, uint64_t* out4);
 int32_t s4p_set_best_hint(s4p_ctx* ctx, uint32_t best_count);
 
 /* One base over several GPUs (SURVEY.md 8e level 2).  After s4p_set_quad_slice(ctx, part, parts) every fused pass of this
- * context enumerates, gates and scores only the part-th of `parts` equal shares of the base's SECOND pair set (both pair
- * sets and the set-1 structure are still built in full: they are cheap next to the candidates); s4p_base_result then
+ * context enumerates, gates and scores only its share of the base's SECOND pair set -- the pairs whose order key (their
+ * rank in the reference's emission order, the same number on every GPU) is congruent to `part` modulo `parts`; both pair
+ * sets and the set-1 structure are still built in full: they are cheap next to the candidates.  s4p_base_result then
  * describes that share: its quads, candidates, checksums, and its best candidate with the order tag (best_rank) that lets a
  * driver pick, among the shares, the greatest count and -- at equal counts -- the smallest tag, i.e. the reference's first
  * maximum (match4pcsBase.hpp:467-484).  The sharded driver does (s4p_shard_set_mode, s4p_matcher.h). */

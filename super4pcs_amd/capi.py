@@ -478,6 +478,12 @@ class Matcher:
         self._chk(self.L.s4p_profile_get(self.ctx_handle(), C.byref(p), int(reset)))
         return p
 
+    def set_quad_slice(self, part, parts):
+        """SURVEY 8e level 2: this matcher's fused passes take the share `part` of `parts` of every base's second pair set."""
+        rc = self.L.s4p_set_quad_slice(self.ctx_handle(), int(part), int(parts))
+        if rc != S4P_OK:
+            raise S4PError(rc, self.L.s4p_last_error(self.ctx_handle()).decode())
+
     def set_quad_chunking(self, enable=True, grow_cap_quads=0):
         rc = self.L.s4p_set_quad_chunking(self.ctx_handle(), int(enable), int(grow_cap_quads))
         if rc != S4P_OK:

@@ -564,13 +564,11 @@ int32_t run_chunked(s4p_ctx* c, const DevCounters& first, s4p_base_result* r) {
   const uint64_t Ktot = first.K;
   const uint64_t target = std::max<uint64_t>(L.cap_quads * 6 / 10, 1);          // entries are in append order, i.e. shuffled: ranges are even
   const uint64_t nch = (Ktot + target - 1) / target;
-  const uint64_t share = Q.slice_den ? std::max<uint64_t>(1, uint64_t(m2) / Q.slice_den) : uint64_t(m2);
-  const uint32_t step = uint32_t(std::max<uint64_t>(1, (share + nch - 1) / nch));
+  // (a share of the set, s4p_set_quad_slice, is a predicate on the pairs' order keys inside k_quads: the ranges cover the
+  // whole list on every GPU, and Ktot already counts this GPU's share only)
+  const uint32_t step = uint32_t(std::max<uint64_t>(1, (uint64_t(m2) + nch - 1) / nch));
   std::vector<std::pair<uint32_t, uint32_t>> todo;
-  uint64_t lo = 0, hi = m2;                                // this context's share of the set (s4p_set_quad_slice), as k_quads computes it
-  if (Q.slice_den) { lo = (uint64_t(m2) * Q.slice_num) / Q.slice_den; hi = (uint64_t(m2) * (Q.slice_num + 1u)) / Q.slice_den; }
-  Q.slice_den = 0u;                                        // the chunk passes carry explicit ranges
-  for (uint64_t a = lo; a < hi; a += step) todo.emplace_back(uint32_t(a), uint32_t(std::min<uint64_t>(a + step, hi)));
+  for (uint64_t a = 0; a < m2; a += step) todo.emplace_back(uint32_t(a), uint32_t(std::min<uint64_t>(a + step, m2)));
   std::reverse(todo.begin(), todo.end());
   uint64_t Ksum = 0, Csum = 0, qsum = 0, csum = 0;
   DevCounters best{}; bool have = false;
@@ -900,8 +898,9 @@ int32_t s4p_border_stats(const s4p_ctx* c, uint64_t* out2) {
 // abandoned candidates (s4p_last_candidates, s4p_last_verified) and a base's best_count AT OR BELOW the hint are lower
 // bounds.  0 (the default) = every candidate is counted in full.
 int32_t s4p_set_best_hint(s4p_ctx* c, uint32_t best_count) { if (!c) return S4P_ERR_BAD_ARG; c->best_hint = best_count; return S4P_OK; }
-// SURVEY 8e level 2: this context takes the `part`-th of `parts` equal shares of every base's second pair set (its quads,
-// candidates and their best); parts = 0 or 1 restores the whole set.  Pairs and the set-1 hash are still built in full.
+// SURVEY 8e level 2: this context takes its share of every base's second pair set (order key = part mod parts: the keys, unlike
+// the list positions, are the same on every GPU), with its quads, candidates and their best; parts = 0 or 1 restores the whole
+// set.  Pairs and the set-1 hash are still built in full.
 int32_t s4p_set_quad_slice(s4p_ctx* c, uint32_t part, uint32_t parts) {
   if (!c || (parts && part >= parts)) return S4P_ERR_BAD_ARG;
   c->slice_num = parts > 1 ? part : 0u; c->slice_den = parts > 1 ? parts : 0u;

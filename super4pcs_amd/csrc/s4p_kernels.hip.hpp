@@ -1193,7 +1193,7 @@ struct QuadParams {
   float thr;                   // distance_threshold2 (compared against a SQUARED norm: quirk super4pcs.cc:160)
   int4* quads; unsigned long long* tags; unsigned long long* K_dev; uint32_t K_cap; uint32_t* overflow;
   uint32_t r0, r1;                                       // set-2 entries [r0, min(r1, m2)): the whole set, or one chunk of a base whose quads do not fit
-  uint32_t slice_num, slice_den;                         // slice_den != 0: only the slice_num-th of slice_den equal parts of the set (one GPU's share of a base)
+  uint32_t slice_num, slice_den;                         // slice_den != 0: only the pairs whose order key = slice_num mod slice_den (one GPU's share of a base)
   unsigned long long* qsum_dev; unsigned long long* csum_dev;   // checksums (DevCounters::quad_sum / cand_sum)
   int do_gate; GateParams gate;                          // fused path: gate every quad as it is appended
 };
@@ -1226,11 +1226,7 @@ __global__ __launch_bounds__(256) void k_quads(QuadParams P) {
   __shared__ uint32_t s_item_i[256], s_item_e[256];        // the tile's pairs whose cell holds a set-1 pair, compacted
   __shared__ uint32_t s_mask[256 * kMaskWords];            // each thread's direction mask (row stride 11: conflict-free)
   const uint32_t m2 = min(*P.m2_dev, P.cap2);
-  uint32_t begin = P.r0, end = min(m2, P.r1);
-  if (P.slice_den) {                                       // (m2 only exists on the device when the pass is enqueued)
-    begin = max(begin, uint32_t((uint64_t(m2) * P.slice_num) / P.slice_den));
-    end = min(end, uint32_t((uint64_t(m2) * (P.slice_num + 1u)) / P.slice_den));
-  }
+  const uint32_t begin = P.r0, end = min(m2, P.r1);
   const uint32_t hmask = hash_mask(P.ht);
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   if (threadIdx.x == 0) { st_n = 0; s_qsum = 0ull; s_csum = 0ull; }
@@ -1242,7 +1238,9 @@ __global__ __launch_bounds__(256) void k_quads(QuadParams P) {
     {
       const uint32_t i = i0 + threadIdx.x;
       uint32_t e = kNil;
-      if (i < end) {
+      // A share of the set (one GPU's part of a base) is defined on the pairs' ORDER KEYS, not on their positions: the
+      // position of a pair in the list is whatever the appends of k_pairs made it on this device, its key is the same everywhere.
+      if (i < end && (P.slice_den == 0u || P.okey2[i] % P.slice_den == P.slice_num)) {
         const int2 ab = P.ab2[i];
         const float p1x = P.ux[ab.x], p1y = P.uy[ab.x], p1z = P.uz[ab.x];
         const float p2x = P.ux[ab.y], p2y = P.uy[ab.y], p2z = P.uz[ab.y];

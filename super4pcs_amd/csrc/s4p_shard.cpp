@@ -160,6 +160,14 @@ struct RcclCollective : Collective {                         // RCCL over xGMI, 
     for (auto& e : ev) if (!hip_ok(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate")) return S4P_ERR_HIP;
     if (!hip_ok(hipHostMalloc((void**)&host, kBytes, hipHostMallocDefault), "hipHostMalloc")) return S4P_ERR_HIP;
     if (!hip_ok(hipMalloc((void**)&dev, kBytes), "hipMalloc")) return S4P_ERR_HIP;
+    // First use of a communicator sets up its channels (and loads the collective's kernel): tens of milliseconds, against a
+    // window of ~0.1 ms.  Both collectives of the loop run once here, where every rank is anyway (communicator set-up is
+    // collective), so that the first window and the first improved result of a registration do not pay for it.
+    if (!hip_ok(hipMemsetAsync(dev, 0, kBytes, stream), "hipMemsetAsync")) return S4P_ERR_HIP;
+    if (!nccl_ok(g_rccl.AllReduce(dev, dev, 1, ncclUint64, ncclMax, comm, stream), "ncclAllReduce (set-up)")) return S4P_ERR_STATE;
+    char* drec = reinterpret_cast<char*>(dev) + kKeyBytes;
+    if (!nccl_ok(g_rccl.Broadcast(drec, drec, sizeof(s4p_base_result), ncclChar, 0, comm, stream), "ncclBroadcast (set-up)")) return S4P_ERR_STATE;
+    if (!hip_ok(hipStreamSynchronize(stream), "hipStreamSynchronize")) return S4P_ERR_HIP;
     return S4P_OK;
   }
   ~RcclCollective() override {

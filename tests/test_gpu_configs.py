@@ -1,4 +1,5 @@
-"""-m gpu: the other workloads BASELINE.json lists (configs[1], [3], [4]) as parity cases.
+"""-m gpu: the other workloads BASELINE.json lists (configs[1], [3], [4]) as parity cases, at the reference-feasible sample
+(n = 2000) and at the sample sizes SURVEY.md 8d states for them (configs[2], [3]: n = 20 000; configs[4]: n = 5000).
 
 At these sizes a whole CPU registration is out of reach, so parity is checked where it is cheap and size-independent:
   * sampling (device sampler) and initialisation against the oracle's host code: sampled clouds, trial count,
@@ -199,6 +200,13 @@ def test_config3_lidar_pair_5m_points(oracle_mod, s4p_lib_built):
     # and the fused path (what a rank of the sharded job runs per owned base), two consecutive bases
     _gm, quads, cand = _fused_bases_vs_oracle(oracle_mod, capi, P, Q, delta, 0.4, 2000, 2, 8 << 20, 64 << 20, count_sample=600)
     assert quads > 0 and cand > 0
+    del _gm
+    # ... and at SURVEY.md 8d's sample size for this workload, n = 20 000 sampled Q points (2.2 M / 0.5 M ordered pairs and
+    # ~10^5 congruent quads per base on this scene): the fused pass of the first two bases, ordered quad lists, candidate
+    # counts (LCP over 20 000 queries: the float-query path of k_verify), TryOneBase's state -- against the oracle
+    if SCALE == 1.0:
+        _gm, quads, cand = _fused_bases_vs_oracle(oracle_mod, capi, P, Q, delta, 0.4, 20000, 2, 8 << 20, 64 << 20, count_sample=400)
+        assert quads > 50_000 and cand > 0 and _gm.info().n_sampled_q == 20000
 
 
 def test_config4_part_in_whole_10m_scene(oracle_mod, s4p_lib_built):
@@ -221,6 +229,11 @@ def test_config4_part_in_whole_10m_scene(oracle_mod, s4p_lib_built):
     if SCALE == 1.0:
         _gm, quads, cand = _fused_bases_vs_oracle(oracle_mod, capi, P, Q, delta, 0.2, 2000, 28, 8 << 20, 64 << 20, count_sample=400, skip_bases=17)
         assert quads >= 148 and cand >= 42
+        del _gm
+        # ... and at SURVEY.md 8d's sample size for this workload, n = 5000 sampled Q points.  The base sequence depends on P
+        # only, so the same trials carry quads (more of them): trials 17-19 through the fused pass against the oracle.
+        _gm, quads5, cand5 = _fused_bases_vs_oracle(oracle_mod, capi, P, Q, delta, 0.2, 5000, 3, 8 << 20, 64 << 20, count_sample=400, skip_bases=17)
+        assert quads5 > 15 and cand5 > 2 and _gm.info().n_sampled_q == 5000
 
 
 def test_config2_gpu_scale_sample_20000(oracle_mod, s4p_lib_built):

@@ -513,3 +513,58 @@ def test_early_exit_changes_no_result(oracle_mod, s4p_lib_built):
     quads = of.find_congruent(i1, i2, 2 * delta, p1, p2)
     _nb, per, _bc, _bi = of.try_congruent_set(base, quads)
     assert np.array_equal(quads, g_quads) and np.array_equal(per, g_counts)
+
+
+@pytest.mark.parametrize("parts,chunk", [(2, False), (3, False), (5, True)])
+def test_quad_slices_are_a_partition_of_the_base(oracle_mod, s4p_lib_built, parts, chunk):
+    """s4p_set_quad_slice (one base over several GPUs): the shares are defined on the pairs' order keys, so whatever order
+    each context's pair kernel appended them in, every quad and every candidate of a base belongs to exactly one share --
+    counts and order-independent checksums of the shares add up to the oracle's lists (checksums modulo 2^64), and the best
+    of the shares' winners under (count, smallest tag) is the base's first maximum.  With chunk=True the shares are chunked
+    on top (quad buffers of 1500 entries that may not grow)."""
+    from super4pcs_amd import capi
+    from bench import seg_len32
+    O = oracle_mod
+    delta, overlap, n_s = 0.01, 0.6, 200
+    P, Q, _ = H.small_pair(20000, delta=delta, seed=3)
+    of = O.Matcher(O.make_options(delta, overlap, n_s), full_counts=True, use_kdtree=True)
+    of.init(P, Q)
+    ms = []
+    for k in range(parts):
+        g = capi.Matcher(capi.make_options(delta, overlap, n_s), **({"max_quads": 1500} if chunk else {}))
+        if chunk:
+            g.set_quad_chunking(True, 1500)
+        g.early_exit(False)
+        g.init_full(P, Q)
+        g.set_quad_slice(k, parts)
+        ms.append(g)
+    eps = 2.0 * delta
+    seen = 0
+    M64 = (1 << 64) - 1
+    for _ in range(10):
+        rs = [g.try_one_base()[1] for g in ms]
+        ok, i1, i2, base, bx = of.select_quadrilateral()
+        if not ok:
+            continue
+        p1 = of.extract_pairs(seg_len32(bx[0], bx[1]), 0.0, eps, 0, 1)
+        p2 = of.extract_pairs(seg_len32(bx[2], bx[3]), 0.0, eps, 2, 3)
+        assert all((r.n_pairs1, r.n_pairs2) == (len(p1), len(p2)) for r in rs)
+        if not (len(p1) and len(p2)):
+            continue
+        quads = of.find_congruent(i1, i2, eps, p1, p2)
+        _nb, per, _bc, _bi = of.try_congruent_set(base, quads)
+        assert sum(r.n_quads for r in rs) == len(quads)
+        assert sum(r.quad_checksum for r in rs) & M64 == H.checksum(quads)
+        assert sum(r.n_verified for r in rs) == int((per >= 0).sum())
+        assert sum(r.cand_checksum for r in rs) & M64 == H.checksum(quads[per >= 0])
+        if len(quads) > 50 * parts:
+            assert all(r.n_quads > 0 for r in rs)                     # (the shares are of comparable size)
+        have = [r for r in rs if r.has_best]
+        if (per >= 0).any():
+            k = int(np.flatnonzero(per == per.max())[0])              # first maximum in std::set order
+            w = min(have, key=lambda r: (-int(r.best_count), int(r.best_rank)))
+            assert w.best_count == per.max() and list(w.best_quad) == quads[k].tolist()
+            seen += 1
+    assert seen >= 4
+    if chunk:
+        assert all(g.chunk_stats()["bases"] > 0 for g in ms)
