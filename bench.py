@@ -295,8 +295,9 @@ def cpu_baseline(P, Q, budget_s, sample, ttr_candidates):
                                  "extrapolated_seconds_1_core": ttr_candidates / max(a["value"], 1e-9),
                                  "extrapolated_seconds_all_cores": ttr_candidates / max(b["value"], 1e-9),
                                  "cap_seconds": 600,
-                                 "note": "candidates of the whole registration / sampled candidates-per-second; both exceed the 600 s the "
-                                         "reference's own tests allow when > 600"}
+                                 "note": "candidates of the whole registration / sampled candidates-per-second (the first bases are "
+                                         "the slowest per candidate: no best LCP to exit early against yet); the run itself, all host "
+                                         "cores, 600 s cap: tools/r3_cpu_ttr.py -> profiles/r03_cpu_time_to_register.json (307 s on 256 cores)"}
     return a
 
 

@@ -14,6 +14,7 @@
 #include <chrono>
 #include <cmath>
 #include <condition_variable>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <deque>
@@ -1095,10 +1096,16 @@ int32_t s4p_matcher_perform_n_steps(s4p_matcher* m, int32_t n, s4p_visitor_fn vi
   drain_inflight(m);                       // leftovers of next_base_async calls the caller never waited for
   loop_hint(m, true);
   int32_t rc = S4P_OK;
+  static const bool trace_call = std::getenv("S4P_TRACE_CALL") != nullptr;      // lab aid: where a short call spends its fixed cost
+  using hclock = std::chrono::steady_clock;
+  const auto tc0 = hclock::now();
+  hclock::time_point tc_first_enq = tc0, tc_first_res = tc0, tc_loop_end = tc0;
+  bool seen_enq = false, seen_res = false;
   for (int i = m->current_trial; i < end && rc == S4P_OK; ++i) {
     while (int(fifo.size()) < s4p_pipeline_depth(m->ctx) && next_prep < end) {
       fifo.emplace_back();
       if ((rc = next_base_async(m, true, true, fifo.back())) != S4P_OK) break;
+      if (trace_call && !seen_enq) { tc_first_enq = hclock::now(); seen_enq = true; }
       ++next_prep;
     }
     if (rc != S4P_OK) break;
@@ -1107,6 +1114,7 @@ int32_t s4p_matcher_perform_n_steps(s4p_matcher* m, int32_t n, s4p_visitor_fn vi
     s4p_base_result r;
     rc = wait_base(m, pr, r);
     if (rc != S4P_OK) break;
+    if (trace_call && !seen_res) { tc_first_res = hclock::now(); seen_res = true; }
     // (a base whose quads were processed in chunks keeps no per-candidate records: s4p_last_verified then fails loudly)
     if (visitor && m->visit_candidates && pr.device && r.n_verified) {     // match4pcsBase.hpp:458-465
       std::vector<uint32_t> cnt(size_t(r.n_verified)); std::vector<float> Ts(size_t(r.n_verified) * 16);
@@ -1135,8 +1143,14 @@ int32_t s4p_matcher_perform_n_steps(s4p_matcher* m, int32_t n, s4p_visitor_fn vi
     if (ok || i > m->number_of_trials || fraction >= 0.99 || m->best_lcp == 1.0) break;
   }
   // drain speculative work and put the host state back where the sequential loop stopped
+  if (trace_call) tc_loop_end = hclock::now();
   rewind_speculation(m);
   loop_hint(m, false);
+  if (trace_call) {
+    auto us = [](hclock::time_point a, hclock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+    std::fprintf(stderr, "[s4p] perform_n_steps(%d): first base enqueued after %.0f us, first result after %.0f us, loop %.0f us, rewind %.0f us\n",
+                 n, us(tc0, tc_first_enq), us(tc0, tc_first_res), us(tc0, tc_loop_end), us(tc_loop_end, hclock::now()));
+  }
   if (rc != S4P_OK) return rc;
   m->current_trial += n;
   *improved = m->best_lcp > last_best ? 1 : 0;
