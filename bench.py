@@ -534,7 +534,7 @@ def main():
     def make_driver(m):
         if world > 1:
             # the C++ sharded loop behind the C ABI (s4p_shard_*): RCCL all-reduce(max) of one 8-byte key per window
-            sh = capi.Shard(m, rank, world, True)
+            sh = capi.Shard(m, rank, world, 2)                  # helper threads where they pay (s4p_matcher_set_sharding)
             split = args.shard_mode == "split" or (args.shard_mode == "auto" and scale_mode)
             if split:
                 sh.set_mode(True)
@@ -581,16 +581,18 @@ def main():
                     dist.broadcast(wb, src=root)
                 collective["warmed"] = True
             return sh
-        return sharding.ShardedRansac(m, rank, world, dist, dev)      # world 1: the engine's own pipelined Perform_N_steps
+        return sharding.ShardedRansac(m, rank, world, dist, dev, producer_threads="auto")      # world 1: the engine's own pipelined Perform_N_steps
 
-    def timed_region(steps, warmup, early_exit=True):
-        """Fresh matcher, same seed: W untimed steps, then exactly K timed steps between barrier + synchronize."""
+    def timed_region(steps, warmup, early_exit=True, stage_events=False):
+        """Fresh matcher, same seed: W untimed steps, then exactly K timed steps between barrier + synchronize.  HIP events
+        bracket every k_verify launch of the timed steps (roofline.per_launch); the other stages' events (three more records per
+        base, each a barrier in the lane's stream) only in the separate, unreported pass that fills stage_ms_per_step."""
         m = capi.Matcher(opt, device=local_rank, max_pairs=(32 << 20) if scale_mode else MAX_PAIRS, max_quads=(32 << 20) if scale_mode else MAX_QUADS)
         m.early_exit(early_exit)
         m.init_full(P, Q)                       # sampling, grid build, upload: outside the timed region
         sh = make_driver(m)
         sh.run_windows(warmup)
-        m.profile_enable(True, False)
+        m.profile_enable(1 if (stage_events or scale_mode) else 2, False)      # (a base of the 20 000-point sample takes seconds: events are free)
         m.profile_get(reset=True)
         sync()
         t0 = time.perf_counter()
@@ -630,6 +632,13 @@ def main():
     if hasattr(sh, "close"):
         sh.close()
     m.close()
+    # per-stage HIP-event times: one more pass over the same bases with events around every stage (not part of `value`)
+    stage_prof = prof if scale_mode else None
+    if not scale_mode:
+        ms_, shs_, _dt, _c, stage_prof = timed_region(args.steps, args.warmup, stage_events=True)
+        if hasattr(shs_, "close"):
+            shs_.close()
+        ms_.close()
     # the same timed region with every candidate counted in full (no early exit): what rounds 1 and 2 reported as `value`
     full_mode = None
     if world == 1 and args.full_count_mode:
@@ -651,7 +660,7 @@ def main():
         mi = capi.Matcher(opt, device=local_rank, max_pairs=(32 << 20) if scale_mode else MAX_PAIRS, max_quads=(32 << 20) if scale_mode else MAX_QUADS)
         mi.early_exit(early_exit)
         mi.init_full(P, Q)
-        shi = sharding.ShardedRansac(mi, 0, 1, None, torch.device("cuda", local_rank))
+        shi = sharding.ShardedRansac(mi, 0, 1, None, torch.device("cuda", local_rank), producer_threads="auto")
         shi.run_windows(args.warmup * trials_per_window)
         mi.profile_enable(False, True)
         mi.profile_get(reset=True)
@@ -682,7 +691,6 @@ def main():
     T2c = None
     if world == 1 and args.time_to_register:
         m2 = capi.Matcher(opt, device=local_rank, max_pairs=MAX_PAIRS, max_quads=MAX_QUADS)
-        m2.set_sharding(0, 1, True)
         t_reg = time.perf_counter()
         lcp2, M2, _ = m2.compute_transformation(P, Q)
         t_reg = time.perf_counter() - t_reg
@@ -804,7 +812,6 @@ def main():
         try:
             m1 = capi.Matcher(opt, device=local_rank, max_pairs=MAX_PAIRS, max_quads=MAX_QUADS)
             m1.init_full(P, Q)
-            m1.set_sharding(0, 1, True)
             m1.perform_n_steps(args.warmup)
             m1.profile_enable(True, False)
             m1.profile_get(reset=True)
@@ -920,8 +927,12 @@ def main():
                 "hbm_bound_point": hbm_point,
             },
             "k_apply": apply_row,
-            "stage_ms_per_step": {"pairs_and_prep": prof.pairs_ms_total / max(prof.quads_launches, 1),
-                                  "quads_and_gate": prof.quads_ms_total / max(prof.quads_launches, 1), "verify_and_select": avg_ms},
+            "stage_ms_per_step": None if stage_prof is None else {
+                "pairs_and_prep": stage_prof.pairs_ms_total / max(stage_prof.quads_launches, 1),
+                "quads_and_gate": stage_prof.quads_ms_total / max(stage_prof.quads_launches, 1),
+                "verify_and_select": stage_prof.verify_ms_total / max(stage_prof.verify_launches, 1),
+                "note": "HIP-event time per launch with six bases in flight, from a separate pass over the same bases with events around "
+                        "every stage (the timed passes record events around k_verify only)"},
         }
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(P, Q, args.cpu_seconds, args.sample, ttr["candidates_verified"] if ttr else 0)

@@ -289,6 +289,9 @@ typedef struct {
   double   host_wait_s;          /* host time blocked in stream synchronisation                           */
   uint64_t verify_pruned;        /* candidates abandoned because they could not exceed the best-count hint */
 } s4p_profile;
+/* enable_events: 0 off; 1 HIP events around every stage of a base (five records per base: verify_*, pairs_*, quads_*); 2 around
+ * the LCP-verify kernel only (two records per base: what a throughput measurement that also wants the kernel's launch time
+ * should use -- timing events are barriers in the lane's stream).  count_point_tests: the instrumented verify kernel. */
 int32_t s4p_profile_enable(s4p_ctx* ctx, int32_t enable_events, int32_t count_point_tests);
 int32_t s4p_profile_get(s4p_ctx* ctx, s4p_profile* out, int32_t reset);
 

@@ -95,11 +95,12 @@ int32_t s4p_matcher_try_one_base(s4p_matcher* m, int32_t* ok, s4p_base_result* l
  *   commit    : the "if (lcp > best_LCP_)" update of TryCongruentSet (match4pcsBase.hpp:467-484) applied
  *               to a result that may have been produced on another rank; *ok = TryOneBase's return value. */
 int32_t s4p_matcher_next_base(s4p_matcher* m, int32_t run_device, int32_t* found, int32_t* base_ids, s4p_base_result* result);
-/* Declares this matcher rank `rank` of `world` (trial t is owned by rank t mod world, counted from this call) and,
- * with producer_threads != 0, moves base selection and octree staging onto two helper threads that run ahead of the
- * caller: both are sequential by nature (RNG stream; persistent octree permutation) but never read results.  The
- * caller keeps calling next_base / next_base_async / perform_n_steps as before; state is rewound exactly when a
- * trial loop stops. */
+/* Declares this matcher rank `rank` of `world` (trial t is owned by rank t mod world, counted from this call) and says
+ * whether base selection and octree staging move onto helper threads that run ahead of the caller (both are sequential by
+ * nature -- RNG stream; persistent octree permutation -- but never read results): producer_threads = 0 never, 1 always,
+ * 2 where they pay = with 4 or more ranks, or when SelectQuadrilateral's searches run on the device (sampled P >= 2^20
+ * points); measured in DESIGN.md 5.1.  A matcher this was never called on behaves as (0, 1, 2).  The caller keeps calling
+ * next_base / next_base_async / perform_n_steps as before; state is rewound exactly when a trial loop stops. */
 int32_t s4p_matcher_set_sharding(s4p_matcher* m, int32_t rank, int32_t world, int32_t producer_threads);
 
 /* Pipelined next_base: the owner's device pass is only enqueued (at most two in flight); wait_base

@@ -589,6 +589,7 @@ class Matcher:
         self._chk(self.L.s4p_matcher_visit_candidates(self.h, int(enable)))
 
     def set_sharding(self, rank=0, world=1, producer_threads=True):
+        """producer_threads: False / True force the helper threads off / on, 2 = where they pay (the engine's default)."""
         self._chk(self.L.s4p_matcher_set_sharding(self.h, rank, world, int(producer_threads)))
 
     def next_base_async(self, run_device=True):

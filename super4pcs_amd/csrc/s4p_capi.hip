@@ -169,7 +169,7 @@ struct s4p_ctx {
   PinBuf<uint32_t> sel_hdraws; PinBuf<SelectRecord> sel_hrec; hipStream_t sel_stream = nullptr;
 
   // profiling
-  bool prof_events = false, prof_points = false;
+  bool prof_events = false, prof_stages = false, prof_points = false;      // events around k_verify / around the other stages too / instrumented kernel
   hipEvent_t ev[kMaxLanes][6] = {};
   s4p_profile prof{};
   uint64_t last_K = 0;
@@ -483,7 +483,7 @@ void account_profile(s4p_ctx* c, const DevCounters& d, bool fused) {
       c->prof.verify_launches++; c->prof.verify_ms_total += ms;
       c->prof.verify_candidates += d.C; c->prof.verify_quads += std::min<uint64_t>(d.K, c->lane[c->cur].cap_quads); c->prof.verify_queries += uint64_t(d.C) * c->n_q;
     }
-    if (fused) {
+    if (fused && c->prof_stages) {
       if (hipEventElapsedTime(&ms, c->ev[c->cur][2], c->ev[c->cur][3]) == hipSuccess) { c->prof.pairs_ms_total += ms; c->prof.pairs_launches += 2; }
       if (hipEventElapsedTime(&ms, c->ev[c->cur][3], c->ev[c->cur][4]) == hipSuccess) { c->prof.quads_ms_total += ms; c->prof.quads_launches += 1; }
     }
@@ -691,19 +691,19 @@ int32_t launch_base(s4p_ctx* c, int32_t slot, const int32_t* base_ids, float inv
   const BaseFrame bf = make_base_frame(c, base_ids);
   PrepParams P1; QuadParams Q;
   if (int32_t rc = quad_params(c, inv1, inv2, eps, P1, Q)) return rc;
-  if (c->prof_events) HIPCHK(c, hipEventRecord(c->ev[c->cur][2], L.stream));
+  if (c->prof_stages) HIPCHK(c, hipEventRecord(c->ev[c->cur][2], L.stream));
   { PairParams2 PP{};
     if (int32_t rc = upload_pairs_staged(c, slot, 0, eps, 0, 1, PP.set[0].pair)) return rc;
     if (int32_t rc = upload_pairs_staged(c, slot, 1, eps, 2, 3, PP.set[1].pair)) return rc;
     if (int32_t rc = launch_pairs_kernel(c, PP, 2)) return rc; }
-  if (c->prof_events) HIPCHK(c, hipEventRecord(c->ev[c->cur][3], L.stream));
+  if (c->prof_stages) HIPCHK(c, hipEventRecord(c->ev[c->cur][3], L.stream));
   launch_prep_kernel(c, P1);
   if (c->fuse_gate) { Q.do_gate = 1; Q.gate = gate_params(c, bf); }
   c->slot_q[c->cur] = Q;                                  // (the chunk loop relaunches it range by range if the quads do not fit)
   launch_quads_kernel(c, Q);
   if (!c->fuse_gate) launch_gate_kernel(c, gate_params(c, bf));
   HIPCHK(c, hipGetLastError());
-  if (c->prof_events) HIPCHK(c, hipEventRecord(c->ev[c->cur][4], L.stream));
+  if (c->prof_stages) HIPCHK(c, hipEventRecord(c->ev[c->cur][4], L.stream));
   if (int32_t rc = launch_verify(c, bf)) return rc;
   return enqueue_result(c, bf);
 }
@@ -1602,7 +1602,7 @@ int32_t s4p_apply_bench(s4p_ctx* c, int64_t n, int32_t reps, double* out_ms, uin
 
 int32_t s4p_profile_enable(s4p_ctx* c, int32_t enable_events, int32_t count_point_tests) {
   if (!c) return S4P_ERR_BAD_ARG;
-  c->prof_events = enable_events != 0; c->prof_points = count_point_tests != 0;
+  c->prof_events = enable_events != 0; c->prof_stages = enable_events == 1; c->prof_points = count_point_tests != 0;
   return S4P_OK;
 }
 int32_t s4p_profile_get(s4p_ctx* c, s4p_profile* out, int32_t reset) {

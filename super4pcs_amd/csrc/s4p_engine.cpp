@@ -155,6 +155,7 @@ struct s4p_matcher {
   };
   struct Producer {
     bool enabled = false, running = false, stop = false;
+    int mode = 2;                          // helper threads: 0 never, 1 always, 2 where they pay (update_helper_threads)
     int rank = 0, world = 1;
     long next_index = 0;                   // next trial the selector will draw
     long consumed = 0;                     // trials handed to the main thread
@@ -562,6 +563,21 @@ void tree_main(s4p_matcher* m) {
   }
 }
 
+void producer_stop(s4p_matcher* m);
+
+// Where the helper threads pay.  The host chain of a trial is ~20 us with the host search structures (n_P < 2^20): run inline
+// on the launch thread it costs a 1-GPU job nothing (the GPU step is ~115 us) and a hand-off through four queues costs more
+// than the chain -- measured on the bench workload, one GPU playing rank 0 of a world of 1 / 2 / 3 / 4 / 6 / 8
+// (tools/sim_world.py --threads-ab): 0.135 / 0.137 / 0.133 / 0.144 / 0.157 / 0.197 ms per window inline against
+// 0.139 / 0.138 / 0.132 / 0.141 / 0.130 / 0.120 with the threads; a short call also pays ~1 ms for starting them.  With the
+// searches on the device (n_P >= 2^20) an attempt is a synchronous round trip unless the evaluator thread batches them:
+// 0.139 -> 0.051 ms per trial at n_P = 4.2 M.
+void update_helper_threads(s4p_matcher* m) {
+  auto& P = m->prod;
+  const bool want = P.mode == 1 || (P.mode == 2 && (P.world >= 4 || m->device_select));
+  if (want != P.enabled) { producer_stop(m); P.enabled = want; }
+}
+
 void producer_start(s4p_matcher* m) {
   auto& P = m->prod;
   if (P.running) return;
@@ -849,6 +865,7 @@ int32_t s4p_matcher_init(s4p_matcher* m, const s4p_cloud_view* p, const s4p_clou
   // search structures, built while the device builds its own
   if (const char* e = std::getenv("S4P_DEVICE_SELECT")) { if (m->select_mode < 0) m->select_mode = std::atoi(e) != 0 ? 1 : 0; }
   m->device_select = m->select_mode >= 0 ? m->select_mode != 0 : Ps.size() >= kDeviceSelectMin;
+  update_helper_threads(m);
   m->select_failed.store(false);
   std::thread host_index([m, &Ps] {
     if (m->device_select) { m->P4.clear(); m->P4.shrink_to_fit(); m->fourth = s4p::FourthPointIndex(); return; }
@@ -1010,7 +1027,8 @@ int32_t s4p_matcher_visit_candidates(s4p_matcher* m, int32_t enable) {
 int32_t s4p_matcher_set_sharding(s4p_matcher* m, int32_t rank, int32_t world, int32_t producer_threads) {
   if (!m || world < 1 || rank < 0 || rank >= world) return S4P_ERR_BAD_ARG;
   producer_stop(m);
-  m->prod.rank = rank; m->prod.world = world; m->prod.enabled = producer_threads != 0;
+  m->prod.rank = rank; m->prod.world = world; m->prod.mode = producer_threads < 0 || producer_threads > 2 ? 2 : producer_threads;
+  m->prod.enabled = false; update_helper_threads(m);
   m->prod.consumed = 0; m->prod.next_index = 0;
   m->prod.cap_b = std::max<size_t>(8, 3 * size_t(world));      // the launch thread consumes a window (world trials) at a time
   m->prod.cap_a = std::max<size_t>(24, 3 * size_t(world));

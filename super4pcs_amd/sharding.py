@@ -89,8 +89,10 @@ class ShardedRansac:
         self._best_count = None
         self._slots = None
         self._slot_rr = 0
-        if producer_threads and hasattr(matcher, "set_sharding"):
-            matcher.set_sharding(rank, world, True)     # base selection + octree staging on helper threads
+        if hasattr(matcher, "set_sharding"):
+            # base selection + octree staging on helper threads: True / False force it, "auto" leaves it to the engine
+            # (threads where they pay: 4 or more ranks, or base selection on the device)
+            matcher.set_sharding(rank, world, 2 if producer_threads == "auto" else int(bool(producer_threads)))
 
     def _threshold_count(self):
         """Largest inlier count that does NOT cross the terminate threshold (fixed once the clouds are sampled)."""

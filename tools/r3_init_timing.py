@@ -28,7 +28,6 @@ def run(tag, P, Q, T_gt, delta, overlap, n_s, register=True):
         gm.close()
     if register:
         gm = capi.Matcher(capi.make_options(delta, overlap, n_s))
-        gm.set_sharding(0, 1, True)
         t0 = time.perf_counter()
         lcp, M, _ = gm.compute_transformation(P, Q)
         out["time_to_register_s"] = round(time.perf_counter() - t0, 4)

@@ -15,11 +15,11 @@ from super4pcs_amd import capi, datasets as D  # noqa: E402
 import bench  # noqa: E402
 
 
-def run(tag, P, Q, delta, overlap, n_s, worlds, windows):
+def run(tag, P, Q, delta, overlap, n_s, worlds, windows, producer=True):
     for world in worlds:
         m = capi.Matcher(capi.make_options(delta, overlap, n_s), max_pairs=8 << 20, max_quads=64 << 20)
         m.init_full(P, Q)
-        sh = capi.Shard(m, 0, world, True)
+        sh = capi.Shard(m, 0, world, producer)
         sh.use_null_collective()
         sh.run_windows(3)
         m.profile_enable(True, False); m.profile_get(reset=True)
@@ -29,7 +29,7 @@ def run(tag, P, Q, delta, overlap, n_s, worlds, windows):
         dt = time.perf_counter() - t0
         pr = m.profile_get(reset=True); i1 = m.info()
         trials = windows * world
-        print(json.dumps({"workload": tag, "n_P": int(i1.n_sampled_p), "world": world, "windows": windows,
+        print(json.dumps({"workload": tag, "n_P": int(i1.n_sampled_p), "world": world, "windows": windows, "helper_threads": bool(producer),
                           "ms_per_window": round(dt / windows * 1e3, 4), "candidates_per_s_this_rank": round(cand / dt),
                           "host_select_us_per_trial": round((i1.seconds_select - i0.seconds_select) / trials * 1e6, 2),
                           "host_octree_us_per_trial": round(pr.host_octree_s / trials * 1e6, 2),
@@ -41,6 +41,11 @@ def run(tag, P, Q, delta, overlap, n_s, worlds, windows):
 
 if __name__ == "__main__":
     P, Q, _ = D.bumpy_pair(bench.N_POINTS, overlap=bench.OVERLAP, delta=bench.DELTA, seed=bench.SEED)
+    if "--threads-ab" in sys.argv:                 # helper threads on / off at every world size, small n_P, three passes each
+        for _ in range(3):
+            for producer in (True, False):
+                run("configs[2] 1 M-point pair (n_P = 57 k)", P, Q, bench.DELTA, bench.OVERLAP, bench.SAMPLE, (1, 2, 3, 4, 6, 8), 60, producer)
+        sys.exit(0)
     run("configs[2] 1 M-point pair (n_P = 57 k)", P, Q, bench.DELTA, bench.OVERLAP, bench.SAMPLE, (1, 2, 4, 8), 60)
     P, Q, _ = D.part_in_whole_pair(10_000_000, 100_000, delta=0.05)
     run("configs[4] 10 M-point scene (n_P = 4.2 M)", P, Q, 0.05, 0.2, 2000, (1, 8), 40)
