@@ -471,6 +471,8 @@ def main():
                     help="skip the extra timed region with the early exit off (config.full_count_mode)")
     ap.add_argument("--no-instrumented", dest="instrumented", action="store_false", default=True,
                     help="skip the instrumented replays of the timed bases (byte model = null): for a clean rocprofv3 kernel trace of the command")
+    ap.add_argument("--no-stage-pass", dest="stage_pass", action="store_false", default=True,
+                    help="skip the extra pass with events around every stage (stage_ms_per_step = null): for a clean rocprofv3 kernel trace")
     ap.add_argument("--no-exclusive", dest="exclusive", action="store_false", default=True,
                     help="skip the one-base-in-flight re-run (roofline.per_launch.exclusive)")
     ap.add_argument("--profile-dir", default=None, help="keep the k_verify rows of the rocprofv3 outputs here (e.g. profiles/r03_bench)")
@@ -634,7 +636,7 @@ def main():
     m.close()
     # per-stage HIP-event times: one more pass over the same bases with events around every stage (not part of `value`)
     stage_prof = prof if scale_mode else None
-    if not scale_mode:
+    if not scale_mode and args.stage_pass:
         ms_, shs_, _dt, _c, stage_prof = timed_region(args.steps, args.warmup, stage_events=True)
         if hasattr(shs_, "close"):
             shs_.close()

@@ -649,10 +649,19 @@ void producer_release_slot(s4p_matcher* m, int slot) {
 int32_t next_base_async(s4p_matcher* m, bool run_device, bool snapshot, s4p_matcher::Prepared& pr);
 int32_t wait_base(s4p_matcher* m, const s4p_matcher::Prepared& pr, s4p_base_result& r);
 
+// The helper threads decide who owns a trial from (rank, world).  A caller that skips trials by its own rule (run_device = 0 on a
+// matcher that was never declared part of a sharded job) cannot be served by threads the engine turned on by itself: they
+// are stopped -- which rewinds RNG and octree permutation to this trial -- and stay off for this matcher.
+void caller_owns_trials(s4p_matcher* m, bool run_device) {
+  auto& P = m->prod;
+  if (P.enabled && P.mode == 2 && P.world == 1 && !run_device) { producer_stop(m); P.mode = 0; P.enabled = false; }
+}
+
 int32_t next_base(s4p_matcher* m, bool run_device, bool& found, int ids[4], s4p_base_result& r) {
   using clk = std::chrono::steady_clock;
   float inv1 = 0, inv2 = 0;
   std::memset(&r, 0, sizeof(r));
+  caller_owns_trials(m, run_device);
   if (m->prod.enabled) {                 // same thing through the producer queues
     s4p_matcher::Prepared pr;
     if (int32_t rc = next_base_async(m, run_device, false, pr)) return rc;
@@ -684,6 +693,7 @@ int32_t next_base(s4p_matcher* m, bool run_device, bool& found, int ids[4], s4p_
 int32_t next_base_async(s4p_matcher* m, bool run_device, bool snapshot, s4p_matcher::Prepared& pr) {
   using clk = std::chrono::steady_clock;
   float inv1 = 0, inv2 = 0;
+  caller_owns_trials(m, run_device);
   if (m->prod.enabled) {
     s4p_matcher::Trial t;
     producer_pop(m, t);
@@ -959,6 +969,7 @@ int32_t s4p_matcher_get_sampled_attrs(s4p_matcher* m, int32_t which, float* nx, 
 int32_t s4p_matcher_select_quadrilateral(s4p_matcher* m, int32_t* found, float* inv1, float* inv2, int32_t* base_ids, float* base_xyz) {
   if (!m || !found || !inv1 || !inv2 || !base_ids) return S4P_ERR_BAD_ARG;
   if (!m->ready) return m->fail(S4P_ERR_STATE, "matcher not initialised");
+  producer_stop(m);                       // (helper threads that ran ahead: back to the first trial nobody consumed)
   int ids[4] = {0, 0, 0, 0};
   *found = select_quadrilateral(m, *inv1, *inv2, ids) ? 1 : 0;
   if (m->select_failed.load(std::memory_order_acquire)) return m->fail(S4P_ERR_HIP, "device base selection failed: " + m->select_err);
