@@ -834,6 +834,8 @@ def main():
         avg_ms = prof.verify_ms_total / launches
         cand_per_launch = prof.verify_candidates / launches
         sweep_b, gather_b = structure_bytes_per_candidate(n_q, f_l0, f_l1, f_l2, groups_per_query)
+        if not (f_l0 > 0.0):                                    # byte model not measured (--no-instrumented, a lab flag): no roofline figure
+            gather_b = float("nan")
         achieved = value * gather_b / 1e9                       # per-step figure: bytes of the K timed bases / timed seconds
         survey_b = survey_bytes_per_candidate(n_q, kbar)
         vals = sorted(r[0] for r in runs)
@@ -863,12 +865,12 @@ def main():
                   "frac": req * 128.0 / (ex_ms * 1e-3) / 1e9 / L2_PEAK_GBS,
                   "note": "TCC_HIT_sum + TCC_MISS_sum per launch x 128 B (an upper bound: a 16-B gather moves at most one line) over the kernel's "
                           "own launch time"}
-        fracs = {"hbm": achieved / HBM_PEAK_GBS}
+        fracs = {"hbm": achieved / HBM_PEAK_GBS} if achieved == achieved else {}
         if valu:
             fracs["valu"] = valu["frac"]
         if l2:
             fracs["l2"] = l2["frac"]
-        binding = max(fracs, key=lambda k: fracs[k])
+        binding = max(fracs, key=lambda k: fracs[k]) if fracs else None
         out = {
             "metric": "candidate transforms verified/sec", "value": value, "unit": "candidates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -940,7 +942,15 @@ def main():
             out["cpu_baseline"] = cpu_baseline(P, Q, args.cpu_seconds, args.sample, ttr["candidates_verified"] if ttr else 0)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
+        def clean(o):                                           # (no NaN in the JSON line: a figure that was not measured is null)
+            if isinstance(o, dict):
+                return {k: clean(v) for k, v in o.items()}
+            if isinstance(o, (list, tuple)):
+                return [clean(v) for v in o]
+            if isinstance(o, float) and o != o:
+                return None
+            return o
+        print(json.dumps(clean(out)))
         sys.stdout.flush()
         if parity is not None and parity["mismatches"]:
             print("PARITY GATE FAILED: %s" % parity.get("failed"), file=sys.stderr)
