@@ -184,7 +184,7 @@ struct s4p_ctx {
   double set_clouds_s[4] = {0, 0, 0, 0};      // last s4p_set_clouds: host copies + unit frame + grid plan | device build of the LCP structure | Q-side uploads | total
 
   size_t verify_lds_bytes() const {
-    return gcoarse.n * 4 + (qlds ? size_t((n_q + 127u) & ~127u) * 8 : 0) + size_t(verify_threads / 64) * kQueueWordsPerWave * 4;
+    return gcoarse.n * 4 + (qlds ? size_t((n_q + kSweepStep - 1u) & ~(kSweepStep - 1u)) * 8 : 0) + size_t(verify_threads / 64) * kQueueWordsPerWave * 4;
   }
   // (a chunk pass scores ~10^7 candidates with the chip to itself: two workgroups per CU, as for the HBM-bound structure;
   // measured at the 20 000-point sample: 0.50 s per pass with 512 workgroups, 0.66 s with 256)
@@ -1105,7 +1105,7 @@ int32_t s4p_set_clouds(s4p_ctx* c, const float* px, const float* py, const float
       if (!(0.5f * c->qq.step[k] * c->hgrid.inv_h < 0.004f)) fine_enough = false;
     }
     c->qlds = fine_enough && n_q <= int64_t(kLdsQueries) && getenv("S4P_NO_QLDS") == nullptr &&
-              c->gcoarse.n * 4 + size_t((n_q + 127) & ~int64_t(127)) * 8 + size_t(c->verify_threads / 64) * kQueueWordsPerWave * 4 <= size_t(kVerifyLdsBudget);
+              c->gcoarse.n * 4 + size_t((n_q + int64_t(kSweepStep) - 1) & ~(int64_t(kSweepStep) - 1)) * 8 + size_t(c->verify_threads / 64) * kQueueWordsPerWave * 4 <= size_t(kVerifyLdsBudget);
     std::vector<uint2> packed((size_t)n_q);
     for (int64_t i = 0; i < n_q; ++i) {
       uint32_t u[3];

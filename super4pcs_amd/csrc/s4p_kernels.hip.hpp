@@ -111,7 +111,19 @@ struct LcpGrid {
 // The exact stage takes 128 queued queries at a time, two per lane, so that two point lists are in flight per lane (every
 // batch runs for as many dependent steps as its longest list; two lists per lane halve the steps per query: round 2,
 // k_verify 0.161 -> 0.151 ms alone); the sweep takes two chunks per step so that the queue fits the LDS budget.
-constexpr int kQueueEntries = 384;                // per-wave survivor queue: up to 256 waiting + one step of 2 x 64 entries
+#ifndef S4P_SWEEP_CHUNKS
+// 64-query chunks a sweep step locates together, i.e. reach-word gathers in flight per lane before the first is consumed.  With
+// the early exit the sweep is most of the kernel and a wave spends it waiting on one dependent chain per step (LDS query ->
+// LDS bitmap word -> 8-byte gather) with three waves per SIMD to hide it: 4 chunks per step against 2, same box
+// (tools/r3_run15.sh): k_verify alone 0.0967 -> 0.0863 ms, 121.6 -> 125.1 M candidates/s; every candidate counted in full
+// (no early exit: the exact stage dominates again) 83.5 -> 81.0 M.  The same change cut 12 of 118 vector instructions per step
+// (packed locate, direct ballots) and that alone moved nothing (tools/r3_run14.sh): the sweep waits, it does not compute.
+#define S4P_SWEEP_CHUNKS 4
+#endif
+constexpr uint32_t kSweepChunks = S4P_SWEEP_CHUNKS;
+constexpr uint32_t kSweepStep = 64u * kSweepChunks;             // queries per sweep step; the LDS query copy is padded to a multiple of it
+static_assert(kSweepChunks == 2 || kSweepChunks == 4, "sweep steps of 2 or 4 chunks");
+constexpr int kQueueEntries = 256 + int(kSweepStep);            // per-wave survivor queue: up to 256 waiting + one sweep step
 constexpr uint32_t kQueueHold = 256;              // an exact batch only runs once more than this many wait (or the sweep is over)
 constexpr int kQueueWordsPerWave = kQueueEntries + kQueueEntries / 2;     // 32-bit rank + 16-bit query index per entry: 1920 B
 constexpr int kCoarseMaxWords = 9216;              // 36 KB (two k_verify workgroups per CU share 160 KB: 80 KB each)
@@ -177,6 +189,39 @@ __device__ __forceinline__ void grid_cell(const float* u, const float4 q, int& i
   ix = floor_to_int(__builtin_fmaf(u[0], q.x, __builtin_fmaf(u[1], q.y, __builtin_fmaf(u[2], q.z, u[3]))));
   iy = floor_to_int(__builtin_fmaf(u[4], q.x, __builtin_fmaf(u[5], q.y, __builtin_fmaf(u[6], q.z, u[7]))));
   iz = floor_to_int(__builtin_fmaf(u[8], q.x, __builtin_fmaf(u[9], q.y, __builtin_fmaf(u[10], q.z, u[11]))));
+}
+
+// Two queries at once on the packed-FP32 pipe (v_pk_fma_f32: one issue slot for both): the same three IEEE fma per axis and
+// query in the same order, so the cells are bit-identical to grid_cell's.  The coefficients of an axis travel as two register
+// pairs (a, b) and (c, d); the instruction's operand selectors broadcast one half of a pair to both lanes (op_sel picks the
+// half the LOW result reads, op_sel_hi the half the HIGH result reads), so the transform occupies twelve registers as in the
+// scalar form -- splatting every coefficient into a pair of its own cost twelve more and spilled.
+typedef float v2f_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f_t pk_fma_lo(const v2f_t coef, const v2f_t v, const v2f_t acc) {       // coef.x * v + acc
+  v2f_t r;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(r) : "v"(coef), "v"(v), "v"(acc));
+  return r;
+}
+__device__ __forceinline__ v2f_t pk_fma_hi(const v2f_t coef, const v2f_t v, const v2f_t acc) {       // coef.y * v + acc
+  v2f_t r;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "=v"(r) : "v"(coef), "v"(v), "v"(acc));
+  return r;
+}
+__device__ __forceinline__ v2f_t pk_fma_lo_hi(const v2f_t coef, const v2f_t v) {                      // coef.x * v + coef.y
+  v2f_t r;
+  asm("v_pk_fma_f32 %0, %1, %2, %1 op_sel:[0,0,1] op_sel_hi:[0,1,1]" : "=v"(r) : "v"(coef), "v"(v));
+  return r;
+}
+__device__ __forceinline__ void grid_cell2(const float* u, const float4 q0, const float4 q1, int& ix0, int& iy0, int& iz0, int& ix1, int& iy1, int& iz1) {
+  const v2f_t x = {q0.x, q1.x}, y = {q0.y, q1.y}, z = {q0.z, q1.z};
+  auto axis = [&](const int r) -> v2f_t {
+    const v2f_t ab = {u[4 * r], u[4 * r + 1]}, cd = {u[4 * r + 2], u[4 * r + 3]};
+    return pk_fma_lo(ab, x, pk_fma_hi(ab, y, pk_fma_lo_hi(cd, z)));       // fma(a, x, fma(b, y, fma(c, z, d))) for both queries
+  };
+  const v2f_t px = axis(0), py = axis(1), pz = axis(2);
+  ix0 = floor_to_int(px.x); ix1 = floor_to_int(px.y);
+  iy0 = floor_to_int(py.x); iy1 = floor_to_int(py.y);
+  iz0 = floor_to_int(pz.x); iz1 = floor_to_int(pz.y);
 }
 
 // ---------------------------------------------------------------------------
@@ -533,9 +578,7 @@ __device__ __forceinline__ uint32_t wave_lcp_count(const LcpGrid& g, const LcpTa
   // cell of query i under the candidate, or kNone if it falls outside the grid or into a coarse cube nothing can reach
   // (float -> int conversion saturates and one unsigned compare per axis covers both bounds; a NaN coordinate maps to
   // cell 0 and then fails every exact distance test, so it cannot create an inlier)
-  auto locate = [&](const float4 q, const uint32_t i) -> uint32_t {
-    int ix, iy, iz;
-    grid_cell(X.u, q, ix, iy, iz);
+  auto locate = [&](const int ix, const int iy, const int iz, const uint32_t i) -> uint32_t {
     const bool inb = (uint32_t(ix) < unx) & (uint32_t(iy) < uny) & (uint32_t(iz) < unz) & (i < K.n_q);
     const uint32_t cc = min(mad24(mad24(uint32_t(iz) >> g.cshift, ucy, uint32_t(iy) >> g.cshift), ucx, uint32_t(ix) >> g.cshift), cmax);
     const uint32_t bit = (s_coarse[cc >> 5] >> (cc & 31u)) & 1u;
@@ -548,7 +591,7 @@ __device__ __forceinline__ uint32_t wave_lcp_count(const LcpGrid& g, const LcpTa
   auto push = [&](const uint32_t c, const uint2 w, const uint32_t i) {
     const uint32_t sh = c & 31u;
     const bool reach = (c != kNone) & (((w.x >> sh) & 1u) != 0u);
-    const unsigned long long m = __ballot(reach);
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(reach);       // (the mask itself: __ballot goes through a 0/1 select and a second compare)
     if (COUNT) {
       const unsigned long long m0 = __ballot(c != kNone);
       if (lane == 0) { atomicAdd(K.point_tests + 1, (unsigned long long)__popcll(m0)); atomicAdd(K.point_tests + 2, (unsigned long long)__popcll(m)); }
@@ -563,19 +606,28 @@ __device__ __forceinline__ uint32_t wave_lcp_count(const LcpGrid& g, const LcpTa
   };
   const uint32_t last = K.n_q - 1u;
   bool abandoned = false;
-  for (uint32_t base = 0;; base += 128u) {
+  for (uint32_t base = 0;; base += kSweepStep) {
     const bool more = base < K.n_q;                      // wave-uniform
-    if (more) {                                          // one step: two chunks
-      const uint32_t i0 = base + lane, i1 = i0 + 64u;
-      const float4 q0 = sweep_query<QLDS>(K, s_q, min(i0, last));
-      const float4 q1 = sweep_query<QLDS>(K, s_q, min(i1, last));
-      const uint32_t c0 = locate(q0, i0), c1 = locate(q1, i1);
-      const uint2 w0 = g.reach[c0 == kNone ? 0u : c0 >> 5];
-      const uint2 w1 = g.reach[c1 == kNone ? 0u : c1 >> 5];
-      push(c0, w0, i0); push(c1, w1, i1);
+    if (more) {                                          // one step: kSweepChunks chunks, all their loads in flight together
+      uint32_t ii[kSweepChunks], cc[kSweepChunks];
+      uint2 ww[kSweepChunks];
+#pragma unroll
+      for (uint32_t k = 0; k < kSweepChunks; k += 2u) {
+        ii[k] = base + lane + 64u * k; ii[k + 1u] = ii[k] + 64u;
+        // (the LDS copy is padded to a multiple of a step: no index clamp; locate() rejects i >= n_q)
+        const float4 q0 = sweep_query<QLDS>(K, s_q, QLDS ? ii[k] : min(ii[k], last));
+        const float4 q1 = sweep_query<QLDS>(K, s_q, QLDS ? ii[k + 1u] : min(ii[k + 1u], last));
+        int ix0, iy0, iz0, ix1, iy1, iz1;
+        grid_cell2(X.u, q0, q1, ix0, iy0, iz0, ix1, iy1, iz1);
+        cc[k] = locate(ix0, iy0, iz0, ii[k]); cc[k + 1u] = locate(ix1, iy1, iz1, ii[k + 1u]);
+      }
+#pragma unroll
+      for (uint32_t k = 0; k < kSweepChunks; ++k) ww[k] = g.reach[cc[k] == kNone ? 0u : cc[k] >> 5];
+#pragma unroll
+      for (uint32_t k = 0; k < kSweepChunks; ++k) push(cc[k], ww[k], ii[k]);
       lds_fence();
       // upper bound of what this candidate can still reach: confirmed + waiting + not swept yet (all wave-uniform)
-      const uint32_t swept = min(base + 128u, K.n_q);
+      const uint32_t swept = min(base + kSweepStep, K.n_q);
       if (cnt + qn + (K.n_q - swept) <= K.prune) { abandoned = true; break; }
     }
     // exact stage, ONE code site: 128 entries at a time once more than kQueueHold wait (the queue then still takes a
@@ -587,7 +639,7 @@ __device__ __forceinline__ uint32_t wave_lcp_count(const LcpGrid& g, const LcpTa
       const uint32_t aa = qn - n + min(lane, n - 1u), ab = qn - n + min(lane + 64u, n - 1u);
       if (!SKIP_FINE) {
         const uint32_t h = exact_pair<COUNT>(g, K, Tsrc, va, uint32_t(q_idx[aa]), q_rank[aa], vb, uint32_t(q_idx[ab]), q_rank[ab]);
-        cnt += uint32_t(__popcll(__ballot((h & 1u) != 0u))) + uint32_t(__popcll(__ballot((h & 2u) != 0u)));
+        cnt += uint32_t(__popcll(__builtin_amdgcn_ballot_w64((h & 1u) != 0u))) + uint32_t(__popcll(__builtin_amdgcn_ballot_w64((h & 2u) != 0u)));
       }
       qn -= n;
       lds_fence();
@@ -599,9 +651,9 @@ __device__ __forceinline__ uint32_t wave_lcp_count(const LcpGrid& g, const LcpTa
   return cnt;                                            // wave-uniform
 }
 
-// Global -> LDS copy of the quantised queries (8 B each), padded to a multiple of 128 with the last entry
+// Global -> LDS copy of the quantised queries (8 B each), padded to a multiple of a sweep step with the last entry
 __device__ __forceinline__ void stage_queries(const LcpTask& K, uint2* s_q) {
-  const uint32_t n_pad = (K.n_q + 127u) & ~127u;
+  const uint32_t n_pad = (K.n_q + kSweepStep - 1u) & ~(kSweepStep - 1u);
   for (uint32_t w = threadIdx.x; w < n_pad; w += blockDim.x) s_q[w] = K.qq.packed[min(w, K.n_q - 1u)];
 }
 
@@ -1404,7 +1456,7 @@ __global__ __launch_bounds__(kVerifyMaxThreads, 6) void k_verify(VerifyParams P)
   extern __shared__ uint32_t s_mem[];
   uint32_t* s_coarse = s_mem;                              // LDS: coarse bitmap | quantised queries (QLDS) | 16 survivor queues
   uint2* s_q = reinterpret_cast<uint2*>(s_mem + P.grid.coarse_words);
-  uint32_t* s_queue = reinterpret_cast<uint32_t*>(s_q + (QLDS ? ((P.n_q + 127u) & ~127u) : 0u)) + (threadIdx.x >> 6) * kQueueWordsPerWave;
+  uint32_t* s_queue = reinterpret_cast<uint32_t*>(s_q + (QLDS ? ((P.n_q + kSweepStep - 1u) & ~(kSweepStep - 1u)) : 0u)) + (threadIdx.x >> 6) * kQueueWordsPerWave;
   __shared__ uint32_t s_next, s_last, s_pruned;
   __shared__ uint32_t s_wcnt[kVerifyMaxThreads / 64], s_wcand[kVerifyMaxThreads / 64];
   __shared__ unsigned long long s_wtag[kVerifyMaxThreads / 64];
@@ -1522,7 +1574,7 @@ __global__ __launch_bounds__(kVerifyMaxThreads) void k_verify_T(VerifyTParams P)
   extern __shared__ uint32_t s_mem[];
   uint32_t* s_coarse = s_mem;
   uint2* s_q = reinterpret_cast<uint2*>(s_mem + P.grid.coarse_words);
-  uint32_t* s_queue = reinterpret_cast<uint32_t*>(s_q + (QLDS ? ((P.n_q + 127u) & ~127u) : 0u)) + (threadIdx.x >> 6) * kQueueWordsPerWave;
+  uint32_t* s_queue = reinterpret_cast<uint32_t*>(s_q + (QLDS ? ((P.n_q + kSweepStep - 1u) & ~(kSweepStep - 1u)) : 0u)) + (threadIdx.x >> 6) * kQueueWordsPerWave;
   LcpTask K;
   K.q4 = P.q4; K.n_q = P.n_q; K.qq = P.qq; K.T = reinterpret_cast<const float4*>(P.T); K.t_stride = 4u;
   K.point_tests = COUNT ? &P.ctr->point_tests : nullptr;
