@@ -825,7 +825,7 @@ int32_t s4p_create(const s4p_options* opt, const s4p_limits* lim, int32_t device
     if ((e = hipEventCreateWithFlags(&c->done[sl], hipEventDisableTiming)) != hipSuccess) return fail(e, "hipEventCreate");
   }
   {  // allow the verify kernels their dynamic LDS (coarse bitmap + quantised queries + survivor queues)
-    const int max_lds = kVerifyLdsBudget;
+    const int max_lds = kVerifyLdsOnePerCu;
     const void* fns[] = {(const void*)k_verify<false, false>, (const void*)k_verify<false, true>, (const void*)k_verify<true, false>, (const void*)k_verify<true, true>,
                          (const void*)k_verify_T<false, false>, (const void*)k_verify_T<false, true>, (const void*)k_verify_T<true, false>, (const void*)k_verify_T<true, true>};
     for (const void* fn : fns)
@@ -1104,8 +1104,9 @@ int32_t s4p_set_clouds(s4p_ctx* c, const float* px, const float* py, const float
       c->qq.step[k] = (hi[k] > lo[k]) ? (hi[k] - lo[k]) / 65535.0f : 1.0f;
       if (!(0.5f * c->qq.step[k] * c->hgrid.inv_h < 0.004f)) fine_enough = false;
     }
+    const size_t lds_room = size_t(c->verify_blocks <= 256u ? kVerifyLdsOnePerCu : kVerifyLdsBudget);      // (verify_blocks was settled by the structure build above)
     c->qlds = fine_enough && n_q <= int64_t(kLdsQueries) && getenv("S4P_NO_QLDS") == nullptr &&
-              c->gcoarse.n * 4 + size_t((n_q + int64_t(kSweepStep) - 1) & ~(int64_t(kSweepStep) - 1)) * 8 + size_t(c->verify_threads / 64) * kQueueWordsPerWave * 4 <= size_t(kVerifyLdsBudget);
+              c->gcoarse.n * 4 + size_t((n_q + int64_t(kSweepStep) - 1) & ~(int64_t(kSweepStep) - 1)) * 8 + size_t(c->verify_threads / 64) * kQueueWordsPerWave * 4 <= lds_room;
     std::vector<uint2> packed((size_t)n_q);
     for (int64_t i = 0; i < n_q; ++i) {
       uint32_t u[3];

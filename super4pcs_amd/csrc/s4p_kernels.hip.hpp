@@ -125,9 +125,14 @@ constexpr uint32_t kSweepStep = 64u * kSweepChunks;             // queries per s
 static_assert(kSweepChunks == 2 || kSweepChunks == 4, "sweep steps of 2 or 4 chunks");
 constexpr int kQueueEntries = 256 + int(kSweepStep);            // per-wave survivor queue: up to 256 waiting + one sweep step
 constexpr uint32_t kQueueHold = 256;              // an exact batch only runs once more than this many wait (or the sweep is over)
-constexpr int kQueueWordsPerWave = kQueueEntries + kQueueEntries / 2;     // 32-bit rank + 16-bit query index per entry: 1920 B
+constexpr int kQueueWordsPerWave = kQueueEntries + kQueueEntries / 2;     // 32-bit rank + 16-bit query index per entry: 3 KB
 constexpr int kCoarseMaxWords = 9216;              // 36 KB (two k_verify workgroups per CU share 160 KB: 80 KB each)
-constexpr int kVerifyLdsBudget = 80 * 1024 - 768;  // per workgroup: coarse bitmap + survivor queues (2.25 KB per wave) [+ quantised queries]
+// LDS per k_verify workgroup: coarse bitmap + survivor queues (3 KB per wave) [+ quantised queries].  Two workgroups per CU
+// (structure streaming from HBM, chunk passes) share 160 KB: 80 KB each.  With ONE workgroup per CU (structure cache
+// resident: verify_blocks <= 256) the quantised query copy may take more -- measured with 512-entry queues at 768 threads,
+// where it no longer fits 80 KB (tools/r3_run16.sh): float queries from global memory 125.5 M candidates/s, LDS copy 130.2 M.
+constexpr int kVerifyLdsBudget = 80 * 1024 - 768;
+constexpr int kVerifyLdsOnePerCu = 112 * 1024 - 768;
 
 // value held by every lane of the wave -> SGPR
 __device__ __forceinline__ float wave_uniform(float v) {
@@ -427,10 +432,10 @@ __global__ __launch_bounds__(256) void k_build_masks(MaskParams P) {
 // LCP scoring: Verify() (match4pcsBase.cc:508-567) without the early exit.
 //
 // Structure per wave and candidate:
-//   sweep (two 64-query chunks per step): position in grid units (3 converts + 9 fma + 3 floor-converts), L0 test of the
-//     cell's coarse cube against the LDS bitmap, L1 reach word (8 B gather; rejected lanes read word 0, one broadcast
-//     line); queries whose cell is reachable are compacted (ballot/prefix) into the wave's LDS queue as {query, rank of
-//     the cell among the reachable ones};
+//   sweep (kSweepChunks 64-query chunks per step, their gathers in flight together): position in grid units (3 converts
+//     + 9 fma + 3 floor-converts, two queries per packed instruction), L0 test of the cell's coarse cube against the LDS
+//     bitmap, L1 reach word (8 B gather; rejected lanes read word 0, one broadcast line); queries whose cell is reachable
+//     are compacted (ballot/prefix) into the wave's LDS queue as {query, rank of the cell among the reachable ones};
 //   exact stage whenever 128 entries wait (and once at the end): TWO entries per lane -- the candidate's exact 3x4, list
 //     headers, 4x4x4 sub-cell masks, then the exact predicate sqdist <= delta^2 (kdtree.h:417-421) against the listed
 //     points, both lists advancing together with four 16-byte loads in flight per lane and dependent step.
