@@ -174,7 +174,7 @@ struct s4p_ctx {
   s4p_profile prof{};
   uint64_t last_K = 0;
   uint32_t verify_blocks = 256; bool verify_blocks_fixed = false, verify_blocks_env = false;   // per set_clouds (see there); S4P_VERIFY_BLOCKS fixes it
-  int verify_threads = kVerifyThreadsCached;      // per set_clouds: kVerifyMaxThreads when the point lists exceed the Infinity Cache; S4P_VERIFY_THREADS overrides
+  int verify_threads = kVerifyThreadsCached;      // per set_clouds; S4P_VERIFY_THREADS overrides
   int ablate = 0;                    // S4P_ABLATE (profiling aid, read once at creation)
   // A/B aid: S4P_FUSE_GATE=0 runs the rigid transform + rms gate as a k_gate launch instead of
   // inside k_quads' flush (measured slower)

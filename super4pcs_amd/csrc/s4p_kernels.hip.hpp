@@ -1425,11 +1425,11 @@ __global__ __launch_bounds__(256) void k_quads(QuadParams P) {
 // Persistent workgroups of up to 1024 threads, one wave64 per gated candidate; the length of the gated list lives in
 // device memory (no host round trip).  LDS per workgroup: coarse bitmap (<= 34 KB) + one private survivor queue per wave.
 // ---------------------------------------------------------------------------
-// k_verify / k_verify_T are launched with kVerifyThreadsCached (structure inside the Infinity Cache: the kernel is VALU-issue
-// bound, six waves per SIMD contend less; measured 0.1496 / 0.1443 / 0.1424 / 0.1433 / 0.1458 ms at 512 / 640 / 768 / 896 /
-// 1024 threads, tools/gpu_run19.sh) or with kVerifyMaxThreads (point lists beyond the cache: HBM bound, more waves in
-// flight win: 3.3 vs 4.1 TB/s on the configs[4] structure).  The block size is a launch parameter; the kernels only
-// assume blockDim.x <= kVerifyMaxThreads.
+// k_verify / k_verify_T are launched with kVerifyThreadsCached threads per workgroup (measured 0.1496 / 0.1443 / 0.1424 /
+// 0.1433 / 0.1458 ms at 512 / 640 / 768 / 896 / 1024 threads, tools/gpu_run19.sh; S4P_VERIFY_THREADS overrides) and with one
+// workgroup per CU while the structure is cache resident, two when the point lines stream from HBM or a chunk pass has the
+// chip to itself (s4p_capi.hip: verify_blocks / verify_grid).  The block size is a launch parameter; the kernels only assume
+// blockDim.x <= kVerifyMaxThreads.
 constexpr int kVerifyMaxThreads = 1024;
 constexpr int kVerifyThreadsCached = 768;
 constexpr int kVerifyMaxBlocks = 4096;
