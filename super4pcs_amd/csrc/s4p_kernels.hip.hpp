@@ -122,7 +122,7 @@ struct LcpGrid {
 #endif
 constexpr uint32_t kSweepChunks = S4P_SWEEP_CHUNKS;
 constexpr uint32_t kSweepStep = 64u * kSweepChunks;             // queries per sweep step; the LDS query copy is padded to a multiple of it
-static_assert(kSweepChunks == 2 || kSweepChunks == 4, "sweep steps of 2 or 4 chunks");
+static_assert(kSweepChunks == 2 || kSweepChunks == 4 || kSweepChunks == 8, "sweep steps of 2, 4 or 8 chunks");
 constexpr int kQueueEntries = 256 + int(kSweepStep);            // per-wave survivor queue: up to 256 waiting + one sweep step
 constexpr uint32_t kQueueHold = 256;              // an exact batch only runs once more than this many wait (or the sweep is over)
 constexpr int kQueueWordsPerWave = kQueueEntries + kQueueEntries / 2;     // 32-bit rank + 16-bit query index per entry: 3 KB
