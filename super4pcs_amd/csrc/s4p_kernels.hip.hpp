@@ -123,8 +123,20 @@ struct LcpGrid {
 constexpr uint32_t kSweepChunks = S4P_SWEEP_CHUNKS;
 constexpr uint32_t kSweepStep = 64u * kSweepChunks;             // queries per sweep step; the LDS query copy is padded to a multiple of it
 static_assert(kSweepChunks == 2 || kSweepChunks == 4 || kSweepChunks == 8, "sweep steps of 2, 4 or 8 chunks");
+// S4P_SWEEP_STAGED=1 (build option, UNMEASURED -- DESIGN.md section 9 item 1): the sweep touches LDS only (locate + coarse
+// bitmap) and queues the L0 survivors; the reach-word gather runs later, on the queued entries, and only for candidates the
+// early exit has not dismissed by then.  The queue then holds both kinds of entries and is larger.
+#ifndef S4P_SWEEP_STAGED
+#define S4P_SWEEP_STAGED 0
+#endif
+#if S4P_SWEEP_STAGED
+constexpr int kQueueEntries = 512 + int(kSweepStep);            // reach-tested entries below, L0 survivors of the sweep above them
+constexpr uint32_t kQueueHold = 512;              // the queue is drained (reach test, then exact batches) once more than this many wait
+constexpr uint32_t kExactHold = 256;              // ... down to this many reach-tested entries
+#else
 constexpr int kQueueEntries = 256 + int(kSweepStep);            // per-wave survivor queue: up to 256 waiting + one sweep step
 constexpr uint32_t kQueueHold = 256;              // an exact batch only runs once more than this many wait (or the sweep is over)
+#endif
 constexpr int kQueueWordsPerWave = kQueueEntries + kQueueEntries / 2;     // 32-bit rank + 16-bit query index per entry: 3 KB
 constexpr int kCoarseMaxWords = 9216;              // 36 KB (two k_verify workgroups per CU share 160 KB: 80 KB each)
 // LDS per k_verify workgroup: coarse bitmap + survivor queues (3 KB per wave) [+ quantised queries].  Two workgroups per CU
@@ -655,6 +667,120 @@ __device__ __forceinline__ uint32_t wave_lcp_count(const LcpGrid& g, const LcpTa
   __builtin_amdgcn_wave_barrier();
   return cnt;                                            // wave-uniform
 }
+
+#if S4P_SWEEP_STAGED
+// The same count with a sweep that stays inside the CU.  Queue layout: [0, nb) entries that passed the reach test {rank of the
+// cell among the reachable ones, query}, [nb, nb + na) L0 survivors of the sweep {cell, query}.
+//   sweep step: locate, coarse bitmap, compaction of the L0 survivors -- no global access;
+//   bound after every step: confirmed + nb + na + not swept yet <= prune -> abandoned (an L0 survivor is a possible inlier);
+//   drain (queue filling up, or sweep over and the candidate still alive): the reach word of every L0 survivor, 64 entries per
+//     gather on dense lanes; survivors become reach-tested entries in place (they are written below the read position);
+//     then the bound again with the reach-tested entries, then exact batches as in wave_lcp_count.
+template <bool COUNT, bool SKIP_FINE, bool QLDS>
+__device__ __forceinline__ uint32_t wave_lcp_count_staged(const LcpGrid& g, const LcpTask& K, const uint32_t* s_coarse, const uint2* s_q,
+                                                          uint32_t* s_queue, const float4* Tsrc) {
+  constexpr uint32_t kNone = 0xFFFFFFFFu;
+  const uint32_t lane = threadIdx.x & 63u;
+  uint32_t* q_rank = s_queue;                                                     // 32-bit word of an entry: rank, or cell
+  uint16_t* q_idx = reinterpret_cast<uint16_t*>(s_queue + kQueueEntries);         // its query index
+  uint32_t cnt = 0, nb = 0, na = 0;
+  const uint32_t cmax = g.coarse_words * 32u - 1u;
+  const uint32_t unx = uint32_t(g.nx), uny = uint32_t(g.ny), unz = uint32_t(g.nz);
+  const uint32_t ucx = uint32_t(g.cnx), ucy = uint32_t(g.cny);
+  GridXf X;
+  { float T[12]; load_rows(Tsrc, T); X = locating_xf<QLDS>(g, K, T); }
+  auto locate = [&](const int ix, const int iy, const int iz, const uint32_t i) -> uint32_t {
+    const bool inb = (uint32_t(ix) < unx) & (uint32_t(iy) < uny) & (uint32_t(iz) < unz) & (i < K.n_q);
+    const uint32_t cc = min(mad24(mad24(uint32_t(iz) >> g.cshift, ucy, uint32_t(iy) >> g.cshift), ucx, uint32_t(ix) >> g.cshift), cmax);
+    const uint32_t bit = (s_coarse[cc >> 5] >> (cc & 31u)) & 1u;
+    const uint32_t c = mad24(mad24(uint32_t(iz), uny, uint32_t(iy)), unx, uint32_t(ix));
+    return (inb & (bit != 0u)) ? c : kNone;
+  };
+  auto lds_fence = [&]() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); };
+  auto push_cell = [&](const uint32_t c, const uint32_t i) {
+    const bool hit = c != kNone;
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
+    if (COUNT) { if (lane == 0) atomicAdd(K.point_tests + 1, (unsigned long long)__popcll(m)); }
+    if (m == 0ull) return;
+    if (hit) {
+      const uint32_t at = nb + na + __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u));
+      q_rank[at] = c;
+      q_idx[at] = uint16_t(i);
+    }
+    na += uint32_t(__popcll(m));
+  };
+  auto drain = [&]() {                                     // reach test of [nb, nb + na), survivors appended to [0, nb)
+    uint32_t rd = nb;
+    const uint32_t end = nb + na;
+    while (rd < end) {                                     // wave-uniform
+      const uint32_t n = min(end - rd, 64u);
+      const bool v = lane < n;
+      const uint32_t c = q_rank[rd + min(lane, n - 1u)];
+      const uint32_t i = uint32_t(q_idx[rd + min(lane, n - 1u)]);
+      lds_fence();                                         // every lane holds its entry before any slot of this batch is rewritten
+      const uint2 w = g.reach[c >> 5];
+      const uint32_t sh = c & 31u;
+      const bool reach = v & (((w.x >> sh) & 1u) != 0u);
+      const unsigned long long m = __builtin_amdgcn_ballot_w64(reach);
+      if (COUNT) { if (lane == 0) atomicAdd(K.point_tests + 2, (unsigned long long)__popcll(m)); }
+      if (reach) {                                         // nb <= rd and at most n survivors: the writes stay below rd + n
+        const uint32_t at = nb + __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u));
+        q_rank[at] = w.y + uint32_t(__popc(w.x & ((1u << sh) - 1u)));
+        q_idx[at] = uint16_t(i);
+      }
+      nb += uint32_t(__popcll(m));
+      rd += n;
+      lds_fence();
+    }
+    na = 0u;
+  };
+  const uint32_t last = K.n_q - 1u;
+  bool abandoned = false;
+  for (uint32_t base = 0;; base += kSweepStep) {
+    const bool more = base < K.n_q;                        // wave-uniform
+    const uint32_t unswept = K.n_q - min(base + kSweepStep, K.n_q);
+    if (more) {
+      uint32_t ii[kSweepChunks], cc[kSweepChunks];
+#pragma unroll
+      for (uint32_t k = 0; k < kSweepChunks; k += 2u) {
+        ii[k] = base + lane + 64u * k; ii[k + 1u] = ii[k] + 64u;
+        const float4 q0 = sweep_query<QLDS>(K, s_q, QLDS ? ii[k] : min(ii[k], last));
+        const float4 q1 = sweep_query<QLDS>(K, s_q, QLDS ? ii[k + 1u] : min(ii[k + 1u], last));
+        int ix0, iy0, iz0, ix1, iy1, iz1;
+        grid_cell2(X.u, q0, q1, ix0, iy0, iz0, ix1, iy1, iz1);
+        cc[k] = locate(ix0, iy0, iz0, ii[k]); cc[k + 1u] = locate(ix1, iy1, iz1, ii[k + 1u]);
+      }
+#pragma unroll
+      for (uint32_t k = 0; k < kSweepChunks; ++k) push_cell(cc[k], ii[k]);
+      lds_fence();
+      if (cnt + nb + na + unswept <= K.prune) { abandoned = true; break; }
+    }
+    if (nb + na > kQueueHold || (!more && (nb + na) != 0u)) {
+      drain();
+      if (cnt + nb + (more ? unswept : 0u) <= K.prune) { abandoned = true; break; }
+      while (nb > kExactHold || (!more && nb != 0u)) {
+        if (!more && cnt + nb <= K.prune) { abandoned = true; break; }
+        const uint32_t n = min(nb, 128u);
+        const bool va = lane < n, vb = lane + 64u < n;
+        const uint32_t aa = nb - n + min(lane, n - 1u), ab = nb - n + min(lane + 64u, n - 1u);
+        if (!SKIP_FINE) {
+          const uint32_t h = exact_pair<COUNT>(g, K, Tsrc, va, uint32_t(q_idx[aa]), q_rank[aa], vb, uint32_t(q_idx[ab]), q_rank[ab]);
+          cnt += uint32_t(__popcll(__builtin_amdgcn_ballot_w64((h & 1u) != 0u))) + uint32_t(__popcll(__builtin_amdgcn_ballot_w64((h & 2u) != 0u)));
+        }
+        nb -= n;
+        lds_fence();
+      }
+    }
+    if (!more || abandoned) break;
+  }
+  if (abandoned && K.prune != 0u && K.pruned != nullptr && lane == 0) atomicAdd(K.pruned, 1u);
+  __builtin_amdgcn_wave_barrier();
+  return cnt;
+}
+#define S4P_WAVE_LCP_COUNT wave_lcp_count_staged
+#else
+#define S4P_WAVE_LCP_COUNT wave_lcp_count
+#endif
 
 // Global -> LDS copy of the quantised queries (8 B each), padded to a multiple of a sweep step with the last entry
 __device__ __forceinline__ void stage_queries(const LcpTask& K, uint2* s_q) {
@@ -1491,8 +1617,8 @@ __global__ __launch_bounds__(kVerifyMaxThreads, 6) void k_verify(VerifyParams P)
       if (i >= hi) break;
       i = blockIdx.x + i * gridDim.x;
       const float4* src = P.cand_T + 3 * size_t(i);         // one candidate per wave
-      const uint32_t cnt = P.ablate == 1 ? wave_lcp_count<COUNT, true, QLDS>(P.grid, K, s_coarse, s_q, s_queue, src)
-                                         : wave_lcp_count<COUNT, false, QLDS>(P.grid, K, s_coarse, s_q, s_queue, src);
+      const uint32_t cnt = P.ablate == 1 ? S4P_WAVE_LCP_COUNT<COUNT, true, QLDS>(P.grid, K, s_coarse, s_q, s_queue, src)
+                                         : S4P_WAVE_LCP_COUNT<COUNT, false, QLDS>(P.grid, K, s_coarse, s_q, s_queue, src);
       const uint32_t kraw = uint32_t(__builtin_amdgcn_readfirstlane(int(P.cand_idx[i])));
       const uint32_t k = kraw & ~kBorderFlag;
       const unsigned long long tag = P.tags[k];
@@ -1590,7 +1716,7 @@ __global__ __launch_bounds__(kVerifyMaxThreads) void k_verify_T(VerifyTParams P)
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
   for (uint32_t k = wave; k < P.B; k += nwaves) {
-    const uint32_t cnt = wave_lcp_count<COUNT, false, QLDS>(P.grid, K, s_coarse, s_q, s_queue, K.T + 4 * size_t(k));
+    const uint32_t cnt = S4P_WAVE_LCP_COUNT<COUNT, false, QLDS>(P.grid, K, s_coarse, s_q, s_queue, K.T + 4 * size_t(k));
     if (lane == 0) P.counts[k] = cnt;
   }
 }
