@@ -777,7 +777,19 @@ __device__ __forceinline__ uint32_t wave_lcp_count_staged(const LcpGrid& g, cons
   __builtin_amdgcn_wave_barrier();
   return cnt;
 }
+// With the exit off every candidate pays for all stages and the fused sweep is ahead again (86.4 vs 89.7 M candidates/s,
+// tools/r3_run18.sh): S4P_SWEEP_STAGED=2 picks per candidate -- staged when a bound is in force, fused otherwise (unmeasured).
+template <bool COUNT, bool SKIP_FINE, bool QLDS>
+__device__ __forceinline__ uint32_t wave_lcp_count_auto(const LcpGrid& g, const LcpTask& K, const uint32_t* s_coarse, const uint2* s_q,
+                                                        uint32_t* s_queue, const float4* Tsrc) {
+  if (K.prune != 0u) return wave_lcp_count_staged<COUNT, SKIP_FINE, QLDS>(g, K, s_coarse, s_q, s_queue, Tsrc);      // wave-uniform
+  return wave_lcp_count<COUNT, SKIP_FINE, QLDS>(g, K, s_coarse, s_q, s_queue, Tsrc);
+}
+#if S4P_SWEEP_STAGED == 2
+#define S4P_WAVE_LCP_COUNT wave_lcp_count_auto
+#else
 #define S4P_WAVE_LCP_COUNT wave_lcp_count_staged
+#endif
 #else
 #define S4P_WAVE_LCP_COUNT wave_lcp_count
 #endif
