@@ -83,6 +83,7 @@ struct s4p_ctx {
   // device state
   DevBuf<uint2> greach; DevBuf<uint4> glist_hdr; DevBuf<uint32_t> gcoarse; DevBuf<float4> gnbr; DevBuf<float4> q4, q4v;
   DevBuf<uint2> qquant; QuantQ qq{}; bool qlds = false;      // 16-bit copy of the Morton-ordered queries for the LDS-resident sweep
+  DevBuf<float> qsoa; bool lean = false;                     // float copy x | y | z of the same, padded (the lean sweep of k_verify: early-exit mode)
   DevBuf<float> qx, qy, qz, ux, uy, uz, qnx, qny, qnz, qcr, qcg, qcb;
   // Lanes = HIP streams with private per-base device buffers.  Consecutive bases rotate over the lanes, so the
   // small kernels of base t+1 (pairs, hash build, quad enumeration) run concurrently with the
@@ -184,8 +185,12 @@ struct s4p_ctx {
   double set_clouds_s[4] = {0, 0, 0, 0};      // last s4p_set_clouds: host copies + unit frame + grid plan | device build of the LCP structure | Q-side uploads | total
 
   size_t verify_lds_bytes() const {
-    return gcoarse.n * 4 + (qlds ? size_t((n_q + kSweepStep - 1u) & ~(kSweepStep - 1u)) * 8 : 0) + size_t(verify_threads / 64) * kQueueWordsPerWave * 4;
+    return gcoarse.n * 4 + (qlds ? size_t((n_q + kSweepStep - 1u) & ~(kSweepStep - 1u)) * 8 : 0) + size_t(verify_threads / 64) * kQueueWordsPerWave * 4 + sizeof(VerifyShared);
   }
+  size_t lean_lds_bytes() const {
+    return gcoarse.n * 4 + size_t((n_q + kSweepStep - 1u) & ~(kSweepStep - 1u)) * 12 + size_t(verify_threads / 64) * kLeanQueue * 2 + sizeof(VerifyShared);
+  }
+  bool use_lean() const { return lean && best_hint != 0u; }
   // (a chunk pass scores ~10^7 candidates with the chip to itself: two workgroups per CU, as for the HBM-bound structure;
   // measured at the 20 000-point sample: 0.50 s per pass with 512 workgroups, 0.66 s with 256)
   bool chunk_pass = false;
@@ -400,7 +405,7 @@ void launch_gate_kernel(s4p_ctx* c, const GateParams& G) {
 int32_t launch_verify(s4p_ctx* c, const BaseFrame& bf) {
   s4p_ctx::Lane& L = c->lane[c->cur];
   VerifyParams V{};
-  V.grid = c->dev_grid(); V.q4 = c->q4.p; V.q4v = c->q4v.p; V.qq = c->qq; V.n_q = c->n_q; V.base = bf;
+  V.grid = c->dev_grid(); V.q4 = c->q4.p; V.q4v = c->q4v.p; V.qq = c->qq; V.qsoa = c->qsoa.p; V.n_q = c->n_q; V.base = bf;
   V.quads = L.quads.p; V.tags = L.tags.p; V.counts = L.counts.p; V.cand_idx = L.cand_idx.p; V.cand_T = L.cand_T.p;
   V.ctr = L.ctr.p; V.res = L.ctr.p + 1; V.slots = L.slots.p; V.border = L.border.p; V.count_tests = c->prof_points ? 1 : 0;
   V.prune = c->best_hint;
@@ -412,10 +417,12 @@ int32_t launch_verify(s4p_ctx* c, const BaseFrame& bf) {
     vs = L.vstream;
   }
   if (c->prof_events) HIPCHK(c, hipEventRecord(c->ev[c->cur][0], vs));
-  const size_t lds = c->verify_lds_bytes();
+  const bool lean = c->use_lean();                           // a bound is in force: the lean sweep (s4p_kernels.hip.hpp)
+  const size_t lds = lean ? c->lean_lds_bytes() : c->verify_lds_bytes();
   const dim3 grid(c->verify_grid()), block(c->verify_threads);
-  if (c->prof_points) { if (c->qlds) hipLaunchKernelGGL((k_verify<true, true>), grid, block, lds, vs, V); else hipLaunchKernelGGL((k_verify<true, false>), grid, block, lds, vs, V); }
-  else { if (c->qlds) hipLaunchKernelGGL((k_verify<false, true>), grid, block, lds, vs, V); else hipLaunchKernelGGL((k_verify<false, false>), grid, block, lds, vs, V); }
+  if (lean) { if (c->prof_points) hipLaunchKernelGGL((k_verify<true, false, true>), grid, block, lds, vs, V); else hipLaunchKernelGGL((k_verify<false, false, true>), grid, block, lds, vs, V); }
+  else if (c->prof_points) { if (c->qlds) hipLaunchKernelGGL((k_verify<true, true, false>), grid, block, lds, vs, V); else hipLaunchKernelGGL((k_verify<true, false, false>), grid, block, lds, vs, V); }
+  else { if (c->qlds) hipLaunchKernelGGL((k_verify<false, true, false>), grid, block, lds, vs, V); else hipLaunchKernelGGL((k_verify<false, false, false>), grid, block, lds, vs, V); }
   if (c->prof_events) HIPCHK(c, hipEventRecord(c->ev[c->cur][1], vs));
   HIPCHK(c, hipGetLastError());
   return S4P_OK;
@@ -825,8 +832,9 @@ int32_t s4p_create(const s4p_options* opt, const s4p_limits* lim, int32_t device
     if ((e = hipEventCreateWithFlags(&c->done[sl], hipEventDisableTiming)) != hipSuccess) return fail(e, "hipEventCreate");
   }
   {  // allow the verify kernels their dynamic LDS (coarse bitmap + quantised queries + survivor queues)
-    const int max_lds = kVerifyLdsOnePerCu;
-    const void* fns[] = {(const void*)k_verify<false, false>, (const void*)k_verify<false, true>, (const void*)k_verify<true, false>, (const void*)k_verify<true, true>,
+    const int max_lds = kVerifyLdsOnePerCu + int(sizeof(VerifyShared));
+    const void* fns[] = {(const void*)k_verify<false, false, false>, (const void*)k_verify<false, true, false>, (const void*)k_verify<true, false, false>, (const void*)k_verify<true, true, false>,
+                         (const void*)k_verify<false, false, true>, (const void*)k_verify<true, false, true>,
                          (const void*)k_verify_T<false, false>, (const void*)k_verify_T<false, true>, (const void*)k_verify_T<true, false>, (const void*)k_verify_T<true, true>};
     for (const void* fn : fns)
       if ((e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds)) != hipSuccess) return fail(e, "hipFuncSetAttribute");
@@ -931,7 +939,7 @@ void s4p_destroy(s4p_ctx* c) {
   (void)hipSetDevice(c->device);
   for (auto& L : c->lane) { if (L.stream) (void)hipStreamSynchronize(L.stream); if (L.vstream) (void)hipStreamSynchronize(L.vstream); }
   c->greach.free(); c->glist_hdr.free(); c->gnbr.free();
-  c->gcoarse.free(); c->q4.free(); c->q4v.free(); c->qquant.free();
+  c->gcoarse.free(); c->q4.free(); c->q4v.free(); c->qquant.free(); c->qsoa.free();
   c->qx.free(); c->qy.free(); c->qz.free(); c->ux.free(); c->uy.free(); c->uz.free();
   c->qnx.free(); c->qny.free(); c->qnz.free(); c->qcr.free(); c->qcg.free(); c->qcb.free();
   for (auto& L : c->lane) {
@@ -1120,6 +1128,16 @@ int32_t s4p_set_clouds(s4p_ctx* c, const float* px, const float* py, const float
     HIPCHK(c, c->qquant.alloc(size_t(n_q)));
     HIPCHK(c, hipMemcpy(c->qquant.p, packed.data(), size_t(n_q) * sizeof(uint2), hipMemcpyHostToDevice));
     c->qq.packed = c->qquant.p;
+    // float copy for the lean sweep (early-exit mode): x | y | z, each padded to a multiple of a sweep step with far-away points
+    c->lean = false; c->qsoa.free();
+    if (n_q <= int64_t(kLeanMaxQueries) && getenv("S4P_NO_LEAN") == nullptr) {
+      const size_t n_pad = size_t((n_q + int64_t(kSweepStep) - 1) & ~(int64_t(kSweepStep) - 1));
+      std::vector<float> soa(3 * n_pad, kLeanPad);
+      for (int64_t i = 0; i < n_q; ++i) { soa[size_t(i)] = qv[size_t(i)].x; soa[n_pad + size_t(i)] = qv[size_t(i)].y; soa[2 * n_pad + size_t(i)] = qv[size_t(i)].z; }
+      HIPCHK(c, c->qsoa.alloc(3 * n_pad));
+      HIPCHK(c, hipMemcpy(c->qsoa.p, soa.data(), 3 * n_pad * sizeof(float), hipMemcpyHostToDevice));
+      c->lean = c->gcoarse.n * 4 + n_pad * 12 + size_t(c->verify_threads / 64) * kLeanQueue * 2 <= lds_room;
+    }
   }
   auto up = [&](DevBuf<float>& d, const float* src) -> hipError_t {
     hipError_t e = d.alloc(n_q); if (e != hipSuccess) return e;

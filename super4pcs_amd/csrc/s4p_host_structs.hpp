@@ -446,7 +446,9 @@ struct LcpGridHost {
     reach = double(delta) + 0.01 * double(h);
     cshift = 0;      // coarse level: smallest shift whose bitmap fits the LDS budget (padded to 16 B for the staging)
     while (true) {
-      cnx = ((nx - 1) >> cshift) + 1; cny = ((ny - 1) >> cshift) + 1; cnz = ((nz - 1) >> cshift) + 1;
+      // cnx, cny, cnz: PITCHES of the coarse bitmap = cubes per axis + one cube that no cell maps to (always 0): the lean sweep
+      // of k_verify clamps a coordinate outside the grid onto it instead of testing bounds (s4p_kernels.hip.hpp)
+      cnx = ((nx - 1) >> cshift) + 2; cny = ((ny - 1) >> cshift) + 2; cnz = ((nz - 1) >> cshift) + 2;
       const uint64_t cw = (uint64_t(cnx) * cny * cnz + 31) / 32;
       if (cw <= max_coarse_words) { coarse_words = uint32_t((cw + 3) & ~uint64_t(3)); break; }
       ++cshift;

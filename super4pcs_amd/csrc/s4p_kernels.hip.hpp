@@ -127,7 +127,7 @@ static_assert(kSweepChunks == 2 || kSweepChunks == 4 || kSweepChunks == 8, "swee
 // bitmap) and queues the L0 survivors; the reach-word gather runs later, on the queued entries, and only for candidates the
 // early exit has not dismissed by then.  The queue then holds both kinds of entries and is larger.
 #ifndef S4P_SWEEP_STAGED
-#define S4P_SWEEP_STAGED 0
+#define S4P_SWEEP_STAGED 2
 #endif
 #if S4P_SWEEP_STAGED
 constexpr int kQueueEntries = 512 + int(kSweepStep);            // reach-tested entries below, L0 survivors of the sweep above them
@@ -191,6 +191,12 @@ __device__ __forceinline__ float coarse_scale(const LcpGrid& g) { return __built
 __device__ __forceinline__ uint32_t mad24(uint32_t a, uint32_t b, uint32_t c) {
   uint32_t r;
   asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+// the same with a wave-uniform multiplier taken straight from a scalar register (no v_mov per use)
+__device__ __forceinline__ uint32_t mad24_s(uint32_t a, uint32_t b_uniform, uint32_t c) {
+  uint32_t r;
+  asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b_uniform), "v"(c));
   return r;
 }
 // floor(x) as an integer in one instruction (V_CVT_FLR_I32_F32; the compiler only emits v_floor + v_cvt)
@@ -518,6 +524,27 @@ __device__ __forceinline__ float4 sweep_query(const LcpTask& K, const uint2* s_q
 // three 16-byte loads; group gi lives at float4 index (gi >> 1) * 8 + (gi & 1) * 3) -- empty if the entry is not valid or
 // its sub-cell cannot be reached.
 struct ExactEntry { float tx, ty, tz; uint32_t p, e; };
+// (exact_setup_q: the query point handed over by the caller; exact_setup: read from the float array by index)
+template <bool COUNT>
+__device__ __forceinline__ ExactEntry exact_setup_q(const LcpGrid& g, const LcpTask& K, const float* T, const bool valid, const float4 q, const uint32_t rank) {
+  ExactEntry E;
+  E.tx = E.ty = E.tz = 0.f; E.p = E.e = 0u;
+  if (valid) {
+    const uint4 hdr = g.list_hdr[2u * rank], cel = g.list_hdr[2u * rank + 1u];     // one 32-byte record: both halves arrive together
+    transform_point(T, q, E.tx, E.ty, E.tz);                    // exact (reference order, no fma)
+    const float rx = (E.tx - g.ox) * g.inv_h - __uint_as_float(cel.x), ry = (E.ty - g.oy) * g.inv_h - __uint_as_float(cel.y),
+                rz = (E.tz - g.oz) * g.inv_h - __uint_as_float(cel.z);
+    const uint32_t sx = uint32_t(min(max(int(rx * 4.f), 0), 3)), sy = uint32_t(min(max(int(ry * 4.f), 0), 3)),
+                   sz = uint32_t(min(max(int(rz * 4.f), 0), 3));
+    const uint32_t sb = sz * 16u + sy * 4u + sx;
+    const uint32_t mword = sb < 32u ? hdr.z : hdr.w;
+    if ((mword >> (sb & 31u)) & 1u) {
+      if (COUNT) { atomicAdd(K.point_tests + 3, 1ull); atomicAdd(K.point_tests, (unsigned long long)hdr.y); }   // l2_pass, listed points
+      E.p = 2u * hdr.x; E.e = E.p + (hdr.y + 3u) / 4u;
+    }
+  }
+  return E;
+}
 template <bool COUNT>
 __device__ __forceinline__ ExactEntry exact_setup(const LcpGrid& g, const LcpTask& K, const float* T, const bool valid, const uint32_t i, const uint32_t rank) {
   ExactEntry E;
@@ -793,6 +820,217 @@ __device__ __forceinline__ uint32_t wave_lcp_count_auto(const LcpGrid& g, const 
 #else
 #define S4P_WAVE_LCP_COUNT wave_lcp_count
 #endif
+
+// ---------------------------------------------------------------------------
+// The LEAN sweep: what k_verify runs when an early-exit bound is in force (LcpTask::prune > 0), i.e. inside the trial loops,
+// where all but one candidate in 10^4 are abandoned after a sweep that never needs more than "how many queries COULD still
+// be inliers".  Per 64 queries the fused sweep above issues ~50 vector instructions and the staged one ~37; this one ~16:
+//   * the sampled Q lives in LDS as three float arrays (no 16-bit unpack: 3 conversions per query gone);
+//   * the 3x4 locating transform runs on the MATRIX pipe: v_mfma_f32_4x4x1 with lane l <-> query l, A = one column of the
+//     transform (lane & 3 = row), accumulator seeded with the translation -- three MFMAs per 64 queries leave the position in
+//     COARSE units (2^cshift cells) in the lane's own registers, and the vector pipe never sees the nine multiply-adds;
+//   * only the coarse cube is located (floor, bounds, linear index, one LDS word, one bit): the fine cell and the rank among
+//     the reachable cells are needed only for queries whose candidate survives the sweep, so they are computed THERE;
+//   * a queue entry is the 16-bit query index alone.
+// Everything here only LOCATES: positions may be off by ~1e-5 cell (MFMA accumulation order vs the fma chain of grid_cell),
+// which the structure absorbs at every level independently (a coarse cube is marked if any of its cells is reachable, a cell
+// if a P point lies within delta + 0.01 h of its box: LcpGridHost::plan).  The inlier predicate itself is exact_setup /
+// group_hit, untouched: counts stay bit-exact.
+// Queue of one wave: kLeanQueue 16-bit entries: [0, nb) passed the reach test, [nb, nb + na) L0 survivors of the sweep.
+// Padding queries (index >= n_q) sit at 1e18: a rigid transform sends them outside the grid on at least one axis, so the
+// sweep needs no index test.
+// ---------------------------------------------------------------------------
+#ifndef S4P_LEAN_QUEUE
+#define S4P_LEAN_QUEUE 768
+#endif
+#ifndef S4P_LEAN_MFMA
+#define S4P_LEAN_MFMA 1
+#endif
+constexpr uint32_t kLeanQueue = S4P_LEAN_QUEUE;            // entries per wave (2 B each)
+static_assert(kLeanQueue >= 2u * kSweepStep + 128u && kLeanQueue % 64u == 0u, "lean queue: two sweep steps + one exact batch");
+constexpr float kLeanPad = 1.0e18f;                        // coordinates of the padding queries
+constexpr int kLeanMaxQueries = 2560;                      // sampled-Q points the float LDS copy takes (30 KB)
+typedef float f4_t __attribute__((ext_vector_type(4)));
+
+struct LeanLds { const uint32_t* coarse; const float* qx; const float* qy; const float* qz; uint16_t* queue; };
+
+// LDS word `index` of the array at byte address `base` (wave-uniform): one shift-add for the address (the compiler's own
+// form of base + 4 * (x >> 5) is shift, mask, add)
+__device__ __forceinline__ uint32_t lds_word(const uint32_t base, const uint32_t index) {
+  uint32_t addr;
+  asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(addr) : "v"(index), "s"(base));
+  return *(const __attribute__((address_space(3))) uint32_t*)(uintptr_t(addr));
+}
+__device__ __forceinline__ uint32_t bfe1(const uint32_t word, const uint32_t pos) {      // (word >> (pos & 31)) & 1: the hardware masks pos itself
+  uint32_t r;
+  asm("v_bfe_u32 %0, %1, %2, 1" : "=v"(r) : "v"(word), "v"(pos));
+  return r;
+}
+
+// exact stage for entries that carry only the query index: fine cell (same function, same inputs as the drain's reach test),
+// reach word -> rank, then exact_setup / the point walk as in exact_pair
+template <bool COUNT>
+__device__ __forceinline__ uint32_t exact_pair_lean(const LcpGrid& g, const LcpTask& K, const LeanLds& L, const float4* Tsrc,
+                                                    const bool validA, const uint32_t iA, const bool validB, const uint32_t iB) {
+  ExactEntry A, B;
+  { float T[12]; load_rows(Tsrc, T);
+    const GridXf X = make_grid_xf(g, T, 1.f);
+    auto one = [&](const bool valid, const uint32_t i) -> ExactEntry {
+      const float4 q = make_float4(L.qx[i], L.qy[i], L.qz[i], 0.f);
+      int ix, iy, iz;
+      grid_cell(X.u, q, ix, iy, iz);
+      const uint32_t c = mad24(mad24(uint32_t(iz), uint32_t(g.ny), uint32_t(iy)), uint32_t(g.nx), uint32_t(ix));
+      const uint2 w = g.reach[valid ? c >> 5 : 0u];                   // (valid entries passed the bounds + reach test with this very c)
+      const uint32_t rank = w.y + uint32_t(__popc(w.x & ((1u << (c & 31u)) - 1u)));
+      return exact_setup_q<COUNT>(g, K, T, valid, q, rank);
+    };
+    A = one(validA, iA);
+    B = one(validB, iB); }
+  uint32_t hits = 0;
+  while (A.p < A.e || B.p < B.e) {
+    const bool la = A.p < A.e, lb = B.p < B.e;
+    const uint32_t ia = la ? (A.p >> 1) * 8u + (A.p & 1u) * 3u : 0u, ib = lb ? (B.p >> 1) * 8u + (B.p & 1u) * 3u : 0u;
+    const float4 ax = g.nbr[ia], ay = g.nbr[ia + 1u], az = g.nbr[ia + 2u];
+    const float4 bx = g.nbr[ib], by = g.nbr[ib + 1u], bz = g.nbr[ib + 2u];
+    const bool ha = la && group_hit(ax, ay, az, A.tx, A.ty, A.tz, g.sq_eps);
+    const bool hb = lb && group_hit(bx, by, bz, B.tx, B.ty, B.tz, g.sq_eps);
+    if (ha) { hits |= 1u; A.p = A.e; } else if (la) A.p += 1u;
+    if (hb) { hits |= 2u; B.p = B.e; } else if (lb) B.p += 1u;
+  }
+  return hits;
+}
+
+template <bool COUNT, bool SKIP_FINE>
+__device__ __forceinline__ uint32_t wave_lcp_count_lean(const LcpGrid& g, const LcpTask& K, const LeanLds& L, const float4* Tsrc) {
+  const uint32_t lane = threadIdx.x & 63u;
+  uint16_t* q = L.queue;
+  uint32_t cnt = 0, nb = 0, na = 0;
+  // pitches of the coarse bitmap (g.cnx, g.cny) include one empty border cube per axis (LcpGridHost::plan); mx, my, mz = its index
+  const uint32_t ucx = uint32_t(g.cnx), ucy = uint32_t(g.cny);
+  const uint32_t mx = ucx - 1u, my = ucy - 1u, mz = uint32_t(((g.nz - 1) >> g.cshift) + 1);
+  // locating transform in coarse units (exact power-of-two scaling of the grid-unit transform)
+#if S4P_LEAN_MFMA
+  float a0, a1, a2; f4_t c0;
+  { float T[12]; load_rows(Tsrc, T);
+    const GridXf Xc = make_grid_xf(g, T, coarse_scale(g));
+    const uint32_t r = lane & 3u;                          // A operand: lane (block, r) holds row r of the column
+    a0 = r == 0u ? Xc.u[0] : (r == 1u ? Xc.u[4] : (r == 2u ? Xc.u[8] : 0.f));
+    a1 = r == 0u ? Xc.u[1] : (r == 1u ? Xc.u[5] : (r == 2u ? Xc.u[9] : 0.f));
+    a2 = r == 0u ? Xc.u[2] : (r == 1u ? Xc.u[6] : (r == 2u ? Xc.u[10] : 0.f));
+    c0 = f4_t{Xc.u[3], Xc.u[7], Xc.u[11], 0.f}; }
+#else
+  GridXf Xc;
+  { float T[12]; load_rows(Tsrc, T); Xc = make_grid_xf(g, T, coarse_scale(g)); }
+#endif
+  typedef const __attribute__((address_space(3))) uint32_t* lds_u32_ptr;
+  const uint32_t coarse_base = uint32_t(uintptr_t((lds_u32_ptr)L.coarse));      // byte address of the bitmap inside LDS (0 in k_verify)
+  auto lds_fence = [&]() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); };
+  // reach test of the L0 survivors [nb, nb + na), the survivors compacted in place onto [0, nb)
+  auto drain = [&]() {
+    lds_fence();
+    float T[12]; load_rows(Tsrc, T);
+    const GridXf X = make_grid_xf(g, T, 1.f);
+    uint32_t rd = nb;
+    const uint32_t end = nb + na;
+    while (rd < end) {                                     // wave-uniform
+      const uint32_t n = min(end - rd, 64u);
+      const uint32_t i = uint32_t(q[rd + min(lane, n - 1u)]);
+      lds_fence();                                         // every lane holds its entry before any slot of this batch is rewritten
+      int ix, iy, iz;
+      grid_cell(X.u, make_float4(L.qx[i], L.qy[i], L.qz[i], 0.f), ix, iy, iz);
+      const bool inb = (lane < n) & (uint32_t(ix) < uint32_t(g.nx)) & (uint32_t(iy) < uint32_t(g.ny)) & (uint32_t(iz) < uint32_t(g.nz));
+      const uint32_t c = mad24(mad24(uint32_t(iz), uint32_t(g.ny), uint32_t(iy)), uint32_t(g.nx), uint32_t(ix));
+      const uint2 w = g.reach[inb ? c >> 5 : 0u];
+      const bool reach = inb & (((w.x >> (c & 31u)) & 1u) != 0u);
+      const unsigned long long m = __builtin_amdgcn_ballot_w64(reach);
+      if (reach) q[__builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), nb))] = uint16_t(i);   // nb <= rd: stays below rd + n
+      nb += uint32_t(__popcll(m));
+      rd += n;
+      lds_fence();
+    }
+    if (COUNT) { if (lane == 0) atomicAdd(K.point_tests + 1, (unsigned long long)na); }      // reach words gathered (l0_pass)
+    na = 0u;
+  };
+  const uint32_t n_pad = (K.n_q + kSweepStep - 1u) & ~(kSweepStep - 1u);
+  bool abandoned = false;
+  for (uint32_t base = 0;; base += kSweepStep) {
+    const bool more = base < n_pad;                        // wave-uniform
+    const uint32_t unswept = K.n_q - min(base + kSweepStep, K.n_q);
+    if (more) {
+      // one step = kSweepChunks chunks in four phases, so that the LDS reads of all chunks are in flight together and
+      // dependent MFMAs of one chunk are separated by the other chunks'
+      uint32_t ii[kSweepChunks], cc[kSweepChunks], ww[kSweepChunks];
+      float x[kSweepChunks], y[kSweepChunks], z[kSweepChunks];
+#pragma unroll
+      for (uint32_t k = 0; k < kSweepChunks; ++k) { ii[k] = base + 64u * k + lane; x[k] = L.qx[ii[k]]; y[k] = L.qy[ii[k]]; z[k] = L.qz[ii[k]]; }
+      int cx[kSweepChunks], cy[kSweepChunks], cz[kSweepChunks];
+#if S4P_LEAN_MFMA
+      f4_t d[kSweepChunks];
+#pragma unroll
+      for (uint32_t k = 0; k < kSweepChunks; ++k) d[k] = __builtin_amdgcn_mfma_f32_4x4x1f32(a0, x[k], c0, 0, 0, 0);
+#pragma unroll
+      for (uint32_t k = 0; k < kSweepChunks; ++k) d[k] = __builtin_amdgcn_mfma_f32_4x4x1f32(a1, y[k], d[k], 0, 0, 0);
+#pragma unroll
+      for (uint32_t k = 0; k < kSweepChunks; ++k) d[k] = __builtin_amdgcn_mfma_f32_4x4x1f32(a2, z[k], d[k], 0, 0, 0);
+#pragma unroll
+      for (uint32_t k = 0; k < kSweepChunks; ++k) { cx[k] = floor_to_int(d[k][0]); cy[k] = floor_to_int(d[k][1]); cz[k] = floor_to_int(d[k][2]); }
+#else
+#pragma unroll
+      for (uint32_t k = 0; k < kSweepChunks; k += 2u)
+        grid_cell2(Xc.u, make_float4(x[k], y[k], z[k], 0.f), make_float4(x[k + 1u], y[k + 1u], z[k + 1u], 0.f), cx[k], cy[k], cz[k], cx[k + 1u], cy[k + 1u], cz[k + 1u]);
+#endif
+#pragma unroll
+      for (uint32_t k = 0; k < kSweepChunks; ++k) {
+        // the bitmap has one more (empty) cube per axis: a coordinate outside the grid on either side clamps onto it
+        cc[k] = mad24_s(mad24_s(min(uint32_t(cz[k]), mz), ucy, min(uint32_t(cy[k]), my)), ucx, min(uint32_t(cx[k]), mx));
+        ww[k] = lds_word(coarse_base, cc[k] >> 5);
+      }
+#pragma unroll
+      for (uint32_t k = 0; k < kSweepChunks; ++k) {
+        const uint32_t t = bfe1(ww[k], cc[k]);
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(t != 0u);
+        if (m != 0ull) {
+          uint16_t* qw = q + (nb + na);                       // (uniform: the lane's slot is one shift-add from its mbcnt)
+          if (t != 0u) qw[__builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u))] = uint16_t(ii[k]);
+          na += uint32_t(__popcll(m));
+        }
+      }
+      // (instrumentation counts what is FETCHED: L0 survivors when their reach word is gathered -- drain --, reach survivors
+      // when their list header is read -- exact batch; an abandoned candidate has touched neither)
+      // upper bound of what this candidate can still reach: confirmed + waiting (either kind) + not swept yet
+      if (cnt + nb + na + unswept <= K.prune) { abandoned = true; break; }
+    }
+    if (!more || nb + na + kSweepStep > kLeanQueue) {
+      drain();
+      const uint32_t rest = more ? unswept : 0u;
+      if (cnt + nb + rest <= K.prune) { abandoned = true; break; }
+      while ((more && nb + 2u * kSweepStep > kLeanQueue) || (!more && nb != 0u)) {
+        if (cnt + nb + rest <= K.prune) { abandoned = true; break; }
+        const uint32_t n = min(nb, 128u);
+        const bool va = lane < n, vb = lane + 64u < n;
+        const uint32_t ia = uint32_t(q[nb - n + min(lane, n - 1u)]), ib = uint32_t(q[nb - n + min(lane + 64u, n - 1u)]);
+        if (COUNT) { if (lane == 0) atomicAdd(K.point_tests + 2, (unsigned long long)n); }      // list headers read (l1_pass)
+        if (!SKIP_FINE) {
+          const uint32_t h = exact_pair_lean<COUNT>(g, K, L, Tsrc, va, ia, vb, ib);
+          cnt += uint32_t(__popcll(__builtin_amdgcn_ballot_w64((h & 1u) != 0u))) + uint32_t(__popcll(__builtin_amdgcn_ballot_w64((h & 2u) != 0u)));
+        }
+        nb -= n;
+        lds_fence();
+      }
+    }
+    if (!more || abandoned) break;
+  }
+  if (abandoned && K.pruned != nullptr && lane == 0) atomicAdd(K.pruned, 1u);
+  __builtin_amdgcn_wave_barrier();
+  return cnt;
+}
+
+// Global -> LDS copy of the float queries (SoA, padded on the device side to a multiple of a sweep step with kLeanPad)
+__device__ __forceinline__ void stage_queries_f(const float* src, float* dst, const uint32_t n_words) {
+  const float4* s4 = reinterpret_cast<const float4*>(src);
+  float4* d4 = reinterpret_cast<float4*>(dst);
+  for (uint32_t w = threadIdx.x; w < (n_words >> 2); w += blockDim.x) d4[w] = s4[w];      // n_words = 3 * n_pad, a multiple of 4
+}
 
 // Global -> LDS copy of the quantised queries (8 B each), padded to a multiple of a sweep step with the last entry
 __device__ __forceinline__ void stage_queries(const LcpTask& K, uint2* s_q) {
@@ -1576,6 +1814,7 @@ struct VerifyParams {
   const float4* q4;                                     // sampled Q (centred), packed (x,y,z,0), original order (quad indices)
   const float4* q4v;                                    // the same points in Morton order, for the LCP sweep
   QuantQ qq;                                            // ... and their 16-bit quantisation (QLDS kernels)
+  const float* qsoa;                                    // ... and as x[n_pad] | y[n_pad] | z[n_pad], padded with kLeanPad (LEAN kernels)
   uint32_t n_q;
   BaseFrame base;
   const int4* quads; const unsigned long long* tags; uint32_t* counts;
@@ -1589,20 +1828,38 @@ struct VerifyParams {
   int ablate;                                           // S4P_ABLATE debugging only (0 = full kernel)
 };
 
+struct VerifyShared {                                   // k_verify's workgroup scalars, at the end of its dynamic LDS
+  unsigned long long wtag[kVerifyMaxThreads / 64];
+  uint32_t wcnt[kVerifyMaxThreads / 64], wcand[kVerifyMaxThreads / 64];
+  uint32_t next, last, pruned, pad;
+};
+
 // better(a, b): a wins over b if its count is greater, or equal with a smaller tag (= earlier in reference order)
 __device__ __forceinline__ bool slot_better(const uint32_t ca, const unsigned long long ta, const uint32_t cb, const unsigned long long tb, const bool b_valid) {
   return !b_valid || ca > cb || (ca == cb && ta < tb);
 }
 
-template <bool COUNT, bool QLDS>
+// LEAN (launched when an early-exit bound is in force and the float copy of the sampled Q fits LDS): wave_lcp_count_lean,
+// LDS = coarse bitmap | float queries x, y, z | one 16-bit queue per wave; QLDS is then meaningless (false).
+template <bool COUNT, bool QLDS, bool LEAN>
 __global__ __launch_bounds__(kVerifyMaxThreads, 6) void k_verify(VerifyParams P) {   // <= 80 VGPRs: six waves per SIMD (two 768-thread workgroups per CU)
   extern __shared__ uint32_t s_mem[];
   uint32_t* s_coarse = s_mem;                              // LDS: coarse bitmap | quantised queries (QLDS) | 16 survivor queues
   uint2* s_q = reinterpret_cast<uint2*>(s_mem + P.grid.coarse_words);
   uint32_t* s_queue = reinterpret_cast<uint32_t*>(s_q + (QLDS ? ((P.n_q + kSweepStep - 1u) & ~(kSweepStep - 1u)) : 0u)) + (threadIdx.x >> 6) * kQueueWordsPerWave;
-  __shared__ uint32_t s_next, s_last, s_pruned;
-  __shared__ uint32_t s_wcnt[kVerifyMaxThreads / 64], s_wcand[kVerifyMaxThreads / 64];
-  __shared__ unsigned long long s_wtag[kVerifyMaxThreads / 64];
+  const uint32_t n_pad = (P.n_q + kSweepStep - 1u) & ~(kSweepStep - 1u);
+  LeanLds LL;
+  LL.coarse = s_coarse;
+  { float* f = reinterpret_cast<float*>(s_mem + P.grid.coarse_words);
+    LL.qx = f; LL.qy = f + n_pad; LL.qz = f + 2u * n_pad;
+    LL.queue = reinterpret_cast<uint16_t*>(f + 3u * n_pad) + uint32_t(__builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6))) * kLeanQueue; }   // (uniform: scalar register)
+  // The workgroup's few scalars live at the END of the dynamic segment (VerifyShared), not in static __shared__: the coarse
+  // bitmap then starts at LDS address 0 and the sweep's word address needs no base added (one vector instruction per chunk).
+  VerifyShared& S = *reinterpret_cast<VerifyShared*>(LEAN
+      ? reinterpret_cast<uint32_t*>(reinterpret_cast<uint16_t*>(s_mem + P.grid.coarse_words + 3u * n_pad) + (blockDim.x >> 6) * kLeanQueue)
+      : reinterpret_cast<uint32_t*>(s_q + (QLDS ? n_pad : 0u)) + (blockDim.x >> 6) * kQueueWordsPerWave);
+  uint32_t& s_next = S.next; uint32_t& s_last = S.last; uint32_t& s_pruned = S.pruned;
+  uint32_t* s_wcnt = S.wcnt; uint32_t* s_wcand = S.wcand; unsigned long long* s_wtag = S.wtag;
   const uint32_t C = P.ctr->C;
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   // Work split: every workgroup owns a fixed share of the gated candidate list (static: a single-address global cursor
@@ -1620,7 +1877,8 @@ __global__ __launch_bounds__(kVerifyMaxThreads, 6) void k_verify(VerifyParams P)
     LcpTask K;
     K.q4 = P.q4v; K.n_q = P.n_q; K.qq = P.qq; K.T = P.cand_T; K.t_stride = 3u; K.point_tests = &P.ctr->point_tests;
     K.prune = P.prune; K.pruned = &s_pruned;
-    if (QLDS) stage_queries(K, s_q);
+    if (LEAN) stage_queries_f(P.qsoa, const_cast<float*>(LL.qx), 3u * n_pad);
+    else if (QLDS) stage_queries(K, s_q);
     stage_coarse(P.grid, s_coarse);                        // ends with a workgroup barrier
     while (true) {
       uint32_t i = 0;
@@ -1629,8 +1887,10 @@ __global__ __launch_bounds__(kVerifyMaxThreads, 6) void k_verify(VerifyParams P)
       if (i >= hi) break;
       i = blockIdx.x + i * gridDim.x;
       const float4* src = P.cand_T + 3 * size_t(i);         // one candidate per wave
-      const uint32_t cnt = P.ablate == 1 ? S4P_WAVE_LCP_COUNT<COUNT, true, QLDS>(P.grid, K, s_coarse, s_q, s_queue, src)
-                                         : S4P_WAVE_LCP_COUNT<COUNT, false, QLDS>(P.grid, K, s_coarse, s_q, s_queue, src);
+      uint32_t cnt;
+      if (LEAN) cnt = P.ablate == 1 ? wave_lcp_count_lean<COUNT, true>(P.grid, K, LL, src) : wave_lcp_count_lean<COUNT, false>(P.grid, K, LL, src);
+      else cnt = P.ablate == 1 ? S4P_WAVE_LCP_COUNT<COUNT, true, QLDS>(P.grid, K, s_coarse, s_q, s_queue, src)
+                               : S4P_WAVE_LCP_COUNT<COUNT, false, QLDS>(P.grid, K, s_coarse, s_q, s_queue, src);
       const uint32_t kraw = uint32_t(__builtin_amdgcn_readfirstlane(int(P.cand_idx[i])));
       const uint32_t k = kraw & ~kBorderFlag;
       const unsigned long long tag = P.tags[k];
