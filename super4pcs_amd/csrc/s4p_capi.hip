@@ -371,7 +371,7 @@ int32_t quad_params(s4p_ctx* c, float inv1, float inv2, float thr2, PrepParams& 
   Q.m2_dev = &L.ctr.p->m2; Q.cap2 = uint32_t(L.cap_pairs); Q.ht = ht; Q.thr = thr2;
   Q.quads = L.quads.p; Q.tags = L.tags.p; Q.K_dev = &L.ctr.p->K; Q.K_cap = uint32_t(L.cap_quads); Q.overflow = &L.ctr.p->overflow;
   Q.r0 = 0u; Q.r1 = 0xFFFFFFFFu; Q.qsum_dev = &L.ctr.p->quad_sum; Q.csum_dev = &L.ctr.p->cand_sum;
-  Q.slice_num = c->slice_num; Q.slice_den = c->slice_den;
+  Q.slice_num = 0u; Q.slice_den = 0u;                       // (a share of the set, s4p_set_quad_slice, applies to the fused passes only: launch_base)
   Q.do_gate = 0;
   return S4P_OK;
 }
@@ -706,6 +706,7 @@ int32_t launch_base(s4p_ctx* c, int32_t slot, const int32_t* base_ids, float inv
   if (c->prof_stages) HIPCHK(c, hipEventRecord(c->ev[c->cur][3], L.stream));
   launch_prep_kernel(c, P1);
   if (c->fuse_gate) { Q.do_gate = 1; Q.gate = gate_params(c, bf); }
+  Q.slice_num = c->slice_num; Q.slice_den = c->slice_den;
   c->slot_q[c->cur] = Q;                                  // (the chunk loop relaunches it range by range if the quads do not fit)
   launch_quads_kernel(c, Q);
   if (!c->fuse_gate) launch_gate_kernel(c, gate_params(c, bf));

@@ -171,7 +171,11 @@ struct s4p_matcher {
     struct Attempt { uint32_t idx[2001]; std::mt19937 rng_before; int status = -1; int ids[4] = {0, 0, 0, 0}; float inv1 = 0, inv2 = 0; };
     static constexpr uint32_t kRing = 64;
     std::unique_ptr<Attempt[]> ring;
-    std::atomic<uint32_t> ring_state[kRing];     // 0 free, 1 drawn, 2 evaluated
+    // state of a slot = 3 * lap + phase (lap = seq / kRing; phase 0 free, 1 drawn, 2 evaluated): every stage waits for the
+    // exact (lap, phase) of ITS attempt.  With the bare phase an evaluator descheduled on attempt 5 for ~1 ms let the other one
+    // work through 6..68 and claim 69, find slot 5 still "drawn" and evaluate attempt 5's draws as attempt 69.
+    std::atomic<uint64_t> ring_state[kRing];
+    static uint64_t tag(uint64_t seq, uint32_t phase) { return 3ull * (seq / kRing) + phase; }
     std::atomic<uint64_t> drawn{0}, claimed{0}, taken{0};
     std::thread drawer, evals[2], assembler;
     int n_eval = 2;
@@ -425,7 +429,7 @@ inline void spin_until_ready(const std::atomic<size_t>& ready, const std::atomic
 
 // waits until `st` holds `want`; false if the producer is stopping.  Spins first (a streaming stage never sleeps), then
 // naps: when the GPU is the bottleneck the queues are full and the helpers idle cheaply.
-inline bool wait_state(const std::atomic<uint32_t>& st, uint32_t want, const std::atomic<bool>& stop) {
+inline bool wait_state(const std::atomic<uint64_t>& st, uint64_t want, const std::atomic<bool>& stop) {
   for (int spin = 0;; ++spin) {
     if (st.load(std::memory_order_acquire) == want) return true;
     if (stop.load(std::memory_order_relaxed)) return false;
@@ -439,12 +443,12 @@ void drawer_main(s4p_matcher* m) {
   const uint32_t n = uint32_t(m->Ps.size());
   for (uint64_t seq = P.drawn.load();; ++seq) {
     const uint32_t slot = uint32_t(seq % s4p_matcher::Producer::kRing);
-    if (!wait_state(P.ring_state[slot], 0u, P.stop_flag)) return;
+    if (!wait_state(P.ring_state[slot], s4p_matcher::Producer::tag(seq, 0u), P.stop_flag)) return;
     s4p_matcher::Producer::Attempt& a = P.ring[slot];
     a.rng_before = m->rng;
     a.status = -1;
     if (n) draw_attempt(m->rng, n, a.idx);
-    P.ring_state[slot].store(1u, std::memory_order_release);
+    P.ring_state[slot].store(s4p_matcher::Producer::tag(seq, 1u), std::memory_order_release);
     P.drawn.store(seq + 1, std::memory_order_release);
   }
 }
@@ -457,12 +461,12 @@ void evaluator_main(s4p_matcher* m) {
     while (true) {
       const uint64_t seq = P.claimed.fetch_add(1);
       const uint32_t slot = uint32_t(seq % s4p_matcher::Producer::kRing);
-      if (!wait_state(P.ring_state[slot], 1u, P.stop_flag)) return;
+      if (!wait_state(P.ring_state[slot], s4p_matcher::Producer::tag(seq, 1u), P.stop_flag)) return;
       s4p_matcher::Producer::Attempt& a = P.ring[slot];
       const auto t0 = clk::now();
       a.status = m->Ps.size() ? eval_attempt_host(m, a.idx, a.ids, a.inv1, a.inv2) : kAttemptNoTriangle;
       P.select_ns.fetch_add(uint64_t(std::chrono::duration_cast<std::chrono::nanoseconds>(clk::now() - t0).count()));
-      P.ring_state[slot].store(2u, std::memory_order_release);
+      P.ring_state[slot].store(s4p_matcher::Producer::tag(seq, 2u), std::memory_order_release);
     }
   }
   // searches on the device: every attempt that has been drawn so far (up to the batch size) goes into ONE set of launches
@@ -474,9 +478,9 @@ void evaluator_main(s4p_matcher* m) {
   const float too_small = float(std::pow(double(m->max_base_diameter * kBaseTooSmall), 2));
   while (true) {
     const uint64_t seq0 = P.claimed.load();
-    if (!wait_state(P.ring_state[seq0 % s4p_matcher::Producer::kRing], 1u, P.stop_flag)) return;
+    if (!wait_state(P.ring_state[seq0 % s4p_matcher::Producer::kRing], s4p_matcher::Producer::tag(seq0, 1u), P.stop_flag)) return;
     int nb = 1;
-    while (nb < bmax && P.ring_state[(seq0 + uint64_t(nb)) % s4p_matcher::Producer::kRing].load(std::memory_order_acquire) == 1u) ++nb;
+    while (nb < bmax && P.ring_state[(seq0 + uint64_t(nb)) % s4p_matcher::Producer::kRing].load(std::memory_order_acquire) == s4p_matcher::Producer::tag(seq0 + uint64_t(nb), 1u)) ++nb;
     for (int k = 0; k < nb; ++k) std::memcpy(draws.data() + size_t(k) * 2001, P.ring[(seq0 + uint64_t(k)) % s4p_matcher::Producer::kRing].idx, 2001 * sizeof(uint32_t));
     const auto t0 = clk::now();
     const int32_t rc = m->Ps.size() ? s4p_select_base_points_batch(m->ctx, draws.data(), nb, limit, too_small, got.data(), xyz.data(), st.data()) : S4P_OK;
@@ -494,7 +498,7 @@ void evaluator_main(s4p_matcher* m) {
       }
     }
     P.select_ns.fetch_add(uint64_t(std::chrono::duration_cast<std::chrono::nanoseconds>(clk::now() - t0).count()));
-    for (int k = 0; k < nb; ++k) P.ring_state[(seq0 + uint64_t(k)) % s4p_matcher::Producer::kRing].store(2u, std::memory_order_release);
+    for (int k = 0; k < nb; ++k) P.ring_state[(seq0 + uint64_t(k)) % s4p_matcher::Producer::kRing].store(s4p_matcher::Producer::tag(seq0 + uint64_t(k), 2u), std::memory_order_release);
     P.claimed.store(seq0 + uint64_t(nb));
   }
 }
@@ -512,12 +516,12 @@ void assembler_main(s4p_matcher* m) {
     for (int attempt = 0; attempt < 1000; ++attempt) {
       const uint64_t seq = P.taken.load();
       const uint32_t slot = uint32_t(seq % s4p_matcher::Producer::kRing);
-      if (!wait_state(P.ring_state[slot], 2u, P.stop_flag)) return;      // (P.partial tells producer_stop where this trial's draws began)
+      if (!wait_state(P.ring_state[slot], s4p_matcher::Producer::tag(seq, 2u), P.stop_flag)) return;      // (P.partial tells producer_stop where this trial's draws began)
       s4p_matcher::Producer::Attempt& a = P.ring[slot];
       if (first) { t.rng_before = a.rng_before; P.partial_rng = a.rng_before; P.partial = true; first = false; }
       const int status = a.status;
       if (status == kAttemptFound) { t.found = true; t.inv1 = a.inv1; t.inv2 = a.inv2; for (int k = 0; k < 4; ++k) t.ids[k] = a.ids[k]; }
-      P.ring_state[slot].store(0u, std::memory_order_release);
+      P.ring_state[slot].store(s4p_matcher::Producer::tag(seq + s4p_matcher::Producer::kRing, 0u), std::memory_order_release);      // free for the next lap
       P.taken.store(seq + 1, std::memory_order_release);
       if (status != kAttemptRetry) break;                    // found, or SelectRandomTriangle failed: the reference gives up (:285-287)
     }
@@ -587,7 +591,7 @@ void producer_start(s4p_matcher* m) {
   for (int sl = nslots / 2; sl < nslots; ++sl) P.free_slots.push_back(sl);      // the lower half belongs to s4p_try_base_async
   P.next_index = P.consumed;
   if (!P.ring) P.ring.reset(new s4p_matcher::Producer::Attempt[s4p_matcher::Producer::kRing]);
-  for (auto& st : P.ring_state) st.store(0u);
+  for (auto& st : P.ring_state) st.store(0ull);
   P.drawn.store(0); P.claimed.store(0); P.taken.store(0); P.partial = false;
   P.n_eval = m->device_select ? 1 : 2;
   P.drawer = std::thread(drawer_main, m);

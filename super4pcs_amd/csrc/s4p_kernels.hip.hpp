@@ -844,7 +844,7 @@ __device__ __forceinline__ uint32_t wave_lcp_count_auto(const LcpGrid& g, const 
 #define S4P_LEAN_QUEUE 768
 #endif
 #ifndef S4P_LEAN_MFMA
-#define S4P_LEAN_MFMA 1
+#define S4P_LEAN_MFMA 0
 #endif
 constexpr uint32_t kLeanQueue = S4P_LEAN_QUEUE;            // entries per wave (2 B each)
 static_assert(kLeanQueue >= 2u * kSweepStep + 128u && kLeanQueue % 64u == 0u, "lean queue: two sweep steps + one exact batch");

@@ -214,7 +214,7 @@ struct TrialOps {                                            // what the loop ne
   int depth = 2;
 };
 
-struct BaseId { bool found = false; int32_t ids[4] = {0, 0, 0, 0}; };
+struct BaseId { bool found = false; int32_t ids[4] = {0, 0, 0, 0}; int32_t failed_rc = 0; };      // failed_rc: (split loop) this rank could not even enqueue the trial
 struct Window { std::vector<BaseId> bases; bool mine_found = false; s4p_base_result r{}; uint64_t verified = 0; int slot = -1; };
 
 struct Loop {
@@ -294,15 +294,24 @@ struct Loop {
       have_posted = true;
       return S4P_OK;
     };
-    // A LOCAL failure: the other ranks post one window ahead of the one they complete, so they are (or will be) inside the
-    // all-reduce of the next window this rank has not posted, and of the one after it: post the error key for both.
+    // A LOCAL failure while window W (= posted_n) was being prepared or waited for.  The healthy ranks go on with
+    //   reduce(W), complete(W-1) [result, and a BROADCAST of its winner if it improved the best], reduce(W+1), complete(W): error
+    // so this rank owes them exactly that sequence: the error key as its reduction of W, the completion of the window it has
+    // already posted (the broadcast is a collective too: leaving it out pairs the others' broadcast with this rank's next
+    // all-reduce -- ADVICE r03), then the error key once more for W+1.  If W-1 turns out to have crossed the terminate
+    // threshold nobody posts W+1; the others still read the error out of W's reduction.
     auto leave = [&](int32_t rc) -> int32_t {
       if (rc == S4P_OK || remote_error || terminated || !coll) return rc;
       const std::string keep = err;
       for (int k = 0; k < 2 && posted_n < n; ++k, ++posted_n) {
         const int slot = slot_rr; slot_rr ^= 1;
         uint64_t dummy = 0;
-        if (coll->post(slot, kErrorKey) != S4P_OK || coll->result(slot, &dummy) != S4P_OK) break;
+        if (coll->post(slot, kErrorKey) != S4P_OK) break;
+        if (k == 0 && have_posted) {
+          have_posted = false;
+          if (complete_window(posted) != S4P_OK) { (void)coll->result(slot, &dummy); break; }      // (another rank failed too, or the collective did)
+        }
+        if (coll->result(slot, &dummy) != S4P_OK || terminated) break;
       }
       err = keep;
       return rc;
@@ -341,6 +350,8 @@ struct SplitLoop {
   uint32_t best_count = 0;
   bool terminated = false;
   uint64_t trials_done = 0, local_candidates = 0;
+  int32_t local_fail = 0;                 // a local failure the other ranks have not been told about yet (a failed commit): the next reduction carries the error key
+  bool commit_failed = false;
   std::string err;
   int32_t fail(int32_t rc, const std::string& m) { err = m; return rc; }
 
@@ -349,6 +360,7 @@ struct SplitLoop {
     const uint32_t thi = uint32_t(r.best_rank >> 32), tlo = uint32_t(r.best_rank);
     uint64_t a = usable ? ((uint64_t(r.best_count) + 1ull) << 32) | uint64_t(0xFFFFFFFFu - thi) : 0ull, ga = 0;
     if (b.found && !usable && r.n_pairs1 == ~0ull) a = kErrorKey;             // (a rank whose pass failed: see run())
+    if (local_fail) a = kErrorKey;
     if (int32_t rc = coll->post(0, a)) return fail(rc, coll->err);
     if (int32_t rc = coll->result(0, &ga)) return fail(rc, coll->err);
     if (ga == kErrorKey) return fail(S4P_ERR_STATE, "a rank of the sharded job failed on this base (see that rank's error)");
@@ -365,20 +377,23 @@ struct SplitLoop {
       if (int32_t rc = coll->broadcast(&wr, sizeof wr, root)) return fail(rc, coll->err);
       wr.n_quads = std::max<uint64_t>(wr.n_quads, 1);                          // (some share had quads: TryOneBase went on to TryCongruentSet)
       bool ok = false;
-      if (int32_t rc = ops.commit(b.ids, &wr, &ok)) return rc;
+      if (int32_t rc = ops.commit(b.ids, &wr, &ok)) { commit_failed = true; return rc; }
       best_count = wr.best_count;
       terminated = terminated || ok;
     }
     return S4P_OK;
   }
-  // n trials, `depth` of them in flight on the device; the reduction of trial t runs while t+1 .. t+depth-1 compute
+  // n trials, `depth` of them in flight on the device; the reduction of trial t runs while t+1 .. t+depth-1 compute.
+  // Every local failure -- a trial that cannot be enqueued (HIP error, device selection error: NOT symmetric over the ranks),
+  // a pass that fails, a commit that fails -- reaches the other ranks as the error key in the reduction they are waiting in
+  // (ADVICE r03), and no device pass is left un-waited when the loop is left.
   int32_t run(int n) {
     std::deque<BaseId> inflight;
     auto drain_one = [&]() -> int32_t {
       BaseId b = inflight.front(); inflight.pop_front();
       s4p_base_result r; std::memset(&r, 0, sizeof r);
-      int32_t rc = S4P_OK;
-      if (b.found) rc = ops.wait_own(&r);
+      int32_t rc = b.failed_rc;
+      if (rc == S4P_OK && b.found) rc = ops.wait_own(&r);
       if (rc != S4P_OK) { std::memset(&r, 0, sizeof r); r.n_pairs1 = ~0ull; b.found = true; }     // tell the others, then leave
       local_candidates += rc == S4P_OK ? r.n_verified : 0;
       ++trials_done;
@@ -388,13 +403,29 @@ struct SplitLoop {
       if (rc != S4P_OK) { err = keep; return rc; }
       return rc2;
     };
+    // leaving with an error: the shares still in flight are waited for (their results are dropped); after a failed commit
+    // the next reduction of this call, if there is one, carries the error key
+    auto leave = [&](int32_t rc) -> int32_t {
+      const std::string keep = err;
+      if (commit_failed && !inflight.empty() && !terminated) { local_fail = rc; (void)drain_one(); }
+      while (!inflight.empty()) {
+        const BaseId b = inflight.front(); inflight.pop_front();
+        s4p_base_result r;
+        if (b.failed_rc == S4P_OK && b.found) (void)ops.wait_own(&r);
+      }
+      local_fail = 0; commit_failed = false;
+      err = keep;
+      return rc;
+    };
     for (int t = 0; t < n && !terminated; ++t) {
       BaseId b;
-      if (int32_t rc = ops.prepare(&b.found, b.ids)) return rc;               // (a failed prepare is symmetric: every rank selects the same base)
+      const int32_t prc = ops.prepare(&b.found, b.ids);
+      if (prc != S4P_OK) { b.found = true; b.failed_rc = prc; }
       inflight.push_back(b);
-      if (int(inflight.size()) >= ops.depth) if (int32_t rc = drain_one()) return rc;
+      if (prc != S4P_OK) break;                              // the earlier trials are reduced in order, then this one posts the error key
+      if (int(inflight.size()) >= ops.depth) if (int32_t rc = drain_one()) return leave(rc);
     }
-    while (!inflight.empty()) if (int32_t rc = drain_one()) return rc;
+    while (!inflight.empty()) if (int32_t rc = drain_one()) return leave(rc);
     return S4P_OK;
   }
 };
@@ -404,6 +435,7 @@ struct SplitLoop {
 struct s4p_shard {
   s4p_matcher* m = nullptr;
   int mode = 0;                        // 0: trials sharded by base (window loop), 1: every base split over all ranks
+  int producer_threads = 2;            // the helper-thread policy given to s4p_shard_create (0 never, 1 always, 2 where they pay): set_mode keeps it
   SplitLoop split;
   int64_t init_generation = -1;        // the matcher initialisation the loop state belongs to
   Loop loop;
@@ -429,6 +461,7 @@ int32_t s4p_shard_create(s4p_matcher* m, int32_t rank, int32_t world, int32_t pr
   if (int32_t rc = s4p_matcher_set_sharding(m, rank, world, producer_threads)) return rc;
   s4p_shard* s = new s4p_shard();
   s->m = m;
+  s->producer_threads = producer_threads;
   s->loop.rank = rank; s->loop.world = world;
   *out = s;
   return S4P_OK;
@@ -465,7 +498,7 @@ int32_t s4p_shard_set_mode(s4p_shard* s, int32_t mode) {
   if (!s || (mode != 0 && mode != 1)) return S4P_ERR_BAD_ARG;
   s4p_matcher* m = s->m;
   // split mode: this rank runs EVERY trial (it owns them all as far as base selection and staging go) on its share of the quads
-  if (int32_t rc = s4p_matcher_set_sharding(m, mode ? 0 : s->loop.rank, mode ? 1 : s->loop.world, 1)) return rc;
+  if (int32_t rc = s4p_matcher_set_sharding(m, mode ? 0 : s->loop.rank, mode ? 1 : s->loop.world, s->producer_threads)) return rc;
   if (int32_t rc = s4p_set_quad_slice(s4p_matcher_ctx(m), mode ? uint32_t(s->loop.rank) : 0u, mode ? uint32_t(s->loop.world) : 0u)) return rc;
   s->mode = mode;
   return S4P_OK;

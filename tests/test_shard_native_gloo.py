@@ -132,6 +132,28 @@ def test_a_failing_rank_takes_every_rank_out_of_the_loop(world, fail_rank, fail_
         assert code == (-5 if rank == fail_rank else -7)        # the failing rank keeps its own error; the others: S4P_ERR_STATE
 
 
+@pytest.mark.parametrize("world,depth,fail_offset", [(2, 1, 1), (2, 3, 1), (4, 2, 1), (4, 3, 1), (2, 2, 2)])
+def test_a_rank_failing_right_after_an_improving_window(world, depth, fail_offset, s4p_lib_built):
+    """The failing rank has already posted the window before the one it fails in; if that window improved the best LCP the
+    healthy ranks BROADCAST its winner between their next two all-reduces.  The failing rank has to take part in that
+    broadcast on its way out (it used to answer it with an all-reduce, i.e. a hang or garbage)."""
+    n_windows, seed = 12, 1
+    table = outcome_table(seed, n_windows * world)
+    improving = sorted({t // world for t, _ in sequential_commits(table, 3, N_Q)})
+    w = next(x for x in improving if 0 < x + fail_offset < n_windows - 1)
+    owner = next(t for t, _ in sequential_commits(table, 3, N_Q) if t // world == w) % world
+    fail_rank = (owner + 1) % world                                   # not the broadcast root
+    res = _run(world, seed, n_windows, N_Q, depth, fail_at=(fail_rank, w + fail_offset))
+    assert len(res) == world
+    for rank, tag, code, _ in res:
+        assert tag == "error"
+        assert code == (-5 if rank == fail_rank else -7)
+    # ... and once with the failing rank BEING the root of that broadcast
+    res = _run(world, seed, n_windows, N_Q, depth, fail_at=(owner, w + fail_offset))
+    for rank, tag, code, _ in res:
+        assert tag == "error" and code == (-5 if rank == owner else -7)
+
+
 # ---- SURVEY 8e level 2: every base split over all ranks (SplitLoop in s4p_shard.cpp) -------------------------------------
 def split_table(seed, n_trials, world):
     """Per trial: found (same on every rank: all ranks select the same base) and, per rank, its share's (usable, count, tag)."""
