@@ -180,6 +180,7 @@ struct s4p_ctx {
   // A/B aid: S4P_FUSE_GATE=0 runs the rigid transform + rms gate as a k_gate launch instead of
   // inside k_quads' flush (measured slower)
   bool fuse_gate = true;
+  bool pairs_v2 = true;              // S4P_PAIRS_V2=0: the round-3 k_pairs (one wave per primitive) instead of the transposed k_pairs2 (A/B aid)
   int cu_split = 0;                  // S4P_CU_SPLIT (0 = off): one CU in n for the small kernels, the rest for k_verify
   double host_octree_s = 0, host_wait_s = 0;
   double set_clouds_s[4] = {0, 0, 0, 0};      // last s4p_set_clouds: host copies + unit frame + grid plan | device build of the LCP structure | Q-side uploads | total
@@ -281,6 +282,18 @@ int32_t upload_pairs_staged(s4p_ctx* c, int slot, int set, float pair_distance_e
 // loop 2 + the pair filters (k_pairs) for one set, or for both sets of a base in one launch: one wave per (primitive,
 // part); about 4000 work items per set fill the chip once with both sets in flight
 int32_t launch_pairs_kernel(s4p_ctx* c, const PairParams2& PP, int n_sets) {
+  if (c->pairs_v2) {
+    // k_pairs2: one wave per (tile of 64 primitives, chunk of 64 sequence slots); persistent 512-thread workgroups, at most
+    // two waves per SIMD over both sets
+    uint32_t n_seq_max = 0;
+    for (int k = 0; k < n_sets; ++k) n_seq_max = std::max(n_seq_max, PP.set[k].pair.n_seq);
+    const uint64_t items = uint64_t((c->n_q + 63u) / 64u) * uint64_t((n_seq_max + 63u) / 64u);
+    const uint32_t wgs = uint32_t(std::min<uint64_t>(std::max<uint64_t>((items + kPair2Waves - 1u) / kPair2Waves, 1u), n_sets == 2 ? 128u : 256u));
+    if (c->angle_pairs) hipLaunchKernelGGL(k_pairs2<true>, dim3(wgs, uint32_t(n_sets)), dim3(64 * kPair2Waves), 0, c->lane[c->cur].stream, PP);
+    else hipLaunchKernelGGL(k_pairs2<false>, dim3(wgs, uint32_t(n_sets)), dim3(64 * kPair2Waves), 0, c->lane[c->cur].stream, PP);
+    HIPCHK(c, hipGetLastError());
+    return S4P_OK;
+  }
   const uint32_t items = c->n_q * pair_split(c->n_q);
   const uint32_t wgs = std::min<uint32_t>(std::max<uint32_t>((items + kPairWaves - 1u) / kPairWaves, 1u), 4096u);
   if (c->angle_pairs) hipLaunchKernelGGL(k_pairs<true>, dim3(wgs, uint32_t(n_sets)), dim3(64 * kPairWaves), 0, c->lane[c->cur].stream, PP);
@@ -396,7 +409,7 @@ void launch_quads_kernel(s4p_ctx* c, const QuadParams& Q) {
 }
 void launch_gate_kernel(s4p_ctx* c, const GateParams& G) {
   s4p_ctx::Lane& L = c->lane[c->cur];
-  GateKernelParams K{G, L.quads.p, &L.ctr.p->K, uint32_t(L.cap_quads)};   // (K: 64-bit counter)
+  GateKernelParams K{G, L.quads.p, L.tags.p, &L.ctr.p->K, uint32_t(L.cap_quads)};   // (K: 64-bit counter)
   if (c->opt.max_angle >= 0.f) hipLaunchKernelGGL(k_gate<true>, dim3(1024), dim3(256), 0, L.stream, K);
   else hipLaunchKernelGGL(k_gate<false>, dim3(1024), dim3(256), 0, L.stream, K);
 }
@@ -738,7 +751,7 @@ hipError_t alloc_lane_buffers(uint64_t mp_, uint64_t mq_, s4p_ctx::LaneBufs& L, 
 #define A(buf, cnt) if ((e = (buf).alloc(cnt)) != hipSuccess) { *what = "hipMalloc " #buf; return e; }
   A(L.ab1, mp); A(L.ab2, mp); A(L.okey1, mp); A(L.okey2, mp); A(L.cell1, mp);
   A(L.bucket1, mp); A(L.next1, mp); A(L.ew1, mp);
-  A(L.quads, mq); A(L.tags, mq); A(L.counts, mq); A(L.cand_idx, mq); A(L.cand_T, mq * 3);
+  A(L.quads, mq); A(L.tags, mq); A(L.counts, mq); A(L.cand_idx, mq); A(L.cand_T, mq * kCandStride);
   A(L.ht_keys, hts); A(L.ht_heads, hts); L.ht_mask = hts - 1;
 #undef A
   *what = "hipMemset";
@@ -748,7 +761,7 @@ hipError_t alloc_lane_buffers(uint64_t mp_, uint64_t mq_, s4p_ctx::LaneBufs& L, 
   return hipSuccess;
 }
 size_t lane_bytes(uint64_t mp, uint64_t mq) {            // what alloc_lane_buffers takes per lane
-  return size_t(mp) * (8 + 8 + 4 * 5 + 16) + size_t(mq) * (16 + 8 + 4 + 4 + 48) + size_t(next_pow2(2 * mp)) * 16;
+  return size_t(mp) * (8 + 8 + 4 * 5 + 16) + size_t(mq) * (16 + 8 + 4 + 4 + 16 * kCandStride) + size_t(next_pow2(2 * mp)) * 16;
 }
 
 }  // namespace
@@ -785,6 +798,7 @@ int32_t s4p_create(const s4p_options* opt, const s4p_limits* lim, int32_t device
   }
   if (const char* vb = getenv("S4P_VERIFY_BLOCKS")) { const int v = atoi(vb); if (v >= 64 && v <= kVerifyMaxBlocks) { c->verify_blocks = uint32_t(v); c->verify_blocks_fixed = true; c->verify_blocks_env = true; } }   // tuning knob
   if (const char* fu = getenv("S4P_FUSE_GATE")) c->fuse_gate = atoi(fu) != 0;
+  if (const char* pv = getenv("S4P_PAIRS_V2")) c->pairs_v2 = atoi(pv) != 0;
   if (const char* cs = getenv("S4P_CU_SPLIT")) { const int v = atoi(cs); if (v >= 2 && v <= 64) c->cu_split = v; }
   if (const char* at = getenv("S4P_ANGLE_TOL")) { const float v = float(atof(at)); if (v > 1e-6f) c->angle_tol = v; }
   if (const char* qc = getenv("S4P_QUAD_GROW_CAP")) { const long long v = atoll(qc); if (v > 0 && v <= 0x7FFFFFFFll) c->quad_grow_cap = uint64_t(v); }
@@ -1440,9 +1454,9 @@ int32_t s4p_last_verified(s4p_ctx* c, uint32_t* counts, float* transforms16, int
   const uint32_t Cdev = c->hctr[c->cur].p->C;               // as the device counted them (incl. candidates the host rejected afterwards)
   *n_out = 0;
   if (Cdev == 0) return S4P_OK;
-  std::vector<uint32_t> idx(Cdev); std::vector<float4> T(size_t(Cdev) * 3);
+  std::vector<uint32_t> idx(Cdev); std::vector<float4> T(size_t(Cdev) * kCandStride);
   HIPCHK(c, hipMemcpy(idx.data(), L.cand_idx.p, size_t(Cdev) * 4, hipMemcpyDeviceToHost));
-  HIPCHK(c, hipMemcpy(T.data(), L.cand_T.p, size_t(Cdev) * 48, hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(T.data(), L.cand_T.p, size_t(Cdev) * 16 * kCandStride, hipMemcpyDeviceToHost));
   for (auto& k : idx) k &= ~kBorderFlag;
   const uint64_t K = c->last_K;
   std::vector<unsigned long long> t(K); std::vector<uint32_t> cn(K);
@@ -1460,7 +1474,7 @@ int32_t s4p_last_verified(s4p_ctx* c, uint32_t* counts, float* transforms16, int
     const uint32_t a = order[i];
     counts[i] = cn[idx[a]];
     float* o = transforms16 + 16 * size_t(i);
-    std::memcpy(o, &T[size_t(a) * 3], 48);
+    std::memcpy(o, &T[size_t(a) * kCandStride], 48);
     o[12] = 0.f; o[13] = 0.f; o[14] = 0.f; o[15] = 1.f;
   }
   return S4P_OK;

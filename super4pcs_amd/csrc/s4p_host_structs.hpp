@@ -120,7 +120,7 @@ class PairOctree {
     auto emit = [&](const Node& nd, float h) {
       leaves[li] = Leaf{nd.c[0], nd.c[1], nd.c[2], h};
       leaf_off[li] = at;
-      for (uint32_t k = nd.begin; k < nd.end; ++k, ++at) seq_id[at] = ids[k];
+      for (uint32_t k = nd.begin; k < nd.end; ++k, ++at) seq_id[at] = ids[k] | (li << 16);      // id | leaf << 16 (both < 2^16: n_Q <= 46 340)
       ++li;
     };
     for (const Node& nd : nxt_) emit(nd, eps_unit * 2.f);

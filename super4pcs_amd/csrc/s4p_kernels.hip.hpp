@@ -901,7 +901,9 @@ __device__ __forceinline__ uint32_t exact_pair_lean(const LcpGrid& g, const LcpT
 }
 
 template <bool COUNT, bool SKIP_FINE>
-__device__ __forceinline__ uint32_t wave_lcp_count_lean(const LcpGrid& g, const LcpTask& K, const LeanLds& L, const float4* Tsrc) {
+__device__ __forceinline__ uint32_t wave_lcp_count_lean(const LcpGrid& g, const LcpTask& K, const LeanLds& L, const float4* Tsrc, const float4 t0, const float4 t1, const float4 t2) {
+  // t0..t2: the rows at Tsrc, already in registers (k_verify fetches a candidate's record while the previous one is swept); the
+  // rare drain / exact batches read them again through Tsrc
   const uint32_t lane = threadIdx.x & 63u;
   uint16_t* q = L.queue;
   uint32_t cnt = 0, nb = 0, na = 0;
@@ -911,7 +913,7 @@ __device__ __forceinline__ uint32_t wave_lcp_count_lean(const LcpGrid& g, const 
   // locating transform in coarse units (exact power-of-two scaling of the grid-unit transform)
 #if S4P_LEAN_MFMA
   float a0, a1, a2; f4_t c0;
-  { float T[12]; load_rows(Tsrc, T);
+  { const float T[12] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w, t2.x, t2.y, t2.z, t2.w};
     const GridXf Xc = make_grid_xf(g, T, coarse_scale(g));
     const uint32_t r = lane & 3u;                          // A operand: lane (block, r) holds row r of the column
     a0 = r == 0u ? Xc.u[0] : (r == 1u ? Xc.u[4] : (r == 2u ? Xc.u[8] : 0.f));
@@ -920,7 +922,8 @@ __device__ __forceinline__ uint32_t wave_lcp_count_lean(const LcpGrid& g, const 
     c0 = f4_t{Xc.u[3], Xc.u[7], Xc.u[11], 0.f}; }
 #else
   GridXf Xc;
-  { float T[12]; load_rows(Tsrc, T); Xc = make_grid_xf(g, T, coarse_scale(g)); }
+  { const float T[12] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w, t2.x, t2.y, t2.z, t2.w};
+    Xc = make_grid_xf(g, T, coarse_scale(g)); }
 #endif
   typedef const __attribute__((address_space(3))) uint32_t* lds_u32_ptr;
   const uint32_t coarse_base = uint32_t(uintptr_t((lds_u32_ptr)L.coarse));      // byte address of the bitmap inside LDS (0 in k_verify)
@@ -1389,10 +1392,34 @@ __device__ __forceinline__ bool sphere_box(float cx, float cy, float cz, float r
   return (dmin[0] + (dmin[1] + dmin[2])) < r2 && r2 < (dmax[0] + (dmax[1] + dmax[2]));
 }
 
+// the same test with the squared radius precomputed (identical arithmetic: r2 = r * r is what sphere_box forms itself)
+__device__ __forceinline__ bool sphere_box_r2(float cx, float cy, float cz, float r2, float4 leaf) {
+  const float h = leaf.w;
+  float dmin[3], dmax[3];
+  const float c[3] = {cx, cy, cz};
+  const float nc[3] = {leaf.x, leaf.y, leaf.z};
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float mn = nc[k] - h, mx = nc[k] + h;
+    const float sqmin = (c[k] - mn) * (c[k] - mn);
+    const float sqmax = (c[k] - mx) * (c[k] - mx);
+    dmin[k] = (c[k] < mn) ? sqmin : ((c[k] > mx) ? sqmax : 0.f);
+    dmax[k] = (sqmin < sqmax) ? sqmax : sqmin;
+  }
+  return (dmin[0] + (dmin[1] + dmin[2])) < r2 && r2 < (dmax[0] + (dmax[1] + dmax[2]));
+}
+
 // PairCreationFunctor::process(i = pId, j) filters (pairCreationFunctor.h:151-218): p = Q[j], q = Q[i]
+__device__ __forceinline__ bool pair_filters_w(const PairParams& P, const uint32_t pId, const uint32_t j,
+                                               const float wxi, const float wyi, const float wzi, const float wxj, const float wyj, const float wzj);
 __device__ __forceinline__ bool pair_filters(const PairParams& P, const uint32_t pId, const uint32_t j,
                                              const float wxi, const float wyi, const float wzi) {
-  const float wx = wxi - P.qx[j], wy = wyi - P.qy[j], wz = wzi - P.qz[j];
+  return pair_filters_w(P, pId, j, wxi, wyi, wzi, P.qx[j], P.qy[j], P.qz[j]);
+}
+// (the world point of j handed in: k_pairs2 holds it in registers)
+__device__ __forceinline__ bool pair_filters_w(const PairParams& P, const uint32_t pId, const uint32_t j,
+                                               const float wxi, const float wyi, const float wzi, const float wxj, const float wyj, const float wzj) {
+  const float wx = wxi - wxj, wy = wyi - wyj, wz = wzi - wzj;
   const float distance = sqrtf(sqn3(wx, wy, wz));
   bool acc = !(fabs(double(distance) - P.pair_distance) > P.pair_distance_eps);   // :162
   if (acc && P.max_normal_difference > 0.f && P.nx != nullptr) {              // :166-180
@@ -1415,7 +1442,7 @@ __device__ __forceinline__ bool pair_filters(const PairParams& P, const uint32_t
   }
   if (acc && P.max_translation_distance > 0.f) {                              // :194-200
     const bool good =
-        sqrtf(sqn3(P.qx[j] - P.b1pos[0], P.qy[j] - P.b1pos[1], P.qz[j] - P.b1pos[2])) < P.max_translation_distance &&
+        sqrtf(sqn3(wxj - P.b1pos[0], wyj - P.b1pos[1], wzj - P.b1pos[2])) < P.max_translation_distance &&
         sqrtf(sqn3(wxi - P.b2pos[0], wyi - P.b2pos[1], wzi - P.b2pos[2])) < P.max_translation_distance;
     if (!good) acc = false;
   }
@@ -1498,7 +1525,7 @@ __global__ __launch_bounds__(64 * kPairWaves) void k_pairs(PairParams2 PP) {
         uint32_t j = 0, s = 0;
         if (t < total) {
           s = o_beg + (t - (o_incl - o_len));
-          j = P.seq_id[s];
+          j = P.seq_id[s] & 0xFFFFu;                                              // (upper half: the slot's leaf, for k_pairs2)
           if (pId > j) {                                                          // intersectionFunctor.h:210
             const float dx = P.ux[j] - cx, dy = P.uy[j] - cy, dz = P.uz[j] - cz;
             const float d = sqrtf(sqn3(dx, dy, dz)) - P.nRadius;
@@ -1560,6 +1587,173 @@ __global__ __launch_bounds__(64 * kPairWaves) void k_pairs(PairParams2 PP) {
 }
 
 // ---------------------------------------------------------------------------
+// k_pairs2: the same loop 2, TRANSPOSED (round 4).  k_pairs walks (primitive -> touched leaves -> their points) with one
+// wave per primitive: every round of 64 point slots pays a 6-step cross-lane binary search for the owning leaf and two
+// dependent gathers (slot -> id -> coordinates), ~1.5 us of latency per round.  Here a wave owns a TILE of 64 primitives
+// (lane = primitive, its centre in registers) times a CHUNK of 64 consecutive point slots of the leaf-major sequence: the
+// chunk's ids, points and leaf records are gathered ONCE (lane = slot, all loads independent), and the wave then runs over
+// the chunk's leaves and points with UNIFORM control flow and no memory access:
+//   per leaf run: box test per lane (intersect, intersectionPrimitive.h:117-142; intersectionFunctor.h:205);
+//   per point: its record broadcast by v_readlane, squared distance to the 64 centres and a conservative PRE-test
+//     (r - E)^2 <= s2 <= (r + E)^2 of the point test -- no square root; the few lanes that pass (a few % of the tests) are
+//     queued as (lane, slot) in LDS;
+//   per 64 queued candidates, on dense lanes: the exact point test (intersectPoint, :154-157: correctly rounded sqrt) and
+//     the world-space filters of PairCreationFunctor::process (pairCreationFunctor.h:151-218), operands fetched across lanes
+//     with ds_bpermute; accepted pairs go to the wave's LDS stage and are appended as in k_pairs.
+// Every (primitive, point) test of the reference's loop is decided exactly once; the pre-test only removes tests whose
+// outcome is certain (margin E - eps covers the rounding of the exact expression with three orders of magnitude to spare).
+// The leaf of a slot travels in the upper half of its sequence word (PairOctree::flatten: id | leaf << 16; both < 2^16
+// because n_Q <= 46 340).  Order keys as in k_pairs: 2 * (pId * n_seq + slot) + {0, 1}.
+// ---------------------------------------------------------------------------
+constexpr int kPair2Waves = 8;      // waves per workgroup: few workgroups = few appends on the one pair counter
+constexpr int kPair2StageW = 256;   // staged accepted (primitive, slot) per wave between two flushes
+constexpr int kPair2Queue = 128;    // queued (lane, slot-in-chunk) candidates per wave: a batch of 64 runs when 64 wait
+
+template <bool ANGLE>
+__global__ __launch_bounds__(64 * kPair2Waves) void k_pairs2(PairParams2 PP) {
+  const PairParams& P = PP.set[blockIdx.y].pair;
+  __shared__ uint32_t st_e[kPair2Waves][kPair2StageW];   // primitive | slot << 16
+  __shared__ uint8_t st_f[kPair2Waves][ANGLE ? kPair2StageW : 4];   // ANGLE: 1 = the second of the two ordered pairs
+  __shared__ uint16_t s_qc[kPair2Waves][kPair2Queue];    // candidate queue: lane | k << 6
+  __shared__ uint32_t s_cnt[kPair2Waves], s_base;
+  const uint32_t lane = threadIdx.x & 63u, wave = uint32_t(__builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6)));
+  uint32_t n_st = 0;                                     // staged entries of this wave (wave-uniform)
+  auto wave_fence = [&]() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); };
+  auto write_out = [&](const uint32_t base) {            // entries -> ordered pairs at positions base, base + 1, ...
+    for (uint32_t pe = lane; pe < (ANGLE ? n_st : 2u * n_st); pe += 64u) {
+      const uint32_t e = ANGLE ? pe : pe >> 1, second = ANGLE ? uint32_t(st_f[wave][e]) : pe & 1u;
+      const uint32_t at = base + pe;
+      if ((ANGLE ? at : (at | 1u)) < P.cap) {              // both pairs of an entry fit, or neither is written
+        const uint32_t w = st_e[wave][e], pId = w & 0xFFFFu, sl = w >> 16;
+        const uint32_t j = P.seq_id[sl] & 0xFFFFu;
+        // pairs->emplace_back(j, i) then pairs->emplace_back(i, j)   pairCreationFunctor.h:214-215
+        P.ab[at] = second ? make_int2(int(pId), int(j)) : make_int2(int(j), int(pId));
+        P.okey[at] = 2u * (pId * P.n_seq + sl) + second;
+      } else {
+        atomicOr(P.overflow, P.overflow_bit);
+      }
+    }
+    wave_fence();
+  };
+  const uint32_t n_tiles = (P.n_q + 63u) >> 6, n_chunks = (P.n_seq + 63u) >> 6;
+  const uint32_t gw = blockIdx.x * kPair2Waves + wave, nw = gridDim.x * kPair2Waves;
+  const float r2 = P.nRadius * P.nRadius, e2 = P.eps_unit * P.eps_unit;
+  // pre-test bounds on the squared distance: |sqrt(s2) - r| < eps can only hold inside [(r - E)^2, (r + E)^2], E = eps
+  // widened by 1e-4 relative + 1e-6 absolute (the exact expression rounds three times at 6e-8 relative each)
+  const float E = P.eps_unit * 1.0001f + 1e-6f * (P.nRadius + 1.f);
+  const float lo_r = fmaxf(P.nRadius - E, 0.f), hi_r = P.nRadius + E;
+  const float lo2 = lo_r * lo_r * 0.9999f, hi2 = hi_r * hi_r * 1.0001f;
+  // item = (chunk, tile), tile fastest: the waves of a workgroup share their chunk's gathers in cache
+  for (uint32_t item = gw; item < n_tiles * n_chunks; item += nw) {
+    const uint32_t chunk = item / n_tiles, tile = item - chunk * n_tiles;
+    const uint32_t s0 = chunk * 64u, n_in = min(64u, P.n_seq - s0);
+    // the chunk: lane = slot -- id, unit point, world point, and the record of the slot's leaf (box, end of its slot range)
+    const uint32_t sw = P.seq_id[s0 + min(lane, n_in - 1u)];
+    const uint32_t jl = sw & 0xFFFFu, leaf_l = sw >> 16;
+    const float pux = P.ux[jl], puy = P.uy[jl], puz = P.uz[jl];
+    const float pwx = P.qx[jl], pwy = P.qy[jl], pwz = P.qz[jl];
+    const float4 box_l = P.leaves[leaf_l];
+    const uint32_t end_l = P.leaf_off[leaf_l + 1u];
+    // the tile: lane = primitive
+    const uint32_t pId = tile * 64u + lane;
+    const bool pvalid = pId < P.n_q;
+    const uint32_t pi = min(pId, P.n_q - 1u);
+    const float cx = P.ux[pi], cy = P.uy[pi], cz = P.uz[pi];
+    const float wxi = P.qx[pi], wyi = P.qy[pi], wzi = P.qz[pi];
+    auto bcast = [&](const float v, const uint32_t k) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), int(k))); };
+    auto fetch = [&](const float v, const uint32_t from) { return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(int(from << 2), __builtin_bit_cast(int, v))); };
+    uint32_t nq = 0;                                        // queued candidates (wave-uniform)
+    // exact tests of up to 64 queued candidates, one per lane
+    auto run_batch = [&]() {
+      wave_fence();
+      const uint32_t n = min(nq, 64u);
+      const bool v = lane < n;
+      const uint32_t ent = uint32_t(s_qc[wave][nq - n + min(lane, n - 1u)]);
+      const uint32_t L = ent & 63u, k = ent >> 6;
+      nq -= n;
+      // the candidate's primitive (lane L of the tile) and point (slot k of the chunk)
+      const float ccx = fetch(cx, L), ccy = fetch(cy, L), ccz = fetch(cz, L);
+      const float cwx = fetch(wxi, L), cwy = fetch(wyi, L), cwz = fetch(wzi, L);
+      const uint32_t j = uint32_t(__builtin_amdgcn_ds_bpermute(int(k << 2), int(jl)));
+      const float qx_ = fetch(pux, k), qy_ = fetch(puy, k), qz_ = fetch(puz, k);
+      const float wxj = fetch(pwx, k), wyj = fetch(pwy, k), wzj = fetch(pwz, k);
+      const uint32_t cp = tile * 64u + L;
+      bool acc = false;
+      if (v) {
+        const float dx = qx_ - ccx, dy = qy_ - ccy, dz = qz_ - ccz;
+        const float d = sqrtf(sqn3(dx, dy, dz)) - P.nRadius;
+        if (d * d < e2) acc = pair_filters_w(P, cp, j, cwx, cwy, cwz, wxj, wyj, wzj);      // intersectPoint intersectionPrimitive.h:154-157
+      }
+      bool emit_a = acc, emit_b = false;                    // ANGLE: (j,i) / (i,j) separately
+      if (ANGLE) {
+        emit_a = false;
+        if (acc) {                                          // pairCreationFunctor.h:203-212
+          float sx = cwx - wxj, sy = cwy - wyj, sz = cwz - wzj;
+          normalize3(sx, sy, sz);
+          const float dd = dot3(P.seg1[0], P.seg1[1], P.seg1[2], sx, sy, sz), nd = -dd;
+          emit_a = dd >= P.cos_min && dd <= 1.f;
+          emit_b = nd >= P.cos_min && nd <= 1.f;
+        }
+      }
+      const unsigned long long m = __builtin_amdgcn_ballot_w64(emit_a);
+      const unsigned long long mb = ANGLE ? __builtin_amdgcn_ballot_w64(emit_b) : 0ull;
+      if ((m | mb) == 0ull) return;
+      const uint32_t word = cp | ((s0 + k) << 16);
+      if (emit_a) {
+        const uint32_t e = n_st + __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u));
+        st_e[wave][e] = word; if (ANGLE) st_f[wave][e] = 0;
+      }
+      n_st += uint32_t(__popcll(m));
+      if (ANGLE) {
+        if (emit_b) {
+          const uint32_t e = n_st + __builtin_amdgcn_mbcnt_hi(uint32_t(mb >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mb), 0u));
+          st_e[wave][e] = word; st_f[wave][e] = 1;
+        }
+        n_st += uint32_t(__popcll(mb));
+      }
+      if (n_st + (ANGLE ? 128u : 64u) > uint32_t(kPair2StageW)) {   // stage full before the end: this wave appends on its own
+        wave_fence();
+        uint32_t b = 0;
+        if (lane == 0) b = atomicAdd(P.counter, ANGLE ? n_st : 2u * n_st);
+        write_out(uint32_t(__builtin_amdgcn_readfirstlane(int(b))));
+        n_st = 0;
+      }
+    };
+    for (uint32_t k = 0; k < n_in;) {                       // uniform: one run of slots = the part of one leaf inside the chunk
+      const float4 box = make_float4(bcast(box_l.x, k), bcast(box_l.y, k), bcast(box_l.z, k), bcast(box_l.w, k));
+      const uint32_t k1 = min(uint32_t(__builtin_amdgcn_readlane(int(end_l), int(k))) - s0, n_in);
+      const bool touch = pvalid && sphere_box_r2(cx, cy, cz, r2, box);     // intersect, intersectionPrimitive.h:117-142
+      if (__builtin_amdgcn_ballot_w64(touch) == 0ull) { k = k1; continue; }
+      for (; k < k1; ++k) {                                 // uniform: one point of the leaf against the 64 primitives
+        const uint32_t j = uint32_t(__builtin_amdgcn_readlane(int(jl), int(k)));
+        const float dx = bcast(pux, k) - cx, dy = bcast(puy, k) - cy, dz = bcast(puz, k) - cz;
+        const float s2 = sqn3(dx, dy, dz);
+        const bool pre = touch & (pId > j) & (s2 >= lo2) & (s2 <= hi2);      // intersectionFunctor.h:210 + the certain part of :211
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(pre);
+        if (m == 0ull) continue;
+        if (pre) s_qc[wave][nq + __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u))] = uint16_t(lane | (k << 6));
+        nq += uint32_t(__popcll(m));
+        if (nq >= 64u) run_batch();
+      }
+    }
+    while (nq != 0u) run_batch();                           // (the queue refers to this item's registers: empty it before the next)
+  }
+  wave_fence();
+  // end of the workgroup's items: ONE global atomic for the waves' leftovers
+  if (lane == 0) s_cnt[wave] = n_st;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t tot = 0;
+    for (int w = 0; w < kPair2Waves; ++w) tot += s_cnt[w];
+    s_base = tot ? atomicAdd(P.counter, ANGLE ? tot : 2u * tot) : 0u;
+  }
+  __syncthreads();
+  uint32_t before = 0;
+  for (uint32_t w = 0; w < wave; ++w) before += s_cnt[w];
+  if (n_st) write_out(s_base + (ANGLE ? before : 2u * before));
+}
+
+// ---------------------------------------------------------------------------
 // ComputeRigidTransformation + rms gate of one congruent quad (match4pcsBase.cc:365-500, match4pcsBase.hpp:436-439)
 // and the compaction of the passing candidates.  Shared by k_gate (stage-level entry point) and k_quads (fused path).
 // ---------------------------------------------------------------------------
@@ -1567,9 +1761,10 @@ struct GateParams {
   const float4* q4;                                     // sampled Q (centred), packed (x,y,z,0), original order (quad indices)
   BaseFrame base;
   uint32_t* counts;                                     // per quad: kGateFailed, later the inlier count
-  uint32_t* cand_idx; float4* cand_T;                   // gated candidates: quad index + 3x4 transform
+  uint32_t* cand_idx; float4* cand_T;                   // gated candidates: quad index + 64-byte record {3x4 transform | tag, quad index}
   uint32_t* C_dev;
 };
+constexpr uint32_t kCandStride = 4;                     // float4 per candidate record: one 64-byte line, everything k_verify needs of a candidate
 // 0 = rejected, 1 = candidate, 2 = candidate whose Euler-angle bound the host settles (rigid_verdict)
 template <bool ANGLE>
 __device__ __forceinline__ int gate_quad(const GateParams& G, const int4 qd, float T[12]) {
@@ -1579,18 +1774,19 @@ __device__ __forceinline__ int gate_quad(const GateParams& G, const int4 qd, flo
   return rigid_verdict<ANGLE>(G.base, q, T, c2);
 }
 // k: index of the quad, with kBorderFlag set if its gate is undecided
-__device__ __forceinline__ void store_candidate(const GateParams& G, const uint32_t at, const uint32_t k, const float T[12]) {
+__device__ __forceinline__ void store_candidate(const GateParams& G, const uint32_t at, const uint32_t k, const float T[12], const unsigned long long tag) {
   G.cand_idx[at] = k;
-  float4* dst = G.cand_T + 3 * size_t(at);
+  float4* dst = G.cand_T + kCandStride * size_t(at);
   dst[0] = make_float4(T[0], T[1], T[2], T[3]);
   dst[1] = make_float4(T[4], T[5], T[6], T[7]);
   dst[2] = make_float4(T[8], T[9], T[10], T[11]);
+  dst[3] = make_float4(__uint_as_float(uint32_t(tag)), __uint_as_float(uint32_t(tag >> 32)), __uint_as_float(k), 0.f);
 }
 
 // k_gate: one thread per congruent quad (s4p_try_congruent_set, where the quads come from the caller).  Passing
 // candidates are compacted (wave-aggregated append) into cand_idx / cand_T so that the scoring kernel sees a dense,
 // perfectly balanceable list; failing ones get counts[k] = kGateFailed.
-struct GateKernelParams { GateParams g; const int4* quads; const unsigned long long* K_dev; uint32_t K_cap; };
+struct GateKernelParams { GateParams g; const int4* quads; const unsigned long long* tags; const unsigned long long* K_dev; uint32_t K_cap; };
 template <bool ANGLE>
 __global__ __launch_bounds__(256) void k_gate(GateKernelParams P) {
   const uint32_t K = uint32_t(min(*P.K_dev, (unsigned long long)P.K_cap));
@@ -1610,7 +1806,7 @@ __global__ __launch_bounds__(256) void k_gate(GateKernelParams P) {
     uint32_t base = 0;
     if (lane == leader) base = atomicAdd(P.g.C_dev, uint32_t(__popcll(pass)));
     base = __shfl(base, leader);
-    if (ok) store_candidate(P.g, base + uint32_t(__popcll(pass & ((1ull << lane) - 1ull))), k | (vd == 2 ? kBorderFlag : 0u), T);
+    if (ok) store_candidate(P.g, base + uint32_t(__popcll(pass & ((1ull << lane) - 1ull))), k | (vd == 2 ? kBorderFlag : 0u), T, P.tags[k]);
   }
 }
 
@@ -1737,7 +1933,7 @@ __global__ __launch_bounds__(256) void k_quads(QuadParams P) {
               if (P.do_gate) {
                 float T[12];
                 const int vd = gate_quad<ANGLE>(P.gate, quad, T);
-                if (vd) { store_candidate(P.gate, atomicAdd(P.gate.C_dev, 1u), uint32_t(at) | (vd == 2 ? kBorderFlag : 0u), T); atomicAdd(&s_csum, mix); }
+                if (vd) { store_candidate(P.gate, atomicAdd(P.gate.C_dev, 1u), uint32_t(at) | (vd == 2 ? kBorderFlag : 0u), T, tag); atomicAdd(&s_csum, mix); }
                 else P.gate.counts[at] = kGateFailed;
               }
             } else atomicOr(P.overflow, 4u);
@@ -1776,7 +1972,7 @@ __global__ __launch_bounds__(256) void k_quads(QuadParams P) {
           if (ok) {
             uint32_t before = 0;
             for (uint32_t w = 0; w < wave; ++w) before += s_wc[w];
-            store_candidate(P.gate, s_cbase + before + uint32_t(__popcll(pass & ((1ull << lane) - 1ull))), uint32_t(at) | (vd == 2 ? kBorderFlag : 0u), T);
+            store_candidate(P.gate, s_cbase + before + uint32_t(__popcll(pass & ((1ull << lane) - 1ull))), uint32_t(at) | (vd == 2 ? kBorderFlag : 0u), T, e < n ? st_t[e] : 0ull);
           }
           __syncthreads();                                      // s_wc / s_cbase are rewritten by the next chunk
         }
@@ -1842,7 +2038,7 @@ __device__ __forceinline__ bool slot_better(const uint32_t ca, const unsigned lo
 // LEAN (launched when an early-exit bound is in force and the float copy of the sampled Q fits LDS): wave_lcp_count_lean,
 // LDS = coarse bitmap | float queries x, y, z | one 16-bit queue per wave; QLDS is then meaningless (false).
 template <bool COUNT, bool QLDS, bool LEAN>
-__global__ __launch_bounds__(kVerifyMaxThreads, 6) void k_verify(VerifyParams P) {   // <= 80 VGPRs: six waves per SIMD (two 768-thread workgroups per CU)
+__global__ __launch_bounds__(kVerifyMaxThreads, LEAN ? 4 : 6) void k_verify(VerifyParams P) {   // fused: <= 80 VGPRs, six waves per SIMD (two 768-thread workgroups per CU); lean: one workgroup per CU, <= 128
   extern __shared__ uint32_t s_mem[];
   uint32_t* s_coarse = s_mem;                              // LDS: coarse bitmap | quantised queries (QLDS) | 16 survivor queues
   uint2* s_q = reinterpret_cast<uint2*>(s_mem + P.grid.coarse_words);
@@ -1875,29 +2071,41 @@ __global__ __launch_bounds__(kVerifyMaxThreads, 6) void k_verify(VerifyParams P)
   if (lo < hi && P.ablate != 2) {                          // (uniform) otherwise: more workgroups than candidates
     if (threadIdx.x == 0) { s_next = lo; s_pruned = 0u; }
     LcpTask K;
-    K.q4 = P.q4v; K.n_q = P.n_q; K.qq = P.qq; K.T = P.cand_T; K.t_stride = 3u; K.point_tests = &P.ctr->point_tests;
+    K.q4 = P.q4v; K.n_q = P.n_q; K.qq = P.qq; K.T = P.cand_T; K.t_stride = kCandStride; K.point_tests = &P.ctr->point_tests;
     K.prune = P.prune; K.pruned = &s_pruned;
     if (LEAN) stage_queries_f(P.qsoa, const_cast<float*>(LL.qx), 3u * n_pad);
     else if (QLDS) stage_queries(K, s_q);
     stage_coarse(P.grid, s_coarse);                        // ends with a workgroup barrier
-    while (true) {
-      uint32_t i = 0;
-      if (lane == 0) i = atomicAdd(&s_next, 1u);
-      i = uint32_t(__builtin_amdgcn_readfirstlane(int(i)));
-      if (i >= hi) break;
-      i = blockIdx.x + i * gridDim.x;
-      const float4* src = P.cand_T + 3 * size_t(i);         // one candidate per wave
+    // A candidate is one 64-byte record {3x4 transform | tag, quad index}.  The wave holds TWO tickets: the record of the next
+    // candidate is in flight while the current one is swept, so the chain "ticket -> record -> transform" (three dependent
+    // memory round trips per candidate in the round-3 kernel: transform, quad index, tag) is off the critical path.
+    auto take = [&]() -> uint32_t {
+      uint32_t t = 0;
+      if (lane == 0) t = atomicAdd(&s_next, 1u);
+      return uint32_t(__builtin_amdgcn_readfirstlane(int(t)));
+    };
+    uint32_t t_cur = take();
+    float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0, r3 = r0;
+    if (t_cur < hi) { const float4* rec = P.cand_T + kCandStride * size_t(blockIdx.x + t_cur * gridDim.x); r0 = rec[0]; r1 = rec[1]; r2 = rec[2]; r3 = rec[3]; }
+    while (t_cur < hi) {
+      const uint32_t i = blockIdx.x + t_cur * gridDim.x;
+      const uint32_t t_nxt = take();
+      float4 n0 = r0, n1 = r1, n2 = r2, n3 = r3;
+      if (t_nxt < hi) { const float4* rec = P.cand_T + kCandStride * size_t(blockIdx.x + t_nxt * gridDim.x); n0 = rec[0]; n1 = rec[1]; n2 = rec[2]; n3 = rec[3]; }
+      const float4* src = P.cand_T + kCandStride * size_t(i);         // one candidate per wave
       uint32_t cnt;
-      if (LEAN) cnt = P.ablate == 1 ? wave_lcp_count_lean<COUNT, true>(P.grid, K, LL, src) : wave_lcp_count_lean<COUNT, false>(P.grid, K, LL, src);
+      if (LEAN) cnt = P.ablate == 1 ? wave_lcp_count_lean<COUNT, true>(P.grid, K, LL, src, r0, r1, r2) : wave_lcp_count_lean<COUNT, false>(P.grid, K, LL, src, r0, r1, r2);
       else cnt = P.ablate == 1 ? S4P_WAVE_LCP_COUNT<COUNT, true, QLDS>(P.grid, K, s_coarse, s_q, s_queue, src)
                                : S4P_WAVE_LCP_COUNT<COUNT, false, QLDS>(P.grid, K, s_coarse, s_q, s_queue, src);
-      const uint32_t kraw = uint32_t(__builtin_amdgcn_readfirstlane(int(P.cand_idx[i])));
+      const uint32_t kraw = uint32_t(__builtin_amdgcn_readfirstlane(int(__float_as_uint(r3.z))));
       const uint32_t k = kraw & ~kBorderFlag;
-      const unsigned long long tag = P.tags[k];
+      const unsigned long long tag = (unsigned long long)uint32_t(__builtin_amdgcn_readfirstlane(int(__float_as_uint(r3.x)))) |
+                                     ((unsigned long long)uint32_t(__builtin_amdgcn_readfirstlane(int(__float_as_uint(r3.y)))) << 32);
       if (lane == 0) P.counts[k] = cnt;
       if (kraw & kBorderFlag) {                              // scored, but the host decides whether it is a candidate at all
         if (lane == 0) { const uint32_t n = atomicAdd(&P.ctr->n_border, 1u); if (n < kBorderCap) P.border[n] = i; }
       } else if (slot_better(cnt, tag, bc, bt, bi != kNil)) { bc = cnt; bt = tag; bi = i; }
+      t_cur = t_nxt; r0 = n0; r1 = n1; r2 = n2; r3 = n3;
     }
   }
   // ---- selection: wave bests -> workgroup best -> slot; the last workgroup to finish reduces the slots ----

@@ -34,7 +34,10 @@ static int run_octree(const char* path) {
     std::printf("%u %u\n", tree.n_seq(), tree.n_leaf());
     for (size_t i = 0; i < n; ++i) std::printf("%u ", tree.ids[i]);
     std::printf("\n");
-    for (uint32_t i = 0; i < tree.n_seq(); ++i) std::printf("%u ", sid[i]);
+    // a sequence word is id | leaf << 16: the leaf must be the one whose slot range holds the word
+    for (uint32_t l = 0; l < tree.n_leaf(); ++l)
+      for (uint32_t i = loff[l]; i < loff[l + 1]; ++i) if ((sid[i] >> 16) != l) { std::printf("bad leaf tag\n"); return 1; }
+    for (uint32_t i = 0; i < tree.n_seq(); ++i) std::printf("%u ", sid[i] & 0xFFFFu);
     std::printf("\n");
   }
   return 0;
