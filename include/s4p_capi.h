@@ -98,8 +98,8 @@ int32_t s4p_device_name(const s4p_ctx* ctx, char* buf, int32_t buflen);
  *    CHUNKS: ranges of the second pair set are enumerated into the quad buffers, gated, LCP-scored and folded one after
  *    the other with the reference's first-maximum rule, so winner, best count, n_quads, n_verified and the checksums are
  *    those of an unbounded pass; afterwards the lane's quad buffers grow towards grow_cap_quads (default 32 Mi entries)
- *    so that later bases of that size take one pass.  Only the per-candidate records (s4p_last_candidates /
- *    s4p_last_verified) are not available for a chunked base (S4P_ERR_UNSUPPORTED).
+ *    so that later bases of that size take one pass.  The per-candidate records of such a base (s4p_last_candidates /
+ *    s4p_last_verified, the reference's per-candidate visitor calls) are available too: see s4p_keep_candidate_records.
  * Growth is refused (S4P_ERR_CAPACITY, loudly) when the lanes together would take more than 60 % of the device memory.
  * s4p_set_auto_grow(0) / s4p_set_quad_chunking(0, ..) restore the strict contract of the stage-level entry points: an
  * overflowing base fails with S4P_ERR_CAPACITY.  s4p_chunk_stats: {chunked bases, chunk passes, range splits, quads of
@@ -241,6 +241,23 @@ int32_t s4p_last_candidates(s4p_ctx* ctx, int32_t* quads, int32_t* counts, int64
  * match4pcsBase.hpp:458-465): inlier counts and row-major 4x4 transforms (centred frame) of the candidates verified
  * by the base whose s4p_try_base_wait returned last, in reference order.  Valid until that lane is reused. */
 int32_t s4p_last_verified(s4p_ctx* ctx, uint32_t* counts, float* transforms16, int64_t cap, int64_t* n_out);
+
+/* Per-candidate records of a base that takes SEVERAL device passes -- a fused base whose quads exceed the lane's buffers
+ * (chunked, see above), a caller's quad list longer than them (s4p_try_congruent_set scores it in slices).  The reference
+ * delivers v(-1, lcp, T) for every candidate of every base (match4pcsBase.hpp:458-465) and returns whole quad lists
+ * (super4pcs.cc:166-174), whatever their size.
+ *  - s4p_set_candidate_sink: while a sink is set, every base hands its verified candidates to it from inside the wait
+ *    (s4p_try_base_wait / s4p_try_base / s4p_try_congruent_set), in REFERENCE ORDER, in one call or -- for a multi-pass
+ *    base -- one call per pass: counts[n] and row-major 4x4 transforms (centred frame).  A chunked base is then cut along the
+ *    order key of its first pair set, the primary key of the reference's candidate order, so pass after pass comes out in
+ *    that order and the host never holds more than one pass.  The matcher's per-candidate visitor runs on this.
+ *  - s4p_keep_candidate_records(ctx, 1): the same ordered passes, the records (and the quads with their counts) kept on the
+ *    host for s4p_last_candidates / s4p_last_verified (memory: 20 B per quad + 68 B per candidate).
+ *  - with neither, those two calls replay a multi-pass fused base once in that mode (possible until its staging slot is
+ *    rewritten: S4P_ERR_STATE afterwards). */
+typedef void (*s4p_candidate_sink)(void* user, const uint32_t* counts, const float* transforms16, int64_t n);
+int32_t s4p_set_candidate_sink(s4p_ctx* ctx, s4p_candidate_sink sink, void* user);
+int32_t s4p_keep_candidate_records(s4p_ctx* ctx, int32_t enable);
 
 /* ---- base selection: Match4PCSBase::SelectRandomTriangle + the 4th-point scan of SelectQuadrilateral
  * (match4pcsBase.cc:185-218, 279-338) as device reductions over the sampled P resident in HBM: ONE attempt.

@@ -106,6 +106,13 @@ class Match4PCSBase {
     pull_sampled(0, ps, sampled_P_3D_);
     pull_sampled(1, qu, sampled_Q_3D_);
     Log<LogLevel::Verbose>("norm_max_dist: ", options_.delta);
+    // The virtual handler, "called once the internal state of the Base class has been set" (match4pcsBase.h:262-272,
+    // match4pcsBase.hpp:197-198): with the caller's P and Q, after sampling / centring / the trial count, and with
+    // best_LCP_ still 0 -- the initial LCP (= Verify(transform_), :200) is assigned after it, as in the reference.
+    const Scalar initial_lcp = best_LCP_;
+    best_LCP_ = Scalar(0);
+    Initialize(P, Q);
+    best_LCP_ = initial_lcp;
     Log<LogLevel::Verbose>("Initial LCP: ", best_LCP_);
   }
 
@@ -229,6 +236,8 @@ class Match4PCSBase {
   bool TryCongruentSet(int base_id1, int base_id2, int base_id3, int base_id4, const std::vector<Quadrilateral>& congruent_quads,
                        const Visitor& v, size_t& nbCongruent) {
     const int32_t ids[4] = {base_id1, base_id2, base_id3, base_id4};
+    // (an empty set -- a hook that answered "found" with nothing in the list: the reference's loop does nothing, :363-497)
+    if (congruent_quads.empty()) { nbCongruent = 0; return best_LCP_ > options_.getTerminateThreshold(); }
     std::vector<int32_t> q(congruent_quads.size() * 4);
     for (size_t i = 0; i < congruent_quads.size(); ++i) for (int k = 0; k < 4; ++k) q[4 * i + size_t(k)] = congruent_quads[i][k];
     s4p_base_result r;

@@ -22,6 +22,7 @@ EXPORTED_SYMBOLS = [
     "s4p_extract_pairs", "s4p_find_congruent", "s4p_try_congruent_set", "s4p_verify_transforms", "s4p_verify_transforms_counted",
     "s4p_transform_points_device", "s4p_apply_bench", "s4p_select_base_points", "s4p_grow_limits", "s4p_get_limits", "s4p_try_base", "s4p_last_verified", "s4p_try_base_async", "s4p_try_base_wait", "s4p_pair_state_words", "s4p_pair_state_save", "s4p_pair_state_restore", "s4p_stage_slots", "s4p_pipeline_depth", "s4p_stage_base", "s4p_try_base_staged_async", "s4p_skip_base", "s4p_last_candidates", "s4p_transform_points", "s4p_profile_enable", "s4p_profile_get",
     "s4p_selftest_ieee", "s4p_set_quad_chunking", "s4p_chunk_stats", "s4p_set_auto_grow", "s4p_lane_growths", "s4p_border_stats", "s4p_set_clouds_timing", "s4p_set_best_hint", "s4p_select_base_points_batch", "s4p_select_batch_max", "s4p_set_quad_slice", "s4p_quad_mix",
+    "s4p_set_candidate_sink", "s4p_keep_candidate_records",
 ]
 
 
@@ -273,6 +274,33 @@ class Context:
         self._chk(self.L.s4p_last_candidates(self.h, _i(quads), _i(counts), cap, C.byref(K)))
         return quads[:K.value].copy(), counts[:K.value].copy()
 
+    def last_verified(self, cap):
+        """(counts[C], transforms[C, 4, 4]) of the last base's verified candidates in reference order."""
+        cap = max(int(cap), 1)
+        counts = np.empty(cap, np.uint32); T = np.empty((cap, 16), np.float32)
+        n = C.c_int64()
+        self.L.s4p_last_verified.restype = C.c_int32
+        self.L.s4p_last_verified.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_float), C.c_int64, C.POINTER(C.c_int64)]
+        self._chk(self.L.s4p_last_verified(self.h, counts.ctypes.data_as(C.POINTER(C.c_uint32)), _f(T), cap, C.byref(n)))
+        return counts[:n.value].copy(), T[:n.value].reshape(-1, 4, 4).copy()
+
+    def keep_candidate_records(self, enable=True):
+        self.L.s4p_keep_candidate_records.restype = C.c_int32
+        self.L.s4p_keep_candidate_records.argtypes = [C.c_void_p, C.c_int32]
+        self._chk(self.L.s4p_keep_candidate_records(self.h, int(enable)))
+
+    def set_candidate_sink(self, fn):
+        """fn(counts: uint32[n], transforms: float32[n, 4, 4]) per device pass, in reference order; None removes the sink."""
+        self.L.s4p_set_candidate_sink.restype = C.c_int32
+        self.L.s4p_set_candidate_sink.argtypes = [C.c_void_p, CANDIDATE_SINK, C.c_void_p]
+        if fn is None:
+            self._sink = C.cast(None, CANDIDATE_SINK)
+        else:
+            def tramp(_u, counts, T, n):
+                fn(np.ctypeslib.as_array(counts, (n,)).copy(), np.ctypeslib.as_array(T, (n * 16,)).reshape(n, 4, 4).copy())
+            self._sink = CANDIDATE_SINK(tramp)
+        self._chk(self.L.s4p_set_candidate_sink(self.h, self._sink, None))
+
     def transform_points(self, M, xyz):
         M = np.ascontiguousarray(M, np.float32).reshape(16)
         x, y, z = _col(xyz, 0).copy(), _col(xyz, 1).copy(), _col(xyz, 2).copy()
@@ -349,6 +377,7 @@ MATCHER_SYMBOLS = [
     "s4p_matcher_global_transform", "s4p_matcher_compute_transformation", "s4p_matcher_advance_trials", "s4p_matcher_set_early_exit", "s4p_matcher_loop_begin", "s4p_matcher_loop_end",
 ]
 VISITOR_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_float, C.c_float, C.POINTER(C.c_float))
+CANDIDATE_SINK = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_float), C.c_int64)
 _MATCHER_DECLARED = False
 
 

@@ -115,6 +115,8 @@ struct s4p_ctx {
     DevBuf<uint32_t> seq[2];          // device copy of a staged sequence blob (layout: StageSlot)
     // launch record of the base in flight: what a relaunch after a buffer growth needs (finish_result)
     int sv_slot = -1; int32_t sv_ids[4] = {0, 0, 0, 0}; float sv_inv1 = 0.f, sv_inv2 = 0.f; float sv_bx[12] = {0}, sv_brgb[12] = {0};
+    uint64_t sv_gen = 0;              // generation of the staging slot when the base was launched (a replay needs the same content)
+    uint32_t sv_nseq1 = 0;            // sequence length of the base's first pair set: its order keys are below 2 * n_q * sv_nseq1
   };
   static constexpr int kMaxLanes = 8;
   Lane lane[kMaxLanes];
@@ -127,6 +129,7 @@ struct s4p_ctx {
     // one blob per pair set, uploaded with a single copy: seq_id[n_seq] | leaf_off[n_leaf + 1] | pad to 16 B | leaves[n_leaf]
     PinBuf<uint32_t> seq[2];
     uint32_t n_seq[2] = {0, 0}, n_leaf[2] = {0, 0};
+    uint64_t gen = 0;                 // bumped whenever the slot is (re)written
     static uint32_t leaf_word(uint32_t n_seq, uint32_t n_leaf) { return (n_seq + n_leaf + 1u + 3u) & ~3u; }
     static size_t blob_words(size_t n_q) { return 2 * n_q + 8 + 4 * n_q; }      // n_leaf <= n_seq <= n_q
     float eps_unit[2] = {0, 0}, n_radius[2] = {0, 0}, distance[2] = {0, 0}, normal_angle[2] = {0, 0};
@@ -159,7 +162,21 @@ struct s4p_ctx {
   float cos_min = -1.f; bool angle_pairs = false; float angle_tol = 1e-6f;   // S4P_ANGLE_TOL (read at creation) widens the device margin: a test aid
   uint64_t border_settled = 0, border_rejected = 0;
   std::vector<uint32_t> border_failed;   // quads of the last pass whose undecided gate the host rejected (per-candidate outputs say -1 for them)
-  bool last_chunked = false;         // the per-candidate records of the last base were overwritten chunk by chunk
+  bool last_chunked = false;         // the last base took several device passes (chunked fused base, sliced s4p_try_congruent_set)
+  // Per-candidate records of such a base.  With keep_records (s4p_keep_candidate_records) or a sink (s4p_set_candidate_sink)
+  // the passes run in REFERENCE ORDER -- chunks are ranges of the set-1 order key, the primary key of the std::set order
+  // (super4pcs.cc:127,166) -- and every pass's records are read back, sorted by tag and appended to `kept` / handed to the
+  // sink, so the reference's per-candidate visitor calls (match4pcsBase.hpp:458-465) and the list-returning debug calls work
+  // at any size.  Without either, s4p_last_candidates / s4p_last_verified replay the base once in that mode.
+  bool keep_records = false;
+  s4p_candidate_sink sink = nullptr; void* sink_user = nullptr;
+  struct Kept {
+    bool valid = false;
+    std::vector<int32_t> quads, qcounts;       // every quad of the base in reference order, -1 = gate failed
+    std::vector<uint32_t> counts; std::vector<float> T16;     // the verified candidates in reference order
+    void clear() { valid = false; quads.clear(); qcounts.clear(); counts.clear(); T16.clear(); }
+  } kept;
+  bool capturing() const { return keep_records || sink != nullptr; }
   bool broken = false;               // a growth failed half-way: the lane buffers are inconsistent, every pass is refused
   uint64_t chunk_bases = 0, chunk_passes = 0, chunk_splits = 0, chunk_quads = 0;
   DevBuf<float> tbuf; size_t tbuf_cap = 0;      // s4p_transform_points: two device + two pinned staging chunks
@@ -239,7 +256,7 @@ void stage_pairs(s4p_ctx* c, int slot, int set, float pair_distance, float pair_
     c->tree.build(c->hux.data(), c->huy.data(), c->huz.data(), c->n_q, nRadius, eps_n, 50);
     c->host_octree_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
   if (!copy) return;
-  st.n_seq[set] = c->tree.n_seq(); st.n_leaf[set] = c->tree.n_leaf();
+  st.n_seq[set] = c->tree.n_seq(); st.n_leaf[set] = c->tree.n_leaf(); st.gen++;
   st.eps_unit[set] = c->tree.eps_unit; st.n_radius[set] = nRadius; st.distance[set] = pair_distance; st.normal_angle[set] = pair_normals_angle;
   static_assert(sizeof(Leaf) == sizeof(float4), "leaf records are uploaded as float4");
   uint32_t* blob = st.seq[set].p;
@@ -385,6 +402,7 @@ int32_t quad_params(s4p_ctx* c, float inv1, float inv2, float thr2, PrepParams& 
   Q.quads = L.quads.p; Q.tags = L.tags.p; Q.K_dev = &L.ctr.p->K; Q.K_cap = uint32_t(L.cap_quads); Q.overflow = &L.ctr.p->overflow;
   Q.r0 = 0u; Q.r1 = 0xFFFFFFFFu; Q.qsum_dev = &L.ctr.p->quad_sum; Q.csum_dev = &L.ctr.p->cand_sum;
   Q.slice_num = 0u; Q.slice_den = 0u;                       // (a share of the set, s4p_set_quad_slice, applies to the fused passes only: launch_base)
+  Q.k1_lo = 0u; Q.k1_hi = 0xFFFFFFFFu; Q.k1_all = 1;
   Q.do_gate = 0;
   return S4P_OK;
 }
@@ -567,6 +585,52 @@ int32_t settle_borderline(s4p_ctx* c, DevCounters& d, const BaseFrame& bf) {
 
 int32_t launch_verify(s4p_ctx* c, const BaseFrame& bf);
 int32_t enqueue_result(s4p_ctx* c, const BaseFrame& bf);
+
+// Records of the device pass that just finished on lane c->cur (d: its counters, after settle_borderline), in reference
+// order: verified candidates (count + row-major 4x4 of the centred frame) -> sink and/or `kept`; with want_quads also every
+// quad with its count (-1 = gate failed) -> `kept` (s4p_last_candidates).  tag_base: added to the pass's tags (slices of a
+// caller's list number their quads from 0).
+int32_t capture_pass(s4p_ctx* c, const DevCounters& d, bool want_quads, bool to_kept) {
+  s4p_ctx::Lane& L = c->lane[c->cur];
+  const uint64_t K = std::min<uint64_t>(d.K, L.cap_quads);
+  const uint32_t Cdev = c->hctr[c->cur].p->C;                // as the device counted them (incl. candidates the host rejected afterwards)
+  if (K == 0) return S4P_OK;
+  std::vector<unsigned long long> t(K); std::vector<uint32_t> cn(K);
+  HIPCHK(c, hipMemcpy(t.data(), L.tags.p, K * 8, hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(cn.data(), L.counts.p, K * 4, hipMemcpyDeviceToHost));
+  if (Cdev) {
+    std::vector<uint32_t> idx(Cdev); std::vector<float4> T(size_t(Cdev) * kCandStride);
+    HIPCHK(c, hipMemcpy(idx.data(), L.cand_idx.p, size_t(Cdev) * 4, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(T.data(), L.cand_T.p, size_t(Cdev) * 16 * kCandStride, hipMemcpyDeviceToHost));
+    std::vector<uint32_t> order; order.reserve(Cdev);
+    for (uint32_t a = 0; a < Cdev; ++a) { idx[a] &= ~kBorderFlag; if (cn[idx[a]] != kGateFailed) order.push_back(a); }
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return t[idx[a]] < t[idx[b]]; });
+    const size_t n = order.size();
+    std::vector<uint32_t> oc(n); std::vector<float> oT(n * 16);
+    for (size_t i = 0; i < n; ++i) {
+      const uint32_t a = order[i];
+      oc[i] = cn[idx[a]];
+      float* o = oT.data() + 16 * i;
+      std::memcpy(o, &T[size_t(a) * kCandStride], 48);
+      o[12] = 0.f; o[13] = 0.f; o[14] = 0.f; o[15] = 1.f;
+    }
+    if (c->sink && n) c->sink(c->sink_user, oc.data(), oT.data(), int64_t(n));
+    if (to_kept) { c->kept.counts.insert(c->kept.counts.end(), oc.begin(), oc.end()); c->kept.T16.insert(c->kept.T16.end(), oT.begin(), oT.end()); }
+  }
+  if (want_quads && to_kept) {
+    std::vector<int4> q(K);
+    HIPCHK(c, hipMemcpy(q.data(), L.quads.p, K * 16, hipMemcpyDeviceToHost));
+    std::vector<uint32_t> order(K);
+    std::iota(order.begin(), order.end(), 0u);
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return t[a] < t[b]; });
+    for (uint64_t i = 0; i < K; ++i) {
+      const int4 v = q[order[i]];
+      c->kept.quads.push_back(v.x); c->kept.quads.push_back(v.y); c->kept.quads.push_back(v.z); c->kept.quads.push_back(v.w);
+      c->kept.qcounts.push_back(cn[order[i]] == kGateFailed ? -1 : int32_t(cn[order[i]]));
+    }
+  }
+  return S4P_OK;
+}
 void launch_quads_kernel(s4p_ctx* c, const QuadParams& Q);
 void launch_gate_kernel(s4p_ctx* c, const GateParams& G);
 GateParams gate_params(s4p_ctx* c, const BaseFrame& bf);
@@ -589,19 +653,27 @@ int32_t run_chunked(s4p_ctx* c, const DevCounters& first, s4p_base_result* r) {
   const uint64_t nch = (Ktot + target - 1) / target;
   // (a share of the set, s4p_set_quad_slice, is a predicate on the pairs' order keys inside k_quads: the ranges cover the
   // whole list on every GPU, and Ktot already counts this GPU's share only)
-  const uint32_t step = uint32_t(std::max<uint64_t>(1, (uint64_t(m2) + nch - 1) / nch));
-  std::vector<std::pair<uint32_t, uint32_t>> todo;
-  for (uint64_t a = 0; a < m2; a += step) todo.emplace_back(uint32_t(a), uint32_t(std::min<uint64_t>(a + step, m2)));
+  // Two ways to cut the base.  Default: ranges of the SECOND pair set's entries (even, cheap: a pass enumerates only its
+  // range).  With a listener for per-candidate records: ranges of the FIRST pair set's order key -- the primary key of the
+  // reference's candidate order, so that pass after pass the records come out in that order; every pass then walks the
+  // whole second set and keeps the quads whose set-1 pair lies in the range (k_quads: k1_lo, k1_hi).
+  const bool ordered = c->capturing();
+  const uint64_t span = ordered ? 2ull * uint64_t(c->n_q) * uint64_t(std::max<uint32_t>(L.sv_nseq1, 1u)) : uint64_t(m2);
+  const uint64_t step = std::max<uint64_t>(1, (span + nch - 1) / nch);
+  std::vector<std::pair<uint64_t, uint64_t>> todo;
+  for (uint64_t a = 0; a < span; a += step) todo.emplace_back(a, std::min<uint64_t>(a + step, span));
   std::reverse(todo.begin(), todo.end());
+  if (ordered) c->kept.clear();
   uint64_t Ksum = 0, Csum = 0, qsum = 0, csum = 0;
   DevCounters best{}; bool have = false;
   c->chunk_bases++; c->chunk_quads += Ktot;
   if (!c->hmm[li].p) HIPCHK(c, c->hmm[li].alloc(2));
   while (!todo.empty()) {
-    const std::pair<uint32_t, uint32_t> rg = todo.back(); todo.pop_back();
+    const std::pair<uint64_t, uint64_t> rg = todo.back(); todo.pop_back();
     c->hmm[li].p[0] = m1; c->hmm[li].p[1] = m2;            // k_verify cleared the live counters: the pair counts come back
     HIPCHK(c, hipMemcpyAsync(&L.ctr.p->m1, c->hmm[li].p, 8, hipMemcpyHostToDevice, L.stream));
-    Q.r0 = rg.first; Q.r1 = rg.second;
+    if (ordered) { Q.r0 = 0u; Q.r1 = 0xFFFFFFFFu; Q.k1_all = 0; Q.k1_lo = uint32_t(rg.first); Q.k1_hi = uint32_t(std::min<uint64_t>(rg.second, 0xFFFFFFFFull)); }
+    else { Q.r0 = uint32_t(rg.first); Q.r1 = uint32_t(rg.second); }
     launch_quads_kernel(c, Q);
     if (!Q.do_gate) launch_gate_kernel(c, gate_params(c, bf));
     HIPCHK(c, hipGetLastError());
@@ -613,14 +685,15 @@ int32_t run_chunked(s4p_ctx* c, const DevCounters& first, s4p_base_result* r) {
     HIPCHK(c, hipEventSynchronize(c->done[li]));
     DevCounters d = *c->hctr[li].p;
     if (d.overflow & 4u) {
-      if (rg.second - rg.first < 2u) S4P_FAIL(c, S4P_ERR_CAPACITY, "one set-2 pair has more congruent quads than max_quads: raise s4p_limits.max_quads");
-      const uint32_t mid = rg.first + (rg.second - rg.first) / 2u;
+      if (rg.second - rg.first < 2u) S4P_FAIL(c, S4P_ERR_CAPACITY, "one pair has more congruent quads than max_quads: raise s4p_limits.max_quads");
+      const uint64_t mid = rg.first + (rg.second - rg.first) / 2u;
       todo.emplace_back(mid, rg.second); todo.emplace_back(rg.first, mid);
       c->chunk_splits++;
       continue;
     }
     if (d.overflow) S4P_FAIL(c, S4P_ERR_STATE, "chunk pass: unexpected overflow bits");
     if (int32_t rc = settle_borderline(c, d, bf)) return rc;
+    if (ordered) if (int32_t rc = capture_pass(c, d, c->keep_records, c->keep_records)) return rc;
     c->chunk_passes++;
     account_profile(c, d, false);
     Ksum += d.K; Csum += d.C; qsum += d.quad_sum; csum += d.cand_sum;
@@ -637,6 +710,7 @@ int32_t run_chunked(s4p_ctx* c, const DevCounters& first, s4p_base_result* r) {
   r->n_pairs1 = m1; r->n_pairs2 = m2; r->n_quads = Ksum; r->n_verified = Csum;
   r->quad_checksum = qsum; r->cand_checksum = csum;
   fill_winner(best, have, bf, r);
+  if (ordered && c->keep_records) c->kept.valid = true;
   c->last_K = 0; c->last_chunked = true;
   c->need_quads = Ktot; c->need_pairs = 0;
   return S4P_OK;
@@ -676,6 +750,7 @@ int32_t finish_result(s4p_ctx* c, s4p_base_result* r, bool fused) {
       r->quad_checksum = d.quad_sum; r->cand_checksum = d.cand_sum;
       fill_winner(d, d.C != 0, bf, r);
       c->last_K = d.K; c->last_chunked = false;
+      if (c->sink && fused) if (int32_t rc = capture_pass(c, d, false, false)) return rc;
       return S4P_OK;
     }
     s4p_ctx::Lane& L = c->lane[li];
@@ -1268,29 +1343,59 @@ int32_t s4p_try_congruent_set(s4p_ctx* c, const int32_t* base_ids, const int32_t
   if (!c || !base_ids || !result) return S4P_ERR_BAD_ARG;
   if (!c->clouds_set) S4P_FAIL(c, S4P_ERR_STATE, "s4p_set_clouds not called");
   for (int i = 0; i < 4; ++i) if (base_ids[i] < 0 || uint32_t(base_ids[i]) >= c->n_p) S4P_FAIL(c, S4P_ERR_BAD_ARG, "base id out of range");
-  if (K < 0 || uint64_t(K) > c->lane[0].cap_quads) S4P_FAIL(c, S4P_ERR_CAPACITY, "more quads than max_quads");
+  if (K < 0) S4P_FAIL(c, S4P_ERR_BAD_ARG, "negative quad count");
   if (K > 0 && !quads) S4P_FAIL(c, S4P_ERR_BAD_ARG, "null quads");
   for (int64_t i = 0; i < 4 * K; ++i) if (quads[i] < 0 || uint32_t(quads[i]) >= c->n_q) S4P_FAIL(c, S4P_ERR_BAD_ARG, "quad index out of range");
   S4P_NEED_IDLE(c);
   HIPCHK(c, hipSetDevice(c->device));
-  if (int32_t rc = reset_counters(c)) return rc;
   const BaseFrame bf = make_base_frame(c, base_ids);
-  std::vector<unsigned long long> tg((size_t)K);
-  std::iota(tg.begin(), tg.end(), 0ull);
-  if (K > 0) {
-    HIPCHK(c, hipMemcpyAsync(c->lane[c->cur].quads.p, quads, size_t(K) * 16, hipMemcpyHostToDevice, c->lane[c->cur].stream));
-    HIPCHK(c, hipMemcpyAsync(c->lane[c->cur].tags.p, tg.data(), size_t(K) * 8, hipMemcpyHostToDevice, c->lane[c->cur].stream));
+  s4p_ctx::Lane& L = c->lane[c->cur];
+  // The caller's list may be longer than the lane's quad buffers (the reference's std::vector has no such limit,
+  // match4pcsBase.hpp:340-351): it is scored in slices, each slice's best folded with the rule of the single pass
+  // (greatest count, then smallest position in the list), the per-candidate records kept on the host if somebody listens.
+  const uint64_t cap = std::max<uint64_t>(L.cap_quads, 1);
+  const bool sliced = uint64_t(K) > cap;
+  if (sliced || c->capturing()) c->kept.clear();
+  DevCounters best{}; bool have = false;
+  uint64_t Csum = 0, csum = 0;
+  for (uint64_t off = 0; off == 0 || off < uint64_t(K); off += cap) {
+    const uint64_t n = std::min<uint64_t>(cap, uint64_t(K) - off);
+    if (int32_t rc = reset_counters(c)) return rc;
+    std::vector<unsigned long long> tg((size_t)n);
+    std::iota(tg.begin(), tg.end(), (unsigned long long)off);
+    if (n > 0) {
+      HIPCHK(c, hipMemcpyAsync(L.quads.p, quads + 4 * off, size_t(n) * 16, hipMemcpyHostToDevice, L.stream));
+      HIPCHK(c, hipMemcpyAsync(L.tags.p, tg.data(), size_t(n) * 8, hipMemcpyHostToDevice, L.stream));
+    }
+    const unsigned long long k64 = (unsigned long long)n;
+    HIPCHK(c, hipMemcpyAsync(&L.ctr.p->K, &k64, 8, hipMemcpyHostToDevice, L.stream));
+    launch_gate_kernel(c, gate_params(c, bf));
+    if (int32_t rc = launch_verify(c, bf)) return rc;
+    s4p_base_result part;
+    if (int32_t rc = fetch_result(c, bf, &part)) return rc;        // (waits: tg may go out of scope)
+    if (per_candidate && n > 0) {
+      std::vector<uint32_t> cnt((size_t)n);
+      HIPCHK(c, hipMemcpy(cnt.data(), L.counts.p, size_t(n) * 4, hipMemcpyDeviceToHost));
+      for (uint64_t i = 0; i < n; ++i) per_candidate[off + i] = cnt[i] == kGateFailed ? -1 : int32_t(cnt[i]);
+    }
+    if (sliced || c->capturing()) {
+      DevCounters d = *c->hctr[c->cur].p;
+      d.C = uint32_t(part.n_verified);
+      if (int32_t rc = capture_pass(c, d, true, true)) return rc;
+    }
+    Csum += part.n_verified; csum += part.cand_checksum;
+    if (!sliced) { *result = part; if (c->capturing()) { c->kept.valid = true; c->last_chunked = true; } return S4P_OK; }
+    if (part.has_best && (!have || part.best_count > best.best_count || (part.best_count == best.best_count && part.best_rank < best.best_tag))) {
+      have = true; best.best_count = part.best_count; best.best_tag = part.best_rank;
+      for (int i = 0; i < 4; ++i) best.best_quad[i] = part.best_quad[i];
+      for (int i = 0; i < 16; ++i) best.best_T[i] = part.best_transform[i];
+      for (int i = 0; i < 3; ++i) best.best_c2[i] = part.best_centroid2[i];
+    }
   }
-  const unsigned long long k64 = (unsigned long long)K;
-  HIPCHK(c, hipMemcpyAsync(&c->lane[c->cur].ctr.p->K, &k64, 8, hipMemcpyHostToDevice, c->lane[c->cur].stream));
-  launch_gate_kernel(c, gate_params(c, bf));
-  if (int32_t rc = launch_verify(c, bf)) return rc;
-  if (int32_t rc = fetch_result(c, bf, result)) return rc;
-  if (per_candidate && K > 0) {
-    std::vector<uint32_t> cnt((size_t)K);
-    HIPCHK(c, hipMemcpy(cnt.data(), c->lane[c->cur].counts.p, size_t(K) * 4, hipMemcpyDeviceToHost));
-    for (int64_t i = 0; i < K; ++i) per_candidate[i] = cnt[i] == kGateFailed ? -1 : int32_t(cnt[i]);
-  }
+  std::memset(result, 0, sizeof(*result));
+  result->n_quads = uint64_t(K); result->n_verified = Csum; result->cand_checksum = csum;
+  fill_winner(best, have, bf, result);
+  c->kept.valid = true; c->last_chunked = true; c->last_K = 0;
   return S4P_OK;
 }
 
@@ -1369,7 +1474,7 @@ int32_t s4p_try_base_staged_async(s4p_ctx* c, int32_t slot, const int32_t* base_
   HIPCHK(c, hipSetDevice(c->device));
   c->cur = int(c->q_tail % uint32_t(c->n_lanes));
   s4p_ctx::Lane& L = c->lane[c->cur];
-  L.sv_slot = slot; L.sv_inv1 = inv1; L.sv_inv2 = inv2;
+  L.sv_slot = slot; L.sv_inv1 = inv1; L.sv_inv2 = inv2; L.sv_gen = c->stage[slot].gen; L.sv_nseq1 = c->stage[slot].n_seq[0];
   for (int i = 0; i < 4; ++i) L.sv_ids[i] = base_ids[i];
   std::memcpy(L.sv_bx, c->base_xyz, sizeof L.sv_bx); std::memcpy(L.sv_brgb, c->base_rgb, sizeof L.sv_brgb);
   if (int32_t rc = launch_base(c, slot, base_ids, inv1, inv2)) return rc;
@@ -1421,9 +1526,49 @@ int32_t s4p_skip_base(s4p_ctx* c) {
   return s4p_stage_base(c, c->base_xyz, c->base_nrm, 0, 0);
 }
 
+namespace {
+// The last base took several device passes and nobody kept its records: run it once more in reference-ordered chunks with the
+// records kept.  Possible while the base's launch record is intact (its staging slot has not been rewritten).
+int32_t replay_for_records(s4p_ctx* c) {
+  if (c->kept.valid) return S4P_OK;
+  s4p_ctx::Lane& L = c->lane[c->cur];
+  if (L.sv_slot < 0 || c->stage[L.sv_slot].gen != L.sv_gen)
+    S4P_FAIL(c, S4P_ERR_STATE, "the per-candidate records of a base processed in chunks were not kept and the base can no longer be replayed: "
+                               "call s4p_keep_candidate_records(ctx, 1) (or set a sink) before the base");
+  const bool keep = c->keep_records;
+  c->keep_records = true;
+  s4p_base_result again;
+  int32_t rc = relaunch_base(c);
+  if (rc == S4P_OK) rc = finish_result(c, &again, true);
+  c->keep_records = keep;
+  return rc;
+}
+}  // namespace
+
+int32_t s4p_keep_candidate_records(s4p_ctx* c, int32_t enable) {
+  if (!c) return S4P_ERR_BAD_ARG;
+  c->keep_records = enable != 0;
+  return S4P_OK;
+}
+int32_t s4p_set_candidate_sink(s4p_ctx* c, s4p_candidate_sink sink, void* user) {
+  if (!c) return S4P_ERR_BAD_ARG;
+  c->sink = sink; c->sink_user = user;
+  return S4P_OK;
+}
+
 int32_t s4p_last_candidates(s4p_ctx* c, int32_t* quads, int32_t* counts, int64_t cap, int64_t* n_out) {
   if (!c || !n_out) return S4P_ERR_BAD_ARG;
-  if (c->last_chunked) S4P_FAIL(c, S4P_ERR_UNSUPPORTED, "the last base was processed in chunks: its per-candidate records were not kept");
+  if (c->last_chunked) {
+    HIPCHK(c, hipSetDevice(c->device));
+    if (int32_t rc = replay_for_records(c)) return rc;
+    const int64_t K = int64_t(c->kept.qcounts.size());
+    *n_out = K;
+    if (K == 0) return S4P_OK;
+    if (cap < K || !quads || !counts) S4P_FAIL(c, S4P_ERR_CAPACITY, "s4p_last_candidates: output buffer too small");
+    std::memcpy(quads, c->kept.quads.data(), size_t(K) * 16);
+    std::memcpy(counts, c->kept.qcounts.data(), size_t(K) * 4);
+    return S4P_OK;
+  }
   const uint64_t K = c->last_K;
   *n_out = int64_t(K);
   if (K == 0) return S4P_OK;
@@ -1448,8 +1593,17 @@ int32_t s4p_last_candidates(s4p_ctx* c, int32_t* quads, int32_t* counts, int64_t
 // inlier count and the 3x4 transform each was scored with (cand_T, kept in HBM by k_gate).
 int32_t s4p_last_verified(s4p_ctx* c, uint32_t* counts, float* transforms16, int64_t cap, int64_t* n_out) {
   if (!c || !n_out) return S4P_ERR_BAD_ARG;
-  if (c->last_chunked) S4P_FAIL(c, S4P_ERR_UNSUPPORTED, "the last base was processed in chunks: its per-candidate records were not kept");
   HIPCHK(c, hipSetDevice(c->device));
+  if (c->last_chunked) {
+    if (int32_t rc = replay_for_records(c)) return rc;
+    const int64_t C = int64_t(c->kept.counts.size());
+    *n_out = C;
+    if (C == 0) return S4P_OK;
+    if (cap < C || !counts || !transforms16) S4P_FAIL(c, S4P_ERR_CAPACITY, "s4p_last_verified: output buffer too small");
+    std::memcpy(counts, c->kept.counts.data(), size_t(C) * 4);
+    std::memcpy(transforms16, c->kept.T16.data(), size_t(C) * 64);
+    return S4P_OK;
+  }
   const s4p_ctx::Lane& L = c->lane[c->cur];
   const uint32_t Cdev = c->hctr[c->cur].p->C;               // as the device counted them (incl. candidates the host rejected afterwards)
   *n_out = 0;

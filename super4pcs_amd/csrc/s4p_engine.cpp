@@ -1111,6 +1111,27 @@ static void rewind_speculation(s4p_matcher* m) {
   fifo.clear();
 }
 
+// The reference's per-candidate visitor call v(-1, lcp, T) (match4pcsBase.hpp:458-465) as a candidate sink of the context: the
+// verified candidates of a base arrive in reference order, pass by pass for a base that takes several (s4p_capi.h).
+namespace {
+struct CandidateVisit { s4p_matcher* m; s4p_visitor_fn visitor; void* user; int32_t needs_global; };
+void candidate_sink(void* u, const uint32_t* counts, const float* transforms16, int64_t n) {
+  const CandidateVisit& cv = *static_cast<const CandidateVisit*>(u);
+  const s4p_matcher* m = cv.m;
+  for (int64_t k = 0; k < n; ++k) {
+    float T[16];
+    std::memcpy(T, transforms16 + 16 * size_t(k), sizeof T);
+    if (cv.needs_global) {      // getGlobalTransform of :446-456: t_global = t + centroid_P - R * centroid_Q
+      for (int a = 0; a < 3; ++a) {
+        const float rq = T[4 * a] * m->centroid_q[0] + (T[4 * a + 1] * m->centroid_q[1] + T[4 * a + 2] * m->centroid_q[2]);
+        T[4 * a + 3] = (T[4 * a + 3] + m->centroid_p[a]) - rq;
+      }
+    }
+    cv.visitor(cv.user, -1.f, float(counts[size_t(k)]) / float(m->Qs.size()), T);
+  }
+}
+}  // namespace
+
 int32_t s4p_matcher_perform_n_steps(s4p_matcher* m, int32_t n, s4p_visitor_fn visitor, void* user, int32_t needs_global,
                                     float* transformation, int32_t* improved, int32_t* done) {
   if (!m || !transformation || !improved || !done) return S4P_ERR_BAD_ARG;
@@ -1145,25 +1166,15 @@ int32_t s4p_matcher_perform_n_steps(s4p_matcher* m, int32_t n, s4p_visitor_fn vi
     s4p_matcher::Prepared pr = std::move(fifo.front());
     fifo.erase(fifo.begin());
     s4p_base_result r;
+    // match4pcsBase.hpp:458-465: the per-candidate calls of this base are made from inside the wait (the sink is set for this
+    // wait only: bases that are drained when the loop stops must not produce calls the sequential loop never made)
+    CandidateVisit cv{m, visitor, user, needs_global};
+    const bool listen = visitor && m->visit_candidates && pr.device;
+    if (listen) (void)s4p_set_candidate_sink(m->ctx, candidate_sink, &cv);
     rc = wait_base(m, pr, r);
+    if (listen) (void)s4p_set_candidate_sink(m->ctx, nullptr, nullptr);
     if (rc != S4P_OK) break;
     if (trace_call && !seen_res) { tc_first_res = hclock::now(); seen_res = true; }
-    // (a base whose quads were processed in chunks keeps no per-candidate records: s4p_last_verified then fails loudly)
-    if (visitor && m->visit_candidates && pr.device && r.n_verified) {     // match4pcsBase.hpp:458-465
-      std::vector<uint32_t> cnt(size_t(r.n_verified)); std::vector<float> Ts(size_t(r.n_verified) * 16);
-      int64_t nv = 0;
-      if (int32_t vrc = s4p_last_verified(m->ctx, cnt.data(), Ts.data(), int64_t(r.n_verified), &nv)) { rc = m->ctx_fail(vrc); break; }
-      for (int64_t k = 0; k < nv; ++k) {
-        float* T = Ts.data() + 16 * size_t(k);
-        if (needs_global) {      // getGlobalTransform of :446-456: t_global = t + centroid_P - R * centroid_Q
-          for (int a = 0; a < 3; ++a) {
-            const float rq = T[4 * a] * m->centroid_q[0] + (T[4 * a + 1] * m->centroid_q[1] + T[4 * a + 2] * m->centroid_q[2]);
-            T[4 * a + 3] = (T[4 * a + 3] + m->centroid_p[a]) - rq;
-          }
-        }
-        visitor(user, -1.f, float(cnt[size_t(k)]) / float(m->Qs.size()), T);
-      }
-    }
     ok = commit_base(m, pr.found, pr.ids, r);
     const float fraction_try = float(i) / float(m->number_of_trials);
     // integer seconds / integer max_time_seconds: reference quirk, :240-243

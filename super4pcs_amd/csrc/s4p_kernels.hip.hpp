@@ -928,31 +928,47 @@ __device__ __forceinline__ uint32_t wave_lcp_count_lean(const LcpGrid& g, const 
   typedef const __attribute__((address_space(3))) uint32_t* lds_u32_ptr;
   const uint32_t coarse_base = uint32_t(uintptr_t((lds_u32_ptr)L.coarse));      // byte address of the bitmap inside LDS (0 in k_verify)
   auto lds_fence = [&]() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); };
-  // reach test of the L0 survivors [nb, nb + na), the survivors compacted in place onto [0, nb)
-  auto drain = [&]() {
+  // Reach test of the L0 survivors [nb, nb + na), the survivors compacted in place onto [0, nb).  The reach word is the one
+  // global access of the lean path, a dependent ~1 us round trip: kSweepChunks batches of 64 entries are located and gathered
+  // TOGETHER (one exposure per 256 entries instead of four), and after every round the bound is applied to "survivors so far
+  // + entries not tested yet (+ rest: queries not swept yet)" -- a candidate whose L0 survivors exceeded the bound is usually
+  // dismissed before all of them have been tested (measured on the bench workload: one candidate in five reaches this point and
+  // its serial 64-entry batches were ~40 % of the kernel's wave time).  Returns true if the candidate is dismissed.
+  auto drain = [&](const uint32_t rest) -> bool {
     lds_fence();
     float T[12]; load_rows(Tsrc, T);
     const GridXf X = make_grid_xf(g, T, 1.f);
     uint32_t rd = nb;
     const uint32_t end = nb + na;
+    bool dead = false;
     while (rd < end) {                                     // wave-uniform
-      const uint32_t n = min(end - rd, 64u);
-      const uint32_t i = uint32_t(q[rd + min(lane, n - 1u)]);
-      lds_fence();                                         // every lane holds its entry before any slot of this batch is rewritten
-      int ix, iy, iz;
-      grid_cell(X.u, make_float4(L.qx[i], L.qy[i], L.qz[i], 0.f), ix, iy, iz);
-      const bool inb = (lane < n) & (uint32_t(ix) < uint32_t(g.nx)) & (uint32_t(iy) < uint32_t(g.ny)) & (uint32_t(iz) < uint32_t(g.nz));
-      const uint32_t c = mad24(mad24(uint32_t(iz), uint32_t(g.ny), uint32_t(iy)), uint32_t(g.nx), uint32_t(ix));
-      const uint2 w = g.reach[inb ? c >> 5 : 0u];
-      const bool reach = inb & (((w.x >> (c & 31u)) & 1u) != 0u);
-      const unsigned long long m = __builtin_amdgcn_ballot_w64(reach);
-      if (reach) q[__builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), nb))] = uint16_t(i);   // nb <= rd: stays below rd + n
-      nb += uint32_t(__popcll(m));
-      rd += n;
+      uint32_t ii[kSweepChunks], cc[kSweepChunks]; bool vv[kSweepChunks]; uint2 ww[kSweepChunks];
+#pragma unroll
+      for (uint32_t k = 0; k < kSweepChunks; ++k) { const uint32_t at = rd + 64u * k + lane; vv[k] = at < end; ii[k] = uint32_t(q[min(at, end - 1u)]); }
+      lds_fence();                                         // every lane holds its entries before any slot of this round is rewritten
+#pragma unroll
+      for (uint32_t k = 0; k < kSweepChunks; ++k) {
+        int ix, iy, iz;
+        grid_cell(X.u, make_float4(L.qx[ii[k]], L.qy[ii[k]], L.qz[ii[k]], 0.f), ix, iy, iz);
+        vv[k] = vv[k] & (uint32_t(ix) < uint32_t(g.nx)) & (uint32_t(iy) < uint32_t(g.ny)) & (uint32_t(iz) < uint32_t(g.nz));
+        cc[k] = mad24(mad24(uint32_t(iz), uint32_t(g.ny), uint32_t(iy)), uint32_t(g.nx), uint32_t(ix));
+        ww[k] = g.reach[vv[k] ? cc[k] >> 5 : 0u];
+      }
+      const uint32_t n_round = min(end - rd, kSweepStep);
+#pragma unroll
+      for (uint32_t k = 0; k < kSweepChunks; ++k) {
+        const bool reach = vv[k] & (((ww[k].x >> (cc[k] & 31u)) & 1u) != 0u);
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(reach);
+        if (reach) q[__builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), nb))] = uint16_t(ii[k]);   // nb <= rd: below the entries read
+        nb += uint32_t(__popcll(m));
+      }
+      if (COUNT) { if (lane == 0) atomicAdd(K.point_tests + 1, (unsigned long long)n_round); }      // reach words gathered (l0_pass)
+      rd += n_round;
       lds_fence();
+      if (cnt + nb + (end - rd) + rest <= K.prune) { dead = true; break; }
     }
-    if (COUNT) { if (lane == 0) atomicAdd(K.point_tests + 1, (unsigned long long)na); }      // reach words gathered (l0_pass)
     na = 0u;
+    return dead;
   };
   const uint32_t n_pad = (K.n_q + kSweepStep - 1u) & ~(kSweepStep - 1u);
   bool abandoned = false;
@@ -1004,9 +1020,8 @@ __device__ __forceinline__ uint32_t wave_lcp_count_lean(const LcpGrid& g, const 
       if (cnt + nb + na + unswept <= K.prune) { abandoned = true; break; }
     }
     if (!more || nb + na + kSweepStep > kLeanQueue) {
-      drain();
       const uint32_t rest = more ? unswept : 0u;
-      if (cnt + nb + rest <= K.prune) { abandoned = true; break; }
+      if (drain(rest)) { abandoned = true; break; }
       while ((more && nb + 2u * kSweepStep > kLeanQueue) || (!more && nb != 0u)) {
         if (cnt + nb + rest <= K.prune) { abandoned = true; break; }
         const uint32_t n = min(nb, 128u);
@@ -1823,6 +1838,8 @@ struct QuadParams {
   int4* quads; unsigned long long* tags; unsigned long long* K_dev; uint32_t K_cap; uint32_t* overflow;
   uint32_t r0, r1;                                       // set-2 entries [r0, min(r1, m2)): the whole set, or one chunk of a base whose quads do not fit
   uint32_t slice_num, slice_den;                         // slice_den != 0: only the pairs whose order key = slice_num mod slice_den (one GPU's share of a base)
+  uint32_t k1_lo, k1_hi;                                 // only set-1 pairs with order key in [k1_lo, k1_hi): a chunk of a base in REFERENCE order (whole base: 0, 2^32 - 1 with k1_all)
+  int k1_all;                                            // 1: no filter on the set-1 order key (the default; saves its gather per hop)
   unsigned long long* qsum_dev; unsigned long long* csum_dev;   // checksums (DevCounters::quad_sum / cand_sum)
   int do_gate; GateParams gate;                          // fused path: gate every quad as it is appended
 };
@@ -1918,7 +1935,8 @@ __global__ __launch_bounds__(256) void k_quads(QuadParams P) {
         const float4 ep = P.ew1[e];
         const uint32_t nxt = P.next1[e];
         const float dx = eq.x - ep.x, dy = eq.y - ep.y, dz = eq.z - ep.z;
-        if (((row[b >> 5] >> (b & 31u)) & 1u) && sqn3(dx, dy, dz) <= P.thr) {       // super4pcs.cc:160
+        if (((row[b >> 5] >> (b & 31u)) & 1u) && sqn3(dx, dy, dz) <= P.thr &&       // super4pcs.cc:160
+            (P.k1_all || (P.okey1[e] >= P.k1_lo && P.okey1[e] < P.k1_hi))) {
           const int2 ab1 = P.ab1[e];
           const int4 quad = make_int4(ab1.x, ab1.y, ab2.x, ab2.y);                 // :171-172
           const unsigned long long tag = ((unsigned long long)P.okey1[e] << 32) | ok2;

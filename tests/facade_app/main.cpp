@@ -61,6 +61,25 @@ class FilteringMatcher : public MatchSuper4PCS {
   }
 };
 
+// A subclass that overrides the third plugin point, Initialize (match4pcsBase.h:262-272): the reference calls it from init()
+// once per ComputeTransformation, with the caller's clouds, after the sampled clouds exist and before the initial LCP is
+// assigned (match4pcsBase.hpp:197-200).  It keeps the stock pair / quad hooks, and says so, so the fused loop still runs.
+class InitCountingMatcher : public MatchSuper4PCS {
+ public:
+  using MatchSuper4PCS::MatchSuper4PCS;
+  int init_calls = 0;
+  size_t seen_p = 0, seen_q = 0, sampled_p_at_call = 0, sampled_q_at_call = 0;
+  float lcp_at_call = -1.f;
+ protected:
+  void Initialize(const std::vector<Point3D>& P, const std::vector<Point3D>& Q) override {
+    ++init_calls; seen_p = P.size(); seen_q = Q.size();
+    sampled_p_at_call = sampled_P_3D_.size(); sampled_q_at_call = sampled_Q_3D_.size();
+    lcp_at_call = best_LCP_;
+    MatchSuper4PCS::Initialize(P, Q);
+  }
+  bool uses_stock_hooks() const override { return true; }
+};
+
 static bool same_matrix(const Match4PCSBase::MatrixType& a, const Match4PCSBase::MatrixType& b) {
   for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) if (!(a(r, c) == b(r, c))) return false;
   return true;
@@ -119,6 +138,21 @@ int main(int argc, char** argv) {
       if (fm.extract_calls < 2 || fm.extract_calls % 2 != 0) return 10;          // two calls per trial (match4pcsBase.hpp:328-331)
       if (!(fm.pairs_kept < fm.pairs_found) || fm.find_calls < 1) return 11;
       if (fm.pairs_seen_by_find > fm.pairs_kept) return 12;                       // FindCongruentQuadrilaterals got the FILTERED lists
+    }
+    // the Initialize plugin point: called exactly once per ComputeTransformation, at the point the reference calls it
+    {
+      InitCountingMatcher im(opt, logger);
+      Match4PCSBase::MatrixType mat_i = Match4PCSBase::MatrixType::Identity();
+      std::vector<Point3D> Q5 = Q;
+      const float score_i = im.ComputeTransformation(P, &Q5, mat_i);
+      std::printf("Initialize hook: %d call(s), saw %zu / %zu points, %zu / %zu sampled, best_LCP_ %.3f at the call; score %.4f\n",
+                  im.init_calls, im.seen_p, im.seen_q, im.sampled_p_at_call, im.sampled_q_at_call, im.lcp_at_call, score_i);
+      if (im.init_calls != 1 || im.seen_p != P.size() || im.seen_q != Q.size()) return 13;
+      if (im.sampled_p_at_call == 0 || im.sampled_q_at_call == 0 || im.lcp_at_call != 0.f) return 14;
+      if (score_i != score || !same_matrix(mat, mat_i)) return 15;                 // same registration as the stock class
+      std::vector<Point3D> Q6 = Q;
+      (void)im.ComputeTransformation(P, &Q6, mat_i);
+      if (im.init_calls != 2) return 16;
     }
     // empty sets (tests/externalAppTest/main.cpp): kLargeNumber
     std::vector<Point3D> e1, e2;

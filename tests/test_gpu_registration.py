@@ -318,14 +318,19 @@ def test_config1_hippo_pair_matches_reference_run(s4p_lib_built):
     assert np.array_equal(M[:3, :3], g["M"][:3, :3]) and np.max(np.abs(M - g["M"])) <= 1e-4
 
 
-def test_per_candidate_visitor_calls(oracle_mod, s4p_lib_built):
-    """match4pcsBase.hpp:458-465: the visitor sees every verified candidate (fraction == -1) in candidate order."""
+@pytest.mark.parametrize("chunked", [False, True])
+def test_per_candidate_visitor_calls(oracle_mod, s4p_lib_built, chunked):
+    """match4pcsBase.hpp:458-465: the visitor sees every verified candidate (fraction == -1) in candidate order -- also when a
+    base takes several device passes (quad buffers of 1500 entries that may not grow: the passes are then cut along the
+    set-1 order key, so the records come out in reference order chunk by chunk)."""
     from super4pcs_amd import capi
     O = oracle_mod
     delta, overlap, n_s = 0.01, 0.6, 200
     P, Q, _ = H.small_pair(20000, delta=delta, seed=31)
     om = H.init_oracle(O, P, Q, delta, overlap, n_s)          # full counts
-    gm = capi.Matcher(capi.make_options(delta, overlap, n_s))
+    gm = capi.Matcher(capi.make_options(delta, overlap, n_s), **({"max_quads": 1500} if chunked else {}))
+    if chunked:
+        gm.set_quad_chunking(True, 1500)
     gm.init_full(P, Q)
     gm.visit_candidates(True)
     seen, per_trial = [], []
@@ -357,6 +362,71 @@ def test_per_candidate_visitor_calls(oracle_mod, s4p_lib_built):
     assert len(per_trial) == n_trials + 1                      # v(0, ...) once, then once per trial
     for (gl, gT), (wl, wT) in zip(seen, want):
         assert gl == wl and np.array_equal(gT, wT)
+    if chunked:
+        st = gm.chunk_stats()
+        assert st["bases"] >= 3 and st["passes"] >= 2 * st["bases"]
+
+
+def test_records_of_a_multi_pass_base_through_the_stage_calls(oracle_mod, s4p_lib_built):
+    """s4p_last_candidates / s4p_last_verified after a base that was processed in chunks (replayed once in reference-ordered
+    chunks when nobody asked for the records beforehand, kept on the fly with s4p_keep_candidate_records), and
+    s4p_try_congruent_set with more quads than the lane's buffers hold (scored in slices): the reference's std::vectors simply
+    grow (super4pcs.cc:166-174, match4pcsBase.hpp:340-351, :458-465), so none of these may refuse."""
+    from super4pcs_amd import capi
+    O = oracle_mod
+    delta, overlap, n_s = 0.01, 0.6, 300
+    P, Q, _ = H.small_pair(25000, delta=delta, seed=17)
+    m = H.init_oracle(O, P, Q, delta, overlap, n_s)
+    big = capi.Context(capi.make_options(delta, overlap, n_s))
+    small = capi.Context(capi.make_options(delta, overlap, n_s), max_quads=2000)
+    small.set_quad_chunking(True, 2000)
+    kept = capi.Context(capi.make_options(delta, overlap, n_s), max_quads=2000)
+    kept.set_quad_chunking(True, 2000)
+    kept.keep_candidate_records(True)
+    sunk = capi.Context(capi.make_options(delta, overlap, n_s), max_quads=2000)
+    sunk.set_quad_chunking(True, 2000)
+    for c in (big, small, kept, sunk):
+        c.set_clouds(m.cloud(0), m.cloud(1))
+    checked = 0
+    for t in range(10):
+        ok, i1, i2, base, bx = m.select_quadrilateral()
+        if not ok:
+            continue
+        eps = 2.0 * delta
+        d1 = float(np.float32(np.linalg.norm(bx[0] - bx[1]))); d2 = float(np.float32(np.linalg.norm(bx[2] - bx[3])))
+        p1 = m.extract_pairs(d1, 0.0, eps, 0, 1); p2 = m.extract_pairs(d2, 0.0, eps, 2, 3)
+        got = []
+        sunk.set_candidate_sink(lambda cnt, T: got.append((cnt, T)))
+        res = []
+        for c in (big, small, kept, sunk):
+            c.set_base(bx)
+            res.append(c.try_base(base, i1, i2))
+        sunk.set_candidate_sink(None)
+        rb, rs, rk, rn = res
+        for r in (rs, rk, rn):
+            assert (r.n_quads, r.n_verified, r.quad_checksum, r.cand_checksum) == (rb.n_quads, rb.n_verified, rb.quad_checksum, rb.cand_checksum)
+            assert (r.has_best, r.best_count, list(r.best_quad)) == (rb.has_best, rb.best_count, list(rb.best_quad))
+        if rb.n_quads <= 2000:
+            continue
+        checked += 1
+        bq, bc = big.last_candidates(rb.n_quads)
+        bv, bT = big.last_verified(max(rb.n_verified, 1))
+        for c in (small, kept):                                  # replay / kept on the fly
+            q_, c_ = c.last_candidates(rb.n_quads)
+            assert np.array_equal(q_, bq) and np.array_equal(c_, bc)
+            v_, T_ = c.last_verified(max(rb.n_verified, 1))
+            assert np.array_equal(v_, bv) and np.array_equal(T_, bT)
+        assert len(got) >= 2                                     # the sink saw the base pass by pass, in reference order
+        assert np.array_equal(np.concatenate([g[0] for g in got]), bv) and np.array_equal(np.concatenate([g[1] for g in got]), bT)
+        # a caller's quad list longer than the buffers: slices
+        rr_b, per_b = big.try_congruent_set(base, bq)
+        rr_s, per_s = small.try_congruent_set(base, bq)
+        assert np.array_equal(per_b, per_s) and np.array_equal(per_b, bc)
+        assert (rr_s.n_verified, rr_s.best_count, list(rr_s.best_quad)) == (rr_b.n_verified, rr_b.best_count, list(rr_b.best_quad))
+        assert np.array_equal(np.frombuffer(bytes(rr_s.best_transform), np.float32), np.frombuffer(bytes(rr_b.best_transform), np.float32))
+        v2, T2 = small.last_verified(max(rb.n_verified, 1))
+        assert np.array_equal(v2, bv) and np.array_equal(T2, bT)
+    assert checked >= 2
 
 
 @pytest.mark.parametrize("producer", [False, True])
