@@ -253,6 +253,24 @@ class Matcher:
         return {"K": int(out[0]), "quad_sum": int(out[1]), "C": int(out[2]), "cand_sum": int(out[3]),
                 "sample": None if smp is None else smp[:ns.value].copy()}
 
+    def count_congruent_best(self, inv1, inv2, thr, pairs1, pairs2, base, threads=0):
+        """count_congruent + the winner TryCongruentSet would keep (every gated candidate verified in full): adds
+        found, best_count, best_quad (first maximum in the reference's candidate order)."""
+        p1 = np.ascontiguousarray(pairs1, np.int32); p2 = np.ascontiguousarray(pairs2, np.int32)
+        out = (C.c_uint64 * 4)(); best = (C.c_uint64 * 4)()
+        b = np.ascontiguousarray(base, np.int32)
+        self.L.s4po_count_congruent_best.restype = None
+        self.L.s4po_count_congruent_best.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_int32), C.c_int64,
+                                                     C.POINTER(C.c_int32), C.c_int64, C.POINTER(C.c_int32), C.c_int32,
+                                                     C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        self.L.s4po_count_congruent_best(self.h, inv1, inv2, thr, _i(p1), p1.shape[0], _i(p2), p2.shape[0], _i(b),
+                                         int(threads) or (os.cpu_count() or 1), out, best)
+        quad = None
+        if best[0]:
+            quad = [int(p1[best[2], 0]), int(p1[best[2], 1]), int(p2[best[3], 0]), int(p2[best[3], 1])]
+        return {"K": int(out[0]), "quad_sum": int(out[1]), "C": int(out[2]), "cand_sum": int(out[3]),
+                "found": bool(best[0]), "best_count": int(best[1]), "best_quad": quad}
+
     def try_congruent_set(self, base, quads):
         base = np.ascontiguousarray(base, np.int32); quads = np.ascontiguousarray(quads, np.int32)
         K = quads.shape[0]

@@ -818,7 +818,8 @@ struct Matcher {
   void count_congruent(float invariant1, float invariant2, float distance_threshold2,
                        const std::vector<std::pair<int, int>>& P_pairs, const std::vector<std::pair<int, int>>& Q_pairs,
                        const int* base /* 4 sampled-P ids or nullptr */, int threads, uint64_t out[4],
-                       uint64_t sample_mod, std::vector<std::array<int, 4>>* sample) const {
+                       uint64_t sample_mod, std::vector<std::array<int, 4>>* sample,
+                       uint64_t* best7 = nullptr /* {found, max inlier count, id (set-1 pair), i (set-2 pair), then the quad is id/i's} */) const {
     float s01[3], s23[3];
     sub3(base3D[1].pos, base3D[0].pos, s01); normalize3(s01);
     sub3(base3D[3].pos, base3D[2].pos, s23); normalize3(s23);
@@ -857,10 +858,14 @@ struct Matcher {
     const float max_angle_rad = float(double(opt.max_angle) * pi / 180.0);
     uint64_t K = 0, ksum = 0, C = 0, csum = 0;
     std::vector<std::array<int, 4>> picked;
+    // (best7) the winner TryCongruentSet would keep: every gated candidate verified in full, greatest inlier count, then the
+    // smallest (id, i) = the first such candidate in the std::set order of super4pcs.cc:127,166 (match4pcsBase.hpp:467-484)
+    bool w_found = false; unsigned w_count = 0; uint64_t w_key = ~0ull;
     auto lower = [&](uint64_t key) { return std::lower_bound(keyed.begin(), keyed.end(), std::make_pair(key, 0u)); };
 #pragma omp parallel num_threads(threads) reduction(+ : K, ksum, C, csum)
     {
       std::vector<std::array<int, 4>> mine;
+      bool t_found = false; unsigned t_count = 0; uint64_t t_key = ~0ull;
 #pragma omp for schedule(dynamic, 256)
       for (long long i = 0; i < (long long)Q_pairs.size(); ++i) {                  // :132-164
         const float* p1 = upts[Q_pairs[i].first].data();
@@ -903,12 +908,24 @@ struct Matcher {
           if (ok && rms >= 0.f && rms < 2.0f * opt.delta) {
             ++C; csum += mix;
             if (sample && sample_mod && mix % sample_mod == 0) mine.push_back({a, b, cq, dq});
+            if (best7) {
+              unsigned good = 0; uint64_t nq_ = 0;
+              const float* Tc = T;
+              // full count (no early exit): verify_against with a best of 0 never leaves early
+              (void)verify_against(Tc, 0.f, &good, &nq_);
+              const uint64_t key = (uint64_t(unsigned(id)) << 32) | uint64_t(unsigned(i));
+              if (!t_found || good > t_count || (good == t_count && key < t_key)) { t_found = true; t_count = good; t_key = key; }
+            }
           }
         }
       }
 #pragma omp critical
-      picked.insert(picked.end(), mine.begin(), mine.end());
+      {
+        picked.insert(picked.end(), mine.begin(), mine.end());
+        if (t_found && (!w_found || t_count > w_count || (t_count == w_count && t_key < w_key))) { w_found = true; w_count = t_count; w_key = t_key; }
+      }
     }
+    if (best7) { best7[0] = w_found ? 1 : 0; best7[1] = w_count; best7[2] = w_key >> 32; best7[3] = w_key & 0xFFFFFFFFull; }
     out[0] = K; out[1] = ksum; out[2] = C; out[3] = csum;
     if (sample) { std::sort(picked.begin(), picked.end()); *sample = std::move(picked); }
   }
@@ -1378,6 +1395,18 @@ void s4po_count_congruent(void* h, float inv1, float inv2, float thr, const int3
                      sample_quads ? &sample : nullptr);
   if (n_sample) *n_sample = int64_t(sample.size());
   for (int64_t i = 0; i < int64_t(sample.size()) && i < sample_cap; ++i) for (int k = 0; k < 4; ++k) sample_quads[4 * i + k] = sample[size_t(i)][k];
+}
+// The same streaming enumeration with every gated candidate VERIFIED in full: best4 = {found, greatest inlier count, index
+// of the winner's set-1 pair, index of its set-2 pair} -- the candidate TryCongruentSet would keep (first maximum in the
+// reference's candidate order).  Cost: candidates x n_Q kd-tree queries; for sizes the host can afford.
+void s4po_count_congruent_best(void* h, float inv1, float inv2, float thr, const int32_t* pairs1, int64_t m1,
+                               const int32_t* pairs2, int64_t m2, const int32_t* base, int32_t threads, uint64_t* out4, uint64_t* best4) {
+  Matcher* m = static_cast<Matcher*>(h);
+  std::vector<std::pair<int, int>> p1(m1), p2(m2);
+  for (int64_t i = 0; i < m1; ++i) p1[i] = {pairs1[2 * i], pairs1[2 * i + 1]};
+  for (int64_t i = 0; i < m2; ++i) p2[i] = {pairs2[2 * i], pairs2[2 * i + 1]};
+  int b4[4] = {base[0], base[1], base[2], base[3]};
+  m->count_congruent(inv1, inv2, thr, p1, p2, b4, threads < 1 ? 1 : threads, out4, 0, nullptr, best4);
 }
 uint64_t s4po_quad_mix(int32_t a, int32_t b, int32_t c, int32_t d) { return Matcher::quad_mix(a, b, c, d); }
 

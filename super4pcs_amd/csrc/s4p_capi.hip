@@ -83,6 +83,7 @@ struct s4p_ctx {
   // device state
   DevBuf<uint2> greach; DevBuf<uint4> glist_hdr; DevBuf<uint32_t> gcoarse; DevBuf<float4> gnbr; DevBuf<float4> q4, q4v;
   DevBuf<uint2> qquant; QuantQ qq{}; bool qlds = false;      // 16-bit copy of the Morton-ordered queries for the LDS-resident sweep
+  DevBuf<unsigned long long> cyc;                            // S4P_CYCLE_PROF lab builds: per-phase cycle sums of the lean k_verify (printed at s4p_destroy)
   DevBuf<float> qsoa; bool lean = false;                     // float copy x | y | z of the same, padded (the lean sweep of k_verify: early-exit mode)
   DevBuf<float> qx, qy, qz, ux, uy, uz, qnx, qny, qnz, qcr, qcg, qcb;
   // Lanes = HIP streams with private per-base device buffers.  Consecutive bases rotate over the lanes, so the
@@ -441,6 +442,7 @@ int32_t launch_verify(s4p_ctx* c, const BaseFrame& bf) {
   V.ctr = L.ctr.p; V.res = L.ctr.p + 1; V.slots = L.slots.p; V.border = L.border.p; V.count_tests = c->prof_points ? 1 : 0;
   V.prune = c->best_hint;
   V.ablate = c->ablate;
+  V.cyc = c->cyc.p;
   hipStream_t vs = L.stream;
   if (L.vstream) {                                           // CU partition: k_verify on the big partition, after the lane's small kernels
     HIPCHK(c, hipEventRecord(L.chain, L.stream));
@@ -663,7 +665,7 @@ int32_t run_chunked(s4p_ctx* c, const DevCounters& first, s4p_base_result* r) {
   std::vector<std::pair<uint64_t, uint64_t>> todo;
   for (uint64_t a = 0; a < span; a += step) todo.emplace_back(a, std::min<uint64_t>(a + step, span));
   std::reverse(todo.begin(), todo.end());
-  if (ordered) c->kept.clear();
+  c->kept.clear();                                         // (records of an earlier base must never answer for this one)
   uint64_t Ksum = 0, Csum = 0, qsum = 0, csum = 0;
   DevCounters best{}; bool have = false;
   c->chunk_bases++; c->chunk_quads += Ktot;
@@ -933,6 +935,9 @@ int32_t s4p_create(const s4p_options* opt, const s4p_limits* lim, int32_t device
   if ((e = hipStreamCreateWithFlags(&c->sel_stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
   if ((e = c->sel_draws.alloc(size_t(kSelectDraws) * kSelectBatch)) != hipSuccess || (e = c->sel_rec.alloc(kSelectBatch)) != hipSuccess) return fail(e, "hipMalloc selection buffers");
   if ((e = c->sel_hdraws.alloc(size_t(kSelectDraws) * kSelectBatch)) != hipSuccess || (e = c->sel_hrec.alloc(kSelectBatch)) != hipSuccess) return fail(e, "hipHostMalloc selection buffers");
+#if S4P_CYCLE_PROF
+  if ((e = c->cyc.alloc(16)) != hipSuccess || (e = hipMemset(c->cyc.p, 0, 16 * sizeof(unsigned long long))) != hipSuccess) return fail(e, "hipMalloc cycle counters");
+#endif
   *out = c;
   return S4P_OK;
 }
@@ -1028,6 +1033,16 @@ void s4p_destroy(s4p_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   for (auto& L : c->lane) { if (L.stream) (void)hipStreamSynchronize(L.stream); if (L.vstream) (void)hipStreamSynchronize(L.vstream); }
+#if S4P_CYCLE_PROF
+  if (c->cyc.p) {
+    unsigned long long v[16] = {0};
+    if (hipMemcpy(v, c->cyc.p, sizeof v, hipMemcpyDeviceToHost) == hipSuccess && v[8])
+      fprintf(stderr, "[s4p cycle prof] waves %llu candidates %llu drains %llu exact batches %llu | per wave (cycles): lifetime %.0f staging %.0f loop %.0f "
+                      "(sweep %.0f drain %.0f exact %.0f record wait %.0f) tail %.0f\n", v[8], v[9], v[10], v[11], double(v[0]) / v[8], double(v[1]) / v[8],
+              double(v[2]) / v[8], double(v[3]) / v[8], double(v[4]) / v[8], double(v[5]) / v[8], double(v[6]) / v[8], double(v[7]) / v[8]);
+  }
+#endif
+  c->cyc.free();
   c->greach.free(); c->glist_hdr.free(); c->gnbr.free();
   c->gcoarse.free(); c->q4.free(); c->q4v.free(); c->qquant.free(); c->qsoa.free();
   c->qx.free(); c->qy.free(); c->qz.free(); c->ux.free(); c->uy.free(); c->uz.free();

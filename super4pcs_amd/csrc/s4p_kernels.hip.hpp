@@ -854,6 +854,18 @@ typedef float f4_t __attribute__((ext_vector_type(4)));
 
 struct LeanLds { const uint32_t* coarse; const float* qx; const float* qy; const float* qz; uint16_t* queue; };
 
+// -DS4P_CYCLE_PROF=1 (lab build, tools/r4): every wave of the lean k_verify adds the shader-clock cycles it spent in each
+// phase to VerifyParams::cyc -- where a wave's lifetime goes, which no counter of the SQ tells directly.
+#ifndef S4P_CYCLE_PROF
+#define S4P_CYCLE_PROF 0
+#endif
+struct CycleProf { unsigned long long sweep, drain, exact; uint32_t n_drain, n_exact; };
+#if S4P_CYCLE_PROF
+#define S4P_CYC_NOW() __builtin_readcyclecounter()
+#else
+#define S4P_CYC_NOW() 0ull
+#endif
+
 // LDS word `index` of the array at byte address `base` (wave-uniform): one shift-add for the address (the compiler's own
 // form of base + 4 * (x >> 5) is shift, mask, add)
 __device__ __forceinline__ uint32_t lds_word(const uint32_t base, const uint32_t index) {
@@ -901,7 +913,8 @@ __device__ __forceinline__ uint32_t exact_pair_lean(const LcpGrid& g, const LcpT
 }
 
 template <bool COUNT, bool SKIP_FINE>
-__device__ __forceinline__ uint32_t wave_lcp_count_lean(const LcpGrid& g, const LcpTask& K, const LeanLds& L, const float4* Tsrc, const float4 t0, const float4 t1, const float4 t2) {
+__device__ __forceinline__ uint32_t wave_lcp_count_lean(const LcpGrid& g, const LcpTask& K, const LeanLds& L, const float4* Tsrc, const float4 t0, const float4 t1, const float4 t2,
+                                                        CycleProf& CP) {
   // t0..t2: the rows at Tsrc, already in registers (k_verify fetches a candidate's record while the previous one is swept); the
   // rare drain / exact batches read them again through Tsrc
   const uint32_t lane = threadIdx.x & 63u;
@@ -975,6 +988,7 @@ __device__ __forceinline__ uint32_t wave_lcp_count_lean(const LcpGrid& g, const 
   for (uint32_t base = 0;; base += kSweepStep) {
     const bool more = base < n_pad;                        // wave-uniform
     const uint32_t unswept = K.n_q - min(base + kSweepStep, K.n_q);
+    const unsigned long long cyc_a = S4P_CYC_NOW();
     if (more) {
       // one step = kSweepChunks chunks in four phases, so that the LDS reads of all chunks are in flight together and
       // dependent MFMAs of one chunk are separated by the other chunks'
@@ -1019,21 +1033,28 @@ __device__ __forceinline__ uint32_t wave_lcp_count_lean(const LcpGrid& g, const 
       // upper bound of what this candidate can still reach: confirmed + waiting (either kind) + not swept yet
       if (cnt + nb + na + unswept <= K.prune) { abandoned = true; break; }
     }
+    const unsigned long long cyc_b = S4P_CYC_NOW();
+    if (S4P_CYCLE_PROF) CP.sweep += cyc_b - cyc_a;
     if (!more || nb + na + kSweepStep > kLeanQueue) {
       const uint32_t rest = more ? unswept : 0u;
-      if (drain(rest)) { abandoned = true; break; }
+      const bool dead = drain(rest);
+      const unsigned long long cyc_c = S4P_CYC_NOW();
+      if (S4P_CYCLE_PROF) { CP.drain += cyc_c - cyc_b; CP.n_drain += 1u; }
+      if (dead) { abandoned = true; break; }
       while ((more && nb + 2u * kSweepStep > kLeanQueue) || (!more && nb != 0u)) {
         if (cnt + nb + rest <= K.prune) { abandoned = true; break; }
         const uint32_t n = min(nb, 128u);
         const bool va = lane < n, vb = lane + 64u < n;
         const uint32_t ia = uint32_t(q[nb - n + min(lane, n - 1u)]), ib = uint32_t(q[nb - n + min(lane + 64u, n - 1u)]);
         if (COUNT) { if (lane == 0) atomicAdd(K.point_tests + 2, (unsigned long long)n); }      // list headers read (l1_pass)
+        const unsigned long long cyc_d = S4P_CYC_NOW();
         if (!SKIP_FINE) {
           const uint32_t h = exact_pair_lean<COUNT>(g, K, L, Tsrc, va, ia, vb, ib);
           cnt += uint32_t(__popcll(__builtin_amdgcn_ballot_w64((h & 1u) != 0u))) + uint32_t(__popcll(__builtin_amdgcn_ballot_w64((h & 2u) != 0u)));
         }
         nb -= n;
         lds_fence();
+        if (S4P_CYCLE_PROF) { CP.exact += S4P_CYC_NOW() - cyc_d; CP.n_exact += 1u; }
       }
     }
     if (!more || abandoned) break;
@@ -2038,6 +2059,7 @@ struct VerifyParams {
   uint4* slots;                                         // per workgroup: {best count, its candidate, tag lo, tag hi}
   uint32_t* border;                                     // candidates (positions in cand_idx) with an undecided gate, kBorderCap entries
   uint32_t prune;                                       // best inlier count of the registration at launch (LcpTask::prune), 0 = count every candidate in full
+  unsigned long long* cyc;                              // S4P_CYCLE_PROF builds: 16 accumulators (see k_verify), else unused
   int count_tests;                                      // instrumentation counters are live: carry them into res
   int ablate;                                           // S4P_ABLATE debugging only (0 = full kernel)
 };
@@ -2074,6 +2096,11 @@ __global__ __launch_bounds__(kVerifyMaxThreads, LEAN ? 4 : 6) void k_verify(Veri
       : reinterpret_cast<uint32_t*>(s_q + (QLDS ? n_pad : 0u)) + (blockDim.x >> 6) * kQueueWordsPerWave);
   uint32_t& s_next = S.next; uint32_t& s_last = S.last; uint32_t& s_pruned = S.pruned;
   uint32_t* s_wcnt = S.wcnt; uint32_t* s_wcand = S.wcand; unsigned long long* s_wtag = S.wtag;
+  const unsigned long long cyc_entry = S4P_CYC_NOW();
+  unsigned long long cyc_staged = cyc_entry, cyc_loop_end = cyc_entry, cyc_wait = 0ull;
+  uint32_t n_cand = 0;
+  CycleProf CP{0ull, 0ull, 0ull, 0u, 0u};
+  (void)cyc_staged; (void)cyc_loop_end; (void)cyc_wait; (void)n_cand;
   const uint32_t C = P.ctr->C;
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   // Work split: every workgroup owns a fixed share of the gated candidate list (static: a single-address global cursor
@@ -2102,6 +2129,7 @@ __global__ __launch_bounds__(kVerifyMaxThreads, LEAN ? 4 : 6) void k_verify(Veri
       if (lane == 0) t = atomicAdd(&s_next, 1u);
       return uint32_t(__builtin_amdgcn_readfirstlane(int(t)));
     };
+    cyc_staged = S4P_CYC_NOW();
     uint32_t t_cur = take();
     float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0, r3 = r0;
     if (t_cur < hi) { const float4* rec = P.cand_T + kCandStride * size_t(blockIdx.x + t_cur * gridDim.x); r0 = rec[0]; r1 = rec[1]; r2 = rec[2]; r3 = rec[3]; }
@@ -2112,7 +2140,12 @@ __global__ __launch_bounds__(kVerifyMaxThreads, LEAN ? 4 : 6) void k_verify(Veri
       if (t_nxt < hi) { const float4* rec = P.cand_T + kCandStride * size_t(blockIdx.x + t_nxt * gridDim.x); n0 = rec[0]; n1 = rec[1]; n2 = rec[2]; n3 = rec[3]; }
       const float4* src = P.cand_T + kCandStride * size_t(i);         // one candidate per wave
       uint32_t cnt;
-      if (LEAN) cnt = P.ablate == 1 ? wave_lcp_count_lean<COUNT, true>(P.grid, K, LL, src, r0, r1, r2) : wave_lcp_count_lean<COUNT, false>(P.grid, K, LL, src, r0, r1, r2);
+#if S4P_CYCLE_PROF
+      { const unsigned long long w0 = S4P_CYC_NOW();          // how long the record of THIS candidate keeps the wave waiting
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        cyc_wait += S4P_CYC_NOW() - w0; ++n_cand; }
+#endif
+      if (LEAN) cnt = P.ablate == 1 ? wave_lcp_count_lean<COUNT, true>(P.grid, K, LL, src, r0, r1, r2, CP) : wave_lcp_count_lean<COUNT, false>(P.grid, K, LL, src, r0, r1, r2, CP);
       else cnt = P.ablate == 1 ? S4P_WAVE_LCP_COUNT<COUNT, true, QLDS>(P.grid, K, s_coarse, s_q, s_queue, src)
                                : S4P_WAVE_LCP_COUNT<COUNT, false, QLDS>(P.grid, K, s_coarse, s_q, s_queue, src);
       const uint32_t kraw = uint32_t(__builtin_amdgcn_readfirstlane(int(__float_as_uint(r3.z))));
@@ -2126,6 +2159,9 @@ __global__ __launch_bounds__(kVerifyMaxThreads, LEAN ? 4 : 6) void k_verify(Veri
       t_cur = t_nxt; r0 = n0; r1 = n1; r2 = n2; r3 = n3;
     }
   }
+#if S4P_CYCLE_PROF
+  cyc_loop_end = S4P_CYC_NOW();
+#endif
   // ---- selection: wave bests -> workgroup best -> slot; the last workgroup to finish reduces the slots ----
   auto wave_reduce = [&]() {
 #pragma unroll
@@ -2147,6 +2183,15 @@ __global__ __launch_bounds__(kVerifyMaxThreads, LEAN ? 4 : 6) void k_verify(Veri
     }
   };
   block_reduce(false);                                     // (the wave's best is uniform over its lanes)
+#if S4P_CYCLE_PROF
+  if (LEAN && P.cyc != nullptr && lane == 0) {              // per wave: [0] lifetime up to here [1] staging [2] candidate loop [3] sweep [4] drain [5] exact
+    const unsigned long long now = S4P_CYC_NOW();           //           [6] record wait [7] tail barrier [8] waves [9] candidates [10] drains [11] exact batches
+    atomicAdd(P.cyc + 0, now - cyc_entry); atomicAdd(P.cyc + 1, cyc_staged - cyc_entry); atomicAdd(P.cyc + 2, cyc_loop_end - cyc_staged);
+    atomicAdd(P.cyc + 3, CP.sweep); atomicAdd(P.cyc + 4, CP.drain); atomicAdd(P.cyc + 5, CP.exact); atomicAdd(P.cyc + 6, cyc_wait);
+    atomicAdd(P.cyc + 7, now - cyc_loop_end); atomicAdd(P.cyc + 8, 1ull); atomicAdd(P.cyc + 9, (unsigned long long)n_cand);
+    atomicAdd(P.cyc + 10, (unsigned long long)CP.n_drain); atomicAdd(P.cyc + 11, (unsigned long long)CP.n_exact);
+  }
+#endif
   if (threadIdx.x == 0) {
     if (lo < hi && P.ablate != 2 && s_pruned) atomicAdd(&P.ctr->pruned, s_pruned);
     P.slots[blockIdx.x] = make_uint4(bc, bi, uint32_t(bt), uint32_t(bt >> 32));

@@ -290,3 +290,54 @@ def test_config2_gpu_scale_sample_20000(oracle_mod, s4p_lib_built):
     _gr, g_per = ctx.try_congruent_set(base, smp[:300])
     assert np.array_equal(g_per, o_per) and (o_per >= 0).all()
     assert o_per.max() <= r.best_count
+
+
+def test_chunked_winner_equals_the_oracles_streaming_winner(oracle_mod, s4p_lib_built):
+    """The winner of a CHUNKED base -- greatest inlier count, ties to the first candidate in the reference's order
+    (match4pcsBase.hpp:467-484) -- against the oracle's streaming pass, which verifies every gated candidate of the base in
+    full and keeps (max count, min (id, i)).  Sample size 4000 on the configs[2] clouds: ~10^6 candidates per base, a size the
+    host's cores can verify; the quad buffers are held at 256 Ki entries so that every base takes a dozen passes, once cut
+    along the second pair set (default) and once along the first set's order key (the ordered mode of the record sink)."""
+    from super4pcs_amd import capi, datasets as D
+    import bench
+    from bench import seg_len32
+    if SCALE != 1.0:
+        pytest.skip("full-size case")
+    O = oracle_mod
+    n_s = 4000
+    P, Q, _ = D.bumpy_pair(bench.N_POINTS, overlap=bench.OVERLAP, delta=bench.DELTA, seed=bench.SEED)
+    om = O.Matcher(O.make_options(bench.DELTA, bench.OVERLAP, n_s), full_counts=True, use_kdtree=True, keep_trace=False)
+    om.init(P, Q)
+    Ps, Qs = om.cloud(0), om.cloud(1)
+    eps = 2.0 * bench.DELTA
+    ctxs = []
+    for ordered in (False, True):
+        c = capi.Context(capi.make_options(bench.DELTA, bench.OVERLAP, n_s), max_pairs=4 << 20, max_quads=256 << 10)
+        c.set_quad_chunking(True, 256 << 10)
+        c.set_clouds(Ps, Qs)
+        if ordered:
+            c.set_candidate_sink(lambda cnt, T: None)
+        ctxs.append(c)
+    done = 0
+    for _ in range(3):
+        ok, i1, i2, base, bx = om.select_quadrilateral()
+        if not ok:
+            continue
+        p1 = om.extract_pairs_cap(seg_len32(bx[0], bx[1]), 0.0, eps, 0, 1, 1 << 23)
+        p2 = om.extract_pairs_cap(seg_len32(bx[2], bx[3]), 0.0, eps, 2, 3, 1 << 23)
+        if not (len(p1) and len(p2)):
+            continue
+        want = om.count_congruent_best(i1, i2, eps, p1, p2, base)
+        for c in ctxs:
+            c.set_base(bx)
+            before = c.chunk_stats()["passes"]
+            r = c.try_base(base, i1, i2)
+            assert (r.n_quads, r.quad_checksum, r.n_verified, r.cand_checksum) == (want["K"], want["quad_sum"], want["C"], want["cand_sum"])
+            if want["K"] > (256 << 10):
+                assert c.chunk_stats()["passes"] - before >= 2
+            assert bool(r.has_best) == want["found"]
+            if want["found"]:
+                assert r.best_count == want["best_count"] and list(r.best_quad) == want["best_quad"]
+        done += 1 if want["K"] > (256 << 10) else 0
+    assert done >= 1
+

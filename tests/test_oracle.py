@@ -187,5 +187,15 @@ def test_streaming_quad_count_equals_the_list_enumeration(oracle_mod):
             want = want[np.lexsort(want.T[::-1])] if len(want) else want
             assert np.array_equal(got["sample"], want)
         assert om.L.s4po_quad_mix(1, 2, 3, 4) == int(H.quad_mix([[1, 2, 3, 4]])[0]) == 6837720401966776326
+        # ... and the streaming WINNER (every gated candidate verified in full, greatest count, then first in the reference's
+        # candidate order) is the one the list form keeps: the first maximum of per (try_congruent_set runs in full-count mode)
+        for threads in (1, 4):
+            wb = om.count_congruent_best(i1, i2, eps, p1, p2, base, threads=threads)
+            assert (wb["K"], wb["C"]) == (len(quads), len(gated))
+            if len(gated):
+                k_first_max = int(np.argmax(np.where(per >= 0, per, -1)))
+                assert wb["found"] and wb["best_count"] == int(per[k_first_max]) and wb["best_quad"] == list(quads[k_first_max])
+            else:
+                assert not wb["found"]
         seen += len(quads)
     assert seen > 1000
