@@ -865,6 +865,11 @@ struct CycleProf { unsigned long long sweep, drain, exact; uint32_t n_drain, n_e
 #else
 #define S4P_CYC_NOW() 0ull
 #endif
+#if S4P_CYCLE_PROF == 1            // 1: stamps inside the sweep loop too (they serialise it: relative shares only); 2: per-wave phases only
+#define S4P_CYC_FINE() __builtin_readcyclecounter()
+#else
+#define S4P_CYC_FINE() 0ull
+#endif
 
 // LDS word `index` of the array at byte address `base` (wave-uniform): one shift-add for the address (the compiler's own
 // form of base + 4 * (x >> 5) is shift, mask, add)
@@ -988,7 +993,7 @@ __device__ __forceinline__ uint32_t wave_lcp_count_lean(const LcpGrid& g, const 
   for (uint32_t base = 0;; base += kSweepStep) {
     const bool more = base < n_pad;                        // wave-uniform
     const uint32_t unswept = K.n_q - min(base + kSweepStep, K.n_q);
-    const unsigned long long cyc_a = S4P_CYC_NOW();
+    const unsigned long long cyc_a = S4P_CYC_FINE();
     if (more) {
       // one step = kSweepChunks chunks in four phases, so that the LDS reads of all chunks are in flight together and
       // dependent MFMAs of one chunk are separated by the other chunks'
@@ -1033,13 +1038,13 @@ __device__ __forceinline__ uint32_t wave_lcp_count_lean(const LcpGrid& g, const 
       // upper bound of what this candidate can still reach: confirmed + waiting (either kind) + not swept yet
       if (cnt + nb + na + unswept <= K.prune) { abandoned = true; break; }
     }
-    const unsigned long long cyc_b = S4P_CYC_NOW();
-    if (S4P_CYCLE_PROF) CP.sweep += cyc_b - cyc_a;
+    const unsigned long long cyc_b = S4P_CYC_FINE();
+    if (S4P_CYCLE_PROF == 1) CP.sweep += cyc_b - cyc_a;
     if (!more || nb + na + kSweepStep > kLeanQueue) {
       const uint32_t rest = more ? unswept : 0u;
       const bool dead = drain(rest);
-      const unsigned long long cyc_c = S4P_CYC_NOW();
-      if (S4P_CYCLE_PROF) { CP.drain += cyc_c - cyc_b; CP.n_drain += 1u; }
+      const unsigned long long cyc_c = S4P_CYC_FINE();
+      if (S4P_CYCLE_PROF == 1) { CP.drain += cyc_c - cyc_b; CP.n_drain += 1u; }
       if (dead) { abandoned = true; break; }
       while ((more && nb + 2u * kSweepStep > kLeanQueue) || (!more && nb != 0u)) {
         if (cnt + nb + rest <= K.prune) { abandoned = true; break; }
@@ -1047,14 +1052,14 @@ __device__ __forceinline__ uint32_t wave_lcp_count_lean(const LcpGrid& g, const 
         const bool va = lane < n, vb = lane + 64u < n;
         const uint32_t ia = uint32_t(q[nb - n + min(lane, n - 1u)]), ib = uint32_t(q[nb - n + min(lane + 64u, n - 1u)]);
         if (COUNT) { if (lane == 0) atomicAdd(K.point_tests + 2, (unsigned long long)n); }      // list headers read (l1_pass)
-        const unsigned long long cyc_d = S4P_CYC_NOW();
+        const unsigned long long cyc_d = S4P_CYC_FINE();
         if (!SKIP_FINE) {
           const uint32_t h = exact_pair_lean<COUNT>(g, K, L, Tsrc, va, ia, vb, ib);
           cnt += uint32_t(__popcll(__builtin_amdgcn_ballot_w64((h & 1u) != 0u))) + uint32_t(__popcll(__builtin_amdgcn_ballot_w64((h & 2u) != 0u)));
         }
         nb -= n;
         lds_fence();
-        if (S4P_CYCLE_PROF) { CP.exact += S4P_CYC_NOW() - cyc_d; CP.n_exact += 1u; }
+        if (S4P_CYCLE_PROF == 1) { CP.exact += S4P_CYC_FINE() - cyc_d; CP.n_exact += 1u; }
       }
     }
     if (!more || abandoned) break;
@@ -2140,7 +2145,7 @@ __global__ __launch_bounds__(kVerifyMaxThreads, LEAN ? 4 : 6) void k_verify(Veri
       if (t_nxt < hi) { const float4* rec = P.cand_T + kCandStride * size_t(blockIdx.x + t_nxt * gridDim.x); n0 = rec[0]; n1 = rec[1]; n2 = rec[2]; n3 = rec[3]; }
       const float4* src = P.cand_T + kCandStride * size_t(i);         // one candidate per wave
       uint32_t cnt;
-#if S4P_CYCLE_PROF
+#if S4P_CYCLE_PROF == 1
       { const unsigned long long w0 = S4P_CYC_NOW();          // how long the record of THIS candidate keeps the wave waiting
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         cyc_wait += S4P_CYC_NOW() - w0; ++n_cand; }
