@@ -112,7 +112,6 @@ struct s4p_ctx {
     DevBuf<DevCounters> ctr;          // [0] live counters of the base in flight, [1] its result record (what the host reads)
     DevBuf<uint4> slots;              // k_verify: per-workgroup best, reduced by its last workgroup
     DevBuf<uint32_t> border;          // k_verify: candidates whose Euler-angle gate the host settles (max_angle >= 0), kBorderCap entries
-    DevBuf<uint16_t> heavy;           // k_verify (lean): scratch lists of deferred candidates, kHeavyBlocks x kHeavySlots x kLeanMaxQueries entries
     bool dirty = false;               // a stage-level call left the live counters non-zero: clear before a fused pass
     DevBuf<uint32_t> seq[2];          // device copy of a staged sequence blob (layout: StageSlot)
     // launch record of the base in flight: what a relaunch after a buffer growth needs (finish_result)
@@ -211,7 +210,6 @@ struct s4p_ctx {
     return gcoarse.n * 4 + size_t((n_q + kSweepStep - 1u) & ~(kSweepStep - 1u)) * 12 + size_t(verify_threads / 64) * kLeanQueue * 2 + sizeof(VerifyShared);
   }
   bool use_lean() const { return lean && best_hint != 0u; }
-  static constexpr uint32_t kHeavyBlocks = 512;            // k_verify grids up to this size get scratch lists for deferred candidates (21 MB per lane)
   // (a chunk pass scores ~10^7 candidates with the chip to itself: two workgroups per CU, as for the HBM-bound structure;
   // measured at the 20 000-point sample: 0.50 s per pass with 512 workgroups, 0.66 s with 256)
   bool chunk_pass = false;
@@ -445,8 +443,6 @@ int32_t launch_verify(s4p_ctx* c, const BaseFrame& bf) {
   V.prune = c->best_hint;
   V.ablate = c->ablate;
   V.cyc = c->cyc.p;
-  static const bool no_defer = getenv("S4P_NO_DEFER") != nullptr;      // A/B aid: heavy candidates finished inline by their own wave (the round-4 run-4 kernel)
-  V.heavy = no_defer ? nullptr : L.heavy.p; V.heavy_stride = uint32_t((c->n_q + kSweepStep - 1u) & ~(kSweepStep - 1u)); V.heavy_blocks = s4p_ctx::kHeavyBlocks;
   hipStream_t vs = L.stream;
   if (L.vstream) {                                           // CU partition: k_verify on the big partition, after the lane's small kernels
     HIPCHK(c, hipEventRecord(L.chain, L.stream));
@@ -916,7 +912,7 @@ int32_t s4p_create(const s4p_options* opt, const s4p_limits* lim, int32_t device
       if ((e = hipEventCreateWithFlags(&L.chain, hipEventDisableTiming)) != hipSuccess) return fail(e, "hipEventCreate");
       if (!getenv("S4P_VERIFY_BLOCKS")) { c->verify_blocks = 2u * nbig; c->verify_blocks_fixed = true; }
     } else if ((e = hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
-    A(L.ctr, 2); A(L.slots, kVerifyMaxBlocks); A(L.border, kBorderCap); A(L.heavy, size_t(s4p_ctx::kHeavyBlocks) * kHeavySlots * kLeanMaxQueries);
+    A(L.ctr, 2); A(L.slots, kVerifyMaxBlocks); A(L.border, kBorderCap);
     if ((e = hipMemset(L.ctr.p, 0, 2 * sizeof(DevCounters))) != hipSuccess) return fail(e, "hipMemset");
     const char* what = nullptr;
     if ((e = alloc_lane_buffers(c->max_pairs, c->max_quads, L, &what)) != hipSuccess) return fail(e, what);
@@ -1052,7 +1048,7 @@ void s4p_destroy(s4p_ctx* c) {
   c->qx.free(); c->qy.free(); c->qz.free(); c->ux.free(); c->uy.free(); c->uz.free();
   c->qnx.free(); c->qny.free(); c->qnz.free(); c->qcr.free(); c->qcg.free(); c->qcb.free();
   for (auto& L : c->lane) {
-    L.free_all(); L.ctr.free(); L.slots.free(); L.border.free(); L.heavy.free();
+    L.free_all(); L.ctr.free(); L.slots.free(); L.border.free();
     for (int s = 0; s < 2; ++s) L.seq[s].free();
   }
   for (auto& h : c->hctr) h.free();

@@ -852,24 +852,7 @@ constexpr float kLeanPad = 1.0e18f;                        // coordinates of the
 constexpr int kLeanMaxQueries = 2560;                      // sampled-Q points the float LDS copy takes (30 KB)
 typedef float f4_t __attribute__((ext_vector_type(4)));
 
-// HEAVY candidates.  Most candidates are dismissed by the bound after an LDS-only sweep (~2.6 us of one wave); a candidate that
-// really aligns the clouds keeps most of its queries alive: the 768-entry queue fills every other step, every fill costs a
-// reach-word round trip plus two serial exact batches (~6 us per step, ~50 us per candidate) -- twenty times a plain
-// candidate, on ONE wave, while the other eleven waves of the workgroup run out of tickets and idle at the final barrier: the
-// light cycle profile of run 6 shows 53 % of a wave's lifetime in that barrier.  So a heavy candidate does not run its exact
-// tests inside the sweep: whenever its queue fills, the reach-tested entries are SPILLED to a global scratch list and the sweep
-// goes on; if the candidate is still alive at the end it is DEFERRED, and after the ticket loop the whole workgroup finishes
-// its deferred candidates together -- twelve waves x 128 entries of exact tests in flight at once instead of one.
-constexpr uint32_t kHeavySlots = 8;                         // deferred candidates a workgroup can hold (more: the inline path)
-constexpr uint32_t kLeanDeferred = 0xFFFFFFFFu;             // wave_lcp_count_lean's return value for a deferred candidate
-struct HeavyCtl {                                           // (in VerifyShared)
-  uint32_t n;                                               // slots handed out
-  uint32_t cand[kHeavySlots];                               // position in the candidate list, kNil = slot given back
-  uint32_t n_ent[kHeavySlots];                              // entries in the slot's scratch list
-  uint32_t hits;                                            // inliers of the candidate being finished
-};
-struct LeanLds { const uint32_t* coarse; const float* qx; const float* qy; const float* qz; uint16_t* queue;
-                 HeavyCtl* heavy; uint16_t* scratch; uint32_t scratch_stride; };     // scratch: this workgroup's kHeavySlots lists (nullptr: no deferral)
+struct LeanLds { const uint32_t* coarse; const float* qx; const float* qy; const float* qz; uint16_t* queue; };
 
 // -DS4P_CYCLE_PROF=1 (lab build, tools/r4): every wave of the lean k_verify adds the shader-clock cycles it spent in each
 // phase to VerifyParams::cyc -- where a wave's lifetime goes, which no counter of the SQ tells directly.
@@ -936,9 +919,9 @@ __device__ __forceinline__ uint32_t exact_pair_lean(const LcpGrid& g, const LcpT
 
 template <bool COUNT, bool SKIP_FINE>
 __device__ __forceinline__ uint32_t wave_lcp_count_lean(const LcpGrid& g, const LcpTask& K, const LeanLds& L, const float4* Tsrc, const float4 t0, const float4 t1, const float4 t2,
-                                                        const uint32_t cand_pos, CycleProf& CP) {
-  // t0..t2: the rows at Tsrc, already in registers; the drain / exact batches read them again through Tsrc.  cand_pos: the
-  // candidate's position in the list (what a deferral records)
+                                                        CycleProf& CP) {
+  // t0..t2: the rows at Tsrc, already in registers (k_verify fetches a candidate's record while the previous one is swept); the
+  // rare drain / exact batches read them again through Tsrc
   const uint32_t lane = threadIdx.x & 63u;
   uint16_t* q = L.queue;
   uint32_t cnt = 0, nb = 0, na = 0;
@@ -1007,24 +990,6 @@ __device__ __forceinline__ uint32_t wave_lcp_count_lean(const LcpGrid& g, const 
   };
   const uint32_t n_pad = (K.n_q + kSweepStep - 1u) & ~(kSweepStep - 1u);
   bool abandoned = false;
-  uint32_t spilled = 0, slot = kNil;                       // entries of this candidate in its scratch list; its slot (kNil: none yet / none to be had)
-  bool inline_mode = false;                                // an exact batch of this candidate has run inside the sweep: it stays on that path
-  // reach-tested entries [0, nb) -> the candidate's scratch list (the slot is taken at the first spill); false: no slot left
-  auto spill = [&]() -> bool {
-    if (L.scratch == nullptr) return false;
-    if (slot == kNil) {
-      uint32_t sl = 0;
-      if (lane == 0) sl = atomicAdd(&L.heavy->n, 1u);
-      sl = uint32_t(__builtin_amdgcn_readfirstlane(int(sl)));
-      if (sl >= kHeavySlots) return false;
-      slot = sl;
-      if (lane == 0) L.heavy->cand[slot] = kNil;           // (until the candidate is really deferred)
-    }
-    uint16_t* dst = L.scratch + size_t(slot) * L.scratch_stride + spilled;
-    for (uint32_t e = lane; e < nb; e += 64u) dst[e] = q[e];
-    spilled += nb; nb = 0u;
-    return true;
-  };
   for (uint32_t base = 0;; base += kSweepStep) {
     const bool more = base < n_pad;                        // wave-uniform
     const uint32_t unswept = K.n_q - min(base + kSweepStep, K.n_q);
@@ -1070,44 +1035,31 @@ __device__ __forceinline__ uint32_t wave_lcp_count_lean(const LcpGrid& g, const 
       }
       // (instrumentation counts what is FETCHED: L0 survivors when their reach word is gathered -- drain --, reach survivors
       // when their list header is read -- exact batch; an abandoned candidate has touched neither)
-      // upper bound of what this candidate can still reach: confirmed + waiting (any kind) + not swept yet
-      if (cnt + spilled + nb + na + unswept <= K.prune) { abandoned = true; break; }
+      // upper bound of what this candidate can still reach: confirmed + waiting (either kind) + not swept yet
+      if (cnt + nb + na + unswept <= K.prune) { abandoned = true; break; }
     }
     const unsigned long long cyc_b = S4P_CYC_FINE();
     if (S4P_CYCLE_PROF == 1) CP.sweep += cyc_b - cyc_a;
     if (!more || nb + na + kSweepStep > kLeanQueue) {
-      const uint32_t rest = (more ? unswept : 0u) + spilled;
+      const uint32_t rest = more ? unswept : 0u;
       const bool dead = drain(rest);
       const unsigned long long cyc_c = S4P_CYC_FINE();
       if (S4P_CYCLE_PROF == 1) { CP.drain += cyc_c - cyc_b; CP.n_drain += 1u; }
       if (dead) { abandoned = true; break; }
-      // still alive.  Heavy (the queue cannot take another step, or entries are already spilled, or more than one exact batch
-      // waits at the end): spill and go on / defer.  Light: the one batch inline.  No slot left: everything inline, as before.
-      const bool must_free = more && nb + 2u * kSweepStep > kLeanQueue;
-      if ((must_free || (!more && (spilled != 0u || nb > 128u))) && !inline_mode && spill()) {
-        if (!more) {
-          if (lane == 0) { L.heavy->n_ent[slot] = spilled; L.heavy->cand[slot] = cand_pos; }
-          return kLeanDeferred;
+      while ((more && nb + 2u * kSweepStep > kLeanQueue) || (!more && nb != 0u)) {
+        if (cnt + nb + rest <= K.prune) { abandoned = true; break; }
+        const uint32_t n = min(nb, 128u);
+        const bool va = lane < n, vb = lane + 64u < n;
+        const uint32_t ia = uint32_t(q[nb - n + min(lane, n - 1u)]), ib = uint32_t(q[nb - n + min(lane + 64u, n - 1u)]);
+        if (COUNT) { if (lane == 0) atomicAdd(K.point_tests + 2, (unsigned long long)n); }      // list headers read (l1_pass)
+        const unsigned long long cyc_d = S4P_CYC_FINE();
+        if (!SKIP_FINE) {
+          const uint32_t h = exact_pair_lean<COUNT>(g, K, L, Tsrc, va, ia, vb, ib);
+          cnt += uint32_t(__popcll(__builtin_amdgcn_ballot_w64((h & 1u) != 0u))) + uint32_t(__popcll(__builtin_amdgcn_ballot_w64((h & 2u) != 0u)));
         }
-      } else {
-        inline_mode = true;
-        while ((more && nb + 2u * kSweepStep > kLeanQueue) || (!more && nb != 0u)) {
-          if (cnt + nb + rest <= K.prune) { abandoned = true; break; }
-          const uint32_t n = min(nb, 128u);
-          const bool va = lane < n, vb = lane + 64u < n;
-          const uint32_t ia = uint32_t(q[nb - n + min(lane, n - 1u)]), ib = uint32_t(q[nb - n + min(lane + 64u, n - 1u)]);
-          if (COUNT) { if (lane == 0) atomicAdd(K.point_tests + 2, (unsigned long long)n); }      // list headers read (l1_pass)
-          const unsigned long long cyc_d = S4P_CYC_FINE();
-          if (!SKIP_FINE) {
-            const uint32_t h = exact_pair_lean<COUNT>(g, K, L, Tsrc, va, ia, vb, ib);
-            cnt += uint32_t(__popcll(__builtin_amdgcn_ballot_w64((h & 1u) != 0u))) + uint32_t(__popcll(__builtin_amdgcn_ballot_w64((h & 2u) != 0u)));
-          }
-          nb -= n;
-          lds_fence();
-          if (S4P_CYCLE_PROF == 1) { CP.exact += S4P_CYC_FINE() - cyc_d; CP.n_exact += 1u; }
-        }
-        // (the two paths never mix: spill() can only fail before a candidate's first spill, and a candidate that has run an
-        // inline batch never spills)
+        nb -= n;
+        lds_fence();
+        if (S4P_CYCLE_PROF == 1) { CP.exact += S4P_CYC_FINE() - cyc_d; CP.n_exact += 1u; }
       }
     }
     if (!more || abandoned) break;
@@ -2113,7 +2065,6 @@ struct VerifyParams {
   uint32_t* border;                                     // candidates (positions in cand_idx) with an undecided gate, kBorderCap entries
   uint32_t prune;                                       // best inlier count of the registration at launch (LcpTask::prune), 0 = count every candidate in full
   unsigned long long* cyc;                              // S4P_CYCLE_PROF builds: 16 accumulators (see k_verify), else unused
-  uint16_t* heavy; uint32_t heavy_stride, heavy_blocks; // lean kernels: scratch lists of deferred candidates, [block][kHeavySlots][heavy_stride]; usable for gridDim.x <= heavy_blocks
   int count_tests;                                      // instrumentation counters are live: carry them into res
   int ablate;                                           // S4P_ABLATE debugging only (0 = full kernel)
 };
@@ -2122,10 +2073,7 @@ struct VerifyShared {                                   // k_verify's workgroup 
   unsigned long long wtag[kVerifyMaxThreads / 64];
   uint32_t wcnt[kVerifyMaxThreads / 64], wcand[kVerifyMaxThreads / 64];
   uint32_t next, last, pruned, pad;
-  HeavyCtl heavy;                                       // lean kernels: deferred candidates of the workgroup
-  uint32_t pad2;
 };
-static_assert(sizeof(VerifyShared) % 8 == 0, "VerifyShared follows 8-byte aligned queues");
 
 // better(a, b): a wins over b if its count is greater, or equal with a smaller tag (= earlier in reference order)
 __device__ __forceinline__ bool slot_better(const uint32_t ca, const unsigned long long ta, const uint32_t cb, const unsigned long long tb, const bool b_valid) {
@@ -2135,7 +2083,7 @@ __device__ __forceinline__ bool slot_better(const uint32_t ca, const unsigned lo
 // LEAN (launched when an early-exit bound is in force and the float copy of the sampled Q fits LDS): wave_lcp_count_lean,
 // LDS = coarse bitmap | float queries x, y, z | one 16-bit queue per wave; QLDS is then meaningless (false).
 template <bool COUNT, bool QLDS, bool LEAN>
-__global__ __launch_bounds__(kVerifyMaxThreads, 6) void k_verify(VerifyParams P) {   // <= 80 VGPRs: six waves per SIMD, i.e. two 768-thread workgroups per CU (of one launch, or of two lanes)
+__global__ __launch_bounds__(kVerifyMaxThreads, LEAN ? 4 : 6) void k_verify(VerifyParams P) {   // fused: <= 80 VGPRs, six waves per SIMD (two 768-thread workgroups per CU); lean: one workgroup per CU, <= 128
   extern __shared__ uint32_t s_mem[];
   uint32_t* s_coarse = s_mem;                              // LDS: coarse bitmap | quantised queries (QLDS) | 16 survivor queues
   uint2* s_q = reinterpret_cast<uint2*>(s_mem + P.grid.coarse_words);
@@ -2146,17 +2094,12 @@ __global__ __launch_bounds__(kVerifyMaxThreads, 6) void k_verify(VerifyParams P)
   { float* f = reinterpret_cast<float*>(s_mem + P.grid.coarse_words);
     LL.qx = f; LL.qy = f + n_pad; LL.qz = f + 2u * n_pad;
     LL.queue = reinterpret_cast<uint16_t*>(f + 3u * n_pad) + uint32_t(__builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6))) * kLeanQueue; }   // (uniform: scalar register)
-  LL.heavy = nullptr; LL.scratch = nullptr; LL.scratch_stride = P.heavy_stride;
   // The workgroup's few scalars live at the END of the dynamic segment (VerifyShared), not in static __shared__: the coarse
   // bitmap then starts at LDS address 0 and the sweep's word address needs no base added (one vector instruction per chunk).
   VerifyShared& S = *reinterpret_cast<VerifyShared*>(LEAN
       ? reinterpret_cast<uint32_t*>(reinterpret_cast<uint16_t*>(s_mem + P.grid.coarse_words + 3u * n_pad) + (blockDim.x >> 6) * kLeanQueue)
       : reinterpret_cast<uint32_t*>(s_q + (QLDS ? n_pad : 0u)) + (blockDim.x >> 6) * kQueueWordsPerWave);
   uint32_t& s_next = S.next; uint32_t& s_last = S.last; uint32_t& s_pruned = S.pruned;
-  if (LEAN) {
-    LL.heavy = &S.heavy;
-    if (P.heavy != nullptr && gridDim.x <= P.heavy_blocks) LL.scratch = P.heavy + size_t(blockIdx.x) * kHeavySlots * P.heavy_stride;
-  }
   uint32_t* s_wcnt = S.wcnt; uint32_t* s_wcand = S.wcand; unsigned long long* s_wtag = S.wtag;
   const unsigned long long cyc_entry = S4P_CYC_NOW();
   unsigned long long cyc_staged = cyc_entry, cyc_loop_end = cyc_entry, cyc_wait = 0ull;
@@ -2176,17 +2119,40 @@ __global__ __launch_bounds__(kVerifyMaxThreads, 6) void k_verify(VerifyParams P)
   const uint32_t lo = 0u, hi = blockIdx.x < C ? (C - blockIdx.x + gridDim.x - 1u) / gridDim.x : 0u;
   uint32_t bc = 0, bi = kNil; unsigned long long bt = ~0ull;                // this wave's / thread's best
   if (lo < hi && P.ablate != 2) {                          // (uniform) otherwise: more workgroups than candidates
-    if (threadIdx.x == 0) { s_next = lo; s_pruned = 0u; S.heavy.n = 0u; S.heavy.hits = 0u; }
+    if (threadIdx.x == 0) { s_next = lo; s_pruned = 0u; }
     LcpTask K;
     K.q4 = P.q4v; K.n_q = P.n_q; K.qq = P.qq; K.T = P.cand_T; K.t_stride = kCandStride; K.point_tests = &P.ctr->point_tests;
     K.prune = P.prune; K.pruned = &s_pruned;
     if (LEAN) stage_queries_f(P.qsoa, const_cast<float*>(LL.qx), 3u * n_pad);
     else if (QLDS) stage_queries(K, s_q);
     stage_coarse(P.grid, s_coarse);                        // ends with a workgroup barrier
-    // A candidate is one 64-byte record {3x4 transform | tag, quad index}: one line, everything the wave needs of it.  (Holding
-    // the NEXT candidate's record in registers while the current one is swept was measured: 16 more VGPRs, no gain.)
+    // A candidate is one 64-byte record {3x4 transform | tag, quad index}.  The wave holds TWO tickets: the record of the next
+    // candidate is in flight while the current one is swept, so the chain "ticket -> record -> transform" (three dependent
+    // memory round trips per candidate in the round-3 kernel: transform, quad index, tag) is off the critical path.
+    auto take = [&]() -> uint32_t {
+      uint32_t t = 0;
+      if (lane == 0) t = atomicAdd(&s_next, 1u);
+      return uint32_t(__builtin_amdgcn_readfirstlane(int(t)));
+    };
     cyc_staged = S4P_CYC_NOW();
-    auto settle = [&](const uint32_t i, const float4 r3, const uint32_t cnt) {     // count of candidate i is final: record it, compare
+    uint32_t t_cur = take();
+    float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0, r3 = r0;
+    if (t_cur < hi) { const float4* rec = P.cand_T + kCandStride * size_t(blockIdx.x + t_cur * gridDim.x); r0 = rec[0]; r1 = rec[1]; r2 = rec[2]; r3 = rec[3]; }
+    while (t_cur < hi) {
+      const uint32_t i = blockIdx.x + t_cur * gridDim.x;
+      const uint32_t t_nxt = take();
+      float4 n0 = r0, n1 = r1, n2 = r2, n3 = r3;
+      if (t_nxt < hi) { const float4* rec = P.cand_T + kCandStride * size_t(blockIdx.x + t_nxt * gridDim.x); n0 = rec[0]; n1 = rec[1]; n2 = rec[2]; n3 = rec[3]; }
+      const float4* src = P.cand_T + kCandStride * size_t(i);         // one candidate per wave
+      uint32_t cnt;
+#if S4P_CYCLE_PROF == 1
+      { const unsigned long long w0 = S4P_CYC_NOW();          // how long the record of THIS candidate keeps the wave waiting
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        cyc_wait += S4P_CYC_NOW() - w0; ++n_cand; }
+#endif
+      if (LEAN) cnt = P.ablate == 1 ? wave_lcp_count_lean<COUNT, true>(P.grid, K, LL, src, r0, r1, r2, CP) : wave_lcp_count_lean<COUNT, false>(P.grid, K, LL, src, r0, r1, r2, CP);
+      else cnt = P.ablate == 1 ? S4P_WAVE_LCP_COUNT<COUNT, true, QLDS>(P.grid, K, s_coarse, s_q, s_queue, src)
+                               : S4P_WAVE_LCP_COUNT<COUNT, false, QLDS>(P.grid, K, s_coarse, s_q, s_queue, src);
       const uint32_t kraw = uint32_t(__builtin_amdgcn_readfirstlane(int(__float_as_uint(r3.z))));
       const uint32_t k = kraw & ~kBorderFlag;
       const unsigned long long tag = (unsigned long long)uint32_t(__builtin_amdgcn_readfirstlane(int(__float_as_uint(r3.x)))) |
@@ -2195,58 +2161,7 @@ __global__ __launch_bounds__(kVerifyMaxThreads, 6) void k_verify(VerifyParams P)
       if (kraw & kBorderFlag) {                              // scored, but the host decides whether it is a candidate at all
         if (lane == 0) { const uint32_t n = atomicAdd(&P.ctr->n_border, 1u); if (n < kBorderCap) P.border[n] = i; }
       } else if (slot_better(cnt, tag, bc, bt, bi != kNil)) { bc = cnt; bt = tag; bi = i; }
-    };
-    while (true) {
-      uint32_t t = 0;
-      if (lane == 0) t = atomicAdd(&s_next, 1u);
-      t = uint32_t(__builtin_amdgcn_readfirstlane(int(t)));
-      if (t >= hi) break;
-      const uint32_t i = blockIdx.x + t * gridDim.x;
-      const float4* src = P.cand_T + kCandStride * size_t(i);         // one candidate per wave
-      const float4 r0 = src[0], r1 = src[1], r2 = src[2], r3 = src[3];
-      uint32_t cnt;
-#if S4P_CYCLE_PROF == 1
-      { const unsigned long long w0 = S4P_CYC_NOW();          // how long the record of THIS candidate keeps the wave waiting
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        cyc_wait += S4P_CYC_NOW() - w0; ++n_cand; }
-#endif
-      if (LEAN) cnt = P.ablate == 1 ? wave_lcp_count_lean<COUNT, true>(P.grid, K, LL, src, r0, r1, r2, i, CP) : wave_lcp_count_lean<COUNT, false>(P.grid, K, LL, src, r0, r1, r2, i, CP);
-      else cnt = P.ablate == 1 ? S4P_WAVE_LCP_COUNT<COUNT, true, QLDS>(P.grid, K, s_coarse, s_q, s_queue, src)
-                               : S4P_WAVE_LCP_COUNT<COUNT, false, QLDS>(P.grid, K, s_coarse, s_q, s_queue, src);
-      if (LEAN && cnt == kLeanDeferred) continue;            // a heavy candidate: finished by the whole workgroup below
-      settle(i, r3, cnt);
-    }
-    if (LEAN) {
-      // The workgroup's deferred candidates, one after the other, all waves together: wave w takes the entries
-      // [128 w, 128 (w + 1)), [128 (w + waves), ...) of the candidate's scratch list -- every exact test of the candidate in
-      // flight at once -- and adds its inliers to an LDS counter; wave 0 settles the candidate.
-      __syncthreads();
-      const uint32_t nh = min(S.heavy.n, kHeavySlots);        // (uniform: LDS)
-      const uint32_t nwaves = blockDim.x >> 6;
-      for (uint32_t h = 0; h < nh; ++h) {
-        const uint32_t i = S.heavy.cand[h];
-        if (i == kNil) continue;                              // (uniform) the slot was taken and its candidate dismissed after all
-        const uint32_t n_ent = S.heavy.n_ent[h];
-        const uint16_t* ent = LL.scratch + size_t(h) * LL.scratch_stride;
-        const float4* src = P.cand_T + kCandStride * size_t(i);
-        uint32_t mine = 0;
-        for (uint32_t b = wave * 128u; b < n_ent; b += nwaves * 128u) {
-          const uint32_t n = min(128u, n_ent - b);
-          const bool va = lane < n, vb = lane + 64u < n;
-          const uint32_t ia = uint32_t(ent[b + min(lane, n - 1u)]), ib = uint32_t(ent[b + min(lane + 64u, n - 1u)]);
-          if (COUNT) { if (lane == 0) atomicAdd(K.point_tests + 2, (unsigned long long)n); }
-          if (P.ablate != 1) {
-            const uint32_t hm = exact_pair_lean<COUNT>(P.grid, K, LL, src, va, ia, vb, ib);
-            mine += uint32_t(__popcll(__builtin_amdgcn_ballot_w64((hm & 1u) != 0u))) + uint32_t(__popcll(__builtin_amdgcn_ballot_w64((hm & 2u) != 0u)));
-          }
-        }
-        if (lane == 0 && mine) atomicAdd(&S.heavy.hits, mine);
-        __syncthreads();
-        if (wave == 0) { const float4 r3 = src[3]; settle(i, r3, S.heavy.hits); }
-        __syncthreads();
-        if (threadIdx.x == 0) S.heavy.hits = 0u;
-        __syncthreads();
-      }
+      t_cur = t_nxt; r0 = n0; r1 = n1; r2 = n2; r3 = n3;
     }
   }
 #if S4P_CYCLE_PROF
