@@ -2083,7 +2083,7 @@ __device__ __forceinline__ bool slot_better(const uint32_t ca, const unsigned lo
 // LEAN (launched when an early-exit bound is in force and the float copy of the sampled Q fits LDS): wave_lcp_count_lean,
 // LDS = coarse bitmap | float queries x, y, z | one 16-bit queue per wave; QLDS is then meaningless (false).
 template <bool COUNT, bool QLDS, bool LEAN>
-__global__ __launch_bounds__(kVerifyMaxThreads, LEAN ? 4 : 6) void k_verify(VerifyParams P) {   // fused: <= 80 VGPRs, six waves per SIMD (two 768-thread workgroups per CU); lean: one workgroup per CU, <= 128
+__global__ __launch_bounds__(kVerifyMaxThreads, 6) void k_verify(VerifyParams P) {   // <= 80 VGPRs: six waves per SIMD, i.e. two 768-thread workgroups per CU (of one launch, or of two lanes)
   extern __shared__ uint32_t s_mem[];
   uint32_t* s_coarse = s_mem;                              // LDS: coarse bitmap | quantised queries (QLDS) | 16 survivor queues
   uint2* s_q = reinterpret_cast<uint2*>(s_mem + P.grid.coarse_words);
@@ -2126,24 +2126,19 @@ __global__ __launch_bounds__(kVerifyMaxThreads, LEAN ? 4 : 6) void k_verify(Veri
     if (LEAN) stage_queries_f(P.qsoa, const_cast<float*>(LL.qx), 3u * n_pad);
     else if (QLDS) stage_queries(K, s_q);
     stage_coarse(P.grid, s_coarse);                        // ends with a workgroup barrier
-    // A candidate is one 64-byte record {3x4 transform | tag, quad index}.  The wave holds TWO tickets: the record of the next
-    // candidate is in flight while the current one is swept, so the chain "ticket -> record -> transform" (three dependent
-    // memory round trips per candidate in the round-3 kernel: transform, quad index, tag) is off the critical path.
-    auto take = [&]() -> uint32_t {
+    // A candidate is one 64-byte record {3x4 transform | tag, quad index}: one line, everything the wave needs of it.  (Holding
+    // the NEXT candidate's record in registers while the current one is swept was measured in round 4: 16 more VGPRs, no gain;
+    // so was finishing "heavy" candidates -- those that stay alive through the whole sweep -- by the whole workgroup after the
+    // ticket loop: slower, most of them die in their first exact batch.  profiles/HISTORY.md.)
+    cyc_staged = S4P_CYC_NOW();
+    while (true) {
       uint32_t t = 0;
       if (lane == 0) t = atomicAdd(&s_next, 1u);
-      return uint32_t(__builtin_amdgcn_readfirstlane(int(t)));
-    };
-    cyc_staged = S4P_CYC_NOW();
-    uint32_t t_cur = take();
-    float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0, r3 = r0;
-    if (t_cur < hi) { const float4* rec = P.cand_T + kCandStride * size_t(blockIdx.x + t_cur * gridDim.x); r0 = rec[0]; r1 = rec[1]; r2 = rec[2]; r3 = rec[3]; }
-    while (t_cur < hi) {
-      const uint32_t i = blockIdx.x + t_cur * gridDim.x;
-      const uint32_t t_nxt = take();
-      float4 n0 = r0, n1 = r1, n2 = r2, n3 = r3;
-      if (t_nxt < hi) { const float4* rec = P.cand_T + kCandStride * size_t(blockIdx.x + t_nxt * gridDim.x); n0 = rec[0]; n1 = rec[1]; n2 = rec[2]; n3 = rec[3]; }
+      t = uint32_t(__builtin_amdgcn_readfirstlane(int(t)));
+      if (t >= hi) break;
+      const uint32_t i = blockIdx.x + t * gridDim.x;
       const float4* src = P.cand_T + kCandStride * size_t(i);         // one candidate per wave
+      const float4 r0 = src[0], r1 = src[1], r2 = src[2], r3 = src[3];
       uint32_t cnt;
 #if S4P_CYCLE_PROF == 1
       { const unsigned long long w0 = S4P_CYC_NOW();          // how long the record of THIS candidate keeps the wave waiting
@@ -2161,7 +2156,6 @@ __global__ __launch_bounds__(kVerifyMaxThreads, LEAN ? 4 : 6) void k_verify(Veri
       if (kraw & kBorderFlag) {                              // scored, but the host decides whether it is a candidate at all
         if (lane == 0) { const uint32_t n = atomicAdd(&P.ctr->n_border, 1u); if (n < kBorderCap) P.border[n] = i; }
       } else if (slot_better(cnt, tag, bc, bt, bi != kNil)) { bc = cnt; bt = tag; bi = i; }
-      t_cur = t_nxt; r0 = n0; r1 = n1; r2 = n2; r3 = n3;
     }
   }
 #if S4P_CYCLE_PROF

@@ -77,19 +77,30 @@ def sphere_cloud(n, seed):
     return d.astype(np.float32)
 
 
-def lidar_pair(n_points, delta=0.05, seed=5, extent=60.0, n_boxes=120, n_cyl=30, yaw_deg=30.0, shift=10.0,
-               first_scan_points=None, second_scan_points=None):
-    """Config-4 style pair: two simulated terrestrial scans of one scene (ground plane, axis-aligned
-    boxes, vertical cylinders) from poses `shift` metres apart and `yaw_deg` apart, ~1/r^2 density, range noise
-    sigma = delta.  Returns (P, Q, T_gt) with Q expressed in the second scanner's frame."""
+def lidar_pair(n_points, delta=0.05, seed=5, extent=30.0, n_boxes=200, n_cyl=50, yaw_deg=30.0, shift=10.0,
+               first_scan_points=None, second_scan_points=None, ground_fraction=0.3):
+    """Config-4 style pair: two simulated terrestrial scans of one scene (ground plane, 200 axis-aligned boxes
+    with roofs, 50 vertical cylinders) from poses `shift` metres apart and `yaw_deg` apart, ~1/r^2 density, range noise
+    sigma = delta.  Returns (P, Q, T_gt) with Q expressed in the second scanner's frame.
+
+    Round 4: the scene is 30 m across instead of 60 m and the ground carries 30 % of the returns instead of 50 %.  With
+    delta = 0.05 m the sampled Q (sample_size 20 000) has to be about as dense as delta for a congruent base to exist at all
+    (4PCS assumes sample spacing ~ delta): on the 60 m scene a sampled point had a partner within 2 delta with probability
+    ~0.01 per base point, 1466 trials verified 403 candidates and the registration ended on a pose that slid along the ground
+    plane.  On the denser scene the reference's estimator recovers the generator's pose (tests/test_gpu_configs.py).
+    Feature sizes scale with extent / 30, so a reduced-scale case (extent ~ sqrt(scale), sample ~ scale) keeps the density."""
     rng = np.random.default_rng(seed)
-    boxes = np.concatenate([rng.uniform(-extent / 2, extent / 2, (n_boxes, 2)), rng.uniform(1.5, 6.0, (n_boxes, 3))], axis=1)
-    cyls = np.concatenate([rng.uniform(-extent / 2, extent / 2, (n_cyl, 2)), rng.uniform(0.2, 0.8, (n_cyl, 1)), rng.uniform(3, 10, (n_cyl, 1))], axis=1)
+    k = extent / 30.0
+    boxes = np.concatenate([rng.uniform(-extent / 2, extent / 2, (n_boxes, 2)), rng.uniform(0.8 * k, 3.5 * k, (n_boxes, 2)),
+                            rng.uniform(1.5 * k, 8.0 * k, (n_boxes, 1))], axis=1)
+    cyls = np.concatenate([rng.uniform(-extent / 2, extent / 2, (n_cyl, 2)), rng.uniform(0.15 * k, 0.6 * k, (n_cyl, 1)),
+                           rng.uniform(3 * k, 10 * k, (n_cyl, 1))], axis=1)
+    eye = 1.8 * k
 
     def surface_samples(n):
         pts = []
-        ng = n // 2
-        r = extent / 2 * np.sqrt(rng.uniform(0, 1, ng)) ** 1.5          # denser near the centre
+        ng = int(n * ground_fraction)
+        r = extent / 2 * np.sqrt(rng.uniform(0, 1, ng))
         a = rng.uniform(0, 2 * np.pi, ng)
         pts.append(np.stack([r * np.cos(a), r * np.sin(a), np.zeros(ng)], 1))
         nb = n - ng
@@ -98,10 +109,11 @@ def lidar_pair(n_points, delta=0.05, seed=5, extent=60.0, n_boxes=120, n_cyl=30,
         out = np.zeros((nb, 3))
         isb = which < n_boxes
         b = boxes[np.minimum(which, n_boxes - 1)]
-        face = rng.integers(0, 4, nb)
+        face = rng.integers(0, 5, nb)                                   # four walls and the roof
         bx = np.where(face < 2, (face * 2 - 1) * 0.5 * b[:, 2], u * b[:, 2])
-        by = np.where(face < 2, v * b[:, 3], ((face - 2) * 2 - 1) * 0.5 * b[:, 3])
-        out[isb] = np.stack([b[:, 0] + bx, b[:, 1] + by, w * b[:, 4]], 1)[isb]
+        by = np.where(face < 2, v * b[:, 3], np.where(face < 4, ((face - 2) * 2 - 1) * 0.5 * b[:, 3], v * b[:, 3]))
+        bz = np.where(face == 4, b[:, 4], w * b[:, 4])
+        out[isb] = np.stack([b[:, 0] + bx, b[:, 1] + by, bz], 1)[isb]
         c = cyls[np.clip(which - n_boxes, 0, n_cyl - 1)]
         th = 2 * np.pi * (u + 0.5)
         out[~isb] = np.stack([c[:, 0] + c[:, 2] * np.cos(th), c[:, 1] + c[:, 2] * np.sin(th), w * c[:, 3]], 1)[~isb]
@@ -112,13 +124,13 @@ def lidar_pair(n_points, delta=0.05, seed=5, extent=60.0, n_boxes=120, n_cyl=30,
         if n <= 0:
             return np.zeros((0, 3))
         got, have = [], 0
-        while have < n:                                              # range-dependent thinning keeps ~1/3: draw until n
+        while have < n:                                              # range-dependent thinning: draw until n
             S = surface_samples(min(max(n, 1 << 16), 1 << 22))
-            d = np.linalg.norm(S - np.array([pose_xy[0], pose_xy[1], 1.8]), axis=1)
-            keep = rng.uniform(0, 1, len(S)) < np.clip((6.0 / np.maximum(d, 1.0)) ** 1.2, 0, 1)
+            d = np.linalg.norm(S - np.array([pose_xy[0], pose_xy[1], eye]), axis=1)
+            keep = rng.uniform(0, 1, len(S)) < np.clip((6.0 * k / np.maximum(d, 1.0 * k)) ** 1.2, 0, 1)
             got.append(S[keep]); have += int(keep.sum())
         S = np.concatenate(got)[:n]
-        dirs = S - np.array([pose_xy[0], pose_xy[1], 1.8])
+        dirs = S - np.array([pose_xy[0], pose_xy[1], eye])
         dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
         return S + dirs * rng.normal(scale=delta, size=(len(S), 1))
 
@@ -132,12 +144,30 @@ def lidar_pair(n_points, delta=0.05, seed=5, extent=60.0, n_boxes=120, n_cyl=30,
     return P.astype(np.float32), Q.astype(np.float32), T
 
 
-def part_in_whole_pair(n_scene, n_query, delta=0.05, seed=9, radius=7.0, spot=(4.0, 3.0, 1.0)):
+def lidar_pair_scaled(scale, delta=0.05, seed=5, **kw):
+    """The configs[3] pair at a fraction of its size, geometrically similar (every length x sqrt(scale): scene 30 m, poses
+    10 m apart, box and cylinder sizes; same 200 boxes and 50 cylinders) with 5 M x scale returns per scan: same point
+    density, same structure per square metre of sample.  Only delta (the noise) is not scaled.  Use with a sample of
+    20 000 x scale."""
+    r = float(np.sqrt(scale))
+    return lidar_pair(int(5_000_000 * scale), delta=delta, seed=seed, extent=30.0 * r, shift=10.0 * r, **kw)
+
+
+def part_in_whole_scaled(scale, delta=0.05, seed=9):
+    """configs[4] at a fraction of its size, geometrically similar (lengths x sqrt(scale), incl. the 3 m ball of the query):
+    10 M x scale scene points, 100 k x scale query points.  Use with a sample of 5000 x scale."""
+    r = float(np.sqrt(scale))
+    return part_in_whole_pair(int(10_000_000 * scale), int(100_000 * scale), delta=delta, seed=seed, radius=3.0 * r,
+                              spot=(2.0 * r, 1.5 * r, 1.0 * r), extent=30.0 * r, shift=10.0 * r)
+
+
+def part_in_whole_pair(n_scene, n_query, delta=0.05, seed=9, radius=3.0, spot=(2.0, 1.5, 1.0), extent=30.0, shift=10.0, n_boxes=200, n_cyl=50):
     """Config-5 style pair (BASELINE.json configs[4]): a `n_query`-point query cut out of a second scan (everything
-    within `radius` metres of `spot`, in world coordinates) against a `n_scene`-point scene; P = scene, Q = query in
-    the second scanner's frame.  Returns (P, Q, T_gt)."""
-    P, _, T = lidar_pair(n_scene, delta=delta, seed=seed, second_scan_points=0)
-    _, Qfull, _ = lidar_pair(max(24 * n_query, 1 << 16), delta=delta, seed=seed, first_scan_points=0)   # same scene, same poses
+    within `radius` metres of `spot`, in world coordinates: SURVEY.md 8d's 3 m ball) against a `n_scene`-point scene;
+    P = scene, Q = query in the second scanner's frame.  Returns (P, Q, T_gt)."""
+    P, _, T = lidar_pair(n_scene, delta=delta, seed=seed, second_scan_points=0, extent=extent, shift=shift, n_boxes=n_boxes, n_cyl=n_cyl)
+    _, Qfull, _ = lidar_pair(max(24 * n_query, 1 << 16), delta=delta, seed=seed, first_scan_points=0, extent=extent, shift=shift,
+                             n_boxes=n_boxes, n_cyl=n_cyl)   # same scene, same poses
     Qw = Qfull.astype(np.float64) @ T[:3, :3].T + T[:3, 3]
     near = np.nonzero(np.linalg.norm(Qw - np.asarray(spot), axis=1) < radius)[0]
     if len(near) > n_query:
