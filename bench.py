@@ -343,6 +343,27 @@ def pmc_passes(args, timeout_s=240):
     return got, note
 
 
+def extra_sample_line(args, sample=20000, timeout_s=240):
+    """SURVEY 8d's other sample size of the benchmarked clouds (n = 20 000 sampled Q points: ~27 M pairs and ~10^9 congruent quads
+    per base, every base chunked) as a second, reported figure of the driver's own command: one warm-up base + one timed base
+    in a process of its own, no oracle (the parity of that size is tests/test_gpu_configs.py::test_config2_gpu_scale_sample_20000
+    and `bench.py --sample 20000` with its own gate)."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--sample", str(sample), "--steps", "1", "--warmup", "1", "--repeats", "1", "--points", str(args.points),
+           "--no-parity", "--cpu-seconds", "0", "--no-pmc", "--no-hbm-point", "--no-time-to-register", "--no-stage-pass", "--no-instrumented",
+           "--no-exclusive", "--no-full-count-mode", "--no-extra"]
+    t0 = time.perf_counter()
+    try:
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=timeout_s, check=True)
+        line = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][-1]
+        d = json.loads(line)
+        return {"sample_size": sample, "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"], "warmup": d["warmup"],
+                "n_Q": d["config"]["n_Q"], "candidates_timed": d["config"]["candidates_timed"], "chunked_bases": d["config"]["chunked_bases"],
+                "k_verify": (d.get("provenance") or {}).get("k_verify"), "wall_s": time.perf_counter() - t0,
+                "note": "same clouds, sample_size %d: one timed base after one warm-up base, separate process; reported, not `value`" % sample}
+    except Exception as e:                                      # noqa: BLE001 -- the bench line must still be printed
+        return {"sample_size": sample, "error": "%s" % type(e).__name__, "wall_s": time.perf_counter() - t0}
+
+
 def part_in_whole_structure(device, n_transforms, seed=11):
     """BASELINE configs[4]'s structure (100 k-point query in a 10 M-point scene: n_P ~ 4.2 M sampled scene points -> ~1.4 GB
     of point lines, >> the 256 MB Infinity Cache) and a batch of transforms that slide the query over the WHOLE scene
@@ -484,6 +505,8 @@ def main():
     ap.add_argument("--hbm-transforms", type=int, default=4096)
     ap.add_argument("--points", type=int, default=N_POINTS)
     ap.add_argument("--sample", type=int, default=SAMPLE)
+    ap.add_argument("--no-extra", dest="extra", action="store_false", default=True,
+                    help="skip the `extra` object: the same clouds at SURVEY 8d's GPU-scale sample (n = 20 000), two bases, in a process of its own")
     args = ap.parse_args()
 
     scale_mode = args.sample > 5000          # the "GPU-scale" sample: bases of ~10^9 quads, seconds per base
@@ -631,6 +654,13 @@ def main():
     final_info = info                           # state after the last repeat's windows (N > 1: compared across ranks below)
     chunk_stats = m.chunk_stats()
     lane_growths = m.capacity_growths()
+    # which code produced this line: commit + source digest stamped at build time, the k_verify instantiation the loop launches
+    import hashlib
+    from super4pcs_amd import build as _build
+    provenance = dict(_build.build_info(), k_verify=m.verify_kernel_info(),
+                      bench_py_sha16=hashlib.sha256(open(os.path.abspath(__file__), "rb").read()).hexdigest()[:16],
+                      library=os.environ.get("S4P_LIB", "super4pcs_amd/lib/libsuper4pcs_amd.so"),
+                      env={k: v for k, v in os.environ.items() if k.startswith("S4P_")})
     if hasattr(sh, "close"):
         sh.close()
     m.close()
@@ -903,10 +933,11 @@ def main():
                            "launch of the timed bases; FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B), uncalibrated for 16-B gathers; "
                            "counts L2 -> fabric requests including Infinity-Cache hits" % (args.warmup, args.steps),
                 "algorithmic_bytes_per_candidate": gather_b,
-                "definition": "achieved = gather bytes the three-level structure requires per candidate (8 B reach word per L0 survivor, 32 B header + "
-                              "16 B query per L1 survivor, 48 B per group of four points a mask survivor walks, 64 B candidate record; fractions measured "
-                              "by an instrumented replay of the timed bases IN THE TIMED MODE: with the early exit, queries a candidate never gets to are "
-                              "not counted) x candidates of the timed bases / timed seconds: the per-step figure, "
+                "definition": "achieved = gather bytes the three-level structure requires per candidate (8 B reach word per L0 survivor whose candidate "
+                              "outlives its LDS-only sweep, 32 B header per reach survivor that enters an exact batch, 48 B per group of four points a "
+                              "mask survivor walks, 64 B candidate record; counted by an instrumented replay of the timed bases IN THE TIMED MODE: what "
+                              "is FETCHED -- a candidate the bound dismisses after its sweep has fetched only its record) x candidates of the timed "
+                              "bases / timed seconds: the per-step figure, "
                               "independent of how many bases are in flight.  The working set (point lines ~19 MB) is Infinity-Cache resident, so this is "
                               "priced against a roof the kernel is NOT bound by -- `binding` names the resource closest to its roof.  DESIGN.md section 7.",
                 "binding": {"resource": binding, "fracs": fracs},
@@ -924,7 +955,8 @@ def main():
                                    exclusive, achieved=exclusive["candidates_per_launch"] * gather_b / (exclusive["avg_launch_ms"] * 1e-3) / 1e9,
                                    frac=exclusive["candidates_per_launch"] * gather_b / (exclusive["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                    note="same bases with one base in flight (S4P_LANES=1): k_verify's own launch time")},
-                "lds_sweep": {"bytes_per_candidate": sweep_b, "note": "8 B per query out of the workgroup's LDS copy of the quantised queries"},
+                "lds_sweep": {"bytes_per_candidate": sweep_b * 1.5, "note": "12 B per query out of the workgroup's LDS copy of the float queries "
+                              "(lean sweep) + one 4-byte word of the LDS-resident coarse bitmap; never leaves the CU"},
                 "survey_8d_model": {"bytes_per_candidate": survey_b, "GBps": value * survey_b / 1e9,
                                     "note": "SURVEY.md 8d figure (27 cells x 8 B per query, no cache credit): a cell-probing kernel this one "
                                             "replaced; kept for reference, not a roofline fraction"},
@@ -942,6 +974,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(P, Q, args.cpu_seconds, args.sample, ttr["candidates_verified"] if ttr else 0)
         else:
             out["cpu_baseline"] = None
+        out["provenance"] = provenance
+        out["extra"] = extra_sample_line(args) if (world == 1 and args.extra and not scale_mode and not args.inner) else None
         def clean(o):                                           # (no NaN in the JSON line: a figure that was not measured is null)
             if isinstance(o, dict):
                 return {k: clean(v) for k, v in o.items()}

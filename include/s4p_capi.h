@@ -88,6 +88,9 @@ int32_t s4p_create(const s4p_options* opt, const s4p_limits* limits /*nullable*/
 void    s4p_destroy(s4p_ctx* ctx);
 const char* s4p_last_error(const s4p_ctx* ctx);   /* ctx may be NULL: last create error */
 int32_t s4p_device_name(const s4p_ctx* ctx, char* buf, int32_t buflen);
+/* Which k_verify instantiation the trial loops launch on the clouds that are set, with its grid, block and LDS sizes
+ * (measurement provenance; no reference counterpart). */
+int32_t s4p_verify_kernel_info(const s4p_ctx* ctx, char* buf, int32_t buflen);
 
 /* Device buffer capacities follow the data, as the reference's std::vectors do (super4pcs.cc:166-174, :196,
  * match4pcsBase.hpp:340-351):

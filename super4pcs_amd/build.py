@@ -44,11 +44,57 @@ def _compile(out, defines=(), verbose=False):
     return out
 
 
+def source_digest():
+    """sha256 over the device / host sources and the two C-ABI headers (sorted by name): ties a measurement to the code that
+    produced it (the GPU box has no .git; tests/test_profiles_consistency.py recomputes it from the recorded commit)."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join("super4pcs_amd", "csrc", f) for f in os.listdir(CSRC)) + ["include/s4p_capi.h", "include/s4p_matcher.h"]
+    for rel in files:
+        h.update(rel.encode())
+        with open(os.path.join(ROOT, rel), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+BUILD_INFO = os.path.join(LIBDIR, "BUILD_INFO.json")
+
+
+def _stamp():
+    """lib/BUILD_INFO.json: the commit the library was built at (dirty = sources differ from that commit) and the source digest."""
+    import json
+    sha, dirty = None, None
+    try:
+        sha = subprocess.check_output(["git", "rev-parse", "HEAD"], cwd=ROOT, stderr=subprocess.DEVNULL).decode().strip()
+        dirty = bool(subprocess.check_output(["git", "status", "--porcelain", "--", "super4pcs_amd/csrc", "include"], cwd=ROOT,
+                                             stderr=subprocess.DEVNULL).decode().strip())
+    except Exception:                                              # noqa: BLE001 -- no git here (the GPU box): keep what the dev box stamped
+        if os.path.exists(BUILD_INFO):
+            return
+    with open(BUILD_INFO, "w") as fh:
+        json.dump({"git_sha": sha, "dirty": dirty, "source_sha16": source_digest()}, fh)
+
+
+def build_info():
+    import json
+    try:
+        with open(BUILD_INFO) as fh:
+            info = json.load(fh)
+    except Exception:                                              # noqa: BLE001
+        info = {"git_sha": None, "dirty": None, "source_sha16": None}
+    info["source_sha16_now"] = source_digest()                     # must equal source_sha16: the sources the .so was built from
+    return info
+
+
 def build(force=False, verbose=False):
     if not force and not needs_build():
+        if not os.path.exists(BUILD_INFO):
+            _stamp()
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
-    return _compile(LIB, (), verbose)
+    out = _compile(LIB, (), verbose)
+    _stamp()
+    return out
 
 
 def build_variant(name, defines):

@@ -22,7 +22,7 @@ EXPORTED_SYMBOLS = [
     "s4p_extract_pairs", "s4p_find_congruent", "s4p_try_congruent_set", "s4p_verify_transforms", "s4p_verify_transforms_counted",
     "s4p_transform_points_device", "s4p_apply_bench", "s4p_select_base_points", "s4p_grow_limits", "s4p_get_limits", "s4p_try_base", "s4p_last_verified", "s4p_try_base_async", "s4p_try_base_wait", "s4p_pair_state_words", "s4p_pair_state_save", "s4p_pair_state_restore", "s4p_stage_slots", "s4p_pipeline_depth", "s4p_stage_base", "s4p_try_base_staged_async", "s4p_skip_base", "s4p_last_candidates", "s4p_transform_points", "s4p_profile_enable", "s4p_profile_get",
     "s4p_selftest_ieee", "s4p_set_quad_chunking", "s4p_chunk_stats", "s4p_set_auto_grow", "s4p_lane_growths", "s4p_border_stats", "s4p_set_clouds_timing", "s4p_set_best_hint", "s4p_select_base_points_batch", "s4p_select_batch_max", "s4p_set_quad_slice", "s4p_quad_mix",
-    "s4p_set_candidate_sink", "s4p_keep_candidate_records",
+    "s4p_set_candidate_sink", "s4p_keep_candidate_records", "s4p_verify_kernel_info",
 ]
 
 
@@ -512,6 +512,13 @@ class Matcher:
         rc = self.L.s4p_set_quad_slice(self.ctx_handle(), int(part), int(parts))
         if rc != S4P_OK:
             raise S4PError(rc, self.L.s4p_last_error(self.ctx_handle()).decode())
+
+    def verify_kernel_info(self):
+        buf = C.create_string_buffer(1024)
+        self.L.s4p_verify_kernel_info.restype = C.c_int32
+        self.L.s4p_verify_kernel_info.argtypes = [C.c_void_p, C.c_char_p, C.c_int32]
+        self.L.s4p_verify_kernel_info(self.ctx_handle(), buf, 1024)
+        return buf.value.decode()
 
     def set_quad_chunking(self, enable=True, grow_cap_quads=0):
         rc = self.L.s4p_set_quad_chunking(self.ctx_handle(), int(enable), int(grow_cap_quads))

@@ -84,7 +84,8 @@ struct s4p_ctx {
   DevBuf<uint2> greach; DevBuf<uint4> glist_hdr; DevBuf<uint32_t> gcoarse; DevBuf<float4> gnbr; DevBuf<float4> q4, q4v;
   DevBuf<uint2> qquant; QuantQ qq{}; bool qlds = false;      // 16-bit copy of the Morton-ordered queries for the LDS-resident sweep
   DevBuf<unsigned long long> cyc;                            // S4P_CYCLE_PROF lab builds: per-phase cycle sums of the lean k_verify (printed at s4p_destroy)
-  DevBuf<float> qsoa; bool lean = false;                     // float copy x | y | z of the same, padded (the lean sweep of k_verify: early-exit mode)
+  DevBuf<float> qsoa; bool lean = false, lean_lds = false;   // lean_lds: the float copy fits LDS (else the lean sweep reads q4v from global memory)
+                      // float copy x | y | z of the same, padded (the lean sweep of k_verify: early-exit mode)
   DevBuf<float> qx, qy, qz, ux, uy, uz, qnx, qny, qnz, qcr, qcg, qcb;
   // Lanes = HIP streams with private per-base device buffers.  Consecutive bases rotate over the lanes, so the
   // small kernels of base t+1 (pairs, hash build, quad enumeration) run concurrently with the
@@ -207,7 +208,7 @@ struct s4p_ctx {
     return gcoarse.n * 4 + (qlds ? size_t((n_q + kSweepStep - 1u) & ~(kSweepStep - 1u)) * 8 : 0) + size_t(verify_threads / 64) * kQueueWordsPerWave * 4 + sizeof(VerifyShared);
   }
   size_t lean_lds_bytes() const {
-    return gcoarse.n * 4 + size_t((n_q + kSweepStep - 1u) & ~(kSweepStep - 1u)) * 12 + size_t(verify_threads / 64) * kLeanQueue * 2 + sizeof(VerifyShared);
+    return gcoarse.n * 4 + (lean_lds ? size_t((n_q + kSweepStep - 1u) & ~(kSweepStep - 1u)) * 12 : 0) + size_t(verify_threads / 64) * kLeanQueue * 2 + sizeof(VerifyShared);
   }
   bool use_lean() const { return lean && best_hint != 0u; }
   // (a chunk pass scores ~10^7 candidates with the chip to itself: two workgroups per CU, as for the HBM-bound structure;
@@ -453,7 +454,8 @@ int32_t launch_verify(s4p_ctx* c, const BaseFrame& bf) {
   const bool lean = c->use_lean();                           // a bound is in force: the lean sweep (s4p_kernels.hip.hpp)
   const size_t lds = lean ? c->lean_lds_bytes() : c->verify_lds_bytes();
   const dim3 grid(c->verify_grid()), block(c->verify_threads);
-  if (lean) { if (c->prof_points) hipLaunchKernelGGL((k_verify<true, false, true>), grid, block, lds, vs, V); else hipLaunchKernelGGL((k_verify<false, false, true>), grid, block, lds, vs, V); }
+  if (lean && c->lean_lds) { if (c->prof_points) hipLaunchKernelGGL((k_verify<true, true, true>), grid, block, lds, vs, V); else hipLaunchKernelGGL((k_verify<false, true, true>), grid, block, lds, vs, V); }
+  else if (lean) { if (c->prof_points) hipLaunchKernelGGL((k_verify<true, false, true>), grid, block, lds, vs, V); else hipLaunchKernelGGL((k_verify<false, false, true>), grid, block, lds, vs, V); }
   else if (c->prof_points) { if (c->qlds) hipLaunchKernelGGL((k_verify<true, true, false>), grid, block, lds, vs, V); else hipLaunchKernelGGL((k_verify<true, false, false>), grid, block, lds, vs, V); }
   else { if (c->qlds) hipLaunchKernelGGL((k_verify<false, true, false>), grid, block, lds, vs, V); else hipLaunchKernelGGL((k_verify<false, false, false>), grid, block, lds, vs, V); }
   if (c->prof_events) HIPCHK(c, hipEventRecord(c->ev[c->cur][1], vs));
@@ -926,7 +928,7 @@ int32_t s4p_create(const s4p_options* opt, const s4p_limits* lim, int32_t device
   {  // allow the verify kernels their dynamic LDS (coarse bitmap + quantised queries + survivor queues)
     const int max_lds = kVerifyLdsOnePerCu + int(sizeof(VerifyShared));
     const void* fns[] = {(const void*)k_verify<false, false, false>, (const void*)k_verify<false, true, false>, (const void*)k_verify<true, false, false>, (const void*)k_verify<true, true, false>,
-                         (const void*)k_verify<false, false, true>, (const void*)k_verify<true, false, true>,
+                         (const void*)k_verify<false, false, true>, (const void*)k_verify<true, false, true>, (const void*)k_verify<false, true, true>, (const void*)k_verify<true, true, true>,
                          (const void*)k_verify_T<false, false>, (const void*)k_verify_T<false, true>, (const void*)k_verify_T<true, false>, (const void*)k_verify_T<true, true>};
     for (const void* fn : fns)
       if ((e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds)) != hipSuccess) return fail(e, "hipFuncSetAttribute");
@@ -1070,6 +1072,21 @@ int32_t s4p_device_name(const s4p_ctx* c, char* buf, int32_t buflen) {
   return S4P_OK;
 }
 
+// Which k_verify instantiation the trial loops launch on the clouds that are set, and how (measurement provenance: the
+// bench line records it next to the commit): e.g. "k_verify<false, true, true> lean sweep, queries in LDS; 256 x 768 threads, 77.1 KB LDS".
+int32_t s4p_verify_kernel_info(const s4p_ctx* c, char* buf, int32_t buflen) {
+  if (!c || !buf || buflen <= 0) return S4P_ERR_BAD_ARG;
+  if (!c->clouds_set) { snprintf(buf, size_t(buflen), "no clouds set"); return S4P_OK; }
+  const char* loop = c->lean ? (c->lean_lds ? "k_verify<false, true, true> lean sweep (coarse-only, 16-bit queue entries), float queries in LDS"
+                                            : "k_verify<false, false, true> lean sweep (coarse-only, 16-bit queue entries), queries from global memory")
+                             : (c->qlds ? "k_verify<false, true, false> fused/staged sweep, quantised queries in LDS" : "k_verify<false, false, false> fused/staged sweep, float queries from global memory");
+  const char* full = c->qlds ? "k_verify<false, true, false>" : "k_verify<false, false, false>";
+  snprintf(buf, size_t(buflen), "with an early-exit bound: %s; full counts: %s (S4P_SWEEP_STAGED=%d, S4P_SWEEP_CHUNKS=%d, S4P_LEAN_MFMA=%d); %u x %d threads, %.1f KB LDS (lean) / %.1f KB (fused)",
+           loop, full, int(S4P_SWEEP_STAGED), int(S4P_SWEEP_CHUNKS), int(S4P_LEAN_MFMA), c->verify_blocks, c->verify_threads,
+           double(c->lean ? c->lean_lds_bytes() : 0) / 1024.0, double(c->verify_lds_bytes()) / 1024.0);
+  return S4P_OK;
+}
+
 namespace {
 // exclusive scan of v[0..n) in place on stream st, *total = the sum (k_scan_* in s4p_kernels.hip.hpp); tmp: >= n / kScanTile + 1 words
 void launch_scan(uint32_t* v, uint32_t n, uint32_t* total, uint32_t* tmp, hipStream_t st) {
@@ -1198,10 +1215,12 @@ int32_t s4p_set_clouds(s4p_ctx* c, const float* px, const float* py, const float
       key[size_t(i)] = spread(a) | (spread(b) << 1) | (spread(d) << 2);
     }
     std::sort(ord.begin(), ord.end(), [&](uint32_t x, uint32_t y) { return key[x] < key[y]; });
-    std::vector<float4> qv((size_t)n_q);
+    // (padded to a multiple of a sweep step with far-away points: the lean sweep of k_verify reads whole steps)
+    const size_t n_pad_q = size_t((n_q + int64_t(kSweepStep) - 1) & ~(int64_t(kSweepStep) - 1));
+    std::vector<float4> qv(n_pad_q, make_float4(kLeanPad, kLeanPad, kLeanPad, 0.f));
     for (int64_t i = 0; i < n_q; ++i) qv[size_t(i)] = q4[ord[size_t(i)]];
-    HIPCHK(c, c->q4v.alloc(size_t(n_q)));
-    HIPCHK(c, hipMemcpy(c->q4v.p, qv.data(), size_t(n_q) * sizeof(float4), hipMemcpyHostToDevice));
+    HIPCHK(c, c->q4v.alloc(n_pad_q));
+    HIPCHK(c, hipMemcpy(c->q4v.p, qv.data(), n_pad_q * sizeof(float4), hipMemcpyHostToDevice));
     // 16-bit quantisation of the same points over their bounding box, for the sweep's LDS copy (s4p_kernels.hip.hpp,
     // "LCP scoring").  Used when the sample fits the LDS budget and half a quantisation step stays below 0.004 cell
     // (the structure's slack is 0.01 cell); otherwise the sweep reads the float points from global memory.
@@ -1234,14 +1253,19 @@ int32_t s4p_set_clouds(s4p_ctx* c, const float* px, const float* py, const float
     HIPCHK(c, hipMemcpy(c->qquant.p, packed.data(), size_t(n_q) * sizeof(uint2), hipMemcpyHostToDevice));
     c->qq.packed = c->qquant.p;
     // float copy for the lean sweep (early-exit mode): x | y | z, each padded to a multiple of a sweep step with far-away points
-    c->lean = false; c->qsoa.free();
-    if (n_q <= int64_t(kLeanMaxQueries) && getenv("S4P_NO_LEAN") == nullptr) {
-      const size_t n_pad = size_t((n_q + int64_t(kSweepStep) - 1) & ~(int64_t(kSweepStep) - 1));
-      std::vector<float> soa(3 * n_pad, kLeanPad);
-      for (int64_t i = 0; i < n_q; ++i) { soa[size_t(i)] = qv[size_t(i)].x; soa[n_pad + size_t(i)] = qv[size_t(i)].y; soa[2 * n_pad + size_t(i)] = qv[size_t(i)].z; }
-      HIPCHK(c, c->qsoa.alloc(3 * n_pad));
-      HIPCHK(c, hipMemcpy(c->qsoa.p, soa.data(), 3 * n_pad * sizeof(float), hipMemcpyHostToDevice));
-      c->lean = c->gcoarse.n * 4 + n_pad * 12 + size_t(c->verify_threads / 64) * kLeanQueue * 2 <= lds_room;
+    c->lean = false; c->lean_lds = false; c->qsoa.free();
+    if (getenv("S4P_NO_LEAN") == nullptr) {
+      const size_t n_pad = n_pad_q;
+      const size_t fixed = c->gcoarse.n * 4 + size_t(c->verify_threads / 64) * kLeanQueue * 2;
+      if (n_q <= int64_t(kLeanMaxQueries) && fixed + n_pad * 12 <= lds_room && getenv("S4P_LEAN_GLOBAL") == nullptr) {
+        std::vector<float> soa(3 * n_pad, kLeanPad);
+        for (int64_t i = 0; i < n_q; ++i) { soa[size_t(i)] = qv[size_t(i)].x; soa[n_pad + size_t(i)] = qv[size_t(i)].y; soa[2 * n_pad + size_t(i)] = qv[size_t(i)].z; }
+        HIPCHK(c, c->qsoa.alloc(3 * n_pad));
+        HIPCHK(c, hipMemcpy(c->qsoa.p, soa.data(), 3 * n_pad * sizeof(float), hipMemcpyHostToDevice));
+        c->lean = c->lean_lds = true;
+      } else if (n_q <= 65535 && fixed <= size_t(kVerifyLdsBudget)) {
+        c->lean = true;                                      // queries from global memory (S4P_LEAN_GLOBAL=1 forces this form: test aid)
+      }
     }
   }
   auto up = [&](DevBuf<float>& d, const float* src) -> hipError_t {

@@ -886,14 +886,21 @@ __device__ __forceinline__ uint32_t bfe1(const uint32_t word, const uint32_t pos
 
 // exact stage for entries that carry only the query index: fine cell (same function, same inputs as the drain's reach test),
 // reach word -> rank, then exact_setup / the point walk as in exact_pair
-template <bool COUNT>
+// query i of the sweep order: from the LDS copy (QL) or from the padded float4 array in global memory (samples that do not
+// fit LDS: the 20 000-point sample of SURVEY 8d; same values, so both kernels locate and count identically)
+template <bool QL>
+__device__ __forceinline__ float4 lean_query(const LcpTask& K, const LeanLds& L, const uint32_t i) {
+  if (QL) return make_float4(L.qx[i], L.qy[i], L.qz[i], 0.f);
+  return K.q4[i];
+}
+template <bool COUNT, bool QL>
 __device__ __forceinline__ uint32_t exact_pair_lean(const LcpGrid& g, const LcpTask& K, const LeanLds& L, const float4* Tsrc,
                                                     const bool validA, const uint32_t iA, const bool validB, const uint32_t iB) {
   ExactEntry A, B;
   { float T[12]; load_rows(Tsrc, T);
     const GridXf X = make_grid_xf(g, T, 1.f);
     auto one = [&](const bool valid, const uint32_t i) -> ExactEntry {
-      const float4 q = make_float4(L.qx[i], L.qy[i], L.qz[i], 0.f);
+      const float4 q = lean_query<QL>(K, L, i);
       int ix, iy, iz;
       grid_cell(X.u, q, ix, iy, iz);
       const uint32_t c = mad24(mad24(uint32_t(iz), uint32_t(g.ny), uint32_t(iy)), uint32_t(g.nx), uint32_t(ix));
@@ -917,7 +924,7 @@ __device__ __forceinline__ uint32_t exact_pair_lean(const LcpGrid& g, const LcpT
   return hits;
 }
 
-template <bool COUNT, bool SKIP_FINE>
+template <bool COUNT, bool SKIP_FINE, bool QL>
 __device__ __forceinline__ uint32_t wave_lcp_count_lean(const LcpGrid& g, const LcpTask& K, const LeanLds& L, const float4* Tsrc, const float4 t0, const float4 t1, const float4 t2,
                                                         CycleProf& CP) {
   // t0..t2: the rows at Tsrc, already in registers (k_verify fetches a candidate's record while the previous one is swept); the
@@ -967,7 +974,7 @@ __device__ __forceinline__ uint32_t wave_lcp_count_lean(const LcpGrid& g, const 
 #pragma unroll
       for (uint32_t k = 0; k < kSweepChunks; ++k) {
         int ix, iy, iz;
-        grid_cell(X.u, make_float4(L.qx[ii[k]], L.qy[ii[k]], L.qz[ii[k]], 0.f), ix, iy, iz);
+        grid_cell(X.u, lean_query<QL>(K, L, ii[k]), ix, iy, iz);
         vv[k] = vv[k] & (uint32_t(ix) < uint32_t(g.nx)) & (uint32_t(iy) < uint32_t(g.ny)) & (uint32_t(iz) < uint32_t(g.nz));
         cc[k] = mad24(mad24(uint32_t(iz), uint32_t(g.ny), uint32_t(iy)), uint32_t(g.nx), uint32_t(ix));
         ww[k] = g.reach[vv[k] ? cc[k] >> 5 : 0u];
@@ -1000,7 +1007,7 @@ __device__ __forceinline__ uint32_t wave_lcp_count_lean(const LcpGrid& g, const 
       uint32_t ii[kSweepChunks], cc[kSweepChunks], ww[kSweepChunks];
       float x[kSweepChunks], y[kSweepChunks], z[kSweepChunks];
 #pragma unroll
-      for (uint32_t k = 0; k < kSweepChunks; ++k) { ii[k] = base + 64u * k + lane; x[k] = L.qx[ii[k]]; y[k] = L.qy[ii[k]]; z[k] = L.qz[ii[k]]; }
+      for (uint32_t k = 0; k < kSweepChunks; ++k) { ii[k] = base + 64u * k + lane; const float4 p = lean_query<QL>(K, L, ii[k]); x[k] = p.x; y[k] = p.y; z[k] = p.z; }
       int cx[kSweepChunks], cy[kSweepChunks], cz[kSweepChunks];
 #if S4P_LEAN_MFMA
       f4_t d[kSweepChunks];
@@ -1054,7 +1061,7 @@ __device__ __forceinline__ uint32_t wave_lcp_count_lean(const LcpGrid& g, const 
         if (COUNT) { if (lane == 0) atomicAdd(K.point_tests + 2, (unsigned long long)n); }      // list headers read (l1_pass)
         const unsigned long long cyc_d = S4P_CYC_FINE();
         if (!SKIP_FINE) {
-          const uint32_t h = exact_pair_lean<COUNT>(g, K, L, Tsrc, va, ia, vb, ib);
+          const uint32_t h = exact_pair_lean<COUNT, QL>(g, K, L, Tsrc, va, ia, vb, ib);
           cnt += uint32_t(__popcll(__builtin_amdgcn_ballot_w64((h & 1u) != 0u))) + uint32_t(__popcll(__builtin_amdgcn_ballot_w64((h & 2u) != 0u)));
         }
         nb -= n;
@@ -2080,8 +2087,9 @@ __device__ __forceinline__ bool slot_better(const uint32_t ca, const unsigned lo
   return !b_valid || ca > cb || (ca == cb && ta < tb);
 }
 
-// LEAN (launched when an early-exit bound is in force and the float copy of the sampled Q fits LDS): wave_lcp_count_lean,
-// LDS = coarse bitmap | float queries x, y, z | one 16-bit queue per wave; QLDS is then meaningless (false).
+// LEAN (launched when an early-exit bound is in force): wave_lcp_count_lean, LDS = coarse bitmap | float queries x, y, z (QLDS:
+// the sample fits) | one 16-bit queue per wave.  Without QLDS the lean sweep reads the queries from the padded float4 array in
+// global memory (VerifyParams::q4v holds n_pad entries): the 20 000-point sample.
 template <bool COUNT, bool QLDS, bool LEAN>
 __global__ __launch_bounds__(kVerifyMaxThreads, 6) void k_verify(VerifyParams P) {   // <= 80 VGPRs: six waves per SIMD, i.e. two 768-thread workgroups per CU (of one launch, or of two lanes)
   extern __shared__ uint32_t s_mem[];
@@ -2091,13 +2099,14 @@ __global__ __launch_bounds__(kVerifyMaxThreads, 6) void k_verify(VerifyParams P)
   const uint32_t n_pad = (P.n_q + kSweepStep - 1u) & ~(kSweepStep - 1u);
   LeanLds LL;
   LL.coarse = s_coarse;
+  const uint32_t lean_q_words = QLDS ? 3u * n_pad : 0u;     // lean kernels: QLDS = the float copy of the queries is staged in LDS
   { float* f = reinterpret_cast<float*>(s_mem + P.grid.coarse_words);
     LL.qx = f; LL.qy = f + n_pad; LL.qz = f + 2u * n_pad;
-    LL.queue = reinterpret_cast<uint16_t*>(f + 3u * n_pad) + uint32_t(__builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6))) * kLeanQueue; }   // (uniform: scalar register)
+    LL.queue = reinterpret_cast<uint16_t*>(f + lean_q_words) + uint32_t(__builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6))) * kLeanQueue; }   // (uniform: scalar register)
   // The workgroup's few scalars live at the END of the dynamic segment (VerifyShared), not in static __shared__: the coarse
   // bitmap then starts at LDS address 0 and the sweep's word address needs no base added (one vector instruction per chunk).
   VerifyShared& S = *reinterpret_cast<VerifyShared*>(LEAN
-      ? reinterpret_cast<uint32_t*>(reinterpret_cast<uint16_t*>(s_mem + P.grid.coarse_words + 3u * n_pad) + (blockDim.x >> 6) * kLeanQueue)
+      ? reinterpret_cast<uint32_t*>(reinterpret_cast<uint16_t*>(s_mem + P.grid.coarse_words + lean_q_words) + (blockDim.x >> 6) * kLeanQueue)
       : reinterpret_cast<uint32_t*>(s_q + (QLDS ? n_pad : 0u)) + (blockDim.x >> 6) * kQueueWordsPerWave);
   uint32_t& s_next = S.next; uint32_t& s_last = S.last; uint32_t& s_pruned = S.pruned;
   uint32_t* s_wcnt = S.wcnt; uint32_t* s_wcand = S.wcand; unsigned long long* s_wtag = S.wtag;
@@ -2123,7 +2132,7 @@ __global__ __launch_bounds__(kVerifyMaxThreads, 6) void k_verify(VerifyParams P)
     LcpTask K;
     K.q4 = P.q4v; K.n_q = P.n_q; K.qq = P.qq; K.T = P.cand_T; K.t_stride = kCandStride; K.point_tests = &P.ctr->point_tests;
     K.prune = P.prune; K.pruned = &s_pruned;
-    if (LEAN) stage_queries_f(P.qsoa, const_cast<float*>(LL.qx), 3u * n_pad);
+    if (LEAN) { if (QLDS) stage_queries_f(P.qsoa, const_cast<float*>(LL.qx), 3u * n_pad); }
     else if (QLDS) stage_queries(K, s_q);
     stage_coarse(P.grid, s_coarse);                        // ends with a workgroup barrier
     // A candidate is one 64-byte record {3x4 transform | tag, quad index}: one line, everything the wave needs of it.  (Holding
@@ -2145,7 +2154,7 @@ __global__ __launch_bounds__(kVerifyMaxThreads, 6) void k_verify(VerifyParams P)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         cyc_wait += S4P_CYC_NOW() - w0; ++n_cand; }
 #endif
-      if (LEAN) cnt = P.ablate == 1 ? wave_lcp_count_lean<COUNT, true>(P.grid, K, LL, src, r0, r1, r2, CP) : wave_lcp_count_lean<COUNT, false>(P.grid, K, LL, src, r0, r1, r2, CP);
+      if (LEAN) cnt = P.ablate == 1 ? wave_lcp_count_lean<COUNT, true, QLDS>(P.grid, K, LL, src, r0, r1, r2, CP) : wave_lcp_count_lean<COUNT, false, QLDS>(P.grid, K, LL, src, r0, r1, r2, CP);
       else cnt = P.ablate == 1 ? S4P_WAVE_LCP_COUNT<COUNT, true, QLDS>(P.grid, K, s_coarse, s_q, s_queue, src)
                                : S4P_WAVE_LCP_COUNT<COUNT, false, QLDS>(P.grid, K, s_coarse, s_q, s_queue, src);
       const uint32_t kraw = uint32_t(__builtin_amdgcn_readfirstlane(int(__float_as_uint(r3.z))));

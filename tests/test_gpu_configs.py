@@ -96,6 +96,8 @@ def _fused_bases_vs_oracle(O, capi, P, Q, delta, overlap, n_s, n_bases, max_pair
     om_ref = O.Matcher(oopt, full_counts=False, use_kdtree=True, keep_trace=True)
     om_full = O.Matcher(oopt, full_counts=True, use_kdtree=True, keep_trace=False)
     om_ref.init(P, Q); om_full.init(P, Q)
+    for om in (om_ref, om_full):                     # candidate loops under OpenMP (same results; a base of the dense scenes has ~10^6 candidates)
+        om.L.s4po_set_threads(om.h, os.cpu_count() or 1)
     gm = capi.Matcher(capi.make_options(delta, overlap, n_s), max_pairs=max_pairs, max_quads=max_quads)
     gm.init_full(P, Q)
     assert np.array_equal(gm.sampled(0), om_ref.cloud(0)) and np.array_equal(gm.sampled(1), om_ref.cloud(1))
@@ -222,74 +224,18 @@ def test_config4_part_in_whole_10m_scene(oracle_mod, s4p_lib_built):
     om, gm, ctx = _stagewise_parity(oracle_mod, capi, P, Q, T_gt, delta, 0.2, 2000, 6, 8 << 20, 64 << 20, 0.3, need_quads=False)
     _engine_invariants(gm, ctx, 8, need_candidates=False)
     del om, gm, ctx
-    # Bases whose two segments both fit inside the query DO produce quads and candidates -- about one base in twenty of
-    # this seeded sequence; the first are trials 18 (15 quads, 2 candidates) and 44 (133 quads, 40 candidates).  Trials
-    # 0-16 are skipped on the host, trials 17-44 go through the fused pass against the oracle, so this config cannot pass on
-    # empty lists.
+    # Bases whose two segments both fit inside the query DO produce quads and candidates -- about one base in ten of this
+    # seeded sequence on the round-4 scene; the first are trials 12 (785 559 quads, 780 789 candidates at n = 2000) and 21
+    # (39 517 quads, 15 267 candidates).  Trials 0-11 are skipped on the host, trials 12-21 go through the fused pass against
+    # the oracle, so this config cannot pass on empty lists.
     if SCALE == 1.0:
-        _gm, quads, cand = _fused_bases_vs_oracle(oracle_mod, capi, P, Q, delta, 0.2, 2000, 28, 8 << 20, 64 << 20, count_sample=400, skip_bases=17)
-        assert quads >= 148 and cand >= 42
+        _gm, quads, cand = _fused_bases_vs_oracle(oracle_mod, capi, P, Q, delta, 0.2, 2000, 10, 8 << 20, 64 << 20, count_sample=400, skip_bases=12)
+        assert quads >= 500_000 and cand >= 500_000
         del _gm
         # ... and at SURVEY.md 8d's sample size for this workload, n = 5000 sampled Q points.  The base sequence depends on P
-        # only, so the same trials carry quads (more of them): trials 17-19 through the fused pass against the oracle.
-        _gm, quads5, cand5 = _fused_bases_vs_oracle(oracle_mod, capi, P, Q, delta, 0.2, 5000, 3, 8 << 20, 64 << 20, count_sample=400, skip_bases=17)
-        assert quads5 > 15 and cand5 > 2 and _gm.info().n_sampled_q == 5000
-
-
-def test_config2_gpu_scale_sample_20000(oracle_mod, s4p_lib_built):
-    """configs[2] at the "GPU-scale" sample size of SURVEY.md 8d (n = 20 000 sampled Q points), first base of the seeded
-    sequence.  ExtractPairs, both sets (16.8 M and 10.2 M ordered pairs), in the reference's emission order against the
-    oracle; then the FUSED pass of that base to completion.  Its ~10^9 congruent quads exceed any quad buffer, so the base
-    is chunked (ranges of the second pair set -> enumerate -> gate -> score -> fold).  Lists of that size cannot be compared
-    (the reference's own std::set would need ~50 GB); the oracle's streaming enumeration (OpenMP over set 2, pinned to the
-    list form on small cases, tests/test_oracle.py) gives the number of quads, the number that pass the rms gate and the
-    order-independent checksums of both, plus a deterministic subsample of the gated quads whose inlier counts the
-    stage-level entry point and the oracle's kd-tree Verify must agree on; the winner's gate and count are recomputed by
-    the oracle and no sampled candidate may beat it."""
-    from super4pcs_amd import capi, datasets as D
-    import bench
-    from bench import seg_len32
-    if SCALE != 1.0:
-        pytest.skip("full-size case")
-    O = oracle_mod
-    n_s = 20000
-    P, Q, _ = D.bumpy_pair(bench.N_POINTS, overlap=bench.OVERLAP, delta=bench.DELTA, seed=bench.SEED)
-    om = O.Matcher(O.make_options(bench.DELTA, bench.OVERLAP, n_s), full_counts=True, use_kdtree=True, keep_trace=False)
-    om.init(P, Q)
-    Ps, Qs = om.cloud(0), om.cloud(1)
-    assert Qs.shape[0] == n_s
-    ctx = capi.Context(capi.make_options(bench.DELTA, bench.OVERLAP, n_s), max_pairs=32 << 20, max_quads=16 << 20)
-    ctx.set_clouds(Ps, Qs)
-    ok, i1, i2, base, bx = om.select_quadrilateral()
-    assert ok
-    ctx.set_base(bx)
-    eps = 2.0 * bench.DELTA
-    sets = []
-    for a, b in ((0, 1), (2, 3)):
-        d = seg_len32(bx[a], bx[b])
-        want_p = om.extract_pairs_cap(d, 0.0, eps, a, b, 1 << 25)
-        got_p = ctx.extract_pairs(d, 0.0, eps, a, b, cap=1 << 25)
-        assert got_p.shape == want_p.shape and np.array_equal(got_p, want_p)          # same pairs, same emission order
-        sets.append(want_p)
-    assert sets[0].shape[0] + sets[1].shape[0] > 20_000_000
-    want = om.count_congruent(i1, i2, eps, sets[0], sets[1], base=base, sample_mod=1 << 18, sample_cap=1 << 14)
-    # default limits (1 Mi pairs, 4 Mi quads): the lane grows its pair buffers and redoes the base, then chunks its quads
-    gm = capi.Matcher(capi.make_options(bench.DELTA, bench.OVERLAP, n_s))
-    gm.init_full(P, Q)
-    _ok, r = gm.try_one_base()
-    assert (r.n_pairs1, r.n_pairs2) == (sets[0].shape[0], sets[1].shape[0])
-    assert (r.n_quads, r.quad_checksum) == (want["K"], want["quad_sum"])
-    assert (r.n_verified, r.cand_checksum) == (want["C"], want["cand_sum"])
-    st = gm.chunk_stats()
-    assert r.n_quads > (200 << 20) and st["bases"] == 1 and st["passes"] >= 8 and gm.capacity_growths() >= 1
-    smp = want["sample"]
-    assert len(smp) >= 100
-    _nb, w_per, _bc, _bi = om.try_congruent_set(base, np.array([list(r.best_quad)], np.int32))
-    assert w_per[0] == r.best_count
-    _nb, o_per, _bc, _bi = om.try_congruent_set(base, smp[:300])
-    _gr, g_per = ctx.try_congruent_set(base, smp[:300])
-    assert np.array_equal(g_per, o_per) and (o_per >= 0).all()
-    assert o_per.max() <= r.best_count
+        # only, so the same trials carry quads (~40 x more of them): trial 21 through the fused pass against the oracle.
+        _gm, quads5, cand5 = _fused_bases_vs_oracle(oracle_mod, capi, P, Q, delta, 0.2, 5000, 1, 8 << 20, 64 << 20, count_sample=400, skip_bases=21)
+        assert quads5 > 100_000 and cand5 > 10_000 and _gm.info().n_sampled_q == 5000
 
 
 def _whole_registration_vs_oracle(oracle_mod, capi, P, Q, delta, overlap, n_s, threads=0):
@@ -341,7 +287,7 @@ def test_config4_whole_registration_at_reduced_scale(oracle_mod, s4p_lib_built):
 def test_chunked_winner_equals_the_oracles_streaming_winner(oracle_mod, s4p_lib_built):
     """The winner of a CHUNKED base -- greatest inlier count, ties to the first candidate in the reference's order
     (match4pcsBase.hpp:467-484) -- against the oracle's streaming pass, which verifies every gated candidate of the base in
-    full and keeps (max count, min (id, i)).  Sample size 4000 on the configs[2] clouds: ~10^6 candidates per base, a size the
+    full and keeps (max count, min (id, i)).  Sample size 3200 on the configs[2] clouds: ~4 10^5 candidates per base, a size the
     host's cores can verify; the quad buffers are held at 256 Ki entries so that every base takes a dozen passes, once cut
     along the second pair set (default) and once along the first set's order key (the ordered mode of the record sink)."""
     from super4pcs_amd import capi, datasets as D
@@ -350,7 +296,7 @@ def test_chunked_winner_equals_the_oracles_streaming_winner(oracle_mod, s4p_lib_
     if SCALE != 1.0:
         pytest.skip("full-size case")
     O = oracle_mod
-    n_s = 4000
+    n_s = 3200
     P, Q, _ = D.bumpy_pair(bench.N_POINTS, overlap=bench.OVERLAP, delta=bench.DELTA, seed=bench.SEED)
     om = O.Matcher(O.make_options(bench.DELTA, bench.OVERLAP, n_s), full_counts=True, use_kdtree=True, keep_trace=False)
     om.init(P, Q)
@@ -365,7 +311,7 @@ def test_chunked_winner_equals_the_oracles_streaming_winner(oracle_mod, s4p_lib_
             c.set_candidate_sink(lambda cnt, T: None)
         ctxs.append(c)
     done = 0
-    for _ in range(3):
+    for _ in range(2):
         ok, i1, i2, base, bx = om.select_quadrilateral()
         if not ok:
             continue

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Copies the summaries of the round-3 final pass (tools/r3_run13.sh -> gpurun_out/) into profiles/ (tracked)."""
+"""Copies the summaries of the round-3 final pass (tools/lab/r3_run13.sh -> gpurun_out/) into profiles/ (tracked)."""
 import glob
 import os
 import shutil
