@@ -1352,13 +1352,65 @@ int32_t s4p_find_congruent(s4p_ctx* c, float inv1, float inv2, float /*thr1*/, f
   const uint32_t mm[2] = {uint32_t(m1), uint32_t(m2)};
   HIPCHK(c, hipMemcpyAsync(&c->lane[c->cur].ctr.p->m1, mm, 8, hipMemcpyHostToDevice, c->lane[c->cur].stream));
   c->lane[c->cur].dirty = true;
-  { PrepParams P1; QuadParams Q;
-    if (int32_t rc = quad_params(c, inv1, inv2, thr2, P1, Q)) return rc;
-    launch_prep_kernel(c, P1);
-    launch_quads_kernel(c, Q);
-    HIPCHK(c, hipGetLastError()); }
-  HIPCHK(c, hipMemcpyAsync(c->hctr[c->cur].p, c->lane[c->cur].ctr.p, sizeof(DevCounters), hipMemcpyDeviceToHost, c->lane[c->cur].stream));
-  HIPCHK(c, hipStreamSynchronize(c->lane[c->cur].stream));
+  PrepParams P1; QuadParams Q;
+  if (int32_t rc = quad_params(c, inv1, inv2, thr2, P1, Q)) return rc;
+  launch_prep_kernel(c, P1);
+  launch_quads_kernel(c, Q);
+  HIPCHK(c, hipGetLastError());
+  s4p_ctx::Lane& L = c->lane[c->cur];
+  HIPCHK(c, hipMemcpyAsync(c->hctr[c->cur].p, L.ctr.p, sizeof(DevCounters), hipMemcpyDeviceToHost, L.stream));
+  HIPCHK(c, hipStreamSynchronize(L.stream));
+  if (c->hctr[c->cur].p->overflow == 4u && c->chunking) {
+    // More congruent quads than the lane's quad buffers hold (the reference's std::vector<Quadrilateral> simply grows,
+    // super4pcs.cc:166-174): the counter kept counting, so the size of the list is known; it is enumerated again in ranges of
+    // the FIRST pair set (a quad's tag is (index in P_pairs) << 32 | index in Q_pairs: ranges in ascending order are chunks
+    // of the std::set order), each chunk sorted and appended to the caller's buffer.
+    const uint64_t Ktot = c->hctr[c->cur].p->K;
+    *n_out = int64_t(Ktot);
+    if (!out_quads || uint64_t(cap) < Ktot) S4P_FAIL(c, S4P_ERR_CAPACITY, "s4p_find_congruent: output buffer too small");
+    const uint64_t target = std::max<uint64_t>(L.cap_quads * 6 / 10, 1), nch = (Ktot + target - 1) / target;
+    const uint64_t step = std::max<uint64_t>(1, (uint64_t(m1) + nch - 1) / nch);
+    std::vector<std::pair<uint64_t, uint64_t>> todo;
+    for (uint64_t a = 0; a < uint64_t(m1); a += step) todo.emplace_back(a, std::min<uint64_t>(a + step, uint64_t(m1)));
+    std::reverse(todo.begin(), todo.end());
+    uint64_t at = 0;
+    while (!todo.empty()) {
+      const std::pair<uint64_t, uint64_t> rg = todo.back(); todo.pop_back();
+      const unsigned long long zero = 0ull; const uint32_t z32 = 0u;
+      HIPCHK(c, hipMemcpyAsync(&L.ctr.p->K, &zero, 8, hipMemcpyHostToDevice, L.stream));
+      HIPCHK(c, hipMemcpyAsync(&L.ctr.p->overflow, &z32, 4, hipMemcpyHostToDevice, L.stream));
+      Q.k1_all = 0; Q.k1_lo = uint32_t(rg.first); Q.k1_hi = uint32_t(rg.second);
+      launch_quads_kernel(c, Q);
+      HIPCHK(c, hipGetLastError());
+      HIPCHK(c, hipMemcpyAsync(c->hctr[c->cur].p, L.ctr.p, sizeof(DevCounters), hipMemcpyDeviceToHost, L.stream));
+      HIPCHK(c, hipStreamSynchronize(L.stream));
+      const DevCounters& d = *c->hctr[c->cur].p;
+      if (d.overflow & 4u) {
+        if (rg.second - rg.first < 2u) S4P_FAIL(c, S4P_ERR_CAPACITY, "one pair has more congruent quads than max_quads: raise s4p_limits.max_quads");
+        const uint64_t mid = rg.first + (rg.second - rg.first) / 2u;
+        todo.emplace_back(mid, rg.second); todo.emplace_back(rg.first, mid);
+        continue;
+      }
+      const uint64_t Kc = d.K;
+      if (at + Kc > Ktot) S4P_FAIL(c, S4P_ERR_STATE, "chunked quad enumeration disagrees with the counting pass");
+      std::vector<int4> q(Kc); std::vector<unsigned long long> t(Kc);
+      if (Kc) {
+        HIPCHK(c, hipMemcpy(q.data(), L.quads.p, size_t(Kc) * 16, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(t.data(), L.tags.p, size_t(Kc) * 8, hipMemcpyDeviceToHost));
+      }
+      std::vector<uint32_t> order(Kc);
+      std::iota(order.begin(), order.end(), 0u);
+      std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return t[a] < t[b]; });
+      for (uint64_t i = 0; i < Kc; ++i) {
+        const int4 v = q[order[i]];
+        int32_t* o = out_quads + 4 * (at + i);
+        o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+      }
+      at += Kc;
+    }
+    if (at != Ktot) S4P_FAIL(c, S4P_ERR_STATE, "chunked quad enumeration disagrees with the counting pass");
+    return S4P_OK;
+  }
   if (int32_t rc = check_overflow(c, *c->hctr[c->cur].p)) return rc;
   const uint32_t K = c->hctr[c->cur].p->K;
   *n_out = K;

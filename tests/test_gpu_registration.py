@@ -426,6 +426,10 @@ def test_records_of_a_multi_pass_base_through_the_stage_calls(oracle_mod, s4p_li
         assert np.array_equal(np.frombuffer(bytes(rr_s.best_transform), np.float32), np.frombuffer(bytes(rr_b.best_transform), np.float32))
         v2, T2 = small.last_verified(max(rb.n_verified, 1))
         assert np.array_equal(v2, bv) and np.array_equal(T2, bT)
+        # FindCongruentQuadrilaterals returning a list longer than the device buffers (super4pcs.cc:166-174): enumerated in
+        # ranges of the first pair set, in the reference's std::set order
+        sq = small.find_congruent(i1, i2, eps, p1, p2, cap=len(bq) + 8)
+        assert np.array_equal(sq, bq)
     assert checked >= 2
 
 
