@@ -26,6 +26,11 @@ EXPORTED_SYMBOLS = [
 ]
 
 
+# (the library asks for 8 hardware queues when it is loaded; a Python process usually initialises HIP earlier -- through torch --
+# so the same request is made here, at import; see s4p_capi.hip)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+
 class S4PError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__("s4p error %s (%d): %s" % (ERR_NAMES.get(code, "?"), code, msg))

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Recomputes every figure of a bench line's `roofline` object from the files committed next to it (no GPU needed):
-  python tools/recompute_roofline.py [profiles/r03_bench_final.json [profiles/r03_bench_final]]
+  python tools/recompute_roofline.py [profiles/r04_bench_final.json [profiles/r04_bench_final]]      (default: the newest round)
   - frac (per step): value x algorithmic_bytes_per_candidate / 8 TB/s
   - traffic: mean FETCH_SIZE (KB, x 2: gfx950 tallies 128-B requests at 64 B) + mean WRITE_SIZE (KB) of the timed launches
   - valu: mean SQ_ACTIVE_INST_VALU / (1024 SIMDs x mean GRBM_GUI_ACTIVE / 8 XCDs / 4)
@@ -14,7 +14,9 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-line = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r03_bench_final.json")
+_newest = next((r for r in ("r04", "r03") if os.path.exists(os.path.join(ROOT, "profiles", r + "_bench_final.json"))), "r03")
+line = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", _newest + "_bench_final.json")
+_round = os.path.basename(line)[:3]
 pdir = sys.argv[2] if len(sys.argv) > 2 else os.path.splitext(line)[0]
 d = json.load(open(line))
 r = d["roofline"]
@@ -65,8 +67,8 @@ if os.path.exists(kt) and os.path.exists(cc) and r.get("hbm_bound_point"):
     show("hbm_bound_point.kernel_ms", ms, h["kernel_ms"])
     show("hbm_bound_point.measured_GBps", fetch[0] * 1024 * 2 / (ms * 1e-3) / 1e9, h["measured_GBps"])
     show("hbm_bound_point.frac (algorithmic gathers)", h["algorithmic_bytes"] / (ms * 1e-3) / 1e9 / h["peak_GBps"], h["frac"])
-stats = os.path.join(ROOT, "profiles", "r03_kernel_stats_bench_final.csv")
-under = os.path.join(ROOT, "profiles", "r03_bench_under_rocprof_final.json")
+stats = os.path.join(ROOT, "profiles", _round + "_kernel_stats_bench_final.csv")
+under = os.path.join(ROOT, "profiles", _round + "_bench_under_rocprof_final.json")
 if os.path.exists(stats) and os.path.exists(under):
     row = next(x for x in csv.DictReader(open(stats)) if "k_verify<" in x["Name"])
     hip = json.load(open(under))["roofline"]["per_launch"]["avg_launch_ms"]
