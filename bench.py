@@ -611,6 +611,8 @@ def main():
             return sh
         return sharding.ShardedRansac(m, rank, world, dist, dev, producer_threads="auto")      # world 1: the engine's own pipelined Perform_N_steps
 
+    per_rank = {}
+
     def timed_region(steps, warmup, early_exit=True, stage_events=False):
         """Fresh matcher, same seed: W untimed steps, then exactly K timed steps between barrier + synchronize.  HIP events
         bracket every k_verify launch of the timed steps (roofline.per_launch); the other stages' events (three more records per
@@ -630,7 +632,15 @@ def main():
         prof = m.profile_get(reset=True)
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         tc = torch.tensor([cand], dtype=torch.int64, device=dev)
+        per_rank["ms_per_step"], per_rank["candidates"] = [dt / max(steps, 1) * 1e3], [int(cand)]
         if dist is not None:
+            # what every rank measured on its own clock / counted on its own GPU (the line's ms_per_step is the MAX, value the SUM)
+            gt = [torch.zeros_like(tt) for _ in range(world)]
+            gc = [torch.zeros_like(tc) for _ in range(world)]
+            dist.all_gather(gt, tt)
+            dist.all_gather(gc, tc)
+            per_rank["ms_per_step"] = [float(x.item()) / max(steps, 1) * 1e3 for x in gt]
+            per_rank["candidates"] = [int(x.item()) for x in gc]
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dist.all_reduce(tc, op=dist.ReduceOp.SUM)
         return m, sh, float(tt.item()), int(tc.item()), prof
@@ -647,11 +657,11 @@ def main():
                 sh.close()
             m.close()
         m, sh, dt_max, cand_all, prof = timed_region(args.steps, args.warmup)
-        runs.append((cand_all / dt_max, dt_max, cand_all, prof))
+        runs.append((cand_all / dt_max, dt_max, cand_all, prof, dict(per_rank)))
         finals.append(m.info())
     order = sorted(range(len(runs)), key=lambda k: runs[k][0])
     med = order[len(order) // 2]
-    value, dt_max, cand_all, prof = runs[med]
+    value, dt_max, cand_all, prof, per_rank_med = runs[med]
     info = finals[-1]
     n_q, n_p = info.n_sampled_q, info.n_sampled_p
     final_info = info                           # state after the last repeat's windows (N > 1: compared across ranks below)
@@ -919,6 +929,10 @@ def main():
                        "candidates_timed": cand_all, "point_queries_per_s": cand_all * n_q / dt_max,
                        "parallelism": "bases sharded over %d GPU(s), one 8-byte all-reduce(max) per window" % world,
                        "collective": collective["kind"], "shard_mode": collective.get("mode"),
+                       "ranks": {"n_ranks": world, "torch_distributed_world": (dist.get_world_size() if dist is not None else 1),
+                                 "per_rank_ms_per_step": per_rank_med.get("ms_per_step"), "per_rank_candidates": per_rank_med.get("candidates"),
+                                 "note": "each rank's own wall clock over the K timed steps and its own candidate count in the median repeat; "
+                                         "`ms_per_step` is the max over ranks, `value` the sum of the candidates / that time"},
                        "early_exit": {"on": True, "candidates_abandoned": int(prof.verify_pruned), "fraction": prof.verify_pruned / max(cand_all, 1),
                                       "exact_point_tests_per_query": kbar, "exact_point_tests_per_query_full_counts": None if full_walk is None else full_walk["kbar"],
                                       "note": "candidates that can no longer EXCEED the registration's best inlier count are abandoned (every candidate that "
