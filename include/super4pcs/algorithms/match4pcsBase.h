@@ -162,12 +162,13 @@ class Match4PCSBase {
       done = (ok || current_trial_ >= number_of_trials_) ? 1 : 0;
     }
     if (improved) {                                   // :259-268 -- the final apply runs on the GPU (k_apply)
-      *Q = Q_copy_;
-      const int64_t nq = int64_t(Q->size());
+      // *Q = Q_copy_ with the transformed positions: one pass out of the AoS copy, one pass back into *Q
+      const int64_t nq = int64_t(Q_copy_.size());
       std::vector<float> x(nq), y(nq), z(nq);
-      for (int64_t i = 0; i < nq; ++i) { x[i] = (*Q)[i].x(); y[i] = (*Q)[i].y(); z[i] = (*Q)[i].z(); }
+      for (int64_t i = 0; i < nq; ++i) { x[i] = Q_copy_[i].x(); y[i] = Q_copy_[i].y(); z[i] = Q_copy_[i].z(); }
       check(s4p_transform_points(s4p_matcher_ctx(engine_), M, x.data(), y.data(), z.data(), nq));
-      for (int64_t i = 0; i < nq; ++i) { (*Q)[i].x() = x[i]; (*Q)[i].y() = y[i]; (*Q)[i].z() = z[i]; }
+      Q->resize(size_t(nq));
+      for (int64_t i = 0; i < nq; ++i) { Point3D p = Q_copy_[i]; p.x() = x[i]; p.y() = y[i]; p.z() = z[i]; (*Q)[i] = p; }
     }
     return done != 0;
   }

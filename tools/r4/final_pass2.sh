@@ -13,13 +13,13 @@ timeout 900 python bench.py --profile-dir $O/bench_final > $O/bench_final.json 2
 echo "bench rc=$?" >> $O/log2.txt
 timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_command.json 2> $O/bench_driver_command.err
 echo "bench20 rc=$?" >> $O/log2.txt
-rm -rf $O/stats
-( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d "$GRAFT_REPO_ROOT/$O/stats" -o r --output-format csv -- python "$GRAFT_REPO_ROOT/bench.py" --repeats 1 --cpu-seconds 0 --no-parity --no-pmc --no-hbm-point --no-time-to-register --no-exclusive --no-instrumented --no-full-count-mode --no-stage-pass --no-extra > "$GRAFT_REPO_ROOT/$O/bench_under_rocprof.json" 2> "$GRAFT_REPO_ROOT/$O/stats.err" )
-echo "rocprof rc=$?" >> $O/log2.txt
+timeout 420 python -m pytest tests/test_facade.py tests/test_gpu_configs.py -m gpu -q -x --timeout 400 --durations=5 -k "facade or reduced_scale" > $O/gpu_tests_part2.log 2>&1
+echo "pytest part 2 rc=$?" >> $O/log2.txt
+tail -12 $O/gpu_tests_part2.log >> $O/log2.txt
 python - <<'PY' >> gpurun_out/r04_final/log2.txt
 import json, glob, csv
 O='gpurun_out/r04_final'
-for f in ('bench_2ranks_dryrun','bench_final','bench_driver_command','bench_under_rocprof'):
+for f in ('bench_2ranks_dryrun','bench_final','bench_driver_command'):
     try:
         line=[l for l in open('%s/%s.json'%(O,f)).read().splitlines() if l.startswith('{"metric')][-1]
         d=json.loads(line); r=d['roofline']
