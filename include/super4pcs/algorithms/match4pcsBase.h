@@ -10,7 +10,10 @@
 #include <array>
 #include <chrono>
 #include <cmath>
+#include <exception>
+#include <memory>
 #include <stdexcept>
+#include <thread>
 #include <type_traits>
 #include <string>
 #include <utility>
@@ -93,6 +96,16 @@ class Match4PCSBase {
   void init(const std::vector<Point3D>& P, const std::vector<Point3D>& Q, const Sampler& sampler) {
     std::vector<Point3D> ps, qu;
     const bool sample_q = Q.size() > options_.sample_size;
+    // Q_copy_ = Q (match4pcsBase.hpp:191) is a whole-cloud copy nothing below reads: it runs beside the sampling and the
+    // engine's init and is complete before Initialize() -- the first code of a subclass that could look at it -- is called
+    struct CopyOfQ {
+      std::exception_ptr failed;
+      std::thread t;
+      CopyOfQ(std::vector<Point3D>& dst, const std::vector<Point3D>& src)
+          : t([this, &dst, &src] { try { dst = src; } catch (...) { failed = std::current_exception(); } }) {}
+      void wait() { if (t.joinable()) t.join(); if (failed) { std::exception_ptr f = failed; failed = nullptr; std::rethrow_exception(f); } }
+      ~CopyOfQ() { if (t.joinable()) t.join(); }
+    } copy_of_q(Q_copy_, Q);
     if (P.size() > options_.sample_size) sampler(P, options_, ps);
     else { Log<LogLevel::ErrorReport>("(P) More samples requested than available: use whole cloud"); ps = P; }
     if (sample_q) sampler(Q, options_, qu);
@@ -100,7 +113,6 @@ class Match4PCSBase {
     Soa sp(ps), sq(qu);
     const s4p_cloud_view vp = sp.view(), vq = sq.view();
     check(s4p_matcher_init(engine_, &vp, &vq, sample_q ? 1 : 0));
-    Q_copy_ = Q;
     refresh();
     // sampled clouds as the engine holds them (centred; Q shuffled and truncated)
     pull_sampled(0, ps, sampled_P_3D_);
@@ -109,6 +121,7 @@ class Match4PCSBase {
     // The virtual handler, "called once the internal state of the Base class has been set" (match4pcsBase.h:262-272,
     // match4pcsBase.hpp:197-198): with the caller's P and Q, after sampling / centring / the trial count, and with
     // best_LCP_ still 0 -- the initial LCP (= Verify(transform_), :200) is assigned after it, as in the reference.
+    copy_of_q.wait();
     const Scalar initial_lcp = best_LCP_;
     best_LCP_ = Scalar(0);
     Initialize(P, Q);
@@ -163,12 +176,18 @@ class Match4PCSBase {
     }
     if (improved) {                                   // :259-268 -- the final apply runs on the GPU (k_apply)
       // *Q = Q_copy_ with the transformed positions: one pass out of the AoS copy, one pass back into *Q
-      const int64_t nq = int64_t(Q_copy_.size());
-      std::vector<float> x(nq), y(nq), z(nq);
-      for (int64_t i = 0; i < nq; ++i) { x[i] = Q_copy_[i].x(); y[i] = Q_copy_[i].y(); z[i] = Q_copy_[i].z(); }
-      check(s4p_transform_points(s4p_matcher_ctx(engine_), M, x.data(), y.data(), z.data(), nq));
-      Q->resize(size_t(nq));
-      for (int64_t i = 0; i < nq; ++i) { Point3D p = Q_copy_[i]; p.x() = x[i]; p.y() = y[i]; p.z() = z[i]; (*Q)[i] = p; }
+      const size_t nq = Q_copy_.size();
+      const std::unique_ptr<float[]> x(new float[nq]), y(new float[nq]), z(new float[nq]);
+      const std::vector<Point3D>& src = Q_copy_;
+      detail::for_ranges(nq, [&](size_t b, size_t e) {
+        for (size_t i = b; i < e; ++i) { x[i] = src[i].x(); y[i] = src[i].y(); z[i] = src[i].z(); }
+      });
+      check(s4p_transform_points(s4p_matcher_ctx(engine_), M, x.get(), y.get(), z.get(), int64_t(nq)));
+      Q->resize(nq);
+      std::vector<Point3D>& dst = *Q;
+      detail::for_ranges(nq, [&](size_t b, size_t e) {
+        for (size_t i = b; i < e; ++i) { Point3D p = src[i]; p.x() = x[i]; p.y() = y[i]; p.z() = z[i]; dst[i] = p; }
+      });
     }
     return done != 0;
   }

@@ -123,6 +123,11 @@ def load_library():
     if hasattr(L, "s4p_select_base_points"):
         L.s4p_select_base_points.restype = C.c_int32
         L.s4p_select_base_points.argtypes = [vp, C.POINTER(C.c_uint32), C.c_float, C.c_float, ip, fp, ip]
+    if hasattr(L, "s4p_select_base_points_batch"):
+        L.s4p_select_base_points_batch.restype = C.c_int32
+        L.s4p_select_base_points_batch.argtypes = [vp, C.POINTER(C.c_uint32), C.c_int32, C.c_float, C.c_float, ip, fp, ip]
+        L.s4p_select_batch_max.restype = C.c_int32
+        L.s4p_select_batch_max.argtypes = []
     L.s4p_profile_enable.restype = C.c_int32
     L.s4p_profile_enable.argtypes = [vp, C.c_int32, C.c_int32]
     L.s4p_profile_get.restype = C.c_int32
@@ -325,6 +330,16 @@ class Context:
         ids = np.empty(4, np.int32); xyz = np.empty(12, np.float32); st = C.c_int32()
         self._chk(self.L.s4p_select_base_points(self.h, d.ctypes.data_as(C.POINTER(C.c_uint32)), float(limit_sq), float(too_small), _i(ids), _f(xyz), C.byref(st)))
         return int(st.value), ids, xyz.reshape(4, 3)
+
+    def select_base_points_batch(self, draws, limit_sq, too_small):
+        """Consecutive attempts in one set of launches: (status[n], ids[n, 4], xyz[n, 4, 3]); see s4p_select_base_points_batch."""
+        d = np.ascontiguousarray(draws, np.uint32)
+        n = d.shape[0]
+        assert d.shape == (n, 2001) and 1 <= n <= int(self.L.s4p_select_batch_max())
+        ids = np.empty((n, 4), np.int32); xyz = np.empty((n, 12), np.float32); st = np.empty(n, np.int32)
+        self._chk(self.L.s4p_select_base_points_batch(self.h, d.ctypes.data_as(C.POINTER(C.c_uint32)), n, float(limit_sq), float(too_small),
+                                                     _i(ids), _f(xyz), _i(st)))
+        return st, ids, xyz.reshape(n, 4, 3)
 
     def profile_enable(self, events=True, point_tests=False):
         self._chk(self.L.s4p_profile_enable(self.h, int(events), int(point_tests)))

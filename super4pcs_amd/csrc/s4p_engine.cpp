@@ -470,7 +470,7 @@ void evaluator_main(s4p_matcher* m) {
     }
   }
   // searches on the device: every attempt that has been drawn so far (up to the batch size) goes into ONE set of launches
-  const int bmax = std::min(8, s4p_select_batch_max());
+  const int bmax = s4p_select_batch_max();                   // one scan of P serves the whole batch (k_select_fourth)
   std::vector<uint32_t> draws(size_t(bmax) * 2001);
   std::vector<int32_t> got(size_t(bmax) * 4), st(static_cast<size_t>(bmax));
   std::vector<float> xyz(size_t(bmax) * 12);
@@ -783,6 +783,22 @@ int32_t try_one_base(s4p_matcher* m, bool& ok, s4p_base_result* last) {
 
 bool view_ok(const s4p_cloud_view* v) { return v && v->x && v->y && v->z && v->n >= 0; }
 
+// S4P_TRACE_INIT=1 (lab aid, like S4P_TRACE_CALL): where init spends its time, one line on stderr per call
+struct InitTrace {
+  using clk = std::chrono::steady_clock;
+  const bool on = std::getenv("S4P_TRACE_INIT") != nullptr;
+  clk::time_point t = clk::now();
+  std::string line;
+  void lap(const char* what) {
+    if (!on) return;
+    const auto now = clk::now();
+    char buf[96];
+    std::snprintf(buf, sizeof buf, "%s\"%s_ms\": %.3f", line.empty() ? "" : ", ", what, std::chrono::duration<double, std::milli>(now - t).count());
+    line += buf; t = now;
+  }
+  void print(const char* tag) const { if (on) std::fprintf(stderr, "{\"s4p_trace\": \"%s\", %s}\n", tag, line.c_str()); }
+};
+
 // Bases started with s4p_matcher_next_base_async and never waited for: their kernels still read the lane buffers, and
 // the context's FIFO must stay in step with m->inflight.  Called before anything that re-initialises or restarts.
 void drain_inflight(s4p_matcher* m) {
@@ -836,6 +852,7 @@ int32_t s4p_matcher_init(s4p_matcher* m, const s4p_cloud_view* p, const s4p_clou
   drain_inflight(m);
   m->prod.consumed = 0; m->prod.next_index = 0;
   m->ready = false; m->init_generation++;
+  InitTrace trace;
   Cloud& Ps = m->Ps; Cloud& Qs = m->Qs;
   Ps = Cloud(); Qs = Cloud();
   Ps.init_flags(*p); Qs.init_flags(*q);
@@ -852,8 +869,10 @@ int32_t s4p_matcher_init(s4p_matcher* m, const s4p_cloud_view* p, const s4p_clou
     Qs.reserve(size_t(q->n));
     for (int64_t i = 0; i < q->n; ++i) Qs.push_from(*q, i);
   }
+  trace.lap("copy_in_and_shuffle_q");
   centre_cloud(Ps, m->centroid_p);
   centre_cloud(Qs, m->centroid_q);
+  trace.lap("centre");
   // P_diameter_: 1000 random pair distances in the sampled Q (quirk), match4pcsBase.hpp:155-164
   m->p_diameter = 0.f;
   const unsigned long nq = (unsigned long)Qs.size();
@@ -896,8 +915,11 @@ int32_t s4p_matcher_init(s4p_matcher* m, const s4p_cloud_view* p, const s4p_clou
                                   Qs.has_c ? Qs.r.data() : nullptr, Qs.has_c ? Qs.g.data() : nullptr, Qs.has_c ? Qs.b.data() : nullptr,
                                   int64_t(Qs.size())))
     return m->ctx_fail(rc);
+  trace.lap("set_clouds");
   uint32_t c0 = 0;
   if (int32_t rc = s4p_verify_transforms(m->ctx, m->transform, 1, &c0)) return m->ctx_fail(rc);
+  trace.lap("initial_lcp");
+  trace.print("s4p_matcher_init");
   m->best_count = c0;
   m->best_lcp = float(c0) / float(Qs.size());
   m->ready = true;
@@ -910,8 +932,8 @@ int32_t s4p_matcher_init_full(s4p_matcher* m, const s4p_cloud_view* P, const s4p
   bool sampler_failed = false;
   auto subset = [&](const s4p_cloud_view& v, bool sample, std::vector<std::vector<float>>& store) -> s4p_cloud_view {
     if (!sample) return v;                                          // "use whole cloud", match4pcsBase.hpp:115-119
-    std::vector<int64_t> idx(size_t(v.n));
-    const int64_t k = voxel_first_hits(v.x, v.y, v.z, v.n, m->opt.delta, idx.data(), m->device);
+    const std::unique_ptr<int64_t[]> idx(new int64_t[size_t(v.n)]);  // only the first k entries are written and read: no zero-fill pass
+    const int64_t k = voxel_first_hits(v.x, v.y, v.z, v.n, m->opt.delta, idx.get(), m->device);
     if (k < 0) { sampler_failed = true; return v; }
     const float* src[9] = {v.x, v.y, v.z, v.nx, v.ny, v.nz, v.r, v.g, v.b};
     store.assign(9, {});
@@ -927,8 +949,12 @@ int32_t s4p_matcher_init_full(s4p_matcher* m, const s4p_cloud_view* P, const s4p
   std::vector<std::vector<float>> sp, sq;
   const bool sample_p = uint64_t(P->n) > m->opt.sample_size;
   const bool sample_q = uint64_t(Q->n) > m->opt.sample_size;
+  InitTrace trace;
   const s4p_cloud_view pv = subset(*P, sample_p, sp);
+  trace.lap("sample_and_gather_p");
   const s4p_cloud_view qv = subset(*Q, sample_q, sq);
+  trace.lap("sample_and_gather_q");
+  trace.print("s4p_matcher_init_full");
   if (sampler_failed) return m->fail(S4P_ERR_HIP, "device UniformDistSampler failed (HIP error, see stderr); no silent host fallback");
   return s4p_matcher_init(m, &pv, &qv, sample_q ? 1 : 0);
 }

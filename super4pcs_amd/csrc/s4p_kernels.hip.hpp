@@ -2380,24 +2380,72 @@ __global__ __launch_bounds__(1024) void k_select_triangle(const float4* __restri
   rec->status = kSelectNoFourth;                // until k_select_fourth finds one
 }
 
-__global__ __launch_bounds__(256) void k_select_fourth(const float4* __restrict__ p4, uint32_t n_p, float too_small, SelectRecord* rec_all) {
-  SelectRecord* rec = rec_all + blockIdx.y;                // attempt = blockIdx.y
-  if (rec->status != kSelectNoFourth) return;
-  const float pa = rec->pa, pb = rec->pb, pc = rec->pc;
-  const float4 A = p4[rec->ids[0]], B = p4[rec->ids[1]], Cc = p4[rec->ids[2]];
-  unsigned long long key = ~0ull;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_p; i += gridDim.x * blockDim.x) {
-    const float4 p = p4[i];
-    const float d = fabsf(((pa * p.x + pb * p.y) + pc * p.z) - 1.0f);
-    if (!(d < 3.402823466e+38f)) continue;
-    if (!(sqn3(p.x - A.x, p.y - A.y, p.z - A.z) >= too_small)) continue;
-    if (!(sqn3(p.x - B.x, p.y - B.y, p.z - B.z) >= too_small)) continue;
-    if (!(sqn3(p.x - Cc.x, p.y - Cc.y, p.z - Cc.z) >= too_small)) continue;
-    const unsigned long long k2 = (static_cast<unsigned long long>(__float_as_uint(d)) << 32) | i;
-    key = k2 < key ? k2 : key;
+// One pass over the sampled P for ALL attempts of a batch: a thread holds a tile of points in registers and the best
+// (distance, index) key of every attempt so far, so the 16 bytes of a point are read once per batch instead of once per
+// attempt (at n_P = 4.2 M: 67 MB per scan).  A point further from an attempt's plane than that attempt's best so far cannot
+// become its minimum and skips the three sphere tests; equal distances still compete on the index (the reference keeps the
+// first, match4pcsBase.cc:324-338).  The minimum does not depend on the order of the scan.
+constexpr int kSelectTile = 4;
+__global__ __launch_bounds__(256, 2) void k_select_fourth(const float4* __restrict__ p4, uint32_t n_p, float too_small, SelectRecord* rec_all,
+                                                          int32_t n_attempts) {
+  __shared__ float4 s_par[kSelectBatch][3];        // {pa, pb, pc, A.x} {A.y, A.z, B.x, B.y} {B.z, C.x, C.y, C.z}
+  __shared__ uint32_t s_live;                      // bit a: attempt a has a triangle and a plane and waits for its fourth point
+  const uint32_t t = threadIdx.x;
+  if (t == 0) s_live = 0u;
+  __syncthreads();
+  if (t < uint32_t(n_attempts) && rec_all[t].status == kSelectNoFourth) {
+    const SelectRecord* rec = rec_all + t;
+    const float4 A = p4[rec->ids[0]], B = p4[rec->ids[1]], Cc = p4[rec->ids[2]];
+    s_par[t][0] = make_float4(rec->pa, rec->pb, rec->pc, A.x);
+    s_par[t][1] = make_float4(A.y, A.z, B.x, B.y);
+    s_par[t][2] = make_float4(B.z, Cc.x, Cc.y, Cc.z);
+    atomicOr(&s_live, 1u << t);
   }
-  for (int s = 32; s > 0; s >>= 1) { const unsigned long long k2 = shfl_xor_u64(key, s); key = k2 < key ? k2 : key; }
-  if ((threadIdx.x & 63u) == 0 && key != ~0ull) atomicMin(&rec->fourth_key, key);
+  __syncthreads();
+  const uint32_t live = s_live;
+  if (live == 0u) return;
+  unsigned long long key[kSelectBatch];
+#pragma unroll
+  for (int a = 0; a < kSelectBatch; ++a) key[a] = ~0ull;
+  const uint32_t stride = gridDim.x * blockDim.x;
+  const float not_a_point = __uint_as_float(0x7FC00000u);          // past the end: the distance is a NaN and fails `d < FLT_MAX`
+  for (uint32_t i0 = blockIdx.x * blockDim.x + t; i0 < n_p; i0 += uint32_t(kSelectTile) * stride) {
+    float4 p[kSelectTile];
+#pragma unroll
+    for (int k = 0; k < kSelectTile; ++k) p[k] = p4[min(i0 + uint32_t(k) * stride, n_p - 1u)];      // (the loads of a tile in flight together)
+#pragma unroll
+    for (int k = 0; k < kSelectTile; ++k) p[k].x = i0 + uint32_t(k) * stride < n_p ? p[k].x : not_a_point;
+    // the 12 parameters of an attempt are re-read from LDS for every tile (3 ds_read_b128 against ~50 vector instructions per
+    // point): hoisted out of the scan they would be 192 registers and cost the occupancy that hides the loads of the tile
+    uint32_t zero = 0u;
+    asm volatile("" : "+v"(zero));
+#pragma unroll
+    for (int a = 0; a < kSelectBatch; ++a) {
+      if (!((live >> a) & 1u)) continue;
+      const float4* par = s_par[uint32_t(a) + zero];
+      const float4 q0 = par[0], q1 = par[1], q2 = par[2];
+#pragma unroll
+      for (int k = 0; k < kSelectTile; ++k) {
+        const float d = fabsf(((q0.x * p[k].x + q0.y * p[k].y) + q0.z * p[k].z) - 1.0f);
+        // one rarely-taken branch per point and attempt: `d < FLT_MAX` drops infinities and NaNs (whose bit patterns would pass
+        // the comparison with the initial key), the bit comparison everything further from the plane than the best so far
+        if (__float_as_uint(d) <= uint32_t(key[a] >> 32) && d < 3.402823466e+38f) {
+          const bool far = sqn3(p[k].x - q0.w, p[k].y - q1.x, p[k].z - q1.y) >= too_small &&
+                           sqn3(p[k].x - q1.z, p[k].y - q1.w, p[k].z - q2.x) >= too_small &&
+                           sqn3(p[k].x - q2.y, p[k].y - q2.z, p[k].z - q2.w) >= too_small;
+          const unsigned long long k2 = (static_cast<unsigned long long>(__float_as_uint(d)) << 32) | (i0 + uint32_t(k) * stride);
+          key[a] = (far && k2 < key[a]) ? k2 : key[a];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < kSelectBatch; ++a) {
+    if (!((live >> a) & 1u)) continue;
+    unsigned long long best = key[a];
+    for (int s = 32; s > 0; s >>= 1) { const unsigned long long k2 = shfl_xor_u64(best, s); best = k2 < best ? k2 : best; }
+    if ((t & 63u) == 0 && best != ~0ull) atomicMin(&rec_all[a].fourth_key, best);
+  }
 }
 
 __global__ void k_select_finish(const float4* __restrict__ p4, SelectRecord* rec_all) {

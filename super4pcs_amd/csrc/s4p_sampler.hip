@@ -15,7 +15,9 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <mutex>
 #include <vector>
 
@@ -161,11 +163,19 @@ long long gpu_uniform_dist_sample(const float* x, const float* y, const float* z
     S.cap_blocks = nblocks;
   }
   if (!S.d_misc && !ok(hipMalloc((void**)&S.d_misc, 8))) return -2;
+  // S4P_TRACE_INIT=1 (lab aid): upload / kernels / read-back of this call on stderr; costs two extra synchronisations
+  static const bool trace = std::getenv("S4P_TRACE_INIT") != nullptr;
+  using clk = std::chrono::steady_clock;
+  const auto t_begin = clk::now();
+  auto ms_since = [](clk::time_point a) { return std::chrono::duration<double, std::milli>(clk::now() - a).count(); };
   float* dx = S.d_xyz; float* dy = dx + un; float* dz = dy + un;
   if (!ok(hipMemcpyAsync(dx, x, un * 4, hipMemcpyHostToDevice, S.stream)) || !ok(hipMemcpyAsync(dy, y, un * 4, hipMemcpyHostToDevice, S.stream)) ||
       !ok(hipMemcpyAsync(dz, z, un * 4, hipMemcpyHostToDevice, S.stream))) return -2;
   if (!ok(hipMemsetAsync(S.d_keys, 0xFF, tab * 8, S.stream)) || !ok(hipMemsetAsync(S.d_vals, 0xFF, tab * 4, S.stream)) ||
       !ok(hipMemsetAsync(S.d_misc, 0, 8, S.stream))) return -2;
+  double ms_upload = 0.0;
+  if (trace) { if (!ok(hipStreamSynchronize(S.stream))) return -2; ms_upload = ms_since(t_begin); }
+  const auto t_kernels = clk::now();
   const float scale = 1.0f / delta;                                                      // sampling.h:76
   hipLaunchKernelGGL(k_vox_insert, dim3(2048), dim3(256), 0, S.stream, dx, dy, dz, uint32_t(un), scale, S.d_keys, S.d_vals, uint32_t(tab - 1), S.d_slot, S.d_misc + 1);
   hipLaunchKernelGGL(k_vox_flag, dim3(nblocks), dim3(kScanBlock), 0, S.stream, S.d_vals, S.d_slot, uint32_t(un), S.d_blocks);
@@ -174,10 +184,14 @@ long long gpu_uniform_dist_sample(const float* x, const float* y, const float* z
   uint32_t misc[2] = {0, 0};
   if (!ok(hipGetLastError()) || !ok(hipMemcpyAsync(misc, S.d_misc, 8, hipMemcpyDeviceToHost, S.stream)) || !ok(hipStreamSynchronize(S.stream))) return -2;
   if (misc[1]) return -1;                         // a voxel coordinate outside +-2^20: host path handles it
+  const double ms_kernels = ms_since(t_kernels);
+  const auto t_back = clk::now();
   const uint32_t kept = misc[0];
   std::vector<uint32_t> idx(kept);
   if (kept && !ok(hipMemcpy(idx.data(), S.d_out, size_t(kept) * 4, hipMemcpyDeviceToHost))) return -2;
   for (uint32_t i = 0; i < kept; ++i) out_index[i] = (long long)idx[i];
+  if (trace) std::fprintf(stderr, "{\"s4p_trace\": \"device sampler\", \"points\": %lld, \"kept\": %u, \"alloc_and_upload_ms\": %.3f, \"kernels_ms\": %.3f, \"read_back_ms\": %.3f}\n",
+                          n, kept, ms_upload, ms_kernels, ms_since(t_back));
   return (long long)kept;
 }
 

@@ -109,6 +109,51 @@ def test_attempt_status_codes(s4p_lib_built):
     _check_attempts(capi, ball, 0.05, 1e3, 3, 4, expect={3})
 
 
+def test_a_batch_of_attempts_equals_the_attempts_one_by_one(s4p_lib_built):
+    """k_select_fourth scans P once for a whole batch: every batch size up to the maximum, attempts that have no triangle
+    (all draws equal: every cross product is zero) mixed with attempts that find a base, against the literal loops and against
+    the same attempts evaluated singly."""
+    from super4pcs_amd import capi, datasets
+    P, _Q, _ = datasets.bumpy_pair(60000, overlap=0.6, delta=0.01, noise_sigma=0.003, seed=13)
+    P = P.astype(F) - P.astype(F).mean(axis=0)
+    ctx = _ctx_for(capi, P, 0.01)
+    rng = np.random.default_rng(17)
+    limit_sq = float(F(0.7) * F(0.7))
+    too_small = float(F(float(F(0.7) * F(0.2)) ** 2))
+    bmax = int(ctx.L.s4p_select_batch_max())
+    assert bmax >= 16
+    seen = set()
+    for n in (1, 2, 3, 5, 8, 13, bmax):
+        draws = rng.integers(0, len(P), (n, 2001)).astype(np.uint32)
+        for a in range(1, n, 3):
+            draws[a, :] = draws[a, 0]                           # SelectRandomTriangle fails for this attempt only
+        st, ids, xyz = ctx.select_base_points_batch(draws, limit_sq, too_small)
+        for a in range(n):
+            w_st, w_ids = _literal_attempt(P, draws[a], limit_sq, too_small)
+            assert int(st[a]) == w_st and list(ids[a]) == w_ids, (n, a, int(st[a]), list(ids[a]), w_st, w_ids)
+            s1, i1, x1 = ctx.select_base_points(draws[a], limit_sq, too_small)
+            assert s1 == int(st[a]) and np.array_equal(i1, ids[a]) and np.array_equal(x1, xyz[a])
+            seen.add(w_st)
+    assert seen == {0, 1}, seen
+    # ties and the "no admissible fourth point" answer inside a batch
+    g = np.arange(12, dtype=F)
+    L = np.stack(np.meshgrid(g, g, g, indexing="ij"), axis=-1).reshape(-1, 3) * F(0.25) + F(0.5)
+    L = np.concatenate([L, L[::-1]])
+    ctx = _ctx_for(capi, L, 0.25)
+    draws = rng.integers(0, len(L), (bmax, 2001)).astype(np.uint32)
+    st, ids, _ = ctx.select_base_points_batch(draws, float(F(2.0) * F(2.0)), float(F(float(F(2.0) * F(0.2)) ** 2)))
+    for a in range(bmax):
+        w_st, w_ids = _literal_attempt(L, draws[a], float(F(2.0) * F(2.0)), float(F(float(F(2.0) * F(0.2)) ** 2)))
+        assert int(st[a]) == w_st and list(ids[a]) == w_ids, (a, int(st[a]), list(ids[a]), w_st, w_ids)
+    ball = rng.normal(size=(4096, 3)).astype(F)
+    ball /= np.linalg.norm(ball, axis=1, keepdims=True).astype(F)
+    ball = (ball + F(3.0)).astype(F)
+    ctx = _ctx_for(capi, ball, 0.05)
+    draws = rng.integers(0, len(ball), (7, 2001)).astype(np.uint32)
+    st, ids, _ = ctx.select_base_points_batch(draws, 1e3 * 1e3, float(F(float(F(1e3) * F(0.2)) ** 2)))
+    assert list(st) == [3] * 7 and all(int(i[3]) == -1 for i in ids)
+
+
 def test_out_of_range_draw_is_refused(s4p_lib_built):
     from super4pcs_amd import capi
     P = np.random.default_rng(0).random((1000, 3)).astype(F)

@@ -46,6 +46,7 @@ if __name__ == "__main__":
             for producer in (True, False):
                 run("configs[2] 1 M-point pair (n_P = 57 k)", P, Q, bench.DELTA, bench.OVERLAP, bench.SAMPLE, (1, 2, 3, 4, 6, 8), 60, producer)
         sys.exit(0)
-    run("configs[2] 1 M-point pair (n_P = 57 k)", P, Q, bench.DELTA, bench.OVERLAP, bench.SAMPLE, (1, 2, 4, 8), 60)
+    if "--only-big" not in sys.argv:
+        run("configs[2] 1 M-point pair (n_P = 57 k)", P, Q, bench.DELTA, bench.OVERLAP, bench.SAMPLE, (1, 2, 4, 8), 60)
     P, Q, _ = D.part_in_whole_pair(10_000_000, 100_000, delta=0.05)
     run("configs[4] 10 M-point scene (n_P = 4.2 M)", P, Q, 0.05, 0.2, 2000, (1, 8), 40)
