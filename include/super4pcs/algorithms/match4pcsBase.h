@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <array>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <exception>
@@ -26,6 +27,21 @@
 
 #ifdef S4P_HAVE_EIGEN
 #include <Eigen/Geometry>
+#endif
+
+// -DS4P_FACADE_TRACE: where a ComputeTransformation call spends its time on the host side of the C ABI (stderr); lab aid
+#ifdef S4P_FACADE_TRACE
+#include <cstdio>
+#define S4P_FACADE_LAP(what)                                                                                     \
+  do {                                                                                                           \
+    const auto s4p_now_ = std::chrono::steady_clock::now();                                                      \
+    std::fprintf(stderr, "[facade] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(s4p_now_ - s4p_lap_).count()); \
+    s4p_lap_ = s4p_now_;                                                                                         \
+  } while (0)
+#define S4P_FACADE_LAP_BEGIN() auto s4p_lap_ = std::chrono::steady_clock::now()
+#else
+#define S4P_FACADE_LAP(what) do {} while (0)
+#define S4P_FACADE_LAP_BEGIN() do {} while (0)
 #endif
 
 namespace GlobalRegistration {
@@ -94,6 +110,7 @@ class Match4PCSBase {
   // ---- match4pcsBase.hpp:90-203 ------------------------------------------------------------------
   template <typename Sampler>
   void init(const std::vector<Point3D>& P, const std::vector<Point3D>& Q, const Sampler& sampler) {
+    S4P_FACADE_LAP_BEGIN();
     std::vector<Point3D> ps, qu;
     const bool sample_q = Q.size() > options_.sample_size;
     // Q_copy_ = Q (match4pcsBase.hpp:191) is a whole-cloud copy nothing below reads: it runs beside the sampling and the
@@ -106,13 +123,18 @@ class Match4PCSBase {
       void wait() { if (t.joinable()) t.join(); if (failed) { std::exception_ptr f = failed; failed = nullptr; std::rethrow_exception(f); } }
       ~CopyOfQ() { if (t.joinable()) t.join(); }
     } copy_of_q(Q_copy_, Q);
+    S4P_FACADE_LAP("start copy of Q");
     if (P.size() > options_.sample_size) sampler(P, options_, ps);
     else { Log<LogLevel::ErrorReport>("(P) More samples requested than available: use whole cloud"); ps = P; }
+    S4P_FACADE_LAP("sampler(P)");
     if (sample_q) sampler(Q, options_, qu);
     else { Log<LogLevel::ErrorReport>("(Q) More samples requested than available: use whole cloud"); qu = Q; }
+    S4P_FACADE_LAP("sampler(Q)");
     Soa sp(ps), sq(qu);
     const s4p_cloud_view vp = sp.view(), vq = sq.view();
+    S4P_FACADE_LAP("SoA of the samples");
     check(s4p_matcher_init(engine_, &vp, &vq, sample_q ? 1 : 0));
+    S4P_FACADE_LAP("s4p_matcher_init");
     refresh();
     // sampled clouds as the engine holds them (centred; Q shuffled and truncated)
     pull_sampled(0, ps, sampled_P_3D_);
@@ -121,7 +143,9 @@ class Match4PCSBase {
     // The virtual handler, "called once the internal state of the Base class has been set" (match4pcsBase.h:262-272,
     // match4pcsBase.hpp:197-198): with the caller's P and Q, after sampling / centring / the trial count, and with
     // best_LCP_ still 0 -- the initial LCP (= Verify(transform_), :200) is assigned after it, as in the reference.
+    S4P_FACADE_LAP("pull sampled clouds");
     copy_of_q.wait();
+    S4P_FACADE_LAP("wait for the copy of Q");
     const Scalar initial_lcp = best_LCP_;
     best_LCP_ = Scalar(0);
     Initialize(P, Q);
@@ -140,6 +164,7 @@ class Match4PCSBase {
   template <typename Visitor>
   bool Perform_N_steps(int n, MatrixRef transformation, std::vector<Point3D>* Q, const Visitor& v) {
     if (Q == nullptr) return false;
+    S4P_FACADE_LAP_BEGIN();
     float M[16];
     to_rowmajor(transformation, M);
     int32_t improved = 0, done = 0;
@@ -174,6 +199,7 @@ class Match4PCSBase {
       if (improved) { current_transform(true, M); from_rowmajor(M, transformation); }      // getGlobalTransform, :259-262
       done = (ok || current_trial_ >= number_of_trials_) ? 1 : 0;
     }
+    S4P_FACADE_LAP("trial loop");
     if (improved) {                                   // :259-268 -- the final apply runs on the GPU (k_apply)
       // *Q = Q_copy_ with the transformed positions: one pass out of the AoS copy, one pass back into *Q
       const size_t nq = Q_copy_.size();
@@ -182,12 +208,15 @@ class Match4PCSBase {
       detail::for_ranges(nq, [&](size_t b, size_t e) {
         for (size_t i = b; i < e; ++i) { x[i] = src[i].x(); y[i] = src[i].y(); z[i] = src[i].z(); }
       });
+      S4P_FACADE_LAP("positions out of Q_copy_");
       check(s4p_transform_points(s4p_matcher_ctx(engine_), M, x.get(), y.get(), z.get(), int64_t(nq)));
+      S4P_FACADE_LAP("s4p_transform_points");
       Q->resize(nq);
       std::vector<Point3D>& dst = *Q;
       detail::for_ranges(nq, [&](size_t b, size_t e) {
         for (size_t i = b; i < e; ++i) { Point3D p = src[i]; p.x() = x[i]; p.y() = y[i]; p.z() = z[i]; dst[i] = p; }
       });
+      S4P_FACADE_LAP("*Q = Q_copy_, transformed");
     }
     return done != 0;
   }
@@ -308,24 +337,34 @@ class Match4PCSBase {
   }
 
  private:
+  // SoA view of a cloud for the C ABI: positions always; normals / colours only when some point carries them (the flags are
+  // found in a first pass, so that a plain xyz cloud costs three arrays, not nine); whole-cloud sizes on a few threads
   struct Soa {
-    std::vector<float> a[9];
+    std::unique_ptr<float[]> a[9];
+    size_t n = 0;
     bool has_n = false, has_c = false;
-    explicit Soa(const std::vector<Point3D>& pts) {
-      const size_t n = pts.size();
-      for (auto& v : a) v.resize(n);
-      for (size_t i = 0; i < n; ++i) {
-        a[0][i] = pts[i].x(); a[1][i] = pts[i].y(); a[2][i] = pts[i].z();
-        for (int k = 0; k < 3; ++k) { a[3 + k][i] = pts[i].normal()(k); a[6 + k][i] = pts[i].rgb()(k); }
-        has_n = has_n || pts[i].normal().squaredNorm() > 0.f;
-        has_c = has_c || pts[i].rgb()(0) >= 0.f;
-      }
+    explicit Soa(const std::vector<Point3D>& pts) : n(pts.size()) {
+      std::atomic<unsigned> flags{0u};
+      detail::for_ranges(n, [&](size_t b, size_t e) {
+        unsigned f = 0;
+        for (size_t i = b; i < e && f != 3u; ++i)
+          f |= (pts[i].normal().squaredNorm() > 0.f ? 1u : 0u) | (pts[i].rgb()(0) >= 0.f ? 2u : 0u);
+        flags.fetch_or(f, std::memory_order_relaxed);
+      });
+      has_n = (flags.load() & 1u) != 0; has_c = (flags.load() & 2u) != 0;
+      for (int k = 0; k < 3; ++k) a[k].reset(new float[n ? n : 1]);
+      if (has_n) for (int k = 3; k < 6; ++k) a[k].reset(new float[n ? n : 1]);
+      if (has_c) for (int k = 6; k < 9; ++k) a[k].reset(new float[n ? n : 1]);
+      detail::for_ranges(n, [&](size_t b, size_t e) {
+        for (size_t i = b; i < e; ++i) { a[0][i] = pts[i].x(); a[1][i] = pts[i].y(); a[2][i] = pts[i].z(); }
+        if (has_n) for (size_t i = b; i < e; ++i) for (int k = 0; k < 3; ++k) a[3 + k][i] = pts[i].normal()(k);
+        if (has_c) for (size_t i = b; i < e; ++i) for (int k = 0; k < 3; ++k) a[6 + k][i] = pts[i].rgb()(k);
+      });
     }
     s4p_cloud_view view() const {
-      return s4p_cloud_view{a[0].data(), a[1].data(), a[2].data(),
-                            has_n ? a[3].data() : nullptr, has_n ? a[4].data() : nullptr, has_n ? a[5].data() : nullptr,
-                            has_c ? a[6].data() : nullptr, has_c ? a[7].data() : nullptr, has_c ? a[8].data() : nullptr,
-                            int64_t(a[0].size())};
+      return s4p_cloud_view{a[0].get(), a[1].get(), a[2].get(),
+                            has_n ? a[3].get() : nullptr, has_n ? a[4].get() : nullptr, has_n ? a[5].get() : nullptr,
+                            has_c ? a[6].get() : nullptr, has_c ? a[7].get() : nullptr, has_c ? a[8].get() : nullptr, int64_t(n)};
     }
   };
   template <typename Visitor>
@@ -366,17 +405,22 @@ class Match4PCSBase {
     s4p_matcher_info i;
     check(s4p_matcher_get_info(engine_, &i));
     const size_t n = size_t(which == 0 ? i.n_sampled_p : i.n_sampled_q);
-    std::vector<float> v[9];
-    for (auto& a : v) a.resize(n);
     int32_t has_n = 0, has_c = 0;
-    check(s4p_matcher_get_sampled(engine_, which, v[0].data(), v[1].data(), v[2].data()));
-    check(s4p_matcher_get_sampled_attrs(engine_, which, v[3].data(), v[4].data(), v[5].data(), v[6].data(), v[7].data(), v[8].data(), &has_n, &has_c));
+    check(s4p_matcher_get_sampled_attrs(engine_, which, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &has_n, &has_c));   // the flags only
+    std::unique_ptr<float[]> v[9];
+    for (int k = 0; k < 9; ++k)
+      if (k < 3 || (k < 6 ? has_n : has_c)) v[k].reset(new float[n ? n : 1]);
+    check(s4p_matcher_get_sampled(engine_, which, v[0].get(), v[1].get(), v[2].get()));
+    if (has_n || has_c)
+      check(s4p_matcher_get_sampled_attrs(engine_, which, v[3].get(), v[4].get(), v[5].get(), v[6].get(), v[7].get(), v[8].get(), nullptr, nullptr));
     out.assign(n, Point3D());
-    for (size_t k = 0; k < n; ++k) {
-      out[k].x() = v[0][k]; out[k].y() = v[1][k]; out[k].z() = v[2][k];
-      if (has_n) out[k].set_normal(typename Point3D::VectorType(v[3][k], v[4][k], v[5][k]));
-      if (has_c) out[k].set_rgb(typename Point3D::VectorType(v[6][k], v[7][k], v[8][k]));
-    }
+    detail::for_ranges(n, [&](size_t b, size_t e) {
+      for (size_t k = b; k < e; ++k) {
+        out[k].x() = v[0][k]; out[k].y() = v[1][k]; out[k].z() = v[2][k];
+        if (has_n) out[k].set_normal(typename Point3D::VectorType(v[3][k], v[4][k], v[5][k]));
+        if (has_c) out[k].set_rgb(typename Point3D::VectorType(v[6][k], v[7][k], v[8][k]));
+      }
+    });
   }
 };
 

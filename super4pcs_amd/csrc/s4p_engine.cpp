@@ -180,6 +180,9 @@ struct s4p_matcher {
     std::thread drawer, evals[2], assembler;
     int n_eval = 2;
     std::atomic<uint64_t> select_ns{0};
+    // S4P_TRACE_CHAIN=1 (lab aid): busy time of every stage of the host chain, printed when the helpers stop
+    std::atomic<uint64_t> draw_ns{0}, tree_ns{0}, batches{0}, attempts_done{0}, trials_done{0};
+    std::chrono::steady_clock::time_point started;
     bool partial = false; std::mt19937 partial_rng;     // the assembler stopped inside a trial: where that trial's draws began
     std::mutex mu;
     // one condition per wait reason: a hand-off wakes only the thread that can use it, and a full queue's
@@ -445,9 +448,11 @@ void drawer_main(s4p_matcher* m) {
     const uint32_t slot = uint32_t(seq % s4p_matcher::Producer::kRing);
     if (!wait_state(P.ring_state[slot], s4p_matcher::Producer::tag(seq, 0u), P.stop_flag)) return;
     s4p_matcher::Producer::Attempt& a = P.ring[slot];
+    const auto t0 = std::chrono::steady_clock::now();
     a.rng_before = m->rng;
     a.status = -1;
     if (n) draw_attempt(m->rng, n, a.idx);
+    P.draw_ns.fetch_add(uint64_t(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count()), std::memory_order_relaxed);
     P.ring_state[slot].store(s4p_matcher::Producer::tag(seq, 1u), std::memory_order_release);
     P.drawn.store(seq + 1, std::memory_order_release);
   }
@@ -466,6 +471,7 @@ void evaluator_main(s4p_matcher* m) {
       const auto t0 = clk::now();
       a.status = m->Ps.size() ? eval_attempt_host(m, a.idx, a.ids, a.inv1, a.inv2) : kAttemptNoTriangle;
       P.select_ns.fetch_add(uint64_t(std::chrono::duration_cast<std::chrono::nanoseconds>(clk::now() - t0).count()));
+      P.batches.fetch_add(1, std::memory_order_relaxed); P.attempts_done.fetch_add(1, std::memory_order_relaxed);
       P.ring_state[slot].store(s4p_matcher::Producer::tag(seq, 2u), std::memory_order_release);
     }
   }
@@ -498,6 +504,7 @@ void evaluator_main(s4p_matcher* m) {
       }
     }
     P.select_ns.fetch_add(uint64_t(std::chrono::duration_cast<std::chrono::nanoseconds>(clk::now() - t0).count()));
+    P.batches.fetch_add(1, std::memory_order_relaxed); P.attempts_done.fetch_add(uint64_t(nb), std::memory_order_relaxed);
     for (int k = 0; k < nb; ++k) P.ring_state[(seq0 + uint64_t(k)) % s4p_matcher::Producer::kRing].store(s4p_matcher::Producer::tag(seq0 + uint64_t(k), 2u), std::memory_order_release);
     P.claimed.store(seq0 + uint64_t(nb));
   }
@@ -549,6 +556,7 @@ void tree_main(s4p_matcher* m) {
       P.qa_ready.store(P.qa.size(), std::memory_order_release);
       wake_selector = P.qa.size() == P.cap_a / 2; }
     if (wake_selector) P.cv_a_space.notify_one();
+    const auto tree_t0 = std::chrono::steady_clock::now();
     if (t.found && t.owned) {
       std::unique_lock<std::mutex> lk(P.mu);
       P.cv_slot.wait(lk, [&] { return P.stop || !P.free_slots.empty(); });
@@ -559,6 +567,8 @@ void tree_main(s4p_matcher* m) {
     s4p_pair_state_save(m->ctx, t.pair_before.data());
     if (t.found) (void)s4p_stage_base(m->ctx, t.bx, t.bn, t.owned ? 1 : 0, t.owned ? t.slot : 0);
     t.staged = true;
+    P.tree_ns.fetch_add(uint64_t(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tree_t0).count()), std::memory_order_relaxed);
+    P.trials_done.fetch_add(1, std::memory_order_relaxed);
     { std::unique_lock<std::mutex> lk(P.mu);
       P.cv_b_space.wait(lk, [&] { return P.stop || P.qb.size() < P.cap_b; });
       P.qb.push_back(std::move(t));       // also when stopping: its octree effect is already applied
@@ -593,6 +603,8 @@ void producer_start(s4p_matcher* m) {
   if (!P.ring) P.ring.reset(new s4p_matcher::Producer::Attempt[s4p_matcher::Producer::kRing]);
   for (auto& st : P.ring_state) st.store(0ull);
   P.drawn.store(0); P.claimed.store(0); P.taken.store(0); P.partial = false;
+  P.draw_ns.store(0); P.tree_ns.store(0); P.batches.store(0); P.attempts_done.store(0); P.trials_done.store(0);
+  P.started = std::chrono::steady_clock::now();
   P.n_eval = m->device_select ? 1 : 2;
   P.drawer = std::thread(drawer_main, m);
   for (int k = 0; k < P.n_eval; ++k) P.evals[k] = std::thread(evaluator_main, m);
@@ -612,6 +624,15 @@ void producer_stop(s4p_matcher* m) {
   for (int k = 0; k < P.n_eval; ++k) P.evals[k].join();
   P.assembler.join(); P.tree.join();
   P.running = false;
+  if (std::getenv("S4P_TRACE_CHAIN")) {
+    const double wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - P.started).count();
+    std::fprintf(stderr, "{\"s4p_trace\": \"host chain\", \"world\": %d, \"device_selection\": %d, \"wall_ms\": %.3f, \"attempts_drawn\": %llu, "
+                 "\"attempts_evaluated\": %llu, \"evaluator_calls\": %llu, \"trials_staged\": %llu, \"trials_consumed\": %ld, \"drawer_busy_ms\": %.3f, "
+                 "\"evaluators_busy_ms\": %.3f, \"tree_busy_ms\": %.3f}\n", P.world, m->device_select ? 1 : 0, wall_ms,
+                 (unsigned long long)P.drawn.load(), (unsigned long long)P.attempts_done.load(), (unsigned long long)P.batches.load(),
+                 (unsigned long long)P.trials_done.load(), P.consumed, double(P.draw_ns.load()) * 1e-6, double(P.select_ns.load()) * 1e-6,
+                 double(P.tree_ns.load()) * 1e-6);
+  }
   // the random stream goes back to where the first trial that was not handed to the main thread began
   if (!P.qb.empty()) {
     m->rng = P.qb.front().rng_before;

@@ -2382,9 +2382,11 @@ __global__ __launch_bounds__(1024) void k_select_triangle(const float4* __restri
 
 // One pass over the sampled P for ALL attempts of a batch: a thread holds a tile of points in registers and the best
 // (distance, index) key of every attempt so far, so the 16 bytes of a point are read once per batch instead of once per
-// attempt (at n_P = 4.2 M: 67 MB per scan).  A point further from an attempt's plane than that attempt's best so far cannot
-// become its minimum and skips the three sphere tests; equal distances still compete on the index (the reference keeps the
-// first, match4pcsBase.cc:324-338).  The minimum does not depend on the order of the scan.
+// attempt (at n_P = 4.2 M: 67 MB per scan).  A point further from an attempt's plane than the best admissible point known so
+// far cannot become the minimum and skips the three sphere tests; equal distances still compete on the index (the reference
+// keeps the first, match4pcsBase.cc:324-338).  To make that filter bite, trip 0 takes ONE point per thread through every
+// test, the waves publish their minima (atomicMin on the records, as at the end), and from trip 1 on every thread starts a
+// tile from the best key anyone has published: adopting another thread's key cannot change the minimum over all points.
 constexpr int kSelectTile = 4;
 __global__ __launch_bounds__(256, 2) void k_select_fourth(const float4* __restrict__ p4, uint32_t n_p, float too_small, SelectRecord* rec_all,
                                                           int32_t n_attempts) {
@@ -2407,16 +2409,39 @@ __global__ __launch_bounds__(256, 2) void k_select_fourth(const float4* __restri
   unsigned long long key[kSelectBatch];
 #pragma unroll
   for (int a = 0; a < kSelectBatch; ++a) key[a] = ~0ull;
-  const uint32_t stride = gridDim.x * blockDim.x;
-  const float not_a_point = __uint_as_float(0x7FC00000u);          // past the end: the distance is a NaN and fails `d < FLT_MAX`
-  for (uint32_t i0 = blockIdx.x * blockDim.x + t; i0 < n_p; i0 += uint32_t(kSelectTile) * stride) {
+  auto publish = [&]() {                           // (every lane of the block is here: `live` and the trip count are uniform)
+#pragma unroll
+    for (int a = 0; a < kSelectBatch; ++a) {
+      if (!((live >> a) & 1u)) continue;
+      unsigned long long best = key[a];
+      for (int s = 32; s > 0; s >>= 1) { const unsigned long long k2 = shfl_xor_u64(best, s); best = k2 < best ? k2 : best; }
+      if ((t & 63u) == 0 && best != ~0ull) atomicMin(&rec_all[a].fourth_key, best);
+    }
+  };
+  const uint32_t nthreads = gridDim.x * blockDim.x, gid = blockIdx.x * blockDim.x + t;
+  const uint32_t rest = n_p > nthreads ? n_p - nthreads : 0u;
+  const uint32_t trips = 1u + (rest + uint32_t(kSelectTile) * nthreads - 1u) / (uint32_t(kSelectTile) * nthreads);
+  const float not_a_point = __uint_as_float(0x7FC00000u);          // no point in this slot: the distance is a NaN and fails `d < FLT_MAX`
+  for (uint32_t trip = 0; trip < trips; ++trip) {
+    uint32_t idx[kSelectTile];
     float4 p[kSelectTile];
 #pragma unroll
-    for (int k = 0; k < kSelectTile; ++k) p[k] = p4[min(i0 + uint32_t(k) * stride, n_p - 1u)];      // (the loads of a tile in flight together)
+    for (int k = 0; k < kSelectTile; ++k)
+      idx[k] = trip == 0u ? (k == 0 ? gid : 0xFFFFFFFFu) : nthreads + ((trip - 1u) * uint32_t(kSelectTile) + uint32_t(k)) * nthreads + gid;
 #pragma unroll
-    for (int k = 0; k < kSelectTile; ++k) p[k].x = i0 + uint32_t(k) * stride < n_p ? p[k].x : not_a_point;
-    // the 12 parameters of an attempt are re-read from LDS for every tile (3 ds_read_b128 against ~50 vector instructions per
-    // point): hoisted out of the scan they would be 192 registers and cost the occupancy that hides the loads of the tile
+    for (int k = 0; k < kSelectTile; ++k) p[k] = p4[min(idx[k], n_p - 1u)];      // (the loads of a tile in flight together)
+#pragma unroll
+    for (int k = 0; k < kSelectTile; ++k) p[k].x = idx[k] < n_p ? p[k].x : not_a_point;
+    if (trip != 0u) {
+#pragma unroll
+      for (int a = 0; a < kSelectBatch; ++a) {
+        if (!((live >> a) & 1u)) continue;
+        const unsigned long long seen = __hip_atomic_load(&rec_all[a].fourth_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        key[a] = seen < key[a] ? seen : key[a];
+      }
+    }
+    // the 12 parameters of an attempt are re-read from LDS for every tile (3 ds_read_b128 against the vector instructions of
+    // four points): hoisted out of the scan they would be 192 registers and cost the occupancy that hides the loads of the tile
     uint32_t zero = 0u;
     asm volatile("" : "+v"(zero));
 #pragma unroll
@@ -2433,19 +2458,14 @@ __global__ __launch_bounds__(256, 2) void k_select_fourth(const float4* __restri
           const bool far = sqn3(p[k].x - q0.w, p[k].y - q1.x, p[k].z - q1.y) >= too_small &&
                            sqn3(p[k].x - q1.z, p[k].y - q1.w, p[k].z - q2.x) >= too_small &&
                            sqn3(p[k].x - q2.y, p[k].y - q2.z, p[k].z - q2.w) >= too_small;
-          const unsigned long long k2 = (static_cast<unsigned long long>(__float_as_uint(d)) << 32) | (i0 + uint32_t(k) * stride);
+          const unsigned long long k2 = (static_cast<unsigned long long>(__float_as_uint(d)) << 32) | idx[k];
           key[a] = (far && k2 < key[a]) ? k2 : key[a];
         }
       }
     }
+    if (trip == 0u && trips > 1u) publish();
   }
-#pragma unroll
-  for (int a = 0; a < kSelectBatch; ++a) {
-    if (!((live >> a) & 1u)) continue;
-    unsigned long long best = key[a];
-    for (int s = 32; s > 0; s >>= 1) { const unsigned long long k2 = shfl_xor_u64(best, s); best = k2 < best ? k2 : best; }
-    if ((t & 63u) == 0 && best != ~0ull) atomicMin(&rec_all[a].fourth_key, best);
-  }
+  publish();
 }
 
 __global__ void k_select_finish(const float4* __restrict__ p4, SelectRecord* rec_all) {
