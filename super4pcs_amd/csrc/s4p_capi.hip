@@ -1815,9 +1815,10 @@ int32_t s4p_select_base_points_batch(s4p_ctx* c, const uint32_t* draws, int32_t 
   std::memcpy(c->sel_hdraws.p, draws, sizeof(uint32_t) * nd);
   HIPCHK(c, hipMemcpyAsync(c->sel_draws.p, c->sel_hdraws.p, sizeof(uint32_t) * nd, hipMemcpyHostToDevice, st));
   hipLaunchKernelGGL(k_select_triangle, dim3(uint32_t(n_attempts)), dim3(1024), 0, st, c->p4o.p, c->sel_draws.p, limit_sq, c->sel_rec.p);
-  // (one scan of P serves the whole batch: one point per thread in the first trip, kSelectTile per thread and trip after it)
-  const uint32_t blocks = std::max<uint32_t>(1u, std::min<uint32_t>(1024u, (c->n_p + 255u) / 256u));
-  hipLaunchKernelGGL(k_select_fourth, dim3(blocks), dim3(256), 0, st, c->p4o.p, c->n_p, too_small, c->sel_rec.p, n_attempts);
+  // (one scan of P serves the whole batch: one point per thread in the first trip, kSelectTile per thread and trip after it; at
+  // most one workgroup per CU, each ending in one atomic per attempt)
+  const uint32_t blocks = std::max<uint32_t>(1u, std::min<uint32_t>(256u, (c->n_p + uint32_t(kSelectThreads) - 1u) / uint32_t(kSelectThreads)));
+  hipLaunchKernelGGL(k_select_fourth, dim3(blocks), dim3(kSelectThreads), 0, st, c->p4o.p, c->n_p, too_small, c->sel_rec.p, n_attempts);
   hipLaunchKernelGGL(k_select_finish, dim3(uint32_t(n_attempts)), dim3(64), 0, st, c->p4o.p, c->sel_rec.p);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipMemcpyAsync(c->sel_hrec.p, c->sel_rec.p, sizeof(SelectRecord) * size_t(n_attempts), hipMemcpyDeviceToHost, st));

@@ -2382,18 +2382,23 @@ __global__ __launch_bounds__(1024) void k_select_triangle(const float4* __restri
 
 // One pass over the sampled P for ALL attempts of a batch: a thread holds a tile of points in registers and the best
 // (distance, index) key of every attempt so far, so the 16 bytes of a point are read once per batch instead of once per
-// attempt (at n_P = 4.2 M: 67 MB per scan).  A point further from an attempt's plane than the best admissible point known so
-// far cannot become the minimum and skips the three sphere tests; equal distances still compete on the index (the reference
-// keeps the first, match4pcsBase.cc:324-338).  To make that filter bite, trip 0 takes ONE point per thread through every
-// test, the waves publish their minima (atomicMin on the records, as at the end), and from trip 1 on every thread starts a
-// tile from the best key anyone has published: adopting another thread's key cannot change the minimum over all points.
+// attempt (at n_P = 4.2 M: 67 MB per scan).  A point further from an attempt's plane than the best admissible point the
+// WORKGROUP has seen so far (s_bound, kept with LDS atomics) cannot become the minimum and skips the three sphere tests; equal
+// distances still compete on the index (the reference keeps the first, match4pcsBase.cc:324-338).  Trip 0 takes one point per
+// thread so that the bound exists after 1024 points; the other trips take tiles.  A workgroup reduces its keys in LDS and
+// issues ONE atomicMin per attempt: same-address device atomics are served one after the other (~35 ns each on this part --
+// with one per wave, 8192 of them, they WERE the kernel: ~300 us whatever the batch size, profiles/r04_select_probe*).
 constexpr int kSelectTile = 4;
-__global__ __launch_bounds__(256, 2) void k_select_fourth(const float4* __restrict__ p4, uint32_t n_p, float too_small, SelectRecord* rec_all,
-                                                          int32_t n_attempts) {
+constexpr int kSelectThreads = 1024;
+__global__ __launch_bounds__(kSelectThreads) void k_select_fourth(const float4* __restrict__ p4, uint32_t n_p, float too_small,
+                                                                  SelectRecord* rec_all, int32_t n_attempts) {
   __shared__ float4 s_par[kSelectBatch][3];        // {pa, pb, pc, A.x} {A.y, A.z, B.x, B.y} {B.z, C.x, C.y, C.z}
+  __shared__ uint32_t s_bound[kSelectBatch];       // bits of the smallest admissible distance any thread of the workgroup has seen
+  __shared__ unsigned long long s_red[kSelectBatch][kSelectThreads / 64];
   __shared__ uint32_t s_live;                      // bit a: attempt a has a triangle and a plane and waits for its fourth point
   const uint32_t t = threadIdx.x;
   if (t == 0) s_live = 0u;
+  if (t < uint32_t(kSelectBatch)) s_bound[t] = 0xFFFFFFFFu;
   __syncthreads();
   if (t < uint32_t(n_attempts) && rec_all[t].status == kSelectNoFourth) {
     const SelectRecord* rec = rec_all + t;
@@ -2409,15 +2414,6 @@ __global__ __launch_bounds__(256, 2) void k_select_fourth(const float4* __restri
   unsigned long long key[kSelectBatch];
 #pragma unroll
   for (int a = 0; a < kSelectBatch; ++a) key[a] = ~0ull;
-  auto publish = [&]() {                           // (every lane of the block is here: `live` and the trip count are uniform)
-#pragma unroll
-    for (int a = 0; a < kSelectBatch; ++a) {
-      if (!((live >> a) & 1u)) continue;
-      unsigned long long best = key[a];
-      for (int s = 32; s > 0; s >>= 1) { const unsigned long long k2 = shfl_xor_u64(best, s); best = k2 < best ? k2 : best; }
-      if ((t & 63u) == 0 && best != ~0ull) atomicMin(&rec_all[a].fourth_key, best);
-    }
-  };
   const uint32_t nthreads = gridDim.x * blockDim.x, gid = blockIdx.x * blockDim.x + t;
   const uint32_t rest = n_p > nthreads ? n_p - nthreads : 0u;
   const uint32_t trips = 1u + (rest + uint32_t(kSelectTile) * nthreads - 1u) / (uint32_t(kSelectTile) * nthreads);
@@ -2432,16 +2428,8 @@ __global__ __launch_bounds__(256, 2) void k_select_fourth(const float4* __restri
     for (int k = 0; k < kSelectTile; ++k) p[k] = p4[min(idx[k], n_p - 1u)];      // (the loads of a tile in flight together)
 #pragma unroll
     for (int k = 0; k < kSelectTile; ++k) p[k].x = idx[k] < n_p ? p[k].x : not_a_point;
-    if (trip != 0u) {
-#pragma unroll
-      for (int a = 0; a < kSelectBatch; ++a) {
-        if (!((live >> a) & 1u)) continue;
-        const unsigned long long seen = __hip_atomic_load(&rec_all[a].fourth_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        key[a] = seen < key[a] ? seen : key[a];
-      }
-    }
-    // the 12 parameters of an attempt are re-read from LDS for every tile (3 ds_read_b128 against the vector instructions of
-    // four points): hoisted out of the scan they would be 192 registers and cost the occupancy that hides the loads of the tile
+    // the parameters and the bound of an attempt are re-read from LDS for every tile (3 ds_read_b128 + 1 ds_read_b32 against
+    // the vector instructions of four points): hoisted out of the scan the parameters alone would be 192 registers
     uint32_t zero = 0u;
     asm volatile("" : "+v"(zero));
 #pragma unroll
@@ -2449,23 +2437,39 @@ __global__ __launch_bounds__(256, 2) void k_select_fourth(const float4* __restri
       if (!((live >> a) & 1u)) continue;
       const float4* par = s_par[uint32_t(a) + zero];
       const float4 q0 = par[0], q1 = par[1], q2 = par[2];
+      const uint32_t bound = s_bound[uint32_t(a) + zero];
 #pragma unroll
       for (int k = 0; k < kSelectTile; ++k) {
         const float d = fabsf(((q0.x * p[k].x + q0.y * p[k].y) + q0.z * p[k].z) - 1.0f);
         // one rarely-taken branch per point and attempt: `d < FLT_MAX` drops infinities and NaNs (whose bit patterns would pass
-        // the comparison with the initial key), the bit comparison everything further from the plane than the best so far
-        if (__float_as_uint(d) <= uint32_t(key[a] >> 32) && d < 3.402823466e+38f) {
+        // the comparison with the initial bound), the bit comparison everything further from the plane than the bound
+        if (__float_as_uint(d) <= bound && d < 3.402823466e+38f) {
           const bool far = sqn3(p[k].x - q0.w, p[k].y - q1.x, p[k].z - q1.y) >= too_small &&
                            sqn3(p[k].x - q1.z, p[k].y - q1.w, p[k].z - q2.x) >= too_small &&
                            sqn3(p[k].x - q2.y, p[k].y - q2.z, p[k].z - q2.w) >= too_small;
           const unsigned long long k2 = (static_cast<unsigned long long>(__float_as_uint(d)) << 32) | idx[k];
-          key[a] = (far && k2 < key[a]) ? k2 : key[a];
+          if (far) {
+            key[a] = k2 < key[a] ? k2 : key[a];
+            atomicMin(&s_bound[a], __float_as_uint(d));
+          }
         }
       }
     }
-    if (trip == 0u && trips > 1u) publish();
   }
-  publish();
+  // workgroup minimum per attempt, one device atomic each (every lane of the workgroup is here: `live` and `trips` are uniform)
+#pragma unroll
+  for (int a = 0; a < kSelectBatch; ++a) {
+    if (!((live >> a) & 1u)) continue;
+    unsigned long long best = key[a];
+    for (int s = 32; s > 0; s >>= 1) { const unsigned long long k2 = shfl_xor_u64(best, s); best = k2 < best ? k2 : best; }
+    if ((t & 63u) == 0) s_red[a][t >> 6] = best;
+  }
+  __syncthreads();
+  if (t < uint32_t(kSelectBatch) && ((live >> t) & 1u)) {
+    unsigned long long best = ~0ull;
+    for (uint32_t w = 0; w < blockDim.x / 64u; ++w) best = s_red[t][w] < best ? s_red[t][w] : best;
+    if (best != ~0ull) atomicMin(&rec_all[t].fourth_key, best);
+  }
 }
 
 __global__ void k_select_finish(const float4* __restrict__ p4, SelectRecord* rec_all) {

@@ -1,9 +1,9 @@
 #!/bin/bash
-# round 4, run 13: k_select_fourth with the published bound -- parity tests, cost of a batch call on an idle GPU, the host chain
+# round 4, run 13 / 15: k_select_fourth (13: bound published through the records; 15: workgroup bound in LDS, one atomic per workgroup) -- parity tests, cost of a batch call on an idle GPU, the host chain
 # of a rank of a world of 8 at n_P = 4.2 M; the drop-in with the lean SoA / sampled-cloud passes
 cd "$GRAFT_REPO_ROOT"
 export TMPDIR=/tmp
-O=gpurun_out/r4_run13; mkdir -p $O
+O=gpurun_out/r4_run15; mkdir -p $O
 timeout 240 python -m pytest tests/test_gpu_select.py tests/test_facade.py -m gpu -q -x --timeout 200 > $O/tests.log 2>&1
 echo "pytest rc=$?" >> $O/tests.log
 tail -5 $O/tests.log
