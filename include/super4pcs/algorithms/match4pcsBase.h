@@ -111,7 +111,6 @@ class Match4PCSBase {
   template <typename Sampler>
   void init(const std::vector<Point3D>& P, const std::vector<Point3D>& Q, const Sampler& sampler) {
     S4P_FACADE_LAP_BEGIN();
-    std::vector<Point3D> ps, qu;
     const bool sample_q = Q.size() > options_.sample_size;
     // Q_copy_ = Q (match4pcsBase.hpp:191) is a whole-cloud copy nothing below reads: it runs beside the sampling and the
     // engine's init and is complete before Initialize() -- the first code of a subclass that could look at it -- is called
@@ -124,21 +123,11 @@ class Match4PCSBase {
       ~CopyOfQ() { if (t.joinable()) t.join(); }
     } copy_of_q(Q_copy_, Q);
     S4P_FACADE_LAP("start copy of Q");
-    if (P.size() > options_.sample_size) sampler(P, options_, ps);
-    else { Log<LogLevel::ErrorReport>("(P) More samples requested than available: use whole cloud"); ps = P; }
-    S4P_FACADE_LAP("sampler(P)");
-    if (sample_q) sampler(Q, options_, qu);
-    else { Log<LogLevel::ErrorReport>("(Q) More samples requested than available: use whole cloud"); qu = Q; }
-    S4P_FACADE_LAP("sampler(Q)");
-    Soa sp(ps), sq(qu);
-    const s4p_cloud_view vp = sp.view(), vq = sq.view();
-    S4P_FACADE_LAP("SoA of the samples");
-    check(s4p_matcher_init(engine_, &vp, &vq, sample_q ? 1 : 0));
-    S4P_FACADE_LAP("s4p_matcher_init");
+    init_engine(P, Q, sampler, sample_q, std::is_same<Sampler, DefaultSampler>());
     refresh();
     // sampled clouds as the engine holds them (centred; Q shuffled and truncated)
-    pull_sampled(0, ps, sampled_P_3D_);
-    pull_sampled(1, qu, sampled_Q_3D_);
+    pull_sampled(0, sampled_P_3D_);
+    pull_sampled(1, sampled_Q_3D_);
     Log<LogLevel::Verbose>("norm_max_dist: ", options_.delta);
     // The virtual handler, "called once the internal state of the Base class has been set" (match4pcsBase.h:262-272,
     // match4pcsBase.hpp:197-198): with the caller's P and Q, after sampling / centring / the trial count, and with
@@ -151,6 +140,39 @@ class Match4PCSBase {
     Initialize(P, Q);
     best_LCP_ = initial_lcp;
     Log<LogLevel::Verbose>("Initial LCP: ", best_LCP_);
+  }
+
+  // Sampling (match4pcsBase.hpp:112-127) + the engine's init.  A user-supplied Sampler is host code and runs here on the
+  // std::vector<Point3D>, its output handed to the engine as SoA arrays.  The stock UniformDistSampler is the engine's own
+  // device sampler (sampling.h forwards to it), so for it the whole clouds go down once as SoA views and the sampled
+  // vectors are never built on this side of the ABI: same voxel rule, same kept points, same shuffle, one pass less over
+  // half a million Point3D.
+  template <typename Sampler>
+  void init_engine(const std::vector<Point3D>& P, const std::vector<Point3D>& Q, const Sampler& sampler, bool sample_q, std::false_type) {
+    S4P_FACADE_LAP_BEGIN();
+    std::vector<Point3D> ps, qu;
+    if (P.size() > options_.sample_size) sampler(P, options_, ps);
+    else { Log<LogLevel::ErrorReport>("(P) More samples requested than available: use whole cloud"); ps = P; }
+    S4P_FACADE_LAP("sampler(P)");
+    if (sample_q) sampler(Q, options_, qu);
+    else { Log<LogLevel::ErrorReport>("(Q) More samples requested than available: use whole cloud"); qu = Q; }
+    S4P_FACADE_LAP("sampler(Q)");
+    Soa sp(ps), sq(qu);
+    const s4p_cloud_view vp = sp.view(), vq = sq.view();
+    S4P_FACADE_LAP("SoA of the samples");
+    check(s4p_matcher_init(engine_, &vp, &vq, sample_q ? 1 : 0));
+    S4P_FACADE_LAP("s4p_matcher_init");
+  }
+  template <typename Sampler>
+  void init_engine(const std::vector<Point3D>& P, const std::vector<Point3D>& Q, const Sampler&, bool sample_q, std::true_type) {
+    S4P_FACADE_LAP_BEGIN();
+    if (!(P.size() > options_.sample_size)) Log<LogLevel::ErrorReport>("(P) More samples requested than available: use whole cloud");
+    if (!sample_q) Log<LogLevel::ErrorReport>("(Q) More samples requested than available: use whole cloud");
+    Soa sp(P), sq(Q);
+    const s4p_cloud_view vp = sp.view(), vq = sq.view();
+    S4P_FACADE_LAP("SoA of P and Q");
+    check(s4p_matcher_init_full(engine_, &vp, &vq));
+    S4P_FACADE_LAP("s4p_matcher_init_full");
   }
 
   // ---- match4pcsBase.hpp:208-274 -----------------------------------------------------------------
@@ -401,7 +423,7 @@ class Match4PCSBase {
   }
   // Sampled clouds as the engine holds them: centred positions plus the normals / colours that travelled with each
   // point through sampling, shuffle and truncation (match4pcsBase.hpp:112-138).
-  void pull_sampled(int which, const std::vector<Point3D>&, std::vector<Point3D>& out) {
+  void pull_sampled(int which, std::vector<Point3D>& out) {
     s4p_matcher_info i;
     check(s4p_matcher_get_info(engine_, &i));
     const size_t n = size_t(which == 0 ? i.n_sampled_p : i.n_sampled_q);

@@ -127,6 +127,34 @@ int main(int argc, char** argv) {
       std::printf("routes: staged %.6f (%d visitor calls) fused %.6f (%d)\n", score, vis.calls, score_s, vis_s.calls);
       if (score_s != score || !same_matrix(mat, mat_s) || !same_cloud || vis.calls != vis_s.calls) return 9;
     }
+    // a user-supplied Sampler (any type that is not the stock one) runs on this side of the ABI and its output goes down as
+    // the sampled clouds; the stock sampler is handed to the engine together with the whole clouds.  A sampler that merely
+    // forwards to the stock one must therefore give the same registration through the other route.
+    {
+      struct ForwardingSampler {
+        mutable int calls = 0;
+        void operator()(const std::vector<Point3D>& in, const Match4PCSOptions& o, std::vector<Point3D>& out) const {
+          ++calls;
+          Sampling::UniformDistSampler()(in, o, out);
+        }
+      } fwd;
+      MatchSuper4PCS user(opt, logger), stock(opt, logger);
+      Match4PCSBase::MatrixType mat_u = Match4PCSBase::MatrixType::Identity(), mat_s = Match4PCSBase::MatrixType::Identity();
+      std::vector<Point3D> Qu = Q, Qs = Q;
+      const float score_u = user.ComputeTransformation(P, &Qu, mat_u, fwd);
+      const float score_s = stock.ComputeTransformation(P, &Qs, mat_s);
+      bool same = fwd.calls == 2 && score_u == score_s && same_matrix(mat_u, mat_s) && Qu.size() == Qs.size() &&
+                  user.getFirstSampled().size() == stock.getFirstSampled().size() &&
+                  user.getSecondSampled().size() == stock.getSecondSampled().size();
+      for (size_t i = 0; same && i < Qu.size(); ++i) same = Qu[i].x() == Qs[i].x() && Qu[i].y() == Qs[i].y() && Qu[i].z() == Qs[i].z();
+      for (size_t i = 0; same && i < user.getFirstSampled().size(); ++i)
+        same = user.getFirstSampled()[i].x() == stock.getFirstSampled()[i].x() && user.getFirstSampled()[i].z() == stock.getFirstSampled()[i].z();
+      for (size_t i = 0; same && i < user.getSecondSampled().size(); ++i)
+        same = user.getSecondSampled()[i].y() == stock.getSecondSampled()[i].y();
+      std::printf("samplers: user-supplied %.6f (%d calls) stock %.6f, sampled %zu / %zu\n", score_u, fwd.calls, score_s,
+                  user.getFirstSampled().size(), user.getSecondSampled().size());
+      if (!same) return 17;
+    }
     // a subclass that filters pairs: its hooks must be called by the trial loop and must shape the result's inputs
     {
       FilteringMatcher fm(opt, logger);

@@ -34,3 +34,4 @@ def test_facade_registers_on_gpu(tmp_path, s4p_lib_built):
     assert out.returncode == 0, out.stdout + out.stderr
     assert "score" in out.stdout and "quads" in out.stdout
     assert "routes: staged" in out.stdout and "filtering subclass" in out.stdout     # overridden hooks are honoured (main.cpp)
+    assert "samplers: user-supplied" in out.stdout                                   # both sampling routes, same registration
