@@ -114,14 +114,7 @@ class Match4PCSBase {
     const bool sample_q = Q.size() > options_.sample_size;
     // Q_copy_ = Q (match4pcsBase.hpp:191) is a whole-cloud copy nothing below reads: it runs beside the sampling and the
     // engine's init and is complete before Initialize() -- the first code of a subclass that could look at it -- is called
-    struct CopyOfQ {
-      std::exception_ptr failed;
-      std::thread t;
-      CopyOfQ(std::vector<Point3D>& dst, const std::vector<Point3D>& src)
-          : t([this, &dst, &src] { try { dst = src; } catch (...) { failed = std::current_exception(); } }) {}
-      void wait() { if (t.joinable()) t.join(); if (failed) { std::exception_ptr f = failed; failed = nullptr; std::rethrow_exception(f); } }
-      ~CopyOfQ() { if (t.joinable()) t.join(); }
-    } copy_of_q(Q_copy_, Q);
+    Async copy_of_q([this, &Q] { Q_copy_ = Q; });
     S4P_FACADE_LAP("start copy of Q");
     init_engine(P, Q, sampler, sample_q, std::is_same<Sampler, DefaultSampler>());
     refresh();
@@ -168,8 +161,13 @@ class Match4PCSBase {
     S4P_FACADE_LAP_BEGIN();
     if (!(P.size() > options_.sample_size)) Log<LogLevel::ErrorReport>("(P) More samples requested than available: use whole cloud");
     if (!sample_q) Log<LogLevel::ErrorReport>("(Q) More samples requested than available: use whole cloud");
-    Soa sp(P), sq(Q);
-    const s4p_cloud_view vp = sp.view(), vq = sq.view();
+    std::unique_ptr<Soa> sp, sq;
+    {
+      Async soa_of_p([&sp, &P] { sp.reset(new Soa(P)); });
+      sq.reset(new Soa(Q));
+      soa_of_p.wait();
+    }
+    const s4p_cloud_view vp = sp->view(), vq = sq->view();
     S4P_FACADE_LAP("SoA of P and Q");
     check(s4p_matcher_init_full(engine_, &vp, &vq));
     S4P_FACADE_LAP("s4p_matcher_init_full");
@@ -359,6 +357,16 @@ class Match4PCSBase {
   }
 
  private:
+  // a callable on a thread of its own; wait() joins and rethrows what it threw
+  struct Async {
+    std::exception_ptr failed;
+    std::thread t;
+    template <class F> explicit Async(F f) : t([this, f] { try { f(); } catch (...) { failed = std::current_exception(); } }) {}
+    void wait() { if (t.joinable()) t.join(); if (failed) { std::exception_ptr f = failed; failed = nullptr; std::rethrow_exception(f); } }
+    ~Async() { if (t.joinable()) t.join(); }
+    Async(const Async&) = delete;
+    Async& operator=(const Async&) = delete;
+  };
   // SoA view of a cloud for the C ABI: positions always; normals / colours only when some point carries them (the flags are
   // found in a first pass, so that a plain xyz cloud costs three arrays, not nine); whole-cloud sizes on a few threads
   struct Soa {
@@ -366,19 +374,21 @@ class Match4PCSBase {
     size_t n = 0;
     bool has_n = false, has_c = false;
     explicit Soa(const std::vector<Point3D>& pts) : n(pts.size()) {
+      for (int k = 0; k < 3; ++k) a[k].reset(new float[n ? n : 1]);
       std::atomic<unsigned> flags{0u};
-      detail::for_ranges(n, [&](size_t b, size_t e) {
+      detail::for_ranges(n, [&](size_t b, size_t e) {                          // positions, and whether anything else is there
         unsigned f = 0;
-        for (size_t i = b; i < e && f != 3u; ++i)
+        for (size_t i = b; i < e; ++i) {
+          a[0][i] = pts[i].x(); a[1][i] = pts[i].y(); a[2][i] = pts[i].z();
           f |= (pts[i].normal().squaredNorm() > 0.f ? 1u : 0u) | (pts[i].rgb()(0) >= 0.f ? 2u : 0u);
+        }
         flags.fetch_or(f, std::memory_order_relaxed);
       });
       has_n = (flags.load() & 1u) != 0; has_c = (flags.load() & 2u) != 0;
-      for (int k = 0; k < 3; ++k) a[k].reset(new float[n ? n : 1]);
+      if (!has_n && !has_c) return;
       if (has_n) for (int k = 3; k < 6; ++k) a[k].reset(new float[n ? n : 1]);
       if (has_c) for (int k = 6; k < 9; ++k) a[k].reset(new float[n ? n : 1]);
       detail::for_ranges(n, [&](size_t b, size_t e) {
-        for (size_t i = b; i < e; ++i) { a[0][i] = pts[i].x(); a[1][i] = pts[i].y(); a[2][i] = pts[i].z(); }
         if (has_n) for (size_t i = b; i < e; ++i) for (int k = 0; k < 3; ++k) a[3 + k][i] = pts[i].normal()(k);
         if (has_c) for (size_t i = b; i < e; ++i) for (int k = 0; k < 3; ++k) a[6 + k][i] = pts[i].rgb()(k);
       });

@@ -3,7 +3,7 @@
 # checked against each other
 cd "$GRAFT_REPO_ROOT"
 export TMPDIR=/tmp
-O=gpurun_out/r4_run16; mkdir -p $O
+O=gpurun_out/r4_run17; mkdir -p $O
 timeout 240 python -m pytest tests/test_facade.py tests/test_cli.py -m gpu -q -x --timeout 200 > $O/tests.log 2>&1
 echo "pytest rc=$?" >> $O/tests.log
 tail -5 $O/tests.log
