@@ -1763,7 +1763,10 @@ int32_t s4p_transform_points(s4p_ctx* c, const float* M, float* x, float* y, flo
   if (!c || !M || (n > 0 && (!x || !y || !z))) return S4P_ERR_BAD_ARG;
   if (n <= 0) return S4P_OK;
   HIPCHK(c, hipSetDevice(c->device));
-  constexpr size_t kChunk = size_t(1) << 20;                        // points per chunk: 12 MB per staging buffer
+  // points per chunk: 1.5 MB per staging buffer.  A whole 1 M-point cloud in ONE chunk (the size until round 4) serialised
+  // copy-in, upload, kernel, download and copy-out and paid for 24 MB of pinned memory on a context's first call; with eight
+  // chunks the host copies of one chunk run beside the DMA of its neighbours.
+  constexpr size_t kChunk = size_t(1) << 17;
   const size_t chunk = std::min<size_t>(kChunk, size_t(n));
   if (c->tbuf_cap < 2 * 3 * chunk) { HIPCHK(c, c->tbuf.alloc(2 * 3 * chunk)); c->tbuf_cap = 2 * 3 * chunk; }
   if (c->tpin.n < 2 * 3 * chunk) HIPCHK(c, c->tpin.alloc(2 * 3 * chunk));

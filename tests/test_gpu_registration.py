@@ -71,12 +71,13 @@ def test_transform_points_matches_oracle_order(oracle_mod, s4p_lib_built):
     from super4pcs_amd import capi
     rng = np.random.default_rng(9)
     ctx = capi.Context(capi.make_options(0.01, 0.5, 200))
-    X = rng.normal(size=(100003, 3)).astype(np.float32)
     M = H.random_rigid(rng, 0.3)
-    got = ctx.transform_points(M, X)
-    x, y, z = X[:, 0], X[:, 1], X[:, 2]
-    want = np.stack([((M[r, 0] * x + M[r, 1] * y) + M[r, 2] * z) + M[r, 3] for r in range(3)], axis=1)
-    assert np.array_equal(got, want)
+    for n in (100003, 131072, 300007, 1):                         # one chunk, exactly one, three with a ragged tail, one point
+        X = rng.normal(size=(n, 3)).astype(np.float32)
+        got = ctx.transform_points(M, X)
+        x, y, z = X[:, 0], X[:, 1], X[:, 2]
+        want = np.stack([((M[r, 0] * x + M[r, 1] * y) + M[r, 2] * z) + M[r, 3] for r in range(3)], axis=1)
+        assert np.array_equal(got, want), n
 
 
 def test_options_rejected_loudly(s4p_lib_built):
