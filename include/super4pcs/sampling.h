@@ -19,9 +19,9 @@ namespace detail {
 // not throw.
 template <class F>
 inline void for_ranges(size_t n, F&& fn) {
-  const size_t kMinPerThread = size_t(1) << 17;
+  const size_t kMinPerThread = size_t(1) << 16;
   const unsigned hw = std::thread::hardware_concurrency();
-  const size_t parts = std::min<size_t>(std::min<size_t>(8, hw ? hw : 1), n / kMinPerThread);
+  const size_t parts = std::min<size_t>(std::min<size_t>(16, hw ? hw : 1), n / kMinPerThread);
   if (parts <= 1) { fn(size_t(0), n); return; }
   const size_t step = (n + parts - 1) / parts;
   std::vector<std::thread> helpers;
