@@ -228,7 +228,13 @@ class Match4PCSBase {
       const size_t nq = Q_copy_.size();
       const std::unique_ptr<float[]> x(new float[nq]), y(new float[nq]), z(new float[nq]);
       const std::vector<Point3D>& src = Q_copy_;
-      if (q_positions_ && q_positions_->n == nq) {    // (Q_copy_ has not changed since init built these from the same cloud)
+      // the SoA positions init built from the same cloud, unless a subclass has rewritten Q_copy_ since (spot check)
+      bool reuse = q_positions_ && q_positions_->n == nq;
+      for (size_t k = 0; reuse && k < 32 && nq; ++k) {
+        const size_t i = (nq - 1) * k / 31;
+        reuse = q_positions_->a[0][i] == src[i].x() && q_positions_->a[1][i] == src[i].y() && q_positions_->a[2][i] == src[i].z();
+      }
+      if (reuse) {
         const Soa& q = *q_positions_;
         detail::for_ranges(nq, [&](size_t b, size_t e) {
           std::memcpy(x.get() + b, q.a[0].get() + b, (e - b) * sizeof(float));
