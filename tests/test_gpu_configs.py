@@ -190,8 +190,9 @@ def test_config1_partial_scan_pair_whole_registration(oracle_mod, s4p_lib_built)
     assert np.max(np.abs(g_M[:3, :3] - T_gt[:3, :3])) < 0.05      # and it is the right pose
 
 
-def test_config3_lidar_pair_5m_points(oracle_mod, s4p_lib_built):
+def test_config3_lidar_pair_5m_points(oracle_mod, s4p_lib_built, monkeypatch):
     """configs[3]: 5 M-point LiDAR-style pair (the per-GPU share of the sharded job is the same registration state)."""
+    monkeypatch.setenv("S4PO_SKIP_MEAN_DISTANCE", "1")      # oracle: MeanDistance() feeds nothing (s4p_oracle.cpp, init); n_P queries saved per oracle matcher
     from super4pcs_amd import capi, datasets as D
     n = int(5_000_000 * SCALE)
     delta = 0.05
@@ -211,9 +212,10 @@ def test_config3_lidar_pair_5m_points(oracle_mod, s4p_lib_built):
         assert quads > 50_000 and cand > 0 and _gm.info().n_sampled_q == 20000
 
 
-def test_config4_part_in_whole_10m_scene(oracle_mod, s4p_lib_built):
+def test_config4_part_in_whole_10m_scene(oracle_mod, s4p_lib_built, monkeypatch):
     """configs[4]: 100 k-point query in a 10 M-point scene (P = scene: ~10^6 sampled points in the LCP grid and in the
     base search)."""
+    monkeypatch.setenv("S4PO_SKIP_MEAN_DISTANCE", "1")      # oracle: MeanDistance() feeds nothing (s4p_oracle.cpp, init); n_P queries saved per oracle matcher
     from super4pcs_amd import capi, datasets as D
     delta = 0.05
     P, Q, T_gt = D.part_in_whole_pair(10_000_000, 100_000, delta=delta) if SCALE == 1.0 else D.part_in_whole_scaled(SCALE, delta=delta)
