@@ -199,3 +199,19 @@ def test_streaming_quad_count_equals_the_list_enumeration(oracle_mod):
                 assert not wb["found"]
         seen += len(quads)
     assert seen > 1000
+
+
+def test_sampler_keeps_the_first_point_of_every_voxel_on_a_scene_of_planes(oracle_mod):
+    """sampling.h:59-122 on structured data (planes, boxes, a ground grid -- where the reference's own hash clusters and the
+    oracle keeps its voxels under a mixing hash instead): the kept points are exactly the first point, in input order, of every
+    delta-voxel, computed here with numpy from the same float32 arithmetic (floor(x * (1 / delta)))."""
+    from super4pcs_amd import datasets
+    P, _Q, _T = datasets.lidar_pair(300_000, delta=0.05)
+    X = np.ascontiguousarray(P, np.float32)
+    for delta in (0.05, 0.2):
+        scale = np.float32(1.0) / np.float32(delta)
+        vox = np.floor(X * scale).astype(np.int64)
+        _u, first = np.unique(vox, axis=0, return_index=True)
+        want = X[np.sort(first)]
+        got = oracle_mod.sample(X, delta)
+        assert got.shape == want.shape and np.array_equal(got, want), (delta, got.shape, want.shape)
