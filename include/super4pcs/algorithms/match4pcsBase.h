@@ -18,6 +18,7 @@
 #include <thread>
 #include <type_traits>
 #include <string>
+#include <system_error>
 #include <utility>
 #include <vector>
 
@@ -375,11 +376,14 @@ class Match4PCSBase {
   }
 
  private:
-  // a callable on a thread of its own; wait() joins and rethrows what it threw
+  // a callable on a thread of its own (or inline when none can be started); wait() joins and rethrows what it threw
   struct Async {
     std::exception_ptr failed;
     std::thread t;
-    template <class F> explicit Async(F f) : t([this, f] { try { f(); } catch (...) { failed = std::current_exception(); } }) {}
+    template <class F> explicit Async(F f) {
+      auto body = [this, f] { try { f(); } catch (...) { failed = std::current_exception(); } };
+      try { t = std::thread(body); } catch (const std::system_error&) { body(); }       // no thread to be had: run it here
+    }
     void wait() { if (t.joinable()) t.join(); if (failed) { std::exception_ptr f = failed; failed = nullptr; std::rethrow_exception(f); } }
     ~Async() { if (t.joinable()) t.join(); }
     Async(const Async&) = delete;

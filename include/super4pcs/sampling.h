@@ -26,8 +26,15 @@ inline void for_ranges(size_t n, F&& fn) {
   const size_t step = (n + parts - 1) / parts;
   std::vector<std::thread> helpers;
   helpers.reserve(parts - 1);
-  for (size_t p = 1; p < parts; ++p) helpers.emplace_back([&fn, p, step, n] { fn(std::min(n, p * step), std::min(n, (p + 1) * step)); });
+  size_t started = 1;                              // ranges [0, started) are taken care of: range 0 by this thread
+  try {
+    for (; started < parts; ++started) {
+      const size_t p = started;
+      helpers.emplace_back([&fn, p, step, n] { fn(std::min(n, p * step), std::min(n, (p + 1) * step)); });
+    }
+  } catch (...) {}                                 // no more threads to be had: the remaining ranges run here
   fn(size_t(0), std::min(n, step));
+  for (size_t p = started; p < parts; ++p) fn(std::min(n, p * step), std::min(n, (p + 1) * step));
   for (auto& t : helpers) t.join();
 }
 
