@@ -208,6 +208,8 @@ struct s4p_ctx {
   bool pairs_v2 = true;              // S4P_PAIRS_V2=0: the round-3 k_pairs (one wave per primitive) instead of the transposed k_pairs2 (A/B aid)
   int cu_split = 0;                  // S4P_CU_SPLIT (0 = off): one CU in n for the small kernels, the rest for k_verify
   double host_octree_s = 0, host_wait_s = 0;
+  // S4P_TRACE_LAUNCH=1 (lab aid): where the launch thread's time goes inside launch_base, printed by s4p_destroy
+  bool trace_launch = false; double lt[8] = {0, 0, 0, 0, 0, 0, 0, 0}; uint64_t lt_n = 0;
   double set_clouds_s[4] = {0, 0, 0, 0};      // last s4p_set_clouds: host copies + unit frame + grid plan | device build of the LCP structure | Q-side uploads | total
 
   size_t verify_lds_bytes() const {
@@ -791,18 +793,26 @@ int32_t finish_result(s4p_ctx* c, s4p_base_result* r, bool fused) {
 // + counters cleared for the lane's next base), then the read-back of the result record.
 int32_t launch_base(s4p_ctx* c, int32_t slot, const int32_t* base_ids, float inv1, float inv2) {
   s4p_ctx::Lane& L = c->lane[c->cur];
+  using lclk = std::chrono::steady_clock;
+  lclk::time_point tp[8];
+  auto lap = [&](int k) { if (c->trace_launch) tp[k] = lclk::now(); };
+  lap(0);
   if (L.dirty) { if (int32_t rc = reset_counters(c)) return rc; }
   const float eps = 2.0f * c->opt.delta;
   const BaseFrame bf = make_base_frame(c, base_ids);
   PrepParams P1; QuadParams Q;
   if (int32_t rc = quad_params(c, inv1, inv2, eps, P1, Q)) return rc;
   if (c->prof_stages) HIPCHK(c, hipEventRecord(c->ev[c->cur][2], L.stream));
+  lap(1);
   { PairParams2 PP{};
     if (int32_t rc = upload_pairs_staged(c, slot, 0, eps, 0, 1, PP.set[0].pair)) return rc;
     if (int32_t rc = upload_pairs_staged(c, slot, 1, eps, 2, 3, PP.set[1].pair)) return rc;
+    lap(2);
     if (int32_t rc = launch_pairs_kernel(c, PP, 2)) return rc; }
   if (c->prof_stages) HIPCHK(c, hipEventRecord(c->ev[c->cur][3], L.stream));
+  lap(3);
   launch_prep_kernel(c, P1);
+  lap(4);
   if (c->fuse_gate) { Q.do_gate = 1; Q.gate = gate_params(c, bf); }
   Q.slice_num = c->slice_num; Q.slice_den = c->slice_den;
   c->slot_q[c->cur] = Q;                                  // (the chunk loop relaunches it range by range if the quads do not fit)
@@ -810,8 +820,13 @@ int32_t launch_base(s4p_ctx* c, int32_t slot, const int32_t* base_ids, float inv
   if (!c->fuse_gate) launch_gate_kernel(c, gate_params(c, bf));
   HIPCHK(c, hipGetLastError());
   if (c->prof_stages) HIPCHK(c, hipEventRecord(c->ev[c->cur][4], L.stream));
+  lap(5);
   if (int32_t rc = launch_verify(c, bf)) return rc;
-  return enqueue_result(c, bf);
+  lap(6);
+  const int32_t rc = enqueue_result(c, bf);
+  lap(7);
+  if (c->trace_launch) { for (int k = 0; k < 7; ++k) c->lt[k] += std::chrono::duration<double>(tp[k + 1] - tp[k]).count(); c->lt_n++; }
+  return rc;
 }
 
 int32_t fetch_result(s4p_ctx* c, const BaseFrame& bf, s4p_base_result* r) {
@@ -883,6 +898,7 @@ int32_t s4p_create(const s4p_options* opt, const s4p_limits* lim, int32_t device
   }
   if (const char* vb = getenv("S4P_VERIFY_BLOCKS")) { const int v = atoi(vb); if (v >= 64 && v <= kVerifyMaxBlocks) { c->verify_blocks = uint32_t(v); c->verify_blocks_fixed = true; c->verify_blocks_env = true; } }   // tuning knob
   if (const char* fu = getenv("S4P_FUSE_GATE")) c->fuse_gate = atoi(fu) != 0;
+  c->trace_launch = getenv("S4P_TRACE_LAUNCH") != nullptr;
   if (const char* pv = getenv("S4P_PAIRS_V2")) c->pairs_v2 = atoi(pv) != 0;
   if (const char* cs = getenv("S4P_CU_SPLIT")) { const int v = atoi(cs); if (v >= 2 && v <= 64) c->cu_split = v; }
   if (const char* at = getenv("S4P_ANGLE_TOL")) { const float v = float(atof(at)); if (v > 1e-6f) c->angle_tol = v; }
@@ -1050,6 +1066,11 @@ void s4p_destroy(s4p_ctx* c) {
               double(v[2]) / v[8], double(v[3]) / v[8], double(v[4]) / v[8], double(v[5]) / v[8], double(v[6]) / v[8], double(v[7]) / v[8]);
   }
 #endif
+  if (c->trace_launch && c->lt_n)
+    fprintf(stderr, "{\"s4p_trace\": \"launch\", \"bases\": %llu, \"us_per_base\": {\"params\": %.2f, \"uploads\": %.2f, \"k_pairs\": %.2f, \"k_prep\": %.2f, \"k_quads\": %.2f, "
+                    "\"k_verify\": %.2f, \"result\": %.2f, \"wait\": %.2f, \"octree\": %.2f}}\n", (unsigned long long)c->lt_n, c->lt[0] / c->lt_n * 1e6, c->lt[1] / c->lt_n * 1e6,
+            c->lt[2] / c->lt_n * 1e6, c->lt[3] / c->lt_n * 1e6, c->lt[4] / c->lt_n * 1e6, c->lt[5] / c->lt_n * 1e6, c->lt[6] / c->lt_n * 1e6,
+            c->host_wait_s / c->lt_n * 1e6, c->host_octree_s / c->lt_n * 1e6);
   c->cyc.free();
   c->greach.free(); c->glist_hdr.free(); c->gnbr.free();
   c->gcoarse.free(); c->q4.free(); c->q4v.free(); c->qquant.free(); c->qsoa.free();
