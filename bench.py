@@ -518,9 +518,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    # the library's lanes are HIP streams; the runtime reads this when it initialises (the library sets it itself when it is
-    # loaded first -- here torch initialises HIP before it): s4p_capi.hip, DESIGN.md 5.4
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    # the library's lanes are HIP streams; the runtime reads this when it initialises (the library itself never
+    # touches the environment; opt out with S4P_KEEP_HW_QUEUES=1): s4p_capi.hip, DESIGN.md 5.4
+    if os.environ.get("S4P_KEEP_HW_QUEUES") != "1":
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback of the product path)")

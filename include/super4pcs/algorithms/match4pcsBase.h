@@ -145,7 +145,6 @@ class Match4PCSBase {
   template <typename Sampler>
   void init_engine(const std::vector<Point3D>& P, const std::vector<Point3D>& Q, const Sampler& sampler, bool sample_q, std::false_type) {
     S4P_FACADE_LAP_BEGIN();
-    q_positions_.reset();
     std::vector<Point3D> ps, qu;
     if (P.size() > options_.sample_size) sampler(P, options_, ps);
     else { Log<LogLevel::ErrorReport>("(P) More samples requested than available: use whole cloud"); ps = P; }
@@ -174,7 +173,6 @@ class Match4PCSBase {
     S4P_FACADE_LAP("SoA of P and Q");
     check(s4p_matcher_init_full(engine_, &vp, &vq));
     S4P_FACADE_LAP("s4p_matcher_init_full");
-    q_positions_ = std::move(sq);                   // the positions of Q_copy_, for the final apply (12 bytes per point)
   }
 
   // ---- match4pcsBase.hpp:208-274 -----------------------------------------------------------------
@@ -229,24 +227,12 @@ class Match4PCSBase {
       const size_t nq = Q_copy_.size();
       const std::unique_ptr<float[]> x(new float[nq]), y(new float[nq]), z(new float[nq]);
       const std::vector<Point3D>& src = Q_copy_;
-      // the SoA positions init built from the same cloud, unless a subclass has rewritten Q_copy_ since (spot check)
-      bool reuse = q_positions_ && q_positions_->n == nq;
-      for (size_t k = 0; reuse && k < 32 && nq; ++k) {
-        const size_t i = (nq - 1) * k / 31;
-        reuse = q_positions_->a[0][i] == src[i].x() && q_positions_->a[1][i] == src[i].y() && q_positions_->a[2][i] == src[i].z();
-      }
-      if (reuse) {
-        const Soa& q = *q_positions_;
-        detail::for_ranges(nq, [&](size_t b, size_t e) {
-          std::memcpy(x.get() + b, q.a[0].get() + b, (e - b) * sizeof(float));
-          std::memcpy(y.get() + b, q.a[1].get() + b, (e - b) * sizeof(float));
-          std::memcpy(z.get() + b, q.a[2].get() + b, (e - b) * sizeof(float));
-        });
-      } else {
-        detail::for_ranges(nq, [&](size_t b, size_t e) {
-          for (size_t i = b; i < e; ++i) { x[i] = src[i].x(); y[i] = src[i].y(); z[i] = src[i].z(); }
-        });
-      }
+      // Always out of Q_copy_ itself, as the reference does (`*Q = Q_copy_`, :264): protected state a subclass may have
+      // rewritten in Initialize() or from a visitor; a threaded AoS -> SoA pass (the SoA copy kept from init was
+      // validated on 32 points only and held 12 bytes per point for the life of the matcher -- removed)
+      detail::for_ranges(nq, [&](size_t b, size_t e) {
+        for (size_t i = b; i < e; ++i) { x[i] = src[i].x(); y[i] = src[i].y(); z[i] = src[i].z(); }
+      });
       S4P_FACADE_LAP("positions out of Q_copy_");
       check(s4p_transform_points(s4p_matcher_ctx(engine_), M, x.get(), y.get(), z.get(), int64_t(nq)));
       S4P_FACADE_LAP("s4p_transform_points");
@@ -421,7 +407,6 @@ class Match4PCSBase {
                             has_c ? a[6].get() : nullptr, has_c ? a[7].get() : nullptr, has_c ? a[8].get() : nullptr, int64_t(n)};
     }
   };
-  std::unique_ptr<Soa> q_positions_;
   template <typename Visitor>
   struct VisitorThunk {
     const Visitor* v;

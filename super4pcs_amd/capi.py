@@ -26,9 +26,11 @@ EXPORTED_SYMBOLS = [
 ]
 
 
-# (the library asks for 8 hardware queues when it is loaded; a Python process usually initialises HIP earlier -- through torch --
-# so the same request is made here, at import; see s4p_capi.hip)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# The lanes are HIP streams and the runtime maps them onto GPU_MAX_HW_QUEUES hardware queues (default 4; 8 measured +2 %): the
+# request has to be in the environment before HIP initialises, so it is made here, at import (the library itself never
+# touches the process environment; see s4p_capi.hip)
+if os.environ.get("S4P_KEEP_HW_QUEUES") != "1":        # opt-out: leave the runtime's default number of hardware queues alone
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 
 class S4PError(RuntimeError):

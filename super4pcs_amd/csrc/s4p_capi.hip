@@ -61,11 +61,12 @@ float angle_threshold(double theta, bool* monotone) {
 }
 }  // namespace
 
-// Six lanes = six HIP streams with kernels in flight; the runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues
-// (default 4) and kernels of streams that share a queue serialise.  Measured on the bench workload (round 4, run 10):
-// 2 queues 120.7, default (4) 176.6, 8 queues 180.3 M candidates/s.  The variable is read when the HIP runtime initialises, so
-// it is set when this library is loaded -- unless the user has set it.
-__attribute__((constructor)) static void s4p_more_hardware_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+// The lanes are HIP streams; the runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and kernels of
+// streams that share a queue serialise (measured on the bench workload, round 4: 2 queues 120.7, 4 queues 176.6, 8 queues
+// 180.3 M candidates/s).  The variable is read when the HIP runtime initialises, so it is the APPLICATION's to set: the
+// library does not touch the process environment (a load-time setenv was a process-wide side effect on every other HIP user
+// and is not thread-safe against a concurrent getenv -- ADVICE r04).  The Python entry points (super4pcs_amd/capi.py, bench.py)
+// set it before HIP initialises unless S4P_KEEP_HW_QUEUES=1; INTEGRATION.md tells a C++ application to export it.
 
 struct s4p_ctx {
   int device = 0;
@@ -1679,6 +1680,10 @@ int32_t s4p_last_candidates(s4p_ctx* c, int32_t* quads, int32_t* counts, int64_t
   if (c->last_chunked) {
     HIPCHK(c, hipSetDevice(c->device));
     if (int32_t rc = replay_for_records(c)) return rc;
+  }
+  // (the replay may have fitted ONE pass -- the lane has grown towards quad_grow_cap since the base was chunked -- and then left
+  // its records on the device like any single-pass base: last_chunked says which of the two read-backs applies NOW)
+  if (c->last_chunked) {
     const int64_t K = int64_t(c->kept.qcounts.size());
     *n_out = K;
     if (K == 0) return S4P_OK;
@@ -1712,8 +1717,8 @@ int32_t s4p_last_candidates(s4p_ctx* c, int32_t* quads, int32_t* counts, int64_t
 int32_t s4p_last_verified(s4p_ctx* c, uint32_t* counts, float* transforms16, int64_t cap, int64_t* n_out) {
   if (!c || !n_out) return S4P_ERR_BAD_ARG;
   HIPCHK(c, hipSetDevice(c->device));
-  if (c->last_chunked) {
-    if (int32_t rc = replay_for_records(c)) return rc;
+  if (c->last_chunked) if (int32_t rc = replay_for_records(c)) return rc;
+  if (c->last_chunked) {                                   // (else: the replay fitted one pass, see s4p_last_candidates)
     const int64_t C = int64_t(c->kept.counts.size());
     *n_out = C;
     if (C == 0) return S4P_OK;

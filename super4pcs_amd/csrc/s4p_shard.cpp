@@ -24,6 +24,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <functional>
@@ -227,7 +228,9 @@ struct Loop {
   uint64_t trials_prepared = 0, trial_limit = ~0ull;     // trials of the common sequence handed out so far / never run from here on
   int slot_rr = 0;
   std::string err;
+  bool coll_failed = false;               // the collective itself failed (not "some rank posted the error key"): nothing further is posted
   int32_t fail(int32_t rc, const std::string& m) { err = m; return rc; }
+  int32_t cfail(int32_t rc) { coll_failed = true; return fail(rc, coll->err); }
 
   int32_t prepare_window(Window& w) {
     w.bases.resize(size_t(world));
@@ -253,28 +256,46 @@ struct Loop {
       const uint64_t key = window_key(w.r.best_count, w.r.has_best != 0, usable, uint32_t(rank), threshold_count);
       w.slot = slot_rr;
       slot_rr ^= 1;
-      if (int32_t rc = coll->post(w.slot, key)) return fail(rc, coll->err);
+      if (int32_t rc = coll->post(w.slot, key)) return cfail(rc);
     }
     return S4P_OK;
   }
+  bool commit_failed = false;             // complete_window failed in THIS rank's commit: a local failure (the collectives of the window are done)
   int32_t complete_window(Window& w) {
     trials_done += uint64_t(world);
     if (w.slot < 0) return S4P_OK;
     uint64_t key = 0;
-    if (int32_t rc = coll->result(w.slot, &key)) return fail(rc, coll->err);      // always consumed: the slot is reused
+    if (int32_t rc = coll->result(w.slot, &key)) return cfail(rc);      // always consumed: the slot is reused
     if (key == kErrorKey) return fail(S4P_ERR_STATE, "a rank of the sharded job failed in this window (see that rank's error)");
     if (terminated) return S4P_OK;                           // a window posted before the threshold was crossed: not committed
     const Decoded d = decode_key(key);
     if (d.any && d.count > best_count) {                     // the window improved the best LCP: fetch the winner's record
       if (d.trial >= uint32_t(world)) return fail(S4P_ERR_STATE, "corrupt window key");
       s4p_base_result wr = w.r;                              // (the owner's own record; everybody else receives it)
-      if (int32_t rc = coll->broadcast(&wr, sizeof wr, int(d.trial))) return fail(rc, coll->err);
-      bool ok = false;
-      if (int32_t rc = ops.commit(w.bases[d.trial].ids, &wr, &ok)) return rc;
+      if (int32_t rc = coll->broadcast(&wr, sizeof wr, int(d.trial))) return cfail(rc);
+      // the crossing is read off the KEY, before the commit: a rank whose commit fails must still agree with the others on
+      // whether the job has stopped posting
+      terminated = terminated || d.crossed;
       best_count = wr.best_count;
-      terminated = terminated || ok || d.crossed;
+      bool ok = false;
+      if (int32_t rc = ops.commit(w.bases[d.trial].ids, &wr, &ok)) { commit_failed = true; return rc; }
+      terminated = terminated || ok;
     }
     return S4P_OK;
+  }
+  // Closes every call of run() on every rank: one more 8-byte all-reduce(MAX) of "did this rank fail locally".  A failure the
+  // window protocol could not carry any more -- the commit of the LAST window of a call, a failure at depth 1 -- reaches the
+  // others here instead of leaving them to pair their next call's collectives with a rank that has left.  The
+  // ranks are aligned when they get here: a local failure has posted the error keys it owed (leave), a rank that READ an
+  // error key has posted exactly what the failing rank answered.  Not after a failure of the collective itself.
+  int32_t close_call(int32_t rc, bool local_failure, bool collective_broken) {
+    if (!coll || collective_broken) return rc;
+    const std::string keep = err;
+    uint64_t g = 0;
+    if (coll->post(2, local_failure ? kErrorKey : 0ull) != S4P_OK || coll->result(2, &g) != S4P_OK) { if (rc == S4P_OK) return fail(S4P_ERR_STATE, coll->err); err = keep; return rc; }
+    if (rc == S4P_OK && g == kErrorKey) return fail(S4P_ERR_STATE, "a rank of the sharded job failed at the end of this call (see that rank's error)");
+    err = keep;
+    return rc;
   }
   // n windows (n * world trials) through a three-stage software pipeline: window w+d is PREPARED (own device pass
   // enqueued, the other ranks' bases advanced on the host) while the passes of windows w+1..w+d-1 are in flight;
@@ -284,12 +305,17 @@ struct Loop {
     Window posted; bool have_posted = false;
     int posted_n = 0;                                        // windows of this call whose key this rank has posted
     bool remote_error = false;
+    commit_failed = false; coll_failed = false;
     auto advance = [&]() -> int32_t {
       Window nxt = std::move(prepared.front());
       prepared.pop_front();
       if (int32_t rc = post_window(nxt)) return rc;
       if (nxt.slot >= 0) ++posted_n;
-      if (have_posted) if (int32_t rc = complete_window(posted)) { remote_error = true; return rc; }
+      if (have_posted) if (int32_t rc = complete_window(posted)) {
+        if (commit_failed) { posted = std::move(nxt); have_posted = true; }      // local: the window just posted is still owed its completion (leave)
+        else remote_error = true;
+        return rc;
+      }
       posted = std::move(nxt);
       have_posted = true;
       return S4P_OK;
@@ -299,22 +325,30 @@ struct Loop {
     // so this rank owes them exactly that sequence: the error key as its reduction of W, the completion of the window it has
     // already posted (the broadcast is a collective too: leaving it out pairs the others' broadcast with this rank's next
     // all-reduce -- ADVICE r03), then the error key once more for W+1.  If W-1 turns out to have crossed the terminate
-    // threshold nobody posts W+1; the others still read the error out of W's reduction.
+    // threshold nobody posts W+1; the others still read the error out of W's reduction.  A failed COMMIT (of window W-1, with W
+    // already posted) is the same situation one window later: `posted` is then W, the error keys go out for W+1 and W+2.
     auto leave = [&](int32_t rc) -> int32_t {
-      if (rc == S4P_OK || remote_error || terminated || !coll) return rc;
+      if (coll_failed) return rc;                            // the collective is gone: nothing can be told to anybody
+      if (rc == S4P_OK || remote_error || !coll) return close_call(rc, false, false);      // (remote: this rank read the error key)
+      if (terminated) return close_call(rc, true, false);
       const std::string keep = err;
+      bool broken = false;
       for (int k = 0; k < 2 && posted_n < n; ++k, ++posted_n) {
         const int slot = slot_rr; slot_rr ^= 1;
         uint64_t dummy = 0;
-        if (coll->post(slot, kErrorKey) != S4P_OK) break;
+        if (coll->post(slot, kErrorKey) != S4P_OK) { broken = true; break; }
         if (k == 0 && have_posted) {
           have_posted = false;
-          if (complete_window(posted) != S4P_OK) { (void)coll->result(slot, &dummy); break; }      // (another rank failed too, or the collective did)
+          if (complete_window(posted) != S4P_OK && !commit_failed) { (void)coll->result(slot, &dummy); broken = true; break; }      // (another rank failed too, or the collective did)
         }
-        if (coll->result(slot, &dummy) != S4P_OK || terminated) break;
+        if (coll->result(slot, &dummy) != S4P_OK) { broken = true; break; }
+        if (terminated) break;
       }
+      // the window this rank had already posted when nothing further is posted in this call (the last window): the others
+      // complete it -- result and, if it improved the best, a broadcast -- and so does this rank
+      if (!broken && have_posted) { have_posted = false; const bool cf = commit_failed; if (complete_window(posted) != S4P_OK && !commit_failed) broken = true; commit_failed = cf || commit_failed; }
       err = keep;
-      return rc;
+      return close_call(rc, true, broken || coll_failed);
     };
     for (int w = 0; w < n; ++w) {
       if (terminated) break;                                 // threshold crossed: no further bases are selected or launched
@@ -323,8 +357,11 @@ struct Loop {
       if (int(prepared.size()) >= ops.depth) if (int32_t rc = advance()) return leave(rc);
     }
     while (!prepared.empty()) if (int32_t rc = advance()) return leave(rc);
-    if (have_posted) if (int32_t rc = complete_window(posted)) { remote_error = true; return rc; }
-    return S4P_OK;
+    if (have_posted) {
+      have_posted = false;
+      if (int32_t rc = complete_window(posted)) { if (!commit_failed) remote_error = true; return leave(rc); }
+    }
+    return close_call(S4P_OK, false, false);
   }
 };
 
@@ -355,40 +392,61 @@ struct SplitLoop {
   std::string err;
   int32_t fail(int32_t rc, const std::string& m) { err = m; return rc; }
 
+  uint32_t threshold_count = 0xFFFFFFFFu; // largest inlier count that does not cross the terminate threshold (threshold_count_for)
+  bool remote_error = false, coll_failed = false;
+  int32_t cfail(int32_t rc) { coll_failed = true; return fail(rc, coll->err); }
+
   int32_t reduce_and_commit(const BaseId& b, const s4p_base_result& r) {
     const bool usable = b.found && r.n_pairs1 && r.n_pairs2 && r.n_quads && r.has_best;
     const uint32_t thi = uint32_t(r.best_rank >> 32), tlo = uint32_t(r.best_rank);
     uint64_t a = usable ? ((uint64_t(r.best_count) + 1ull) << 32) | uint64_t(0xFFFFFFFFu - thi) : 0ull, ga = 0;
     if (b.found && !usable && r.n_pairs1 == ~0ull) a = kErrorKey;             // (a rank whose pass failed: see run())
     if (local_fail) a = kErrorKey;
-    if (int32_t rc = coll->post(0, a)) return fail(rc, coll->err);
-    if (int32_t rc = coll->result(0, &ga)) return fail(rc, coll->err);
-    if (ga == kErrorKey) return fail(S4P_ERR_STATE, "a rank of the sharded job failed on this base (see that rank's error)");
+    if (int32_t rc = coll->post(0, a)) return cfail(rc);
+    if (int32_t rc = coll->result(0, &ga)) return cfail(rc);
+    if (ga == kErrorKey) { remote_error = a != kErrorKey; return fail(S4P_ERR_STATE, "a rank of the sharded job failed on this base (see that rank's error)"); }
     const uint64_t kb = (ga != 0 && a == ga) ? (uint64_t(0xFFFFFFFFu - tlo) << 16) | uint64_t(rank + 1) : 0ull;
     uint64_t gb = 0;
-    if (int32_t rc = coll->post(1, kb)) return fail(rc, coll->err);
-    if (int32_t rc = coll->result(1, &gb)) return fail(rc, coll->err);
+    if (int32_t rc = coll->post(1, kb)) return cfail(rc);
+    if (int32_t rc = coll->result(1, &gb)) return cfail(rc);
     if (ga == 0 || gb == 0) return S4P_OK;                                     // no share of this base verified a candidate
     const uint32_t win_count = uint32_t(ga >> 32) - 1u;
     const int root = int(gb & 0xFFFFull) - 1;
     if (root < 0 || root >= world) return fail(S4P_ERR_STATE, "corrupt split-base key");
     if (win_count > best_count) {                                              // only an improvement travels (and is committed)
       s4p_base_result wr = r;
-      if (int32_t rc = coll->broadcast(&wr, sizeof wr, root)) return fail(rc, coll->err);
+      if (int32_t rc = coll->broadcast(&wr, sizeof wr, root)) return cfail(rc);
       wr.n_quads = std::max<uint64_t>(wr.n_quads, 1);                          // (some share had quads: TryOneBase went on to TryCongruentSet)
+      // the crossing is read off the reduced count, before the commit: a rank whose commit fails must still agree with the
+      // others on whether the job has stopped reducing
+      terminated = terminated || win_count > threshold_count;
+      best_count = wr.best_count;
       bool ok = false;
       if (int32_t rc = ops.commit(b.ids, &wr, &ok)) { commit_failed = true; return rc; }
-      best_count = wr.best_count;
       terminated = terminated || ok;
     }
     return S4P_OK;
   }
+  // Closes every call of run() on every rank (as Loop::close_call): one 8-byte all-reduce(MAX) of "did this rank fail
+  // locally", so that a failure the per-trial reductions could not carry any more -- the commit of the LAST trial of a call --
+  // still reaches every rank inside this call.
+  int32_t close_call(int32_t rc, bool local_failure) {
+    if (!coll || coll_failed) return rc;
+    const std::string keep = err;
+    uint64_t g = 0;
+    if (coll->post(2, local_failure ? kErrorKey : 0ull) != S4P_OK || coll->result(2, &g) != S4P_OK) { if (rc == S4P_OK) return fail(S4P_ERR_STATE, coll->err); err = keep; return rc; }
+    if (rc == S4P_OK && g == kErrorKey) return fail(S4P_ERR_STATE, "a rank of the sharded job failed at the end of this call (see that rank's error)");
+    err = keep;
+    return rc;
+  }
   // n trials, `depth` of them in flight on the device; the reduction of trial t runs while t+1 .. t+depth-1 compute.
   // Every local failure -- a trial that cannot be enqueued (HIP error, device selection error: NOT symmetric over the ranks),
   // a pass that fails, a commit that fails -- reaches the other ranks as the error key in the reduction they are waiting in
-  // (ADVICE r03), and no device pass is left un-waited when the loop is left.
+  //  or, when this call has no reduction left, in the status reduction that closes the call; no device
+  // pass is left un-waited when the loop is left.
   int32_t run(int n) {
     std::deque<BaseId> inflight;
+    remote_error = false; coll_failed = false; commit_failed = false; local_fail = 0;
     auto drain_one = [&]() -> int32_t {
       BaseId b = inflight.front(); inflight.pop_front();
       s4p_base_result r; std::memset(&r, 0, sizeof r);
@@ -404,9 +462,10 @@ struct SplitLoop {
       return rc2;
     };
     // leaving with an error: the shares still in flight are waited for (their results are dropped); after a failed commit
-    // the next reduction of this call, if there is one, carries the error key
+    // the next reduction of this call, if there is one, carries the error key; the status reduction closes the call
     auto leave = [&](int32_t rc) -> int32_t {
       const std::string keep = err;
+      const bool local = !remote_error;
       if (commit_failed && !inflight.empty() && !terminated) { local_fail = rc; (void)drain_one(); }
       while (!inflight.empty()) {
         const BaseId b = inflight.front(); inflight.pop_front();
@@ -415,7 +474,7 @@ struct SplitLoop {
       }
       local_fail = 0; commit_failed = false;
       err = keep;
-      return rc;
+      return close_call(rc, local);
     };
     for (int t = 0; t < n && !terminated; ++t) {
       BaseId b;
@@ -426,7 +485,7 @@ struct SplitLoop {
       if (int(inflight.size()) >= ops.depth) if (int32_t rc = drain_one()) return leave(rc);
     }
     while (!inflight.empty()) if (int32_t rc = drain_one()) return leave(rc);
-    return S4P_OK;
+    return close_call(S4P_OK, false);
   }
 };
 
@@ -512,6 +571,7 @@ static int32_t shard_run_split(s4p_shard* s, int32_t n_trials, uint64_t* candida
   if (s->init_generation != s4p_matcher_init_generation(m)) { s->init_generation = s4p_matcher_init_generation(m); L.terminated = false; L.trials_done = 0; }
   L.rank = s->loop.rank; L.world = s->loop.world; L.coll = s->coll;
   L.best_count = info.best_count;
+  L.threshold_count = threshold_count_for(uint32_t(info.n_sampled_q), s4p_matcher_terminate_threshold(m));
   L.ops.depth = std::max(1, s4p_pipeline_depth(s4p_matcher_ctx(m)));
   L.ops.prepare = [m, s](bool* found, int32_t ids[4]) -> int32_t {
     int32_t f = 0;
@@ -648,6 +708,15 @@ int32_t s4p_shard_compute_transformation(s4p_shard* s, const s4p_cloud_view* P, 
   return S4P_OK;
 }
 
+// Test aid of the two replay harnesses below: S4P_TEST_FAIL_COMMIT="<rank>:<k>" makes the k-th commit (0-based) of that rank fail,
+// the one local failure the recorded outcomes cannot express (tests/test_shard_native_gloo.py).
+static bool replay_commit_fails(int rank, int n_commits_so_far) {
+  const char* e = std::getenv("S4P_TEST_FAIL_COMMIT");
+  if (!e) return false;
+  int r = -1, k = -1;
+  return std::sscanf(e, "%d:%d", &r, &k) == 2 && r == rank && k == n_commits_so_far;
+}
+
 // Host-only self-check of the window loop (no matcher, no GPU): this rank replays recorded outcomes of ITS trials
 // (found[w], results[w] for window w) through the same Loop and the given collective, and logs every commit.
 // The CPU tests run it over gloo with 2 and 4 ranks against the sequential semantics.
@@ -679,6 +748,7 @@ int32_t s4p_shard_replay(int32_t rank, int32_t world, const s4p_collective* coll
     return S4P_OK;
   };
   L.ops.commit = [&](const int32_t ids[4], const s4p_base_result* r, bool* ok) -> int32_t {
+    if (replay_commit_fails(rank, *n_commits)) { L.err = "injected failure of this rank's commit"; return S4P_ERR_CAPACITY; }
     if (*n_commits < commit_cap) { if (commit_trials) commit_trials[*n_commits] = ids[0]; if (commit_counts) commit_counts[*n_commits] = r->best_count; }
     ++*n_commits;
     *ok = r->best_count > threshold_count;
@@ -700,7 +770,7 @@ int32_t s4p_shard_replay_split(int32_t rank, int32_t world, const s4p_collective
     return S4P_ERR_BAD_ARG;
   CallbackCollective cc(*coll);
   SplitLoop L;
-  L.rank = rank; L.world = world; L.coll = &cc; L.best_count = start_best_count;
+  L.rank = rank; L.world = world; L.coll = &cc; L.best_count = start_best_count; L.threshold_count = threshold_count;
   L.ops.depth = std::max(1, depth);
   int prepared = 0;
   std::deque<int> own;
@@ -720,6 +790,7 @@ int32_t s4p_shard_replay_split(int32_t rank, int32_t world, const s4p_collective
     return S4P_OK;
   };
   L.ops.commit = [&](const int32_t ids[4], const s4p_base_result* r, bool* ok) -> int32_t {
+    if (replay_commit_fails(rank, *n_commits)) { L.err = "injected failure of this rank's commit"; return S4P_ERR_CAPACITY; }
     if (*n_commits < commit_cap) {
       if (commit_trials) commit_trials[*n_commits] = ids[0];
       if (commit_counts) commit_counts[*n_commits] = r->best_count;

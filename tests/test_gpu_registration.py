@@ -386,7 +386,10 @@ def test_records_of_a_multi_pass_base_through_the_stage_calls(oracle_mod, s4p_li
     kept.keep_candidate_records(True)
     sunk = capi.Context(capi.make_options(delta, overlap, n_s), max_quads=2000)
     sunk.set_quad_chunking(True, 2000)
-    for c in (big, small, kept, sunk):
+    # the DEFAULT growth policy: small buffers, grow cap left at 32 Mi -- after a chunked base the lane widens, so
+    # the replay for its records fits one pass and must be read back as a single-pass base (it used to report zero records)
+    grown = capi.Context(capi.make_options(delta, overlap, n_s), max_quads=2000)
+    for c in (big, small, kept, sunk, grown):
         c.set_clouds(m.cloud(0), m.cloud(1))
     checked = 0
     for t in range(10):
@@ -399,12 +402,12 @@ def test_records_of_a_multi_pass_base_through_the_stage_calls(oracle_mod, s4p_li
         got = []
         sunk.set_candidate_sink(lambda cnt, T: got.append((cnt, T)))
         res = []
-        for c in (big, small, kept, sunk):
+        for c in (big, small, kept, sunk, grown):
             c.set_base(bx)
             res.append(c.try_base(base, i1, i2))
         sunk.set_candidate_sink(None)
-        rb, rs, rk, rn = res
-        for r in (rs, rk, rn):
+        rb, rs, rk, rn, rg = res
+        for r in (rs, rk, rn, rg):
             assert (r.n_quads, r.n_verified, r.quad_checksum, r.cand_checksum) == (rb.n_quads, rb.n_verified, rb.quad_checksum, rb.cand_checksum)
             assert (r.has_best, r.best_count, list(r.best_quad)) == (rb.has_best, rb.best_count, list(rb.best_quad))
         if rb.n_quads <= 2000:
@@ -412,7 +415,7 @@ def test_records_of_a_multi_pass_base_through_the_stage_calls(oracle_mod, s4p_li
         checked += 1
         bq, bc = big.last_candidates(rb.n_quads)
         bv, bT = big.last_verified(max(rb.n_verified, 1))
-        for c in (small, kept):                                  # replay / kept on the fly
+        for c in (small, kept, grown):                           # replay in chunks / kept on the fly / replay in ONE pass after the growth
             q_, c_ = c.last_candidates(rb.n_quads)
             assert np.array_equal(q_, bq) and np.array_equal(c_, bc)
             v_, T_ = c.last_verified(max(rb.n_verified, 1))

@@ -33,8 +33,10 @@ def sequential_commits(table, start_best, threshold_count):
     return commits
 
 
-def _worker(rank, world, port, seed, n_windows, threshold_count, depth, q, fail_at=None):
+def _worker(rank, world, port, seed, n_windows, threshold_count, depth, q, fail_at=None, fail_commit=None):
     sys.path.insert(0, ROOT)
+    if fail_commit is not None:
+        os.environ["S4P_TEST_FAIL_COMMIT"] = "%d:%d" % fail_commit      # (rank, k): that rank's k-th commit fails (s4p_shard_replay)
     import torch.distributed as dist
     from super4pcs_amd import capi
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
@@ -72,12 +74,12 @@ def _free_port():
     return p
 
 
-def _run(world, seed, n_windows, threshold_count, depth, fail_at=None):
+def _run(world, seed, n_windows, threshold_count, depth, fail_at=None, fail_commit=None):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, seed, n_windows, threshold_count, depth, q, fail_at)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, seed, n_windows, threshold_count, depth, q, fail_at, fail_commit)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=180) for _ in range(world))
@@ -154,6 +156,39 @@ def test_a_rank_failing_right_after_an_improving_window(world, depth, fail_offse
         assert tag == "error" and code == (-5 if rank == owner else -7)
 
 
+@pytest.mark.parametrize("world,depth,which", [(2, 1, "first"), (2, 3, "middle"), (4, 2, "middle"), (4, 3, "last"), (2, 1, "last")])
+def test_a_commit_that_fails_on_one_rank_takes_every_rank_out(world, depth, which, s4p_lib_built):
+    """a commit that fails on ONE rank is a local failure like a failed pass -- the other ranks committed the
+    same window successfully and go on.  In the middle of a call the failing rank completes the window it has already posted
+    and answers the next two reductions with the error key; when the failing commit belongs to the LAST improving window --
+    possibly the last window of the call, where no reduction is left to carry it -- the status reduction that closes every
+    call tells the others.  Either way every rank returns an error and nobody blocks (180 s queue timeout)."""
+    n_windows, seed = 12, 1
+    table = outcome_table(seed, n_windows * world)
+    improving = sorted({t // world for t, _ in sequential_commits(table, 3, N_Q)})
+    assert len(improving) >= 2
+    k = {"first": 0, "middle": len(improving) // 2, "last": len(improving) - 1}[which]
+    fail_rank = world - 1
+    res = _run(world, seed, n_windows, N_Q, depth, fail_commit=(fail_rank, k))
+    assert len(res) == world
+    for rank, tag, code, _ in res:
+        assert tag == "error"
+        assert code == (-5 if rank == fail_rank else -7)
+
+
+def test_a_commit_that_fails_in_the_last_window_of_the_call(s4p_lib_built):
+    """The same with the improving window being the very last one of the call: only the closing status reduction is left."""
+    world, seed = 2, 1
+    table = outcome_table(seed, 12 * world)
+    last_improving = max(t // world for t, _ in sequential_commits(table, 3, N_Q))
+    n_windows = last_improving + 1                                     # the call ends with that window
+    k = len({t // world for t, _ in sequential_commits(table[:n_windows * world], 3, N_Q)}) - 1
+    for depth in (1, 3):
+        res = _run(world, seed, n_windows, N_Q, depth, fail_commit=(0, k))
+        for rank, tag, code, _ in res:
+            assert tag == "error" and code == (-5 if rank == 0 else -7)
+
+
 # ---- SURVEY 8e level 2: every base split over all ranks (SplitLoop in s4p_shard.cpp) -------------------------------------
 def split_table(seed, n_trials, world):
     """Per trial: found (same on every rank: all ranks select the same base) and, per rank, its share's (usable, count, tag)."""
@@ -185,8 +220,10 @@ def split_sequential(table, start_best, threshold_count):
     return commits
 
 
-def _split_worker(rank, world, port, seed, n_trials, threshold_count, depth, q, fail_at=None):
+def _split_worker(rank, world, port, seed, n_trials, threshold_count, depth, q, fail_at=None, fail_commit=None):
     sys.path.insert(0, ROOT)
+    if fail_commit is not None:
+        os.environ["S4P_TEST_FAIL_COMMIT"] = "%d:%d" % fail_commit
     import torch.distributed as dist
     from super4pcs_amd import capi
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
@@ -214,12 +251,12 @@ def _split_worker(rank, world, port, seed, n_trials, threshold_count, depth, q, 
     dist.destroy_process_group()
 
 
-def _run_split(world, seed, n_trials, threshold_count, depth, fail_at=None):
+def _run_split(world, seed, n_trials, threshold_count, depth, fail_at=None, fail_commit=None):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_split_worker, args=(r, world, port, seed, n_trials, threshold_count, depth, q, fail_at)) for r in range(world)]
+    procs = [ctx.Process(target=_split_worker, args=(r, world, port, seed, n_trials, threshold_count, depth, q, fail_at, fail_commit)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=180) for _ in range(world))
@@ -246,3 +283,16 @@ def test_split_base_loop_a_failing_rank_takes_every_rank_out(s4p_lib_built):
     res = _run_split(3, 5, 20, N_Q, 2, fail_at=(1, 6))
     for rank, tag, code, _ in res:
         assert tag == "error" and code == (-5 if rank == 1 else -7)
+
+
+@pytest.mark.parametrize("which", ["first", "last"])
+def test_split_base_loop_a_failing_commit_takes_every_rank_out(which, s4p_lib_built):
+    """A commit that fails on one rank of the split loop: mid-call the next reduction carries the error key, after the last
+    improving base of the call the closing status reduction does."""
+    world, seed, n_trials = 3, 1, 40
+    want = split_sequential(split_table(seed, n_trials, world), 3, N_Q)
+    assert len(want) >= 2
+    k = 0 if which == "first" else len(want) - 1
+    res = _run_split(world, seed, n_trials, N_Q, 2, fail_commit=(2, k))
+    for rank, tag, code, _ in res:
+        assert tag == "error" and code == (-5 if rank == 2 else -7)
