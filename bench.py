@@ -305,11 +305,20 @@ def pmc_passes(args, timeout_s=240):
     """rocprofv3 --pmc passes over an inner run of this script with the SAME warm-up + timed bases and the default lanes
     (counters serialise the launches: per-kernel numbers are the kernel's own).  Three passes -- the TCC slots do not hold
     FETCH_SIZE and WRITE_SIZE together (MI355X_MICROARCH.md "rocprofv3 PMC slots").  Returns {counter: (mean per k_verify
-    launch, launches)} and notes."""
+    launch, launches)}, notes, and the same counters + the kernel's own duration (kernel trace of the counter passes) for ALL
+    FOUR kernels of a device pass ({kernel: {...}}: every launch covers a group of bases)."""
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return {}, ["rocprofv3 not found"]
     got, note = {}, []
+    KERNELS = ("k_pairs2", "k_prep", "k_quads", "k_verify")
+    per_kernel = {k: {} for k in KERNELS}
+
+    def kname(row_name):
+        for k in KERNELS:
+            if ("s4p::%s<" % k) in row_name or ("s4p::%s(" % k) in row_name:
+                return k
+        return None
     for ctrs in (["FETCH_SIZE", "GRBM_GUI_ACTIVE", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY"],
                  ["WRITE_SIZE"], ["TCC_HIT_sum", "TCC_MISS_sum"]):
         d = tempfile.mkdtemp(prefix="s4p_pmc_", dir="/tmp")
@@ -320,10 +329,30 @@ def pmc_passes(args, timeout_s=240):
         try:
             subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=True)
             vals = {}
+            allk = {k: {} for k in KERNELS}
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
-                    if "k_verify<" in row.get("Kernel_Name", "") and row.get("Counter_Name") in ctrs:
+                    if row.get("Counter_Name") not in ctrs:
+                        continue
+                    if "k_verify<" in row.get("Kernel_Name", ""):
                         vals.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+                    kn = kname(row.get("Kernel_Name", ""))
+                    if kn:
+                        allk[kn].setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+            for kn, cs in allk.items():
+                for cname, v in cs.items():
+                    per_kernel[kn][cname] = float(np.mean(v[len(v) // 4:]))      # (skip the warm-up quarter)
+                    per_kernel[kn]["launches"] = len(v)
+            if "GRBM_GUI_ACTIVE" in ctrs:                        # the kernels' own durations: launches are serialised under --pmc
+                dur = {k: [] for k in KERNELS}
+                for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
+                    for row in csv.DictReader(open(f)):
+                        kn = kname(row.get("Kernel_Name", ""))
+                        if kn:
+                            dur[kn].append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3)
+                for kn, v in dur.items():
+                    if v:
+                        per_kernel[kn]["avg_us"] = float(np.mean(v[len(v) // 4:]))
             # the inner run launches warm-up + timed bases: keep the timed ones (the last `steps` launches)
             for k, v in vals.items():
                 v = v[-args.steps:] if len(v) >= args.steps else v
@@ -340,26 +369,95 @@ def pmc_passes(args, timeout_s=240):
             note.append("%s pass failed: %s" % ("+".join(ctrs), type(e).__name__))
         finally:
             shutil.rmtree(d, ignore_errors=True)
-    return got, note
+    return got, note, per_kernel
 
 
-def extra_sample_line(args, sample=20000, timeout_s=240):
-    """SURVEY 8d's other sample size of the benchmarked clouds (n = 20 000 sampled Q points: ~27 M pairs and ~10^9 congruent quads
-    per base, every base chunked) as a second, reported figure of the driver's own command: one warm-up base + one timed base
-    in a process of its own, no oracle (the parity of that size is tests/test_gpu_configs.py::test_config2_gpu_scale_sample_20000
-    and `bench.py --sample 20000` with its own gate)."""
-    cmd = [sys.executable, os.path.abspath(__file__), "--sample", str(sample), "--steps", "1", "--warmup", "1", "--repeats", "1", "--points", str(args.points),
-           "--no-parity", "--cpu-seconds", "0", "--no-pmc", "--no-hbm-point", "--no-time-to-register", "--no-stage-pass", "--no-instrumented",
-           "--no-exclusive", "--no-full-count-mode", "--no-extra"]
+GOLDEN_SCALE = os.path.join(ROOT, "tests", "golden", "scale_config2_n20000.json")
+
+
+def scale_golden_inner(args, device):
+    """The `extra` figure's own process: the benchmarked clouds at SURVEY 8d's GPU-scale sample (n = 20 000 sampled Q points:
+    ~27 M ordered pairs and ~10^9 congruent quads per base, every base chunked).  The seeded bases the oracle's committed record
+    covers (tests/golden/scale_config2_n20000.json: trials 0 and 1, written by tests/golden/make_scale_golden.py on the CPU --
+    the oracle needs the better part of an hour for them) run one at a time through TryOneBase; the LAST one is the timed
+    base.  Every base is checked against the record: pair counts, number of congruent quads and of gated candidates with
+    their order-independent checksums, the inlier counts of a deterministic subsample of the gated quads (stage-level entry
+    point), and the winner must not be beaten by any sampled candidate.  Prints one JSON object."""
+    import hashlib
+    from super4pcs_amd import capi, datasets
+    G = json.load(open(GOLDEN_SCALE))
+    P, Q, _ = datasets.bumpy_pair(args.points, overlap=OVERLAP, delta=DELTA, seed=SEED)
+    opt = capi.make_options(DELTA, OVERLAP, args.sample)
+    m = capi.Matcher(opt, device=device, max_pairs=32 << 20, max_quads=32 << 20)
+    m.init_full(P, Q)
+    info = m.info()
+    mism = []
+
+    def check(ok, what):
+        if not ok:
+            mism.append(what)
+
+    check((info.n_sampled_p, info.n_sampled_q, info.number_of_trials) == (G["n_P"], G["n_Q"], G["number_of_trials"]), "sampled clouds / trial count")
+    saved = os.environ.get("S4P_LANES")
+    os.environ["S4P_LANES"] = "1"                       # the stage-level context needs one lane
+    ctx = capi.Context(opt, device=device, max_pairs=1 << 20, max_quads=1 << 20)
+    if saved is None:
+        os.environ.pop("S4P_LANES", None)
+    else:
+        os.environ["S4P_LANES"] = saved
+    ctx.set_clouds(m.sampled(0), m.sampled(1))
+    m.loop_begin()                                      # (the trial loops' mode: commits refresh the early-exit bound)
+    timed = None
+    parity = {"bases": 0, "quads": 0, "candidates": 0, "candidates_count_checked": 0, "golden": os.path.relpath(GOLDEN_SCALE, ROOT),
+              "golden_sha16": hashlib.sha256(open(GOLDEN_SCALE, "rb").read()).hexdigest()[:16]}
+    for rec in G["bases"]:
+        t0 = time.perf_counter()
+        _ok, r = m.try_one_base()
+        dt = time.perf_counter() - t0
+        b = rec["trial"]
+        check((r.n_pairs1, r.n_pairs2) == (rec["pairs"][0]["n"], rec["pairs"][1]["n"]), "base %d: pair counts" % b)
+        check((r.n_quads, "%016x" % r.quad_checksum) == (rec["K"], rec["quad_sum"]), "base %d: quads %d / checksum vs the oracle's %d" % (b, r.n_quads, rec["K"]))
+        check((r.n_verified, "%016x" % r.cand_checksum) == (rec["C"], rec["cand_sum"]), "base %d: candidates %d / checksum vs the oracle's %d" % (b, r.n_verified, rec["C"]))
+        smp = np.array(rec["sample_quads"], np.int32).reshape(-1, 4)
+        want = np.array(rec["sample_counts"], np.int32)
+        ctx.set_base(m.sampled(0)[np.array(rec["base"])])
+        _gr, g_per = ctx.try_congruent_set(np.array(rec["base"], np.int32), smp)
+        check(np.array_equal(g_per, want), "base %d: inlier counts of %d sampled candidates" % (b, len(smp)))
+        check(bool(r.has_best) and int(want.max()) <= int(r.best_count), "base %d: a sampled candidate beats the reported winner" % b)
+        parity["bases"] += 1; parity["quads"] += int(r.n_quads); parity["candidates"] += int(r.n_verified); parity["candidates_count_checked"] += int(len(smp))
+        timed = {"seconds": dt, "candidates": int(r.n_verified), "trial": b}
+    m.loop_end()
+    parity["mismatches"] = len(mism)
+    parity["what"] = ("every base of this run (trials %s; the last one is the timed base): pair counts, number of congruent quads and of gated candidates "
+                      "with their order-independent checksums, the inlier counts of a deterministic subsample of the gated quads, and no sampled "
+                      "candidate beats the winner -- against the oracle's committed record" % [r_["trial"] for r_ in G["bases"]])
+    if mism:
+        parity["failed"] = mism[:20]
+    st = m.chunk_stats()
+    out = {"sample_size": args.sample, "value": timed["candidates"] / timed["seconds"], "unit": "candidates/s", "ms_per_step": timed["seconds"] * 1e3,
+           "steps": 1, "warmup": len(G["bases"]) - 1, "n_Q": info.n_sampled_q, "candidates_timed": timed["candidates"], "timed_trial": timed["trial"],
+           "chunked_bases": st["bases"], "chunk_passes": st["passes"], "k_verify": m.verify_kernel_info(), "parity": parity}
+    m.close()
+    print(json.dumps(out))
+    return 1 if mism else 0
+
+
+def extra_sample_line(args, sample=20000, timeout_s=300):
+    """SURVEY 8d's other sample size of the benchmarked clouds (n = 20 000 sampled Q points) as a second, reported figure of the
+    driver's own command, in a process of its own (scale_golden_inner): one warm-up base + one timed base, both checked against
+    the oracle's committed record.  The live-oracle gate of that size is `bench.py --sample 20000`; the GPU test of the same
+    record is tests/test_gpu_configs.py::test_config2_gpu_scale_sample_20000."""
     t0 = time.perf_counter()
+    if args.points != N_POINTS or not os.path.exists(GOLDEN_SCALE):
+        return {"sample_size": sample, "error": "no golden record for this workload (%s)" % os.path.relpath(GOLDEN_SCALE, ROOT), "wall_s": 0.0}
+    cmd = [sys.executable, os.path.abspath(__file__), "--sample", str(sample), "--points", str(args.points), "--scale-golden-inner"]
     try:
-        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=timeout_s, check=True)
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=timeout_s)
         line = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][-1]
         d = json.loads(line)
-        return {"sample_size": sample, "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"], "warmup": d["warmup"],
-                "n_Q": d["config"]["n_Q"], "candidates_timed": d["config"]["candidates_timed"], "chunked_bases": d["config"]["chunked_bases"],
-                "k_verify": (d.get("provenance") or {}).get("k_verify"), "wall_s": time.perf_counter() - t0,
-                "note": "same clouds, sample_size %d: one timed base after one warm-up base, separate process; reported, not `value`" % sample}
+        d["wall_s"] = time.perf_counter() - t0
+        d["note"] = "same clouds, sample_size %d: one timed base after one warm-up base, separate process; reported, not `value`" % sample
+        return d
     except Exception as e:                                      # noqa: BLE001 -- the bench line must still be printed
         return {"sample_size": sample, "error": "%s" % type(e).__name__, "wall_s": time.perf_counter() - t0}
 
@@ -502,6 +600,7 @@ def main():
                          "level 2; auto = split at the GPU-scale sample, where a base takes seconds)")
     ap.add_argument("--inner", action="store_true", help="(used by the --pmc passes) timed region only, no JSON")
     ap.add_argument("--hbm-point-inner", action="store_true", help="(used by the HBM-bound point) one cold scoring launch")
+    ap.add_argument("--scale-golden-inner", action="store_true", help="(used by the `extra` object) the golden-checked bases at --sample, one JSON object")
     ap.add_argument("--hbm-transforms", type=int, default=4096)
     ap.add_argument("--points", type=int, default=N_POINTS)
     ap.add_argument("--sample", type=int, default=SAMPLE)
@@ -550,6 +649,8 @@ def main():
     if args.hbm_point_inner:
         hbm_point_inner(local_rank, args.hbm_transforms)
         return
+    if args.scale_golden_inner:
+        raise SystemExit(scale_golden_inner(args, local_rank))
 
     P, Q, T_gt = datasets.bumpy_pair(args.points, overlap=OVERLAP, delta=DELTA, seed=SEED)
     opt = capi.make_options(DELTA, OVERLAP, args.sample)
@@ -825,9 +926,9 @@ def main():
             if failed:
                 parity["failed"] = failed
 
-    pmc, pmc_note = {}, ["skipped"]
+    pmc, pmc_note, pmc_kernels = {}, ["skipped"], {}
     if rank == 0 and world == 1 and args.pmc:
-        pmc, pmc_note = pmc_passes(args)
+        pmc, pmc_note, pmc_kernels = pmc_passes(args)
     hbm_point = None
     if rank == 0 and world == 1 and args.hbm_point:
         hbm_point = hbm_bound_point(args, local_rank)
@@ -909,6 +1010,27 @@ def main():
                   "frac": req * 128.0 / (ex_ms * 1e-3) / 1e9 / L2_PEAK_GBS,
                   "note": "TCC_HIT_sum + TCC_MISS_sum per launch x 128 B (an upper bound: a 16-B gather moves at most one line) over the kernel's "
                           "own launch time"}
+        # all four kernels of a device pass: own duration under the counter passes (launches serialised), issue /
+        # wait shares and L2 hit rate from the same passes; a launch covers a GROUP of bases
+        kernels_tbl = {}
+        for kn, cs in (pmc_kernels or {}).items():
+            if not cs:
+                continue
+            row = {"launches": cs.get("launches"), "avg_us_per_launch": cs.get("avg_us")}
+            if cs.get("GRBM_GUI_ACTIVE") and cs.get("SQ_ACTIVE_INST_VALU") is not None:
+                row["valu_frac"] = cs["SQ_ACTIVE_INST_VALU"] / (N_SIMDS * cs["GRBM_GUI_ACTIVE"] / 8.0 / 4.0)
+            if cs.get("SQ_WAVE_CYCLES") and cs.get("SQ_WAIT_ANY") is not None:
+                row["wait_any_frac_of_wave_cycles"] = cs["SQ_WAIT_ANY"] / cs["SQ_WAVE_CYCLES"]
+            if cs.get("TCC_HIT_sum") is not None and cs.get("TCC_MISS_sum") is not None:
+                rq = cs["TCC_HIT_sum"] + cs["TCC_MISS_sum"]
+                row["l2_hit_rate"] = cs["TCC_HIT_sum"] / max(rq, 1.0)
+                if cs.get("avg_us"):
+                    row["l2_frac_at_128B_per_request"] = rq * 128.0 / (cs["avg_us"] * 1e-6) / 1e9 / L2_PEAK_GBS
+            if cs.get("FETCH_SIZE") is not None and cs.get("avg_us"):
+                row["fetch_GBps_uncorrected"] = cs["FETCH_SIZE"] * 1024.0 / (cs["avg_us"] * 1e-6) / 1e9      # FETCH_SIZE in KB; NOT doubled (gathers: the gfx950 factor is calibrated for wide streams only)
+            fr = {k: row[k2] for k, k2 in (("valu", "valu_frac"), ("l2", "l2_frac_at_128B_per_request")) if row.get(k2) is not None}
+            row["binding"] = ("latency (nothing above 0.5: waiting %.2f of the wave-cycles)" % row.get("wait_any_frac_of_wave_cycles", float("nan"))) if (not fr or max(fr.values()) < 0.5) else max(fr, key=lambda k: fr[k])
+            kernels_tbl[kn] = row
         fracs = {"hbm": achieved / HBM_PEAK_GBS} if achieved == achieved else {}
         if valu:
             fracs["valu"] = valu["frac"]
@@ -917,6 +1039,10 @@ def main():
         binding = max(fracs, key=lambda k: fracs[k]) if fracs else None
         out = {
             "metric": "candidate transforms verified/sec", "value": value, "unit": "candidates/s",
+            # the same timed region with every candidate counted in full (no early-exit bound): quoted beside `value` everywhere
+            "value_full_count": None if full_mode is None else full_mode["value"],
+            "steps_note": "the timed region of %d steps is %.2f ms: pipeline fill is in it (the lanes start empty after the warm-up bases have been "
+                          "waited for); the default run (200 steps) is the steadier figure" % (args.steps, dt_max * 1e3),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong" if collective.get("split") else "weak",     # split mode: the K bases are shared by all GPUs; by base: K bases per GPU
@@ -959,6 +1085,10 @@ def main():
                               "independent of how many bases are in flight.  The working set (point lines ~19 MB) is Infinity-Cache resident, so this is "
                               "priced against a roof the kernel is NOT bound by -- `binding` names the resource closest to its roof.  DESIGN.md section 7.",
                 "binding": {"resource": binding, "fracs": fracs},
+                "kernels": kernels_tbl or None,
+                "kernels_note": "all four kernels of a device pass, each launch covering a group of up to 3 bases: own duration with the launches "
+                                "serialised by the counter collection, VALU issue share of the SIMD quad-cycles, share of the wave-cycles spent "
+                                "waiting, L2 hit rate and request rate against the L2 peak, L2->fabric read rate (FETCH_SIZE as counted, not doubled)",
                 "valu": valu, "l2": l2,
                 "pass_fractions": {"coarse_bitmap_L0": f_l0, "reach_bit_L1": f_l1, "subcell_mask_L2": f_l2}, "kbar": kbar, "groups_per_query": groups_per_query,
                 "full_count_mode": None if (full_walk is None or full_mode is None) else dict(
@@ -967,8 +1097,8 @@ def main():
                     note="the same figure with the early exit off: every candidate walks the structure for all n_Q queries (what rounds 1-2 reported)"),
                 "per_launch": {"avg_launch_ms": avg_ms, "launches": int(prof.verify_launches), "candidates_per_launch": cand_per_launch,
                                "achieved": cand_per_launch * gather_b / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0,
-                               "note": "HIP-event duration of a launch in the default configuration: six bases in flight stretch every launch, so "
-                                       "this is not a per-step cost",
+                               "note": "HIP-event duration of a launch in the default configuration: a launch covers a group of up to three bases and the "
+                                       "launches of the other groups in flight stretch it, so this is not a per-step cost",
                                "exclusive": None if exclusive is None else dict(
                                    exclusive, achieved=exclusive["candidates_per_launch"] * gather_b / (exclusive["avg_launch_ms"] * 1e-3) / 1e9,
                                    frac=exclusive["candidates_per_launch"] * gather_b / (exclusive["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -985,8 +1115,8 @@ def main():
                 "pairs_and_prep": stage_prof.pairs_ms_total / max(stage_prof.quads_launches, 1),
                 "quads_and_gate": stage_prof.quads_ms_total / max(stage_prof.quads_launches, 1),
                 "verify_and_select": stage_prof.verify_ms_total / max(stage_prof.verify_launches, 1),
-                "note": "HIP-event time per launch with six bases in flight, from a separate pass over the same bases with events around "
-                        "every stage (the timed passes record events around k_verify only)"},
+                "note": "HIP-event time per launch (a group of up to three bases) with the other groups in flight, from a separate pass over the same "
+                        "bases with events around every stage (the timed passes record events around k_verify only)"},
         }
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(P, Q, args.cpu_seconds, args.sample, ttr["candidates_verified"] if ttr else 0)

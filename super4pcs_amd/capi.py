@@ -559,6 +559,17 @@ class Matcher:
         self.L.s4p_matcher_set_early_exit.argtypes = [C.c_void_p, C.c_int32]
         self._chk(self.L.s4p_matcher_set_early_exit(self.h, int(enable)))
 
+    def loop_begin(self):
+        """Bracket a driver's own trial loop (TryOneBase one at a time): commits refresh the device's early-exit bound."""
+        self.L.s4p_matcher_loop_begin.restype = C.c_int32
+        self.L.s4p_matcher_loop_begin.argtypes = [C.c_void_p]
+        self._chk(self.L.s4p_matcher_loop_begin(self.h))
+
+    def loop_end(self):
+        self.L.s4p_matcher_loop_end.restype = C.c_int32
+        self.L.s4p_matcher_loop_end.argtypes = [C.c_void_p]
+        self._chk(self.L.s4p_matcher_loop_end(self.h))
+
     def set_clouds_timing(self):
         o = (C.c_double * 4)()
         self.L.s4p_set_clouds_timing(self.ctx_handle(), o)

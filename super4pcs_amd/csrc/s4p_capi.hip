@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -12,6 +13,7 @@
 #include <cstring>
 #include <numeric>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "s4p_host_structs.hpp"
@@ -35,15 +37,6 @@ struct PinBuf {
   void free() { if (p) { (void)hipHostFree(p); p = nullptr; } n = 0; }
 };
 uint32_t next_pow2(uint64_t v) { uint64_t p = 1; while (p < v) p <<= 1; return uint32_t(p); }
-// k_pairs: waves per primitive (PairParams::split), so that a set has about 4000 work items whatever the sample size
-uint32_t pair_split(uint32_t n_q) {
-  static const uint32_t target = getenv("S4P_PAIR_ITEMS") ? uint32_t(atoi(getenv("S4P_PAIR_ITEMS"))) : 4096u;      // tuning aid
-  return std::min<uint32_t>(8u, std::max<uint32_t>(1u, target / std::max<uint32_t>(n_q, 1u)));
-}
-// Smallest float x with acosf(x) <= theta, acosf being libm's (what the reference's std::acos(float) calls): the
-// segment-angle filter "acos(d) <= theta" (pairCreationFunctor.h:205,209) then is "d >= x && d <= 1" exactly, provided
-// acosf is monotone around x -- checked over +-512 neighbouring floats (its error is < 1 ulp while 512 ulps of the
-// argument move the result by hundreds of ulps, so a violation further out is impossible).
 uint32_t float_key(float f) { uint32_t b; std::memcpy(&b, &f, 4); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
 float key_float(uint32_t k) { const uint32_t b = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k; float f; std::memcpy(&f, &b, 4); return f; }
 float angle_threshold(double theta, bool* monotone) {
@@ -110,40 +103,63 @@ struct s4p_ctx {
       ew1.free(); quads.free(); tags.free(); counts.free(); cand_idx.free(); cand_T.free(); ht_keys.free(); ht_heads.free();
     }
   };
+  // What a group launch needs of one base: the parameter records of its four kernels and the upload of its staged sequences,
+  // built when the base is submitted (s4p_try_base_staged_async), consumed when its group is launched (flush_group).
+  struct LaunchRec {
+    PairParams2 pp; PrepParams p1; QuadParams q; BaseFrame bf;
+    const uint32_t* up_src = nullptr; uint32_t* up_dst = nullptr; size_t up_bytes = 0;
+  };
   struct Lane : LaneBufs {
-    hipStream_t stream = nullptr;
-    // CU partition (S4P_CU_SPLIT = n > 1): `stream` runs on one CU in n (the latency-bound pair / prep / quad kernels and
-    // the copies), `vstream` on the others (k_verify, sized to 2 workgroups per CU of ITS partition), chained by `chain`.
-    // Without the partition a k_verify launch is sized to the whole chip and slows 1.9x when another lane's small
-    // kernels hold some of its CU slots (its 512 workgroups then need a second round).
-    hipStream_t vstream = nullptr; hipEvent_t chain = nullptr;
-    DevBuf<DevCounters> ctr;          // [0] live counters of the base in flight, [1] its result record (what the host reads)
+    hipStream_t stream = nullptr;     // the lane's own stream: group launches run on the stream of the group's first lane, solo passes (stage-level calls, chunk passes, a base redone after a growth) on the lane's own
+    DevBuf<DevCounters> ctr;          // [0] live counters of the base in flight (its result record is pinned host memory: hctr)
+    LaunchRec rec;
+    bool pending = false;             // submitted, its group not launched yet
+    uint32_t seq = 0;                 // number of the launch whose result record the host waits for (DevCounters::seq)
     DevBuf<uint4> slots;              // k_verify: per-workgroup best, reduced by its last workgroup
     DevBuf<uint32_t> border;          // k_verify: candidates whose Euler-angle gate the host settles (max_angle >= 0), kBorderCap entries
     bool dirty = false;               // a stage-level call left the live counters non-zero: clear before a fused pass
-    DevBuf<uint32_t> seq[2];          // device copy of a staged sequence blob (layout: StageSlot)
+    DevBuf<uint32_t> seqbuf;          // device copy of a staged sequence blob, both pair sets (layout: StageSlot)
     // launch record of the base in flight: what a relaunch after a buffer growth needs (finish_result)
     int sv_slot = -1; int32_t sv_ids[4] = {0, 0, 0, 0}; float sv_inv1 = 0.f, sv_inv2 = 0.f; float sv_bx[12] = {0}, sv_brgb[12] = {0};
     uint64_t sv_gen = 0;              // generation of the staging slot when the base was launched (a replay needs the same content)
     uint32_t sv_nseq1 = 0;            // sequence length of the base's first pair set: its order keys are below 2 * n_q * sv_nseq1
   };
-  static constexpr int kMaxLanes = 8;
+  static constexpr int kMaxLanes = 12;
   Lane lane[kMaxLanes];
-  int n_lanes = 6;                   // S4P_LANES (1..8): bases in flight (measured 3: 66, 4: 72, 5: 77.5, 6: 81, 8: 79 M candidates/s)
-  PinBuf<DevCounters> hctr[kMaxLanes];      // [pipeline slot == lane]
+  // Bases in flight = lanes (S4P_LANES, 1..12); consecutive lanes form GROUPS of `group` bases (S4P_GROUP, 1..kGroupMax) that
+  // go through every kernel in ONE launch (s4p_kernels.hip.hpp "BASE GROUPS").  A group is launched when its last base has been
+  // submitted -- or earlier, with the bases it has, when somebody waits for one of them -- so any call pattern (one base at a
+  // time, the engine's pipelined loop, the sharded loops) gets the same results; only the packing differs.
+  int n_lanes = 9, group = 3;
+  // Grids of k_prep / k_quads: their trip counts (pairs of a base) live in device memory, so the grids are sized by what the
+  // registration's bases have needed so far (a decaying maximum with head-room) instead of the worst case -- a grid of 1024 /
+  // 2048 workgroups per base of which a hundred find work is mostly dispatch cost.  A base that needs more takes a second
+  // grid-stride pass: slower, same result.  0 = no estimate yet (first bases, stage-level calls): the full grids.
+  uint32_t est_m1 = 0, est_m2 = 0;
+  uint32_t launch_seq = 0;           // group launches so far (written into the result records: DevCounters::seq)
+  DevBuf<uint32_t> group_done;       // one k_verify ticket counter per lane (a launch uses the one of its first lane)
+  // Result records: pinned host memory the last workgroup of k_verify writes directly (no read-back copy in the stream)
+  struct HostRec { DevCounters* p = nullptr; DevCounters* dev = nullptr; size_t n = 0;
+    hipError_t alloc(size_t) { free(); hipError_t e = hipHostMalloc((void**)&p, sizeof(DevCounters), hipHostMallocMapped | hipHostMallocCoherent); if (e != hipSuccess) { p = nullptr; return e; }
+      n = 1; std::memset(p, 0, sizeof(DevCounters)); return hipHostGetDevicePointer((void**)&dev, p, 0); }
+    void free() { if (p) { (void)hipHostFree(p); p = nullptr; dev = nullptr; } n = 0; } };
+  HostRec hctr[kMaxLanes];           // [pipeline slot == lane]
   // Staging ring: host-built octree sequences of the two pair sets of a base, in pinned memory.  A slot is
   // written by whoever stages the base (the caller thread, or the engine's octree thread through s4p_stage_base)
   // and read by the H2D copies of s4p_try_base_staged_async; the engine recycles a slot after that base's wait.
   struct StageSlot {
-    // one blob per pair set, uploaded with a single copy: seq_id[n_seq] | leaf_off[n_leaf + 1] | pad to 16 B | leaves[n_leaf]
-    PinBuf<uint32_t> seq[2];
+    // one blob per pair set: seq_id[n_seq] | leaf_off[n_leaf + 1] | pad to 16 B | leaves[n_leaf]; set 1 right behind set 0
+    // (off[1], a multiple of 4 words) so that ONE copy uploads both
+    PinBuf<uint32_t> blob;
+    uint32_t off[2] = {0, 0};
     uint32_t n_seq[2] = {0, 0}, n_leaf[2] = {0, 0};
+    static uint32_t set_words(uint32_t n_seq, uint32_t n_leaf) { return (leaf_word(n_seq, n_leaf) + 4u * n_leaf + 3u) & ~3u; }
     uint64_t gen = 0;                 // bumped whenever the slot is (re)written
     static uint32_t leaf_word(uint32_t n_seq, uint32_t n_leaf) { return (n_seq + n_leaf + 1u + 3u) & ~3u; }
     static size_t blob_words(size_t n_q) { return 2 * n_q + 8 + 4 * n_q; }      // n_leaf <= n_seq <= n_q
     float eps_unit[2] = {0, 0}, n_radius[2] = {0, 0}, distance[2] = {0, 0}, normal_angle[2] = {0, 0};
   };
-  static constexpr int kStageSlots = 24;   // 0..11: self-staging of s4p_try_base_async; 12..23: a threaded driver
+  static constexpr int kStageSlots = 32;   // 0..15: self-staging of s4p_try_base_async; 16..31: a threaded driver
   StageSlot stage[kStageSlots];
   uint32_t stage_rr = 0;             // round-robin slot for the self-staging (single-thread) paths
   int cur = 0;                       // slot used by the call in progress
@@ -203,14 +219,12 @@ struct s4p_ctx {
   uint32_t verify_blocks = 256; bool verify_blocks_fixed = false, verify_blocks_env = false;   // per set_clouds (see there); S4P_VERIFY_BLOCKS fixes it
   int verify_threads = kVerifyThreadsCached;      // per set_clouds; S4P_VERIFY_THREADS overrides
   int ablate = 0;                    // S4P_ABLATE (profiling aid, read once at creation)
-  // A/B aid: S4P_FUSE_GATE=0 runs the rigid transform + rms gate as a k_gate launch instead of
-  // inside k_quads' flush (measured slower)
-  bool fuse_gate = true;
-  bool pairs_v2 = true;              // S4P_PAIRS_V2=0: the round-3 k_pairs (one wave per primitive) instead of the transposed k_pairs2 (A/B aid)
-  int cu_split = 0;                  // S4P_CU_SPLIT (0 = off): one CU in n for the small kernels, the rest for k_verify
   double host_octree_s = 0, host_wait_s = 0;
-  // S4P_TRACE_LAUNCH=1 (lab aid): where the launch thread's time goes inside launch_base, printed by s4p_destroy
-  bool trace_launch = false; double lt[8] = {0, 0, 0, 0, 0, 0, 0, 0}; uint64_t lt_n = 0;
+  // S4P_TRACE_LAUNCH=1 (lab aid): where the launch thread's time goes inside flush_lanes, printed by s4p_destroy
+  double wait_timeout_s = 600.0;      // S4P_WAIT_TIMEOUT_S: a device pass that has not finished by then is reported as an error (wait_lane)
+  bool debug = false;                // S4P_DEBUG=1 (lab aid): launches and waits on stderr
+  bool trace_launch = false; double lt[8] = {0, 0, 0, 0, 0, 0, 0, 0}; uint64_t lt_n = 0, lt_groups = 0;
+  int lane_group_n[kMaxLanes] = {0};  // bases of the launch a lane was the FIRST lane of (its profiling events), else 0
   double set_clouds_s[4] = {0, 0, 0, 0};      // last s4p_set_clouds: host copies + unit frame + grid plan | device build of the LCP structure | Q-side uploads | total
 
   size_t verify_lds_bytes() const {
@@ -270,18 +284,19 @@ void stage_pairs(s4p_ctx* c, int slot, int set, float pair_distance, float pair_
   st.n_seq[set] = c->tree.n_seq(); st.n_leaf[set] = c->tree.n_leaf(); st.gen++;
   st.eps_unit[set] = c->tree.eps_unit; st.n_radius[set] = nRadius; st.distance[set] = pair_distance; st.normal_angle[set] = pair_normals_angle;
   static_assert(sizeof(Leaf) == sizeof(float4), "leaf records are uploaded as float4");
-  uint32_t* blob = st.seq[set].p;
+  // set 0 at the start of the slot's blob, set 1 right behind it (set 0 of a base is always staged first)
+  st.off[set] = set == 0 ? 0u : s4p_ctx::StageSlot::set_words(st.n_seq[0], st.n_leaf[0]);
+  uint32_t* blob = st.blob.p + st.off[set];
   c->tree.flatten(blob, blob + st.n_seq[set], reinterpret_cast<Leaf*>(blob + s4p_ctx::StageSlot::leaf_word(st.n_seq[set], st.n_leaf[set])));
 }
 
-// part 2: upload the staged sequence of one set and fill its kernel parameters.
-int32_t upload_pairs_staged(s4p_ctx* c, int slot, int set, float pair_distance_epsilon, int bp1, int bp2, PairParams& P) {
+// part 2: the kernel parameters of one staged set on lane c->cur (the upload of the blob is the caller's: one copy per base)
+void fill_pair_params(s4p_ctx* c, int slot, int set, float pair_distance_epsilon, int bp1, int bp2, PairParams& P) {
   const s4p_ctx::StageSlot& st = c->stage[slot];
   s4p_ctx::Lane& L = c->lane[c->cur];
   const uint32_t n_seq = st.n_seq[set], n_leaf = st.n_leaf[set];
   const uint32_t leaf_word = s4p_ctx::StageSlot::leaf_word(n_seq, n_leaf);
-  uint32_t* dseq = L.seq[set].p;
-  if (n_seq) HIPCHK(c, hipMemcpyAsync(dseq, st.seq[set].p, (size_t(leaf_word) + 4u * n_leaf) * sizeof(uint32_t), hipMemcpyHostToDevice, L.stream));
+  uint32_t* dseq = L.seqbuf.p + st.off[set];
   P = PairParams{};
   P.ux = c->ux.p; P.uy = c->uy.p; P.uz = c->uz.p; P.qx = c->qx.p; P.qy = c->qy.p; P.qz = c->qz.p;
   P.nx = c->has_normals ? c->qnx.p : nullptr; P.ny = c->qny.p; P.nz = c->qnz.p;
@@ -299,45 +314,41 @@ int32_t upload_pairs_staged(s4p_ctx* c, int slot, int set, float pair_distance_e
   P.ab = set == 0 ? L.ab1.p : L.ab2.p; P.okey = set == 0 ? L.okey1.p : L.okey2.p;
   P.counter = set == 0 ? &L.ctr.p->m1 : &L.ctr.p->m2;
   P.cap = uint32_t(L.cap_pairs); P.overflow = &L.ctr.p->overflow; P.overflow_bit = set == 0 ? 1u : 2u;
-  P.split = pair_split(c->n_q);
+  P.split = 1u;
   { float sx = c->base_xyz[3 * bp2] - c->base_xyz[3 * bp1], sy = c->base_xyz[3 * bp2 + 1] - c->base_xyz[3 * bp1 + 1],
           sz = c->base_xyz[3 * bp2 + 2] - c->base_xyz[3 * bp1 + 2];                 // setBase, pairCreationFunctor.h:135-143
     normalize3(sx, sy, sz);
     P.seg1[0] = sx; P.seg1[1] = sy; P.seg1[2] = sz; P.cos_min = c->cos_min; }
-  return S4P_OK;
 }
 
-// loop 2 + the pair filters (k_pairs) for one set, or for both sets of a base in one launch: one wave per (primitive,
-// part); about 4000 work items per set fill the chip once with both sets in flight
-int32_t launch_pairs_kernel(s4p_ctx* c, const PairParams2& PP, int n_sets) {
-  if (c->pairs_v2) {
-    // k_pairs2: one wave per (tile of 64 primitives, chunk of 64 sequence slots); persistent 512-thread workgroups, at most
-    // two waves per SIMD over both sets
-    uint32_t n_seq_max = 0;
-    for (int k = 0; k < n_sets; ++k) n_seq_max = std::max(n_seq_max, PP.set[k].pair.n_seq);
-    const uint64_t items = uint64_t((c->n_q + 63u) / 64u) * uint64_t((n_seq_max + 63u) / 64u);
-    const uint32_t wgs = uint32_t(std::min<uint64_t>(std::max<uint64_t>((items + kPair2Waves - 1u) / kPair2Waves, 1u), n_sets == 2 ? 128u : 256u));
-    if (c->angle_pairs) hipLaunchKernelGGL(k_pairs2<true>, dim3(wgs, uint32_t(n_sets)), dim3(64 * kPair2Waves), 0, c->lane[c->cur].stream, PP);
-    else hipLaunchKernelGGL(k_pairs2<false>, dim3(wgs, uint32_t(n_sets)), dim3(64 * kPair2Waves), 0, c->lane[c->cur].stream, PP);
-    HIPCHK(c, hipGetLastError());
-    return S4P_OK;
-  }
-  const uint32_t items = c->n_q * pair_split(c->n_q);
-  const uint32_t wgs = std::min<uint32_t>(std::max<uint32_t>((items + kPairWaves - 1u) / kPairWaves, 1u), 4096u);
-  if (c->angle_pairs) hipLaunchKernelGGL(k_pairs<true>, dim3(wgs, uint32_t(n_sets)), dim3(64 * kPairWaves), 0, c->lane[c->cur].stream, PP);
-  else hipLaunchKernelGGL(k_pairs<false>, dim3(wgs, uint32_t(n_sets)), dim3(64 * kPairWaves), 0, c->lane[c->cur].stream, PP);
+// loop 2 + the pair filters (k_pairs2) of the first n_bases records of PG, n_sets sets each, in one launch: one wave per
+// (tile of 64 primitives, chunk of 64 sequence slots); persistent 512-thread workgroups, at most two waves per SIMD over the
+// two sets of a base
+int32_t launch_pairs_kernel(s4p_ctx* c, const PairGroup& PG, int n_bases, int n_sets, hipStream_t st) {
+  uint32_t n_seq_max = 0;
+  for (int b = 0; b < n_bases; ++b) for (int k = 0; k < n_sets; ++k) n_seq_max = std::max(n_seq_max, PG.base[b].set[k].pair.n_seq);
+  if (n_seq_max == 0) return S4P_OK;
+  const uint64_t items = uint64_t((c->n_q + 63u) / 64u) * uint64_t((n_seq_max + 63u) / 64u);
+  const uint32_t wgs = uint32_t(std::min<uint64_t>(std::max<uint64_t>((items + kPair2Waves - 1u) / kPair2Waves, 1u), n_sets == 2 ? 128u : 256u));
+  const dim3 grid(wgs, uint32_t(n_sets == 2 ? 2 * n_bases : 1));
+  if (c->angle_pairs) hipLaunchKernelGGL(k_pairs2<true>, grid, dim3(64 * kPair2Waves), 0, st, PG);
+  else hipLaunchKernelGGL(k_pairs2<false>, grid, dim3(64 * kPair2Waves), 0, st, PG);
   HIPCHK(c, hipGetLastError());
   return S4P_OK;
 }
 
+// one set through the stage-level entry point (s4p_extract_pairs): staged, uploaded and extracted on lane c->cur's own stream
 int32_t launch_pairs(s4p_ctx* c, int set, float pair_distance, float pair_normals_angle, float pair_distance_epsilon,
                      int bp1, int bp2) {
   const int slot = int(c->stage_rr % uint32_t(s4p_ctx::kStageSlots));
   stage_pairs(c, slot, set, pair_distance, pair_normals_angle, pair_distance_epsilon, true);
-  PairParams2 PP{};
-  if (int32_t rc = upload_pairs_staged(c, slot, set, pair_distance_epsilon, bp1, bp2, PP.set[0].pair)) return rc;
-  if (PP.set[0].pair.n_seq == 0) return S4P_OK;
-  return launch_pairs_kernel(c, PP, 1);
+  PairGroup PG{};
+  fill_pair_params(c, slot, set, pair_distance_epsilon, bp1, bp2, PG.base[0].set[0].pair);
+  const s4p_ctx::StageSlot& st = c->stage[slot];
+  s4p_ctx::Lane& L = c->lane[c->cur];
+  if (st.n_seq[set] == 0) return S4P_OK;
+  HIPCHK(c, hipMemcpyAsync(L.seqbuf.p + st.off[set], st.blob.p + st.off[set], size_t(s4p_ctx::StageSlot::set_words(st.n_seq[set], st.n_leaf[set])) * 4, hipMemcpyHostToDevice, L.stream));
+  return launch_pairs_kernel(c, PG, 1, 1, L.stream);
 }
 
 // segment lengths / normal "angles" of an ordered base (match4pcsBase.hpp:318-326)
@@ -412,7 +423,7 @@ int32_t quad_params(s4p_ctx* c, float inv1, float inv2, float thr2, PrepParams& 
   Q.m2_dev = &L.ctr.p->m2; Q.cap2 = uint32_t(L.cap_pairs); Q.ht = ht; Q.thr = thr2;
   Q.quads = L.quads.p; Q.tags = L.tags.p; Q.K_dev = &L.ctr.p->K; Q.K_cap = uint32_t(L.cap_quads); Q.overflow = &L.ctr.p->overflow;
   Q.r0 = 0u; Q.r1 = 0xFFFFFFFFu; Q.qsum_dev = &L.ctr.p->quad_sum; Q.csum_dev = &L.ctr.p->cand_sum;
-  Q.slice_num = 0u; Q.slice_den = 0u;                       // (a share of the set, s4p_set_quad_slice, applies to the fused passes only: launch_base)
+  Q.slice_num = 0u; Q.slice_den = 0u;                       // (a share of the set, s4p_set_quad_slice, applies to the fused passes only: prepare_base)
   Q.k1_lo = 0u; Q.k1_hi = 0xFFFFFFFFu; Q.k1_all = 1;
   Q.do_gate = 0;
   return S4P_OK;
@@ -425,16 +436,32 @@ GateParams gate_params(s4p_ctx* c, const BaseFrame& bf) {
   return G;
 }
 
-void launch_prep_kernel(s4p_ctx* c, const PrepParams& P1) {
-  hipLaunchKernelGGL(k_prep, dim3(1024), dim3(256), 0, c->lane[c->cur].stream, P1);      // set 1: hash build (set 2 is prepared inside k_quads)
+// Group launches: the first n records of a group, on stream st.
+uint32_t est_grid(uint32_t est, uint32_t full) {             // workgroups of 256 threads for an estimated entry count (+50 %), within [64, full]
+  if (est == 0u) return full;
+  const uint64_t want = (uint64_t(est) * 3u / 2u + 255u) / 256u;
+  return uint32_t(std::min<uint64_t>(full, std::max<uint64_t>(64u, want)));
 }
-void launch_quads_kernel(s4p_ctx* c, const QuadParams& Q) {
+void launch_prep_group(const PrepGroup& G, int n, hipStream_t st, uint32_t est = 0) {
+  hipLaunchKernelGGL(k_prep, dim3(est_grid(est, 1024u), uint32_t(n)), dim3(256), 0, st, G);      // set 1: hash build (set 2 is prepared inside k_quads)
+}
+void launch_quads_group(s4p_ctx* c, const QuadGroup& G, int n, hipStream_t st, uint32_t est = 0) {
   // one set-2 entry per thread in ONE pass for up to 512 k entries (a second grid-stride pass doubles the chain of
   // dependent gathers of the workgroups that get one); idle workgroups leave after reading the count
-  const uint64_t span = uint64_t(Q.r1) - uint64_t(Q.r0);    // (the whole set: 2^32 - 1)
-  const uint32_t blocks = uint32_t(std::min<uint64_t>(2048u, std::max<uint64_t>(1u, (span + 255u) / 256u)));
-  if (c->opt.max_angle >= 0.f) hipLaunchKernelGGL(k_quads<true>, dim3(blocks), dim3(256), 0, c->lane[c->cur].stream, Q);
-  else hipLaunchKernelGGL(k_quads<false>, dim3(blocks), dim3(256), 0, c->lane[c->cur].stream, Q);
+  uint64_t span = 1;
+  for (int b = 0; b < n; ++b) span = std::max<uint64_t>(span, uint64_t(G.base[b].r1) - uint64_t(G.base[b].r0));    // (the whole set: 2^32 - 1)
+  const uint32_t blocks = std::min(est_grid(est, 2048u), uint32_t(std::min<uint64_t>(2048u, std::max<uint64_t>(1u, (span + 255u) / 256u))));
+  if (c->opt.max_angle >= 0.f) hipLaunchKernelGGL(k_quads<true>, dim3(blocks, uint32_t(n)), dim3(256), 0, st, G);
+  else hipLaunchKernelGGL(k_quads<false>, dim3(blocks, uint32_t(n)), dim3(256), 0, st, G);
+}
+// single-base forms on lane c->cur's own stream (stage-level calls, chunk passes)
+void launch_prep_kernel(s4p_ctx* c, const PrepParams& P1) {
+  PrepGroup G{}; G.base[0] = P1;
+  launch_prep_group(G, 1, c->lane[c->cur].stream);
+}
+void launch_quads_kernel(s4p_ctx* c, const QuadParams& Q) {
+  QuadGroup G{}; G.base[0] = Q;
+  launch_quads_group(c, G, 1, c->lane[c->cur].stream);
 }
 void launch_gate_kernel(s4p_ctx* c, const GateParams& G) {
   s4p_ctx::Lane& L = c->lane[c->cur];
@@ -443,23 +470,28 @@ void launch_gate_kernel(s4p_ctx* c, const GateParams& G) {
   else hipLaunchKernelGGL(k_gate<false>, dim3(1024), dim3(256), 0, L.stream, K);
 }
 
-// Verify of every gated candidate + winner selection + result record (k_verify), bracketed by the profiling events
-int32_t launch_verify(s4p_ctx* c, const BaseFrame& bf) {
-  s4p_ctx::Lane& L = c->lane[c->cur];
+// Verify of every gated candidate of the bases on lanes[0..n) + winner selection + result records (k_verify), on stream vs,
+// bracketed by the profiling events of the first lane.  Every lane's result record gets the number of this launch.
+int32_t launch_verify_group(s4p_ctx* c, const int* lanes, int n, hipStream_t vs) {
   VerifyParams V{};
-  V.grid = c->dev_grid(); V.q4 = c->q4.p; V.q4v = c->q4v.p; V.qq = c->qq; V.qsoa = c->qsoa.p; V.n_q = c->n_q; V.base = bf;
-  V.quads = L.quads.p; V.tags = L.tags.p; V.counts = L.counts.p; V.cand_idx = L.cand_idx.p; V.cand_T = L.cand_T.p;
-  V.ctr = L.ctr.p; V.res = L.ctr.p + 1; V.slots = L.slots.p; V.border = L.border.p; V.count_tests = c->prof_points ? 1 : 0;
+  V.grid = c->dev_grid(); V.q4 = c->q4.p; V.q4v = c->q4v.p; V.qq = c->qq; V.qsoa = c->qsoa.p; V.n_q = c->n_q;
+  V.n_bases = uint32_t(n);
+  const uint32_t seq = ++c->launch_seq ? c->launch_seq : ++c->launch_seq;      // (never 0: a fresh record reads 0)
+  for (int b = 0; b < n; ++b) {
+    s4p_ctx::Lane& L = c->lane[lanes[b]];
+    VerifyBase& B = V.b[b];
+    B.base = c->slot_bf[lanes[b]];
+    B.quads = L.quads.p; B.tags = L.tags.p; B.counts = L.counts.p; B.cand_idx = L.cand_idx.p; B.cand_T = L.cand_T.p;
+    B.ctr = L.ctr.p; B.res = c->hctr[lanes[b]].dev; B.slots = L.slots.p; B.border = L.border.p;
+    L.seq = seq;
+  }
+  V.group_done = c->group_done.p + lanes[0];
+  V.seq = seq;
+  V.count_tests = c->prof_points ? 1 : 0;
   V.prune = c->best_hint;
   V.ablate = c->ablate;
   V.cyc = c->cyc.p;
-  hipStream_t vs = L.stream;
-  if (L.vstream) {                                           // CU partition: k_verify on the big partition, after the lane's small kernels
-    HIPCHK(c, hipEventRecord(L.chain, L.stream));
-    HIPCHK(c, hipStreamWaitEvent(L.vstream, L.chain, 0));
-    vs = L.vstream;
-  }
-  if (c->prof_events) HIPCHK(c, hipEventRecord(c->ev[c->cur][0], vs));
+  if (c->prof_events) HIPCHK(c, hipEventRecord(c->ev[lanes[0]][0], vs));
   const bool lean = c->use_lean();                           // a bound is in force: the lean sweep (s4p_kernels.hip.hpp)
   const size_t lds = lean ? c->lean_lds_bytes() : c->verify_lds_bytes();
   const dim3 grid(c->verify_grid()), block(c->verify_threads);
@@ -467,20 +499,58 @@ int32_t launch_verify(s4p_ctx* c, const BaseFrame& bf) {
   else if (lean) { if (c->prof_points) hipLaunchKernelGGL((k_verify<true, false, true>), grid, block, lds, vs, V); else hipLaunchKernelGGL((k_verify<false, false, true>), grid, block, lds, vs, V); }
   else if (c->prof_points) { if (c->qlds) hipLaunchKernelGGL((k_verify<true, true, false>), grid, block, lds, vs, V); else hipLaunchKernelGGL((k_verify<true, false, false>), grid, block, lds, vs, V); }
   else { if (c->qlds) hipLaunchKernelGGL((k_verify<false, true, false>), grid, block, lds, vs, V); else hipLaunchKernelGGL((k_verify<false, false, false>), grid, block, lds, vs, V); }
-  if (c->prof_events) HIPCHK(c, hipEventRecord(c->ev[c->cur][1], vs));
+  if (c->prof_events) HIPCHK(c, hipEventRecord(c->ev[lanes[0]][1], vs));
   HIPCHK(c, hipGetLastError());
+  if (c->debug) fprintf(stderr, "[s4p] k_verify launched: seq %u, %d base(s), first lane %d, lean %d, lds %zu, grid %u x %d, prune %u\n", seq, n, lanes[0], int(lean), lds, grid.x, c->verify_threads, V.prune);
   return S4P_OK;
 }
+// the base on lane c->cur alone, on the lane's own stream (chunk passes, s4p_try_congruent_set)
+int32_t launch_verify(s4p_ctx* c, const BaseFrame& bf) {
+  c->slot_bf[c->cur] = bf;
+  const int lane = c->cur;
+  c->lane_group_n[lane] = 1;
+  return launch_verify_group(c, &lane, 1, c->lane[c->cur].stream);
+}
 
-// enqueue the result read-back of the base in slot c->cur and mark its completion
+// mark the completion of the pass of lane c->cur on its own stream (the result record itself is written by k_verify)
 int32_t enqueue_result(s4p_ctx* c, const BaseFrame& bf) {
   c->slot_bf[c->cur] = bf;
-  hipStream_t rs = c->lane[c->cur].vstream ? c->lane[c->cur].vstream : c->lane[c->cur].stream;      // the stream k_verify ran on
-  HIPCHK(c, hipMemcpyAsync(c->hctr[c->cur].p, c->lane[c->cur].ctr.p + 1, sizeof(DevCounters), hipMemcpyDeviceToHost, rs));
-  HIPCHK(c, hipEventRecord(c->done[c->cur], rs));
+  HIPCHK(c, hipEventRecord(c->done[c->cur], c->lane[c->cur].stream));
   return S4P_OK;
 }
 
+// Wait for the result record of lane li: the host polls the launch number k_verify writes last into the pinned record (a
+// few microseconds sooner than the stream's event, and no read-back copy in the stream), with the event as the fallback and
+// as the carrier of asynchronous errors.
+int32_t wait_lane(s4p_ctx* c, int li) {
+  const volatile uint32_t* seq = &c->hctr[li].p->seq;
+  const uint32_t want = c->lane[li].seq;
+  const auto t0 = std::chrono::steady_clock::now();
+  auto waited = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
+  if (c->debug) fprintf(stderr, "[s4p] wait lane %d for seq %u (record has %u)\n", li, want, unsigned(*seq));
+  for (uint32_t spin = 0;; ++spin) {
+    if (*seq == want) { std::atomic_thread_fence(std::memory_order_acquire); return S4P_OK; }
+    if ((spin & 1023u) == 1023u) {
+      const hipError_t q = hipEventQuery(c->done[li]);
+      if (q == hipSuccess) break;                            // the launch is over: the record is complete whatever the poll saw
+      if (q != hipErrorNotReady) { c->err = std::string("hipEventQuery: ") + hipGetErrorString(q); return S4P_ERR_HIP; }
+      const double w = waited();
+      if (w > 0.002) std::this_thread::sleep_for(std::chrono::microseconds(w > 0.1 ? 500 : 20));      // a long pass (chunks: seconds): stop burning the core
+      if (w > c->wait_timeout_s) {                           // a device pass that never finishes must not hang the caller for ever
+        char b[320];
+        snprintf(b, sizeof b, "the device pass on lane %d did not finish within %.0f s (record seq %u, expected %u): S4P_WAIT_TIMEOUT_S", li, c->wait_timeout_s, unsigned(*seq), unsigned(want));
+        c->err = b;
+        return S4P_ERR_HIP;
+      }
+    }
+  }
+  if (*seq != want) {
+    HIPCHK(c, hipEventSynchronize(c->done[li]));
+    if (*seq != want) S4P_FAIL(c, S4P_ERR_STATE, "k_verify finished without writing its result record");
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  return S4P_OK;
+}
 size_t lane_bytes(uint64_t mp, uint64_t mq);
 
 hipError_t alloc_lane_buffers(uint64_t mp_, uint64_t mq_, s4p_ctx::LaneBufs& L, const char** what);
@@ -528,12 +598,12 @@ int32_t grow_lane(s4p_ctx* c, int li, uint64_t mp, uint64_t mq) {
 }
 
 void account_profile(s4p_ctx* c, const DevCounters& d, bool fused) {
-  if (c->prof_events) {
+  if (c->prof_events) {                                    // per base
+    c->prof.verify_candidates += d.C; c->prof.verify_quads += std::min<uint64_t>(d.K, c->lane[c->cur].cap_quads); c->prof.verify_queries += uint64_t(d.C) * c->n_q;
+  }
+  if (c->prof_events && c->lane_group_n[c->cur] > 0) {     // per launch: the events belong to the first lane of a group launch
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, c->ev[c->cur][0], c->ev[c->cur][1]) == hipSuccess) {
-      c->prof.verify_launches++; c->prof.verify_ms_total += ms;
-      c->prof.verify_candidates += d.C; c->prof.verify_quads += std::min<uint64_t>(d.K, c->lane[c->cur].cap_quads); c->prof.verify_queries += uint64_t(d.C) * c->n_q;
-    }
+    if (hipEventElapsedTime(&ms, c->ev[c->cur][0], c->ev[c->cur][1]) == hipSuccess) { c->prof.verify_launches++; c->prof.verify_ms_total += ms; }
     if (fused && c->prof_stages) {
       if (hipEventElapsedTime(&ms, c->ev[c->cur][2], c->ev[c->cur][3]) == hipSuccess) { c->prof.pairs_ms_total += ms; c->prof.pairs_launches += 2; }
       if (hipEventElapsedTime(&ms, c->ev[c->cur][3], c->ev[c->cur][4]) == hipSuccess) { c->prof.quads_ms_total += ms; c->prof.quads_launches += 1; }
@@ -598,6 +668,7 @@ int32_t settle_borderline(s4p_ctx* c, DevCounters& d, const BaseFrame& bf) {
 
 int32_t launch_verify(s4p_ctx* c, const BaseFrame& bf);
 int32_t enqueue_result(s4p_ctx* c, const BaseFrame& bf);
+int32_t wait_lane(s4p_ctx* c, int li);
 
 // Records of the device pass that just finished on lane c->cur (d: its counters, after settle_borderline), in reference
 // order: verified candidates (count + row-major 4x4 of the centred frame) -> sink and/or `kept`; with want_quads also every
@@ -695,7 +766,7 @@ int32_t run_chunked(s4p_ctx* c, const DevCounters& first, s4p_base_result* r) {
     c->chunk_pass = false;
     if (vrc) return vrc;
     if (int32_t rc = enqueue_result(c, bf)) return rc;
-    HIPCHK(c, hipEventSynchronize(c->done[li]));
+    if (int32_t rc = wait_lane(c, li)) return rc;
     DevCounters d = *c->hctr[li].p;
     if (d.overflow & 4u) {
       if (rg.second - rg.first < 2u) S4P_FAIL(c, S4P_ERR_CAPACITY, "one pair has more congruent quads than max_quads: raise s4p_limits.max_quads");
@@ -729,33 +800,40 @@ int32_t run_chunked(s4p_ctx* c, const DevCounters& first, s4p_base_result* r) {
   return S4P_OK;
 }
 
-int32_t launch_base(s4p_ctx* c, int32_t slot, const int32_t* base_ids, float inv1, float inv2);
+int32_t prepare_base(s4p_ctx* c, int32_t slot, const int32_t* base_ids, float inv1, float inv2);
+int32_t flush_lanes(s4p_ctx* c, const int* lanes, int n, hipStream_t st);
 int32_t reset_counters(s4p_ctx* c);
 
 // The base of lane c->cur once more, after the lane's buffers have grown: same staged sequences (the staging slot is
-// recycled only after the wait has returned), same base points, same parameters.
+// recycled only after the wait has returned), same base points, same parameters -- alone, on the lane's own stream.
 int32_t relaunch_base(s4p_ctx* c) {
   s4p_ctx::Lane& L = c->lane[c->cur];
   float kx[12], kc[12];
   std::memcpy(kx, c->base_xyz, sizeof kx); std::memcpy(kc, c->base_rgb, sizeof kc);
   std::memcpy(c->base_xyz, L.sv_bx, sizeof kx); std::memcpy(c->base_rgb, L.sv_brgb, sizeof kc);
-  const int32_t rc = launch_base(c, L.sv_slot, L.sv_ids, L.sv_inv1, L.sv_inv2);
+  int32_t rc = prepare_base(c, L.sv_slot, L.sv_ids, L.sv_inv1, L.sv_inv2);
   std::memcpy(c->base_xyz, kx, sizeof kx); std::memcpy(c->base_rgb, kc, sizeof kc);
   if (rc) return rc;
-  HIPCHK(c, hipEventSynchronize(c->done[c->cur]));
-  return S4P_OK;
+  const int lane = c->cur;
+  if ((rc = flush_lanes(c, &lane, 1, L.stream)) != S4P_OK) return rc;
+  return wait_lane(c, lane);
 }
 
 // wait for slot c->cur and turn its counters into an s4p_base_result
 int32_t finish_result(s4p_ctx* c, s4p_base_result* r, bool fused) {
   { auto t0 = std::chrono::steady_clock::now();
-    HIPCHK(c, hipEventSynchronize(c->done[c->cur]));
-    c->host_wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+    const int32_t wrc = wait_lane(c, c->cur);
+    c->host_wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (wrc) return wrc; }
   const int li = c->cur;
   for (int attempt = 0;; ++attempt) {
     DevCounters d = *c->hctr[li].p;                        // (a copy: relaunches and chunk passes reuse the pinned record)
     const BaseFrame& bf = c->slot_bf[li];
     if (attempt == 0) account_profile(c, d, fused);
+    if (fused) {                                           // what the next launches size their k_prep / k_quads grids by: rises at once, decays slowly
+      c->est_m1 = std::max(d.m1, c->est_m1 - c->est_m1 / 16u);
+      c->est_m2 = std::max(d.m2, c->est_m2 - c->est_m2 / 16u);
+    }
     if (!d.overflow) {
       if (int32_t rc = settle_borderline(c, d, bf)) return rc;
       std::memset(r, 0, sizeof(*r));
@@ -789,45 +867,77 @@ int32_t finish_result(s4p_ctx* c, s4p_base_result* r, bool fused) {
   }
 }
 
-// The device pass of one base on lane c->cur: 2 uploads and 4 launches (k_pairs: both pair sets; k_prep: their
-// preparation; k_quads: enumeration + rigid transform + rms gate; k_verify: LCP of every candidate + winner + result record
-// + counters cleared for the lane's next base), then the read-back of the result record.
-int32_t launch_base(s4p_ctx* c, int32_t slot, const int32_t* base_ids, float inv1, float inv2) {
+// First half of a base's device pass, on lane c->cur: the parameter records of its four kernels (and the upload of its staged
+// sequences) into the lane's launch record.  Nothing is enqueued: the launch belongs to the base's GROUP (flush_lanes).
+int32_t prepare_base(s4p_ctx* c, int32_t slot, const int32_t* base_ids, float inv1, float inv2) {
   s4p_ctx::Lane& L = c->lane[c->cur];
+  s4p_ctx::LaunchRec& R = L.rec;
+  const float eps = 2.0f * c->opt.delta;
+  R.bf = make_base_frame(c, base_ids);
+  if (int32_t rc = quad_params(c, inv1, inv2, eps, R.p1, R.q)) return rc;
+  R.pp = PairParams2{};
+  fill_pair_params(c, slot, 0, eps, 0, 1, R.pp.set[0].pair);
+  fill_pair_params(c, slot, 1, eps, 2, 3, R.pp.set[1].pair);
+  const s4p_ctx::StageSlot& st = c->stage[slot];
+  R.up_src = st.blob.p; R.up_dst = L.seqbuf.p;
+  R.up_bytes = (size_t(st.off[1]) + s4p_ctx::StageSlot::set_words(st.n_seq[1], st.n_leaf[1])) * sizeof(uint32_t);      // both sets, one copy
+  R.q.do_gate = 1; R.q.gate = gate_params(c, R.bf);
+  R.q.slice_num = c->slice_num; R.q.slice_den = c->slice_den;
+  c->slot_q[c->cur] = R.q;                                // (the chunk loop relaunches it range by range if the quads do not fit)
+  c->slot_bf[c->cur] = R.bf;
+  return S4P_OK;
+}
+
+// The device pass of the prepared bases on lanes[0..n) as ONE chain on stream st: per base one upload, then four launches
+// that cover all of them (k_pairs2: both pair sets of every base; k_prep; k_quads: enumeration + rigid transform + rms gate;
+// k_verify: LCP of every candidate + winners + result records, counters cleared for the lanes' next bases), then every
+// lane's completion event.
+int32_t flush_lanes(s4p_ctx* c, const int* lanes, int n, hipStream_t st) {
   using lclk = std::chrono::steady_clock;
   lclk::time_point tp[8];
   auto lap = [&](int k) { if (c->trace_launch) tp[k] = lclk::now(); };
   lap(0);
-  if (L.dirty) { if (int32_t rc = reset_counters(c)) return rc; }
-  const float eps = 2.0f * c->opt.delta;
-  const BaseFrame bf = make_base_frame(c, base_ids);
-  PrepParams P1; QuadParams Q;
-  if (int32_t rc = quad_params(c, inv1, inv2, eps, P1, Q)) return rc;
-  if (c->prof_stages) HIPCHK(c, hipEventRecord(c->ev[c->cur][2], L.stream));
+  PairGroup PG{}; PrepGroup G1{}; QuadGroup GQ{};
+  for (int b = 0; b < n; ++b) {
+    s4p_ctx::Lane& L = c->lane[lanes[b]];
+    if (L.dirty) {                                         // a stage-level call left the live counters non-zero
+      hipLaunchKernelGGL(k_reset_counters, dim3(1), dim3(1), 0, st, L.ctr.p);
+      L.dirty = false;
+    }
+    PG.base[b] = L.rec.pp; G1.base[b] = L.rec.p1; GQ.base[b] = L.rec.q;
+    L.pending = false;
+  }
+  if (c->prof_stages) HIPCHK(c, hipEventRecord(c->ev[lanes[0]][2], st));
   lap(1);
-  { PairParams2 PP{};
-    if (int32_t rc = upload_pairs_staged(c, slot, 0, eps, 0, 1, PP.set[0].pair)) return rc;
-    if (int32_t rc = upload_pairs_staged(c, slot, 1, eps, 2, 3, PP.set[1].pair)) return rc;
-    lap(2);
-    if (int32_t rc = launch_pairs_kernel(c, PP, 2)) return rc; }
-  if (c->prof_stages) HIPCHK(c, hipEventRecord(c->ev[c->cur][3], L.stream));
+  for (int b = 0; b < n; ++b) {
+    const s4p_ctx::LaunchRec& R = c->lane[lanes[b]].rec;
+    if (R.up_bytes) HIPCHK(c, hipMemcpyAsync(R.up_dst, R.up_src, R.up_bytes, hipMemcpyHostToDevice, st));
+  }
+  lap(2);
+  if (int32_t rc = launch_pairs_kernel(c, PG, n, 2, st)) return rc;
+  if (c->prof_stages) HIPCHK(c, hipEventRecord(c->ev[lanes[0]][3], st));
   lap(3);
-  launch_prep_kernel(c, P1);
+  launch_prep_group(G1, n, st, c->est_m1);
   lap(4);
-  if (c->fuse_gate) { Q.do_gate = 1; Q.gate = gate_params(c, bf); }
-  Q.slice_num = c->slice_num; Q.slice_den = c->slice_den;
-  c->slot_q[c->cur] = Q;                                  // (the chunk loop relaunches it range by range if the quads do not fit)
-  launch_quads_kernel(c, Q);
-  if (!c->fuse_gate) launch_gate_kernel(c, gate_params(c, bf));
+  launch_quads_group(c, GQ, n, st, c->est_m2);
   HIPCHK(c, hipGetLastError());
-  if (c->prof_stages) HIPCHK(c, hipEventRecord(c->ev[c->cur][4], L.stream));
+  if (c->prof_stages) HIPCHK(c, hipEventRecord(c->ev[lanes[0]][4], st));
   lap(5);
-  if (int32_t rc = launch_verify(c, bf)) return rc;
+  if (int32_t rc = launch_verify_group(c, lanes, n, st)) return rc;
   lap(6);
-  const int32_t rc = enqueue_result(c, bf);
+  for (int b = 0; b < n; ++b) { HIPCHK(c, hipEventRecord(c->done[lanes[b]], st)); c->lane_group_n[lanes[b]] = (b == 0) ? n : 0; }
   lap(7);
-  if (c->trace_launch) { for (int k = 0; k < 7; ++k) c->lt[k] += std::chrono::duration<double>(tp[k + 1] - tp[k]).count(); c->lt_n++; }
-  return rc;
+  if (c->trace_launch) { for (int k = 0; k < 7; ++k) c->lt[k] += std::chrono::duration<double>(tp[k + 1] - tp[k]).count(); c->lt_n += uint64_t(n); c->lt_groups++; }
+  return S4P_OK;
+}
+
+// The pending bases of group g (consecutive lanes, oldest first) as one launch on the stream of the group's first lane.
+int32_t flush_group(s4p_ctx* c, int g) {
+  int lanes[kGroupMax]; int n = 0;
+  const int lo = g * c->group, hi = std::min(c->n_lanes, lo + c->group);
+  for (int li = lo; li < hi; ++li) if (c->lane[li].pending && n < kGroupMax) lanes[n++] = li;
+  if (n == 0) return S4P_OK;
+  return flush_lanes(c, lanes, n, c->lane[lo].stream);
 }
 
 int32_t fetch_result(s4p_ctx* c, const BaseFrame& bf, s4p_base_result* r) {
@@ -898,10 +1008,10 @@ int32_t s4p_create(const s4p_options* opt, const s4p_limits* lim, int32_t device
     if (c->ablate) fprintf(stderr, "super4pcs_amd: S4P_ABLATE=%d is set: k_verify skips work, every result of this context is invalid\n", c->ablate);
   }
   if (const char* vb = getenv("S4P_VERIFY_BLOCKS")) { const int v = atoi(vb); if (v >= 64 && v <= kVerifyMaxBlocks) { c->verify_blocks = uint32_t(v); c->verify_blocks_fixed = true; c->verify_blocks_env = true; } }   // tuning knob
-  if (const char* fu = getenv("S4P_FUSE_GATE")) c->fuse_gate = atoi(fu) != 0;
+  if (const char* gr = getenv("S4P_GROUP")) { const int v = atoi(gr); if (v >= 1 && v <= kGroupMax) c->group = v; }
   c->trace_launch = getenv("S4P_TRACE_LAUNCH") != nullptr;
-  if (const char* pv = getenv("S4P_PAIRS_V2")) c->pairs_v2 = atoi(pv) != 0;
-  if (const char* cs = getenv("S4P_CU_SPLIT")) { const int v = atoi(cs); if (v >= 2 && v <= 64) c->cu_split = v; }
+  c->debug = getenv("S4P_DEBUG") != nullptr;
+  if (const char* wt = getenv("S4P_WAIT_TIMEOUT_S")) { const double v = atof(wt); if (v > 0.0) c->wait_timeout_s = v; }
   if (const char* at = getenv("S4P_ANGLE_TOL")) { const float v = float(atof(at)); if (v > 1e-6f) c->angle_tol = v; }
   if (const char* qc = getenv("S4P_QUAD_GROW_CAP")) { const long long v = atoll(qc); if (v > 0 && v <= 0x7FFFFFFFll) c->quad_grow_cap = uint64_t(v); }
   snprintf(c->devname, sizeof c->devname, "%s (%s)", prop.name, prop.gcnArchName);
@@ -924,25 +1034,15 @@ int32_t s4p_create(const s4p_options* opt, const s4p_limits* lim, int32_t device
 #define A(buf, cnt) if ((e = (buf).alloc(cnt)) != hipSuccess) return fail(e, "hipMalloc " #buf)
   for (int li = 0; li < c->n_lanes; ++li) {
     s4p_ctx::Lane& L = c->lane[li];
-    if (c->cu_split > 1) {
-      const uint32_t ncu = uint32_t(prop.multiProcessorCount);
-      std::vector<uint32_t> small((ncu + 31) / 32, 0u), big((ncu + 31) / 32, 0u);
-      uint32_t nbig = 0;
-      for (uint32_t cu = 0; cu < ncu; ++cu) {
-        if (cu % uint32_t(c->cu_split) == uint32_t(c->cu_split) - 1u) small[cu >> 5] |= 1u << (cu & 31u);
-        else { big[cu >> 5] |= 1u << (cu & 31u); ++nbig; }
-      }
-      if ((e = hipExtStreamCreateWithCUMask(&L.stream, uint32_t(small.size()), small.data())) != hipSuccess) return fail(e, "hipExtStreamCreateWithCUMask");
-      if ((e = hipExtStreamCreateWithCUMask(&L.vstream, uint32_t(big.size()), big.data())) != hipSuccess) return fail(e, "hipExtStreamCreateWithCUMask");
-      if ((e = hipEventCreateWithFlags(&L.chain, hipEventDisableTiming)) != hipSuccess) return fail(e, "hipEventCreate");
-      if (!getenv("S4P_VERIFY_BLOCKS")) { c->verify_blocks = 2u * nbig; c->verify_blocks_fixed = true; }
-    } else if ((e = hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
+    if ((e = hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
     A(L.ctr, 2); A(L.slots, kVerifyMaxBlocks); A(L.border, kBorderCap);
     if ((e = hipMemset(L.ctr.p, 0, 2 * sizeof(DevCounters))) != hipSuccess) return fail(e, "hipMemset");
     const char* what = nullptr;
     if ((e = alloc_lane_buffers(c->max_pairs, c->max_quads, L, &what)) != hipSuccess) return fail(e, what);
     L.dirty = true;                                       // first use of a lane starts with an explicit clear (best_tag = ~0)
   }
+  A(c->group_done, s4p_ctx::kMaxLanes);
+  if ((e = hipMemset(c->group_done.p, 0, s4p_ctx::kMaxLanes * sizeof(uint32_t))) != hipSuccess) return fail(e, "hipMemset");
 #undef A
   for (int sl = 0; sl < s4p_ctx::kMaxLanes; ++sl) {
     if ((e = c->hctr[sl].alloc(1)) != hipSuccess) return fail(e, "hipHostMalloc");
@@ -995,7 +1095,6 @@ int32_t s4p_grow_limits(s4p_ctx* c, uint64_t min_pairs, uint64_t min_quads) {
   for (int li = 0; li < c->n_lanes; ++li) {
     s4p_ctx::Lane& L = c->lane[li];
     HIPCHK(c, hipStreamSynchronize(L.stream));
-    if (L.vstream) HIPCHK(c, hipStreamSynchronize(L.vstream));
     if (L.cap_pairs >= mp && L.cap_quads >= mq) continue;
     if (int32_t rc = grow_lane(c, li, std::max(mp, L.cap_pairs), std::max(mq, L.cap_quads))) return rc;
   }
@@ -1057,7 +1156,7 @@ int32_t s4p_get_limits(const s4p_ctx* c, s4p_limits* out) {
 void s4p_destroy(s4p_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  for (auto& L : c->lane) { if (L.stream) (void)hipStreamSynchronize(L.stream); if (L.vstream) (void)hipStreamSynchronize(L.vstream); }
+  for (auto& L : c->lane) if (L.stream) (void)hipStreamSynchronize(L.stream);
 #if S4P_CYCLE_PROF
   if (c->cyc.p) {
     unsigned long long v[16] = {0};
@@ -1079,18 +1178,19 @@ void s4p_destroy(s4p_ctx* c) {
   c->qnx.free(); c->qny.free(); c->qnz.free(); c->qcr.free(); c->qcg.free(); c->qcb.free();
   for (auto& L : c->lane) {
     L.free_all(); L.ctr.free(); L.slots.free(); L.border.free();
-    for (int s = 0; s < 2; ++s) L.seq[s].free();
+    L.seqbuf.free();
   }
   for (auto& h : c->hctr) h.free();
   for (auto& h : c->hmm) h.free();
-  for (auto& st : c->stage) for (int s = 0; s < 2; ++s) st.seq[s].free();
+  for (auto& st : c->stage) st.blob.free();
+  c->group_done.free();
   c->tbuf.free(); c->tpin.free();
   if (c->sel_stream) { (void)hipStreamSynchronize(c->sel_stream); (void)hipStreamDestroy(c->sel_stream); }
   c->p4o.free(); c->sel_draws.free(); c->sel_rec.free(); c->sel_hdraws.free(); c->sel_hrec.free();
   for (auto& e : c->tev) if (e) (void)hipEventDestroy(e);
   for (auto& row : c->ev) for (auto& ev : row) if (ev) (void)hipEventDestroy(ev);
   for (auto& ev : c->done) if (ev) (void)hipEventDestroy(ev);
-  for (auto& L : c->lane) { if (L.chain) (void)hipEventDestroy(L.chain); if (L.vstream) (void)hipStreamDestroy(L.vstream); if (L.stream) (void)hipStreamDestroy(L.stream); }
+  for (auto& L : c->lane) if (L.stream) (void)hipStreamDestroy(L.stream);
   delete c;
 }
 
@@ -1109,9 +1209,9 @@ int32_t s4p_verify_kernel_info(const s4p_ctx* c, char* buf, int32_t buflen) {
                                             : "k_verify<false, false, true> lean sweep (coarse-only, 16-bit queue entries), queries from global memory")
                              : (c->qlds ? "k_verify<false, true, false> fused/staged sweep, quantised queries in LDS" : "k_verify<false, false, false> fused/staged sweep, float queries from global memory");
   const char* full = c->qlds ? "k_verify<false, true, false>" : "k_verify<false, false, false>";
-  snprintf(buf, size_t(buflen), "with an early-exit bound: %s; full counts: %s (S4P_SWEEP_STAGED=%d, S4P_SWEEP_CHUNKS=%d, S4P_LEAN_MFMA=%d); %u x %d threads, %.1f KB LDS (lean) / %.1f KB (fused)",
-           loop, full, int(S4P_SWEEP_STAGED), int(S4P_SWEEP_CHUNKS), int(S4P_LEAN_MFMA), c->verify_blocks, c->verify_threads,
-           double(c->lean ? c->lean_lds_bytes() : 0) / 1024.0, double(c->verify_lds_bytes()) / 1024.0);
+  snprintf(buf, size_t(buflen), "with an early-exit bound: %s; full counts: %s; %u x %d threads, %.1f KB LDS (lean) / %.1f KB (fused); %d lanes in groups of %d bases per launch",
+           loop, full, c->verify_blocks, c->verify_threads,
+           double(c->lean ? c->lean_lds_bytes() : 0) / 1024.0, double(c->verify_lds_bytes()) / 1024.0, c->n_lanes, c->group);
   return S4P_OK;
 }
 
@@ -1305,10 +1405,9 @@ int32_t s4p_set_clouds(s4p_ctx* c, const float* px, const float* py, const float
   c->has_normals = (qnx && qny && qnz); c->has_rgb = (qr && qg && qb);
   if (c->has_normals) { HIPCHK(c, up(c->qnx, qnx)); HIPCHK(c, up(c->qny, qny)); HIPCHK(c, up(c->qnz, qnz)); }
   if (c->has_rgb) { HIPCHK(c, up(c->qcr, qr)); HIPCHK(c, up(c->qcg, qg)); HIPCHK(c, up(c->qcb, qb)); }
-  for (int s = 0; s < 2; ++s) {
-    for (auto& L : c->lane) HIPCHK(c, L.seq[s].alloc(s4p_ctx::StageSlot::blob_words(n_q)));
-    for (auto& st : c->stage) HIPCHK(c, st.seq[s].alloc(s4p_ctx::StageSlot::blob_words(n_q)));
-  }
+  for (int li = 0; li < c->n_lanes; ++li) HIPCHK(c, c->lane[li].seqbuf.alloc(2 * s4p_ctx::StageSlot::blob_words(n_q) + 16));      // both sets of a base
+  for (auto& st : c->stage) HIPCHK(c, st.blob.alloc(2 * s4p_ctx::StageSlot::blob_words(n_q) + 16));
+  c->est_m1 = c->est_m2 = 0u;                            // a new registration: no grid estimates yet
   c->clouds_set = true;
   c->set_clouds_s[2] = sc_since(sc_t2); c->set_clouds_s[3] = sc_since(sc_t0);
   return S4P_OK;
@@ -1526,14 +1625,14 @@ int32_t verify_transforms_impl(s4p_ctx* c, const float* T, int64_t B, uint32_t* 
   S4P_NEED_IDLE(c);
   HIPCHK(c, hipSetDevice(c->device));
   s4p_ctx::Lane& L = c->lane[c->cur];
-  hipStream_t st = L.vstream ? L.vstream : L.stream;          // (the big CU partition, if the context is partitioned)
+  hipStream_t st = L.stream;
   DevBuf<float> dT; DevBuf<uint32_t> dC;
   HIPCHK(c, dT.alloc(size_t(B) * 16));
   hipError_t e = dC.alloc(size_t(B));
   if (e != hipSuccess) { dT.free(); HIPCHK(c, e); }
   int32_t rc = S4P_OK;
   do {
-    if (stats4) { if ((rc = reset_counters(c)) != S4P_OK) break; L.dirty = true; if (L.vstream) (void)hipStreamSynchronize(L.stream); }
+    if (stats4) { if ((rc = reset_counters(c)) != S4P_OK) break; L.dirty = true; }
     if ((e = hipMemcpyAsync(dT.p, T, size_t(B) * 64, hipMemcpyHostToDevice, st)) != hipSuccess) break;
     VerifyTParams V{};
     V.grid = c->dev_grid(); V.q4 = c->q4v.p; V.qq = c->qq; V.n_q = c->n_q; V.T = dT.p; V.B = uint32_t(B);
@@ -1596,8 +1695,13 @@ int32_t s4p_try_base_staged_async(s4p_ctx* c, int32_t slot, const int32_t* base_
   L.sv_slot = slot; L.sv_inv1 = inv1; L.sv_inv2 = inv2; L.sv_gen = c->stage[slot].gen; L.sv_nseq1 = c->stage[slot].n_seq[0];
   for (int i = 0; i < 4; ++i) L.sv_ids[i] = base_ids[i];
   std::memcpy(L.sv_bx, c->base_xyz, sizeof L.sv_bx); std::memcpy(L.sv_brgb, c->base_rgb, sizeof L.sv_brgb);
-  if (int32_t rc = launch_base(c, slot, base_ids, inv1, inv2)) return rc;
+  if (int32_t rc = prepare_base(c, slot, base_ids, inv1, inv2)) return rc;
+  L.pending = true;
   c->q_tail++;
+  // the group goes to the device with its last base (the last lane of the group, or of the context); a wait for one of its
+  // bases launches it earlier with what it has (s4p_try_base_wait)
+  const int g = c->cur / c->group;
+  if (c->cur == std::min(c->n_lanes, (g + 1) * c->group) - 1) return flush_group(c, g);
   return S4P_OK;
 }
 
@@ -1617,6 +1721,7 @@ int32_t s4p_try_base_wait(s4p_ctx* c, s4p_base_result* result) {
   HIPCHK(c, hipSetDevice(c->device));
   c->cur = int(c->q_head % uint32_t(c->n_lanes));
   c->q_head++;
+  if (c->lane[c->cur].pending) if (int32_t rc = flush_group(c, c->cur / c->group)) return rc;      // its group was still filling up
   return finish_result(c, result, true);
 }
 

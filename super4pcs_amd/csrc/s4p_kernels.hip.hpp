@@ -22,6 +22,7 @@
 namespace s4p {
 
 constexpr uint32_t kNil = 0xFFFFFFFFu;
+constexpr int kGroupMax = 3;             // bases one launch of each kernel of a device pass may cover ("BASE GROUPS" below)
 constexpr uint32_t kGateFailed = 0xFFFFFFFFu;
 constexpr int kMaskWords = 11;   // 343 direction buckets (7^3) -> 11 x 32 bit
 constexpr int kMaxConeSamples = 56;
@@ -78,6 +79,9 @@ struct DevCounters {
   float best_T[16];
   float best_c2[3];
   uint32_t has_best;
+  // written LAST into a result record, after a system-scope fence: the number of the launch that produced it.  The result
+  // records live in pinned host memory (k_verify writes them there itself: no read-back copy), the host polls this word.
+  uint32_t seq;
 };
 
 // ---------------------------------------------------------------------------
@@ -111,32 +115,21 @@ struct LcpGrid {
 // The exact stage takes 128 queued queries at a time, two per lane, so that two point lists are in flight per lane (every
 // batch runs for as many dependent steps as its longest list; two lists per lane halve the steps per query: round 2,
 // k_verify 0.161 -> 0.151 ms alone); the sweep takes two chunks per step so that the queue fits the LDS budget.
-#ifndef S4P_SWEEP_CHUNKS
 // 64-query chunks a sweep step locates together, i.e. reach-word gathers in flight per lane before the first is consumed.  With
 // the early exit the sweep is most of the kernel and a wave spends it waiting on one dependent chain per step (LDS query ->
 // LDS bitmap word -> 8-byte gather) with three waves per SIMD to hide it: 4 chunks per step against 2, same box
 // (tools/r3_run15.sh): k_verify alone 0.0967 -> 0.0863 ms, 121.6 -> 125.1 M candidates/s; every candidate counted in full
 // (no early exit: the exact stage dominates again) 83.5 -> 81.0 M.  The same change cut 12 of 118 vector instructions per step
 // (packed locate, direct ballots) and that alone moved nothing (tools/r3_run14.sh): the sweep waits, it does not compute.
-#define S4P_SWEEP_CHUNKS 4
-#endif
-constexpr uint32_t kSweepChunks = S4P_SWEEP_CHUNKS;
+constexpr uint32_t kSweepChunks = 4;
 constexpr uint32_t kSweepStep = 64u * kSweepChunks;             // queries per sweep step; the LDS query copy is padded to a multiple of it
 static_assert(kSweepChunks == 2 || kSweepChunks == 4 || kSweepChunks == 8, "sweep steps of 2, 4 or 8 chunks");
-// S4P_SWEEP_STAGED=1 (build option, UNMEASURED -- DESIGN.md section 9 item 1): the sweep touches LDS only (locate + coarse
-// bitmap) and queues the L0 survivors; the reach-word gather runs later, on the queued entries, and only for candidates the
-// early exit has not dismissed by then.  The queue then holds both kinds of entries and is larger.
-#ifndef S4P_SWEEP_STAGED
-#define S4P_SWEEP_STAGED 2
-#endif
-#if S4P_SWEEP_STAGED
+// Queue of the fused / staged sweeps (wave_lcp_count, wave_lcp_count_staged).  The staged sweep touches LDS only (locate +
+// coarse bitmap) and queues the L0 survivors; the reach-word gather runs later, on the queued entries, and only for candidates
+// the early exit has not dismissed by then: the queue holds both kinds of entries.
 constexpr int kQueueEntries = 512 + int(kSweepStep);            // reach-tested entries below, L0 survivors of the sweep above them
 constexpr uint32_t kQueueHold = 512;              // the queue is drained (reach test, then exact batches) once more than this many wait
 constexpr uint32_t kExactHold = 256;              // ... down to this many reach-tested entries
-#else
-constexpr int kQueueEntries = 256 + int(kSweepStep);            // per-wave survivor queue: up to 256 waiting + one sweep step
-constexpr uint32_t kQueueHold = 256;              // an exact batch only runs once more than this many wait (or the sweep is over)
-#endif
 constexpr int kQueueWordsPerWave = kQueueEntries + kQueueEntries / 2;     // 32-bit rank + 16-bit query index per entry: 3 KB
 constexpr int kCoarseMaxWords = 9216;              // 36 KB (two k_verify workgroups per CU share 160 KB: 80 KB each)
 // LDS per k_verify workgroup: coarse bitmap + survivor queues (3 KB per wave) [+ quantised queries].  Two workgroups per CU
@@ -695,7 +688,6 @@ __device__ __forceinline__ uint32_t wave_lcp_count(const LcpGrid& g, const LcpTa
   return cnt;                                            // wave-uniform
 }
 
-#if S4P_SWEEP_STAGED
 // The same count with a sweep that stays inside the CU.  Queue layout: [0, nb) entries that passed the reach test {rank of the
 // cell among the reachable ones, query}, [nb, nb + na) L0 survivors of the sweep {cell, query}.
 //   sweep step: locate, coarse bitmap, compaction of the L0 survivors -- no global access;
@@ -804,22 +796,15 @@ __device__ __forceinline__ uint32_t wave_lcp_count_staged(const LcpGrid& g, cons
   __builtin_amdgcn_wave_barrier();
   return cnt;
 }
-// With the exit off every candidate pays for all stages and the fused sweep is ahead again (86.4 vs 89.7 M candidates/s,
-// tools/r3_run18.sh): S4P_SWEEP_STAGED=2 picks per candidate -- staged when a bound is in force, fused otherwise (unmeasured).
+// With the exit off every candidate pays for all stages and the fused sweep is ahead again (86.4 vs 89.7 M candidates/s, round 3):
+// picked per candidate -- staged when a bound is in force, fused otherwise.  (Round 5: the builds that fixed one of the two,
+// -DS4P_SWEEP_STAGED=0/1, and the MFMA locate of the lean sweep, -DS4P_LEAN_MFMA=1, are gone; profiles/HISTORY.md has their numbers.)
 template <bool COUNT, bool SKIP_FINE, bool QLDS>
 __device__ __forceinline__ uint32_t wave_lcp_count_auto(const LcpGrid& g, const LcpTask& K, const uint32_t* s_coarse, const uint2* s_q,
                                                         uint32_t* s_queue, const float4* Tsrc) {
   if (K.prune != 0u) return wave_lcp_count_staged<COUNT, SKIP_FINE, QLDS>(g, K, s_coarse, s_q, s_queue, Tsrc);      // wave-uniform
   return wave_lcp_count<COUNT, SKIP_FINE, QLDS>(g, K, s_coarse, s_q, s_queue, Tsrc);
 }
-#if S4P_SWEEP_STAGED == 2
-#define S4P_WAVE_LCP_COUNT wave_lcp_count_auto
-#else
-#define S4P_WAVE_LCP_COUNT wave_lcp_count_staged
-#endif
-#else
-#define S4P_WAVE_LCP_COUNT wave_lcp_count
-#endif
 
 // ---------------------------------------------------------------------------
 // The LEAN sweep: what k_verify runs when an early-exit bound is in force (LcpTask::prune > 0), i.e. inside the trial loops,
@@ -840,13 +825,7 @@ __device__ __forceinline__ uint32_t wave_lcp_count_auto(const LcpGrid& g, const 
 // Padding queries (index >= n_q) sit at 1e18: a rigid transform sends them outside the grid on at least one axis, so the
 // sweep needs no index test.
 // ---------------------------------------------------------------------------
-#ifndef S4P_LEAN_QUEUE
-#define S4P_LEAN_QUEUE 768
-#endif
-#ifndef S4P_LEAN_MFMA
-#define S4P_LEAN_MFMA 0
-#endif
-constexpr uint32_t kLeanQueue = S4P_LEAN_QUEUE;            // entries per wave (2 B each)
+constexpr uint32_t kLeanQueue = 768;                       // entries per wave (2 B each)
 static_assert(kLeanQueue >= 2u * kSweepStep + 128u && kLeanQueue % 64u == 0u, "lean queue: two sweep steps + one exact batch");
 constexpr float kLeanPad = 1.0e18f;                        // coordinates of the padding queries
 constexpr int kLeanMaxQueries = 2560;                      // sampled-Q points the float LDS copy takes (30 KB)
@@ -936,20 +915,9 @@ __device__ __forceinline__ uint32_t wave_lcp_count_lean(const LcpGrid& g, const 
   const uint32_t ucx = uint32_t(g.cnx), ucy = uint32_t(g.cny);
   const uint32_t mx = ucx - 1u, my = ucy - 1u, mz = uint32_t(((g.nz - 1) >> g.cshift) + 1);
   // locating transform in coarse units (exact power-of-two scaling of the grid-unit transform)
-#if S4P_LEAN_MFMA
-  float a0, a1, a2; f4_t c0;
-  { const float T[12] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w, t2.x, t2.y, t2.z, t2.w};
-    const GridXf Xc = make_grid_xf(g, T, coarse_scale(g));
-    const uint32_t r = lane & 3u;                          // A operand: lane (block, r) holds row r of the column
-    a0 = r == 0u ? Xc.u[0] : (r == 1u ? Xc.u[4] : (r == 2u ? Xc.u[8] : 0.f));
-    a1 = r == 0u ? Xc.u[1] : (r == 1u ? Xc.u[5] : (r == 2u ? Xc.u[9] : 0.f));
-    a2 = r == 0u ? Xc.u[2] : (r == 1u ? Xc.u[6] : (r == 2u ? Xc.u[10] : 0.f));
-    c0 = f4_t{Xc.u[3], Xc.u[7], Xc.u[11], 0.f}; }
-#else
   GridXf Xc;
   { const float T[12] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w, t2.x, t2.y, t2.z, t2.w};
     Xc = make_grid_xf(g, T, coarse_scale(g)); }
-#endif
   typedef const __attribute__((address_space(3))) uint32_t* lds_u32_ptr;
   const uint32_t coarse_base = uint32_t(uintptr_t((lds_u32_ptr)L.coarse));      // byte address of the bitmap inside LDS (0 in k_verify)
   auto lds_fence = [&]() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); };
@@ -1009,21 +977,9 @@ __device__ __forceinline__ uint32_t wave_lcp_count_lean(const LcpGrid& g, const 
 #pragma unroll
       for (uint32_t k = 0; k < kSweepChunks; ++k) { ii[k] = base + 64u * k + lane; const float4 p = lean_query<QL>(K, L, ii[k]); x[k] = p.x; y[k] = p.y; z[k] = p.z; }
       int cx[kSweepChunks], cy[kSweepChunks], cz[kSweepChunks];
-#if S4P_LEAN_MFMA
-      f4_t d[kSweepChunks];
-#pragma unroll
-      for (uint32_t k = 0; k < kSweepChunks; ++k) d[k] = __builtin_amdgcn_mfma_f32_4x4x1f32(a0, x[k], c0, 0, 0, 0);
-#pragma unroll
-      for (uint32_t k = 0; k < kSweepChunks; ++k) d[k] = __builtin_amdgcn_mfma_f32_4x4x1f32(a1, y[k], d[k], 0, 0, 0);
-#pragma unroll
-      for (uint32_t k = 0; k < kSweepChunks; ++k) d[k] = __builtin_amdgcn_mfma_f32_4x4x1f32(a2, z[k], d[k], 0, 0, 0);
-#pragma unroll
-      for (uint32_t k = 0; k < kSweepChunks; ++k) { cx[k] = floor_to_int(d[k][0]); cy[k] = floor_to_int(d[k][1]); cz[k] = floor_to_int(d[k][2]); }
-#else
 #pragma unroll
       for (uint32_t k = 0; k < kSweepChunks; k += 2u)
         grid_cell2(Xc.u, make_float4(x[k], y[k], z[k], 0.f), make_float4(x[k + 1u], y[k + 1u], z[k + 1u], 0.f), cx[k], cy[k], cz[k], cx[k + 1u], cy[k + 1u], cz[k + 1u]);
-#endif
 #pragma unroll
       for (uint32_t k = 0; k < kSweepChunks; ++k) {
         // the bitmap has one more (empty) cube per axis: a coordinate outside the grid on either side clamps onto it
@@ -1383,7 +1339,9 @@ __device__ __forceinline__ void cone_mask_row(const ConeTable& cone, const float
 
 // Preparation of set 1 (one thread per pair): invariant point, cell, direction bucket, world point, hash insert.  Set 2 is
 // prepared where it is consumed (k_quads): only the pairs whose cell holds a set-1 pair need their world point and cone mask.
-__global__ __launch_bounds__(256) void k_prep(PrepParams P) {
+struct PrepGroup { PrepParams base[kGroupMax]; };
+__global__ __launch_bounds__(256) void k_prep(PrepGroup PG) {
+  const PrepParams& P = PG.base[blockIdx.y];
   const uint32_t m = min(*P.m_dev, P.cap);
   for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < m; e += gridDim.x * blockDim.x) prep1_item(P, e, P.ab[e]);
 }
@@ -1497,145 +1455,19 @@ __device__ __forceinline__ bool pair_filters_w(const PairParams& P, const uint32
   return acc;
 }
 
-constexpr int kPairStageW = 192;   // accepted (pId, j, slot) per wave between two flushes (12 B each)
-constexpr int kPairWaves = 4;      // waves per workgroup
-
 struct PairSet { PairParams pair; };
 struct PairParams2 { PairSet set[2]; };
 
-// The two pair sets of a base are independent: one launch, blockIdx.y picks the set (gridDim.y = 1 for a single set).
-// ANGLE (options.max_angle > 0): the two ordered pairs of an accepted (i, j) are emitted independently, so the stage holds
-// ORDERED pairs (bit 31 of the slot word = the second of the two) instead of unordered ones.
-template <bool ANGLE>
-__global__ __launch_bounds__(64 * kPairWaves) void k_pairs(PairParams2 PP) {
-  const PairParams& P = PP.set[blockIdx.y].pair;
-  __shared__ uint32_t st_j[kPairWaves][kPairStageW];
-  __shared__ uint32_t st_s[kPairWaves][kPairStageW];
-  __shared__ uint32_t st_p[kPairWaves][kPairStageW];
-  __shared__ uint32_t s_cnt[kPairWaves], s_base;
-  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  uint32_t n_st = 0;                                     // staged entries of this wave (wave-uniform)
-  // writes the wave's n_st staged entries at pair positions base, base + 2, ...: two ordered pairs per entry, one
-  // pair per lane
-  auto write_out = [&](const uint32_t base) {
-    for (uint32_t pe = lane; pe < (ANGLE ? n_st : 2u * n_st); pe += 64u) {
-      const uint32_t e = ANGLE ? pe : pe >> 1, second = ANGLE ? st_s[wave][e] >> 31 : pe & 1u;
-      const uint32_t at = base + pe;
-      if ((ANGLE ? at : (at | 1u)) < P.cap) {              // both pairs of an entry fit, or neither is written
-        const uint32_t j = st_j[wave][e], pId = st_p[wave][e];
-        const uint32_t ok = 2u * (pId * P.n_seq + (st_s[wave][e] & 0x7FFFFFFFu)) + second;
-        // pairs->emplace_back(j, i) then pairs->emplace_back(i, j)   pairCreationFunctor.h:214-215
-        const int2 pr = second ? make_int2(int(pId), int(j)) : make_int2(int(j), int(pId));
-        P.ab[at] = pr; P.okey[at] = ok;
-      } else {
-        atomicOr(P.overflow, P.overflow_bit);
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-  };
-  // work item = (primitive, part): a primitive's leaf tiles are dealt out to `split` waves, so that a 2000-point sample
-  // puts ~8000 short waves on the chip instead of 2000 long ones (the walk is a chain of dependent L2 gathers); the
-  // emission order is carried by the order keys, not by who appends first
-  const uint32_t gw = blockIdx.x * kPairWaves + wave, nw = gridDim.x * kPairWaves;
-  for (uint32_t item = gw; item < P.n_q * P.split; item += nw) {
-    const uint32_t pId = item / P.split, part = item - pId * P.split;
-    const float cx = P.ux[pId], cy = P.uy[pId], cz = P.uz[pId];
-    const float wxi = P.qx[pId], wyi = P.qy[pId], wzi = P.qz[pId];
-    for (uint32_t tile = part * 64u; tile < P.n_leaf; tile += 64u * P.split) {
-      const uint32_t l = tile + lane;
-      uint32_t beg = 0, len = 0;
-      if (l < P.n_leaf && sphere_box(cx, cy, cz, P.nRadius, P.leaves[l])) {     // intersect, intersectionPrimitive.h:117-142
-        beg = P.leaf_off[l];
-        len = P.leaf_off[l + 1u] - beg;
-      }
-      uint32_t incl = len;                               // inclusive prefix of the touched leaves' sizes
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t up = uint32_t(__shfl_up(int(incl), o));
-        if (lane >= uint32_t(o)) incl += up;
-      }
-      const uint32_t total = uint32_t(__builtin_amdgcn_readlane(int(incl), 63));
-      for (uint32_t base = 0; base < total; base += 64u) {
-        const uint32_t t = base + lane;                  // this lane's (leaf, point) slot
-        uint32_t lo = 0u, hi = 63u;                      // owner leaf: first lane whose inclusive prefix exceeds t
-#pragma unroll
-        for (int it = 0; it < 6; ++it) {
-          const uint32_t mid = (lo + hi) >> 1;
-          const uint32_t v = uint32_t(__shfl(int(incl), int(mid)));
-          if (v <= t) lo = mid + 1u; else hi = mid;
-        }
-        const uint32_t owner = min(lo, 63u);
-        const uint32_t o_incl = uint32_t(__shfl(int(incl), int(owner)));
-        const uint32_t o_len = uint32_t(__shfl(int(len), int(owner)));
-        const uint32_t o_beg = uint32_t(__shfl(int(beg), int(owner)));
-        bool acc = false;
-        uint32_t j = 0, s = 0;
-        if (t < total) {
-          s = o_beg + (t - (o_incl - o_len));
-          j = P.seq_id[s] & 0xFFFFu;                                              // (upper half: the slot's leaf, for k_pairs2)
-          if (pId > j) {                                                          // intersectionFunctor.h:210
-            const float dx = P.ux[j] - cx, dy = P.uy[j] - cy, dz = P.uz[j] - cz;
-            const float d = sqrtf(sqn3(dx, dy, dz)) - P.nRadius;
-            if (d * d < P.eps_unit * P.eps_unit)                                  // intersectPoint, intersectionPrimitive.h:154-157
-              acc = pair_filters(P, pId, j, wxi, wyi, wzi);
-          }
-        }
-        bool emit_a = acc, emit_b = false;                // ANGLE: (j,i) / (i,j) separately
-        if (ANGLE) {
-          emit_a = false;
-          if (acc) {                                        // pairCreationFunctor.h:203-212
-            float sx = wxi - P.qx[j], sy = wyi - P.qy[j], sz = wzi - P.qz[j];     // segment2 = (q.pos() - p.pos()).normalized()
-            normalize3(sx, sy, sz);
-            const float d = dot3(P.seg1[0], P.seg1[1], P.seg1[2], sx, sy, sz), nd = -d;   // segment1.dot(-segment2) == -d exactly
-            emit_a = d >= P.cos_min && d <= 1.f;
-            emit_b = nd >= P.cos_min && nd <= 1.f;
-          }
-        }
-        const unsigned long long m = __ballot(emit_a);
-        const unsigned long long mb = ANGLE ? __ballot(emit_b) : 0ull;
-        if ((m | mb) != 0ull) {
-          if (emit_a) {
-            const uint32_t e = n_st + __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u));
-            st_j[wave][e] = j; st_s[wave][e] = s; st_p[wave][e] = pId;
-          }
-          n_st += uint32_t(__popcll(m));
-          if (ANGLE) {
-            if (emit_b) {
-              const uint32_t e = n_st + __builtin_amdgcn_mbcnt_hi(uint32_t(mb >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mb), 0u));
-              st_j[wave][e] = j; st_s[wave][e] = s | 0x80000000u; st_p[wave][e] = pId;
-            }
-            n_st += uint32_t(__popcll(mb));
-          }
-          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-          __builtin_amdgcn_wave_barrier();
-          if (n_st + (ANGLE ? 128u : 64u) > uint32_t(kPairStageW)) {      // stage full before the end: this wave appends on its own
-            uint32_t b = 0;
-            if (lane == 0) b = atomicAdd(P.counter, ANGLE ? n_st : 2u * n_st);
-            b = uint32_t(__builtin_amdgcn_readfirstlane(int(b)));
-            write_out(b);
-            n_st = 0;
-          }
-        }
-      }
-    }
-  }
-  // end of the workgroup's primitives: ONE global atomic for the four waves' leftovers
-  if (lane == 0) s_cnt[wave] = n_st;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t tot = 0;
-    for (int w = 0; w < kPairWaves; ++w) tot += s_cnt[w];
-    s_base = tot ? atomicAdd(P.counter, ANGLE ? tot : 2u * tot) : 0u;
-  }
-  __syncthreads();
-  uint32_t before = 0;
-  for (uint32_t w = 0; w < wave; ++w) before += s_cnt[w];
-  if (n_st) write_out(s_base + (ANGLE ? before : 2u * before));
-}
+// BASE GROUPS (round 5).  Every kernel of a base's device pass takes the parameter records of up to kGroupMax bases and one
+// launch covers them all: blockIdx.y picks the base (k_pairs2: base and pair set), k_verify walks the candidate lists of all
+// of them with ONE staging of its LDS tables.  The kernels of one base are a chain of short, latency-bound launches (21 + 14 +
+// 55 + 62 us alone, most of it fixed cost: k_pairs2 takes 29 us whatever the base, k_verify 30 us + 1.9 ns per candidate,
+// profiles/r05_verify_vs_candidates.json); a launch that covers three bases pays those fixed costs once.  The records travel
+// by value in the kernel argument segment (3 x QuadParams = 3.2 KB of the 4 KB it holds: kGroupMax = 3).
+struct PairGroup { PairParams2 base[kGroupMax]; };
 
 // ---------------------------------------------------------------------------
-// k_pairs2: the same loop 2, TRANSPOSED (round 4).  k_pairs walks (primitive -> touched leaves -> their points) with one
+// k_pairs2: loop 2 TRANSPOSED (round 4).  Round 3's k_pairs walked (primitive -> touched leaves -> their points) with one
 // wave per primitive: every round of 64 point slots pays a 6-step cross-lane binary search for the owning leaf and two
 // dependent gathers (slot -> id -> coordinates), ~1.5 us of latency per round.  Here a wave owns a TILE of 64 primitives
 // (lane = primitive, its centre in registers) times a CHUNK of 64 consecutive point slots of the leaf-major sequence: the
@@ -1658,8 +1490,8 @@ constexpr int kPair2StageW = 256;   // staged accepted (primitive, slot) per wav
 constexpr int kPair2Queue = 128;    // queued (lane, slot-in-chunk) candidates per wave: a batch of 64 runs when 64 wait
 
 template <bool ANGLE>
-__global__ __launch_bounds__(64 * kPair2Waves) void k_pairs2(PairParams2 PP) {
-  const PairParams& P = PP.set[blockIdx.y].pair;
+__global__ __launch_bounds__(64 * kPair2Waves) void k_pairs2(PairGroup PG) {
+  const PairParams& P = PG.base[blockIdx.y >> 1].set[blockIdx.y & 1u].pair;      // blockIdx.y = 2 * base + pair set
   __shared__ uint32_t st_e[kPair2Waves][kPair2StageW];   // primitive | slot << 16
   __shared__ uint8_t st_f[kPair2Waves][ANGLE ? kPair2StageW : 4];   // ANGLE: 1 = the second of the two ordered pairs
   __shared__ uint16_t s_qc[kPair2Waves][kPair2Queue];    // candidate queue: lane | k << 6
@@ -1877,10 +1709,7 @@ struct QuadParams {
   int do_gate; GateParams gate;                          // fused path: gate every quad as it is appended
 };
 
-#ifndef S4P_QUAD_STAGE
-#define S4P_QUAD_STAGE 512           // 23 KB of LDS per workgroup: fits next to two resident k_verify workgroups (48 KB at 1536 did not)
-#endif
-constexpr int kQuadStage = S4P_QUAD_STAGE;   // quads per workgroup between two flushes (24 B each)
+constexpr int kQuadStage = 512;      // quads per workgroup between two flushes (24 B each): 23 KB of LDS per workgroup, fits next to two resident k_verify workgroups (48 KB at 1536 did not)
 
 // One thread per pairs2 entry: hash lookup of its euclidean cell, walk of the set-1 chain (super4pcs.cc:151-163).
 // Matches are staged in LDS and flushed with one global atomic per workgroup round; on the fused path the flush also
@@ -1896,8 +1725,10 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
   return v;
 }
 
+struct QuadGroup { QuadParams base[kGroupMax]; };
 template <bool ANGLE>
-__global__ __launch_bounds__(256) void k_quads(QuadParams P) {
+__global__ __launch_bounds__(256) void k_quads(QuadGroup QG) {
+  const QuadParams& P = QG.base[blockIdx.y];
   __shared__ int4 st_q[kQuadStage];
   __shared__ unsigned long long st_t[kQuadStage];
   __shared__ unsigned long long st_base, s_qsum, s_csum;
@@ -2056,6 +1887,15 @@ __global__ __launch_bounds__(256) void k_quads(QuadParams P) {
 constexpr int kVerifyMaxThreads = 1024;
 constexpr int kVerifyThreadsCached = 768;
 constexpr int kVerifyMaxBlocks = 4096;
+struct VerifyBase {                                     // one base of the launch
+  BaseFrame base;
+  const int4* quads; const unsigned long long* tags; uint32_t* counts;
+  const uint32_t* cand_idx; const float4* cand_T;       // gated candidates: quad index + 3x4 transform
+  DevCounters* ctr;                                     // live counters of the base (reset by the last workgroup)
+  DevCounters* res;                                     // result record of the base: pinned host memory, written by the last workgroup
+  uint4* slots;                                         // per workgroup: {best count, its candidate, tag lo, tag hi}
+  uint32_t* border;                                     // candidates (positions in cand_idx) with an undecided gate, kBorderCap entries
+};
 struct VerifyParams {
   LcpGrid grid;
   const float4* q4;                                     // sampled Q (centred), packed (x,y,z,0), original order (quad indices)
@@ -2063,13 +1903,9 @@ struct VerifyParams {
   QuantQ qq;                                            // ... and their 16-bit quantisation (QLDS kernels)
   const float* qsoa;                                    // ... and as x[n_pad] | y[n_pad] | z[n_pad], padded with kLeanPad (LEAN kernels)
   uint32_t n_q;
-  BaseFrame base;
-  const int4* quads; const unsigned long long* tags; uint32_t* counts;
-  const uint32_t* cand_idx; const float4* cand_T;       // gated candidates: quad index + 3x4 transform
-  DevCounters* ctr;                                     // live counters of the base (reset by the last workgroup)
-  DevCounters* res;                                     // result record of the base (copied to the host)
-  uint4* slots;                                         // per workgroup: {best count, its candidate, tag lo, tag hi}
-  uint32_t* border;                                     // candidates (positions in cand_idx) with an undecided gate, kBorderCap entries
+  VerifyBase b[kGroupMax]; uint32_t n_bases;            // the bases of this launch (1 .. kGroupMax)
+  uint32_t* group_done;                                 // workgroups that have published their bests (the last one selects the winners); left at 0
+  uint32_t seq;                                         // launch number, written last into every result record
   uint32_t prune;                                       // best inlier count of the registration at launch (LcpTask::prune), 0 = count every candidate in full
   unsigned long long* cyc;                              // S4P_CYCLE_PROF builds: 16 accumulators (see k_verify), else unused
   int count_tests;                                      // instrumentation counters are live: carry them into res
@@ -2077,21 +1913,41 @@ struct VerifyParams {
 };
 
 struct VerifyShared {                                   // k_verify's workgroup scalars, at the end of its dynamic LDS
-  unsigned long long wtag[kVerifyMaxThreads / 64];
-  uint32_t wcnt[kVerifyMaxThreads / 64], wcand[kVerifyMaxThreads / 64];
-  uint32_t next, last, pruned, pad;
+  unsigned long long wtag[kGroupMax][kVerifyMaxThreads / 64];
+  uint32_t wcnt[kGroupMax][kVerifyMaxThreads / 64], wcand[kGroupMax][kVerifyMaxThreads / 64];
+  uint32_t pruned[kGroupMax];
+  uint32_t end[kGroupMax];                              // end of base b's tickets in this workgroup's ticket space
+  uint32_t next, last;
 };
 
 // better(a, b): a wins over b if its count is greater, or equal with a smaller tag (= earlier in reference order)
 __device__ __forceinline__ bool slot_better(const uint32_t ca, const unsigned long long ta, const uint32_t cb, const unsigned long long tb, const bool b_valid) {
   return !b_valid || ca > cb || (ca == cb && ta < tb);
 }
+struct WaveBest { uint32_t c, i; unsigned long long t; };      // (count, candidate, tag); i == kNil: none yet
+
+// One ticket from an LDS counter for the whole wave: lane 0 alone performs the add (exec is narrowed around the ONE
+// instruction, inside the asm statement), every lane gets the old value.  No lane-dependent control flow the compiler can
+// see or move: an `if (lane == 0)` around the atomic lets it thread lane 0's path through a loop's back edge (k_verify),
+// and an all-lanes atomicAdd(lane == 0 ? 1 : 0) is turned into a 64-step scalar scan per ticket.
+__device__ __forceinline__ uint32_t wave_ticket(uint32_t* counter) {
+  typedef __attribute__((address_space(3))) uint32_t* lds_ptr;
+  const uint32_t addr = uint32_t(uintptr_t((lds_ptr)counter));
+  uint32_t r; unsigned long long saved;
+  asm volatile("s_mov_b64 %1, exec\n\ts_mov_b64 exec, 1\n\tds_add_rtn_u32 %0, %2, %3\n\ts_waitcnt lgkmcnt(0)\n\ts_mov_b64 exec, %1"
+               : "=&v"(r), "=&s"(saved) : "v"(addr), "v"(1u) : "memory");
+  return uint32_t(__builtin_amdgcn_readfirstlane(int(r)));
+}
 
 // LEAN (launched when an early-exit bound is in force): wave_lcp_count_lean, LDS = coarse bitmap | float queries x, y, z (QLDS:
 // the sample fits) | one 16-bit queue per wave.  Without QLDS the lean sweep reads the queries from the padded float4 array in
 // global memory (VerifyParams::q4v holds n_pad entries): the 20 000-point sample.
+// One launch scores the candidate lists of up to kGroupMax bases: the LDS tables (58 KB per workgroup) are staged once, the
+// waves draw candidates from ONE ticket counter over the workgroup's shares of all lists (a heavy candidate of one base
+// overlaps the cheap ones of the others), every wave keeps one best per base, and the last workgroup to finish writes one
+// result record per base.
 template <bool COUNT, bool QLDS, bool LEAN>
-__global__ __launch_bounds__(kVerifyMaxThreads, 6) void k_verify(VerifyParams P) {   // <= 80 VGPRs: six waves per SIMD, i.e. two 768-thread workgroups per CU (of one launch, or of two lanes)
+__global__ __launch_bounds__(kVerifyMaxThreads, 6) void k_verify(VerifyParams P) {   // <= 80 VGPRs: six waves per SIMD, i.e. two 768-thread workgroups per CU (of one launch, or of two)
   extern __shared__ uint32_t s_mem[];
   uint32_t* s_coarse = s_mem;                              // LDS: coarse bitmap | quantised queries (QLDS) | 16 survivor queues
   uint2* s_q = reinterpret_cast<uint2*>(s_mem + P.grid.coarse_words);
@@ -2108,30 +1964,44 @@ __global__ __launch_bounds__(kVerifyMaxThreads, 6) void k_verify(VerifyParams P)
   VerifyShared& S = *reinterpret_cast<VerifyShared*>(LEAN
       ? reinterpret_cast<uint32_t*>(reinterpret_cast<uint16_t*>(s_mem + P.grid.coarse_words + lean_q_words) + (blockDim.x >> 6) * kLeanQueue)
       : reinterpret_cast<uint32_t*>(s_q + (QLDS ? n_pad : 0u)) + (blockDim.x >> 6) * kQueueWordsPerWave);
-  uint32_t& s_next = S.next; uint32_t& s_last = S.last; uint32_t& s_pruned = S.pruned;
-  uint32_t* s_wcnt = S.wcnt; uint32_t* s_wcand = S.wcand; unsigned long long* s_wtag = S.wtag;
+  uint32_t& s_next = S.next; uint32_t& s_last = S.last;
   const unsigned long long cyc_entry = S4P_CYC_NOW();
   unsigned long long cyc_staged = cyc_entry, cyc_loop_end = cyc_entry, cyc_wait = 0ull;
   uint32_t n_cand = 0;
   CycleProf CP{0ull, 0ull, 0ull, 0u, 0u};
   (void)cyc_staged; (void)cyc_loop_end; (void)cyc_wait; (void)n_cand;
-  const uint32_t C = P.ctr->C;
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  // Work split: every workgroup owns a fixed share of the gated candidate list (static: a single-address global cursor
-  // caps at ~90 dequeues/us, MI355X_MICROARCH "dequeue"); inside the share its waves take candidates from an LDS
+  const uint32_t nb = P.n_bases;
+  // Work split: every workgroup owns a fixed share of every base's gated candidate list (static: a single-address global
+  // cursor caps at ~90 dequeues/us, MI355X_MICROARCH "dequeue"); inside the shares its waves take candidates from an LDS
   // counter, so a wave that drew cheap candidates (few L0 survivors) simply takes more.
-  // Share of this workgroup: candidates blockIdx.x, blockIdx.x + gridDim.x, ...  Neighbours in the candidate order are
-  // neighbours in quad order and cost about the same, so contiguous slices made some workgroups consistently slower than
+  // Share of this workgroup in a list: candidates blockIdx.x, blockIdx.x + gridDim.x, ...  Neighbours in the candidate order
+  // are neighbours in quad order and cost about the same, so contiguous slices made some workgroups consistently slower than
   // others, and the launch ends with its slowest workgroup (0.145 -> 0.136 ms alone with the strided share).  A global
   // counter for the tail of the list was tried on top and is not here: even ~8000 single-address atomics per launch cost
-  // more than the imbalance they remove (0.136 -> 0.172 ms).
-  const uint32_t lo = 0u, hi = blockIdx.x < C ? (C - blockIdx.x + gridDim.x - 1u) / gridDim.x : 0u;
-  uint32_t bc = 0, bi = kNil; unsigned long long bt = ~0ull;                // this wave's / thread's best
-  if (lo < hi && P.ablate != 2) {                          // (uniform) otherwise: more workgroups than candidates
-    if (threadIdx.x == 0) { s_next = lo; s_pruned = 0u; }
+  // more than the imbalance they remove (0.136 -> 0.172 ms, profiles/HISTORY.md).
+  // (the per-base bookkeeping -- ticket ranges, every wave's best per base -- lives in LDS, not in registers: the sweep leaves no
+  // scalar registers to spare, and a candidate costs microseconds against one LDS round trip)
+  if (threadIdx.x == 0) {
+    uint32_t acc = 0;
+    for (uint32_t b = 0; b < uint32_t(kGroupMax); ++b) {
+      const uint32_t Cb = b < nb ? P.b[b].ctr->C : 0u;
+      acc += blockIdx.x < Cb ? (Cb - blockIdx.x + gridDim.x - 1u) / gridDim.x : 0u;
+      S.end[b] = acc; S.pruned[b] = 0u;
+    }
+    s_next = 0u;
+  }
+  if (lane == 0)
+    for (uint32_t b = 0; b < uint32_t(kGroupMax); ++b) { S.wcnt[b][wave] = 0u; S.wcand[b][wave] = kNil; S.wtag[b][wave] = ~0ull; }
+  __syncthreads();
+  // (read back through readfirstlane: the compiler cannot know that an LDS word is the same in every lane, and a ticket loop
+  // whose exit it takes for divergent is structurised into nested loops with partial exec masks around the lane-0 atomic --
+  // measured: that build hung on the device)
+  const uint32_t hi = uint32_t(__builtin_amdgcn_readfirstlane(int(S.end[kGroupMax - 1])));
+  if (hi != 0u && P.ablate != 2) {                         // (uniform) otherwise: more workgroups than candidates
     LcpTask K;
-    K.q4 = P.q4v; K.n_q = P.n_q; K.qq = P.qq; K.T = P.cand_T; K.t_stride = kCandStride; K.point_tests = &P.ctr->point_tests;
-    K.prune = P.prune; K.pruned = &s_pruned;
+    K.q4 = P.q4v; K.n_q = P.n_q; K.qq = P.qq; K.T = P.b[0].cand_T; K.t_stride = kCandStride; K.point_tests = &P.b[0].ctr->point_tests;
+    K.prune = P.prune; K.pruned = &S.pruned[0];
     if (LEAN) { if (QLDS) stage_queries_f(P.qsoa, const_cast<float*>(LL.qx), 3u * n_pad); }
     else if (QLDS) stage_queries(K, s_q);
     stage_coarse(P.grid, s_coarse);                        // ends with a workgroup barrier
@@ -2140,14 +2010,23 @@ __global__ __launch_bounds__(kVerifyMaxThreads, 6) void k_verify(VerifyParams P)
     // so was finishing "heavy" candidates -- those that stay alive through the whole sweep -- by the whole workgroup after the
     // ticket loop: slower, most of them die in their first exact batch.  profiles/HISTORY.md.)
     cyc_staged = S4P_CYC_NOW();
+    // The loop body has NO lane-dependent control flow of its own: the ticket is drawn by wave_ticket (lane 0 adds, inside one asm
+    // statement), the candidate's bookkeeping afterwards is done by all lanes with identical values.  With `if (lane == 0)` regions on both sides of the loop's back edge the compiler threaded lane 0's
+    // path through the edge and re-entered the loop with lanes 1..63 alone -- readfirstlane then read THEIR (zero) ticket: the
+    // group build hung on the device (round 5; the breadcrumb build that perturbed the code did not).
     while (true) {
-      uint32_t t = 0;
-      if (lane == 0) t = atomicAdd(&s_next, 1u);
-      t = uint32_t(__builtin_amdgcn_readfirstlane(int(t)));
+      const uint32_t t = wave_ticket(&s_next);
       if (t >= hi) break;
-      const uint32_t i = blockIdx.x + t * gridDim.x;
-      const float4* src = P.cand_T + kCandStride * size_t(i);         // one candidate per wave
+      // ticket -> (base, position in this workgroup's share of its list)
+      uint32_t bsel = 0u, t0 = 0u;
+#pragma unroll
+      for (int b = 1; b < kGroupMax; ++b) { const uint32_t e = S.end[b - 1]; if (t >= e) { bsel = uint32_t(b); t0 = e; } }
+      bsel = uint32_t(__builtin_amdgcn_readfirstlane(int(bsel))); t0 = uint32_t(__builtin_amdgcn_readfirstlane(int(t0)));
+      const VerifyBase& B = P.b[bsel];
+      const uint32_t i = blockIdx.x + (t - t0) * gridDim.x;
+      const float4* src = B.cand_T + kCandStride * size_t(i);         // one candidate per wave
       const float4 r0 = src[0], r1 = src[1], r2 = src[2], r3 = src[3];
+      K.point_tests = &B.ctr->point_tests; K.pruned = &S.pruned[bsel];
       uint32_t cnt;
 #if S4P_CYCLE_PROF == 1
       { const unsigned long long w0 = S4P_CYC_NOW();          // how long the record of THIS candidate keeps the wave waiting
@@ -2155,42 +2034,50 @@ __global__ __launch_bounds__(kVerifyMaxThreads, 6) void k_verify(VerifyParams P)
         cyc_wait += S4P_CYC_NOW() - w0; ++n_cand; }
 #endif
       if (LEAN) cnt = P.ablate == 1 ? wave_lcp_count_lean<COUNT, true, QLDS>(P.grid, K, LL, src, r0, r1, r2, CP) : wave_lcp_count_lean<COUNT, false, QLDS>(P.grid, K, LL, src, r0, r1, r2, CP);
-      else cnt = P.ablate == 1 ? S4P_WAVE_LCP_COUNT<COUNT, true, QLDS>(P.grid, K, s_coarse, s_q, s_queue, src)
-                               : S4P_WAVE_LCP_COUNT<COUNT, false, QLDS>(P.grid, K, s_coarse, s_q, s_queue, src);
-      const uint32_t kraw = uint32_t(__builtin_amdgcn_readfirstlane(int(__float_as_uint(r3.z))));
-      const uint32_t k = kraw & ~kBorderFlag;
-      const unsigned long long tag = (unsigned long long)uint32_t(__builtin_amdgcn_readfirstlane(int(__float_as_uint(r3.x)))) |
-                                     ((unsigned long long)uint32_t(__builtin_amdgcn_readfirstlane(int(__float_as_uint(r3.y)))) << 32);
-      if (lane == 0) P.counts[k] = cnt;
-      if (kraw & kBorderFlag) {                              // scored, but the host decides whether it is a candidate at all
-        if (lane == 0) { const uint32_t n = atomicAdd(&P.ctr->n_border, 1u); if (n < kBorderCap) P.border[n] = i; }
-      } else if (slot_better(cnt, tag, bc, bt, bi != kNil)) { bc = cnt; bt = tag; bi = i; }
+      else cnt = P.ablate == 1 ? wave_lcp_count_auto<COUNT, true, QLDS>(P.grid, K, s_coarse, s_q, s_queue, src)
+                               : wave_lcp_count_auto<COUNT, false, QLDS>(P.grid, K, s_coarse, s_q, s_queue, src);
+      { // (the record's last 16 bytes are re-read: a line this wave has just held; nothing lives in registers across the sweep)
+        const float4 rr = src[3];
+        const uint32_t kraw = uint32_t(__builtin_amdgcn_readfirstlane(int(__float_as_uint(rr.z)))), k = kraw & ~kBorderFlag;
+        const unsigned long long tag = (unsigned long long)uint32_t(__builtin_amdgcn_readfirstlane(int(__float_as_uint(rr.x)))) |
+                                       ((unsigned long long)uint32_t(__builtin_amdgcn_readfirstlane(int(__float_as_uint(rr.y)))) << 32);
+        B.counts[k] = cnt;                                   // (every lane, same address, same value)
+        if (kraw & kBorderFlag) {                            // (uniform) scored, but the host decides whether it is a candidate at all
+          uint32_t n = 0;
+          if (lane == 0) n = atomicAdd(&B.ctr->n_border, 1u);
+          n = uint32_t(__builtin_amdgcn_readfirstlane(int(n)));
+          if (n < kBorderCap) B.border[n] = i;
+        } else {
+          const uint32_t oc = uint32_t(__builtin_amdgcn_readfirstlane(int(S.wcnt[bsel][wave]))), oi = uint32_t(__builtin_amdgcn_readfirstlane(int(S.wcand[bsel][wave])));
+          const unsigned long long ot = S.wtag[bsel][wave];
+          const unsigned long long otu = (unsigned long long)uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(ot)))) | ((unsigned long long)uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(ot >> 32)))) << 32);
+          if (slot_better(cnt, tag, oc, otu, oi != kNil)) { S.wcnt[bsel][wave] = cnt; S.wtag[bsel][wave] = tag; S.wcand[bsel][wave] = i; }   // (uniform)
+        }
+      }
+      (void)r3;
+      __builtin_amdgcn_wave_barrier();
     }
   }
 #if S4P_CYCLE_PROF
   cyc_loop_end = S4P_CYC_NOW();
 #endif
-  // ---- selection: wave bests -> workgroup best -> slot; the last workgroup to finish reduces the slots ----
-  auto wave_reduce = [&]() {
+  // ---- selection: wave bests (LDS) -> workgroup best -> slot; the last workgroup to finish reduces the slots ----
+  auto wave_reduce = [&](WaveBest& w) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
-      const uint32_t oc = uint32_t(__shfl_xor(int(bc), o)), oi = uint32_t(__shfl_xor(int(bi), o));
-      const uint32_t tl = uint32_t(__shfl_xor(int(uint32_t(bt)), o)), th = uint32_t(__shfl_xor(int(uint32_t(bt >> 32)), o));
+      const uint32_t oc = uint32_t(__shfl_xor(int(w.c), o)), oi = uint32_t(__shfl_xor(int(w.i), o));
+      const uint32_t tl = uint32_t(__shfl_xor(int(uint32_t(w.t)), o)), th = uint32_t(__shfl_xor(int(uint32_t(w.t >> 32)), o));
       const unsigned long long ot = (unsigned long long)tl | ((unsigned long long)th << 32);
-      if (oi != kNil && slot_better(oc, ot, bc, bt, bi != kNil)) { bc = oc; bt = ot; bi = oi; }
+      if (oi != kNil && slot_better(oc, ot, w.c, w.t, w.i != kNil)) { w.c = oc; w.t = ot; w.i = oi; }
     }
   };
-  auto block_reduce = [&](const bool lanes_differ) {        // result valid in thread 0
-    if (lanes_differ) wave_reduce();
-    if (lane == 0) { s_wcnt[wave] = bc; s_wcand[wave] = bi; s_wtag[wave] = bt; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      bc = 0; bi = kNil; bt = ~0ull;
-      for (uint32_t w = 0; w < (blockDim.x >> 6); ++w)
-        if (s_wcand[w] != kNil && slot_better(s_wcnt[w], s_wtag[w], bc, bt, bi != kNil)) { bc = s_wcnt[w]; bt = s_wtag[w]; bi = s_wcand[w]; }
-    }
+  auto block_best = [&](const uint32_t b) -> WaveBest {     // thread 0, after a barrier: the workgroup's best of base b
+    WaveBest r{0u, kNil, ~0ull};
+    for (uint32_t w = 0; w < (blockDim.x >> 6); ++w)
+      if (S.wcand[b][w] != kNil && slot_better(S.wcnt[b][w], S.wtag[b][w], r.c, r.t, r.i != kNil)) { r.c = S.wcnt[b][w]; r.t = S.wtag[b][w]; r.i = S.wcand[b][w]; }
+    return r;
   };
-  block_reduce(false);                                     // (the wave's best is uniform over its lanes)
+  __syncthreads();
 #if S4P_CYCLE_PROF
   if (LEAN && P.cyc != nullptr && lane == 0) {              // per wave: [0] lifetime up to here [1] staging [2] candidate loop [3] sweep [4] drain [5] exact
     const unsigned long long now = S4P_CYC_NOW();           //           [6] record wait [7] tail barrier [8] waves [9] candidates [10] drains [11] exact batches
@@ -2201,49 +2088,61 @@ __global__ __launch_bounds__(kVerifyMaxThreads, 6) void k_verify(VerifyParams P)
   }
 #endif
   if (threadIdx.x == 0) {
-    if (lo < hi && P.ablate != 2 && s_pruned) atomicAdd(&P.ctr->pruned, s_pruned);
-    P.slots[blockIdx.x] = make_uint4(bc, bi, uint32_t(bt), uint32_t(bt >> 32));
-    __threadfence();                                       // release (agent scope): the slot is visible before the ticket
-    const uint32_t ticket = atomicAdd(&P.ctr->done, 1u);
+    for (uint32_t b = 0; b < nb; ++b) {
+      if (S.pruned[b]) atomicAdd(&P.b[b].ctr->pruned, S.pruned[b]);
+      const WaveBest r = block_best(b);
+      P.b[b].slots[blockIdx.x] = make_uint4(r.c, r.i, uint32_t(r.t), uint32_t(r.t >> 32));
+    }
+    __threadfence();                                       // release (agent scope): the slots are visible before the ticket
+    const uint32_t ticket = atomicAdd(P.group_done, 1u);
     s_last = (ticket == gridDim.x - 1u) ? 1u : 0u;
   }
   __syncthreads();
   if (s_last == 0u) return;
   __threadfence();                                         // acquire: the other workgroups' slots
-  bc = 0; bi = kNil; bt = ~0ull;
-  for (uint32_t b = threadIdx.x; b < gridDim.x; b += blockDim.x) {
-    const uint4 sl = P.slots[b];
-    const unsigned long long t = (unsigned long long)sl.z | ((unsigned long long)sl.w << 32);
-    if (sl.y != kNil && slot_better(sl.x, t, bc, bt, bi != kNil)) { bc = sl.x; bt = t; bi = sl.y; }
+  for (uint32_t b = 0; b < nb; ++b) {                      // (S.w* are reused: every thread is past the barrier above)
+    WaveBest r{0u, kNil, ~0ull};
+    for (uint32_t w = threadIdx.x; w < gridDim.x; w += blockDim.x) {
+      const uint4 sl = P.b[b].slots[w];
+      const unsigned long long t = (unsigned long long)sl.z | ((unsigned long long)sl.w << 32);
+      if (sl.y != kNil && slot_better(sl.x, t, r.c, r.t, r.i != kNil)) { r.c = sl.x; r.t = t; r.i = sl.y; }
+    }
+    wave_reduce(r);
+    if (lane == 0) { S.wcnt[b][wave] = r.c; S.wcand[b][wave] = r.i; S.wtag[b][wave] = r.t; }
   }
-  __syncthreads();                                         // (s_w* are reused)
-  block_reduce(true);
+  __syncthreads();
   if (threadIdx.x != 0) return;
-  DevCounters* c = P.ctr;
-  DevCounters* r = P.res;
-  r->m1 = c->m1; r->m2 = c->m2; r->K = c->K; r->C = C; r->overflow = c->overflow;
-  r->quad_sum = c->quad_sum; r->cand_sum = c->cand_sum; r->n_border = c->n_border; r->pruned = c->pruned;
-  r->best_count = bc; r->best_tag = bt; r->has_best = 0u;
-  if (COUNT || P.count_tests) { r->point_tests = c->point_tests; r->l0_pass = c->l0_pass; r->l1_pass = c->l1_pass; r->l2_pass = c->l2_pass; }
-  if (bi != kNil) {                                        // recompute the winner's 4x4 (ComputeRigidTransformation)
-    const uint32_t k = P.cand_idx[bi] & ~kBorderFlag;
-    const int4 qd = P.quads[k];
-    const float4 a = P.q4[qd.x], b = P.q4[qd.y], cc = P.q4[qd.z];
-    const float q[3][3] = {{a.x, a.y, a.z}, {b.x, b.y, b.z}, {cc.x, cc.y, cc.z}};
-    float T[12], c2[3];
-    rigid_gate(P.base, q, T, c2);
-    for (int i = 0; i < 12; ++i) r->best_T[i] = T[i];
-    r->best_T[12] = 0.f; r->best_T[13] = 0.f; r->best_T[14] = 0.f; r->best_T[15] = 1.f;
-    for (int i = 0; i < 3; ++i) r->best_c2[i] = c2[i];
-    r->best_quad[0] = qd.x; r->best_quad[1] = qd.y; r->best_quad[2] = qd.z; r->best_quad[3] = qd.w;
-    r->has_best = 1u;
+  for (uint32_t b = 0; b < nb; ++b) {
+    const VerifyBase& B = P.b[b];
+    DevCounters* c = B.ctr;
+    DevCounters* r = B.res;
+    const WaveBest w = block_best(b);
+    r->m1 = c->m1; r->m2 = c->m2; r->K = c->K; r->C = c->C; r->overflow = c->overflow;
+    r->quad_sum = c->quad_sum; r->cand_sum = c->cand_sum; r->n_border = c->n_border; r->pruned = c->pruned;
+    r->best_count = w.c; r->best_tag = w.t; r->has_best = 0u;
+    if (COUNT || P.count_tests) { r->point_tests = c->point_tests; r->l0_pass = c->l0_pass; r->l1_pass = c->l1_pass; r->l2_pass = c->l2_pass; }
+    if (w.i != kNil) {                                       // recompute the winner's 4x4 (ComputeRigidTransformation)
+      const uint32_t k = B.cand_idx[w.i] & ~kBorderFlag;
+      const int4 qd = B.quads[k];
+      const float4 a = P.q4[qd.x], bq = P.q4[qd.y], cc = P.q4[qd.z];
+      const float q[3][3] = {{a.x, a.y, a.z}, {bq.x, bq.y, bq.z}, {cc.x, cc.y, cc.z}};
+      float T[12], c2[3];
+      rigid_gate(B.base, q, T, c2);
+      for (int i = 0; i < 12; ++i) r->best_T[i] = T[i];
+      r->best_T[12] = 0.f; r->best_T[13] = 0.f; r->best_T[14] = 0.f; r->best_T[15] = 1.f;
+      for (int i = 0; i < 3; ++i) r->best_c2[i] = c2[i];
+      r->best_quad[0] = qd.x; r->best_quad[1] = qd.y; r->best_quad[2] = qd.z; r->best_quad[3] = qd.w;
+      r->has_best = 1u;
+    }
+    // the live counters are ready for the next base on this lane (no separate reset launch)
+    c->m1 = 0; c->m2 = 0; c->K = 0; c->C = 0; c->best_count = 0; c->overflow = 0; c->best_tag = ~0ull; c->has_best = 0;
+    c->quad_sum = 0; c->cand_sum = 0; c->n_border = 0; c->pruned = 0;
+    c->point_tests = 0; c->l0_pass = 0; c->l1_pass = 0; c->l2_pass = 0;
+    c->done = 0;
   }
-  // the live counters are ready for the next base on this lane (no separate reset launch)
-  c->m1 = 0; c->m2 = 0; c->K = 0; c->C = 0; c->best_count = 0; c->overflow = 0; c->best_tag = ~0ull; c->has_best = 0;
-  c->quad_sum = 0; c->cand_sum = 0; c->n_border = 0; c->pruned = 0;
-  c->point_tests = 0; c->l0_pass = 0; c->l1_pass = 0; c->l2_pass = 0;
-  __threadfence();
-  c->done = 0;
+  *P.group_done = 0u;
+  __threadfence_system();                                  // the records (host memory) and the cleared counters before the launch number
+  for (uint32_t b = 0; b < nb; ++b) __hip_atomic_store(&P.b[b].res->seq, P.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // k_verify_T: Verify() for explicit row-major 4x4 transforms (one wave per transform).
@@ -2267,7 +2166,7 @@ __global__ __launch_bounds__(kVerifyMaxThreads) void k_verify_T(VerifyTParams P)
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
   for (uint32_t k = wave; k < P.B; k += nwaves) {
-    const uint32_t cnt = S4P_WAVE_LCP_COUNT<COUNT, false, QLDS>(P.grid, K, s_coarse, s_q, s_queue, K.T + 4 * size_t(k));
+    const uint32_t cnt = wave_lcp_count_auto<COUNT, false, QLDS>(P.grid, K, s_coarse, s_q, s_queue, K.T + 4 * size_t(k));
     if (lane == 0) P.counts[k] = cnt;
   }
 }

@@ -239,11 +239,124 @@ def test_config4_part_in_whole_10m_scene(oracle_mod, s4p_lib_built, monkeypatch)
             _gm, quads, cand = _fused_bases_vs_oracle(oracle_mod, capi, P, Q, delta, 0.2, 2000, 1, 8 << 20, 64 << 20, count_sample=400, skip_bases=21)
             assert quads >= 30_000 and cand >= 10_000
         del _gm
-        # ... and at SURVEY.md 8d's sample size for this workload, n = 5000 sampled Q points.  The base sequence depends on P
-        # only, so the same trials carry quads (~40 x more of them): trial 21 through the fused pass against the oracle.
+        # ... and at SURVEY.md 8d's sample size for this workload, n = 5000 sampled Q points: test_config4_sample_5000_against_the_golden_record
+        # (the oracle's answers for that base are committed: it needs minutes for them); with S4P_TEST_HEAVY also live against the oracle
         if os.environ.get("S4P_TEST_HEAVY"):
             _gm, quads5, cand5 = _fused_bases_vs_oracle(oracle_mod, capi, P, Q, delta, 0.2, 5000, 1, 8 << 20, 64 << 20, count_sample=400, skip_bases=21)
             assert quads5 > 100_000 and cand5 > 10_000 and _gm.info().n_sampled_q == 5000
+
+
+def _golden(name):
+    import json
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name)
+    if not os.path.exists(path):
+        pytest.fail("golden record %s is missing: python tests/golden/make_scale_golden.py" % name)
+    return json.load(open(path))
+
+
+def _bases_vs_golden(oracle_mod, capi, P, Q, delta, overlap, n_s, G, max_pairs, max_quads, ctx_pairs):
+    """Seeded bases at a sample size where the oracle needs minutes to hours, against its COMMITTED answers
+    (tests/golden/make_scale_golden.py, CPU): sampled-cloud sizes and trial count; both pair sets in the reference's emission
+    order (count + SHA-256 of the ordered list, stage-level entry point, octree permutation carried over the skipped
+    trials); the FUSED pass of the base -- chunked when its quads exceed the buffers -- number of quads, of gated candidates
+    and their order-independent checksums; the inlier counts of a deterministic subsample of the gated quads (oracle:
+    kd-tree Verify); the winner -- equal to the oracle's streaming winner where the golden record holds one, otherwise
+    recounted by the oracle here (one candidate) and not beaten by any sampled candidate."""
+    import hashlib
+    from bench import seg_len32
+    eps = 2.0 * delta
+    gm = capi.Matcher(capi.make_options(delta, overlap, n_s), max_pairs=max_pairs, max_quads=max_quads)
+    gm.init_full(P, Q)
+    gi = gm.info()
+    assert (gi.n_sampled_p, gi.n_sampled_q, gi.number_of_trials) == (G["n_P"], G["n_Q"], G["number_of_trials"])
+    sel = capi.Matcher(capi.make_options(delta, overlap, n_s), max_pairs=1 << 16, max_quads=1 << 16)      # the base sequence (host state only)
+    sel.init_full(P, Q)
+    # the stage-level context holds whole pair lists (no growth there) but needs one lane only
+    saved = os.environ.get("S4P_LANES")
+    os.environ["S4P_LANES"] = "1"
+    try:
+        ctx = capi.Context(capi.make_options(delta, overlap, n_s), max_pairs=ctx_pairs, max_quads=1 << 20)
+    finally:
+        if saved is None:
+            os.environ.pop("S4P_LANES", None)
+        else:
+            os.environ["S4P_LANES"] = saved
+    ctx.set_clouds(gm.sampled(0), gm.sampled(1))
+    om = None
+    trial = 0
+    tot_quads = tot_cand = 0
+    for rec in G["bases"]:
+        while trial < rec["trial"]:                     # skipped trials advance the RNG and the pair-octree permutation everywhere
+            ok, _i1, _i2, _b, bx = sel.select_quadrilateral()
+            if ok:
+                ctx.set_base(bx)
+                ctx.extract_pairs(seg_len32(bx[0], bx[1]), 0.0, eps, 0, 1, cap=1 << 26)
+                ctx.extract_pairs(seg_len32(bx[2], bx[3]), 0.0, eps, 2, 3, cap=1 << 26)
+            gm.next_base(run_device=False)
+            trial += 1
+        ok, i1, i2, base, bx = sel.select_quadrilateral()
+        assert ok and [int(v) for v in base] == rec["base"]
+        assert np.float32(i1) == np.float32(rec["inv1"]) and np.float32(i2) == np.float32(rec["inv2"])
+        ctx.set_base(bx)
+        for k, (a, b) in enumerate(((0, 1), (2, 3))):
+            got = ctx.extract_pairs(seg_len32(bx[a], bx[b]), 0.0, eps, a, b, cap=1 << 26)
+            assert got.shape[0] == rec["pairs"][k]["n"]
+            assert hashlib.sha256(np.ascontiguousarray(got, np.int32).tobytes()).hexdigest() == rec["pairs"][k]["sha256"]      # same pairs, same emission order
+        g_ok, r = gm.try_one_base()
+        trial += 1
+        assert (r.n_pairs1, r.n_pairs2) == (rec["pairs"][0]["n"], rec["pairs"][1]["n"])
+        assert (r.n_quads, "%016x" % r.quad_checksum) == (rec["K"], rec["quad_sum"])
+        assert (r.n_verified, "%016x" % r.cand_checksum) == (rec["C"], rec["cand_sum"])
+        smp = np.array(rec["sample_quads"], np.int32).reshape(-1, 4)
+        want = np.array(rec["sample_counts"], np.int32)
+        _gr, g_per = ctx.try_congruent_set(base, smp)
+        assert np.array_equal(g_per, want)
+        assert r.has_best and int(want.max()) <= int(r.best_count)
+        if "winner" in rec:
+            assert rec["winner"]["found"] and r.best_count == rec["winner"]["best_count"] and list(r.best_quad) == rec["winner"]["best_quad"]
+        else:
+            if om is None:
+                om = oracle_mod.Matcher(oracle_mod.make_options(delta, overlap, n_s), full_counts=True, use_kdtree=True, keep_trace=False)
+                om.init(P, Q)
+                assert np.array_equal(gm.sampled(0), om.cloud(0)) and np.array_equal(gm.sampled(1), om.cloud(1))
+            _nb, w_per, _bc, _bi = om.try_congruent_set(base, np.array([list(r.best_quad)], np.int32))
+            assert int(w_per[0]) == int(r.best_count)
+        tot_quads += r.n_quads; tot_cand += r.n_verified
+    return gm, tot_quads, tot_cand
+
+
+def test_config2_gpu_scale_sample_20000(oracle_mod, s4p_lib_built):
+    """configs[2] at the "GPU-scale" sample size of SURVEY.md 8d (n = 20 000 sampled Q points), first base of the seeded
+    sequence: 16.8 M + 10.2 M ordered pairs in the reference's emission order, then the FUSED pass to completion -- its ~10^9
+    congruent quads exceed any quad buffer, so the base is chunked (ranges of the second pair set -> enumerate -> gate ->
+    score -> fold) -- against the oracle's committed record (tests/golden/scale_config2_n20000.json).  Lists of that size
+    cannot be compared (the reference's own std::set would need ~50 GB)."""
+    from super4pcs_amd import capi, datasets as D
+    import bench
+    if SCALE != 1.0:
+        pytest.skip("full-size case")
+    G = _golden("scale_config2_n20000.json")
+    G = dict(G, bases=G["bases"][:1])                   # (the second recorded base serves bench.py's `extra` line)
+    P, Q, _ = D.bumpy_pair(bench.N_POINTS, overlap=bench.OVERLAP, delta=bench.DELTA, seed=bench.SEED)
+    # default limits (1 Mi pairs, 4 Mi quads): the lane grows its pair buffers and redoes the base, then chunks its quads
+    gm, quads, cand = _bases_vs_golden(oracle_mod, capi, P, Q, bench.DELTA, bench.OVERLAP, 20000, G, 0, 0, 32 << 20)
+    st = gm.chunk_stats()
+    assert quads > (200 << 20) and st["bases"] == 1 and st["passes"] >= 8 and gm.capacity_growths() >= 1
+
+
+def test_config4_sample_5000_against_the_golden_record(oracle_mod, s4p_lib_built, monkeypatch):
+    """configs[4] at SURVEY.md 8d's sample size for it (n = 5000 sampled Q points): trial 21 of the seeded sequence (the first
+    cheap base whose two segments fit inside the query) through the stage-level pair extraction and the fused pass, against
+    the oracle's committed record incl. its streaming winner (tests/golden/scale_config4_n5000.json)."""
+    monkeypatch.setenv("S4PO_SKIP_MEAN_DISTANCE", "1")
+    from super4pcs_amd import capi, datasets as D
+    if SCALE != 1.0:
+        pytest.skip("full-size case")
+    G = _golden("scale_config4_n5000.json")
+    delta = 0.05
+    P, Q, _ = D.part_in_whole_pair(10_000_000, 100_000, delta=delta)
+    gm, quads, cand = _bases_vs_golden(oracle_mod, capi, P, Q, delta, 0.2, 5000, G, 8 << 20, 64 << 20, 8 << 20)
+    assert quads > 100_000 and cand > 10_000 and gm.info().n_sampled_q == 5000
 
 
 def _whole_registration_vs_oracle(oracle_mod, capi, P, Q, delta, overlap, n_s, threads=0):
