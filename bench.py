@@ -301,7 +301,7 @@ def cpu_baseline(P, Q, budget_s, sample, ttr_candidates):
     return a
 
 
-def pmc_passes(args, timeout_s=240):
+def pmc_passes(args, n_timed_launches, timeout_s=240):
     """rocprofv3 --pmc passes over an inner run of this script with the SAME warm-up + timed bases and the default lanes
     (counters serialise the launches: per-kernel numbers are the kernel's own).  Three passes -- the TCC slots do not hold
     FETCH_SIZE and WRITE_SIZE together (MI355X_MICROARCH.md "rocprofv3 PMC slots").  Returns {counter: (mean per k_verify
@@ -353,9 +353,10 @@ def pmc_passes(args, timeout_s=240):
                 for kn, v in dur.items():
                     if v:
                         per_kernel[kn]["avg_us"] = float(np.mean(v[len(v) // 4:]))
-            # the inner run launches warm-up + timed bases: keep the timed ones (the last `steps` launches)
+            # the inner run launches warm-up + timed bases (a launch covers a group of bases): keep the timed region's launches,
+            # as many as the main run counted with its HIP events (the last ones)
             for k, v in vals.items():
-                v = v[-args.steps:] if len(v) >= args.steps else v
+                v = v[-n_timed_launches:] if (n_timed_launches and len(v) >= n_timed_launches) else v
                 got[k] = (float(np.mean(v)), len(v))
             if args.profile_dir:
                 os.makedirs(args.profile_dir, exist_ok=True)
@@ -552,7 +553,9 @@ def hbm_bound_point(args, device, n_transforms=4096, timeout_s=300):
                "algorithmic_bytes": len(Ts) * gathers, "achieved_GBps": len(Ts) * gathers / t / 1e9, "peak_GBps": HBM_PEAK_GBS,
                "frac": len(Ts) * gathers / t / 1e9 / HBM_PEAK_GBS,
                "counts_checked_by_oracle": 0, "count_mismatches": None,
-               "note": "kernel duration and FETCH_SIZE (doubled: gfx950 tallies 128-B requests at 64 B) of the single cold k_verify_T launch, "
+               "note": "`frac` is the ALGORITHMIC figure (dependent gathers the structure requires / kernel time); measured_frac doubles FETCH_SIZE, a factor "
+                       "the guide calibrates for wide coalesced streams only -- uncalibrated for 16-byte gathers, an upper bound here.  "
+                       "kernel duration and FETCH_SIZE (doubled: gfx950 tallies 128-B requests at 64 B) of the single cold k_verify_T launch, "
                        "rocprofv3 --kernel-trace --pmc FETCH_SIZE in a process of its own; algorithmic bytes = dependent gathers the structure "
                        "requires (reach words, 32-B headers, query re-reads, 48-B point groups) from the instrumented kernel's counters"}
         # parity of the TIMED launch: the oracle's kd-tree Verify recounts the first 64 transforms on exactly the sampled,
@@ -604,6 +607,8 @@ def main():
     ap.add_argument("--hbm-transforms", type=int, default=4096)
     ap.add_argument("--points", type=int, default=N_POINTS)
     ap.add_argument("--sample", type=int, default=SAMPLE)
+    ap.add_argument("--ttr-configs", default="", help="e.g. 1,3,4: also run tools/init_timing.py for these BASELINE configs (init + whole-registration "
+                    "time at SURVEY 8d's sample sizes; minutes) and put the lines into extra.time_to_register_configs")
     ap.add_argument("--no-extra", dest="extra", action="store_false", default=True,
                     help="skip the `extra` object: the same clouds at SURVEY 8d's GPU-scale sample (n = 20 000), two bases, in a process of its own")
     args = ap.parse_args()
@@ -928,7 +933,7 @@ def main():
 
     pmc, pmc_note, pmc_kernels = {}, ["skipped"], {}
     if rank == 0 and world == 1 and args.pmc:
-        pmc, pmc_note, pmc_kernels = pmc_passes(args)
+        pmc, pmc_note, pmc_kernels = pmc_passes(args, int(prof.verify_launches))
     hbm_point = None
     if rank == 0 and world == 1 and args.hbm_point:
         hbm_point = hbm_bound_point(args, local_rank)
@@ -1124,6 +1129,14 @@ def main():
             out["cpu_baseline"] = None
         out["provenance"] = provenance
         out["extra"] = extra_sample_line(args) if (world == 1 and args.extra and not scale_mode and not args.inner) else None
+        if world == 1 and args.ttr_configs and out["extra"] is not None:
+            # the metric's second half on the other BASELINE configs: a process of its own per run, reported only
+            try:
+                pr = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "init_timing.py")] + args.ttr_configs.split(","),
+                                    stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=900)
+                out["extra"]["time_to_register_configs"] = [json.loads(ln) for ln in pr.stdout.decode().splitlines() if ln.startswith("{")]
+            except Exception as e:                              # noqa: BLE001
+                out["extra"]["time_to_register_configs"] = {"error": type(e).__name__}
         def clean(o):                                           # (no NaN in the JSON line: a figure that was not measured is null)
             if isinstance(o, dict):
                 return {k: clean(v) for k, v in o.items()}

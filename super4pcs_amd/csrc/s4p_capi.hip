@@ -124,13 +124,16 @@ struct s4p_ctx {
     uint64_t sv_gen = 0;              // generation of the staging slot when the base was launched (a replay needs the same content)
     uint32_t sv_nseq1 = 0;            // sequence length of the base's first pair set: its order keys are below 2 * n_q * sv_nseq1
   };
-  static constexpr int kMaxLanes = 12;
+  static constexpr int kMaxLanes = 16;
   Lane lane[kMaxLanes];
-  // Bases in flight = lanes (S4P_LANES, 1..12); consecutive lanes form GROUPS of `group` bases (S4P_GROUP, 1..kGroupMax) that
+  // Bases in flight = lanes (S4P_LANES, 1..16); consecutive lanes form GROUPS of `group` bases (S4P_GROUP, 1..kGroupMax) that
   // go through every kernel in ONE launch (s4p_kernels.hip.hpp "BASE GROUPS").  A group is launched when its last base has been
   // submitted -- or earlier, with the bases it has, when somebody waits for one of them -- so any call pattern (one base at a
   // time, the engine's pipelined loop, the sharded loops) gets the same results; only the packing differs.
-  int n_lanes = 9, group = 3;
+  // Measured on the bench workload (round 5, one box per row, M candidates/s): 6 lanes x 1: 185 (the round-4 shape); 9 x 3: 200;
+  // 12 x 3: 206; 12 x 2: 225; 14 x 2: 228-236; 16 x 2: 212-229; 12 x 1 (twelve streams on 8 hardware queues): 111 -- the number of
+  // STREAMS in use should not exceed GPU_MAX_HW_QUEUES (8); k_verify of a group on a lower-priority stream of its own: 20 (!).
+  int n_lanes = 14, group = 2;
   // Grids of k_prep / k_quads: their trip counts (pairs of a base) live in device memory, so the grids are sized by what the
   // registration's bases have needed so far (a decaying maximum with head-room) instead of the worst case -- a grid of 1024 /
   // 2048 workgroups per base of which a hundred find work is mostly dispatch cost.  A base that needs more takes a second
@@ -159,7 +162,7 @@ struct s4p_ctx {
     static size_t blob_words(size_t n_q) { return 2 * n_q + 8 + 4 * n_q; }      // n_leaf <= n_seq <= n_q
     float eps_unit[2] = {0, 0}, n_radius[2] = {0, 0}, distance[2] = {0, 0}, normal_angle[2] = {0, 0};
   };
-  static constexpr int kStageSlots = 32;   // 0..15: self-staging of s4p_try_base_async; 16..31: a threaded driver
+  static constexpr int kStageSlots = 40;   // 0..19: self-staging of s4p_try_base_async; 20..39: a threaded driver
   StageSlot stage[kStageSlots];
   uint32_t stage_rr = 0;             // round-robin slot for the self-staging (single-thread) paths
   int cur = 0;                       // slot used by the call in progress
@@ -603,6 +606,7 @@ void account_profile(s4p_ctx* c, const DevCounters& d, bool fused) {
   }
   if (c->prof_events && c->lane_group_n[c->cur] > 0) {     // per launch: the events belong to the first lane of a group launch
     float ms = 0.f;
+    (void)hipEventSynchronize(c->ev[c->cur][1]);           // (the host has seen the result record, the stream may not have reached the closing event yet)
     if (hipEventElapsedTime(&ms, c->ev[c->cur][0], c->ev[c->cur][1]) == hipSuccess) { c->prof.verify_launches++; c->prof.verify_ms_total += ms; }
     if (fused && c->prof_stages) {
       if (hipEventElapsedTime(&ms, c->ev[c->cur][2], c->ev[c->cur][3]) == hipSuccess) { c->prof.pairs_ms_total += ms; c->prof.pairs_launches += 2; }
@@ -1039,8 +1043,13 @@ int32_t s4p_create(const s4p_options* opt, const s4p_limits* lim, int32_t device
     if ((e = hipMemset(L.ctr.p, 0, 2 * sizeof(DevCounters))) != hipSuccess) return fail(e, "hipMemset");
     const char* what = nullptr;
     if ((e = alloc_lane_buffers(c->max_pairs, c->max_quads, L, &what)) != hipSuccess) return fail(e, what);
-    L.dirty = true;                                       // first use of a lane starts with an explicit clear (best_tag = ~0)
+    // the first clear of the lane's counters (best_tag = ~0) right here: it also makes the runtime create the stream's hardware
+    // queue NOW -- lazily that costs ~0.1 ms on the first launch of every stream, inside the first bases of a registration
+    // (measured: a 20-base burst after 5 warm-up bases ran at 100 us per base with 14 lanes, 74 us once every lane had been used)
+    hipLaunchKernelGGL(k_reset_counters, dim3(1), dim3(1), 0, L.stream, L.ctr.p);
+    L.dirty = false;
   }
+  for (int li = 0; li < c->n_lanes; ++li) if ((e = hipStreamSynchronize(c->lane[li].stream)) != hipSuccess) return fail(e, "hipStreamSynchronize");
   A(c->group_done, s4p_ctx::kMaxLanes);
   if ((e = hipMemset(c->group_done.p, 0, s4p_ctx::kMaxLanes * sizeof(uint32_t))) != hipSuccess) return fail(e, "hipMemset");
 #undef A

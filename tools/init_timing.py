@@ -2,7 +2,7 @@
 """Initialisation time and time-to-register of the BASELINE configs at the sample sizes SURVEY.md 8d states for them: per
 workload one JSON line with init_full wall time (sampler + engine init + s4p_set_clouds, split into its phases), the wall
 time of one whole ComputeTransformation with inputs in host memory, and the recovered pose against the generator's.
-Run on a GPU box from the repo root: python tools/r4/init_timing.py > gpurun_out/r04_init_and_time_to_register.jsonl"""
+Run on a GPU box from the repo root: python tools/init_timing.py > gpurun_out/r04_init_and_time_to_register.jsonl"""
 import json
 import os
 import sys
@@ -10,7 +10,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from super4pcs_amd import capi, datasets as D  # noqa: E402
 import bench  # noqa: E402
 
@@ -45,7 +45,11 @@ def run(tag, P, Q, T_gt, delta, overlap, n_s, register=True, max_time_seconds=10
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["2", "3", "4"]
+    which = sys.argv[1:] or ["1", "2", "3", "4"]
+    if "1" in which:                                       # configs[1]: the bunny-like partial-scan pair, n = 1000
+        P, Q, T = D.bumpy_pair(40000, overlap=0.45, delta=0.008, noise_sigma=0.3 * 0.008, seed=31)      # the pair of tests/test_gpu_configs.py::test_config1_*
+        run("configs[1] 40 k-point partial-scan pair, sample 350 (the size the oracle replays in the GPU test)", P, Q, T, 0.008, 0.45, 350)
+        run("configs[1] 40 k-point partial-scan pair, sample 1000 (SURVEY 8d)", P, Q, T, 0.008, 0.45, 1000)
     if "2" in which:
         P, Q, T = D.bumpy_pair(bench.N_POINTS, overlap=bench.OVERLAP, delta=bench.DELTA, seed=bench.SEED)
         run("configs[2] 1 M-point pair", P, Q, T, bench.DELTA, bench.OVERLAP, bench.SAMPLE)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """rocprofv3 over the bench workload's timed region (bench.py --inner): per-kernel durations from --kernel-trace and
 per-kernel counters from separate --pmc passes, for ALL kernels of a base (k_pairs, k_prep, k_quads, k_verify).
-Usage: python tools/r4/prof_kernels.py OUT_DIR [--lanes 1] [--steps 100]
+Usage: python tools/prof_kernels.py OUT_DIR [--lanes 1] [--steps 100]
 Writes OUT_DIR/kernels_<tag>.json (means per launch over the timed launches) and keeps the raw CSV rows of those kernels."""
 import argparse
 import csv
@@ -13,7 +13,7 @@ import subprocess
 import sys
 import tempfile
 
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNELS = ("k_pairs", "k_prep", "k_quads", "k_verify")
 PASSES = {
     "sq": ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "GRBM_GUI_ACTIVE"],

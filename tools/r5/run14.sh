@@ -1,0 +1,23 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT"
+export TMPDIR=/tmp
+export S4P_WAIT_TIMEOUT_S=20
+O=gpurun_out/r5_run14; mkdir -p $O
+run() { tag=$1; shift
+  env "$@" timeout -s KILL 60 python tools/r5/tp_probe.py 300 "$tag" > $O/tp_$tag.json 2> $O/tp_$tag.err
+  python - <<PY
+import json
+try:
+    d=json.load(open("$O/tp_$tag.json")); print(d["tag"], d["runs"][0]["mcand_per_s"], d["runs"][0]["us_per_base"], d["runs"][0]["wait_us"], d["best_count"], d["cand"])
+except Exception as e: print("$tag failed", e)
+PY
+}
+run l12g2 S4P_LANES=12 S4P_GROUP=2
+run l16g2 S4P_LANES=16 S4P_GROUP=2
+run l14g2 S4P_LANES=14 S4P_GROUP=2
+run l10g2 S4P_LANES=10 S4P_GROUP=2
+run l12g1 S4P_LANES=12 S4P_GROUP=1
+run l16g1 S4P_LANES=16 S4P_GROUP=1
+run l8g1 S4P_LANES=8 S4P_GROUP=1
+run l15g3 S4P_LANES=15 S4P_GROUP=3
+run l16g2b S4P_LANES=16 S4P_GROUP=2

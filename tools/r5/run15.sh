@@ -1,0 +1,22 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT"
+export TMPDIR=/tmp
+export S4P_WAIT_TIMEOUT_S=20
+O=gpurun_out/r5_run15; mkdir -p $O
+run() { tag=$1; shift
+  env "$@" timeout -s KILL 60 python tools/r5/tp_probe.py 300 "$tag" > $O/tp_$tag.json 2> $O/tp_$tag.err
+  python - <<PY
+import json
+try:
+    d=json.load(open("$O/tp_$tag.json")); print(d["tag"], d["runs"][0]["mcand_per_s"], d["runs"][0]["us_per_base"], d["runs"][0]["wait_us"], d["best_count"], d["cand"])
+except Exception as e: print("$tag failed", e)
+PY
+}
+run q16_l16g2 GPU_MAX_HW_QUEUES=16 S4P_LANES=16 S4P_GROUP=2
+run q12_l16g2 GPU_MAX_HW_QUEUES=12 S4P_LANES=16 S4P_GROUP=2
+run q16_l14g2 GPU_MAX_HW_QUEUES=16 S4P_LANES=14 S4P_GROUP=2
+run q16_l12g1 GPU_MAX_HW_QUEUES=16 S4P_LANES=12 S4P_GROUP=1
+run q8_l14g2 GPU_MAX_HW_QUEUES=8 S4P_LANES=14 S4P_GROUP=2
+run q8_l14g2b GPU_MAX_HW_QUEUES=8 S4P_LANES=14 S4P_GROUP=2
+run q16_l16g1 GPU_MAX_HW_QUEUES=16 S4P_LANES=16 S4P_GROUP=1
+run q24_l16g2 GPU_MAX_HW_QUEUES=24 S4P_LANES=16 S4P_GROUP=2

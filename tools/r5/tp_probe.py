@@ -15,9 +15,11 @@ tag = sys.argv[2] if len(sys.argv) > 2 else ""
 P, Q, _ = datasets.bumpy_pair(1_000_000, overlap=0.5, delta=0.004, seed=20140814)
 opt = capi.make_options(0.004, 0.5, 2000)
 m = capi.Matcher(opt, device=0, max_pairs=8 << 20, max_quads=64 << 20)
+if os.environ.get("TP_FULL") == "1":
+    m.early_exit(False)
 m.init_full(P, Q)
 m.set_sharding(0, 1, 2)
-m.perform_n_steps(5)
+m.perform_n_steps(int(os.environ.get("TP_WARMUP", "5")))
 start_at = float(os.environ.get("TP_START_AT", "0"))
 while time.time() < start_at:
     pass

@@ -14,7 +14,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-_newest = next((r for r in ("r04", "r03") if os.path.exists(os.path.join(ROOT, "profiles", r + "_bench_final.json"))), "r03")
+_newest = next((r for r in ("r05", "r04", "r03") if os.path.exists(os.path.join(ROOT, "profiles", r + "_bench_final.json"))), "r03")
 line = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", _newest + "_bench_final.json")
 _round = os.path.basename(line)[:3]
 pdir = sys.argv[2] if len(sys.argv) > 2 else os.path.splitext(line)[0]
@@ -28,11 +28,14 @@ def show(name, mine, theirs):
     print("%-46s recomputed %-16.6g in the line %-16.6g%s" % (name, mine, theirs if theirs is not None else float("nan"), rel))
 
 
+n_timed = int(r["per_launch"]["launches"]) if _round >= "r05" else steps      # round 5: a launch covers a group of bases; the line says how many launches the timed region had
+
+
 def counters(fname):
     out = {}
     for row in csv.DictReader(open(os.path.join(pdir, fname))):
         out.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
-    return {k: v[-steps:] for k, v in out.items()}                   # the timed launches are the last `steps`
+    return {k: (v[-n_timed:] if len(v) >= n_timed else v) for k, v in out.items()}                   # the timed launches are the last ones
 
 
 def mean(v):
