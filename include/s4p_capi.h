@@ -204,8 +204,14 @@ int32_t s4p_try_base(s4p_ctx* ctx, const int32_t* base_ids, float invariant1, fl
 
 /* Pipelined form of s4p_try_base: _async enqueues the whole device pass of the base set by s4p_set_base
  * and returns at once (the host can select the next base and build its pair octree meanwhile); _wait
- * returns results in submission order.  Up to s4p_pipeline_depth() bases may be in flight; each runs on its own HIP
- * stream with private buffers, so the small kernels of one base overlap the LCP scoring of another. */
+ * returns results in submission order.  Up to s4p_pipeline_depth() bases may be in flight, each with private device
+ * buffers (a "lane").  Consecutive lanes form GROUPS (default: 14 lanes in groups of 2; S4P_LANES, S4P_GROUP): the bases
+ * of a group go through every kernel of the pass in ONE launch, on one HIP stream per group, so that the small kernels
+ * of one group overlap the LCP scoring of another and every launch carries more than one base's work.  A group is
+ * launched when its last base has been submitted -- or earlier, with the bases it has, as soon as _wait is called for
+ * one of them: any call pattern (one base at a time, a full pipeline) gets the same results, only the packing differs.
+ * The number of streams in use should not exceed GPU_MAX_HW_QUEUES (read by the HIP runtime when it initialises; this
+ * library does not touch the environment: export it, e.g. 8, before the first HIP call -- INTEGRATION.md). */
 int32_t s4p_pipeline_depth(const s4p_ctx* ctx);
 int32_t s4p_try_base_async(s4p_ctx* ctx, const int32_t* base_ids, float invariant1, float invariant2);
 int32_t s4p_try_base_wait(s4p_ctx* ctx, s4p_base_result* result);

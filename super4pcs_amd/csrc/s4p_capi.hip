@@ -83,7 +83,6 @@ struct s4p_ctx {
   // device state
   DevBuf<uint2> greach; DevBuf<uint4> glist_hdr; DevBuf<uint32_t> gcoarse; DevBuf<float4> gnbr; DevBuf<float4> q4, q4v;
   DevBuf<uint2> qquant; QuantQ qq{}; bool qlds = false;      // 16-bit copy of the Morton-ordered queries for the LDS-resident sweep
-  DevBuf<unsigned long long> cyc;                            // S4P_CYCLE_PROF lab builds: per-phase cycle sums of the lean k_verify (printed at s4p_destroy)
   DevBuf<float> qsoa; bool lean = false, lean_lds = false;   // lean_lds: the float copy fits LDS (else the lean sweep reads q4v from global memory)
                       // float copy x | y | z of the same, padded (the lean sweep of k_verify: early-exit mode)
   DevBuf<float> qx, qy, qz, ux, uy, uz, qnx, qny, qnz, qcr, qcg, qcb;
@@ -106,7 +105,7 @@ struct s4p_ctx {
   // What a group launch needs of one base: the parameter records of its four kernels and the upload of its staged sequences,
   // built when the base is submitted (s4p_try_base_staged_async), consumed when its group is launched (flush_group).
   struct LaunchRec {
-    PairParams2 pp; PrepParams p1; QuadParams q; BaseFrame bf;
+    PairParams2 pp; PrepParams p1; QuadParams q; BaseFrame bf; bool fused_prep = false;
     const uint32_t* up_src = nullptr; uint32_t* up_dst = nullptr; size_t up_bytes = 0;
   };
   struct Lane : LaneBufs {
@@ -124,9 +123,9 @@ struct s4p_ctx {
     uint64_t sv_gen = 0;              // generation of the staging slot when the base was launched (a replay needs the same content)
     uint32_t sv_nseq1 = 0;            // sequence length of the base's first pair set: its order keys are below 2 * n_q * sv_nseq1
   };
-  static constexpr int kMaxLanes = 16;
+  static constexpr int kMaxLanes = 24;
   Lane lane[kMaxLanes];
-  // Bases in flight = lanes (S4P_LANES, 1..16); consecutive lanes form GROUPS of `group` bases (S4P_GROUP, 1..kGroupMax) that
+  // Bases in flight = lanes (S4P_LANES, 1..24); consecutive lanes form GROUPS of `group` bases (S4P_GROUP, 1..kGroupMax) that
   // go through every kernel in ONE launch (s4p_kernels.hip.hpp "BASE GROUPS").  A group is launched when its last base has been
   // submitted -- or earlier, with the bases it has, when somebody waits for one of them -- so any call pattern (one base at a
   // time, the engine's pipelined loop, the sharded loops) gets the same results; only the packing differs.
@@ -139,6 +138,8 @@ struct s4p_ctx {
   // 2048 workgroups per base of which a hundred find work is mostly dispatch cost.  A base that needs more takes a second
   // grid-stride pass: slower, same result.  0 = no estimate yet (first bases, stage-level calls): the full grids.
   uint32_t est_m1 = 0, est_m2 = 0;
+  bool fuse_prep = true;             // S4P_FUSE_PREP=0: always the k_prep launch (A/B aid)
+  uint64_t prep_redos = 0;           // bases redone because the estimate-sized cell hash was too small
   uint32_t launch_seq = 0;           // group launches so far (written into the result records: DevCounters::seq)
   DevBuf<uint32_t> group_done;       // one k_verify ticket counter per lane (a launch uses the one of its first lane)
   // Result records: pinned host memory the last workgroup of k_verify writes directly (no read-back copy in the stream)
@@ -162,7 +163,7 @@ struct s4p_ctx {
     static size_t blob_words(size_t n_q) { return 2 * n_q + 8 + 4 * n_q; }      // n_leaf <= n_seq <= n_q
     float eps_unit[2] = {0, 0}, n_radius[2] = {0, 0}, distance[2] = {0, 0}, normal_angle[2] = {0, 0};
   };
-  static constexpr int kStageSlots = 40;   // 0..19: self-staging of s4p_try_base_async; 20..39: a threaded driver
+  static constexpr int kStageSlots = 56;   // 0..27: self-staging of s4p_try_base_async; 28..55: a threaded driver
   StageSlot stage[kStageSlots];
   uint32_t stage_rr = 0;             // round-robin slot for the self-staging (single-thread) paths
   int cur = 0;                       // slot used by the call in progress
@@ -413,7 +414,7 @@ int32_t quad_params(s4p_ctx* c, float inv1, float inv2, float thr2, PrepParams& 
     HIPCHK(c, hipMemsetAsync(L.ht_heads.p, 0, L.ht_heads.n * 8, L.stream));
     L.epoch = 1;
   }
-  HashTable ht{L.ht_keys.p, L.ht_heads.p, L.ht_mask, L.epoch, &L.ctr.p->m1, uint32_t(L.cap_pairs)};
+  HashTable ht{L.ht_keys.p, L.ht_heads.p, L.ht_mask, L.epoch, &L.ctr.p->m1, uint32_t(L.cap_pairs), 0u};
   P1 = PrepParams{};
   P1.ux = c->ux.p; P1.uy = c->uy.p; P1.uz = c->uz.p; P1.qx = c->qx.p; P1.qy = c->qy.p; P1.qz = c->qz.p;
   P1.ab = L.ab1.p; P1.m_dev = &L.ctr.p->m1; P1.cap = uint32_t(L.cap_pairs); P1.invariant = inv1; P1.qg = qg;
@@ -493,7 +494,6 @@ int32_t launch_verify_group(s4p_ctx* c, const int* lanes, int n, hipStream_t vs)
   V.count_tests = c->prof_points ? 1 : 0;
   V.prune = c->best_hint;
   V.ablate = c->ablate;
-  V.cyc = c->cyc.p;
   if (c->prof_events) HIPCHK(c, hipEventRecord(c->ev[lanes[0]][0], vs));
   const bool lean = c->use_lean();                           // a bound is in force: the lean sweep (s4p_kernels.hip.hpp)
   const size_t lds = lean ? c->lean_lds_bytes() : c->verify_lds_bytes();
@@ -838,6 +838,14 @@ int32_t finish_result(s4p_ctx* c, s4p_base_result* r, bool fused) {
       c->est_m1 = std::max(d.m1, c->est_m1 - c->est_m1 / 16u);
       c->est_m2 = std::max(d.m2, c->est_m2 - c->est_m2 / 16u);
     }
+    if (fused && (d.overflow & 8u) && !(d.overflow & 3u)) {
+      // the cell hash of this base was sized from the registration's earlier bases (set-1 preparation inside k_pairs2) and this
+      // base has more pairs than that: its pair count is exact (the counter kept counting), est_m1 holds it now -- once more
+      if (attempt >= 4) S4P_FAIL(c, S4P_ERR_STATE, "set-1 cell hash: the size estimate keeps failing");
+      c->prep_redos++;
+      if (int32_t rc = relaunch_base(c)) return rc;
+      continue;
+    }
     if (!d.overflow) {
       if (int32_t rc = settle_borderline(c, d, bf)) return rc;
       std::memset(r, 0, sizeof(*r));
@@ -885,6 +893,17 @@ int32_t prepare_base(s4p_ctx* c, int32_t slot, const int32_t* base_ids, float in
   const s4p_ctx::StageSlot& st = c->stage[slot];
   R.up_src = st.blob.p; R.up_dst = L.seqbuf.p;
   R.up_bytes = (size_t(st.off[1]) + s4p_ctx::StageSlot::set_words(st.n_seq[1], st.n_leaf[1])) * sizeof(uint32_t);      // both sets, one copy
+  // Set-1 preparation inside k_pairs2 when the registration's recent bases say how large the cell hash has to be (est_m1 with
+  // 50 % head-room, 4 slots per pair, >= 64 Ki, a power of two within the allocation); otherwise -- first bases, or after a base
+  // that needed more -- the k_prep launch sizes the table from the final count on the device.
+  R.fused_prep = c->fuse_prep && c->est_m1 != 0u;
+  if (R.fused_prep) {
+    const uint64_t want = std::max<uint64_t>(65536u, 4ull * (uint64_t(c->est_m1) * 3u / 2u));      // (a floor of 64 Ki slots: a redo costs far more than a sparser table)
+    const uint32_t fm = std::min<uint32_t>(next_pow2(want) - 1u, L.ht_mask);
+    R.p1.ht.fixed_mask = fm; R.q.ht.fixed_mask = fm;
+    PairParams& S0 = R.pp.set[0].pair;
+    S0.prep_on = 1; S0.prep = R.p1; S0.prep_overflow = &L.ctr.p->overflow;
+  }
   R.q.do_gate = 1; R.q.gate = gate_params(c, R.bf);
   R.q.slice_num = c->slice_num; R.q.slice_den = c->slice_den;
   c->slot_q[c->cur] = R.q;                                // (the chunk loop relaunches it range by range if the quads do not fit)
@@ -921,7 +940,10 @@ int32_t flush_lanes(s4p_ctx* c, const int* lanes, int n, hipStream_t st) {
   if (int32_t rc = launch_pairs_kernel(c, PG, n, 2, st)) return rc;
   if (c->prof_stages) HIPCHK(c, hipEventRecord(c->ev[lanes[0]][3], st));
   lap(3);
-  launch_prep_group(G1, n, st, c->est_m1);
+  { // the bases whose set-1 preparation does not ride inside k_pairs2 (no size estimate yet) get the k_prep launch
+    PrepGroup GP{}; int np = 0;
+    for (int b = 0; b < n; ++b) if (!c->lane[lanes[b]].rec.fused_prep) GP.base[np++] = G1.base[b];
+    if (np) launch_prep_group(GP, np, st, c->est_m1); }
   lap(4);
   launch_quads_group(c, GQ, n, st, c->est_m2);
   HIPCHK(c, hipGetLastError());
@@ -1012,6 +1034,7 @@ int32_t s4p_create(const s4p_options* opt, const s4p_limits* lim, int32_t device
     if (c->ablate) fprintf(stderr, "super4pcs_amd: S4P_ABLATE=%d is set: k_verify skips work, every result of this context is invalid\n", c->ablate);
   }
   if (const char* vb = getenv("S4P_VERIFY_BLOCKS")) { const int v = atoi(vb); if (v >= 64 && v <= kVerifyMaxBlocks) { c->verify_blocks = uint32_t(v); c->verify_blocks_fixed = true; c->verify_blocks_env = true; } }   // tuning knob
+  if (const char* fp = getenv("S4P_FUSE_PREP")) c->fuse_prep = atoi(fp) != 0;
   if (const char* gr = getenv("S4P_GROUP")) { const int v = atoi(gr); if (v >= 1 && v <= kGroupMax) c->group = v; }
   c->trace_launch = getenv("S4P_TRACE_LAUNCH") != nullptr;
   c->debug = getenv("S4P_DEBUG") != nullptr;
@@ -1069,9 +1092,6 @@ int32_t s4p_create(const s4p_options* opt, const s4p_limits* lim, int32_t device
   if ((e = hipStreamCreateWithFlags(&c->sel_stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
   if ((e = c->sel_draws.alloc(size_t(kSelectDraws) * kSelectBatch)) != hipSuccess || (e = c->sel_rec.alloc(kSelectBatch)) != hipSuccess) return fail(e, "hipMalloc selection buffers");
   if ((e = c->sel_hdraws.alloc(size_t(kSelectDraws) * kSelectBatch)) != hipSuccess || (e = c->sel_hrec.alloc(kSelectBatch)) != hipSuccess) return fail(e, "hipHostMalloc selection buffers");
-#if S4P_CYCLE_PROF
-  if ((e = c->cyc.alloc(16)) != hipSuccess || (e = hipMemset(c->cyc.p, 0, 16 * sizeof(unsigned long long))) != hipSuccess) return fail(e, "hipMalloc cycle counters");
-#endif
   *out = c;
   return S4P_OK;
 }
@@ -1166,21 +1186,11 @@ void s4p_destroy(s4p_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   for (auto& L : c->lane) if (L.stream) (void)hipStreamSynchronize(L.stream);
-#if S4P_CYCLE_PROF
-  if (c->cyc.p) {
-    unsigned long long v[16] = {0};
-    if (hipMemcpy(v, c->cyc.p, sizeof v, hipMemcpyDeviceToHost) == hipSuccess && v[8])
-      fprintf(stderr, "[s4p cycle prof] waves %llu candidates %llu drains %llu exact batches %llu | per wave (cycles): lifetime %.0f staging %.0f loop %.0f "
-                      "(sweep %.0f drain %.0f exact %.0f record wait %.0f) tail %.0f\n", v[8], v[9], v[10], v[11], double(v[0]) / v[8], double(v[1]) / v[8],
-              double(v[2]) / v[8], double(v[3]) / v[8], double(v[4]) / v[8], double(v[5]) / v[8], double(v[6]) / v[8], double(v[7]) / v[8]);
-  }
-#endif
   if (c->trace_launch && c->lt_n)
     fprintf(stderr, "{\"s4p_trace\": \"launch\", \"bases\": %llu, \"us_per_base\": {\"params\": %.2f, \"uploads\": %.2f, \"k_pairs\": %.2f, \"k_prep\": %.2f, \"k_quads\": %.2f, "
-                    "\"k_verify\": %.2f, \"result\": %.2f, \"wait\": %.2f, \"octree\": %.2f}}\n", (unsigned long long)c->lt_n, c->lt[0] / c->lt_n * 1e6, c->lt[1] / c->lt_n * 1e6,
+                    "\"k_verify\": %.2f, \"result\": %.2f, \"wait\": %.2f, \"octree\": %.2f}, \"group_launches\": %llu, \"prep_redos\": %llu}\n", (unsigned long long)c->lt_n, c->lt[0] / c->lt_n * 1e6, c->lt[1] / c->lt_n * 1e6,
             c->lt[2] / c->lt_n * 1e6, c->lt[3] / c->lt_n * 1e6, c->lt[4] / c->lt_n * 1e6, c->lt[5] / c->lt_n * 1e6, c->lt[6] / c->lt_n * 1e6,
-            c->host_wait_s / c->lt_n * 1e6, c->host_octree_s / c->lt_n * 1e6);
-  c->cyc.free();
+            c->host_wait_s / c->lt_n * 1e6, c->host_octree_s / c->lt_n * 1e6, (unsigned long long)c->lt_groups, (unsigned long long)c->prep_redos);
   c->greach.free(); c->glist_hdr.free(); c->gnbr.free();
   c->gcoarse.free(); c->q4.free(); c->q4v.free(); c->qquant.free(); c->qsoa.free();
   c->qx.free(); c->qy.free(); c->qz.free(); c->ux.free(); c->uy.free(); c->uz.free();
@@ -1374,7 +1384,7 @@ int32_t s4p_set_clouds(s4p_ctx* c, const float* px, const float* py, const float
       if (!(0.5f * c->qq.step[k] * c->hgrid.inv_h < 0.004f)) fine_enough = false;
     }
     const size_t lds_room = size_t(c->verify_blocks <= 256u ? kVerifyLdsOnePerCu : kVerifyLdsBudget);      // (verify_blocks was settled by the structure build above)
-    c->qlds = fine_enough && n_q <= int64_t(kLdsQueries) && getenv("S4P_NO_QLDS") == nullptr &&
+    c->qlds = fine_enough && n_q <= int64_t(kLdsQueries) &&
               c->gcoarse.n * 4 + size_t((n_q + int64_t(kSweepStep) - 1) & ~(int64_t(kSweepStep) - 1)) * 8 + size_t(c->verify_threads / 64) * kQueueWordsPerWave * 4 <= lds_room;
     std::vector<uint2> packed((size_t)n_q);
     for (int64_t i = 0; i < n_q; ++i) {
@@ -1391,17 +1401,17 @@ int32_t s4p_set_clouds(s4p_ctx* c, const float* px, const float* py, const float
     c->qq.packed = c->qquant.p;
     // float copy for the lean sweep (early-exit mode): x | y | z, each padded to a multiple of a sweep step with far-away points
     c->lean = false; c->lean_lds = false; c->qsoa.free();
-    if (getenv("S4P_NO_LEAN") == nullptr) {
+    {
       const size_t n_pad = n_pad_q;
       const size_t fixed = c->gcoarse.n * 4 + size_t(c->verify_threads / 64) * kLeanQueue * 2;
-      if (n_q <= int64_t(kLeanMaxQueries) && fixed + n_pad * 12 <= lds_room && getenv("S4P_LEAN_GLOBAL") == nullptr) {
+      if (n_q <= int64_t(kLeanMaxQueries) && fixed + n_pad * 12 <= lds_room) {
         std::vector<float> soa(3 * n_pad, kLeanPad);
         for (int64_t i = 0; i < n_q; ++i) { soa[size_t(i)] = qv[size_t(i)].x; soa[n_pad + size_t(i)] = qv[size_t(i)].y; soa[2 * n_pad + size_t(i)] = qv[size_t(i)].z; }
         HIPCHK(c, c->qsoa.alloc(3 * n_pad));
         HIPCHK(c, hipMemcpy(c->qsoa.p, soa.data(), 3 * n_pad * sizeof(float), hipMemcpyHostToDevice));
         c->lean = c->lean_lds = true;
       } else if (n_q <= 65535 && fixed <= size_t(kVerifyLdsBudget)) {
-        c->lean = true;                                      // queries from global memory (S4P_LEAN_GLOBAL=1 forces this form: test aid)
+        c->lean = true;                                      // queries from global memory (samples that do not fit LDS: the 20 000-point sample)
       }
     }
   }

@@ -136,8 +136,8 @@ constexpr int kCoarseMaxWords = 9216;              // 36 KB (two k_verify workgr
 // (structure streaming from HBM, chunk passes) share 160 KB: 80 KB each.  With ONE workgroup per CU (structure cache
 // resident: verify_blocks <= 256) the quantised query copy may take more -- measured with 512-entry queues at 768 threads,
 // where it no longer fits 80 KB (tools/r3_run16.sh): float queries from global memory 125.5 M candidates/s, LDS copy 130.2 M.
-constexpr int kVerifyLdsBudget = 80 * 1024 - 768;
-constexpr int kVerifyLdsOnePerCu = 112 * 1024 - 768;
+constexpr int kVerifyLdsBudget = 80 * 1024 - 1024;      // (minus VerifyShared, 0.8 KB)
+constexpr int kVerifyLdsOnePerCu = 112 * 1024 - 1024;
 
 // value held by every lane of the wave -> SGPR
 __device__ __forceinline__ float wave_uniform(float v) {
@@ -833,22 +833,6 @@ typedef float f4_t __attribute__((ext_vector_type(4)));
 
 struct LeanLds { const uint32_t* coarse; const float* qx; const float* qy; const float* qz; uint16_t* queue; };
 
-// -DS4P_CYCLE_PROF=1 (lab build, tools/r4): every wave of the lean k_verify adds the shader-clock cycles it spent in each
-// phase to VerifyParams::cyc -- where a wave's lifetime goes, which no counter of the SQ tells directly.
-#ifndef S4P_CYCLE_PROF
-#define S4P_CYCLE_PROF 0
-#endif
-struct CycleProf { unsigned long long sweep, drain, exact; uint32_t n_drain, n_exact; };
-#if S4P_CYCLE_PROF
-#define S4P_CYC_NOW() __builtin_readcyclecounter()
-#else
-#define S4P_CYC_NOW() 0ull
-#endif
-#if S4P_CYCLE_PROF == 1            // 1: stamps inside the sweep loop too (they serialise it: relative shares only); 2: per-wave phases only
-#define S4P_CYC_FINE() __builtin_readcyclecounter()
-#else
-#define S4P_CYC_FINE() 0ull
-#endif
 
 // LDS word `index` of the array at byte address `base` (wave-uniform): one shift-add for the address (the compiler's own
 // form of base + 4 * (x >> 5) is shift, mask, add)
@@ -904,8 +888,7 @@ __device__ __forceinline__ uint32_t exact_pair_lean(const LcpGrid& g, const LcpT
 }
 
 template <bool COUNT, bool SKIP_FINE, bool QL>
-__device__ __forceinline__ uint32_t wave_lcp_count_lean(const LcpGrid& g, const LcpTask& K, const LeanLds& L, const float4* Tsrc, const float4 t0, const float4 t1, const float4 t2,
-                                                        CycleProf& CP) {
+__device__ __forceinline__ uint32_t wave_lcp_count_lean(const LcpGrid& g, const LcpTask& K, const LeanLds& L, const float4* Tsrc, const float4 t0, const float4 t1, const float4 t2) {
   // t0..t2: the rows at Tsrc, already in registers (k_verify fetches a candidate's record while the previous one is swept); the
   // rare drain / exact batches read them again through Tsrc
   const uint32_t lane = threadIdx.x & 63u;
@@ -968,7 +951,6 @@ __device__ __forceinline__ uint32_t wave_lcp_count_lean(const LcpGrid& g, const 
   for (uint32_t base = 0;; base += kSweepStep) {
     const bool more = base < n_pad;                        // wave-uniform
     const uint32_t unswept = K.n_q - min(base + kSweepStep, K.n_q);
-    const unsigned long long cyc_a = S4P_CYC_FINE();
     if (more) {
       // one step = kSweepChunks chunks in four phases, so that the LDS reads of all chunks are in flight together and
       // dependent MFMAs of one chunk are separated by the other chunks'
@@ -1001,13 +983,9 @@ __device__ __forceinline__ uint32_t wave_lcp_count_lean(const LcpGrid& g, const 
       // upper bound of what this candidate can still reach: confirmed + waiting (either kind) + not swept yet
       if (cnt + nb + na + unswept <= K.prune) { abandoned = true; break; }
     }
-    const unsigned long long cyc_b = S4P_CYC_FINE();
-    if (S4P_CYCLE_PROF == 1) CP.sweep += cyc_b - cyc_a;
     if (!more || nb + na + kSweepStep > kLeanQueue) {
       const uint32_t rest = more ? unswept : 0u;
       const bool dead = drain(rest);
-      const unsigned long long cyc_c = S4P_CYC_FINE();
-      if (S4P_CYCLE_PROF == 1) { CP.drain += cyc_c - cyc_b; CP.n_drain += 1u; }
       if (dead) { abandoned = true; break; }
       while ((more && nb + 2u * kSweepStep > kLeanQueue) || (!more && nb != 0u)) {
         if (cnt + nb + rest <= K.prune) { abandoned = true; break; }
@@ -1015,14 +993,12 @@ __device__ __forceinline__ uint32_t wave_lcp_count_lean(const LcpGrid& g, const 
         const bool va = lane < n, vb = lane + 64u < n;
         const uint32_t ia = uint32_t(q[nb - n + min(lane, n - 1u)]), ib = uint32_t(q[nb - n + min(lane + 64u, n - 1u)]);
         if (COUNT) { if (lane == 0) atomicAdd(K.point_tests + 2, (unsigned long long)n); }      // list headers read (l1_pass)
-        const unsigned long long cyc_d = S4P_CYC_FINE();
         if (!SKIP_FINE) {
           const uint32_t h = exact_pair_lean<COUNT, QL>(g, K, L, Tsrc, va, ia, vb, ib);
           cnt += uint32_t(__popcll(__builtin_amdgcn_ballot_w64((h & 1u) != 0u))) + uint32_t(__popcll(__builtin_amdgcn_ballot_w64((h & 2u) != 0u)));
         }
         nb -= n;
         lds_fence();
-        if (S4P_CYCLE_PROF == 1) { CP.exact += S4P_CYC_FINE() - cyc_d; CP.n_exact += 1u; }
       }
     }
     if (!more || abandoned) break;
@@ -1209,11 +1185,16 @@ struct HashTable {
   uint32_t epoch;
   const uint32_t* m1_dev;      // device count of the set-1 pairs of this base (final when k_prep / k_quads run)
   uint32_t cap1;
+  uint32_t fixed_mask;         // != 0: the slots this base uses, fixed by the host from the registration's recent bases (hash_mask)
 };
 // Slots a base really uses: 4 x its set-1 pairs, rounded up to a power of two (>= 4096) -- a few MB that stay in L2 instead
 // of random probes over the whole allocation (HBM + TLB misses on every hop).  Builder (k_prep) and reader (k_quads)
 // derive the same mask from the same device counter; entries of earlier epochs, wherever they lie, read as empty.
+// When the set-1 records are prepared INSIDE k_pairs2 (PairParams::prep_on) the count is not final yet while the table is being
+// built: the host then fixes the size from what the registration's recent bases needed (fixed_mask), with head-room, and an
+// entry whose index would push the load above one half is refused (overflow bit 8: the host redoes the base with the exact size).
 __device__ __forceinline__ uint32_t hash_mask(const HashTable& ht) {
+  if (ht.fixed_mask != 0u) return ht.fixed_mask;
   const uint32_t m = min(*ht.m1_dev, ht.cap1);
   if (m > (ht.mask >> 2)) return ht.mask;                 // (also keeps 4 * m inside 32 bits)
   const uint32_t want = max(4u * m, 4096u);
@@ -1379,6 +1360,10 @@ struct PairParams {
   // float whose libm acosf passes (found by the host with libm itself, s4p_capi.hip angle_threshold); |d| > 1 gives NaN in
   // the reference, i.e. no pair.
   float seg1[3]; float cos_min;
+  // Fused pass, first pair set: the FindCongruentQuadrilaterals preparation of every appended pair (invariant point, cell,
+  // direction bucket, world point, insert into the cell hash: what k_prep does in a launch of its own) runs where the pair is
+  // appended -- one launch and one dependent pass over the pair list less per base (round 5).
+  int prep_on; PrepParams prep; uint32_t* prep_overflow;
 };
 
 __device__ __forceinline__ bool sphere_box(float cx, float cy, float cz, float r, float4 leaf) {
@@ -1507,8 +1492,13 @@ __global__ __launch_bounds__(64 * kPair2Waves) void k_pairs2(PairGroup PG) {
         const uint32_t w = st_e[wave][e], pId = w & 0xFFFFu, sl = w >> 16;
         const uint32_t j = P.seq_id[sl] & 0xFFFFu;
         // pairs->emplace_back(j, i) then pairs->emplace_back(i, j)   pairCreationFunctor.h:214-215
-        P.ab[at] = second ? make_int2(int(pId), int(j)) : make_int2(int(j), int(pId));
+        const int2 ab = second ? make_int2(int(pId), int(j)) : make_int2(int(j), int(pId));
+        P.ab[at] = ab;
         P.okey[at] = 2u * (pId * P.n_seq + sl) + second;
+        if (P.prep_on) {                                     // (uniform) first pair set of a fused pass: its preparation, here
+          if (at <= (P.prep.ht.fixed_mask >> 1)) prep1_item(P.prep, at, ab);
+          else atomicOr(P.prep_overflow, 8u);                // more pairs than the table was sized for: the host redoes the base
+        }
       } else {
         atomicOr(P.overflow, P.overflow_bit);
       }
@@ -1907,7 +1897,6 @@ struct VerifyParams {
   uint32_t* group_done;                                 // workgroups that have published their bests (the last one selects the winners); left at 0
   uint32_t seq;                                         // launch number, written last into every result record
   uint32_t prune;                                       // best inlier count of the registration at launch (LcpTask::prune), 0 = count every candidate in full
-  unsigned long long* cyc;                              // S4P_CYCLE_PROF builds: 16 accumulators (see k_verify), else unused
   int count_tests;                                      // instrumentation counters are live: carry them into res
   int ablate;                                           // S4P_ABLATE debugging only (0 = full kernel)
 };
@@ -1965,11 +1954,6 @@ __global__ __launch_bounds__(kVerifyMaxThreads, 6) void k_verify(VerifyParams P)
       ? reinterpret_cast<uint32_t*>(reinterpret_cast<uint16_t*>(s_mem + P.grid.coarse_words + lean_q_words) + (blockDim.x >> 6) * kLeanQueue)
       : reinterpret_cast<uint32_t*>(s_q + (QLDS ? n_pad : 0u)) + (blockDim.x >> 6) * kQueueWordsPerWave);
   uint32_t& s_next = S.next; uint32_t& s_last = S.last;
-  const unsigned long long cyc_entry = S4P_CYC_NOW();
-  unsigned long long cyc_staged = cyc_entry, cyc_loop_end = cyc_entry, cyc_wait = 0ull;
-  uint32_t n_cand = 0;
-  CycleProf CP{0ull, 0ull, 0ull, 0u, 0u};
-  (void)cyc_staged; (void)cyc_loop_end; (void)cyc_wait; (void)n_cand;
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const uint32_t nb = P.n_bases;
   // Work split: every workgroup owns a fixed share of every base's gated candidate list (static: a single-address global
@@ -2009,7 +1993,6 @@ __global__ __launch_bounds__(kVerifyMaxThreads, 6) void k_verify(VerifyParams P)
     // the NEXT candidate's record in registers while the current one is swept was measured in round 4: 16 more VGPRs, no gain;
     // so was finishing "heavy" candidates -- those that stay alive through the whole sweep -- by the whole workgroup after the
     // ticket loop: slower, most of them die in their first exact batch.  profiles/HISTORY.md.)
-    cyc_staged = S4P_CYC_NOW();
     // The loop body has NO lane-dependent control flow of its own: the ticket is drawn by wave_ticket (lane 0 adds, inside one asm
     // statement), the candidate's bookkeeping afterwards is done by all lanes with identical values.  With `if (lane == 0)` regions on both sides of the loop's back edge the compiler threaded lane 0's
     // path through the edge and re-entered the loop with lanes 1..63 alone -- readfirstlane then read THEIR (zero) ticket: the
@@ -2028,12 +2011,7 @@ __global__ __launch_bounds__(kVerifyMaxThreads, 6) void k_verify(VerifyParams P)
       const float4 r0 = src[0], r1 = src[1], r2 = src[2], r3 = src[3];
       K.point_tests = &B.ctr->point_tests; K.pruned = &S.pruned[bsel];
       uint32_t cnt;
-#if S4P_CYCLE_PROF == 1
-      { const unsigned long long w0 = S4P_CYC_NOW();          // how long the record of THIS candidate keeps the wave waiting
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        cyc_wait += S4P_CYC_NOW() - w0; ++n_cand; }
-#endif
-      if (LEAN) cnt = P.ablate == 1 ? wave_lcp_count_lean<COUNT, true, QLDS>(P.grid, K, LL, src, r0, r1, r2, CP) : wave_lcp_count_lean<COUNT, false, QLDS>(P.grid, K, LL, src, r0, r1, r2, CP);
+      if (LEAN) cnt = P.ablate == 1 ? wave_lcp_count_lean<COUNT, true, QLDS>(P.grid, K, LL, src, r0, r1, r2) : wave_lcp_count_lean<COUNT, false, QLDS>(P.grid, K, LL, src, r0, r1, r2);
       else cnt = P.ablate == 1 ? wave_lcp_count_auto<COUNT, true, QLDS>(P.grid, K, s_coarse, s_q, s_queue, src)
                                : wave_lcp_count_auto<COUNT, false, QLDS>(P.grid, K, s_coarse, s_q, s_queue, src);
       { // (the record's last 16 bytes are re-read: a line this wave has just held; nothing lives in registers across the sweep)
@@ -2058,9 +2036,6 @@ __global__ __launch_bounds__(kVerifyMaxThreads, 6) void k_verify(VerifyParams P)
       __builtin_amdgcn_wave_barrier();
     }
   }
-#if S4P_CYCLE_PROF
-  cyc_loop_end = S4P_CYC_NOW();
-#endif
   // ---- selection: wave bests (LDS) -> workgroup best -> slot; the last workgroup to finish reduces the slots ----
   auto wave_reduce = [&](WaveBest& w) {
 #pragma unroll
@@ -2078,15 +2053,6 @@ __global__ __launch_bounds__(kVerifyMaxThreads, 6) void k_verify(VerifyParams P)
     return r;
   };
   __syncthreads();
-#if S4P_CYCLE_PROF
-  if (LEAN && P.cyc != nullptr && lane == 0) {              // per wave: [0] lifetime up to here [1] staging [2] candidate loop [3] sweep [4] drain [5] exact
-    const unsigned long long now = S4P_CYC_NOW();           //           [6] record wait [7] tail barrier [8] waves [9] candidates [10] drains [11] exact batches
-    atomicAdd(P.cyc + 0, now - cyc_entry); atomicAdd(P.cyc + 1, cyc_staged - cyc_entry); atomicAdd(P.cyc + 2, cyc_loop_end - cyc_staged);
-    atomicAdd(P.cyc + 3, CP.sweep); atomicAdd(P.cyc + 4, CP.drain); atomicAdd(P.cyc + 5, CP.exact); atomicAdd(P.cyc + 6, cyc_wait);
-    atomicAdd(P.cyc + 7, now - cyc_loop_end); atomicAdd(P.cyc + 8, 1ull); atomicAdd(P.cyc + 9, (unsigned long long)n_cand);
-    atomicAdd(P.cyc + 10, (unsigned long long)CP.n_drain); atomicAdd(P.cyc + 11, (unsigned long long)CP.n_exact);
-  }
-#endif
   if (threadIdx.x == 0) {
     for (uint32_t b = 0; b < nb; ++b) {
       if (S.pruned[b]) atomicAdd(&P.b[b].ctr->pruned, S.pruned[b]);
