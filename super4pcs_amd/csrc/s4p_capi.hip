@@ -229,6 +229,7 @@ struct s4p_ctx {
   bool debug = false;                // S4P_DEBUG=1 (lab aid): launches and waits on stderr
   bool trace_launch = false; double lt[8] = {0, 0, 0, 0, 0, 0, 0, 0}; uint64_t lt_n = 0, lt_groups = 0;
   int lane_group_n[kMaxLanes] = {0};  // bases of the launch a lane was the FIRST lane of (its profiling events), else 0
+  bool ev_pending[kMaxLanes] = {false}, ev_fused[kMaxLanes] = {false};      // events of that launch not read yet (harvest_events)
   double set_clouds_s[4] = {0, 0, 0, 0};      // last s4p_set_clouds: host copies + unit frame + grid plan | device build of the LCP structure | Q-side uploads | total
 
   size_t verify_lds_bytes() const {
@@ -440,6 +441,8 @@ GateParams gate_params(s4p_ctx* c, const BaseFrame& bf) {
   return G;
 }
 
+void harvest_events(s4p_ctx* c, int li);
+
 // Group launches: the first n records of a group, on stream st.
 uint32_t est_grid(uint32_t est, uint32_t full) {             // workgroups of 256 threads for an estimated entry count (+50 %), within [64, full]
   if (est == 0u) return full;
@@ -494,6 +497,7 @@ int32_t launch_verify_group(s4p_ctx* c, const int* lanes, int n, hipStream_t vs)
   V.count_tests = c->prof_points ? 1 : 0;
   V.prune = c->best_hint;
   V.ablate = c->ablate;
+  harvest_events(c, lanes[0]);
   if (c->prof_events) HIPCHK(c, hipEventRecord(c->ev[lanes[0]][0], vs));
   const bool lean = c->use_lean();                           // a bound is in force: the lean sweep (s4p_kernels.hip.hpp)
   const size_t lds = lean ? c->lean_lds_bytes() : c->verify_lds_bytes();
@@ -600,19 +604,28 @@ int32_t grow_lane(s4p_ctx* c, int li, uint64_t mp, uint64_t mq) {
   return S4P_OK;
 }
 
+// HIP-event times of the last launch whose first lane was `li`, into the profile (once).
+void harvest_events(s4p_ctx* c, int li) {
+  if (!c->ev_pending[li]) return;
+  c->ev_pending[li] = false;
+  float ms = 0.f;
+  hipError_t e = hipEventElapsedTime(&ms, c->ev[li][0], c->ev[li][1]);
+  if (e == hipErrorNotReady) { (void)hipEventSynchronize(c->ev[li][1]); e = hipEventElapsedTime(&ms, c->ev[li][0], c->ev[li][1]); }
+  if (e == hipSuccess) { c->prof.verify_launches++; c->prof.verify_ms_total += ms; }
+  if (c->ev_fused[li]) {
+    if (hipEventElapsedTime(&ms, c->ev[li][2], c->ev[li][3]) == hipSuccess) { c->prof.pairs_ms_total += ms; c->prof.pairs_launches += 2; }
+    if (hipEventElapsedTime(&ms, c->ev[li][3], c->ev[li][4]) == hipSuccess) { c->prof.quads_ms_total += ms; c->prof.quads_launches += 1; }
+  }
+}
+
 void account_profile(s4p_ctx* c, const DevCounters& d, bool fused) {
   if (c->prof_events) {                                    // per base
     c->prof.verify_candidates += d.C; c->prof.verify_quads += std::min<uint64_t>(d.K, c->lane[c->cur].cap_quads); c->prof.verify_queries += uint64_t(d.C) * c->n_q;
   }
-  if (c->prof_events && c->lane_group_n[c->cur] > 0) {     // per launch: the events belong to the first lane of a group launch
-    float ms = 0.f;
-    (void)hipEventSynchronize(c->ev[c->cur][1]);           // (the host has seen the result record, the stream may not have reached the closing event yet)
-    if (hipEventElapsedTime(&ms, c->ev[c->cur][0], c->ev[c->cur][1]) == hipSuccess) { c->prof.verify_launches++; c->prof.verify_ms_total += ms; }
-    if (fused && c->prof_stages) {
-      if (hipEventElapsedTime(&ms, c->ev[c->cur][2], c->ev[c->cur][3]) == hipSuccess) { c->prof.pairs_ms_total += ms; c->prof.pairs_launches += 2; }
-      if (hipEventElapsedTime(&ms, c->ev[c->cur][3], c->ev[c->cur][4]) == hipSuccess) { c->prof.quads_ms_total += ms; c->prof.quads_launches += 1; }
-    }
-  }
+  // (the events of the launch are read LATER -- harvest_events: when the lane is launched again, or by s4p_profile_get: the host
+  // has seen the result record, the stream may not have reached the closing event yet, and waiting for it here would stall
+  // the launch thread by a few microseconds per launch inside the timed region)
+  if (c->prof_events && c->lane_group_n[c->cur] > 0) { c->ev_pending[c->cur] = true; c->ev_fused[c->cur] = fused && c->prof_stages; }
   c->prof.verify_pruned += d.pruned;
   if (c->prof_points) { c->prof.verify_point_tests += d.point_tests; c->prof.verify_l0_pass += d.l0_pass; c->prof.verify_l1_pass += d.l1_pass; c->prof.verify_l2_pass += d.l2_pass; }
 }
@@ -930,6 +943,7 @@ int32_t flush_lanes(s4p_ctx* c, const int* lanes, int n, hipStream_t st) {
     PG.base[b] = L.rec.pp; G1.base[b] = L.rec.p1; GQ.base[b] = L.rec.q;
     L.pending = false;
   }
+  harvest_events(c, lanes[0]);                              // (the previous launch's, before its events are recorded again)
   if (c->prof_stages) HIPCHK(c, hipEventRecord(c->ev[lanes[0]][2], st));
   lap(1);
   for (int b = 0; b < n; ++b) {
@@ -2047,6 +2061,8 @@ int32_t s4p_profile_enable(s4p_ctx* c, int32_t enable_events, int32_t count_poin
 }
 int32_t s4p_profile_get(s4p_ctx* c, s4p_profile* out, int32_t reset) {
   if (!c || !out) return S4P_ERR_BAD_ARG;
+  (void)hipSetDevice(c->device);
+  for (int li = 0; li < c->n_lanes; ++li) harvest_events(c, li);      // event times of the launches not read yet
   c->prof.host_octree_s = c->host_octree_s; c->prof.host_wait_s = c->host_wait_s;
   if (reset) { c->host_octree_s = 0; c->host_wait_s = 0; }
   *out = c->prof;
