@@ -1009,12 +1009,16 @@ def main():
         l2 = None
         if mean("TCC_HIT_sum") is not None and mean("TCC_MISS_sum") is not None:
             req = mean("TCC_HIT_sum") + mean("TCC_MISS_sum")
-            ex_ms = exclusive["avg_launch_ms"] if exclusive else avg_ms
+            # the launches of the counter passes cover a group of bases like the timed ones and are serialised by the collection: their
+            # OWN duration (kernel trace of the same pass) is the time these requests were made in
+            kv_us = (pmc_kernels.get("k_verify") or {}).get("avg_us")
+            ex_ms = kv_us * 1e-3 if kv_us else (exclusive["avg_launch_ms"] if exclusive else avg_ms)
             l2 = {"hit_rate": mean("TCC_HIT_sum") / max(req, 1), "requests_per_launch": req,
                   "GBps_at_128B_per_request": req * 128.0 / (ex_ms * 1e-3) / 1e9, "peak_GBps": L2_PEAK_GBS,
                   "frac": req * 128.0 / (ex_ms * 1e-3) / 1e9 / L2_PEAK_GBS,
+                  "launch_ms": ex_ms,
                   "note": "TCC_HIT_sum + TCC_MISS_sum per launch x 128 B (an upper bound: a 16-B gather moves at most one line) over the kernel's "
-                          "own launch time"}
+                          "own launch time in the counter pass (launches serialised, a group of bases per launch)"}
         # all four kernels of a device pass: own duration under the counter passes (launches serialised), issue /
         # wait shares and L2 hit rate from the same passes; a launch covers a GROUP of bases
         kernels_tbl = {}

@@ -57,7 +57,7 @@ if a and w:
 if t:
     ct = counters(t)
     req = mean(ct["TCC_HIT_sum"]) + mean(ct["TCC_MISS_sum"])
-    ex = r["per_launch"]["exclusive"]["avg_launch_ms"] if r["per_launch"].get("exclusive") else r["per_launch"]["avg_launch_ms"]
+    ex = r["l2"].get("launch_ms") or (r["per_launch"]["exclusive"]["avg_launch_ms"] if r["per_launch"].get("exclusive") else r["per_launch"]["avg_launch_ms"])
     show("roofline.l2.hit_rate", mean(ct["TCC_HIT_sum"]) / req, r["l2"]["hit_rate"])
     show("roofline.l2.frac", req * 128 / (ex * 1e-3) / 1e9 / r["l2"]["peak_GBps"], r["l2"]["frac"])
 kt, cc = os.path.join(pdir, "hbm_point_kernel_trace.csv"), os.path.join(pdir, "hbm_point_counter_collection.csv")
