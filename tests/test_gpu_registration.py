@@ -646,3 +646,36 @@ def test_quad_slices_are_a_partition_of_the_base(oracle_mod, s4p_lib_built, part
     assert seen >= 4
     if chunk:
         assert any(g.chunk_stats()["bases"] > 0 for g in ms)
+
+
+@pytest.mark.parametrize("lanes,group", [(1, 1), (6, 1), (5, 2), (7, 3), (14, 2), (9, 3)])
+def test_lanes_and_base_groups_change_no_result(oracle_mod, s4p_lib_built, lanes, group, monkeypatch):
+    """Round 5: consecutive bases in flight form GROUPS that go through every kernel in one launch (k_pairs2 / k_quads by
+    blockIdx.y, k_verify over all their candidate lists, result records written into pinned host memory).  Whatever the
+    packing -- one base per launch, full groups, the partial groups a wait flushes, lane counts that are no multiple of the
+    group size -- a whole registration is the oracle's: same totals, same LCP, same 4x4, same transformed cloud; and with
+    TryOneBase one base at a time (every group launched with a single base) the per-base records are the oracle's too."""
+    from super4pcs_amd import capi
+    monkeypatch.setenv("S4P_LANES", str(lanes))
+    monkeypatch.setenv("S4P_GROUP", str(group))
+    delta, overlap, n_s = 0.01, 0.6, 250
+    P, Q, _ = H.small_pair(30000, delta=delta, seed=29)
+    om, (o_lcp, o_M, o_Q), gm, (g_lcp, g_M, g_Q) = _run_both(oracle_mod, P, Q, delta, overlap, n_s)
+    os_, gi = om.stats(), gm.info()
+    assert "%d lanes in groups of %d" % (lanes, group) in gm.verify_kernel_info()
+    assert (gi.pairs_total, gi.quads_total, gi.candidates_verified) == (os_.n_pairs, os_.n_quads, os_.n_verified)
+    assert g_lcp == o_lcp and np.array_equal(g_M, o_M) and np.max(np.abs(g_Q - o_Q)) <= 1e-4
+    # one base at a time through the same context shape
+    om2 = oracle_mod.Matcher(oracle_mod.make_options(delta, overlap, n_s), full_counts=False, use_kdtree=True, keep_trace=True)
+    om2.init(P, Q)
+    g2 = capi.Matcher(capi.make_options(delta, overlap, n_s))
+    g2.init_full(P, Q)
+    for _ in range(12):
+        g_ok, r = g2.try_one_base()
+        assert om2.try_one_base() == g_ok
+        rec = om2.trace()[0][-1]
+        if rec[0]:
+            assert (r.n_pairs1, r.n_pairs2) == (rec[5], rec[6])
+            if rec[5] and rec[6]:
+                assert (r.n_quads, r.n_verified) == (rec[7], rec[8])
+    assert g2.info().best_lcp == om2.stats().best_lcp
