@@ -139,6 +139,7 @@ struct s4p_ctx {
   // grid-stride pass: slower, same result.  0 = no estimate yet (first bases, stage-level calls): the full grids.
   uint32_t est_m1 = 0, est_m2 = 0;
   bool fuse_prep = true;             // S4P_FUSE_PREP=0: always the k_prep launch (A/B aid)
+  uint32_t pair_split = 2;           // waves that share one (tile, chunk) item of k_pairs2 (S4P_PAIR_SPLIT: 1, 2, 4)
   uint64_t prep_redos = 0;           // bases redone because the estimate-sized cell hash was too small
   uint32_t launch_seq = 0;           // group launches so far (written into the result records: DevCounters::seq)
   DevBuf<uint32_t> group_done;       // one k_verify ticket counter per lane (a launch uses the one of its first lane)
@@ -319,7 +320,7 @@ void fill_pair_params(s4p_ctx* c, int slot, int set, float pair_distance_epsilon
   P.ab = set == 0 ? L.ab1.p : L.ab2.p; P.okey = set == 0 ? L.okey1.p : L.okey2.p;
   P.counter = set == 0 ? &L.ctr.p->m1 : &L.ctr.p->m2;
   P.cap = uint32_t(L.cap_pairs); P.overflow = &L.ctr.p->overflow; P.overflow_bit = set == 0 ? 1u : 2u;
-  P.split = 1u;
+  P.split = c->pair_split;
   { float sx = c->base_xyz[3 * bp2] - c->base_xyz[3 * bp1], sy = c->base_xyz[3 * bp2 + 1] - c->base_xyz[3 * bp1 + 1],
           sz = c->base_xyz[3 * bp2 + 2] - c->base_xyz[3 * bp1 + 2];                 // setBase, pairCreationFunctor.h:135-143
     normalize3(sx, sy, sz);
@@ -333,8 +334,8 @@ int32_t launch_pairs_kernel(s4p_ctx* c, const PairGroup& PG, int n_bases, int n_
   uint32_t n_seq_max = 0;
   for (int b = 0; b < n_bases; ++b) for (int k = 0; k < n_sets; ++k) n_seq_max = std::max(n_seq_max, PG.base[b].set[k].pair.n_seq);
   if (n_seq_max == 0) return S4P_OK;
-  const uint64_t items = uint64_t((c->n_q + 63u) / 64u) * uint64_t((n_seq_max + 63u) / 64u);
-  const uint32_t wgs = uint32_t(std::min<uint64_t>(std::max<uint64_t>((items + kPair2Waves - 1u) / kPair2Waves, 1u), n_sets == 2 ? 128u : 256u));
+  const uint64_t items = uint64_t((c->n_q + 63u) / 64u) * uint64_t((n_seq_max + 63u) / 64u) * c->pair_split;
+  const uint32_t wgs = uint32_t(std::min<uint64_t>(std::max<uint64_t>((items + kPair2Waves - 1u) / kPair2Waves, 1u), (n_sets == 2 ? 128u : 256u) * c->pair_split));
   const dim3 grid(wgs, uint32_t(n_sets == 2 ? 2 * n_bases : 1));
   if (c->angle_pairs) hipLaunchKernelGGL(k_pairs2<true>, grid, dim3(64 * kPair2Waves), 0, st, PG);
   else hipLaunchKernelGGL(k_pairs2<false>, grid, dim3(64 * kPair2Waves), 0, st, PG);
@@ -410,9 +411,10 @@ int32_t quad_params(s4p_ctx* c, float inv1, float inv2, float thr2, PrepParams& 
   quad_setup(c, thr2, qg, cone);
   if (qg.egSize > 1024) S4P_FAIL(c, S4P_ERR_UNSUPPORTED, "FindCongruentQuadrilaterals grid finer than 1024^3 cells (delta/extent too small)");
   L.epoch++;
-  if (L.epoch == 0xFFFFFFFFu) {   // wrap: clear the table once every 4e9 bases
-    HIPCHK(c, hipMemsetAsync(L.ht_keys.p, 0, L.ht_keys.n * 8, L.stream));
-    HIPCHK(c, hipMemsetAsync(L.ht_heads.p, 0, L.ht_heads.n * 8, L.stream));
+  if (L.epoch == 0xFFFFFFFFu) {   // wrap, once every 4e9 bases of a lane: clear the table with nothing in flight anywhere (the base is launched on its group's stream, not necessarily the lane's: ADVICE r05)
+    HIPCHK(c, hipDeviceSynchronize());
+    HIPCHK(c, hipMemset(L.ht_keys.p, 0, L.ht_keys.n * 8));
+    HIPCHK(c, hipMemset(L.ht_heads.p, 0, L.ht_heads.n * 8));
     L.epoch = 1;
   }
   HashTable ht{L.ht_keys.p, L.ht_heads.p, L.ht_mask, L.epoch, &L.ctr.p->m1, uint32_t(L.cap_pairs), 0u};
@@ -1049,6 +1051,7 @@ int32_t s4p_create(const s4p_options* opt, const s4p_limits* lim, int32_t device
   }
   if (const char* vb = getenv("S4P_VERIFY_BLOCKS")) { const int v = atoi(vb); if (v >= 64 && v <= kVerifyMaxBlocks) { c->verify_blocks = uint32_t(v); c->verify_blocks_fixed = true; c->verify_blocks_env = true; } }   // tuning knob
   if (const char* fp = getenv("S4P_FUSE_PREP")) c->fuse_prep = atoi(fp) != 0;
+  if (const char* ps = getenv("S4P_PAIR_SPLIT")) { const int v = atoi(ps); if (v == 1 || v == 2 || v == 4) c->pair_split = uint32_t(v); }
   if (const char* gr = getenv("S4P_GROUP")) { const int v = atoi(gr); if (v >= 1 && v <= kGroupMax) c->group = v; }
   c->trace_launch = getenv("S4P_TRACE_LAUNCH") != nullptr;
   c->debug = getenv("S4P_DEBUG") != nullptr;
@@ -1700,6 +1703,18 @@ int32_t s4p_verify_transforms_counted(s4p_ctx* c, const float* T, int64_t B, uin
   return verify_transforms_impl(c, T, B, counts, stats4);
 }
 
+#if defined(S4P_PROF)
+// lab build only (-DS4P_PROF=1): the per-wave stamps of the last launches of kernel `which` (0 k_pairs2, 1 k_quads, 2 k_verify);
+// the device copy is cleared after the read
+int32_t s4p_debug_prof(int32_t which, uint64_t* out, int32_t n_words) {
+  if (which < 0 || which > 2 || !out) return S4P_ERR_BAD_ARG;
+  if (hipDeviceSynchronize() != hipSuccess) return S4P_ERR_HIP;
+  const size_t all = size_t(kProfWords) * kProfWaves, bytes = std::min<size_t>(size_t(n_words), all) * 8, off = size_t(which) * all * 8;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), bytes, off, hipMemcpyDeviceToHost) != hipSuccess) return S4P_ERR_HIP;
+  static std::vector<unsigned long long> zeros(all, 0ull);
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_prof), zeros.data(), all * 8, off, hipMemcpyHostToDevice) == hipSuccess ? S4P_OK : S4P_ERR_HIP;
+}
+#endif
 int32_t s4p_stage_slots(const s4p_ctx*) { return s4p_ctx::kStageSlots; }
 int32_t s4p_pipeline_depth(const s4p_ctx* c) { return c ? c->n_lanes : 0; }
 

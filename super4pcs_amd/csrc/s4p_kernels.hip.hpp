@@ -7,9 +7,9 @@
 // bit-exact against the CPU path.
 //
 // Reference functions restated here (paths under /root/reference/src/super4pcs/):
-//   k_pairs        accelerators/pairExtraction/intersectionFunctor.h:197-233 (loop 2),
+//   k_pairs2       accelerators/pairExtraction/intersectionFunctor.h:197-233 (loop 2),
 //                  intersectionPrimitive.h:117-157, algorithms/pairCreationFunctor.h:151-218
-//   k_prep (and the append step of k_pairs)  algorithms/super4pcs.cc:118-146, accelerators/normalset.hpp:110-127,162-203
+//   k_prep (and the append step of k_pairs2)  algorithms/super4pcs.cc:118-146, accelerators/normalset.hpp:110-127,162-203
 //   k_quads        algorithms/super4pcs.cc:151-163
 //   k_gate/k_quads algorithms/match4pcsBase.cc:365-500 (ComputeRigidTransformation + rms gate, match4pcsBase.hpp:436-439)
 //   k_verify       match4pcsBase.cc:508-567 (Verify), accelerators/kdtree.h:417-421 (predicate),
@@ -20,6 +20,24 @@
 #include <stdint.h>
 
 namespace s4p {
+
+// Lab build (-DS4P_PROF=1, super4pcs_amd/build.py build_variant; tools/r6/wave_prof.py): every wave of k_pairs2 / k_quads /
+// k_verify keeps REFCLK stamps (s_memrealtime, 100 MHz: comparable across CUs and XCDs, which s_memtime is not) and phase
+// accumulators in registers and writes them when it ends -- a store per stamp perturbs what it measures.  Read back by
+// s4p_debug_prof.  Absent from the shipped library.
+#if defined(S4P_PROF)
+constexpr int kProfWords = 12, kProfWaves = 8192;
+__device__ unsigned long long g_prof[3][kProfWords * kProfWaves];      // [0] k_pairs2 [1] k_quads [2] k_verify
+#define PROF_DECL unsigned long long tp_[kProfWords] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define PROF_NOW(v) do { __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_sched_barrier(0); v = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define PROF_STAMP(k) PROF_NOW(tp_[k])
+#define PROF_WRITE(which, wave_id) do { if ((threadIdx.x & 63u) == 0 && (wave_id) < uint32_t(kProfWaves)) for (int k_ = 0; k_ < kProfWords; ++k_) g_prof[which][(wave_id) * kProfWords + k_] = tp_[k_]; } while (0)
+#else
+#define PROF_DECL do { } while (0)
+#define PROF_NOW(v) do { } while (0)
+#define PROF_STAMP(k) do { } while (0)
+#define PROF_WRITE(which, wave_id) do { } while (0)
+#endif
 
 constexpr uint32_t kNil = 0xFFFFFFFFu;
 constexpr int kGroupMax = 3;             // bases one launch of each kernel of a device pass may cover ("BASE GROUPS" below)
@@ -811,13 +829,13 @@ __device__ __forceinline__ uint32_t wave_lcp_count_auto(const LcpGrid& g, const 
 // where all but one candidate in 10^4 are abandoned after a sweep that never needs more than "how many queries COULD still
 // be inliers".  Per 64 queries the fused sweep above issues ~50 vector instructions and the staged one ~37; this one ~16:
 //   * the sampled Q lives in LDS as three float arrays (no 16-bit unpack: 3 conversions per query gone);
-//   * the 3x4 locating transform runs on the MATRIX pipe: v_mfma_f32_4x4x1 with lane l <-> query l, A = one column of the
-//     transform (lane & 3 = row), accumulator seeded with the translation -- three MFMAs per 64 queries leave the position in
-//     COARSE units (2^cshift cells) in the lane's own registers, and the vector pipe never sees the nine multiply-adds;
+//   * the 3x4 locating transform runs in COARSE units (2^cshift cells: an exact power-of-two scaling of the grid-unit
+//     transform) on the packed-FP32 pipe: grid_cell2, two queries per v_pk_fma_f32, nine per pair of queries (the round-4
+//     variant on the matrix pipe -- v_mfma_f32_4x4x1, lane = query -- was measured slower and removed in round 5);
 //   * only the coarse cube is located (floor, bounds, linear index, one LDS word, one bit): the fine cell and the rank among
 //     the reachable cells are needed only for queries whose candidate survives the sweep, so they are computed THERE;
 //   * a queue entry is the 16-bit query index alone.
-// Everything here only LOCATES: positions may be off by ~1e-5 cell (MFMA accumulation order vs the fma chain of grid_cell),
+// Everything here only LOCATES: positions may be off by ~1e-5 cell (coarse-unit rounding vs the fine-unit fma chain of grid_cell),
 // which the structure absorbs at every level independently (a coarse cube is marked if any of its cells is reachable, a cell
 // if a P point lies within delta + 0.01 h of its box: LcpGridHost::plan).  The inlier predicate itself is exact_setup /
 // group_hit, untouched: counts stay bit-exact.
@@ -953,7 +971,7 @@ __device__ __forceinline__ uint32_t wave_lcp_count_lean(const LcpGrid& g, const 
     const uint32_t unswept = K.n_q - min(base + kSweepStep, K.n_q);
     if (more) {
       // one step = kSweepChunks chunks in four phases, so that the LDS reads of all chunks are in flight together and
-      // dependent MFMAs of one chunk are separated by the other chunks'
+      // the dependent packed FMAs of one chunk are separated by the other chunks'
       uint32_t ii[kSweepChunks], cc[kSweepChunks], ww[kSweepChunks];
       float x[kSweepChunks], y[kSweepChunks], z[kSweepChunks];
 #pragma unroll
@@ -1321,6 +1339,7 @@ __device__ __forceinline__ void cone_mask_row(const ConeTable& cone, const float
 // Preparation of set 1 (one thread per pair): invariant point, cell, direction bucket, world point, hash insert.  Set 2 is
 // prepared where it is consumed (k_quads): only the pairs whose cell holds a set-1 pair need their world point and cone mask.
 struct PrepGroup { PrepParams base[kGroupMax]; };
+static_assert(sizeof(PrepGroup) <= 4096, "PrepGroup travels by value in the 4 KB kernel-argument segment");
 __global__ __launch_bounds__(256) void k_prep(PrepGroup PG) {
   const PrepParams& P = PG.base[blockIdx.y];
   const uint32_t m = min(*P.m_dev, P.cap);
@@ -1354,7 +1373,7 @@ struct PairParams {
   float max_normal_difference, max_color_distance, max_translation_distance, norm_threshold;
   float b1pos[3], b2pos[3], b1rgb[3], b2rgb[3];
   int2* ab; uint32_t* okey; uint32_t* counter; uint32_t cap; uint32_t* overflow; uint32_t overflow_bit;
-  uint32_t split;                                          // waves per primitive: wave `part` takes the leaf tiles part, part + split, ...
+  uint32_t split;                                          // waves per (tile, chunk): wave `part` takes the slots [part, part + 1) * 64 / split of the chunk (1, 2 or 4)
   // max_angle > 0 (pairCreationFunctor.h:203-212): (j,i) is emitted iff acosf(segment1 . segment2) <= max_angle * pi / 180,
   // (i,j) iff the same holds for -segment2.  acosf is decreasing, so the test is d >= cos_min with cos_min = the smallest
   // float whose libm acosf passes (found by the host with libm itself, s4p_capi.hip angle_threshold); |d| > 1 gives NaN in
@@ -1450,6 +1469,7 @@ struct PairParams2 { PairSet set[2]; };
 // profiles/r05_verify_vs_candidates.json); a launch that covers three bases pays those fixed costs once.  The records travel
 // by value in the kernel argument segment (3 x QuadParams = 3.2 KB of the 4 KB it holds: kGroupMax = 3).
 struct PairGroup { PairParams2 base[kGroupMax]; };
+static_assert(sizeof(PairGroup) <= 4096, "PairGroup travels by value in the 4 KB kernel-argument segment");
 
 // ---------------------------------------------------------------------------
 // k_pairs2: loop 2 TRANSPOSED (round 4).  Round 3's k_pairs walked (primitive -> touched leaves -> their points) with one
@@ -1483,6 +1503,8 @@ __global__ __launch_bounds__(64 * kPair2Waves) void k_pairs2(PairGroup PG) {
   __shared__ uint32_t s_cnt[kPair2Waves], s_base;
   const uint32_t lane = threadIdx.x & 63u, wave = uint32_t(__builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6)));
   uint32_t n_st = 0;                                     // staged entries of this wave (wave-uniform)
+  PROF_DECL;
+  PROF_STAMP(0);
   auto wave_fence = [&]() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); };
   auto write_out = [&](const uint32_t base) {            // entries -> ordered pairs at positions base, base + 1, ...
     for (uint32_t pe = lane; pe < (ANGLE ? n_st : 2u * n_st); pe += 64u) {
@@ -1514,9 +1536,16 @@ __global__ __launch_bounds__(64 * kPair2Waves) void k_pairs2(PairGroup PG) {
   const float lo_r = fmaxf(P.nRadius - E, 0.f), hi_r = P.nRadius + E;
   const float lo2 = lo_r * lo_r * 0.9999f, hi2 = hi_r * hi_r * 1.0001f;
   // item = (chunk, tile), tile fastest: the waves of a workgroup share their chunk's gathers in cache
-  for (uint32_t item = gw; item < n_tiles * n_chunks; item += nw) {
-    const uint32_t chunk = item / n_tiles, tile = item - chunk * n_tiles;
+  // Items of very different weight (a tile and a chunk that lie at the base's distance from each other hold most of the
+  // candidates: 40 us against a median of 9, profiles/r06_wave_profile_before.log) set the launch's duration, so an item is
+  // shared by `split` waves, each taking a contiguous part of the chunk's slots (all of them gather the whole chunk: cheap).
+  const uint32_t split = P.split, part_slots = 64u / split;
+  for (uint32_t item = gw; item < n_tiles * n_chunks * split; item += nw) {
+    const uint32_t part = item % split, ct = item / split;
+    const uint32_t chunk = ct / n_tiles, tile = ct - chunk * n_tiles;
     const uint32_t s0 = chunk * 64u, n_in = min(64u, P.n_seq - s0);
+    const uint32_t k_lo = part * part_slots, k_hi = min(k_lo + part_slots, n_in);
+    if (k_lo >= n_in) continue;                                // (uniform) the chunk's tail part is empty
     // the chunk: lane = slot -- id, unit point, world point, and the record of the slot's leaf (box, end of its slot range)
     const uint32_t sw = P.seq_id[s0 + min(lane, n_in - 1u)];
     const uint32_t jl = sw & 0xFFFFu, leaf_l = sw >> 16;
@@ -1524,6 +1553,7 @@ __global__ __launch_bounds__(64 * kPair2Waves) void k_pairs2(PairGroup PG) {
     const float pwx = P.qx[jl], pwy = P.qy[jl], pwz = P.qz[jl];
     const float4 box_l = P.leaves[leaf_l];
     const uint32_t end_l = P.leaf_off[leaf_l + 1u];
+    PROF_STAMP(1);
     // the tile: lane = primitive
     const uint32_t pId = tile * 64u + lane;
     const bool pvalid = pId < P.n_q;
@@ -1589,9 +1619,9 @@ __global__ __launch_bounds__(64 * kPair2Waves) void k_pairs2(PairGroup PG) {
         n_st = 0;
       }
     };
-    for (uint32_t k = 0; k < n_in;) {                       // uniform: one run of slots = the part of one leaf inside the chunk
+    for (uint32_t k = k_lo; k < k_hi;) {                    // uniform: one run of slots = the part of one leaf inside this wave's part of the chunk
       const float4 box = make_float4(bcast(box_l.x, k), bcast(box_l.y, k), bcast(box_l.z, k), bcast(box_l.w, k));
-      const uint32_t k1 = min(uint32_t(__builtin_amdgcn_readlane(int(end_l), int(k))) - s0, n_in);
+      const uint32_t k1 = min(uint32_t(__builtin_amdgcn_readlane(int(end_l), int(k))) - s0, k_hi);
       const bool touch = pvalid && sphere_box_r2(cx, cy, cz, r2, box);     // intersect, intersectionPrimitive.h:117-142
       if (__builtin_amdgcn_ballot_w64(touch) == 0ull) { k = k1; continue; }
       for (; k < k1; ++k) {                                 // uniform: one point of the leaf against the 64 primitives
@@ -1609,6 +1639,7 @@ __global__ __launch_bounds__(64 * kPair2Waves) void k_pairs2(PairGroup PG) {
     while (nq != 0u) run_batch();                           // (the queue refers to this item's registers: empty it before the next)
   }
   wave_fence();
+  PROF_STAMP(2);
   // end of the workgroup's items: ONE global atomic for the waves' leftovers
   if (lane == 0) s_cnt[wave] = n_st;
   __syncthreads();
@@ -1618,9 +1649,15 @@ __global__ __launch_bounds__(64 * kPair2Waves) void k_pairs2(PairGroup PG) {
     s_base = tot ? atomicAdd(P.counter, ANGLE ? tot : 2u * tot) : 0u;
   }
   __syncthreads();
+  PROF_STAMP(3);
   uint32_t before = 0;
   for (uint32_t w = 0; w < wave; ++w) before += s_cnt[w];
   if (n_st) write_out(s_base + (ANGLE ? before : 2u * before));
+  PROF_STAMP(4);
+#if defined(S4P_PROF)
+  tp_[5] = n_st;
+#endif
+  PROF_WRITE(0, (blockIdx.y * gridDim.x + blockIdx.x) * kPair2Waves + wave);
 }
 
 // ---------------------------------------------------------------------------
@@ -1716,6 +1753,7 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 }
 
 struct QuadGroup { QuadParams base[kGroupMax]; };
+static_assert(sizeof(QuadGroup) <= 4096, "QuadGroup travels by value in the 4 KB kernel-argument segment");
 template <bool ANGLE>
 __global__ __launch_bounds__(256) void k_quads(QuadGroup QG) {
   const QuadParams& P = QG.base[blockIdx.y];
@@ -1730,8 +1768,14 @@ __global__ __launch_bounds__(256) void k_quads(QuadGroup QG) {
   const uint32_t hmask = hash_mask(P.ht);
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   if (threadIdx.x == 0) { st_n = 0; s_qsum = 0ull; s_csum = 0ull; }
+  PROF_DECL;
+  PROF_STAMP(0);
   __syncthreads();
   for (uint32_t i0 = begin + blockIdx.x * blockDim.x; i0 < end; i0 += gridDim.x * blockDim.x) {
+#if defined(S4P_PROF)
+    unsigned long long pa_, pb_, pc_, pd_, pe_;
+    PROF_NOW(pa_);
+#endif
     // phase A, one thread per set-2 pair of the tile: invariant point -> cell -> head of the cell's set-1 chain (super4pcs.cc:141,
     // normalset.hpp:162-171).  Typically well under half of the pairs fall into a cell that holds a set-1 pair; those are
     // compacted (ballot + per-wave offsets) so that the expensive part below runs on DENSE waves.
@@ -1767,6 +1811,8 @@ __global__ __launch_bounds__(256) void k_quads(QuadGroup QG) {
       __syncthreads();
     }
     const uint32_t n_items = s_ic[0] + s_ic[1] + s_ic[2] + s_ic[3];
+    PROF_NOW(pb_);
+    uint32_t hops_ = 0; (void)hops_;
     if (threadIdx.x < n_items) {
       // phase B, one thread per pair with a chain: world point (super4pcs.cc:142) and the cone mask of its direction
       // (normalset.hpp:174-196) into the thread's LDS row -- what a separate preparation launch used to do for EVERY pair
@@ -1782,6 +1828,7 @@ __global__ __launch_bounds__(256) void k_quads(QuadGroup QG) {
         const float w2x = P.qx[ab2.y], w2y = P.qy[ab2.y], w2z = P.qz[ab2.y];
         eq = make_float4(w1x + P.invariant2 * (w2x - w1x), w1y + P.invariant2 * (w2y - w1y), w1z + P.invariant2 * (w2z - w1z), 0.f);
         cone_mask_row(P.cone, P.qg.nepsilon, p2x - p1x, p2y - p1y, p2z - p1z, row); }
+      PROF_NOW(pc_);
       // phase C: the walk is a chain of dependent gathers (one set-1 pair per hop), so each hop is ONE round trip: the hop's
       // direction bucket, world point and successor are requested together; the bucket test reads the LDS row.
       while (e != kNil) {
@@ -1811,9 +1858,13 @@ __global__ __launch_bounds__(256) void k_quads(QuadGroup QG) {
             } else atomicOr(P.overflow, 4u);
           }
         }
-        e = nxt;
+        e = nxt; ++hops_;
       }
     }
+#if defined(S4P_PROF)
+    else { pc_ = pb_; }
+#endif
+    PROF_NOW(pd_);
     __syncthreads();
     const uint32_t n = min(st_n, uint32_t(kQuadStage));
     if (n) {                                                   // uniform
@@ -1853,7 +1904,16 @@ __global__ __launch_bounds__(256) void k_quads(QuadGroup QG) {
     __syncthreads();
     if (threadIdx.x == 0) st_n = 0;
     __syncthreads();
+#if defined(S4P_PROF)
+    PROF_NOW(pe_);
+    tp_[2] += pb_ - pa_; tp_[3] += pc_ - pb_; tp_[4] += pd_ - pc_; tp_[5] += pe_ - pd_; tp_[6] += 1;
+    { uint32_t hm_ = hops_;
+      for (int o_ = 32; o_ > 0; o_ >>= 1) { const uint32_t v_ = uint32_t(__shfl_xor(int(hm_), o_)); hm_ = v_ > hm_ ? v_ : hm_; }
+      if (hm_ > tp_[7]) tp_[7] = hm_; tp_[8] += n; }
+#endif
   }
+  PROF_STAMP(1);
+  PROF_WRITE(1, (blockIdx.y * gridDim.x + blockIdx.x) * 4u + wave);
   if (threadIdx.x == 0) {                                      // one pair of global atomics per workgroup that found anything
     if (s_qsum) atomicAdd(P.qsum_dev, s_qsum);
     if (s_csum) atomicAdd(P.csum_dev, s_csum);
@@ -1901,6 +1961,7 @@ struct VerifyParams {
   int ablate;                                           // S4P_ABLATE debugging only (0 = full kernel)
 };
 
+static_assert(sizeof(VerifyParams) <= 4096, "VerifyParams travels by value in the 4 KB kernel-argument segment");
 struct VerifyShared {                                   // k_verify's workgroup scalars, at the end of its dynamic LDS
   unsigned long long wtag[kGroupMax][kVerifyMaxThreads / 64];
   uint32_t wcnt[kGroupMax][kVerifyMaxThreads / 64], wcand[kGroupMax][kVerifyMaxThreads / 64];
@@ -1937,6 +1998,8 @@ __device__ __forceinline__ uint32_t wave_ticket(uint32_t* counter) {
 // result record per base.
 template <bool COUNT, bool QLDS, bool LEAN>
 __global__ __launch_bounds__(kVerifyMaxThreads, 6) void k_verify(VerifyParams P) {   // <= 80 VGPRs: six waves per SIMD, i.e. two 768-thread workgroups per CU (of one launch, or of two)
+  PROF_DECL;
+  PROF_STAMP(0);
   extern __shared__ uint32_t s_mem[];
   uint32_t* s_coarse = s_mem;                              // LDS: coarse bitmap | quantised queries (QLDS) | 16 survivor queues
   uint2* s_q = reinterpret_cast<uint2*>(s_mem + P.grid.coarse_words);
@@ -1989,6 +2052,7 @@ __global__ __launch_bounds__(kVerifyMaxThreads, 6) void k_verify(VerifyParams P)
     if (LEAN) { if (QLDS) stage_queries_f(P.qsoa, const_cast<float*>(LL.qx), 3u * n_pad); }
     else if (QLDS) stage_queries(K, s_q);
     stage_coarse(P.grid, s_coarse);                        // ends with a workgroup barrier
+    PROF_STAMP(1);
     // A candidate is one 64-byte record {3x4 transform | tag, quad index}: one line, everything the wave needs of it.  (Holding
     // the NEXT candidate's record in registers while the current one is swept was measured in round 4: 16 more VGPRs, no gain;
     // so was finishing "heavy" candidates -- those that stay alive through the whole sweep -- by the whole workgroup after the
@@ -2009,6 +2073,9 @@ __global__ __launch_bounds__(kVerifyMaxThreads, 6) void k_verify(VerifyParams P)
       const uint32_t i = blockIdx.x + (t - t0) * gridDim.x;
       const float4* src = B.cand_T + kCandStride * size_t(i);         // one candidate per wave
       const float4 r0 = src[0], r1 = src[1], r2 = src[2], r3 = src[3];
+#if defined(S4P_PROF)
+      const unsigned long long tc0_ = __builtin_amdgcn_s_memrealtime();
+#endif
       K.point_tests = &B.ctr->point_tests; K.pruned = &S.pruned[bsel];
       uint32_t cnt;
       if (LEAN) cnt = P.ablate == 1 ? wave_lcp_count_lean<COUNT, true, QLDS>(P.grid, K, LL, src, r0, r1, r2) : wave_lcp_count_lean<COUNT, false, QLDS>(P.grid, K, LL, src, r0, r1, r2);
@@ -2034,8 +2101,13 @@ __global__ __launch_bounds__(kVerifyMaxThreads, 6) void k_verify(VerifyParams P)
       }
       (void)r3;
       __builtin_amdgcn_wave_barrier();
+#if defined(S4P_PROF)
+      { __builtin_amdgcn_s_waitcnt(0); const unsigned long long d_ = __builtin_amdgcn_s_memrealtime() - tc0_;
+        tp_[5] += 1; if (d_ > tp_[6]) tp_[6] = d_; if (d_ > 800ull) { tp_[7] += 1; tp_[8] += d_; } tp_[9] += d_; if (d_ > 2000ull) tp_[10] += 1; }
+#endif
     }
   }
+  PROF_STAMP(2);
   // ---- selection: wave bests (LDS) -> workgroup best -> slot; the last workgroup to finish reduces the slots ----
   auto wave_reduce = [&](WaveBest& w) {
 #pragma unroll
@@ -2053,6 +2125,8 @@ __global__ __launch_bounds__(kVerifyMaxThreads, 6) void k_verify(VerifyParams P)
     return r;
   };
   __syncthreads();
+  PROF_STAMP(3);
+  PROF_WRITE(2, blockIdx.x * 16u + wave);
   if (threadIdx.x == 0) {
     for (uint32_t b = 0; b < nb; ++b) {
       if (S.pruned[b]) atomicAdd(&P.b[b].ctr->pruned, S.pruned[b]);
