@@ -703,6 +703,7 @@ def main():
                     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
                 if int(flag.item()):
                     collective["kind"] = "rccl: ncclAllReduce(uint64, max) per window from the C++ loop (s4p_shard_run_windows, own communicator)"
+                    collective["rccl_reported"] = sh.comm_info()          # (ncclCommCount, ncclCommUserRank) of that communicator
                 else:
                     sh.use_collective(capi.torch_collective(dist, dev))
                     collective["kind"] = "torch-fallback: torch.distributed all_reduce(max) on the nccl (= RCCL) process group through the callback provider"
@@ -1066,6 +1067,8 @@ def main():
                        "parallelism": "bases sharded over %d GPU(s), one 8-byte all-reduce(max) per window" % world,
                        "collective": collective["kind"], "shard_mode": collective.get("mode"),
                        "ranks": {"n_ranks": world, "torch_distributed_world": (dist.get_world_size() if dist is not None else 1),
+                                 "rccl_comm_count": (collective.get("rccl_reported") or (None, None))[0],      # what the library's own communicator says (None: no RCCL communicator in this run)
+                                 "rccl_comm_user_rank": (collective.get("rccl_reported") or (None, None))[1],
                                  "per_rank_ms_per_step": per_rank_med.get("ms_per_step"), "per_rank_candidates": per_rank_med.get("candidates"),
                                  "note": "each rank's own wall clock over the K timed steps and its own candidate count in the median repeat; "
                                          "`ms_per_step` is the max over ranks, `value` the sum of the candidates / that time"},

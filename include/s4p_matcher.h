@@ -196,6 +196,9 @@ const char* s4p_shard_last_error(const s4p_shard* s);
 /* ncclCommInitRank on `device` (the matcher's GPU); collective = ncclAllReduce(uint64, max) / ncclBroadcast on a private stream. */
 int32_t s4p_shard_use_rccl(s4p_shard* s, int32_t device, const uint8_t* unique_id128);
 int32_t s4p_shard_use_collective(s4p_shard* s, const s4p_collective* coll);
+/* What the shard's RCCL communicator itself reports (ncclCommCount / ncclCommUserRank); -1 / -1 when the collective is not
+ * the library's own RCCL communicator.  s4p_shard_use_rccl fails if they disagree with the rank / world the shard was made with. */
+int32_t s4p_shard_comm_info(const s4p_shard* s, int32_t* n_ranks, int32_t* rank);
 /* Measurement aid: the shard plays one rank of its world alone (reduction = own key, broadcast = no-op), so that the
  * per-window cost of a rank at a given world size can be measured on one GPU (tools/sim_world.py). */
 int32_t s4p_shard_use_null_collective(s4p_shard* s);

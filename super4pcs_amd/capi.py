@@ -389,7 +389,7 @@ class MatcherInfo(C.Structure):
 
 SHARD_SYMBOLS = [
     "s4p_rccl_unique_id", "s4p_shard_create", "s4p_shard_destroy", "s4p_shard_last_error", "s4p_shard_use_rccl",
-    "s4p_shard_use_collective", "s4p_shard_use_null_collective", "s4p_shard_set_mode", "s4p_shard_replay_split", "s4p_shard_run_windows", "s4p_shard_compute_transformation", "s4p_shard_replay",
+    "s4p_shard_use_collective", "s4p_shard_comm_info", "s4p_shard_use_null_collective", "s4p_shard_set_mode", "s4p_shard_replay_split", "s4p_shard_run_windows", "s4p_shard_compute_transformation", "s4p_shard_replay",
     "s4p_matcher_terminate_threshold", "s4p_matcher_max_time_seconds", "s4p_matcher_init_generation",
 ]
 MATCHER_SYMBOLS = [
@@ -818,6 +818,14 @@ class Shard:
     def use_rccl(self, device, unique_id):
         buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
         self._chk(self.L.s4p_shard_use_rccl(self.h, device, buf))
+
+    def comm_info(self):
+        """(ranks, rank) as the shard's own RCCL communicator reports them; (-1, -1) for any other collective."""
+        n = C.c_int32(-1); r = C.c_int32(-1)
+        self.L.s4p_shard_comm_info.restype = C.c_int32
+        self.L.s4p_shard_comm_info.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        self._chk(self.L.s4p_shard_comm_info(self.h, C.byref(n), C.byref(r)))
+        return int(n.value), int(r.value)
 
     def set_mode(self, split_bases):
         """False: trials sharded by base (default).  True: every base over all ranks (SURVEY 8e level 2); before init."""

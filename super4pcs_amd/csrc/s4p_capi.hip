@@ -113,6 +113,7 @@ struct s4p_ctx {
     DevBuf<DevCounters> ctr;          // [0] live counters of the base in flight (its result record is pinned host memory: hctr)
     LaunchRec rec;
     bool pending = false;             // submitted, its group not launched yet
+    int32_t failed_rc = 0; std::string failed_msg;      // the launch of this lane's base could not be enqueued (flush_lanes): what its wait returns
     uint32_t seq = 0;                 // number of the launch whose result record the host waits for (DevCounters::seq)
     DevBuf<uint4> slots;              // k_verify: per-workgroup best, reduced by its last workgroup
     DevBuf<uint32_t> border;          // k_verify: candidates whose Euler-angle gate the host settles (max_angle >= 0), kBorderCap entries
@@ -138,6 +139,7 @@ struct s4p_ctx {
   // 2048 workgroups per base of which a hundred find work is mostly dispatch cost.  A base that needs more takes a second
   // grid-stride pass: slower, same result.  0 = no estimate yet (first bases, stage-level calls): the full grids.
   uint32_t est_m1 = 0, est_m2 = 0;
+  bool two_prio = false; int prio_hi = 0, prio_mid = 0;      // group streams on two priority levels (s4p_create: fewer hardware queues than streams)
   bool fuse_prep = true;             // S4P_FUSE_PREP=0: always the k_prep launch (A/B aid)
   uint32_t pair_split = 2;           // waves that share one (tile, chunk) item of k_pairs2 (S4P_PAIR_SPLIT: 1, 2, 4)
   uint64_t prep_redos = 0;           // bases redone because the estimate-sized cell hash was too small
@@ -446,9 +448,9 @@ GateParams gate_params(s4p_ctx* c, const BaseFrame& bf) {
 void harvest_events(s4p_ctx* c, int li);
 
 // Group launches: the first n records of a group, on stream st.
-uint32_t est_grid(uint32_t est, uint32_t full) {             // workgroups of 256 threads for an estimated entry count (+50 %), within [64, full]
+uint32_t est_grid(uint32_t est, uint32_t full, uint32_t threads = 256u) {      // workgroups for an estimated entry count (+50 %), within [64, full]
   if (est == 0u) return full;
-  const uint64_t want = (uint64_t(est) * 3u / 2u + 255u) / 256u;
+  const uint64_t want = (uint64_t(est) * 3u / 2u + threads - 1u) / threads;
   return uint32_t(std::min<uint64_t>(full, std::max<uint64_t>(64u, want)));
 }
 void launch_prep_group(const PrepGroup& G, int n, hipStream_t st, uint32_t est = 0) {
@@ -459,9 +461,10 @@ void launch_quads_group(s4p_ctx* c, const QuadGroup& G, int n, hipStream_t st, u
   // dependent gathers of the workgroups that get one); idle workgroups leave after reading the count
   uint64_t span = 1;
   for (int b = 0; b < n; ++b) span = std::max<uint64_t>(span, uint64_t(G.base[b].r1) - uint64_t(G.base[b].r0));    // (the whole set: 2^32 - 1)
-  const uint32_t blocks = std::min(est_grid(est, 2048u), uint32_t(std::min<uint64_t>(2048u, std::max<uint64_t>(1u, (span + 255u) / 256u))));
-  if (c->opt.max_angle >= 0.f) hipLaunchKernelGGL(k_quads<true>, dim3(blocks, uint32_t(n)), dim3(256), 0, st, G);
-  else hipLaunchKernelGGL(k_quads<false>, dim3(blocks, uint32_t(n)), dim3(256), 0, st, G);
+  const uint32_t full = 2048u * 256u / uint32_t(kQuadThreads);
+  const uint32_t blocks = std::min(est_grid(est, full, uint32_t(kQuadThreads)), uint32_t(std::min<uint64_t>(full, std::max<uint64_t>(1u, (span + kQuadThreads - 1u) / kQuadThreads))));
+  if (c->opt.max_angle >= 0.f) hipLaunchKernelGGL(k_quads<true>, dim3(blocks, uint32_t(n)), dim3(kQuadThreads), 0, st, G);
+  else hipLaunchKernelGGL(k_quads<false>, dim3(blocks, uint32_t(n)), dim3(kQuadThreads), 0, st, G);
 }
 // single-base forms on lane c->cur's own stream (stage-level calls, chunk passes)
 void launch_prep_kernel(s4p_ctx* c, const PrepParams& P1) {
@@ -532,6 +535,11 @@ int32_t enqueue_result(s4p_ctx* c, const BaseFrame& bf) {
 // few microseconds sooner than the stream's event, and no read-back copy in the stream), with the event as the fallback and
 // as the carrier of asynchronous errors.
 int32_t wait_lane(s4p_ctx* c, int li) {
+  if (c->lane[li].failed_rc != S4P_OK) {                     // its launch was never enqueued in full: nothing to wait for, nothing to trust
+    const int32_t rc = c->lane[li].failed_rc;
+    c->err = c->lane[li].failed_msg; c->lane[li].failed_rc = S4P_OK;
+    return rc;
+  }
   const volatile uint32_t* seq = &c->hctr[li].p->seq;
   const uint32_t want = c->lane[li].seq;
   const auto t0 = std::chrono::steady_clock::now();
@@ -651,6 +659,7 @@ int32_t settle_borderline(s4p_ctx* c, DevCounters& d, const BaseFrame& bf) {
   if (!d.n_border) return S4P_OK;
   if (d.n_border > kBorderCap) S4P_FAIL(c, S4P_ERR_STATE, "more candidates with an undecided Euler-angle gate than the device hands over (kBorderCap)");
   s4p_ctx::Lane& L = c->lane[c->cur];
+  HIPCHK(c, hipEventSynchronize(c->done[c->cur]));          // (the wait returned on the record's launch number: the launch itself must be over before its buffers are read back)
   std::vector<uint32_t> pos(d.n_border);
   HIPCHK(c, hipMemcpy(pos.data(), L.border.p, size_t(d.n_border) * 4, hipMemcpyDeviceToHost));
   bool have = d.C > d.n_border;                            // the device selected among the decided candidates only
@@ -698,6 +707,7 @@ int32_t capture_pass(s4p_ctx* c, const DevCounters& d, bool want_quads, bool to_
   const uint64_t K = std::min<uint64_t>(d.K, L.cap_quads);
   const uint32_t Cdev = c->hctr[c->cur].p->C;                // as the device counted them (incl. candidates the host rejected afterwards)
   if (K == 0) return S4P_OK;
+  HIPCHK(c, hipEventSynchronize(c->done[c->cur]));          // (as in settle_borderline)
   std::vector<unsigned long long> t(K); std::vector<uint32_t> cn(K);
   HIPCHK(c, hipMemcpy(t.data(), L.tags.p, K * 8, hipMemcpyDeviceToHost));
   HIPCHK(c, hipMemcpy(cn.data(), L.counts.p, K * 4, hipMemcpyDeviceToHost));
@@ -930,7 +940,15 @@ int32_t prepare_base(s4p_ctx* c, int32_t slot, const int32_t* base_ids, float in
 // that cover all of them (k_pairs2: both pair sets of every base; k_prep; k_quads: enumeration + rigid transform + rms gate;
 // k_verify: LCP of every candidate + winners + result records, counters cleared for the lanes' next bases), then every
 // lane's completion event.
+int32_t flush_lanes_enqueue(s4p_ctx* c, const int* lanes, int n, hipStream_t st);
+// ... and if any step of it fails, every lane of the launch remembers the failure: the wait for such a base returns it instead of
+// polling a result record that still holds the lane's PREVIOUS launch number
 int32_t flush_lanes(s4p_ctx* c, const int* lanes, int n, hipStream_t st) {
+  const int32_t rc = flush_lanes_enqueue(c, lanes, n, st);
+  if (rc != S4P_OK) for (int b = 0; b < n; ++b) { c->lane[lanes[b]].pending = false; c->lane[lanes[b]].failed_rc = rc; c->lane[lanes[b]].failed_msg = c->err; }
+  return rc;
+}
+int32_t flush_lanes_enqueue(s4p_ctx* c, const int* lanes, int n, hipStream_t st) {
   using lclk = std::chrono::steady_clock;
   lclk::time_point tp[8];
   auto lap = [&](int k) { if (c->trace_launch) tp[k] = lclk::now(); };
@@ -1075,10 +1093,27 @@ int32_t s4p_create(const s4p_options* opt, const s4p_limits* lim, int32_t device
   auto fail = [&](hipError_t e, const char* what) { g_create_error = std::string(what) + ": " + hipGetErrorString(e); s4p_destroy(c); return e == hipErrorOutOfMemory ? S4P_ERR_OOM : S4P_ERR_HIP; };
   hipError_t e;
   if ((e = hipSetDevice(device)) != hipSuccess) return fail(e, "hipSetDevice");
+  { // hardware queues the runtime was given against the group streams this context will use (see the stream creation below)
+    const char* hq = getenv("GPU_MAX_HW_QUEUES");
+    const int queues = (hq && atoi(hq) > 0) ? atoi(hq) : 4, streams = (c->n_lanes + c->group - 1) / c->group;
+    int plo = 0, phi = 0;
+    c->two_prio = queues < streams && hipDeviceGetStreamPriorityRange(&plo, &phi) == hipSuccess && plo != phi;
+    if (const char* sp = getenv("S4P_STREAM_PRIO")) c->two_prio = atoi(sp) != 0 && plo != phi;
+    c->prio_hi = phi; c->prio_mid = (plo + phi) / 2;
+    if (c->debug) fprintf(stderr, "[s4p] %d group stream(s) on %d hardware queue(s) per priority level: %s\n", streams, queues, c->two_prio ? "two priority levels" : "one priority level");
+  }
 #define A(buf, cnt) if ((e = (buf).alloc(cnt)) != hipSuccess) return fail(e, "hipMalloc " #buf)
   for (int li = 0; li < c->n_lanes; ++li) {
     s4p_ctx::Lane& L = c->lane[li];
-    if ((e = hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
+    { // The groups' streams share the runtime's hardware queues (GPU_MAX_HW_QUEUES, default 4: read by the runtime when it
+      // initialises -- the application's to set, never this library's), and streams that share a queue serialise: 7 group
+      // streams on 4 queues run at 198 M candidates/s against 231 M on 8.  The runtime keeps a pool of queues PER PRIORITY
+      // LEVEL, so when the environment leaves fewer queues than the context has group streams, the groups alternate between
+      // the normal and the high level and find a queue each: 223 M with nothing exported (profiles/r06_lab/summary_prio.txt;
+      // with 8 queues the one-level form stays: 231 vs 221).  S4P_STREAM_PRIO=0 / 1 forces one / two levels.
+      e = c->two_prio ? hipStreamCreateWithPriority(&L.stream, hipStreamNonBlocking, ((li / c->group) & 1) ? c->prio_hi : c->prio_mid)
+                      : hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking);
+      if (e != hipSuccess) return fail(e, "hipStreamCreate"); }
     A(L.ctr, 2); A(L.slots, kVerifyMaxBlocks); A(L.border, kBorderCap);
     if ((e = hipMemset(L.ctr.p, 0, 2 * sizeof(DevCounters))) != hipSuccess) return fail(e, "hipMemset");
     const char* what = nullptr;
@@ -1850,6 +1885,7 @@ int32_t s4p_last_candidates(s4p_ctx* c, int32_t* quads, int32_t* counts, int64_t
   if (K == 0) return S4P_OK;
   if (cap < int64_t(K) || !quads || !counts) S4P_FAIL(c, S4P_ERR_CAPACITY, "s4p_last_candidates: output buffer too small");
   HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipEventSynchronize(c->done[c->cur]));
   std::vector<int4> q(K); std::vector<unsigned long long> t(K); std::vector<uint32_t> cn(K);
   HIPCHK(c, hipMemcpy(q.data(), c->lane[c->cur].quads.p, K * 16, hipMemcpyDeviceToHost));
   HIPCHK(c, hipMemcpy(t.data(), c->lane[c->cur].tags.p, K * 8, hipMemcpyDeviceToHost));
@@ -1884,6 +1920,7 @@ int32_t s4p_last_verified(s4p_ctx* c, uint32_t* counts, float* transforms16, int
   const uint32_t Cdev = c->hctr[c->cur].p->C;               // as the device counted them (incl. candidates the host rejected afterwards)
   *n_out = 0;
   if (Cdev == 0) return S4P_OK;
+  HIPCHK(c, hipEventSynchronize(c->done[c->cur]));
   std::vector<uint32_t> idx(Cdev); std::vector<float4> T(size_t(Cdev) * kCandStride);
   HIPCHK(c, hipMemcpy(idx.data(), L.cand_idx.p, size_t(Cdev) * 4, hipMemcpyDeviceToHost));
   HIPCHK(c, hipMemcpy(T.data(), L.cand_T.p, size_t(Cdev) * 16 * kCandStride, hipMemcpyDeviceToHost));

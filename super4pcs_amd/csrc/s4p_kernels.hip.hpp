@@ -1736,7 +1736,14 @@ struct QuadParams {
   int do_gate; GateParams gate;                          // fused path: gate every quad as it is appended
 };
 
-constexpr int kQuadStage = 512;      // quads per workgroup between two flushes (24 B each): 23 KB of LDS per workgroup, fits next to two resident k_verify workgroups (48 KB at 1536 did not)
+// Threads per workgroup of k_quads (one set-2 pair per thread and tile).  Every flush of a workgroup is two dependent atomics on
+// the base's quad and candidate counters, and same-address atomics are served one after the other (~17 ns each): with 256
+// threads a base's ~900 workgroups spent 10-24 us of their ~45 in the flush (profiles/r06_wave_profile_before.log).
+#ifndef S4P_QUAD_THREADS
+#define S4P_QUAD_THREADS 256
+#endif
+constexpr int kQuadThreads = S4P_QUAD_THREADS, kQuadWaves = kQuadThreads / 64;
+constexpr int kQuadStage = 2 * kQuadThreads;      // quads per workgroup between two flushes (24 B each)
 
 // One thread per pairs2 entry: hash lookup of its euclidean cell, walk of the set-1 chain (super4pcs.cc:151-163).
 // Matches are staged in LDS and flushed with one global atomic per workgroup round; on the fused path the flush also
@@ -1755,14 +1762,14 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 struct QuadGroup { QuadParams base[kGroupMax]; };
 static_assert(sizeof(QuadGroup) <= 4096, "QuadGroup travels by value in the 4 KB kernel-argument segment");
 template <bool ANGLE>
-__global__ __launch_bounds__(256) void k_quads(QuadGroup QG) {
+__global__ __launch_bounds__(kQuadThreads) void k_quads(QuadGroup QG) {
   const QuadParams& P = QG.base[blockIdx.y];
   __shared__ int4 st_q[kQuadStage];
   __shared__ unsigned long long st_t[kQuadStage];
   __shared__ unsigned long long st_base, s_qsum, s_csum;
-  __shared__ uint32_t st_n, s_wc[4], s_cbase, s_ic[4];
-  __shared__ uint32_t s_item_i[256], s_item_e[256];        // the tile's pairs whose cell holds a set-1 pair, compacted
-  __shared__ uint32_t s_mask[256 * kMaskWords];            // each thread's direction mask (row stride 11: conflict-free)
+  __shared__ uint32_t st_n, s_wc[kQuadWaves], s_cbase, s_ic[kQuadWaves];
+  __shared__ uint32_t s_item_i[kQuadThreads], s_item_e[kQuadThreads];        // the tile's pairs whose cell holds a set-1 pair, compacted
+  __shared__ uint32_t s_mask[kQuadThreads * kMaskWords];   // each thread's direction mask (row stride 11: conflict-free)
   const uint32_t m2 = min(*P.m2_dev, P.cap2);
   const uint32_t begin = P.r0, end = min(m2, P.r1);
   const uint32_t hmask = hash_mask(P.ht);
@@ -1810,7 +1817,9 @@ __global__ __launch_bounds__(256) void k_quads(QuadGroup QG) {
       }
       __syncthreads();
     }
-    const uint32_t n_items = s_ic[0] + s_ic[1] + s_ic[2] + s_ic[3];
+    uint32_t n_items = 0;
+#pragma unroll
+    for (int w = 0; w < kQuadWaves; ++w) n_items += s_ic[w];
     PROF_NOW(pb_);
     uint32_t hops_ = 0; (void)hops_;
     if (threadIdx.x < n_items) {
@@ -1890,7 +1899,7 @@ __global__ __launch_bounds__(256) void k_quads(QuadGroup QG) {
           { const unsigned long long ws = wave_sum_u64(ok ? mix : 0ull); if (lane == 0 && ws) atomicAdd(&s_csum, ws); }
           if (lane == 0) s_wc[wave] = uint32_t(__popcll(pass));
           __syncthreads();
-          if (threadIdx.x == 0) { const uint32_t tot = s_wc[0] + s_wc[1] + s_wc[2] + s_wc[3]; s_cbase = tot ? atomicAdd(P.gate.C_dev, tot) : 0u; }
+          if (threadIdx.x == 0) { uint32_t tot = 0; for (int w = 0; w < kQuadWaves; ++w) tot += s_wc[w]; s_cbase = tot ? atomicAdd(P.gate.C_dev, tot) : 0u; }
           __syncthreads();
           if (ok) {
             uint32_t before = 0;
@@ -1913,7 +1922,7 @@ __global__ __launch_bounds__(256) void k_quads(QuadGroup QG) {
 #endif
   }
   PROF_STAMP(1);
-  PROF_WRITE(1, (blockIdx.y * gridDim.x + blockIdx.x) * 4u + wave);
+  PROF_WRITE(1, (blockIdx.y * gridDim.x + blockIdx.x) * uint32_t(kQuadWaves) + wave);
   if (threadIdx.x == 0) {                                      // one pair of global atomics per workgroup that found anything
     if (s_qsum) atomicAdd(P.qsum_dev, s_qsum);
     if (s_csum) atomicAdd(P.csum_dev, s_csum);
@@ -2181,6 +2190,10 @@ __global__ __launch_bounds__(kVerifyMaxThreads, 6) void k_verify(VerifyParams P)
     c->done = 0;
   }
   *P.group_done = 0u;
+  if (P.ablate == 3) {                                     // S4P_ABLATE=3 (test aid): the launch stalls for ~3 s before its result records appear -- what the
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();      // host's watchdog (S4P_WAIT_TIMEOUT_S) has to turn into an error instead of a hang
+    while (__builtin_amdgcn_s_memrealtime() - t0 < 300000000ull) __builtin_amdgcn_s_sleep(127);
+  }
   __threadfence_system();                                  // the records (host memory) and the cleared counters before the launch number
   for (uint32_t b = 0; b < nb; ++b) __hip_atomic_store(&P.b[b].res->seq, P.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }

@@ -78,6 +78,8 @@ struct Rccl {
   decltype(&ncclAllReduce) AllReduce = nullptr;
   decltype(&ncclBroadcast) Broadcast = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  decltype(&ncclCommCount) CommCount = nullptr;              // (optional: what the communicator itself says about its size and this rank)
+  decltype(&ncclCommUserRank) CommUserRank = nullptr;
   std::string err;
   bool load() {
     if (lib) return true;
@@ -92,6 +94,8 @@ struct Rccl {
     AllReduce = reinterpret_cast<decltype(AllReduce)>(dlsym(lib, "ncclAllReduce"));
     Broadcast = reinterpret_cast<decltype(Broadcast)>(dlsym(lib, "ncclBroadcast"));
     GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
+    CommCount = reinterpret_cast<decltype(CommCount)>(dlsym(lib, "ncclCommCount"));
+    CommUserRank = reinterpret_cast<decltype(CommUserRank)>(dlsym(lib, "ncclCommUserRank"));
     if (!GetUniqueId || !CommInitRank || !CommDestroy || !AllReduce || !Broadcast) { err = "librccl lacks an expected symbol"; lib = nullptr; return false; }
     return true;
   }
@@ -139,6 +143,7 @@ struct NullCollective : Collective {
 
 struct RcclCollective : Collective {                         // RCCL over xGMI, one communicator per matcher
   int device = 0, rank = 0, world = 1;
+  int comm_count = -1, comm_rank = -1;                       // as RCCL reports them (ncclCommCount / ncclCommUserRank); -1: symbol not bound
   ncclComm_t comm = nullptr;
   hipStream_t stream = nullptr;
   hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
@@ -157,6 +162,13 @@ struct RcclCollective : Collective {                         // RCCL over xGMI, 
     ncclUniqueId id;
     std::memcpy(&id, id128, sizeof id);
     if (!nccl_ok(g_rccl.CommInitRank(&comm, world, id, rank), "ncclCommInitRank")) return S4P_ERR_STATE;
+    // the communicator's own view of the job: a line that says "8 ranks" must be RCCL's statement, not the launcher's
+    if (g_rccl.CommCount && !nccl_ok(g_rccl.CommCount(comm, &comm_count), "ncclCommCount")) return S4P_ERR_STATE;
+    if (g_rccl.CommUserRank && !nccl_ok(g_rccl.CommUserRank(comm, &comm_rank), "ncclCommUserRank")) return S4P_ERR_STATE;
+    if ((comm_count >= 0 && comm_count != world) || (comm_rank >= 0 && comm_rank != rank)) {
+      err = "the RCCL communicator reports " + std::to_string(comm_count) + " ranks / rank " + std::to_string(comm_rank) + ", the shard was created as rank " + std::to_string(rank) + " of " + std::to_string(world);
+      return S4P_ERR_STATE;
+    }
     if (!hip_ok(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking), "hipStreamCreate")) return S4P_ERR_HIP;
     for (auto& e : ev) if (!hip_ok(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate")) return S4P_ERR_HIP;
     if (!hip_ok(hipHostMalloc((void**)&host, kBytes, hipHostMallocDefault), "hipHostMalloc")) return S4P_ERR_HIP;
@@ -463,10 +475,18 @@ struct SplitLoop {
     };
     // leaving with an error: the shares still in flight are waited for (their results are dropped); after a failed commit
     // the next reduction of this call, if there is one, carries the error key; the status reduction closes the call
-    auto leave = [&](int32_t rc) -> int32_t {
+    // more: this call still has trials the OTHER ranks will reduce (they committed the window this rank failed to commit and go
+    // on).  With nothing in flight here (depth 1, or the failing commit drained the last share in flight) their next per-trial
+    // reduction must still find a partner: collectives pair by order, not by slot, and it would otherwise pair with this rank's
+    // closing status reduction and leave their own closing reduction without one.
+    auto leave = [&](int32_t rc, bool more) -> int32_t {
       const std::string keep = err;
       const bool local = !remote_error;
       if (commit_failed && !inflight.empty() && !terminated) { local_fail = rc; (void)drain_one(); }
+      else if (commit_failed && inflight.empty() && !terminated && more && !coll_failed) {
+        uint64_t g = 0;
+        if (coll->post(0, kErrorKey) == S4P_OK) (void)coll->result(0, &g);
+      }
       while (!inflight.empty()) {
         const BaseId b = inflight.front(); inflight.pop_front();
         s4p_base_result r;
@@ -482,9 +502,9 @@ struct SplitLoop {
       if (prc != S4P_OK) { b.found = true; b.failed_rc = prc; }
       inflight.push_back(b);
       if (prc != S4P_OK) break;                              // the earlier trials are reduced in order, then this one posts the error key
-      if (int(inflight.size()) >= ops.depth) if (int32_t rc = drain_one()) return leave(rc);
+      if (int(inflight.size()) >= ops.depth) if (int32_t rc = drain_one()) return leave(rc, t + 1 < n);
     }
-    while (!inflight.empty()) if (int32_t rc = drain_one()) return leave(rc);
+    while (!inflight.empty()) if (int32_t rc = drain_one()) return leave(rc, false);
     return close_call(S4P_OK, false);
   }
 };
@@ -536,6 +556,13 @@ int32_t s4p_shard_use_rccl(s4p_shard* s, int32_t device, const uint8_t* unique_i
   if (rc) { s->err = c->err; delete c; return rc; }
   delete s->coll;
   s->coll = c;
+  return S4P_OK;
+}
+
+int32_t s4p_shard_comm_info(const s4p_shard* s, int32_t* n_ranks, int32_t* rank) {
+  if (!s || !n_ranks || !rank) return S4P_ERR_BAD_ARG;
+  *n_ranks = -1; *rank = -1;
+  if (const RcclCollective* c = dynamic_cast<const RcclCollective*>(s->coll)) { *n_ranks = c->comm_count; *rank = c->comm_rank; }
   return S4P_OK;
 }
 

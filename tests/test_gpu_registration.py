@@ -679,3 +679,28 @@ def test_lanes_and_base_groups_change_no_result(oracle_mod, s4p_lib_built, lanes
             if rec[5] and rec[6]:
                 assert (r.n_quads, r.n_verified) == (rec[7], rec[8])
     assert g2.info().best_lcp == om2.stats().best_lcp
+
+
+@pytest.mark.gpu
+def test_a_device_pass_that_stalls_is_an_error_not_a_hang(s4p_lib_built, monkeypatch):
+    """The host waits for a base by polling the launch number k_verify writes last into the pinned result record, with the
+    stream's event as the fallback and a watchdog on top (S4P_WAIT_TIMEOUT_S).  Round 5 found a build whose k_verify never
+    finished by perturbation, not by a test: here a launch that stalls on purpose (S4P_ABLATE=3: the last workgroup sleeps ~3 s
+    before it writes the records) must come back as an error within the watchdog's second -- and the context must survive to be
+    destroyed once the launch has drained."""
+    import time
+    from super4pcs_amd import capi
+    monkeypatch.setenv("S4P_ABLATE", "3")
+    monkeypatch.setenv("S4P_WAIT_TIMEOUT_S", "1")
+    delta, overlap, n_s = 0.01, 0.6, 200
+    P, Q, _ = H.small_pair(20000, delta=delta, seed=3)
+    gm = capi.Matcher(capi.make_options(delta, overlap, n_s))
+    gm.init_full(P, Q)
+    t0 = time.perf_counter()
+    with pytest.raises(capi.S4PError) as e:
+        for _ in range(4):
+            gm.try_one_base()
+    dt = time.perf_counter() - t0
+    assert "did not finish within" in str(e.value) and "S4P_WAIT_TIMEOUT_S" in str(e.value)
+    assert 0.9 <= dt < 2.9                                   # the watchdog, not the end of the stall
+    gm.close()                                              # (waits for the stalled launch: the stall ends after ~3 s)

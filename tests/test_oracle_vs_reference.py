@@ -85,6 +85,55 @@ def test_stages_match_reference_in_order(both):
     assert verified > 100
 
 
+def test_visitor_values_full_counts_vs_the_references_partial_values(both):
+    """DESIGN.md D7, pinned against the reference's own sources: the reference hands its per-candidate visitor v(-1, lcp, T) the
+    value Verify RETURNED, and Verify breaks off as soon as a candidate can no longer reach the running best
+    (match4pcsBase.cc:558-560) -- a partial count that depends on the candidates seen before it.  The drop-in's visitor mode
+    reports every candidate's FULL count instead.  What must hold between the two, candidate by candidate in reference order:
+    the same candidates in the same order; wherever the reference finished its loop the two values are equal; wherever it broke
+    off, its value is a strict lower bound of the full count and the full count lies below the reference's running best --
+    so the winner, the best LCP and every commit are the same under both conventions."""
+    O = both["O"]
+    rm = reflib.RefMatcher(O.make_options(both["delta"], 0.6, 250))      # fresh matchers: this test walks its own base sequence
+    om = O.Matcher(O.make_options(both["delta"], 0.6, 250), full_counts=True)
+    rm.init(both["P"], both["Q"])
+    om.init(both["P"], both["Q"])
+    eps = 2 * both["delta"]
+    n = om.stats().n_Q
+    checked = abandoned = 0
+    for _ in range(14):
+        r = rm.select_quadrilateral()
+        o = om.select_quadrilateral()
+        assert r[0] == o[0]
+        if not r[0]:
+            continue
+        bx, base, i1, i2 = r[4], r[3], r[1], r[2]
+        d1 = float(np.float32(np.linalg.norm(bx[0] - bx[1]))); d2 = float(np.float32(np.linalg.norm(bx[2] - bx[3])))
+        rp1, op1 = rm.extract_pairs(d1, 0.0, eps, 0, 1), om.extract_pairs(d1, 0.0, eps, 0, 1)
+        rp2, op2 = rm.extract_pairs(d2, 0.0, eps, 2, 3), om.extract_pairs(d2, 0.0, eps, 2, 3)
+        if len(rp1) == 0 or len(rp2) == 0:
+            continue
+        rq, oq = rm.find_congruent(i1, i2, eps, rp1, rp2), om.find_congruent(i1, i2, eps, op1, op2)
+        if len(rq) == 0:
+            continue
+        running = _lcp_to_count(rm.best()[1], n)                  # the reference's best_LCP_ before this base
+        r_nb, r_lcps = rm.try_congruent_set(base, rq)           # the reference: early exit against its running best
+        o_nb, full, _, _ = om.try_congruent_set(base, oq)       # the oracle in full-count mode (what the drop-in's visitor reports)
+        assert r_nb == o_nb == len(r_lcps)
+        full = full[full >= 0]
+        for lcp, f in zip(r_lcps, full.tolist()):
+            part = _lcp_to_count(lcp, n)
+            assert part <= f
+            if part == f:
+                running = max(running, f)
+            else:
+                assert f <= running, (part, f, running)          # it could not have become the best
+                abandoned += 1
+            checked += 1
+        assert _lcp_to_count(rm.best()[1], n) == running == _lcp_to_count(om.best()[1], n)      # both conventions commit the same best
+    assert checked > 100 and abandoned > 10
+
+
 def test_verify_matches_reference(both):
     rm, om = both["rm"], both["om"]
     rng = np.random.default_rng(0)

@@ -285,14 +285,16 @@ def test_split_base_loop_a_failing_rank_takes_every_rank_out(s4p_lib_built):
         assert tag == "error" and code == (-5 if rank == 1 else -7)
 
 
-@pytest.mark.parametrize("which", ["first", "last"])
-def test_split_base_loop_a_failing_commit_takes_every_rank_out(which, s4p_lib_built):
+@pytest.mark.parametrize("which,depth", [("first", 2), ("last", 2), ("first", 1), ("last", 1), ("first", 3)])
+def test_split_base_loop_a_failing_commit_takes_every_rank_out(which, depth, s4p_lib_built):
     """A commit that fails on one rank of the split loop: mid-call the next reduction carries the error key, after the last
-    improving base of the call the closing status reduction does."""
+    improving base of the call the closing status reduction does.  At depth 1 nothing is in flight when the commit
+    fails: the failing rank answers the others' next per-trial reduction before it closes the call (the round-5
+    library hangs the other ranks here)."""
     world, seed, n_trials = 3, 1, 40
     want = split_sequential(split_table(seed, n_trials, world), 3, N_Q)
     assert len(want) >= 2
     k = 0 if which == "first" else len(want) - 1
-    res = _run_split(world, seed, n_trials, N_Q, 2, fail_commit=(2, k))
+    res = _run_split(world, seed, n_trials, N_Q, depth, fail_commit=(2, k))
     for rank, tag, code, _ in res:
         assert tag == "error" and code == (-5 if rank == 2 else -7)

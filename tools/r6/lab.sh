@@ -27,6 +27,9 @@ for what in "$@"; do
     benchdef:*)
       spec=${what#benchdef:}
       env $(echo $spec | tr ',' ' ') timeout -s KILL 400 python bench.py --gpus 1 --no-parity --repeats 3 $BQ > $O/bench200np_${spec//[,=]/_}.json 2> $O/bench200np_${spec//[,=]/_}.err; echo "bench200np $spec rc=$?" >> $O/summary.txt ;;
+    b20env:*)
+      spec=${what#b20env:}; lib=${spec%%,*}; envs=${spec#*,}
+      env $(echo $envs | tr ',' ' ') S4P_LIB=$PWD/scratch/lib$lib.so timeout -s KILL 400 python bench.py --gpus 1 --steps 20 --warmup 5 --no-parity $BQ > $O/bench20_${spec//[,=]/_}.json 2> $O/bench20_${spec//[,=]/_}.err; echo "bench20 $spec rc=$?" >> $O/summary.txt ;;
     benchenv:*)
       spec=${what#benchenv:}; lib=${spec%%,*}; envs=${spec#*,}
       env $(echo $envs | tr ',' ' ') S4P_LIB=$PWD/scratch/lib$lib.so timeout -s KILL 400 python bench.py --gpus 1 --no-parity --repeats 3 $BQ > $O/bench200np_${spec//[,=]/_}.json 2> $O/bench200np_${spec//[,=]/_}.err; echo "bench200np $spec rc=$?" >> $O/summary.txt ;;
