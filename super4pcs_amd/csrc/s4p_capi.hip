@@ -83,6 +83,8 @@ struct s4p_ctx {
   // device state
   DevBuf<uint2> greach; DevBuf<uint4> glist_hdr; DevBuf<uint32_t> gcoarse; DevBuf<float4> gnbr; DevBuf<float4> q4, q4v;
   DevBuf<uint2> qquant; QuantQ qq{}; bool qlds = false;      // 16-bit copy of the Morton-ordered queries for the LDS-resident sweep
+  uint32_t verify_blocks_surv = 0;   // workgroups of k_verify when it scores the sweep's survivors (S4P_VERIFY_BLOCKS_SURV; 0: as k_sweep)
+  DevBuf<float> qtiles; uint32_t tile_q = 0, n_tiles = 0; int sweep_pass_env = -1;      // k_sweep's view of the sampled Q: tiles of tile_q points (x | y | z), any sample size.  The first pass runs for samples that do not fit LDS (n_tiles > 1); S4P_SWEEP_PASS=0 / 1 forces it off / on (A/B aid)
   DevBuf<float> qsoa; bool lean = false, lean_lds = false;   // lean_lds: the float copy fits LDS (else the lean sweep reads q4v from global memory)
                       // float copy x | y | z of the same, padded (the lean sweep of k_verify: early-exit mode)
   DevBuf<float> qx, qy, qz, ux, uy, uz, qnx, qny, qnz, qcr, qcg, qcb;
@@ -93,13 +95,13 @@ struct s4p_ctx {
   // growth can build the new set first and swap it in only when every allocation of every lane has succeeded
   struct LaneBufs {
     DevBuf<int2> ab1, ab2; DevBuf<uint32_t> okey1, okey2, cell1, bucket1, next1; DevBuf<float4> ew1;
-    DevBuf<int4> quads; DevBuf<unsigned long long> tags; DevBuf<uint32_t> counts, cand_idx; DevBuf<float4> cand_T;
+    DevBuf<int4> quads; DevBuf<unsigned long long> tags; DevBuf<uint32_t> counts, cand_idx; DevBuf<float4> cand_T, surv_T;      // surv_T: the candidates k_sweep lets through (the list k_verify scores when a bound is in force)
     DevBuf<unsigned long long> ht_keys, ht_heads; uint32_t ht_mask = 0, epoch = 0;
     uint64_t cap_pairs = 0, cap_quads = 0;    // entries these buffers hold (a lane whose base needed more has grown on its own)
     void free_all() {
       cap_pairs = cap_quads = 0;
       ab1.free(); ab2.free(); okey1.free(); okey2.free(); cell1.free(); bucket1.free(); next1.free();
-      ew1.free(); quads.free(); tags.free(); counts.free(); cand_idx.free(); cand_T.free(); ht_keys.free(); ht_heads.free();
+      ew1.free(); quads.free(); tags.free(); counts.free(); cand_idx.free(); cand_T.free(); surv_T.free(); ht_keys.free(); ht_heads.free();
     }
   };
   // What a group launch needs of one base: the parameter records of its four kernels and the upload of its staged sequences,
@@ -242,6 +244,7 @@ struct s4p_ctx {
     return gcoarse.n * 4 + (lean_lds ? size_t((n_q + kSweepStep - 1u) & ~(kSweepStep - 1u)) * 12 : 0) + size_t(verify_threads / 64) * kLeanQueue * 2 + sizeof(VerifyShared);
   }
   bool use_lean() const { return lean && best_hint != 0u; }
+  size_t sweep_lds_bytes() const { return gcoarse.n * 4 + size_t(tile_q) * 12 + sizeof(SweepShared); }
   // (a chunk pass scores ~10^7 candidates with the chip to itself: two workgroups per CU, as for the HBM-bound structure;
   // measured at the 20 000-point sample: 0.50 s per pass with 512 workgroups, 0.66 s with 256)
   bool chunk_pass = false;
@@ -493,7 +496,7 @@ int32_t launch_verify_group(s4p_ctx* c, const int* lanes, int n, hipStream_t vs)
     s4p_ctx::Lane& L = c->lane[lanes[b]];
     VerifyBase& B = V.b[b];
     B.base = c->slot_bf[lanes[b]];
-    B.quads = L.quads.p; B.tags = L.tags.p; B.counts = L.counts.p; B.cand_idx = L.cand_idx.p; B.cand_T = L.cand_T.p;
+    B.quads = L.quads.p; B.tags = L.tags.p; B.counts = L.counts.p; B.cand_idx = L.cand_idx.p; B.cand_T = L.cand_T.p; B.surv_T = L.surv_T.p;
     B.ctr = L.ctr.p; B.res = c->hctr[lanes[b]].dev; B.slots = L.slots.p; B.border = L.border.p;
     L.seq = seq;
   }
@@ -507,8 +510,16 @@ int32_t launch_verify_group(s4p_ctx* c, const int* lanes, int n, hipStream_t vs)
   const bool lean = c->use_lean();                           // a bound is in force: the lean sweep (s4p_kernels.hip.hpp)
   const size_t lds = lean ? c->lean_lds_bytes() : c->verify_lds_bytes();
   const dim3 grid(c->verify_grid()), block(c->verify_threads);
-  if (lean && c->lean_lds) { if (c->prof_points) hipLaunchKernelGGL((k_verify<true, true, true>), grid, block, lds, vs, V); else hipLaunchKernelGGL((k_verify<false, true, true>), grid, block, lds, vs, V); }
-  else if (lean) { if (c->prof_points) hipLaunchKernelGGL((k_verify<true, false, true>), grid, block, lds, vs, V); else hipLaunchKernelGGL((k_verify<false, false, true>), grid, block, lds, vs, V); }
+  if (lean && c->qtiles.p && (c->sweep_pass_env >= 0 ? c->sweep_pass_env != 0 : c->n_tiles > 1u)) {      // first pass: the coarse count of every candidate, survivors -> surv_T (k_sweep)
+    SweepParams W{};
+    W.grid = V.grid; W.qtiles = c->qtiles.p; W.n_q = c->n_q; W.tile_q = c->tile_q; W.n_tiles = c->n_tiles; W.n_bases = uint32_t(n); W.prune = c->best_hint;
+    for (int b = 0; b < n; ++b) { s4p_ctx::Lane& L = c->lane[lanes[b]]; W.b[b] = SweepBase{L.cand_T.p, L.surv_T.p, L.ctr.p, L.counts.p}; }
+    hipLaunchKernelGGL(k_sweep, grid, block, c->sweep_lds_bytes(), vs, W);
+    V.use_surv = 1u;
+  }
+  const dim3 vgrid((V.use_surv && c->verify_blocks_surv && !c->chunk_pass) ? c->verify_blocks_surv : grid.x);
+  if (lean && c->lean_lds) { if (c->prof_points) hipLaunchKernelGGL((k_verify<true, true, true>), vgrid, block, lds, vs, V); else hipLaunchKernelGGL((k_verify<false, true, true>), vgrid, block, lds, vs, V); }
+  else if (lean) { if (c->prof_points) hipLaunchKernelGGL((k_verify<true, false, true>), vgrid, block, lds, vs, V); else hipLaunchKernelGGL((k_verify<false, false, true>), vgrid, block, lds, vs, V); }
   else if (c->prof_points) { if (c->qlds) hipLaunchKernelGGL((k_verify<true, true, false>), grid, block, lds, vs, V); else hipLaunchKernelGGL((k_verify<true, false, false>), grid, block, lds, vs, V); }
   else { if (c->qlds) hipLaunchKernelGGL((k_verify<false, true, false>), grid, block, lds, vs, V); else hipLaunchKernelGGL((k_verify<false, false, false>), grid, block, lds, vs, V); }
   if (c->prof_events) HIPCHK(c, hipEventRecord(c->ev[lanes[0]][1], vs));
@@ -662,7 +673,7 @@ int32_t settle_borderline(s4p_ctx* c, DevCounters& d, const BaseFrame& bf) {
   HIPCHK(c, hipEventSynchronize(c->done[c->cur]));          // (the wait returned on the record's launch number: the launch itself must be over before its buffers are read back)
   std::vector<uint32_t> pos(d.n_border);
   HIPCHK(c, hipMemcpy(pos.data(), L.border.p, size_t(d.n_border) * 4, hipMemcpyDeviceToHost));
-  bool have = d.C > d.n_border;                            // the device selected among the decided candidates only
+  bool have = d.has_best != 0u;                            // the device selected among the decided candidates it scored (with a bound in force: the sweep's survivors)
   for (const uint32_t i : pos) {
     uint32_t kraw = 0, count = 0; int4 qd; unsigned long long tag = 0;
     HIPCHK(c, hipMemcpy(&kraw, L.cand_idx.p + i, 4, hipMemcpyDeviceToHost));
@@ -810,7 +821,7 @@ int32_t run_chunked(s4p_ctx* c, const DevCounters& first, s4p_base_result* r) {
     c->chunk_passes++;
     account_profile(c, d, false);
     Ksum += d.K; Csum += d.C; qsum += d.quad_sum; csum += d.cand_sum;
-    if (d.C && (!have || d.best_count > best.best_count || (d.best_count == best.best_count && d.best_tag < best.best_tag))) { best = d; have = true; }
+    if (d.has_best && (!have || d.best_count > best.best_count || (d.best_count == best.best_count && d.best_tag < best.best_tag))) { best = d; have = true; }
   }
   if (Ksum != Ktot || qsum != first.quad_sum) {
     char b[200];
@@ -876,7 +887,7 @@ int32_t finish_result(s4p_ctx* c, s4p_base_result* r, bool fused) {
       std::memset(r, 0, sizeof(*r));
       r->n_pairs1 = d.m1; r->n_pairs2 = d.m2; r->n_quads = d.K; r->n_verified = d.C;
       r->quad_checksum = d.quad_sum; r->cand_checksum = d.cand_sum;
-      fill_winner(d, d.C != 0, bf, r);
+      fill_winner(d, d.has_best != 0u, bf, r);
       c->last_K = d.K; c->last_chunked = false;
       if (c->sink && fused) if (int32_t rc = capture_pass(c, d, false, false)) return rc;
       return S4P_OK;
@@ -1022,7 +1033,7 @@ hipError_t alloc_lane_buffers(uint64_t mp_, uint64_t mq_, s4p_ctx::LaneBufs& L, 
 #define A(buf, cnt) if ((e = (buf).alloc(cnt)) != hipSuccess) { *what = "hipMalloc " #buf; return e; }
   A(L.ab1, mp); A(L.ab2, mp); A(L.okey1, mp); A(L.okey2, mp); A(L.cell1, mp);
   A(L.bucket1, mp); A(L.next1, mp); A(L.ew1, mp);
-  A(L.quads, mq); A(L.tags, mq); A(L.counts, mq); A(L.cand_idx, mq); A(L.cand_T, mq * kCandStride);
+  A(L.quads, mq); A(L.tags, mq); A(L.counts, mq); A(L.cand_idx, mq); A(L.cand_T, mq * kCandStride); A(L.surv_T, mq * kCandStride);
   A(L.ht_keys, hts); A(L.ht_heads, hts); L.ht_mask = hts - 1;
 #undef A
   *what = "hipMemset";
@@ -1032,7 +1043,7 @@ hipError_t alloc_lane_buffers(uint64_t mp_, uint64_t mq_, s4p_ctx::LaneBufs& L, 
   return hipSuccess;
 }
 size_t lane_bytes(uint64_t mp, uint64_t mq) {            // what alloc_lane_buffers takes per lane
-  return size_t(mp) * (8 + 8 + 4 * 5 + 16) + size_t(mq) * (16 + 8 + 4 + 4 + 16 * kCandStride) + size_t(next_pow2(2 * mp)) * 16;
+  return size_t(mp) * (8 + 8 + 4 * 5 + 16) + size_t(mq) * (16 + 8 + 4 + 4 + 2 * 16 * kCandStride) + size_t(next_pow2(2 * mp)) * 16;
 }
 
 }  // namespace
@@ -1069,6 +1080,8 @@ int32_t s4p_create(const s4p_options* opt, const s4p_limits* lim, int32_t device
   }
   if (const char* vb = getenv("S4P_VERIFY_BLOCKS")) { const int v = atoi(vb); if (v >= 64 && v <= kVerifyMaxBlocks) { c->verify_blocks = uint32_t(v); c->verify_blocks_fixed = true; c->verify_blocks_env = true; } }   // tuning knob
   if (const char* fp = getenv("S4P_FUSE_PREP")) c->fuse_prep = atoi(fp) != 0;
+  if (const char* sp = getenv("S4P_SWEEP_PASS")) c->sweep_pass_env = atoi(sp) != 0 ? 1 : 0;
+  if (const char* sb = getenv("S4P_VERIFY_BLOCKS_SURV")) { const int v = atoi(sb); if (v >= 16 && v <= kVerifyMaxBlocks) c->verify_blocks_surv = uint32_t(v); }
   if (const char* ps = getenv("S4P_PAIR_SPLIT")) { const int v = atoi(ps); if (v == 1 || v == 2 || v == 4) c->pair_split = uint32_t(v); }
   if (const char* gr = getenv("S4P_GROUP")) { const int v = atoi(gr); if (v >= 1 && v <= kGroupMax) c->group = v; }
   c->trace_launch = getenv("S4P_TRACE_LAUNCH") != nullptr;
@@ -1139,6 +1152,7 @@ int32_t s4p_create(const s4p_options* opt, const s4p_limits* lim, int32_t device
                          (const void*)k_verify_T<false, false>, (const void*)k_verify_T<false, true>, (const void*)k_verify_T<true, false>, (const void*)k_verify_T<true, true>};
     for (const void* fn : fns)
       if ((e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds)) != hipSuccess) return fail(e, "hipFuncSetAttribute");
+    if ((e = hipFuncSetAttribute((const void*)k_sweep, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds)) != hipSuccess) return fail(e, "hipFuncSetAttribute");
   }
   for (auto& row : c->ev) for (auto& ev : row) if ((e = hipEventCreate(&ev)) != hipSuccess) return fail(e, "hipEventCreate");
   if ((e = hipStreamCreateWithFlags(&c->sel_stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
@@ -1244,7 +1258,7 @@ void s4p_destroy(s4p_ctx* c) {
             c->lt[2] / c->lt_n * 1e6, c->lt[3] / c->lt_n * 1e6, c->lt[4] / c->lt_n * 1e6, c->lt[5] / c->lt_n * 1e6, c->lt[6] / c->lt_n * 1e6,
             c->host_wait_s / c->lt_n * 1e6, c->host_octree_s / c->lt_n * 1e6, (unsigned long long)c->lt_groups, (unsigned long long)c->prep_redos);
   c->greach.free(); c->glist_hdr.free(); c->gnbr.free();
-  c->gcoarse.free(); c->q4.free(); c->q4v.free(); c->qquant.free(); c->qsoa.free();
+  c->gcoarse.free(); c->q4.free(); c->q4v.free(); c->qquant.free(); c->qsoa.free(); c->qtiles.free();
   c->qx.free(); c->qy.free(); c->qz.free(); c->ux.free(); c->uy.free(); c->uz.free();
   c->qnx.free(); c->qny.free(); c->qnz.free(); c->qcr.free(); c->qcg.free(); c->qcb.free();
   for (auto& L : c->lane) {
@@ -1464,6 +1478,24 @@ int32_t s4p_set_clouds(s4p_ctx* c, const float* px, const float* py, const float
         c->lean = c->lean_lds = true;
       } else if (n_q <= 65535 && fixed <= size_t(kVerifyLdsBudget)) {
         c->lean = true;                                      // queries from global memory (samples that do not fit LDS: the 20 000-point sample)
+      }
+    }
+    // k_sweep's tiles: the same points in the same (Morton) order, tile by tile x | y | z, the last tile padded with far-away points;
+    // one tile while the sample fits kSweepTileMax, tiles of 2048 beyond (any sample size goes through LDS)
+    c->qtiles.free(); c->tile_q = 0; c->n_tiles = 0;
+    if (c->lean) {
+      const uint32_t n_pad = uint32_t(n_pad_q);
+      // as few tiles as fit kSweepTileMax queries each, all of the same size (a multiple of a sweep step): 5000 points are two tiles of 2560
+      c->n_tiles = (n_pad + kSweepTileMax - 1u) / kSweepTileMax;
+      c->tile_q = ((uint32_t(n_q) + c->n_tiles - 1u) / c->n_tiles + kSweepStep - 1u) & ~(kSweepStep - 1u);
+      if (c->gcoarse.n * 4 + size_t(c->tile_q) * 12 + sizeof(SweepShared) <= size_t(kVerifyLdsBudget)) {
+        std::vector<float> tl(size_t(c->n_tiles) * 3u * c->tile_q, kLeanPad);
+        for (int64_t i = 0; i < n_q; ++i) {
+          const size_t t = size_t(i) / c->tile_q, o = size_t(i) % c->tile_q, b0 = t * 3u * c->tile_q;
+          tl[b0 + o] = qv[size_t(i)].x; tl[b0 + c->tile_q + o] = qv[size_t(i)].y; tl[b0 + 2u * c->tile_q + o] = qv[size_t(i)].z;
+        }
+        HIPCHK(c, c->qtiles.alloc(tl.size()));
+        HIPCHK(c, hipMemcpy(c->qtiles.p, tl.data(), tl.size() * sizeof(float), hipMemcpyHostToDevice));
       }
     }
   }

@@ -91,7 +91,8 @@ struct DevCounters {
   unsigned long long point_tests;   // optional instrumentation (COUNT kernels only)
   unsigned long long l0_pass, l1_pass, l2_pass;
   uint32_t done;                    // k_verify: workgroups that have published their best (last one selects the winner)
-  uint32_t pruned;                  // k_verify: candidates abandoned because they could not beat VerifyParams::prune
+  uint32_t pruned;                  // k_sweep + k_verify: candidates abandoned because they could not beat the bound (VerifyParams::prune)
+  uint32_t S;                       // k_sweep: candidates that survived the coarse sweep (the list k_verify scores when a bound is in force)
   // winner record
   int32_t best_quad[4];
   float best_T[16];
@@ -1930,6 +1931,191 @@ __global__ __launch_bounds__(kQuadThreads) void k_quads(QuadGroup QG) {
 }
 
 // ---------------------------------------------------------------------------
+// k_sweep (round 6): the FIRST PASS of Verify when an early-exit bound is in force (VerifyParams::prune > 0: the trial loops).
+// All but a few candidates of a base are dismissed by "how many queries COULD still be inliers": the number of sampled-Q points
+// whose coarse cube (L0 bit) is marked under the candidate's transform is an upper bound of its inlier count, and a candidate
+// whose bound does not EXCEED prune cannot become the best (match4pcsBase.hpp:468).  Until round 5 that count fell
+// out of k_verify's lean sweep, which also queued every L0 survivor for the levels below and so carried a queue per wave (18 KB of
+// LDS), scalar bookkeeping per chunk (SALU 0.6 x VALU), a candidate-record round trip per candidate -- and, for samples that do
+// not fit LDS (n_Q > 2560: the 20 000-point sample), re-streamed the whole query array from L2 for EVERY candidate (4.6 TB/s of
+// L2 reads at 14 M candidates/s).  This pass only COUNTS:
+//   * one wave per BLOCK of kSweepCands candidates; their records are fetched together (one exposure), their coarse-unit
+//     transforms live in registers;
+//   * the sampled Q goes through LDS in TILES of tile_q points (x | y | z floats, padded with far-away points), staged once per
+//     workgroup and tile and swept by every wave for all its block's candidates: query traffic / (waves x kSweepCands);
+//   * per 64 queries and candidate: 3 LDS reads, the packed locate (grid_cell2), clamp, one LDS word, bit extract, ADD -- no
+//     ballot, no queue, no scalar work; one wave reduction per candidate and tile;
+//   * a candidate whose count + unswept queries <= prune is dead: its per-quad count reads 0 (a lower bound, as the
+//     reference's is for what it abandons); the others are copied -- record and candidate index -- to the survivor list, one
+//     global atomic per workgroup and base, and k_verify scores exactly those.
+// Identical results by construction: k_verify applies the same bound again, with the same locate.
+// ---------------------------------------------------------------------------
+constexpr int kSweepCands = 4;                            // candidates per wave and pass over the query tiles
+constexpr uint32_t kSweepTileMax = 2560;                  // queries per LDS tile (30 KB); larger samples take several tiles of 2048
+constexpr int kSweepSurvCap = 1024;                       // survivors a workgroup stages between two flushes
+struct SweepBase {
+  const float4* cand_T; float4* surv_T;                   // gated candidates (64-byte records) -> survivors (same records, .w of the last row = candidate index)
+  DevCounters* ctr; uint32_t* counts;
+};
+struct SweepParams {
+  LcpGrid grid;
+  const float* qtiles;                                    // sampled Q in sweep order: per tile x[tile_q] | y[tile_q] | z[tile_q], padded with kLeanPad
+  uint32_t n_q, tile_q, n_tiles;
+  SweepBase b[kGroupMax]; uint32_t n_bases;
+  uint32_t prune;
+};
+struct SweepShared {
+  uint32_t end[kGroupMax], next, n_surv, dead[kGroupMax], base_pos[kGroupMax];
+  uint32_t surv[kSweepSurvCap];                           // base << 28 | candidate index
+};
+static_assert(sizeof(SweepParams) <= 4096, "SweepParams travels by value in the 4 KB kernel-argument segment");
+static_assert(kGroupMax <= 8, "a staged survivor keeps its base in 3 bits... (28-bit candidate index)");
+
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += uint32_t(__shfl_xor(int(v), o));
+  return v;
+}
+
+__global__ __launch_bounds__(1024, 4) void k_sweep(SweepParams P) {      // (launched with k_verify's grid and block: <= kVerifyMaxThreads)
+  extern __shared__ uint32_t s_mem[];
+  uint32_t* s_coarse = s_mem;                               // LDS: coarse bitmap (address 0) | query tile x | y | z | SweepShared
+  float* s_qx = reinterpret_cast<float*>(s_mem + P.grid.coarse_words);
+  float* s_qy = s_qx + P.tile_q; float* s_qz = s_qy + P.tile_q;
+  SweepShared& S = *reinterpret_cast<SweepShared*>(s_qz + P.tile_q);
+  const uint32_t lane = threadIdx.x & 63u, wave = uint32_t(__builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6))), n_waves = blockDim.x >> 6;
+  const uint32_t nb = P.n_bases;
+  if (threadIdx.x == 0) {
+    uint32_t acc = 0;
+    for (uint32_t b = 0; b < uint32_t(kGroupMax); ++b) {
+      const uint32_t Cb = (b < nb && !(P.b[b].ctr->overflow & 4u)) ? P.b[b].ctr->C : 0u;      // (a pass whose quads overflowed is redone in chunks: nothing to score)
+      acc += blockIdx.x < Cb ? (Cb - blockIdx.x + gridDim.x - 1u) / gridDim.x : 0u;
+      S.end[b] = acc; S.dead[b] = 0u;
+    }
+    S.next = 0u; S.n_surv = 0u;
+  }
+  __syncthreads();
+  const uint32_t hi = uint32_t(__builtin_amdgcn_readfirstlane(int(S.end[kGroupMax - 1])));
+  if (hi == 0u) return;                                     // (uniform) more workgroups than candidates
+  stage_coarse(P.grid, s_coarse);                           // ends with a workgroup barrier
+  auto stage_tile = [&](const uint32_t t) {
+    const float4* src = reinterpret_cast<const float4*>(P.qtiles + size_t(t) * 3u * P.tile_q);
+    float4* dst = reinterpret_cast<float4*>(s_qx);
+    for (uint32_t w = threadIdx.x; w < (3u * P.tile_q) >> 2; w += blockDim.x) dst[w] = src[w];      // (tile_q is a multiple of 256)
+  };
+  if (P.n_tiles == 1u) { stage_tile(0u); __syncthreads(); }
+  // the survivors staged so far -> the bases' survivor lists (all threads; between barriers)
+  auto flush = [&]() {
+    const uint32_t n = min(S.n_surv, uint32_t(kSweepSurvCap));
+    if (n == 0u) return;                                    // (uniform)
+    if (threadIdx.x < uint32_t(kGroupMax)) {
+      uint32_t cnt = 0;
+      for (uint32_t e = 0; e < n; ++e) cnt += (S.surv[e] >> 28) == threadIdx.x ? 1u : 0u;
+      S.base_pos[threadIdx.x] = cnt ? atomicAdd(&P.b[threadIdx.x].ctr->S, cnt) : 0u;
+    }
+    __syncthreads();
+    for (uint32_t e = threadIdx.x; e < n; e += blockDim.x) {
+      const uint32_t w = S.surv[e], b = w >> 28, i = w & 0x0FFFFFFFu;
+      uint32_t before = 0;
+      for (uint32_t f = 0; f < e; ++f) before += (S.surv[f] >> 28) == b ? 1u : 0u;      // (a few dozen entries per flush)
+      const float4* src = P.b[b].cand_T + kCandStride * size_t(i);
+      float4* dst = P.b[b].surv_T + kCandStride * size_t(S.base_pos[b] + before);
+      const float4 r3 = src[3];
+      dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
+      dst[3] = make_float4(r3.x, r3.y, r3.z, __uint_as_float(i));
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) S.n_surv = 0u;
+    __syncthreads();
+  };
+  // pitches of the coarse bitmap include one empty border cube per axis (LcpGridHost::plan): a coordinate outside clamps onto it
+  const uint32_t ucx = uint32_t(P.grid.cnx), ucy = uint32_t(P.grid.cny);
+  const uint32_t mx = ucx - 1u, my = ucy - 1u, mz = uint32_t(((P.grid.nz - 1) >> P.grid.cshift) + 1);
+  const float cs = coarse_scale(P.grid);
+  // every wave of the workgroup takes part in every ROUND (the tile staging is a workgroup affair); a round = kSweepCands tickets per wave
+  const uint32_t per_round = n_waves * uint32_t(kSweepCands), rounds = (hi + per_round - 1u) / per_round;
+  for (uint32_t r = 0; r < rounds; ++r) {
+    const uint32_t t_first = (r * n_waves + wave) * uint32_t(kSweepCands);
+    GridXf X[kSweepCands]; uint32_t bsel[kSweepCands], ci[kSweepCands], kq[kSweepCands], cnt[kSweepCands];
+    bool valid[kSweepCands], alive[kSweepCands], keep[kSweepCands];
+#pragma unroll
+    for (int k = 0; k < kSweepCands; ++k) {
+      const uint32_t t = t_first + uint32_t(k);
+      valid[k] = t < hi; alive[k] = valid[k]; keep[k] = false; cnt[k] = 0u; kq[k] = 0u;
+      uint32_t bs = 0u, t0 = 0u;
+#pragma unroll
+      for (int b = 1; b < kGroupMax; ++b) { const uint32_t e = S.end[b - 1]; if (t >= e) { bs = uint32_t(b); t0 = e; } }
+      bsel[k] = uint32_t(__builtin_amdgcn_readfirstlane(int(bs)));
+      ci[k] = blockIdx.x + (t - uint32_t(__builtin_amdgcn_readfirstlane(int(t0)))) * gridDim.x;
+    }
+#pragma unroll
+    for (int k = 0; k < kSweepCands; ++k) {                 // the block's records: all loads in flight together
+      const float4* src = P.b[valid[k] ? bsel[k] : 0u].cand_T + kCandStride * size_t(valid[k] ? ci[k] : 0u);
+      const float4 r0 = src[0], r1 = src[1], r2 = src[2], r3 = src[3];
+      const float T[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
+      X[k] = make_grid_xf(P.grid, T, cs);
+      const uint32_t kraw = uint32_t(__builtin_amdgcn_readfirstlane(int(__float_as_uint(r3.z))));
+      kq[k] = kraw & ~kBorderFlag;
+      // a candidate whose Euler-angle gate the host still has to settle goes to k_verify whatever its count: only there is it
+      // entered into the list the host works through (it may turn out not to be a candidate at all)
+      keep[k] = valid[k] && (kraw & kBorderFlag) != 0u;
+    }
+    for (uint32_t tile = 0; tile < P.n_tiles; ++tile) {     // uniform
+      if (P.n_tiles > 1u) { __syncthreads(); stage_tile(tile); __syncthreads(); }
+      const uint32_t swept_after = min((tile + 1u) * P.tile_q, P.n_q);
+#pragma unroll
+      for (int k = 0; k < kSweepCands; ++k) {
+        if (!alive[k] || keep[k]) continue;                 // (wave-uniform)
+        uint32_t hits = 0u;
+        for (uint32_t base = 0; base < P.tile_q; base += kSweepStep) {
+          float x[kSweepChunks], y[kSweepChunks], z[kSweepChunks];
+          int cx[kSweepChunks], cy[kSweepChunks], cz[kSweepChunks];
+          uint32_t cc[kSweepChunks], ww[kSweepChunks];
+#pragma unroll
+          for (uint32_t c = 0; c < kSweepChunks; ++c) { const uint32_t i = base + 64u * c + lane; x[c] = s_qx[i]; y[c] = s_qy[i]; z[c] = s_qz[i]; }
+#pragma unroll
+          for (uint32_t c = 0; c < kSweepChunks; c += 2u)
+            grid_cell2(X[k].u, make_float4(x[c], y[c], z[c], 0.f), make_float4(x[c + 1u], y[c + 1u], z[c + 1u], 0.f), cx[c], cy[c], cz[c], cx[c + 1u], cy[c + 1u], cz[c + 1u]);
+#pragma unroll
+          for (uint32_t c = 0; c < kSweepChunks; ++c) {
+            cc[c] = mad24_s(mad24_s(min(uint32_t(cz[c]), mz), ucy, min(uint32_t(cy[c]), my)), ucx, min(uint32_t(cx[c]), mx));
+            ww[c] = lds_word(0u, cc[c] >> 5);              // (the bitmap starts at LDS address 0)
+          }
+#pragma unroll
+          for (uint32_t c = 0; c < kSweepChunks; ++c) hits += bfe1(ww[c], cc[c]);
+        }
+        cnt[k] += wave_sum_u32(hits);
+        if (cnt[k] + (P.n_q - swept_after) <= P.prune) alive[k] = false;      // cannot exceed the bound any more
+      }
+    }
+    // verdicts of the block: dead -> its quad's count reads 0; alive -> staged for the survivor list
+#pragma unroll
+    for (int k = 0; k < kSweepCands; ++k) {
+      if (!valid[k]) continue;                              // (wave-uniform)
+      if (!alive[k]) {
+        if (lane == 0) { P.b[bsel[k]].counts[kq[k]] = 0u; atomicAdd(&S.dead[bsel[k]], 1u); }
+      } else if (lane == 0) {
+        const uint32_t slot = atomicAdd(&S.n_surv, 1u);
+        if (slot < uint32_t(kSweepSurvCap)) S.surv[slot] = (bsel[k] << 28) | ci[k];
+        else {                                              // stage full (a base whose candidates nearly all survive): straight to the list
+          const uint32_t pos = atomicAdd(&P.b[bsel[k]].ctr->S, 1u);
+          const float4* src = P.b[bsel[k]].cand_T + kCandStride * size_t(ci[k]);
+          float4* dst = P.b[bsel[k]].surv_T + kCandStride * size_t(pos);
+          const float4 r3 = src[3];
+          dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = make_float4(r3.x, r3.y, r3.z, __uint_as_float(ci[k]));
+        }
+      }
+    }
+    // (uniform: every wave runs the same rounds)  several tiles: a barrier per round anyway; one tile: every 16th round -- at most
+    // 16 x 16 waves x kSweepCands = 1024 survivors between two looks at the stage, so the direct path above stays a safety net
+    if (P.n_tiles > 1u || (r & 15u) == 15u) { __syncthreads(); if (S.n_surv > uint32_t(kSweepSurvCap) / 4u) flush(); }
+  }
+  __syncthreads();
+  flush();
+  if (threadIdx.x < nb && S.dead[threadIdx.x]) atomicAdd(&P.b[threadIdx.x].ctr->pruned, S.dead[threadIdx.x]);
+}
+
+// ---------------------------------------------------------------------------
 // k_verify: Verify() (match4pcsBase.cc:508-567) of every gated candidate, then -- in the same launch -- the selection of
 // the base's winner (match4pcsBase.hpp:467-484: the first candidate in reference order with the strictly greatest LCP),
 // its transform, and the result record the host reads.  With VerifyParams::prune > 0 a candidate that can no longer
@@ -1943,13 +2129,14 @@ __global__ __launch_bounds__(kQuadThreads) void k_quads(QuadGroup QG) {
 // workgroup per CU while the structure is cache resident, two when the point lines stream from HBM or a chunk pass has the
 // chip to itself (s4p_capi.hip: verify_blocks / verify_grid).  The block size is a launch parameter; the kernels only assume
 // blockDim.x <= kVerifyMaxThreads.
-constexpr int kVerifyMaxThreads = 1024;
+constexpr int kVerifyMaxThreads = 1024;       // (k_sweep's launch bound above says the same)
 constexpr int kVerifyThreadsCached = 768;
 constexpr int kVerifyMaxBlocks = 4096;
 struct VerifyBase {                                     // one base of the launch
   BaseFrame base;
   const int4* quads; const unsigned long long* tags; uint32_t* counts;
   const uint32_t* cand_idx; const float4* cand_T;       // gated candidates: quad index + 3x4 transform
+  const float4* surv_T;                                 // (VerifyParams::use_surv) the candidates k_sweep let through: same records, the candidate's index in .w of the last row
   DevCounters* ctr;                                     // live counters of the base (reset by the last workgroup)
   DevCounters* res;                                     // result record of the base: pinned host memory, written by the last workgroup
   uint4* slots;                                         // per workgroup: {best count, its candidate, tag lo, tag hi}
@@ -1966,6 +2153,7 @@ struct VerifyParams {
   uint32_t* group_done;                                 // workgroups that have published their bests (the last one selects the winners); left at 0
   uint32_t seq;                                         // launch number, written last into every result record
   uint32_t prune;                                       // best inlier count of the registration at launch (LcpTask::prune), 0 = count every candidate in full
+  uint32_t use_surv;                                    // 1: k_sweep ran first -- score the survivor lists (ctr->S entries of surv_T) instead of all gated candidates
   int count_tests;                                      // instrumentation counters are live: carry them into res
   int ablate;                                           // S4P_ABLATE debugging only (0 = full kernel)
 };
@@ -2041,7 +2229,7 @@ __global__ __launch_bounds__(kVerifyMaxThreads, 6) void k_verify(VerifyParams P)
   if (threadIdx.x == 0) {
     uint32_t acc = 0;
     for (uint32_t b = 0; b < uint32_t(kGroupMax); ++b) {
-      const uint32_t Cb = b < nb ? P.b[b].ctr->C : 0u;
+      const uint32_t Cb = b < nb ? (P.use_surv ? P.b[b].ctr->S : P.b[b].ctr->C) : 0u;
       acc += blockIdx.x < Cb ? (Cb - blockIdx.x + gridDim.x - 1u) / gridDim.x : 0u;
       S.end[b] = acc; S.pruned[b] = 0u;
     }
@@ -2079,8 +2267,8 @@ __global__ __launch_bounds__(kVerifyMaxThreads, 6) void k_verify(VerifyParams P)
       for (int b = 1; b < kGroupMax; ++b) { const uint32_t e = S.end[b - 1]; if (t >= e) { bsel = uint32_t(b); t0 = e; } }
       bsel = uint32_t(__builtin_amdgcn_readfirstlane(int(bsel))); t0 = uint32_t(__builtin_amdgcn_readfirstlane(int(t0)));
       const VerifyBase& B = P.b[bsel];
-      const uint32_t i = blockIdx.x + (t - t0) * gridDim.x;
-      const float4* src = B.cand_T + kCandStride * size_t(i);         // one candidate per wave
+      const uint32_t li = blockIdx.x + (t - t0) * gridDim.x;           // position in the list this launch scores
+      const float4* src = (P.use_surv ? B.surv_T : B.cand_T) + kCandStride * size_t(li);         // one candidate per wave
       const float4 r0 = src[0], r1 = src[1], r2 = src[2], r3 = src[3];
 #if defined(S4P_PROF)
       const unsigned long long tc0_ = __builtin_amdgcn_s_memrealtime();
@@ -2092,6 +2280,7 @@ __global__ __launch_bounds__(kVerifyMaxThreads, 6) void k_verify(VerifyParams P)
                                : wave_lcp_count_auto<COUNT, false, QLDS>(P.grid, K, s_coarse, s_q, s_queue, src);
       { // (the record's last 16 bytes are re-read: a line this wave has just held; nothing lives in registers across the sweep)
         const float4 rr = src[3];
+        const uint32_t i = P.use_surv ? uint32_t(__builtin_amdgcn_readfirstlane(int(__float_as_uint(rr.w)))) : li;      // the candidate's index in the gated list
         const uint32_t kraw = uint32_t(__builtin_amdgcn_readfirstlane(int(__float_as_uint(rr.z)))), k = kraw & ~kBorderFlag;
         const unsigned long long tag = (unsigned long long)uint32_t(__builtin_amdgcn_readfirstlane(int(__float_as_uint(rr.x)))) |
                                        ((unsigned long long)uint32_t(__builtin_amdgcn_readfirstlane(int(__float_as_uint(rr.y)))) << 32);
@@ -2166,7 +2355,7 @@ __global__ __launch_bounds__(kVerifyMaxThreads, 6) void k_verify(VerifyParams P)
     DevCounters* c = B.ctr;
     DevCounters* r = B.res;
     const WaveBest w = block_best(b);
-    r->m1 = c->m1; r->m2 = c->m2; r->K = c->K; r->C = c->C; r->overflow = c->overflow;
+    r->m1 = c->m1; r->m2 = c->m2; r->K = c->K; r->C = c->C; r->S = c->S; r->overflow = c->overflow;
     r->quad_sum = c->quad_sum; r->cand_sum = c->cand_sum; r->n_border = c->n_border; r->pruned = c->pruned;
     r->best_count = w.c; r->best_tag = w.t; r->has_best = 0u;
     if (COUNT || P.count_tests) { r->point_tests = c->point_tests; r->l0_pass = c->l0_pass; r->l1_pass = c->l1_pass; r->l2_pass = c->l2_pass; }
@@ -2185,7 +2374,7 @@ __global__ __launch_bounds__(kVerifyMaxThreads, 6) void k_verify(VerifyParams P)
     }
     // the live counters are ready for the next base on this lane (no separate reset launch)
     c->m1 = 0; c->m2 = 0; c->K = 0; c->C = 0; c->best_count = 0; c->overflow = 0; c->best_tag = ~0ull; c->has_best = 0;
-    c->quad_sum = 0; c->cand_sum = 0; c->n_border = 0; c->pruned = 0;
+    c->quad_sum = 0; c->cand_sum = 0; c->n_border = 0; c->pruned = 0; c->S = 0;
     c->point_tests = 0; c->l0_pass = 0; c->l1_pass = 0; c->l2_pass = 0;
     c->done = 0;
   }
@@ -2453,7 +2642,7 @@ __global__ void k_selftest(const float* a, const float* b, uint64_t n, float* o_
 // leaves them cleared for the next base of the lane.
 __global__ void k_reset_counters(DevCounters* c) {
   c->m1 = 0; c->m2 = 0; c->K = 0; c->C = 0; c->best_count = 0; c->overflow = 0;
-  c->best_tag = ~0ull; c->has_best = 0; c->done = 0; c->quad_sum = 0; c->cand_sum = 0; c->n_border = 0; c->pruned = 0;
+  c->best_tag = ~0ull; c->has_best = 0; c->done = 0; c->quad_sum = 0; c->cand_sum = 0; c->n_border = 0; c->pruned = 0; c->S = 0;
   c->point_tests = 0; c->l0_pass = 0; c->l1_pass = 0; c->l2_pass = 0;
 }
 

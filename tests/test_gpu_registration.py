@@ -3,6 +3,8 @@
 Same inputs, same seed -> same sampled clouds, same bases, same per-trial counts, same winning
 candidate; final R,t within 1e-4 (BASELINE.json north_star), LCP (integer inliers) exact.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -704,3 +706,38 @@ def test_a_device_pass_that_stalls_is_an_error_not_a_hang(s4p_lib_built, monkeyp
     assert "did not finish within" in str(e.value) and "S4P_WAIT_TIMEOUT_S" in str(e.value)
     assert 0.9 <= dt < 2.9                                   # the watchdog, not the end of the stall
     gm.close()                                              # (waits for the stalled launch: the stall ends after ~3 s)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("force,n_s,max_angle", [("1", 300, -1.0), ("1", 250, 30.0), (None, 2700, -1.0)])
+def test_the_sweep_pass_changes_no_result(oracle_mod, s4p_lib_built, monkeypatch, force, n_s, max_angle):
+    """Round 6: with an early-exit bound in force k_sweep counts, for every gated candidate, the sampled-Q points whose coarse
+    cube is marked under its transform -- an upper bound of its inlier count -- and only the candidates whose bound exceeds the
+    registration's best go on to k_verify (samples that do not fit LDS by default; S4P_SWEEP_PASS=1 forces the pass for any
+    sample).  Forced on a sample that fits LDS, with the Euler-angle gate in force (undecided candidates must reach the host
+    whatever their count), and on a sample of several LDS tiles (2700 points: two tiles): the registration is the oracle's --
+    LCP, 4x4, transformed cloud, totals -- and the pass really abandons candidates."""
+    from super4pcs_amd import capi
+    if force is not None:
+        monkeypatch.setenv("S4P_SWEEP_PASS", force)
+    if max_angle >= 0:
+        monkeypatch.setenv("S4P_ANGLE_TOL", "0.02")             # many candidates with an undecided gate
+    delta, overlap = 0.01, 0.6
+    if n_s > 2000:
+        delta, overlap = 0.004, 0.8                           # (fewer trials: the oracle replays the whole registration on the host)
+    P, Q, _ = H.small_pair(60000 if n_s > 2000 else 30000, delta=delta, seed=41, overlap=overlap)
+    kw = {"max_angle": max_angle} if max_angle >= 0 else {}
+    O = oracle_mod
+    om = O.Matcher(O.make_options(delta, overlap, n_s, **kw), full_counts=False, use_kdtree=True)
+    if n_s > 2000:
+        om.set_threads(os.cpu_count() or 1)
+    o_lcp, o_M, o_Q = om.compute_transformation(P, Q)
+    gm = capi.Matcher(capi.make_options(delta, overlap, n_s, **kw))
+    gm.profile_enable(True, False)
+    g_lcp, g_M, g_Q = gm.compute_transformation(P, Q)
+    os_, gi = om.stats(), gm.info()
+    if n_s > 2000:
+        assert gi.n_sampled_q > 2560 and "queries from global memory" in gm.verify_kernel_info()
+    assert (gi.pairs_total, gi.quads_total, gi.candidates_verified) == (os_.n_pairs, os_.n_quads, os_.n_verified)
+    assert g_lcp == o_lcp and np.array_equal(g_M, o_M) and np.max(np.abs(g_Q - o_Q)) <= 1e-4
+    assert gm.profile_get().verify_pruned > 0.3 * gi.candidates_verified
