@@ -62,7 +62,7 @@ SEED = 20140814
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 L2_PEAK_GBS = 34500.0          # MI355X_MICROARCH.md: aggregate L2 bandwidth, ~34.5 TB/s
 N_SIMDS = 256 * 4              # 256 CUs x 4 SIMDs
-MAX_PAIRS, MAX_QUADS = 8 << 20, 64 << 20
+MAX_PAIRS, MAX_QUADS = 2 << 20, 8 << 20        # per lane: ~10 x what the workload's largest base needs (a base that needed more would grow its lane)
 
 
 def survey_bytes_per_candidate(n_q, kbar, cells=27):
@@ -443,24 +443,38 @@ def scale_golden_inner(args, device):
     return 1 if mism else 0
 
 
-def extra_sample_line(args, sample=20000, timeout_s=300):
+def extra_sample_start(args, sample=20000):
     """SURVEY 8d's other sample size of the benchmarked clouds (n = 20 000 sampled Q points) as a second, reported figure of the
     driver's own command, in a process of its own (scale_golden_inner): one warm-up base + one timed base, both checked against
     the oracle's committed record.  The live-oracle gate of that size is `bench.py --sample 20000`; the GPU test of the same
-    record is tests/test_gpu_configs.py::test_config2_gpu_scale_sample_20000."""
-    t0 = time.perf_counter()
+    record is tests/test_gpu_configs.py::test_config2_gpu_scale_sample_20000.  Started while the parent is in its host-bound legs
+    (extra_sample_finish collects it)."""
     if args.points != N_POINTS or not os.path.exists(GOLDEN_SCALE):
-        return {"sample_size": sample, "error": "no golden record for this workload (%s)" % os.path.relpath(GOLDEN_SCALE, ROOT), "wall_s": 0.0}
+        return {"sample": sample, "t0": time.perf_counter(), "proc": None, "error": "no golden record for this workload (%s)" % os.path.relpath(GOLDEN_SCALE, ROOT)}
     cmd = [sys.executable, os.path.abspath(__file__), "--sample", str(sample), "--points", str(args.points), "--scale-golden-inner"]
     try:
-        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=timeout_s)
-        line = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][-1]
-        d = json.loads(line)
-        d["wall_s"] = time.perf_counter() - t0
-        d["note"] = "same clouds, sample_size %d: one timed base after one warm-up base, separate process; reported, not `value`" % sample
-        return d
+        return {"sample": sample, "t0": time.perf_counter(), "proc": subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)}
     except Exception as e:                                      # noqa: BLE001 -- the bench line must still be printed
-        return {"sample_size": sample, "error": "%s" % type(e).__name__, "wall_s": time.perf_counter() - t0}
+        return {"sample": sample, "t0": time.perf_counter(), "proc": None, "error": type(e).__name__}
+
+
+def extra_sample_finish(h, timeout_s=300):
+    if h.get("proc") is None:
+        return {"sample_size": h["sample"], "error": h.get("error", "not started"), "wall_s": 0.0}
+    try:
+        stdout, _ = h["proc"].communicate(timeout=timeout_s)
+        line = [ln for ln in stdout.decode().splitlines() if ln.startswith("{")][-1]
+        d = json.loads(line)
+        d["wall_s"] = time.perf_counter() - h["t0"]
+        d["note"] = ("same clouds, sample_size %d: one timed base after one warm-up base, separate process started after the GPU-exclusive "
+                     "measurements of this run and running beside its host-bound legs (oracle replay, CPU baselines); reported, not `value`" % h["sample"])
+        return d
+    except Exception as e:                                      # noqa: BLE001
+        try:
+            h["proc"].kill()
+        except Exception:                                       # noqa: BLE001
+            pass
+        return {"sample_size": h["sample"], "error": "%s" % type(e).__name__, "wall_s": time.perf_counter() - h["t0"]}
 
 
 def part_in_whole_structure(device, n_transforms, seed=11):
@@ -576,7 +590,19 @@ def hbm_bound_point(args, device, n_transforms=4096, timeout_s=300):
     return out
 
 
+_PHASES = []
+
+
+def _lap(name, _t=[None]):
+    """Wall time of the phases of a run (config.phase_seconds): where the minutes of the default command go."""
+    now = time.perf_counter()
+    if _t[0] is not None:
+        _PHASES.append((name, round(now - _t[0], 2)))
+    _t[0] = now
+
+
 def main():
+    _lap("start")
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -757,6 +783,7 @@ def main():
         timed_region(args.steps, args.warmup)
         return
 
+    _lap("import torch + library + synthetic clouds")
     runs, finals = [], []
     m = sh = None
     for _ in range(max(args.repeats, 1)):
@@ -785,6 +812,7 @@ def main():
     if hasattr(sh, "close"):
         sh.close()
     m.close()
+    _lap("timed repeats")
     # per-stage HIP-event times: one more pass over the same bases with events around every stage (not part of `value`)
     stage_prof = prof if scale_mode else None
     if not scale_mode and args.stage_pass:
@@ -837,6 +865,7 @@ def main():
         full_walk = {"kbar": kb_f, "pass_fractions": {"coarse_bitmap_L0": fr_f[0], "reach_bit_L1": fr_f[1], "subcell_mask_L2": fr_f[2]},
                      "groups_per_query": gq_f, "bytes_per_candidate": structure_bytes_per_candidate(n_q, fr_f[0], fr_f[1], fr_f[2], gq_f)[1]}
 
+    _lap("stage pass + full-count region + instrumented replays")
     # time-to-register (the metric's second half): one whole ComputeTransformation on the same pair, wall time from
     # call to return with inputs in host memory (sampling of both 1 M-point clouds, grid build, upload, all trials,
     # final apply).  Reported, never part of `value`.
@@ -855,6 +884,62 @@ def main():
         T2c = np.array(i2.transform, np.float32).reshape(4, 4)
         m2.close()
 
+    _lap("time-to-register")
+    pmc, pmc_note, pmc_kernels = {}, ["skipped"], {}
+    if rank == 0 and world == 1 and args.pmc:
+        pmc, pmc_note, pmc_kernels = pmc_passes(args, int(prof.verify_launches))
+        _lap("rocprofv3 kernel trace + counter passes")
+    hbm_point = None
+    if rank == 0 and world == 1 and args.hbm_point:
+        hbm_point = hbm_bound_point(args, local_rank)
+
+    apply_row = None
+    if rank == 0 and world == 1 and args.hbm_point:
+        # final apply (match4pcsBase.hpp:265-267) on device-resident points: the product's VALU kernel against its MFMA
+        # formulation, GB/s = 24 B per point (12 in, 12 out) / HIP-event time; DESIGN.md section 5.2
+        try:
+            actx = capi.Context(opt, device=local_rank, max_pairs=1 << 16, max_quads=1 << 16)
+            apply_row = {}
+            for n in (1_000_000, 10_000_000):
+                ms_valu, ms_mfma, mism, maxabs = actx.apply_bench(n, 20)
+                apply_row["n=%d" % n] = {"valu_ms": ms_valu, "valu_GBps": 24.0 * n / (ms_valu * 1e-3) / 1e9,
+                                         "mfma_ms": ms_mfma, "mfma_GBps": 24.0 * n / (ms_mfma * 1e-3) / 1e9,
+                                         "coordinates_differing_from_valu": mism, "of": 3 * n, "max_abs_difference": maxabs}
+            actx.close()
+        except Exception as e:                                  # noqa: BLE001
+            apply_row = {"error": "%s: %s" % (type(e).__name__, e)}
+
+    # k_verify with the chip to itself: the same bases with ONE base in flight (S4P_LANES is read at context creation).
+    # With the default number of lanes every launch shares the CUs with the launches of the other lanes, so its HIP-event
+    # duration is not the kernel's own time.
+    _lap("HBM-bound point + final-apply rows")
+    exclusive = None
+    if world == 1 and rank == 0 and args.exclusive:
+        saved = os.environ.get("S4P_LANES")
+        os.environ["S4P_LANES"] = "1"
+        try:
+            m1 = capi.Matcher(opt, device=local_rank, max_pairs=MAX_PAIRS, max_quads=MAX_QUADS)
+            m1.init_full(P, Q)
+            m1.perform_n_steps(args.warmup)
+            m1.profile_enable(True, False)
+            m1.profile_get(reset=True)
+            m1.perform_n_steps(args.steps)
+            p1 = m1.profile_get(reset=True)
+            m1.close()
+            if p1.verify_launches:
+                exclusive = {"avg_launch_ms": p1.verify_ms_total / p1.verify_launches, "launches": int(p1.verify_launches),
+                             "candidates_per_launch": p1.verify_candidates / p1.verify_launches}
+        finally:
+            if saved is None:
+                os.environ.pop("S4P_LANES", None)
+            else:
+                os.environ["S4P_LANES"] = saved
+
+    _lap("one-base-in-flight rerun")
+    # The `extra` figure (the 20 000-point sample, two bases: ~50 s of GPU time in a process of its own) starts HERE, once every
+    # measurement that wants the GPU to itself is over, and runs beside the host-bound legs that follow (the oracle's replay of the
+    # timed bases in the parity gate, the CPU baselines); it is collected when the line is assembled.
+    extra_proc = extra_sample_start(args) if (rank == 0 and world == 1 and args.extra and not scale_mode and not args.inner) else None
     parity = None
     if rank == 0 and world == 1 and args.parity:
         n_par = args.parity_bases if args.parity_bases >= 0 else min(args.steps, 40)
@@ -932,54 +1017,7 @@ def main():
             if failed:
                 parity["failed"] = failed
 
-    pmc, pmc_note, pmc_kernels = {}, ["skipped"], {}
-    if rank == 0 and world == 1 and args.pmc:
-        pmc, pmc_note, pmc_kernels = pmc_passes(args, int(prof.verify_launches))
-    hbm_point = None
-    if rank == 0 and world == 1 and args.hbm_point:
-        hbm_point = hbm_bound_point(args, local_rank)
-
-    apply_row = None
-    if rank == 0 and world == 1 and args.hbm_point:
-        # final apply (match4pcsBase.hpp:265-267) on device-resident points: the product's VALU kernel against its MFMA
-        # formulation, GB/s = 24 B per point (12 in, 12 out) / HIP-event time; DESIGN.md section 5.2
-        try:
-            actx = capi.Context(opt, device=local_rank, max_pairs=1 << 16, max_quads=1 << 16)
-            apply_row = {}
-            for n in (1_000_000, 10_000_000):
-                ms_valu, ms_mfma, mism, maxabs = actx.apply_bench(n, 20)
-                apply_row["n=%d" % n] = {"valu_ms": ms_valu, "valu_GBps": 24.0 * n / (ms_valu * 1e-3) / 1e9,
-                                         "mfma_ms": ms_mfma, "mfma_GBps": 24.0 * n / (ms_mfma * 1e-3) / 1e9,
-                                         "coordinates_differing_from_valu": mism, "of": 3 * n, "max_abs_difference": maxabs}
-            actx.close()
-        except Exception as e:                                  # noqa: BLE001
-            apply_row = {"error": "%s: %s" % (type(e).__name__, e)}
-
-    # k_verify with the chip to itself: the same bases with ONE base in flight (S4P_LANES is read at context creation).
-    # With the default number of lanes every launch shares the CUs with the launches of the other lanes, so its HIP-event
-    # duration is not the kernel's own time.
-    exclusive = None
-    if world == 1 and rank == 0 and args.exclusive:
-        saved = os.environ.get("S4P_LANES")
-        os.environ["S4P_LANES"] = "1"
-        try:
-            m1 = capi.Matcher(opt, device=local_rank, max_pairs=MAX_PAIRS, max_quads=MAX_QUADS)
-            m1.init_full(P, Q)
-            m1.perform_n_steps(args.warmup)
-            m1.profile_enable(True, False)
-            m1.profile_get(reset=True)
-            m1.perform_n_steps(args.steps)
-            p1 = m1.profile_get(reset=True)
-            m1.close()
-            if p1.verify_launches:
-                exclusive = {"avg_launch_ms": p1.verify_ms_total / p1.verify_launches, "launches": int(p1.verify_launches),
-                             "candidates_per_launch": p1.verify_candidates / p1.verify_launches}
-        finally:
-            if saved is None:
-                os.environ.pop("S4P_LANES", None)
-            else:
-                os.environ["S4P_LANES"] = saved
-
+    _lap("parity gate (oracle replay of the warm-up + timed bases; the extra process runs beside it)")
     if rank == 0:
         launches = max(prof.verify_launches, 1)
         avg_ms = prof.verify_ms_total / launches
@@ -1130,12 +1168,16 @@ def main():
                 "note": "HIP-event time per launch (a group of up to three bases) with the other groups in flight, from a separate pass over the same "
                         "bases with events around every stage (the timed passes record events around k_verify only)"},
         }
+        _lap("assembling the line")
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(P, Q, args.cpu_seconds, args.sample, ttr["candidates_verified"] if ttr else 0)
         else:
             out["cpu_baseline"] = None
+        _lap("cpu_baseline (reference on one core + oracle on all cores)")
         out["provenance"] = provenance
-        out["extra"] = extra_sample_line(args) if (world == 1 and args.extra and not scale_mode and not args.inner) else None
+        out["extra"] = extra_sample_finish(extra_proc) if extra_proc is not None else None
+        _lap("waiting for the extra process (the 20 000-point sample, two bases)")
+        out["config"]["phase_seconds"] = dict(_PHASES)
         if world == 1 and args.ttr_configs and out["extra"] is not None:
             # the metric's second half on the other BASELINE configs: a process of its own per run, reported only
             try:

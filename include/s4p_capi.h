@@ -314,6 +314,8 @@ typedef struct {
   double   host_octree_s;        /* host time in the pair-octree builds (loop 1 of IntersectionFunctor)   */
   double   host_wait_s;          /* host time blocked in stream synchronisation                           */
   uint64_t verify_pruned;        /* candidates abandoned because they could not exceed the best-count hint */
+  uint64_t sweep_candidates;     /* candidates that went through the counting first pass (k_sweep: samples beyond LDS) ... */
+  uint64_t sweep_survivors;      /* ... and those it handed on to the scoring pass                                         */
 } s4p_profile;
 /* enable_events: 0 off; 1 HIP events around every stage of a base (five records per base: verify_*, pairs_*, quads_*); 2 around
  * the LCP-verify kernel only (two records per base: what a throughput measurement that also wants the kernel's launch time

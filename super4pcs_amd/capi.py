@@ -28,7 +28,7 @@ EXPORTED_SYMBOLS = [
 
 # The lanes are HIP streams and the runtime maps them onto GPU_MAX_HW_QUEUES hardware queues (default 4; 8 measured +2 %): the
 # request has to be in the environment before HIP initialises, so it is made here, at import (the library itself never
-# touches the process environment; see s4p_capi.hip)
+# touches the process environment; see s4p_capi_ctx.inc)
 if os.environ.get("S4P_KEEP_HW_QUEUES") != "1":        # opt-out: leave the runtime's default number of hardware queues alone
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
@@ -71,6 +71,7 @@ class Profile(C.Structure):
         ("pairs_ms_total", C.c_double), ("quads_ms_total", C.c_double),
         ("pairs_launches", C.c_uint64), ("quads_launches", C.c_uint64),
         ("host_octree_s", C.c_double), ("host_wait_s", C.c_double), ("verify_pruned", C.c_uint64),
+        ("sweep_candidates", C.c_uint64), ("sweep_survivors", C.c_uint64),
     ]
 
 

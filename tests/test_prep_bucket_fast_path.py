@@ -1,5 +1,5 @@
 """k_prep (set 2) takes the direction bucket of a rotated cone sample from the UN-normalised vector when that is safe
-(s4p_kernels.hip.hpp, prep2_group): the rotated vector is unit to rounding, so int((x / 2 + 0.5) / neps) of the normalised
+(s4p_k_prep.hip.hpp, cone_mask_row): the rotated vector is unit to rounding, so int((x / 2 + 0.5) / neps) of the normalised
 vector equals int(fma(x, 0.5, 0.5) * (1 / neps)) of the raw one unless a coordinate lies within 4e-4 of an integer.  This
 test restates both sequences in numpy float32 (same operation order as the kernel / normalset.hpp:110-127, 186-196) on
 a few million random rotations and checks the two facts the kernel relies on: the bucket coordinates differ by far less
