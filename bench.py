@@ -39,14 +39,10 @@ flight; rocprofv3 --pmc passes over an inner run of the same W + K bases give th
 VALU issue utilisation of k_verify, and `binding` names the resource that is closest to its roof.
 """
 import argparse
-import csv
-import glob
 import json
 import os
-import shutil
 import subprocess
 import sys
-import tempfile
 import time
 
 import numpy as np
@@ -54,540 +50,15 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-N_POINTS = 1_000_000
-DELTA = 0.004
-OVERLAP = 0.5
-SAMPLE = 2000
-SEED = 20140814
-HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
-L2_PEAK_GBS = 34500.0          # MI355X_MICROARCH.md: aggregate L2 bandwidth, ~34.5 TB/s
-N_SIMDS = 256 * 4              # 256 CUs x 4 SIMDs
-MAX_PAIRS, MAX_QUADS = 2 << 20, 8 << 20        # per lane: ~10 x what the workload's largest base needs (a base that needed more would grow its lane)
-
-
-def survey_bytes_per_candidate(n_q, kbar, cells=27):
-    """SURVEY.md 8d, no cache credit: B_cand = 16 (quad read) + 8 (count write) + n_Q * (12 + c*8 + kbar*12)."""
-    return 16 + 8 + n_q * (12 + cells * 8 + kbar * 12)
-
-
-def structure_bytes_per_candidate(n_q, f_l0, f_l1, f_l2, groups_per_query):
-    """Bytes the three-level LCP structure REQUIRES per verified candidate:
-    reach word 8 B per L0 survivor; 32 B list header + 16 B exact query per L1 survivor; 48 B (one group of four points:
-    three 16-byte loads) per group a sub-cell-mask survivor walks; 48 B transform + 8 B tag + 4 B index in, 4 B count out.
-    The sweep's own query reads (8 B per query out of the LDS copy) never leave the CU and are reported separately."""
-    sweep = 8.0 * n_q
-    gathers = n_q * (8.0 * f_l0 + 48.0 * f_l1 + 48.0 * groups_per_query) + 64.0
-    return sweep, gathers
-
-
-def seg_len32(a, b):
-    """float32 |a - b| in the reference's evaluation order x + (y + z) (match4pcsBase.hpp:318-321, Eigen 3-vector norm)."""
-    d = (np.asarray(a, np.float32) - np.asarray(b, np.float32)).astype(np.float32)
-    s = np.float32(d[0] * d[0]) + (np.float32(d[1] * d[1]) + np.float32(d[2] * d[2]))
-    return float(np.sqrt(np.float32(s)))
-
-
-def parity_gate(P, Q, opt, warmup, n_bases, full_bases, device, sample):
-    """The W warm-up + n_bases timed bases of the seeded sequence, one by one, on a fresh GPU matcher and on the oracle.
-    Returns (parity object, oracle state after the last base, oracle matcher for recounts)."""
-    from oracle import oracle as O
-    from super4pcs_amd import capi
-    O.build()
-    nproc = os.cpu_count() or 1
-    oopt = O.make_options(DELTA, OVERLAP, sample)
-    om_ref = O.Matcher(oopt, full_counts=False, use_kdtree=True, keep_trace=True)    # reference semantics (early exit)
-    om_ref.set_threads(nproc)                                                         # candidates under OpenMP: same results as the serial loop
-    om_full = O.Matcher(oopt, full_counts=True, use_kdtree=True, keep_trace=False)   # stage-wise, every inlier counted
-    om_full.set_threads(nproc)
-    om_ref.init(P, Q)
-    om_full.init(P, Q)
-    gm = capi.Matcher(opt, device=device, max_pairs=MAX_PAIRS, max_quads=MAX_QUADS)
-    gm.init_full(P, Q)
-    mism = []
-    out = {"bases": 0, "warmup_bases": warmup, "quads": 0, "candidates": 0, "bases_with_every_candidate_counted": 0,
-           "candidates_count_checked": 0}
-
-    def check(ok, what):
-        if not ok:
-            mism.append(what)
-
-    check(np.array_equal(gm.sampled(0), om_ref.cloud(0)) and np.array_equal(gm.sampled(1), om_ref.cloud(1)), "sampled clouds")
-    gi, os_ = gm.info(), om_ref.stats()
-    check((gi.n_sampled_p, gi.n_sampled_q, gi.number_of_trials) == (os_.n_P, os_.n_Q, os_.number_of_trials), "sizes / trial count")
-    check(gi.best_lcp == os_.best_lcp, "initial LCP (Verify(identity))")
-    eps = 2.0 * DELTA
-    cand_before = 0
-    for b in range(warmup + n_bases):
-        timed = b >= warmup
-        g_ok, r = gm.try_one_base()                                   # the fused device pass, as timed
-        want_full = timed and out["bases_with_every_candidate_counted"] < full_bases and r.n_quads > 0
-        if want_full:
-            g_quads, g_counts = gm.last_candidates(r.n_quads)
-        o_ok = om_ref.try_one_base()
-        rec = om_ref.trace()[0][-1]
-        check(g_ok == o_ok, "base %d: TryOneBase return value" % b)
-        if rec[0]:
-            check((r.n_pairs1, r.n_pairs2) == (rec[5], rec[6]), "base %d: pair counts" % b)
-            if rec[5] and rec[6]:
-                check((r.n_quads, r.n_verified) == (rec[7], rec[8]), "base %d: quad / candidate counts" % b)
-        T, lcp, base, cong, _c1, _c2 = om_ref.best()
-        gi = gm.info()
-        check(gi.best_lcp == lcp, "base %d: best LCP" % b)
-        check(list(gi.base) == base.tolist() and list(gi.congruent) == cong.tolist(), "base %d: winning base / quad" % b)
-        check(np.array_equal(np.array(gi.transform, np.float32).reshape(4, 4), T), "base %d: transform" % b)
-        # the stage-wise oracle walks the same sequence (RNG + pair-octree permutation); full counts where asked for
-        ok, i1, i2, obase, bx = om_full.select_quadrilateral()
-        if ok:
-            p1 = om_full.extract_pairs(seg_len32(bx[0], bx[1]), 0.0, eps, 0, 1)
-            p2 = om_full.extract_pairs(seg_len32(bx[2], bx[3]), 0.0, eps, 2, 3)
-            if want_full:
-                o_quads = om_full.find_congruent(i1, i2, eps, p1, p2, cap=max(int(r.n_quads) + 16, 1 << 16)) if (len(p1) and len(p2)) else np.zeros((0, 4), np.int32)
-                same = o_quads.shape == g_quads.shape and np.array_equal(o_quads, g_quads)
-                check(same, "base %d: congruent quads (std::set order)" % b)
-                if same and len(o_quads):
-                    _nb, per, _bc, _bi = om_full.try_congruent_set(obase, o_quads)          # EVERY candidate, full counts
-                    check(np.array_equal(per, g_counts), "base %d: per-candidate inlier counts" % b)
-                    out["candidates_count_checked"] += int((per >= 0).sum())
-                    out["bases_with_every_candidate_counted"] += 1
-        if timed:
-            out["quads"] += int(r.n_quads); out["candidates"] += int(r.n_verified); out["bases"] += 1
-        else:
-            cand_before += int(r.n_verified)
-    T, lcp, base, cong, _c1, _c2 = om_ref.best()
-    state = {"best_lcp": lcp, "base": base.tolist(), "congruent": cong.tolist(), "transform": T.copy(),
-             "candidates_timed": int(om_ref.stats().n_verified) - cand_before}
-    check(state["candidates_timed"] == out["candidates"], "candidates over the timed bases: GPU replay %d vs oracle %d" % (out["candidates"], state["candidates_timed"]))
-    out["mismatches"] = len(mism)
-    out["what"] = ("the %d warm-up + %d timed bases of the seeded sequence, base by base on a fresh GPU matcher and on the oracle in the "
-                   "reference's mode (kd-tree Verify with early exit, candidates under OpenMP): pair / quad / candidate counts, TryOneBase's "
-                   "return value, running best LCP, winning base + quad and 4x4; ordered quad list and the inlier count of EVERY candidate of "
-                   "%d base(s) against the oracle in full-count mode; the final state and the candidate total of every timed repeat "
-                   "against the oracle's" % (warmup, n_bases, out["bases_with_every_candidate_counted"]))
-    if mism:
-        out["failed"] = mism[:20]
-    del gm
-    return out, state, om_full
-
-
-def parity_gate_scale(P, Q, opt, warmup, n_bases, device, sample, sample_mod=1 << 18):
-    """Parity at the "GPU-scale" sample (n = 20 000): a base has ~10^9 congruent quads, which neither the reference's
-    std::set nor the oracle's list form can hold.  Per base the oracle's STREAMING enumeration (OpenMP over the second pair
-    set; pinned to the list form on small cases by tests/test_oracle.py) gives the number of quads, the number that pass
-    the rms gate and order-independent checksums of both, plus a deterministic subsample of the gated quads; the GPU's fused
-    (chunked) pass must reproduce all four numbers, its winner's gate + inlier count are recomputed by the oracle's kd-tree
-    Verify, no sampled candidate may beat it, and the sampled candidates' counts through the stage-level entry point equal
-    the oracle's."""
-    from oracle import oracle as O
-    from super4pcs_amd import capi
-    O.build()
-    om = O.Matcher(O.make_options(DELTA, OVERLAP, sample), full_counts=True, use_kdtree=True, keep_trace=False)
-    om.set_threads(os.cpu_count() or 1)
-    om.init(P, Q)
-    gm = capi.Matcher(opt, device=device)
-    gm.init_full(P, Q)
-    ctx = capi.Context(opt, device=device, max_pairs=32 << 20, max_quads=1 << 20)
-    ctx.set_clouds(om.cloud(0), om.cloud(1))
-    mism = []
-    out = {"bases": 0, "warmup_bases": warmup, "quads": 0, "candidates": 0, "candidates_count_checked": 0}
-
-    def check(ok, what):
-        if not ok:
-            mism.append(what)
-
-    check(np.array_equal(gm.sampled(0), om.cloud(0)) and np.array_equal(gm.sampled(1), om.cloud(1)), "sampled clouds")
-    eps = 2.0 * DELTA
-    bm = {"tests": 0, "l0": 0, "l1": 0, "l2": 0, "queries": 0}
-    for b in range(warmup + n_bases):
-        g_ok, r = gm.try_one_base()
-        ok, i1, i2, base, bx = om.select_quadrilateral()
-        if not ok:
-            check(r.n_pairs1 == 0 and r.n_quads == 0, "base %d: no base found by the oracle" % b)
-            continue
-        p1 = om.extract_pairs_cap(seg_len32(bx[0], bx[1]), 0.0, eps, 0, 1, 1 << 25)
-        p2 = om.extract_pairs_cap(seg_len32(bx[2], bx[3]), 0.0, eps, 2, 3, 1 << 25)
-        check((r.n_pairs1, r.n_pairs2) == (len(p1), len(p2)), "base %d: pair counts" % b)
-        if not (len(p1) and len(p2)):
-            continue
-        want = om.count_congruent(i1, i2, eps, p1, p2, base=base, sample_mod=sample_mod, sample_cap=1 << 15)
-        check((r.n_quads, r.quad_checksum) == (want["K"], want["quad_sum"]), "base %d: quads %d / checksum vs oracle %d" % (b, r.n_quads, want["K"]))
-        check((r.n_verified, r.cand_checksum) == (want["C"], want["cand_sum"]), "base %d: candidates %d / checksum vs oracle %d" % (b, r.n_verified, want["C"]))
-        if r.n_verified:
-            _nb, w_per, _bc, _bi = om.try_congruent_set(base, np.array([list(r.best_quad)], np.int32))
-            check(int(w_per[0]) == int(r.best_count), "base %d: winner's inlier count %d vs oracle %d" % (b, r.best_count, int(w_per[0])))
-            smp = want["sample"][:256]
-            if len(smp):
-                ctx.set_base(bx)
-                _nb, o_per, _bc, _bi = om.try_congruent_set(base, smp)
-                _gr, g_per = ctx.try_congruent_set(base, smp)
-                check(np.array_equal(g_per, o_per), "base %d: inlier counts of %d sampled candidates" % (b, len(smp)))
-                check(int(o_per.max()) <= int(r.best_count), "base %d: a sampled candidate beats the reported winner" % b)
-                out["candidates_count_checked"] += int(len(smp))
-                if b >= warmup:          # the byte model's inputs on this deterministic subsample of the base's candidates
-                    Ts = np.stack([om.compute_rigid(base, q)[2] for q in smp])
-                    st = ctx.verify_stats(Ts)
-                    for k in ("tests", "l0", "l1", "l2"):
-                        bm[k] += st[k]
-                    bm["queries"] += len(smp) * int(om.cloud(1).shape[0])
-        if b >= warmup:
-            out["quads"] += int(r.n_quads); out["candidates"] += int(r.n_verified); out["bases"] += 1
-    out["chunk_stats"] = gm.chunk_stats()
-    out["mismatches"] = len(mism)
-    out["what"] = ("%d timed bases at sample size %d: pair counts, number of congruent quads and of gated candidates with their "
-                   "order-independent checksums against the oracle's streaming enumeration; the winner's gate and inlier count and the counts "
-                   "of a deterministic subsample of the candidates against the oracle's kd-tree Verify" % (n_bases, sample))
-    if mism:
-        out["failed"] = mism[:20]
-    state = {"candidates_timed": out["candidates"], "byte_model": bm}
-    return out, state, None
-
-
-def cpu_baseline(P, Q, budget_s, sample, ttr_candidates):
-    """CPU path on the same workload, bounded samples.
-    A (reference-faithful): 1 thread -- what MatchSuper4PCS does (super4pcs.cc:68-73), kd-tree Verify with early exit.
-       kind "reference": the reference's own sources (oracle/_ref/libs4p_ref.so) run ComputeTransformation and are cut by a
-       visitor exception after budget_s of RANSAC time; kind "port" (the oracle) if the prebuilt library is absent.
-    B (best-effort CPU): the oracle with its CANDIDATE LOOP ONLY under `omp parallel for` on all host
-       cores, as the legacy Match4PCS does by default (match4pcsBase.h:190-192) -- pair extraction and quad enumeration
-       stay serial, as in the reference; also gives the per-stage split."""
-    from oracle import oracle as O
-    from oracle import reflib
-    O.build()
-    nproc = os.cpu_count() or 1
-
-    def port_run(threads, seconds):
-        om = O.Matcher(O.make_options(DELTA, OVERLAP, sample), full_counts=False, use_kdtree=True, keep_trace=False)
-        om.set_threads(threads)
-        om.init(P, Q)
-        om.set_budget(seconds)
-        t0 = time.perf_counter()
-        bases = 0
-        while time.perf_counter() - t0 < seconds:
-            om.try_one_base()
-            bases += 1
-        dt = time.perf_counter() - t0
-        s = om.stats()
-        return {"value": s.n_verified / dt, "unit": "candidates/s", "cores": threads, "kind": "port",
-                "sample": "oracle restatement, first %d base(s) of the same seeded sequence, TryCongruentSet cut after %.0f s wall "
-                          "(%d candidates verified, kd-tree Verify with the reference's early exit)" % (bases, seconds, s.n_verified),
-                "seconds": dt,
-                "stage_seconds": {"select": s.t_select, "pairs": s.t_pairs, "quads": s.t_quads, "verify": s.t_verify}}
-
-    if reflib.available():
-        rm = reflib.RefMatcher(O.make_options(DELTA, OVERLAP, sample))
-        cut, n, sec = rm.bench(P, Q, budget_s)
-        a = {"value": n / max(sec, 1e-9), "unit": "candidates/s", "cores": 1, "kind": "reference",
-             "sample": "reference ComputeTransformation (kd-tree Verify with early exit) on the same clouds/seed, "
-                       "stopped after %.1f s of RANSAC time: %d candidates verified%s" % (sec, n, "" if cut else " (ran to completion)"),
-             "seconds": sec}
-    else:
-        a = port_run(1, budget_s)
-    a["host_cores"] = nproc
-    a["note"] = ("CPU and GPU both abandon a candidate that cannot beat the best LCP so far (match4pcsBase.cc:558-560; the GPU with an "
-                 "order-independent bound against the best at launch time, config.early_exit): a reported baseline, not a target")
-    b = port_run(nproc, max(budget_s * 0.6, 3.0))
-    b["label"] = "candidate loop only under OpenMP (pairs and quads serial, as in the reference)"
-    a["openmp_all_cores"] = b
-    if ttr_candidates:
-        # time-to-register on the CPU (BASELINE.md section 3 "Reported"; the reference's tests allow 600 s): the whole
-        # registration verifies ttr_candidates candidates (counted by the GPU run above, equal to the oracle's by the parity
-        # tests); at the sampled rates that is an EXTRAPOLATION, not a run -- a measured run is in profiles/ (README there)
-        a["time_to_register"] = {"measured": False, "candidates_of_the_registration": int(ttr_candidates),
-                                 "extrapolated_seconds_1_core": ttr_candidates / max(a["value"], 1e-9),
-                                 "extrapolated_seconds_all_cores": ttr_candidates / max(b["value"], 1e-9),
-                                 "cap_seconds": 600,
-                                 "note": "candidates of the whole registration / sampled candidates-per-second (the first bases are "
-                                         "the slowest per candidate: no best LCP to exit early against yet); the run itself, all host "
-                                         "cores, 600 s cap: tools/r3_cpu_ttr.py -> profiles/r03_cpu_time_to_register.json (307 s on 256 cores)"}
-    return a
-
-
-def pmc_passes(args, n_timed_launches, timeout_s=240):
-    """rocprofv3 --pmc passes over an inner run of this script with the SAME warm-up + timed bases and the default lanes
-    (counters serialise the launches: per-kernel numbers are the kernel's own).  Three passes -- the TCC slots do not hold
-    FETCH_SIZE and WRITE_SIZE together (MI355X_MICROARCH.md "rocprofv3 PMC slots").  Returns {counter: (mean per k_verify
-    launch, launches)}, notes, and the same counters + the kernel's own duration (kernel trace of the counter passes) for ALL
-    FOUR kernels of a device pass ({kernel: {...}}: every launch covers a group of bases)."""
-    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
-    if not os.path.exists(exe):
-        return {}, ["rocprofv3 not found"]
-    got, note = {}, []
-    KERNELS = ("k_pairs2", "k_prep", "k_quads", "k_verify")
-    per_kernel = {k: {} for k in KERNELS}
-
-    def kname(row_name):
-        for k in KERNELS:
-            if ("s4p::%s<" % k) in row_name or ("s4p::%s(" % k) in row_name:
-                return k
-        return None
-    for ctrs in (["FETCH_SIZE", "GRBM_GUI_ACTIVE", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY"],
-                 ["WRITE_SIZE"], ["TCC_HIT_sum", "TCC_MISS_sum"]):
-        d = tempfile.mkdtemp(prefix="s4p_pmc_", dir="/tmp")
-        cmd = [exe, "--pmc"] + ctrs + ["--kernel-trace", "-d", d, "-o", "p", "--output-format", "csv", "--",
-               sys.executable, os.path.abspath(__file__), "--inner", "--steps", str(args.steps), "--warmup", str(args.warmup),
-               "--points", str(args.points), "--sample", str(args.sample)]
-        env = dict(os.environ, TMPDIR="/tmp")
-        try:
-            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=True)
-            vals = {}
-            allk = {k: {} for k in KERNELS}
-            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
-                for row in csv.DictReader(open(f)):
-                    if row.get("Counter_Name") not in ctrs:
-                        continue
-                    if "k_verify<" in row.get("Kernel_Name", ""):
-                        vals.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
-                    kn = kname(row.get("Kernel_Name", ""))
-                    if kn:
-                        allk[kn].setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
-            for kn, cs in allk.items():
-                for cname, v in cs.items():
-                    per_kernel[kn][cname] = float(np.mean(v[len(v) // 4:]))      # (skip the warm-up quarter)
-                    per_kernel[kn]["launches"] = len(v)
-            if "GRBM_GUI_ACTIVE" in ctrs:                        # the kernels' own durations: launches are serialised under --pmc
-                dur = {k: [] for k in KERNELS}
-                for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
-                    for row in csv.DictReader(open(f)):
-                        kn = kname(row.get("Kernel_Name", ""))
-                        if kn:
-                            dur[kn].append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3)
-                for kn, v in dur.items():
-                    if v:
-                        per_kernel[kn]["avg_us"] = float(np.mean(v[len(v) // 4:]))
-            # the inner run launches warm-up + timed bases (a launch covers a group of bases): keep the timed region's launches,
-            # as many as the main run counted with its HIP events (the last ones)
-            for k, v in vals.items():
-                v = v[-n_timed_launches:] if (n_timed_launches and len(v) >= n_timed_launches) else v
-                got[k] = (float(np.mean(v)), len(v))
-            if args.profile_dir:
-                os.makedirs(args.profile_dir, exist_ok=True)
-                for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
-                    rows = [r for r in csv.DictReader(open(f)) if "k_verify<" in r.get("Kernel_Name", "")]
-                    if rows:
-                        with open(os.path.join(args.profile_dir, "pmc_%s_k_verify.csv" % "_".join(ctrs)[:60]), "w", newline="") as fo:
-                            w = csv.DictWriter(fo, fieldnames=["Dispatch_Id", "Kernel_Name", "Counter_Name", "Counter_Value"], extrasaction="ignore")
-                            w.writeheader(); w.writerows(rows)
-        except Exception as e:                                  # noqa: BLE001 -- the bench line must still be printed
-            note.append("%s pass failed: %s" % ("+".join(ctrs), type(e).__name__))
-        finally:
-            shutil.rmtree(d, ignore_errors=True)
-    return got, note, per_kernel
-
-
-GOLDEN_SCALE = os.path.join(ROOT, "tests", "golden", "scale_config2_n20000.json")
-
-
-def scale_golden_inner(args, device):
-    """The `extra` figure's own process: the benchmarked clouds at SURVEY 8d's GPU-scale sample (n = 20 000 sampled Q points:
-    ~27 M ordered pairs and ~10^9 congruent quads per base, every base chunked).  The seeded bases the oracle's committed record
-    covers (tests/golden/scale_config2_n20000.json: trials 0 and 1, written by tests/golden/make_scale_golden.py on the CPU --
-    the oracle needs the better part of an hour for them) run one at a time through TryOneBase; the LAST one is the timed
-    base.  Every base is checked against the record: pair counts, number of congruent quads and of gated candidates with
-    their order-independent checksums, the inlier counts of a deterministic subsample of the gated quads (stage-level entry
-    point), and the winner must not be beaten by any sampled candidate.  Prints one JSON object."""
-    import hashlib
-    from super4pcs_amd import capi, datasets
-    G = json.load(open(GOLDEN_SCALE))
-    P, Q, _ = datasets.bumpy_pair(args.points, overlap=OVERLAP, delta=DELTA, seed=SEED)
-    opt = capi.make_options(DELTA, OVERLAP, args.sample)
-    m = capi.Matcher(opt, device=device, max_pairs=32 << 20, max_quads=32 << 20)
-    m.init_full(P, Q)
-    info = m.info()
-    mism = []
-
-    def check(ok, what):
-        if not ok:
-            mism.append(what)
-
-    check((info.n_sampled_p, info.n_sampled_q, info.number_of_trials) == (G["n_P"], G["n_Q"], G["number_of_trials"]), "sampled clouds / trial count")
-    saved = os.environ.get("S4P_LANES")
-    os.environ["S4P_LANES"] = "1"                       # the stage-level context needs one lane
-    ctx = capi.Context(opt, device=device, max_pairs=1 << 20, max_quads=1 << 20)
-    if saved is None:
-        os.environ.pop("S4P_LANES", None)
-    else:
-        os.environ["S4P_LANES"] = saved
-    ctx.set_clouds(m.sampled(0), m.sampled(1))
-    m.loop_begin()                                      # (the trial loops' mode: commits refresh the early-exit bound)
-    timed = None
-    parity = {"bases": 0, "quads": 0, "candidates": 0, "candidates_count_checked": 0, "golden": os.path.relpath(GOLDEN_SCALE, ROOT),
-              "golden_sha16": hashlib.sha256(open(GOLDEN_SCALE, "rb").read()).hexdigest()[:16]}
-    for rec in G["bases"]:
-        t0 = time.perf_counter()
-        _ok, r = m.try_one_base()
-        dt = time.perf_counter() - t0
-        b = rec["trial"]
-        check((r.n_pairs1, r.n_pairs2) == (rec["pairs"][0]["n"], rec["pairs"][1]["n"]), "base %d: pair counts" % b)
-        check((r.n_quads, "%016x" % r.quad_checksum) == (rec["K"], rec["quad_sum"]), "base %d: quads %d / checksum vs the oracle's %d" % (b, r.n_quads, rec["K"]))
-        check((r.n_verified, "%016x" % r.cand_checksum) == (rec["C"], rec["cand_sum"]), "base %d: candidates %d / checksum vs the oracle's %d" % (b, r.n_verified, rec["C"]))
-        smp = np.array(rec["sample_quads"], np.int32).reshape(-1, 4)
-        want = np.array(rec["sample_counts"], np.int32)
-        ctx.set_base(m.sampled(0)[np.array(rec["base"])])
-        _gr, g_per = ctx.try_congruent_set(np.array(rec["base"], np.int32), smp)
-        check(np.array_equal(g_per, want), "base %d: inlier counts of %d sampled candidates" % (b, len(smp)))
-        check(bool(r.has_best) and int(want.max()) <= int(r.best_count), "base %d: a sampled candidate beats the reported winner" % b)
-        parity["bases"] += 1; parity["quads"] += int(r.n_quads); parity["candidates"] += int(r.n_verified); parity["candidates_count_checked"] += int(len(smp))
-        timed = {"seconds": dt, "candidates": int(r.n_verified), "trial": b}
-    m.loop_end()
-    parity["mismatches"] = len(mism)
-    parity["what"] = ("every base of this run (trials %s; the last one is the timed base): pair counts, number of congruent quads and of gated candidates "
-                      "with their order-independent checksums, the inlier counts of a deterministic subsample of the gated quads, and no sampled "
-                      "candidate beats the winner -- against the oracle's committed record" % [r_["trial"] for r_ in G["bases"]])
-    if mism:
-        parity["failed"] = mism[:20]
-    st = m.chunk_stats()
-    out = {"sample_size": args.sample, "value": timed["candidates"] / timed["seconds"], "unit": "candidates/s", "ms_per_step": timed["seconds"] * 1e3,
-           "steps": 1, "warmup": len(G["bases"]) - 1, "n_Q": info.n_sampled_q, "candidates_timed": timed["candidates"], "timed_trial": timed["trial"],
-           "chunked_bases": st["bases"], "chunk_passes": st["passes"], "k_verify": m.verify_kernel_info(), "parity": parity}
-    m.close()
-    print(json.dumps(out))
-    return 1 if mism else 0
-
-
-def extra_sample_start(args, sample=20000):
-    """SURVEY 8d's other sample size of the benchmarked clouds (n = 20 000 sampled Q points) as a second, reported figure of the
-    driver's own command, in a process of its own (scale_golden_inner): one warm-up base + one timed base, both checked against
-    the oracle's committed record.  The live-oracle gate of that size is `bench.py --sample 20000`; the GPU test of the same
-    record is tests/test_gpu_configs.py::test_config2_gpu_scale_sample_20000.  Started while the parent is in its host-bound legs
-    (extra_sample_finish collects it)."""
-    if args.points != N_POINTS or not os.path.exists(GOLDEN_SCALE):
-        return {"sample": sample, "t0": time.perf_counter(), "proc": None, "error": "no golden record for this workload (%s)" % os.path.relpath(GOLDEN_SCALE, ROOT)}
-    cmd = [sys.executable, os.path.abspath(__file__), "--sample", str(sample), "--points", str(args.points), "--scale-golden-inner"]
-    try:
-        return {"sample": sample, "t0": time.perf_counter(), "proc": subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)}
-    except Exception as e:                                      # noqa: BLE001 -- the bench line must still be printed
-        return {"sample": sample, "t0": time.perf_counter(), "proc": None, "error": type(e).__name__}
-
-
-def extra_sample_finish(h, timeout_s=300):
-    if h.get("proc") is None:
-        return {"sample_size": h["sample"], "error": h.get("error", "not started"), "wall_s": 0.0}
-    try:
-        stdout, _ = h["proc"].communicate(timeout=timeout_s)
-        line = [ln for ln in stdout.decode().splitlines() if ln.startswith("{")][-1]
-        d = json.loads(line)
-        d["wall_s"] = time.perf_counter() - h["t0"]
-        d["note"] = ("same clouds, sample_size %d: one timed base after one warm-up base, separate process started after the GPU-exclusive "
-                     "measurements of this run and running beside its host-bound legs (oracle replay, CPU baselines); reported, not `value`" % h["sample"])
-        return d
-    except Exception as e:                                      # noqa: BLE001
-        try:
-            h["proc"].kill()
-        except Exception:                                       # noqa: BLE001
-            pass
-        return {"sample_size": h["sample"], "error": "%s" % type(e).__name__, "wall_s": time.perf_counter() - h["t0"]}
-
-
-def part_in_whole_structure(device, n_transforms, seed=11):
-    """BASELINE configs[4]'s structure (100 k-point query in a 10 M-point scene: n_P ~ 4.2 M sampled scene points -> ~1.4 GB
-    of point lines, >> the 256 MB Infinity Cache) and a batch of transforms that slide the query over the WHOLE scene
-    (uniform over the ground's extent, any yaw), so that consecutive transforms do not share cache lines."""
-    from super4pcs_amd import capi, datasets
-    delta = 0.05
-    P, Q, T_gt = datasets.part_in_whole_pair(10_000_000, 100_000, delta=delta)
-    opt = capi.make_options(delta, 0.2, 5000)
-    m = capi.Matcher(opt, device=device, max_pairs=1 << 20, max_quads=1 << 20)
-    m.init_full(P, Q)
-    i = m.info()
-    Ps, Qs = m.sampled(0), m.sampled(1)
-    m.close()
-    ctx = capi.Context(opt, device=device, max_pairs=1 << 20, max_quads=1 << 20)
-    ctx.set_clouds(Ps, Qs)
-    cP, cQ = np.array(i.centroid_p, np.float64), np.array(i.centroid_q, np.float64)
-    Tg = np.asarray(T_gt, np.float64)
-    Tc = np.eye(4)
-    Tc[:3, :3] = Tg[:3, :3]
-    Tc[:3, 3] = Tg[:3, :3] @ cQ + Tg[:3, 3] - cP
-    lo, hi = Ps.min(axis=0).astype(np.float64), Ps.max(axis=0).astype(np.float64)
-    rng = np.random.default_rng(seed)
-    Ts = []
-    for _ in range(n_transforms):
-        Tp = np.eye(4)
-        a = rng.uniform(-np.pi, np.pi)
-        Tp[:3, :3] = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]])
-        Tp[:3, 3] = [rng.uniform(0.8 * lo[0], 0.8 * hi[0]), rng.uniform(0.8 * lo[1], 0.8 * hi[1]), rng.uniform(-0.05, 0.05)]
-        Ts.append((Tp @ Tc).astype(np.float32))
-    return ctx, Ps, Qs, np.stack(Ts), opt
-
-
-def hbm_point_inner(device, n_transforms):
-    """(run under rocprofv3 by hbm_bound_point) ONE cold s4p_verify_transforms over the configs[4] structure; prints the counts."""
-    ctx, Ps, Qs, Ts, _ = part_in_whole_structure(device, n_transforms)
-    t0 = time.perf_counter()
-    counts = ctx.verify_transforms(Ts)               # first and only scoring launch of this process: nothing is warm
-    dt = time.perf_counter() - t0
-    print(json.dumps({"seconds_wall": dt, "n_P": int(Ps.shape[0]), "n_Q": int(Qs.shape[0]), "counts_head": counts[:128].tolist(),
-                      "mean_inliers": float(np.mean(counts))}))
-
-
-def hbm_bound_point(args, device, n_transforms=4096, timeout_s=300):
-    """One HBM-bound operating point of the same scoring code, measured by rocprofv3 in a process of its own: kernel
-    duration from --kernel-trace and FETCH_SIZE from --pmc of the SINGLE, cold k_verify_T launch; the first 64 counts are
-    recomputed by the oracle's kd-tree Verify on the same sampled clouds (parity of the timed launch itself)."""
-    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
-    if not os.path.exists(exe):
-        return {"error": "rocprofv3 not found"}
-    d = tempfile.mkdtemp(prefix="s4p_hbm_", dir="/tmp")
-    cmd = [exe, "--pmc", "FETCH_SIZE", "--kernel-trace", "-d", d, "-o", "h", "--output-format", "csv", "--",
-           sys.executable, os.path.abspath(__file__), "--hbm-point-inner", "--hbm-transforms", str(n_transforms)]
-    out = {}
-    try:
-        pr = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=timeout_s, check=True)
-        inner = json.loads([l for l in pr.stdout.splitlines() if l.startswith("{")][-1])
-        dur_ns, fetch = None, None
-        for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
-            for row in csv.DictReader(open(f)):
-                if "k_verify_T<" in row.get("Kernel_Name", ""):
-                    dur_ns = float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
-        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
-            for row in csv.DictReader(open(f)):
-                if "k_verify_T<" in row.get("Kernel_Name", "") and row.get("Counter_Name") == "FETCH_SIZE":
-                    fetch = float(row["Counter_Value"])
-            if args.profile_dir:
-                os.makedirs(args.profile_dir, exist_ok=True)
-                shutil.copy(f, os.path.join(args.profile_dir, "hbm_point_counter_collection.csv"))
-        if args.profile_dir:
-            for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
-                shutil.copy(f, os.path.join(args.profile_dir, "hbm_point_kernel_trace.csv"))
-        if dur_ns is None or fetch is None:
-            return {"error": "no k_verify_T row in the rocprofv3 output"}
-        # the byte model's inputs for this structure: an instrumented pass over the same transforms
-        from oracle import oracle as O
-        ctx, Ps, Qs, Ts, _ = part_in_whole_structure(device, n_transforms)
-        stats = ctx.verify_stats(Ts)                 # survivors per level, exact point tests
-        n_q = Qs.shape[0]
-        queries = float(len(Ts)) * n_q
-        groups = stats["tests"] / 4.0 / queries      # (listed points of mask survivors / 4: an upper bound of the groups walked)
-        _sweep, gathers = structure_bytes_per_candidate(n_q, stats["l0"] / queries, stats["l1"] / queries, stats["l2"] / queries, groups)
-        fetch_b = fetch * 1024.0 * 2.0               # KB -> B, x2: gfx950 tallies 128-B read requests at 64 B (MI355X_MICROARCH.md, HBM)
-        t = dur_ns * 1e-9
-        out = {"workload": "configs[4] structure: n_P=%d sampled scene points, n_Q=%d, %d transforms spread over the whole scene, ONE cold launch"
-                           % (inner["n_P"], n_q, len(Ts)),
-               "kernel_ms": dur_ns * 1e-6, "transforms_per_s": len(Ts) / t, "mean_inliers": inner["mean_inliers"],
-               "fetch_bytes": fetch_b, "measured_GBps": fetch_b / t / 1e9, "measured_frac": fetch_b / t / 1e9 / HBM_PEAK_GBS,
-               "algorithmic_bytes": len(Ts) * gathers, "achieved_GBps": len(Ts) * gathers / t / 1e9, "peak_GBps": HBM_PEAK_GBS,
-               "frac": len(Ts) * gathers / t / 1e9 / HBM_PEAK_GBS,
-               "counts_checked_by_oracle": 0, "count_mismatches": None,
-               "note": "`frac` is the ALGORITHMIC figure (dependent gathers the structure requires / kernel time); measured_frac doubles FETCH_SIZE, a factor "
-                       "the guide calibrates for wide coalesced streams only -- uncalibrated for 16-byte gathers, an upper bound here.  "
-                       "kernel duration and FETCH_SIZE (doubled: gfx950 tallies 128-B requests at 64 B) of the single cold k_verify_T launch, "
-                       "rocprofv3 --kernel-trace --pmc FETCH_SIZE in a process of its own; algorithmic bytes = dependent gathers the structure "
-                       "requires (reach words, 32-B headers, query re-reads, 48-B point groups) from the instrumented kernel's counters"}
-        # parity of the TIMED launch: the oracle's kd-tree Verify recounts the first 64 transforms on exactly the sampled,
-        # centred clouds the context was given (the inner process builds them the same way: same seeds)
-        try:
-            om = O.Matcher(O.make_options(0.05, 0.2, 5000), full_counts=True, use_kdtree=True)
-            om.set_sampled(Ps, Qs)
-            want = om.verify_batch(Ts[:64])
-            got = np.array(inner["counts_head"][:64], np.int64)
-            out["counts_checked_by_oracle"] = 64
-            out["count_mismatches"] = int((want.astype(np.int64) != got).sum())
-        except Exception as e:                                  # noqa: BLE001
-            out["count_mismatches"] = "oracle recount failed: %s" % e
-    except Exception as e:                                      # noqa: BLE001
-        out = {"error": "%s: %s" % (type(e).__name__, e)}
-    finally:
-        shutil.rmtree(d, ignore_errors=True)
-    return out
+# (round 6: the 1200-line file is split by subject -- benchlib/: workload + byte models, parity gates, CPU baselines, rocprofv3
+# passes, the GPU-scale sample; this file keeps the command line, the timed region and the JSON line.  The names other code uses
+# from here -- bench.DELTA, bench.seg_len32, ... -- are re-exported.)
+from benchlib.workload import (DELTA, GOLDEN_SCALE, HBM_PEAK_GBS, L2_PEAK_GBS, MAX_PAIRS, MAX_QUADS, N_POINTS, N_SIMDS, OVERLAP, SAMPLE, SEED,      # noqa: E402,F401
+                               seg_len32, structure_bytes_per_candidate, survey_bytes_per_candidate)
+from benchlib.parity import parity_gate, parity_gate_scale                                                  # noqa: E402
+from benchlib.baselines import cpu_baseline                                                                # noqa: E402
+from benchlib.profiling import hbm_bound_point, hbm_point_inner, pmc_passes                                # noqa: E402
+from benchlib.scale import extra_sample_finish, extra_sample_start, scale_golden_inner                     # noqa: E402
 
 
 _PHASES = []
