@@ -10,7 +10,7 @@ namespace s4p {
 // s4p_debug_prof.  Absent from the shipped library.
 #if defined(S4P_PROF)
 constexpr int kProfWords = 12, kProfWaves = 8192;
-__device__ unsigned long long g_prof[3][kProfWords * kProfWaves];      // [0] k_pairs2 [1] k_quads [2] k_verify
+__device__ unsigned long long g_prof[4][kProfWords * kProfWaves];      // [0] k_pairs2 [1] k_quads [2] k_verify [3] k_verify's lean sweep: phase sums per wave (s4p_k_lcp.hip.hpp)
 #define PROF_DECL unsigned long long tp_[kProfWords] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
 #define PROF_NOW(v) do { __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_sched_barrier(0); v = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define PROF_STAMP(k) PROF_NOW(tp_[k])
@@ -192,6 +192,28 @@ __device__ __forceinline__ uint32_t mad24(uint32_t a, uint32_t b, uint32_t c) {
 __device__ __forceinline__ uint32_t mad24_s(uint32_t a, uint32_t b_uniform, uint32_t c) {
   uint32_t r;
   asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b_uniform), "v"(c));
+  return r;
+}
+__device__ __forceinline__ uint32_t mul24_s(uint32_t a, uint32_t b_uniform) {
+  uint32_t r;
+  asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "s"(b_uniform), "v"(a));
+  return r;
+}
+// 16-bit pairs (round 6, the lean sweep's cube coordinates): {lo, hi} -> {u16(RNE(clamp(lo, 0, 1) * 65535)), u16(...hi...)} in one
+// instruction (NaN -> 0); per-half unsigned minimum against a wave-uniform pair; a.lo * k.lo + a.hi * k.hi + c.
+__device__ __forceinline__ uint32_t cvt_pknorm_u16(float lo, float hi) {
+  uint32_t r;
+  asm("v_cvt_pknorm_u16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+__device__ __forceinline__ uint32_t pk_min_u16_s(uint32_t a, uint32_t b_uniform) {
+  uint32_t r;
+  asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "s"(b_uniform));
+  return r;
+}
+__device__ __forceinline__ uint32_t dot2_u16_s(uint32_t a, uint32_t k_uniform, uint32_t c) {
+  uint32_t r;
+  asm("v_dot2_u32_u16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(k_uniform), "v"(c));
   return r;
 }
 // floor(x) as an integer in one instruction (V_CVT_FLR_I32_F32; the compiler only emits v_floor + v_cvt)

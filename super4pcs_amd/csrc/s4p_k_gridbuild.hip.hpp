@@ -127,6 +127,18 @@ __global__ __launch_bounds__(256) void k_grid_headers(GridBuildParams P, const u
     }
   }
 }
+// The coarse bitmap moved up by `shift` bits behind zero bits, for the lean sweep of k_verify (s4p_k_lcp.hip.hpp): its index is
+// (cube + 1) on x and y, so cube -1 of a row must read the (empty) border cube of the row before it and the cubes in front of the
+// first row must read zero words.  dst bit b = src bit b - shift; one thread per destination word, once per cloud.
+__global__ __launch_bounds__(256) void k_coarse_shift(const uint32_t* src, uint32_t n_src, uint32_t shift, uint32_t* dst, uint32_t n_dst) {
+  for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < n_dst; w += gridDim.x * blockDim.x) {
+    const long long first = 32ll * w - (long long)shift;          // source bit behind destination bit 32 w
+    const long long sw = first >> 5;                              // (floor)
+    const uint32_t so = uint32_t(first & 31ll);
+    const uint32_t lo = (sw >= 0 && sw < (long long)n_src) ? src[sw] : 0u, hi = (sw + 1 >= 0 && sw + 1 < (long long)n_src) ? src[sw + 1] : 0u;
+    dst[w] = so ? (lo >> so) | (hi << (32u - so)) : lo;
+  }
+}
 constexpr float kFarAway = 3.0e38f;             // unused slots of a point line: (t - 3e38)^2 = inf, never an inlier, never a NaN
 constexpr uint32_t kLinePoints = 8;              // points per 128-byte line
 // float index of point slot `slot` (0..7), axis `axis` (0..2) inside a line of 32 floats

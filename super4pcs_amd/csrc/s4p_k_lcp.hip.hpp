@@ -51,6 +51,9 @@ struct LcpTask {                 // what the scoring loop needs besides the grid
   // reference's is for every candidate it abandons).  0 = every candidate is counted in full.
   uint32_t prune;
   uint32_t* pruned;                  // (k_verify) per-workgroup LDS counter of abandoned candidates, or nullptr
+#if defined(S4P_PROF)
+  unsigned long long* lp;            // lab build: the calling wave's phase sums of the lean sweep (kProfWords words, in registers)
+#endif
 };
 
 // The locating transform of a candidate: grid units, and for QLDS folded with the de-quantisation
@@ -475,9 +478,14 @@ __device__ __forceinline__ uint32_t wave_lcp_count_lean(const LcpGrid& g, const 
   // + entries not tested yet (+ rest: queries not swept yet)" -- a candidate whose L0 survivors exceeded the bound is usually
   // dismissed before all of them have been tested (measured on the bench workload: one candidate in five reaches this point and
   // its serial 64-entry batches were ~40 % of the kernel's wave time).  Returns true if the candidate is dismissed.
-  auto drain = [&](const uint32_t rest) -> bool {
+  float Tpre[12];                                          // (the lane-parallel path below requests the candidate's rows before it fills the queue)
+  auto drain = [&](const uint32_t rest, auto have_rows) -> bool {
     lds_fence();
-    float T[12]; load_rows(Tsrc, T);
+    float T[12];
+    if constexpr (decltype(have_rows)::value) {
+#pragma unroll
+      for (int i = 0; i < 12; ++i) T[i] = Tpre[i];
+    } else load_rows(Tsrc, T);
     const GridXf X = make_grid_xf(g, T, 1.f);
     uint32_t rd = nb;
     const uint32_t end = nb + na;
@@ -487,17 +495,20 @@ __device__ __forceinline__ uint32_t wave_lcp_count_lean(const LcpGrid& g, const 
 #pragma unroll
       for (uint32_t k = 0; k < kSweepChunks; ++k) { const uint32_t at = rd + 64u * k + lane; vv[k] = at < end; ii[k] = uint32_t(q[min(at, end - 1u)]); }
       lds_fence();                                         // every lane holds its entries before any slot of this round is rewritten
+      const uint32_t n_round = min(end - rd, kSweepStep);
 #pragma unroll
       for (uint32_t k = 0; k < kSweepChunks; ++k) {
+        cc[k] = 0u; ww[k] = make_uint2(0u, 0u);
+        if (k != 0u && 64u * k >= n_round) continue;        // (uniform) a round is rarely full: most candidates bring ~150 entries
         int ix, iy, iz;
         grid_cell(X.u, lean_query<QL>(K, L, ii[k]), ix, iy, iz);
         vv[k] = vv[k] & (uint32_t(ix) < uint32_t(g.nx)) & (uint32_t(iy) < uint32_t(g.ny)) & (uint32_t(iz) < uint32_t(g.nz));
         cc[k] = mad24(mad24(uint32_t(iz), uint32_t(g.ny), uint32_t(iy)), uint32_t(g.nx), uint32_t(ix));
         ww[k] = g.reach[vv[k] ? cc[k] >> 5 : 0u];
       }
-      const uint32_t n_round = min(end - rd, kSweepStep);
 #pragma unroll
       for (uint32_t k = 0; k < kSweepChunks; ++k) {
+        if (k != 0u && 64u * k >= n_round) continue;        // (uniform; vv[k] is false in every lane)
         const bool reach = vv[k] & (((ww[k].x >> (cc[k] & 31u)) & 1u) != 0u);
         const unsigned long long m = __builtin_amdgcn_ballot_w64(reach);
         if (reach) q[__builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), nb))] = uint16_t(ii[k]);   // nb <= rd: below the entries read
@@ -513,6 +524,175 @@ __device__ __forceinline__ uint32_t wave_lcp_count_lean(const LcpGrid& g, const 
   };
   const uint32_t n_pad = (K.n_q + kSweepStep - 1u) & ~(kSweepStep - 1u);
   bool abandoned = false;
+#if defined(S4P_PROF)
+  unsigned long long lp_[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // [0] start [1] sweep end [2] queue filled [3] drain time [4] exact time [5] exact batches [6] sweep steps [7] alive after the sweep
+  PROF_NOW(lp_[0]);
+#endif
+  // drain + exact batches once the queue cannot take another step (or the candidate's last entries are in): `rest` = what has not
+  // been queued yet and may still count.  Returns true if the candidate is abandoned.
+  auto settle = [&](const bool more, const uint32_t rest, auto have_rows) -> bool {
+#if defined(S4P_PROF)
+    unsigned long long sa_, sb_; PROF_NOW(sa_);
+    const bool dd_ = drain(rest, have_rows);
+    PROF_NOW(sb_); lp_[3] += sb_ - sa_;
+    if (dd_) return true;
+#else
+    if (drain(rest, have_rows)) return true;
+#endif
+    while ((more && nb + 2u * kSweepStep > kLeanQueue) || (!more && nb != 0u)) {
+      if (cnt + nb + rest <= K.prune) return true;
+      const uint32_t n = min(nb, 128u);
+      const bool va = lane < n, vb = lane + 64u < n;
+      const uint32_t ia = uint32_t(q[nb - n + min(lane, n - 1u)]), ib = uint32_t(q[nb - n + min(lane + 64u, n - 1u)]);
+      if (COUNT) { if (lane == 0) atomicAdd(K.point_tests + 2, (unsigned long long)n); }      // list headers read (l1_pass)
+      if (!SKIP_FINE) {
+        const uint32_t h = exact_pair_lean<COUNT, QL>(g, K, L, Tsrc, va, ia, vb, ib);
+        cnt += uint32_t(__popcll(__builtin_amdgcn_ballot_w64((h & 1u) != 0u))) + uint32_t(__popcll(__builtin_amdgcn_ballot_w64((h & 2u) != 0u)));
+      }
+      nb -= n;
+      lds_fence();
+#if defined(S4P_PROF)
+      lp_[5] += 1;
+#endif
+    }
+#if defined(S4P_PROF)
+    { unsigned long long sc_; PROF_NOW(sc_); lp_[4] += sc_ - sb_; }
+#endif
+    return false;
+  };
+  if constexpr (QL) {
+    // ---- round 6: the sweep of a sample that lives in LDS COUNTS and REMEMBERS, it does not queue ----
+    // With three waves per SIMD the sweep is bound by VECTOR ISSUE: a wave issues one instruction per four cycles, a SIMD one
+    // vector instruction per four cycles whichever of its waves it comes from, and a step of 256 queries was ~90 vector
+    // instructions (measured per candidate with the lab build's stamps: 3.4 us for its eight steps = ~1000 cycles per step and
+    // wave; more waves per CU change nothing: profiles/r06_lab).  So the sweep is priced in vector instructions per 64 queries:
+    // ~22 until round 5, ~18 here.
+    //   * x and y of two queries leave the packed FMAs already scaled by 1/65535 and offset by half a cube, so ONE
+    //     v_cvt_pknorm_u16_f32 per query rounds (to nearest = floor of the cube coordinate + 1), clamps below at 0 and packs both
+    //     axes (measured on the device: RNE of the exact product, NaN and negatives -> 0, +inf -> 65535);
+    //     ONE v_pk_min_u16 clamps both above, onto the pitch (the bitmap's empty border cube); ONE v_dot2_u32_u16 forms
+    //     x' + pitch_x * y' on top of the z term.  (Before: three floor-converts, three clamps, two multiply-adds.)
+    //     The bitmap this indexes is the copy SHIFTED by pitch_x + 1 bits behind a few zero words (LcpGrid::coarse of the lean
+    //     launches, built once per cloud by k_coarse_shift): cube -1 of a row is the border cube of the row before it, row -1
+    //     of a slab the border row of the slab before it, and in front of the first slab lie the zero words.
+    //   * z keeps the floor-convert + unsigned clamp onto the border slab (a packed form needs pitch_x * pitch_y < 65536).
+    //   * an L0 survivor costs its lane one v_lshl_or_b32 -- the lane's 64-bit shift register holds one bit per chunk of the
+    //     sample -- and the wave one compare for the running total; no prefix sum, no LDS write, no scalar bookkeeping per chunk.
+    //     The queue is filled from the shift registers only for the candidates that are still alive after the whole sweep (one
+    //     in four on the bench workload), with the tighter bound "survivors not queued yet" in place of "queries not swept yet"
+    //     for everything that follows.
+    // The locate may move a query by ~1e-5 cube against grid_cell2 (coefficients rounded after the scaling by 1/65535); the
+    // structure absorbs 1e-2 cell at every level (LcpGridHost::plan), and the exact stage below re-locates in fine units.
+    // (The same transform on the matrix pipe -- v_mfma_f32_4x4x1_16b_f32, lane = query, thirteen MFMAs per step for the eighteen
+    // packed FMAs -- was measured again on this form: no faster, MFMAs take the same issue slots; and this compiler leaves out
+    // the wait states between such an MFMA and a vector instruction that reads its result: wrong counts until s_nop by hand.)
+    static_assert(kLeanMaxQueries <= 64 * 64, "a 64-bit shift register per lane: at most 64 chunks");
+    const uint32_t lim_xy = (ucy << 16) | ucx, kdot = (ucx << 16) | 1u, cnxy = ucx * ucy;
+    float un[8];
+    { const float kn = 1.0f / 65535.0f;
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        un[4 * r + 0] = Xc.u[4 * r + 0] * kn; un[4 * r + 1] = Xc.u[4 * r + 1] * kn; un[4 * r + 2] = Xc.u[4 * r + 2] * kn;
+        un[4 * r + 3] = (Xc.u[4 * r + 3] + 0.5f) * kn;
+      } }
+    auto axis2 = [&](const float a, const float b, const float c, const float d, const v2f_t x, const v2f_t y, const v2f_t z) -> v2f_t {
+      const v2f_t ab = {a, b}, cd = {c, d};
+      return pk_fma_lo(ab, x, pk_fma_hi(ab, y, pk_fma_lo_hi(cd, z)));       // fma(a, x, fma(b, y, fma(c, z, d))) for both queries
+    };
+    uint32_t acc0 = 0u, acc1 = 0u, total = 0u;
+    for (uint32_t base = 0; base < n_pad; base += kSweepStep) {          // wave-uniform
+      const uint32_t unswept = uint32_t(max(int(K.n_q) - int(base + kSweepStep), 0));
+      float x[kSweepChunks], y[kSweepChunks], z[kSweepChunks];
+      uint32_t bb[kSweepChunks], ww[kSweepChunks];
+#pragma unroll
+      for (uint32_t k = 0; k < kSweepChunks; ++k) { const uint32_t i = base + 64u * k + lane; x[k] = L.qx[i]; y[k] = L.qy[i]; z[k] = L.qz[i]; }
+#pragma unroll
+      for (uint32_t k = 0; k < kSweepChunks; k += 2u) {
+        const v2f_t vx = {x[k], x[k + 1u]}, vy = {y[k], y[k + 1u]}, vz = {z[k], z[k + 1u]};
+        const v2f_t px = axis2(un[0], un[1], un[2], un[3], vx, vy, vz), py = axis2(un[4], un[5], un[6], un[7], vx, vy, vz);
+        const v2f_t pz = axis2(Xc.u[8], Xc.u[9], Xc.u[10], Xc.u[11], vx, vy, vz);
+        const uint32_t z0 = min(uint32_t(floor_to_int(pz.x)), mz), z1 = min(uint32_t(floor_to_int(pz.y)), mz);
+        bb[k] = dot2_u16_s(pk_min_u16_s(cvt_pknorm_u16(px.x, py.x), lim_xy), kdot, mul24_s(z0, cnxy));
+        bb[k + 1u] = dot2_u16_s(pk_min_u16_s(cvt_pknorm_u16(px.y, py.y), lim_xy), kdot, mul24_s(z1, cnxy));
+      }
+      __builtin_amdgcn_sched_barrier(0);                                 // (the step's four bitmap words are requested together ...
+#pragma unroll
+      for (uint32_t k = 0; k < kSweepChunks; ++k) ww[k] = lds_word(coarse_base, bb[k] >> 5);
+      __builtin_amdgcn_sched_barrier(0);                                 // ... before the first is consumed: one exposure per step, not four)
+      uint32_t bits = 0u;
+#pragma unroll
+      for (uint32_t k = 0; k < kSweepChunks; ++k) {
+        const uint32_t t = bfe1(ww[k], bb[k]);
+        total += uint32_t(__popcll(__builtin_amdgcn_ballot_w64(t != 0u)));
+        bits = k == 0u ? t : ((bits << 1) | t);
+      }
+      // the lane's 64-bit shift register {acc1, acc0}: after the sweep, chunk c of n sits at bit n - 1 - c
+      acc1 = __builtin_amdgcn_alignbit(acc1, acc0, 32u - kSweepChunks);
+      acc0 = (acc0 << kSweepChunks) | bits;
+#if defined(S4P_PROF)
+      lp_[6] += 1;
+#endif
+      if (total + unswept <= K.prune) { abandoned = true; break; }          // cannot exceed the bound any more: no global access made
+    }
+#if defined(S4P_PROF)
+    PROF_NOW(lp_[1]); lp_[2] = lp_[1]; lp_[7] = abandoned ? 0 : 1;
+#endif
+    const uint32_t n_chunks = n_pad >> 6;
+    if (!abandoned && total <= kLeanQueue) {
+      // The survivors' query indices -> the queue, every lane its own (one candidate in four gets here -- the coarse level alone
+      // dismisses only the far-off ones -- so this is priced like the sweep: a chunk-by-chunk expansion with a ballot per chunk
+      // cost ~250 vector instructions and took back what the sweep had gained).  Lane l writes its popcount(acc) entries behind
+      // those of the lanes below it (inclusive scan on the DPP pipe: row_shr 1, 2, 4, 8 inside the rows of 16, then row_bcast 15
+      // and 31 across them), one entry per trip of a loop that runs for the busiest lane's count: ~6 trips.
+      load_rows(Tsrc, Tpre);                                           // (the drain's transform: its round trip runs beside the queue fill)
+      const uint32_t pc = uint32_t(__popc(acc0)) + uint32_t(__popc(acc1));
+      uint32_t incl = pc;
+      incl += uint32_t(__builtin_amdgcn_update_dpp(0, int(incl), 0x111, 0xf, 0xf, false));
+      incl += uint32_t(__builtin_amdgcn_update_dpp(0, int(incl), 0x112, 0xf, 0xf, false));
+      incl += uint32_t(__builtin_amdgcn_update_dpp(0, int(incl), 0x114, 0xf, 0xf, false));
+      incl += uint32_t(__builtin_amdgcn_update_dpp(0, int(incl), 0x118, 0xf, 0xf, false));
+      incl += uint32_t(__builtin_amdgcn_update_dpp(0, int(incl), 0x142, 0xa, 0xf, false));
+      incl += uint32_t(__builtin_amdgcn_update_dpp(0, int(incl), 0x143, 0xc, 0xf, false));
+      uint16_t* qw = q + (incl - pc);
+      const uint32_t top = (n_chunks - 1u) * 64u + lane;               // bit p of {acc1, acc0} is chunk n_chunks - 1 - p: query top - 64 p
+      uint32_t w = acc0;
+      while (w != 0u) { const uint32_t b = uint32_t(__builtin_ctz(w)); w &= w - 1u; *qw++ = uint16_t(top - 64u * b); }
+      w = acc1;
+      while (w != 0u) { const uint32_t b = uint32_t(__builtin_ctz(w)) + 32u; w &= w - 1u; *qw++ = uint16_t(top - 64u * b); }
+      na = total;
+#if defined(S4P_PROF)
+      PROF_NOW(lp_[2]);
+#endif
+      if (settle(false, 0u, std::true_type{})) abandoned = true;
+    } else if (!abandoned) {
+      // (more L0 survivors than the queue takes: a candidate that really aligns the clouds)  chunk by chunk, a step's worth at a
+      // time, settled whenever the queue cannot take another step
+      uint32_t rest = total;                                           // L0 survivors not queued yet
+      for (uint32_t c0 = 0;; c0 += kSweepChunks) {
+        const bool more = c0 < n_chunks;                               // wave-uniform
+        if (more) {
+#pragma unroll
+          for (uint32_t k = 0; k < kSweepChunks; ++k) {
+            const uint32_t ch = c0 + k;                                // (uniform; n_chunks is a multiple of kSweepChunks)
+            const uint32_t pos = n_chunks - 1u - ch, word = pos < 32u ? acc0 : acc1;
+            const uint32_t t = (word >> (pos & 31u)) & 1u;
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(t != 0u);
+            if (m != 0ull) {
+              uint16_t* qw = q + (nb + na);
+              if (t != 0u) qw[__builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u))] = uint16_t(ch * 64u + lane);
+              const uint32_t n = uint32_t(__popcll(m));
+              na += n; rest -= n;
+            }
+          }
+          if (cnt + nb + na + rest <= K.prune) { abandoned = true; break; }
+        }
+        if (!more || nb + na + kSweepStep > kLeanQueue) {
+          if (settle(more, more ? rest : 0u, std::false_type{})) { abandoned = true; break; }
+        }
+        if (!more) break;
+      }
+    }
+  } else {
   for (uint32_t base = 0;; base += kSweepStep) {
     const bool more = base < n_pad;                        // wave-uniform
     const uint32_t unswept = K.n_q - min(base + kSweepStep, K.n_q);
@@ -549,25 +729,18 @@ __device__ __forceinline__ uint32_t wave_lcp_count_lean(const LcpGrid& g, const 
       if (cnt + nb + na + unswept <= K.prune) { abandoned = true; break; }
     }
     if (!more || nb + na + kSweepStep > kLeanQueue) {
-      const uint32_t rest = more ? unswept : 0u;
-      const bool dead = drain(rest);
-      if (dead) { abandoned = true; break; }
-      while ((more && nb + 2u * kSweepStep > kLeanQueue) || (!more && nb != 0u)) {
-        if (cnt + nb + rest <= K.prune) { abandoned = true; break; }
-        const uint32_t n = min(nb, 128u);
-        const bool va = lane < n, vb = lane + 64u < n;
-        const uint32_t ia = uint32_t(q[nb - n + min(lane, n - 1u)]), ib = uint32_t(q[nb - n + min(lane + 64u, n - 1u)]);
-        if (COUNT) { if (lane == 0) atomicAdd(K.point_tests + 2, (unsigned long long)n); }      // list headers read (l1_pass)
-        if (!SKIP_FINE) {
-          const uint32_t h = exact_pair_lean<COUNT, QL>(g, K, L, Tsrc, va, ia, vb, ib);
-          cnt += uint32_t(__popcll(__builtin_amdgcn_ballot_w64((h & 1u) != 0u))) + uint32_t(__popcll(__builtin_amdgcn_ballot_w64((h & 2u) != 0u)));
-        }
-        nb -= n;
-        lds_fence();
-      }
+      if (settle(more, more ? unswept : 0u, std::false_type{})) { abandoned = true; break; }
     }
     if (!more || abandoned) break;
   }
+  }
+#if defined(S4P_PROF)
+  if (QL) {
+    unsigned long long e_; PROF_NOW(e_);
+    K.lp[0] += 1; K.lp[1] += lp_[1] - lp_[0]; K.lp[2] += lp_[6]; K.lp[3] += lp_[7]; K.lp[4] += lp_[2] - lp_[1];
+    K.lp[5] += lp_[3]; K.lp[6] += lp_[4]; K.lp[7] += lp_[5]; K.lp[8] += e_ - lp_[0]; K.lp[9] += lp_[5] ? 1ull : 0ull; K.lp[10] += abandoned ? 0ull : 1ull; K.lp[11] += cnt;
+  }
+#endif
   if (abandoned && K.pruned != nullptr && lane == 0) atomicAdd(K.pruned, 1u);
   __builtin_amdgcn_wave_barrier();
   return cnt;

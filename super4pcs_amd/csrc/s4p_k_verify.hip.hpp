@@ -320,6 +320,10 @@ __global__ __launch_bounds__(kVerifyMaxThreads, 6) void k_verify(VerifyParams P)
     LcpTask K;
     K.q4 = P.q4v; K.n_q = P.n_q; K.qq = P.qq; K.T = P.b[0].cand_T; K.t_stride = kCandStride; K.point_tests = &P.b[0].ctr->point_tests;
     K.prune = P.prune; K.pruned = &S.pruned[0];
+#if defined(S4P_PROF)
+    unsigned long long lpa_[kProfWords] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    K.lp = lpa_;
+#endif
     if (LEAN) { if (QLDS) stage_queries_f(P.qsoa, const_cast<float*>(LL.qx), 3u * n_pad); }
     else if (QLDS) stage_queries(K, s_q);
     stage_coarse(P.grid, s_coarse);                        // ends with a workgroup barrier
@@ -352,8 +356,8 @@ __global__ __launch_bounds__(kVerifyMaxThreads, 6) void k_verify(VerifyParams P)
       if (LEAN) cnt = P.ablate == 1 ? wave_lcp_count_lean<COUNT, true, QLDS>(P.grid, K, LL, src, r0, r1, r2) : wave_lcp_count_lean<COUNT, false, QLDS>(P.grid, K, LL, src, r0, r1, r2);
       else cnt = P.ablate == 1 ? wave_lcp_count_auto<COUNT, true, QLDS>(P.grid, K, s_coarse, s_q, s_queue, src)
                                : wave_lcp_count_auto<COUNT, false, QLDS>(P.grid, K, s_coarse, s_q, s_queue, src);
-      { // (the record's last 16 bytes are re-read: a line this wave has just held; nothing lives in registers across the sweep)
-        const float4 rr = src[3];
+      { // (round 6: the record's last row stays in registers across the sweep -- re-reading it was a global round trip per candidate)
+        const float4 rr = r3;
         const uint32_t i = P.use_surv ? uint32_t(__builtin_amdgcn_readfirstlane(int(__float_as_uint(rr.w)))) : li;      // the candidate's index in the gated list
         const uint32_t kraw = uint32_t(__builtin_amdgcn_readfirstlane(int(__float_as_uint(rr.z)))), k = kraw & ~kBorderFlag;
         const unsigned long long tag = (unsigned long long)uint32_t(__builtin_amdgcn_readfirstlane(int(__float_as_uint(rr.x)))) |
@@ -371,13 +375,16 @@ __global__ __launch_bounds__(kVerifyMaxThreads, 6) void k_verify(VerifyParams P)
           if (slot_better(cnt, tag, oc, otu, oi != kNil)) { S.wcnt[bsel][wave] = cnt; S.wtag[bsel][wave] = tag; S.wcand[bsel][wave] = i; }   // (uniform)
         }
       }
-      (void)r3;
       __builtin_amdgcn_wave_barrier();
 #if defined(S4P_PROF)
       { __builtin_amdgcn_s_waitcnt(0); const unsigned long long d_ = __builtin_amdgcn_s_memrealtime() - tc0_;
         tp_[5] += 1; if (d_ > tp_[6]) tp_[6] = d_; if (d_ > 800ull) { tp_[7] += 1; tp_[8] += d_; } tp_[9] += d_; if (d_ > 2000ull) tp_[10] += 1; }
 #endif
     }
+#if defined(S4P_PROF)
+    { const uint32_t wid_ = blockIdx.x * 16u + wave;
+      if (lane == 0 && wid_ < uint32_t(kProfWaves)) for (int k_ = 0; k_ < kProfWords; ++k_) g_prof[3][wid_ * kProfWords + k_] = lpa_[k_]; }
+#endif
   }
   PROF_STAMP(2);
   // ---- selection: wave bests (LDS) -> workgroup best -> slot; the last workgroup to finish reduces the slots ----

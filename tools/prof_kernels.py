@@ -18,6 +18,7 @@ KERNELS = ("k_pairs", "k_prep", "k_quads", "k_sweep", "k_verify")
 PASSES = {
     "sq": ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "GRBM_GUI_ACTIVE"],
     "sq2": ["SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_ACTIVE_INST_LDS", "SQ_WAIT_INST_ANY"],
+    "lds": ["SQ_INSTS_LDS", "SQ_ACTIVE_INST_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_WAIT_INST_LDS", "GRBM_GUI_ACTIVE"],
     "tcc": ["TCC_HIT_sum", "TCC_MISS_sum", "TCC_REQ_sum"],
     "fetch": ["FETCH_SIZE"],
     "write": ["WRITE_SIZE"],

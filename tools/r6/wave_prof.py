@@ -33,6 +33,7 @@ m.loop_begin()
 for t in range(int(os.environ.get("BASES", "12"))):
     ok, r = m.try_one_base()
     sp, sq, sv = grab(0), grab(1), grab(2)
+    lean = grab(3).sum(axis=0).astype(np.float64)
     if t < 5:
         continue                                     # (the first bases still run k_prep; the bound is not in force yet)
     print("base %d: m1 %d m2 %d K %d C %d best %d" % (t, r.n_pairs1, r.n_pairs2, r.n_quads, r.n_verified, m.info().best_count))
@@ -60,4 +61,10 @@ for t in range(int(os.environ.get("BASES", "12"))):
             tot = sv[:, 9].sum() / 100.0
             print("     candidates per wave %s ; %.2f us per candidate ; above 8 us: %d (%.0f %% of the candidate time) ; above 20 us: %d ; longest per wave (us) %s" % (
                 [int(np.percentile(busy[:, 5], p)) for p in (5, 50, 95, 100)], tot / max(sv[:, 5].sum(), 1), int(sv[:, 7].sum()), 100.0 * sv[:, 8].sum() / max(sv[:, 9].sum(), 1), int(sv[:, 10].sum()), q(busy[:, 6])))
+    if t >= 5 and lean is not None and lean.size >= 12 and lean[0]:
+        n = float(lean[0]); us = lambda v: float(v) / 100.0
+        print("     lean sweep, per candidate over %d: %.2f us in all | sweep %.2f us (%.1f steps) | alive after the sweep %.3f: queue fill %.2f us, drain %.2f us, exact batches %.2f us "
+              "(%.2f batches; %.3f of the candidates reach one; counted in full %.4f; mean count %.1f)" % (
+                  int(n), us(lean[8]) / n, us(lean[1]) / n, float(lean[2]) / n, float(lean[3]) / n, us(lean[4]) / max(float(lean[3]), 1), us(lean[5]) / max(float(lean[3]), 1),
+                  us(lean[6]) / max(float(lean[9]), 1), float(lean[7]) / max(float(lean[9]), 1), float(lean[9]) / n, float(lean[10]) / n, float(lean[11]) / n))
 m.loop_end()
