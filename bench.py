@@ -214,7 +214,7 @@ def main():
                     dist.broadcast(wb, src=root)
                 collective["warmed"] = True
             return sh
-        return sharding.ShardedRansac(m, rank, world, dist, dev, producer_threads="auto")      # world 1: the engine's own pipelined Perform_N_steps
+        return sharding.ShardedRansac(m, rank, world, dist, dev, producer_threads={"0": False, "1": True}.get(os.environ.get("S4P_BENCH_HELPERS", ""), "auto"))      # world 1: the engine's own pipelined Perform_N_steps
 
     per_rank = {}
 

@@ -148,6 +148,10 @@ __device__ __forceinline__ void cone_mask_row(const ConeTable& cone, const float
     R[6] = 2.f * (xz - wy); R[7] = 2.f * (yz + wx); R[8] = 1.f - 2.f * (xx + yy); }
 #pragma unroll
   for (int w = 0; w < kMaskWords; ++w) row[w] = 0u;
+  // (round 6: four samples per trip, independent chains for a wave that is alone on its SIMD; the row's bits are set by LDS
+  // atomics without a return value -- a read-modify-write per sample was a dependent LDS round trip per sample: phase B of
+  // k_quads 11-15 us of a workgroup's ~45, profiles/r06_wave_profile.txt)
+#pragma unroll 4
   for (int a = 0; a < cone.nb; ++a) {
     const float vx = cone.v[a][0], vy = cone.v[a][1], vz = cone.v[a][2];
     const float fx = __builtin_fmaf(R[0], vx, __builtin_fmaf(R[1], vy, R[2] * vz)), fy = __builtin_fmaf(R[3], vx, __builtin_fmaf(R[4], vy, R[5] * vz)),
@@ -170,7 +174,7 @@ __device__ __forceinline__ void cone_mask_row(const ConeTable& cone, const float
       normalize3(dx, dy, dz);
       id = index_normal(dx, dy, dz, nepsilon);
     }
-    if (id < 343u) row[id >> 5] |= (1u << (id & 31u));
+    if (id < 343u) atomicOr(&row[id >> 5], 1u << (id & 31u));
   }
 }
 
