@@ -53,10 +53,10 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
 
 __global__ __launch_bounds__(1024, 4) void k_sweep(SweepParams P) {      // (launched with k_verify's grid and block: <= kVerifyMaxThreads)
   extern __shared__ uint32_t s_mem[];
-  uint32_t* s_coarse = s_mem;                               // LDS: coarse bitmap (address 0) | query tile x | y | z | SweepShared
+  uint32_t* s_coarse = s_mem;                               // LDS: coarse bitmap, shifted copy (address 0) | query tile x | y | z | 256 x 1.0f | SweepShared
   float* s_qx = reinterpret_cast<float*>(s_mem + P.grid.coarse_words);
   float* s_qy = s_qx + P.tile_q; float* s_qz = s_qy + P.tile_q;
-  SweepShared& S = *reinterpret_cast<SweepShared*>(s_qz + P.tile_q);
+  SweepShared& S = *reinterpret_cast<SweepShared*>(s_qz + P.tile_q + 256u);      // (256 floats of 1.0 lie between the tile and these scalars)
   const uint32_t lane = threadIdx.x & 63u, wave = uint32_t(__builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6))), n_waves = blockDim.x >> 6;
   const uint32_t nb = P.n_bases;
   if (threadIdx.x == 0) {
@@ -104,13 +104,39 @@ __global__ __launch_bounds__(1024, 4) void k_sweep(SweepParams P) {      // (lau
   };
   // pitches of the coarse bitmap include one empty border cube per axis (LcpGridHost::plan): a coordinate outside clamps onto it
   const uint32_t ucx = uint32_t(P.grid.cnx), ucy = uint32_t(P.grid.cny);
-  const uint32_t mx = ucx - 1u, my = ucy - 1u, mz = uint32_t(((P.grid.nz - 1) >> P.grid.cshift) + 1);
-  const float cs = coarse_scale(P.grid);
+  const uint32_t mz = uint32_t(((P.grid.nz - 1) >> P.grid.cshift) + 1);
+  const uint32_t lim_xy = (ucy << 16) | ucx, kdot = (ucx << 16) | 1u, cnxy = ucx * ucy;
+  // (round 6) The block's FOUR transforms are applied by ONE matrix instruction per 16 queries: v_mfma_f32_16x16x4_f32 with
+  //   A[i = 4 c + r][k] = row r of candidate c's locating transform (k = x, y, z, translation): lane l supplies A[l & 15][l >> 4],
+  //   B[k][j]           = coordinate k of query j of the group (k = 3: 1.0):                       lane l supplies B[l >> 4][l & 15],
+  //   D[4 c + r][j]     -> lane l holds rows 4 (l >> 4) .. + 3 of column l & 15: the cube coordinates of query (l & 15) under
+  //                        candidate (l >> 4), in its own registers -- an fmaf chain per element, bit for bit.
+  // One issue slot instead of the eighteen packed FMAs the four candidates took for the same 64 (candidate, query) pairs, and the
+  // sweep is bound by vector issue (s4p_k_lcp.hip.hpp).  What follows a result is the lean sweep's packed form: rows 0 and 1 carry the
+  // 1/65535 scale and the half-cube offset of v_cvt_pknorm_u16_f32 (floor + 1, clamped below, both axes packed), v_pk_min_u16 clamps
+  // above onto the pitch, v_dot2_u32_u16 forms x' + pitch_x y' on the z term, and the bitmap in LDS is the copy shifted by pitch_x + 1
+  // bits (SweepParams::grid.coarse).  Eleven issue slots per 64 pairs against 16.5.
+  // The results of a batch of four MFMAs are read only after the NEXT batch has been issued (the matrix pipe works in order: they
+  // are complete by then), never straight after their own issue -- this compiler leaves out the wait states between an MFMA and a
+  // vector instruction that reads its result (measured with the 4x4x1 form: wrong counts until s_nop by hand).
+  typedef float f4v_t __attribute__((ext_vector_type(4)));
+  const uint32_t kk = lane >> 4, jj = lane & 15u;             // B: coordinate kk of the group's query jj; D: candidate kk of the block, query jj
+  const uint32_t ar = lane & 3u, ac = (lane & 15u) >> 2;      // A: row ar of candidate ac, column kk
+  const float cs = coarse_scale(P.grid), kn = 1.0f / 65535.0f;
+  const float a_org = kk == 3u ? (ar == 0u ? P.grid.ox : (ar == 1u ? P.grid.oy : P.grid.oz)) : 0.f;
+  const float a_scl = ar < 2u ? cs * kn : (ar == 2u ? cs : 0.f);
+  const float a_half = (kk == 3u && ar < 2u) ? 0.5f * kn : 0.f;
+  float* s_ones = s_qz + P.tile_q;                             // 256 x 1.0f behind the tile (the k = 3 lanes read their "coordinate" there)
+  for (uint32_t w = threadIdx.x; w < 256u; w += blockDim.x) s_ones[w] = 1.0f;
+  typedef __attribute__((address_space(3))) float* lds_f32_ptr;
+  const uint32_t q_addr0 = kk < 3u ? uint32_t(uintptr_t((lds_f32_ptr)(s_qx + kk * P.tile_q + jj))) : uint32_t(uintptr_t((lds_f32_ptr)(s_ones + jj)));
+  const uint32_t q_inc = kk < 3u ? 4u * kSweepStep : 0u;       // bytes per step of 256 queries
+  __syncthreads();
   // every wave of the workgroup takes part in every ROUND (the tile staging is a workgroup affair); a round = kSweepCands tickets per wave
   const uint32_t per_round = n_waves * uint32_t(kSweepCands), rounds = (hi + per_round - 1u) / per_round;
   for (uint32_t r = 0; r < rounds; ++r) {
     const uint32_t t_first = (r * n_waves + wave) * uint32_t(kSweepCands);
-    GridXf X[kSweepCands]; uint32_t bsel[kSweepCands], ci[kSweepCands], kq[kSweepCands], cnt[kSweepCands];
+    uint32_t bsel[kSweepCands], ci[kSweepCands], kq[kSweepCands], cnt[kSweepCands];
     bool valid[kSweepCands], alive[kSweepCands], keep[kSweepCands];
 #pragma unroll
     for (int k = 0; k < kSweepCands; ++k) {
@@ -122,43 +148,100 @@ __global__ __launch_bounds__(1024, 4) void k_sweep(SweepParams P) {      // (lau
       bsel[k] = uint32_t(__builtin_amdgcn_readfirstlane(int(bs)));
       ci[k] = blockIdx.x + (t - uint32_t(__builtin_amdgcn_readfirstlane(int(t0)))) * gridDim.x;
     }
+    // the block's records: the lane's A element (one dword of candidate ac's record) and every record's flag word, all in flight together
+    float a_val;
+    { const float* rec[kSweepCands];
 #pragma unroll
-    for (int k = 0; k < kSweepCands; ++k) {                 // the block's records: all loads in flight together
-      const float4* src = P.b[valid[k] ? bsel[k] : 0u].cand_T + kCandStride * size_t(valid[k] ? ci[k] : 0u);
-      const float4 r0 = src[0], r1 = src[1], r2 = src[2], r3 = src[3];
-      const float T[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
-      X[k] = make_grid_xf(P.grid, T, cs);
-      const uint32_t kraw = uint32_t(__builtin_amdgcn_readfirstlane(int(__float_as_uint(r3.z))));
-      kq[k] = kraw & ~kBorderFlag;
-      // a candidate whose Euler-angle gate the host still has to settle goes to k_verify whatever its count: only there is it
-      // entered into the list the host works through (it may turn out not to be a candidate at all)
-      keep[k] = valid[k] && (kraw & kBorderFlag) != 0u;
-    }
+      for (int k = 0; k < kSweepCands; ++k) rec[k] = reinterpret_cast<const float*>(P.b[valid[k] ? bsel[k] : 0u].cand_T + kCandStride * size_t(valid[k] ? ci[k] : 0u));
+      const float* mine = ac == 0u ? rec[0] : (ac == 1u ? rec[1] : (ac == 2u ? rec[2] : rec[3]));
+      const float raw = mine[min(ar, 2u) * 4u + kk];          // (row 3 of the 4 x 4 block does not exist: scaled by 0)
+      uint32_t kraw[kSweepCands];
+#pragma unroll
+      for (int k = 0; k < kSweepCands; ++k) kraw[k] = __float_as_uint(rec[k][14]);      // {tag lo, tag hi, quad index | border flag, -}
+      a_val = ((raw - a_org) * P.grid.inv_h) * a_scl + a_half;
+#pragma unroll
+      for (int k = 0; k < kSweepCands; ++k) {
+        const uint32_t kr = uint32_t(__builtin_amdgcn_readfirstlane(int(kraw[k])));
+        kq[k] = kr & ~kBorderFlag;
+        // a candidate whose Euler-angle gate the host still has to settle goes to k_verify whatever its count: only there is it
+        // entered into the list the host works through (it may turn out not to be a candidate at all)
+        keep[k] = valid[k] && (kr & kBorderFlag) != 0u;
+      } }
     for (uint32_t tile = 0; tile < P.n_tiles; ++tile) {     // uniform
       if (P.n_tiles > 1u) { __syncthreads(); stage_tile(tile); __syncthreads(); }
       const uint32_t swept_after = min((tile + 1u) * P.tile_q, P.n_q);
+      bool any = false;
+#pragma unroll
+      for (int k = 0; k < kSweepCands; ++k) any = any || (alive[k] && !keep[k]);
+      if (!any) continue;                                   // (uniform; the staging barriers above are passed by every wave)
+      uint32_t hits = 0u, q_addr = q_addr0;
+      auto load4 = [&](const uint32_t g0, float b[4]) {      // the B operands of groups g0 .. g0 + 3 of the current step
+#pragma unroll
+        for (uint32_t g = 0; g < 4u; ++g) b[g] = *(const __attribute__((address_space(3))) float*)(uintptr_t(q_addr + 64u * (g0 + g)));
+      };
+      auto mfma4 = [&](const float b[4], f4v_t d[4]) {
+#pragma unroll
+        for (uint32_t g = 0; g < 4u; ++g) d[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_val, b[g], f4v_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      };
+      auto score4 = [&](const f4v_t d[4]) {
+        uint32_t bb[4], ww[4];
+        // (row 3 of a block is never read; without this the compiler hands its register to some temporary while the MFMA that
+        // writes it is still in flight)
+#pragma unroll
+        for (uint32_t g = 0; g < 4u; ++g) asm volatile("" :: "v"(d[g][3]));
+#pragma unroll
+        for (uint32_t g = 0; g < 4u; ++g) {
+          const uint32_t zc = min(uint32_t(floor_to_int(d[g][2])), mz);
+          bb[g] = dot2_u16_s(pk_min_u16_s(cvt_pknorm_u16(d[g][0], d[g][1]), lim_xy), kdot, mul24_s(zc, cnxy));
+        }
+#pragma unroll
+        for (uint32_t g = 0; g < 4u; ++g) ww[g] = lds_word(0u, bb[g] >> 5);              // (the bitmap starts at LDS address 0)
+#pragma unroll
+        for (uint32_t g = 0; g < 4u; ++g) hits += bfe1(ww[g], bb[g]);
+      };
+      f4v_t da[4], db[4];
+      float ba[4], bq[4];
+      load4(0u, ba); mfma4(ba, da);                         // prologue: batch 0 (64 queries = 4 groups of 16) of the first step
+      for (uint32_t base = 0; base < P.tile_q; base += kSweepStep) {      // a step = 256 queries = four batches, A B A B
+        load4(4u, bq);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma4(bq, db);
+        __builtin_amdgcn_sched_barrier(0);
+        score4(da);
+        __builtin_amdgcn_sched_barrier(0);
+        load4(8u, ba);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma4(ba, da);
+        __builtin_amdgcn_sched_barrier(0);
+        score4(db);
+        __builtin_amdgcn_sched_barrier(0);
+        load4(12u, bq);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma4(bq, db);
+        __builtin_amdgcn_sched_barrier(0);
+        score4(da);
+        __builtin_amdgcn_sched_barrier(0);
+        q_addr += q_inc;
+        if (base + kSweepStep < P.tile_q) {                 // (uniform) batch 0 of the next step
+          load4(0u, ba);
+          __builtin_amdgcn_sched_barrier(0);
+          mfma4(ba, da);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        score4(db);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // per-candidate totals of the tile: the sixteen lanes of a row -> its last lane (row_shr 1, 2, 4, 8 on the DPP pipe)
+      uint32_t rs = hits;
+      rs += uint32_t(__builtin_amdgcn_update_dpp(0, int(rs), 0x111, 0xf, 0xf, false));
+      rs += uint32_t(__builtin_amdgcn_update_dpp(0, int(rs), 0x112, 0xf, 0xf, false));
+      rs += uint32_t(__builtin_amdgcn_update_dpp(0, int(rs), 0x114, 0xf, 0xf, false));
+      rs += uint32_t(__builtin_amdgcn_update_dpp(0, int(rs), 0x118, 0xf, 0xf, false));
 #pragma unroll
       for (int k = 0; k < kSweepCands; ++k) {
+        const uint32_t tot = uint32_t(__builtin_amdgcn_readlane(int(rs), 16 * k + 15));
         if (!alive[k] || keep[k]) continue;                 // (wave-uniform)
-        uint32_t hits = 0u;
-        for (uint32_t base = 0; base < P.tile_q; base += kSweepStep) {
-          float x[kSweepChunks], y[kSweepChunks], z[kSweepChunks];
-          int cx[kSweepChunks], cy[kSweepChunks], cz[kSweepChunks];
-          uint32_t cc[kSweepChunks], ww[kSweepChunks];
-#pragma unroll
-          for (uint32_t c = 0; c < kSweepChunks; ++c) { const uint32_t i = base + 64u * c + lane; x[c] = s_qx[i]; y[c] = s_qy[i]; z[c] = s_qz[i]; }
-#pragma unroll
-          for (uint32_t c = 0; c < kSweepChunks; c += 2u)
-            grid_cell2(X[k].u, make_float4(x[c], y[c], z[c], 0.f), make_float4(x[c + 1u], y[c + 1u], z[c + 1u], 0.f), cx[c], cy[c], cz[c], cx[c + 1u], cy[c + 1u], cz[c + 1u]);
-#pragma unroll
-          for (uint32_t c = 0; c < kSweepChunks; ++c) {
-            cc[c] = mad24_s(mad24_s(min(uint32_t(cz[c]), mz), ucy, min(uint32_t(cy[c]), my)), ucx, min(uint32_t(cx[c]), mx));
-            ww[c] = lds_word(0u, cc[c] >> 5);              // (the bitmap starts at LDS address 0)
-          }
-#pragma unroll
-          for (uint32_t c = 0; c < kSweepChunks; ++c) hits += bfe1(ww[c], cc[c]);
-        }
-        cnt[k] += wave_sum_u32(hits);
+        cnt[k] += tot;
         if (cnt[k] + (P.n_q - swept_after) <= P.prune) alive[k] = false;      // cannot exceed the bound any more
       }
     }
