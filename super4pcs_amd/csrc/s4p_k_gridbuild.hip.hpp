@@ -127,6 +127,23 @@ __global__ __launch_bounds__(256) void k_grid_headers(GridBuildParams P, const u
     }
   }
 }
+// k_sweep's own bitmap (round 6): one bit per 2^sx x 2^sy x 2^sz cells, as fine as the LDS of a workgroup that has its CU to
+// itself takes (s4p_set_clouds plans the shifts) -- k_verify's coarse bitmap has to leave room for a second workgroup, queues and
+// the sample.  Built from the reach words (a cell is reachable if a P point lies within delta + 0.01 h of its box), pitches px, py
+// with one empty border cube per axis as in LcpGridHost::plan.
+struct SweepBitmapParams { const uint2* reach; uint32_t n_words; int nx, ny; int sx, sy, sz; uint32_t px, py; uint32_t* out; };
+__global__ __launch_bounds__(256) void k_sweep_bitmap(SweepBitmapParams P) {
+  for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < P.n_words; w += gridDim.x * blockDim.x) {
+    uint32_t bits = P.reach[w].x;
+    while (bits) {
+      const uint32_t b = uint32_t(__ffs(int(bits))) - 1u; bits &= bits - 1u;
+      const uint32_t c = w * 32u + b;
+      const uint32_t ix = c % uint32_t(P.nx), iy = (c / uint32_t(P.nx)) % uint32_t(P.ny), iz = c / (uint32_t(P.nx) * uint32_t(P.ny));
+      const uint32_t bit = ((iz >> P.sz) * P.py + (iy >> P.sy)) * P.px + (ix >> P.sx);
+      atomicOr(&P.out[bit >> 5], 1u << (bit & 31u));
+    }
+  }
+}
 // The coarse bitmap moved up by `shift` bits behind zero bits, for the lean sweep of k_verify (s4p_k_lcp.hip.hpp): its index is
 // (cube + 1) on x and y, so cube -1 of a row must read the (empty) border cube of the row before it and the cubes in front of the
 // first row must read zero words.  dst bit b = src bit b - shift; one thread per destination word, once per cloud.

@@ -33,6 +33,9 @@ struct SweepBase {
 };
 struct SweepParams {
   LcpGrid grid;
+  // the bitmap this pass indexes (shifted copy, k_coarse_shift): k_verify's coarse bitmap, or the finer one of k_sweep_bitmap when the
+  // workgroup has its CU to itself; pitches px, py (border cube included), index of the border slab, cells -> cubes per axis (2^-s)
+  const uint32_t* bm; uint32_t bm_words, px, py, mzc; float scx, scy, scz;
   const float* qtiles;                                    // sampled Q in sweep order: per tile x[tile_q] | y[tile_q] | z[tile_q], padded with kLeanPad
   uint32_t n_q, tile_q, n_tiles;
   SweepBase b[kGroupMax]; uint32_t n_bases;
@@ -54,7 +57,7 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
 __global__ __launch_bounds__(1024, 4) void k_sweep(SweepParams P) {      // (launched with k_verify's grid and block: <= kVerifyMaxThreads)
   extern __shared__ uint32_t s_mem[];
   uint32_t* s_coarse = s_mem;                               // LDS: coarse bitmap, shifted copy (address 0) | query tile x | y | z | 256 x 1.0f | SweepShared
-  float* s_qx = reinterpret_cast<float*>(s_mem + P.grid.coarse_words);
+  float* s_qx = reinterpret_cast<float*>(s_mem + P.bm_words);
   float* s_qy = s_qx + P.tile_q; float* s_qz = s_qy + P.tile_q;
   SweepShared& S = *reinterpret_cast<SweepShared*>(s_qz + P.tile_q + 256u);      // (256 floats of 1.0 lie between the tile and these scalars)
   const uint32_t lane = threadIdx.x & 63u, wave = uint32_t(__builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6))), n_waves = blockDim.x >> 6;
@@ -71,7 +74,7 @@ __global__ __launch_bounds__(1024, 4) void k_sweep(SweepParams P) {      // (lau
   __syncthreads();
   const uint32_t hi = uint32_t(__builtin_amdgcn_readfirstlane(int(S.end[kGroupMax - 1])));
   if (hi == 0u) return;                                     // (uniform) more workgroups than candidates
-  stage_coarse(P.grid, s_coarse);                           // ends with a workgroup barrier
+  { LcpGrid gb = P.grid; gb.coarse = P.bm; gb.coarse_words = P.bm_words; stage_coarse(gb, s_coarse); }      // ends with a workgroup barrier
   auto stage_tile = [&](const uint32_t t) {
     const float4* src = reinterpret_cast<const float4*>(P.qtiles + size_t(t) * 3u * P.tile_q);
     float4* dst = reinterpret_cast<float4*>(s_qx);
@@ -103,8 +106,7 @@ __global__ __launch_bounds__(1024, 4) void k_sweep(SweepParams P) {      // (lau
     __syncthreads();
   };
   // pitches of the coarse bitmap include one empty border cube per axis (LcpGridHost::plan): a coordinate outside clamps onto it
-  const uint32_t ucx = uint32_t(P.grid.cnx), ucy = uint32_t(P.grid.cny);
-  const uint32_t mz = uint32_t(((P.grid.nz - 1) >> P.grid.cshift) + 1);
+  const uint32_t ucx = P.px, ucy = P.py, mz = P.mzc;
   const uint32_t lim_xy = (ucy << 16) | ucx, kdot = (ucx << 16) | 1u, cnxy = ucx * ucy;
   // (round 6) The block's FOUR transforms are applied by ONE matrix instruction per 16 queries: v_mfma_f32_16x16x4_f32 with
   //   A[i = 4 c + r][k] = row r of candidate c's locating transform (k = x, y, z, translation): lane l supplies A[l & 15][l >> 4],
@@ -122,9 +124,9 @@ __global__ __launch_bounds__(1024, 4) void k_sweep(SweepParams P) {      // (lau
   typedef float f4v_t __attribute__((ext_vector_type(4)));
   const uint32_t kk = lane >> 4, jj = lane & 15u;             // B: coordinate kk of the group's query jj; D: candidate kk of the block, query jj
   const uint32_t ar = lane & 3u, ac = (lane & 15u) >> 2;      // A: row ar of candidate ac, column kk
-  const float cs = coarse_scale(P.grid), kn = 1.0f / 65535.0f;
+  const float kn = 1.0f / 65535.0f;
   const float a_org = kk == 3u ? (ar == 0u ? P.grid.ox : (ar == 1u ? P.grid.oy : P.grid.oz)) : 0.f;
-  const float a_scl = ar < 2u ? cs * kn : (ar == 2u ? cs : 0.f);
+  const float a_scl = ar == 0u ? P.scx * kn : (ar == 1u ? P.scy * kn : (ar == 2u ? P.scz : 0.f));
   const float a_half = (kk == 3u && ar < 2u) ? 0.5f * kn : 0.f;
   float* s_ones = s_qz + P.tile_q;                             // 256 x 1.0f behind the tile (the k = 3 lanes read their "coordinate" there)
   for (uint32_t w = threadIdx.x; w < 256u; w += blockDim.x) s_ones[w] = 1.0f;
