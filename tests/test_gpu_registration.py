@@ -709,17 +709,21 @@ def test_a_device_pass_that_stalls_is_an_error_not_a_hang(s4p_lib_built, monkeyp
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("force,n_s,max_angle", [("1", 300, -1.0), ("1", 250, 30.0), (None, 2700, -1.0)])
-def test_the_sweep_pass_changes_no_result(oracle_mod, s4p_lib_built, monkeypatch, force, n_s, max_angle):
+@pytest.mark.parametrize("force,n_s,max_angle,own_bitmap", [("1", 300, -1.0, True), ("1", 250, 30.0, True), (None, 2700, -1.0, True), (None, 2700, -1.0, False)])
+def test_the_sweep_pass_changes_no_result(oracle_mod, s4p_lib_built, monkeypatch, force, n_s, max_angle, own_bitmap):
     """Round 6: with an early-exit bound in force k_sweep counts, for every gated candidate, the sampled-Q points whose coarse
     cube is marked under its transform -- an upper bound of its inlier count -- and only the candidates whose bound exceeds the
     registration's best go on to k_verify (samples that do not fit LDS by default; S4P_SWEEP_PASS=1 forces the pass for any
     sample).  Forced on a sample that fits LDS, with the Euler-angle gate in force (undecided candidates must reach the host
     whatever their count), and on a sample of several LDS tiles (2700 points: two tiles): the registration is the oracle's --
-    LCP, 4x4, transformed cloud, totals -- and the pass really abandons candidates."""
+    LCP, 4x4, transformed cloud, totals -- and the pass really abandons candidates.  The pass indexes a bitmap of its own, as fine
+    as a workgroup with a CU to itself can hold (k_sweep_bitmap; the block's four transforms by one MFMA per 16 queries);
+    S4P_SWEEP_COARSE=1 makes it use k_verify's coarse bitmap instead: the same registration either way."""
     from super4pcs_amd import capi
     if force is not None:
         monkeypatch.setenv("S4P_SWEEP_PASS", force)
+    if not own_bitmap:
+        monkeypatch.setenv("S4P_SWEEP_COARSE", "1")
     if max_angle >= 0:
         monkeypatch.setenv("S4P_ANGLE_TOL", "0.02")             # many candidates with an undecided gate
     delta, overlap = 0.01, 0.6
