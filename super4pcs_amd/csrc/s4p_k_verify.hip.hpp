@@ -13,16 +13,22 @@ namespace s4p {
 // LDS), scalar bookkeeping per chunk (SALU 0.6 x VALU), a candidate-record round trip per candidate -- and, for samples that do
 // not fit LDS (n_Q > 2560: the 20 000-point sample), re-streamed the whole query array from L2 for EVERY candidate (4.6 TB/s of
 // L2 reads at 14 M candidates/s).  This pass only COUNTS:
-//   * one wave per BLOCK of kSweepCands candidates; their records are fetched together (one exposure), their coarse-unit
-//     transforms live in registers;
+//   * one wave per BLOCK of kSweepCands = 4 candidates: lane l works on candidate (l >> 4) and query (l & 15) of a group of 16, and
+//     the block's four transforms are applied to the group by ONE v_mfma_f32_16x16x4_f32 (rows = candidate x coordinate, columns =
+//     queries, k = x, y, z, 1): the one place of the path where the arithmetic is a small dense contraction;
 //   * the sampled Q goes through LDS in TILES of tile_q points (x | y | z floats, padded with far-away points), staged once per
-//     workgroup and tile and swept by every wave for all its block's candidates: query traffic / (waves x kSweepCands);
-//   * per 64 queries and candidate: 3 LDS reads, the packed locate (grid_cell2), clamp, one LDS word, bit extract, ADD -- no
-//     ballot, no queue, no scalar work; one wave reduction per candidate and tile;
+//     workgroup and tile and swept by every wave for its block: query traffic / (waves x kSweepCands);
+//   * per 64 (candidate, query) pairs: one LDS read, one MFMA, then the lean sweep's packed form -- v_cvt_pknorm_u16_f32,
+//     v_pk_min_u16, the z floor and clamp, v_dot2_u32_u16, one LDS word, bit extract, ADD -- no ballot, no queue, no scalar work; one
+//     row reduction (DPP) per candidate and tile;
+//   * the bitmap is the pass's OWN when the workgroup has its CU to itself (samples beyond LDS, chunk passes): one bit per
+//     2^sx x 2^sy x 2^sz cells, the finest shifts that fit 160 KB beside the tile (k_sweep_bitmap, planned by s4p_set_clouds) -- at
+//     the bench clouds 2 x 1 x 1 cells against k_verify's 2 x 2 x 2: half the survivors;
 //   * a candidate whose count + unswept queries <= prune is dead: its per-quad count reads 0 (a lower bound, as the
 //     reference's is for what it abandons); the others are copied -- record and candidate index -- to the survivor list, one
 //     global atomic per workgroup and base, and k_verify scores exactly those.
-// Identical results by construction: k_verify applies the same bound again, with the same locate.
+// Identical results by construction: the count is an upper bound of the inlier count under any locate inside the structure's slack,
+// and k_verify applies its own bound again to what comes through.
 // ---------------------------------------------------------------------------
 constexpr int kSweepCands = 4;                            // candidates per wave and pass over the query tiles
 constexpr uint32_t kSweepTileMax = 2560;                  // queries per LDS tile (30 KB); larger samples take several tiles of 2048

@@ -13,7 +13,7 @@ import pytest
 
 
 def _round():
-    return next(r for r in ("r05", "r04", "r03") if os.path.exists(os.path.join(ROOT, "profiles", r + "_bench_final.json")))
+    return next(r for r in ("r06", "r05", "r04", "r03") if os.path.exists(os.path.join(ROOT, "profiles", r + "_bench_final.json")))
 
 
 def test_roofline_figures_recompute_from_committed_csvs():
