@@ -62,6 +62,14 @@ try:
         print("r06_init_and_time_to_register_final.jsonl")
 except Exception as e:                                              # noqa: BLE001
     print("time-to-register rows:", repr(e))
+# part C: the kernels alone (one base per launch) with their counter CSVs, the lab build's per-wave phase profile, the two-rank dry run
+copy(os.path.join("lanes1", "kernels_lanes1.json"), "r06_kernels_lanes1.json")
+os.makedirs(os.path.join(P, "r06_kernels_lanes1"), exist_ok=True)
+for f in glob.glob(os.path.join(G, "lanes1", "*.csv")):
+    shutil.copy(f, os.path.join(P, "r06_kernels_lanes1", os.path.basename(f)))
+    print("r06_kernels_lanes1/" + os.path.basename(f))
+copy("wave_profile.txt", "r06_wave_profile.txt")
+json_line("bench_2ranks_one_gpu.json", "r06_bench_2ranks_dryrun_one_gpu.json")
 sys.path.insert(0, os.path.join(R, "tools"))
 import kernel_isa_digest  # noqa: E402
 json.dump(kernel_isa_digest.digest(os.path.join(R, "super4pcs_amd", "lib", "libsuper4pcs_amd.so")),

@@ -59,8 +59,9 @@ for t in range(int(os.environ.get("BASES", "12"))):
         print("     staging %s ; ticket loop %s ; waiting in the final barrier %s" % (q(sv[:, 1] - sv[:, 0]), q(sv[:, 2] - sv[:, 1]), q(sv[:, 3] - sv[:, 2])))
         if len(busy):
             tot = sv[:, 9].sum() / 100.0
-            print("     record fetch per candidate %.2f us ; ticket + bookkeeping per candidate %.2f us (whole iteration minus the lean sweep's own time)" % (
-                sv[:, 11].sum() / 100.0 / max(sv[:, 5].sum(), 1), (sv[:, 9].sum() - (lean[8] if lean is not None else 0)) / 100.0 / max(sv[:, 5].sum(), 1)))
+            print("     ticket, record fetch and bookkeeping per candidate %.2f us (whole iteration minus the lean sweep's own time)%s" % (
+                (sv[:, 9].sum() - (lean[8] if lean is not None else 0)) / 100.0 / max(sv[:, 5].sum(), 1),
+                " ; of that the record's round trip %.2f us" % (sv[:, 11].sum() / 100.0 / max(sv[:, 5].sum(), 1)) if sv[:, 11].sum() else ""))
             print("     candidates per wave %s ; %.2f us per candidate ; above 8 us: %d (%.0f %% of the candidate time) ; above 20 us: %d ; longest per wave (us) %s" % (
                 [int(np.percentile(busy[:, 5], p)) for p in (5, 50, 95, 100)], tot / max(sv[:, 5].sum(), 1), int(sv[:, 7].sum()), 100.0 * sv[:, 8].sum() / max(sv[:, 9].sum(), 1), int(sv[:, 10].sum()), q(busy[:, 6])))
     if t >= 5 and lean is not None and lean.size >= 12 and lean[0]:
