@@ -51,6 +51,7 @@ struct LcpTask {                 // what the scoring loop needs besides the grid
   // reference's is for every candidate it abandons).  0 = every candidate is counted in full.
   uint32_t prune;
   uint32_t* pruned;                  // (k_verify) per-workgroup LDS counter of abandoned candidates, or nullptr
+  uint32_t l0_only = 0u;             // (lean sweep of an LDS-resident sample) 1: return the number of L0 survivors of the sweep and stop there
 #if defined(S4P_PROF)
   unsigned long long* lp;            // lab build: the calling wave's phase sums of the lean sweep (kProfWords words, in registers)
 #endif
@@ -456,7 +457,8 @@ __device__ __forceinline__ uint32_t exact_pair_lean(const LcpGrid& g, const LcpT
 }
 
 template <bool COUNT, bool SKIP_FINE, bool QL>
-__device__ __forceinline__ uint32_t wave_lcp_count_lean(const LcpGrid& g, const LcpTask& K, const LeanLds& L, const float4* Tsrc, const float4 t0, const float4 t1, const float4 t2) {
+__device__ __forceinline__ uint32_t wave_lcp_count_lean(const LcpGrid& g, const LcpTask& K, const LeanLds& L, const float4* Tsrc, const float4 t0, const float4 t1, const float4 t2, bool* dead_out = nullptr) {
+  // (dead_out: whether the candidate was abandoned -- the tiled form of k_verify calls this once per tile of the sample and keeps the books itself)
   // t0..t2: the rows at Tsrc, already in registers (k_verify fetches a candidate's record while the previous one is swept); the
   // rare drain / exact batches read them again through Tsrc
   const uint32_t lane = threadIdx.x & 63u;
@@ -638,6 +640,10 @@ __device__ __forceinline__ uint32_t wave_lcp_count_lean(const LcpGrid& g, const 
     PROF_NOW(lp_[1]); lp_[2] = lp_[1]; lp_[7] = abandoned ? 0 : 1;
 #endif
     const uint32_t n_chunks = n_pad >> 6;
+    if (K.l0_only != 0u) {                                             // (uniform) the tiled form's first look at a tile: its L0 survivors, nothing else
+      if (dead_out != nullptr) *dead_out = false;
+      return total;
+    }
     if (!abandoned && total <= kLeanQueue) {
       // The survivors' query indices -> the queue, every lane its own (one candidate in four gets here -- the coarse level alone
       // dismisses only the far-off ones -- so this is priced like the sweep: a chunk-by-chunk expansion with a ballot per chunk
@@ -741,6 +747,7 @@ __device__ __forceinline__ uint32_t wave_lcp_count_lean(const LcpGrid& g, const 
     K.lp[5] += lp_[3]; K.lp[6] += lp_[4]; K.lp[7] += lp_[5]; K.lp[8] += e_ - lp_[0]; K.lp[9] += lp_[5] ? 1ull : 0ull; K.lp[10] += abandoned ? 0ull : 1ull; K.lp[11] += cnt;
   }
 #endif
+  if (dead_out != nullptr) *dead_out = abandoned;
   if (abandoned && K.pruned != nullptr && lane == 0) atomicAdd(K.pruned, 1u);
   __builtin_amdgcn_wave_barrier();
   return cnt;

@@ -313,6 +313,7 @@ struct VerifyParams {
   const float4* q4v;                                    // the same points in Morton order, for the LCP sweep
   QuantQ qq;                                            // ... and their 16-bit quantisation (QLDS kernels)
   const float* qsoa;                                    // ... and as x[n_pad] | y[n_pad] | z[n_pad], padded with kLeanPad (LEAN kernels)
+  const float* qtiles; uint32_t tile_q, n_tiles;        // ... and tile by tile, x | y | z per tile (k_sweep's view): the TILED form scores a sample beyond LDS through them
   uint32_t n_q;
   VerifyBase b[kGroupMax]; uint32_t n_bases;            // the bases of this launch (1 .. kGroupMax)
   uint32_t* group_done;                                 // workgroups that have published their bests (the last one selects the winners); left at 0
@@ -324,12 +325,14 @@ struct VerifyParams {
 };
 
 static_assert(sizeof(VerifyParams) <= 4096, "VerifyParams travels by value in the 4 KB kernel-argument segment");
+constexpr int kVerifyMaxTiles = 24;       // tiles of 2048 points: the largest sample the order keys allow (46 340 points) is 23
 struct VerifyShared {                                   // k_verify's workgroup scalars, at the end of its dynamic LDS
   unsigned long long wtag[kGroupMax][kVerifyMaxThreads / 64];
   uint32_t wcnt[kGroupMax][kVerifyMaxThreads / 64], wcand[kGroupMax][kVerifyMaxThreads / 64];
   uint32_t pruned[kGroupMax];
   uint32_t end[kGroupMax];                              // end of base b's tickets in this workgroup's ticket space
   uint32_t next, last;
+  uint16_t l0t[kVerifyMaxThreads / 64][kVerifyMaxTiles];      // (TILED) every wave's candidate: L0 survivors per tile of the sample
 };
 
 // better(a, b): a wins over b if its count is greater, or equal with a smaller tag (= earlier in reference order)
@@ -358,7 +361,13 @@ __device__ __forceinline__ uint32_t wave_ticket(uint32_t* counter) {
 // waves draw candidates from ONE ticket counter over the workgroup's shares of all lists (a heavy candidate of one base
 // overlaps the cheap ones of the others), every wave keeps one best per base, and the last workgroup to finish writes one
 // result record per base.
-template <bool COUNT, bool QLDS, bool LEAN>
+// TILED (round 6; with QLDS and LEAN): the survivors of k_sweep for a sample that does NOT fit LDS.  Until now their sweep read
+// the queries from global memory -- 320 KB per candidate at the 20 000-point sample, every wave its own stream: 56 % of the GPU time
+// of a base, bound by L2 bandwidth (~1 ms per candidate and wave).  Here the workgroup works in ROUNDS: every wave holds one
+// candidate, the sample passes through LDS tile by tile (k_sweep's tiles) and every wave runs the lean sweep of an LDS-resident
+// sample on its candidate and the current tile -- count, remember, fill, drain, exact batches -- with the bound "confirmed so far +
+// this tile's pending + queries of the later tiles" (the single-pass bound, so the counts and the winner are the single pass's).
+template <bool COUNT, bool QLDS, bool LEAN, bool TILED = false>
 __global__ __launch_bounds__(kVerifyMaxThreads, 6) void k_verify(VerifyParams P) {   // <= 80 VGPRs: six waves per SIMD, i.e. two 768-thread workgroups per CU (of one launch, or of two)
   PROF_DECL;
   PROF_STAMP(0);
@@ -366,7 +375,7 @@ __global__ __launch_bounds__(kVerifyMaxThreads, 6) void k_verify(VerifyParams P)
   uint32_t* s_coarse = s_mem;                              // LDS: coarse bitmap | quantised queries (QLDS) | 16 survivor queues
   uint2* s_q = reinterpret_cast<uint2*>(s_mem + P.grid.coarse_words);
   uint32_t* s_queue = reinterpret_cast<uint32_t*>(s_q + (QLDS ? ((P.n_q + kSweepStep - 1u) & ~(kSweepStep - 1u)) : 0u)) + (threadIdx.x >> 6) * kQueueWordsPerWave;
-  const uint32_t n_pad = (P.n_q + kSweepStep - 1u) & ~(kSweepStep - 1u);
+  const uint32_t n_pad = TILED ? P.tile_q : ((P.n_q + kSweepStep - 1u) & ~(kSweepStep - 1u));      // (TILED: the LDS copy is one tile)
   LeanLds LL;
   LL.coarse = s_coarse;
   const uint32_t lean_q_words = QLDS ? 3u * n_pad : 0u;     // lean kernels: QLDS = the float copy of the queries is staged in LDS
@@ -415,7 +424,7 @@ __global__ __launch_bounds__(kVerifyMaxThreads, 6) void k_verify(VerifyParams P)
     unsigned long long lpa_[kProfWords] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     K.lp = lpa_;
 #endif
-    if (LEAN) { if (QLDS) stage_queries_f(P.qsoa, const_cast<float*>(LL.qx), 3u * n_pad); }
+    if (LEAN) { if (QLDS && !TILED) stage_queries_f(P.qsoa, const_cast<float*>(LL.qx), 3u * n_pad); }
     else if (QLDS) stage_queries(K, s_q);
     stage_coarse(P.grid, s_coarse);                        // ends with a workgroup barrier
     PROF_STAMP(1);
@@ -427,6 +436,110 @@ __global__ __launch_bounds__(kVerifyMaxThreads, 6) void k_verify(VerifyParams P)
     // statement), the candidate's bookkeeping afterwards is done by all lanes with identical values.  With `if (lane == 0)` regions on both sides of the loop's back edge the compiler threaded lane 0's
     // path through the edge and re-entered the loop with lanes 1..63 alone -- readfirstlane then read THEIR (zero) ticket: the
     // group build hung on the device (round 5; the breadcrumb build that perturbed the code did not).
+    // a scored candidate: its count into the per-quad array, into the border list (undecided gate) or into the wave's best of its base
+    auto commit = [&](const uint32_t bsel, const uint32_t li, const float4 rr, const uint32_t cnt) {
+      const VerifyBase& B = P.b[bsel];
+      { // (round 6: the record's last row stays in registers across the sweep -- re-reading it was a global round trip per candidate)
+        const uint32_t i = P.use_surv ? uint32_t(__builtin_amdgcn_readfirstlane(int(__float_as_uint(rr.w)))) : li;      // the candidate's index in the gated list
+        const uint32_t kraw = uint32_t(__builtin_amdgcn_readfirstlane(int(__float_as_uint(rr.z)))), k = kraw & ~kBorderFlag;
+        const unsigned long long tag = (unsigned long long)uint32_t(__builtin_amdgcn_readfirstlane(int(__float_as_uint(rr.x)))) |
+                                       ((unsigned long long)uint32_t(__builtin_amdgcn_readfirstlane(int(__float_as_uint(rr.y)))) << 32);
+        B.counts[k] = cnt;                                   // (every lane, same address, same value)
+        if (kraw & kBorderFlag) {                            // (uniform) scored, but the host decides whether it is a candidate at all
+          uint32_t n = 0;
+          if (lane == 0) n = atomicAdd(&B.ctr->n_border, 1u);
+          n = uint32_t(__builtin_amdgcn_readfirstlane(int(n)));
+          if (n < kBorderCap) B.border[n] = i;
+        } else {
+          const uint32_t oc = uint32_t(__builtin_amdgcn_readfirstlane(int(S.wcnt[bsel][wave]))), oi = uint32_t(__builtin_amdgcn_readfirstlane(int(S.wcand[bsel][wave])));
+          const unsigned long long ot = S.wtag[bsel][wave];
+          const unsigned long long otu = (unsigned long long)uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(ot)))) | ((unsigned long long)uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(ot >> 32)))) << 32);
+          if (slot_better(cnt, tag, oc, otu, oi != kNil)) { S.wcnt[bsel][wave] = cnt; S.wtag[bsel][wave] = tag; S.wcand[bsel][wave] = i; }   // (uniform)
+        }
+      }
+    };
+    if constexpr (TILED) {
+      // ROUNDS: every wave holds one candidate of the workgroup's share, the tiles pass through LDS in lockstep, twice:
+      //   pass A (all tiles): the candidate's L0 survivors per tile (the same sweep, counting only).  Their sum over the tiles NOT
+      //     YET SCORED is what those can still add: against "every query of the later tiles" it dismisses a survivor of k_sweep
+      //     after a tile or two of pass B instead of after nine of ten (measured with the weaker bound: ~430 us per survivor and
+      //     wave, ten tiles of drains);
+      //   pass B (until no wave of the workgroup has a live candidate): count, remember, fill, drain, exact batches on the tile,
+      //     bound = confirmed + this tile's pending + pass A's counts of the tiles still to come.
+      // Pass A is worth its sweeps only when the bound has teeth: against a best of a few per cent of the sample (the first bases of
+      // a registration) nearly every candidate runs through all its tiles anyway, and "every query of the tiles to come" is used.
+      // (A carousel -- every wave its own candidate and pass, synchronised only on the tile in LDS -- was measured slower: the cheap
+      // pass-A steps of one wave wait for the drains of another's pass B at every tile.)
+      const bool per_tile = P.n_tiles <= uint32_t(kVerifyMaxTiles) && P.prune * 10u >= P.n_q;
+      auto stage_tile = [&](const uint32_t tile) {             // (all threads, between barriers)
+        const float4* tsrc = reinterpret_cast<const float4*>(P.qtiles + size_t(tile) * 3u * P.tile_q);
+        float4* tdst = reinterpret_cast<float4*>(const_cast<float*>(LL.qx));
+        for (uint32_t w = threadIdx.x; w < (3u * P.tile_q) >> 2; w += blockDim.x) tdst[w] = tsrc[w];
+      };
+      auto queries_in = [&](const uint32_t tile) { const uint32_t first = tile * P.tile_q; return first < P.n_q ? min(P.tile_q, P.n_q - first) : 0u; };
+      const uint32_t n_waves = blockDim.x >> 6, rounds = (hi + n_waves - 1u) / n_waves;
+      const uint32_t wv = uint32_t(__builtin_amdgcn_readfirstlane(int(wave)));
+      for (uint32_t r = 0; r < rounds; ++r) {                 // (uniform over the workgroup: the tile staging is a workgroup affair)
+        const uint32_t t = r * n_waves + wv;
+        const bool valid = t < hi;                            // (wave-uniform)
+        uint32_t bsel = 0u, li = 0u;
+        { uint32_t bs = 0u, t0 = 0u;
+          const uint32_t tt = valid ? t : 0u;
+#pragma unroll
+          for (int b = 1; b < kGroupMax; ++b) { const uint32_t e = S.end[b - 1]; if (tt >= e) { bs = uint32_t(b); t0 = e; } }
+          bsel = uint32_t(__builtin_amdgcn_readfirstlane(int(bs))); t0 = uint32_t(__builtin_amdgcn_readfirstlane(int(t0)));
+          li = blockIdx.x + (tt - t0) * gridDim.x; }
+        const VerifyBase& B = P.b[bsel];
+        const float4* src = (P.use_surv ? B.surv_T : B.cand_T) + kCandStride * size_t(valid ? li : 0u);
+        const float4 r0 = src[0], r1 = src[1], r2 = src[2], r3 = src[3];
+        uint32_t later = 0u;
+        if (per_tile) {
+          for (uint32_t tile = 0; tile < P.n_tiles; ++tile) {   // uniform
+            __syncthreads();
+            stage_tile(tile);
+            __syncthreads();
+            const uint32_t in_tile = queries_in(tile);
+            uint32_t h = 0u;
+            if (valid && in_tile != 0u) {
+              LcpTask Kc = K;
+              Kc.n_q = in_tile; Kc.prune = 0u; Kc.pruned = nullptr; Kc.l0_only = 1u;
+              h = wave_lcp_count_lean<COUNT, false, true>(P.grid, Kc, LL, src, r0, r1, r2);
+            }
+            S.l0t[wave][tile] = uint16_t(h);                    // (every lane, same value)
+            later += h;
+          }
+        } else {
+          later = P.n_q;
+        }
+        uint32_t cnt = 0u;
+        bool alive = valid, was_abandoned = false;
+        if (alive && later <= P.prune) { alive = false; was_abandoned = true; }      // (the coarse count alone: cannot exceed the best)
+        for (uint32_t tile = 0; tile < P.n_tiles; ++tile) {   // uniform
+          if (__syncthreads_or(alive ? 1 : 0) == 0) break;      // (uniform) nobody in the workgroup has a live candidate any more
+          stage_tile(tile);
+          __syncthreads();
+          const uint32_t in_tile = queries_in(tile);
+          if (alive && in_tile != 0u) {                       // (wave-uniform)
+            later -= per_tile ? uint32_t(S.l0t[wave][tile]) : in_tile;
+            LcpTask Kt = K;
+            Kt.n_q = in_tile; Kt.point_tests = &B.ctr->point_tests; Kt.pruned = nullptr;
+            // "cannot exceed the best" for this tile: its pending entries may still add at most prune - confirmed - (what the tiles
+            // to come can add); while that is negative the candidate cannot be dismissed yet and the tile is simply counted
+            const bool bounded = P.prune >= cnt + later;
+            Kt.prune = bounded ? P.prune - cnt - later : 0u;
+            bool dead = false;
+            cnt += P.ablate == 1 ? wave_lcp_count_lean<COUNT, true, true>(P.grid, Kt, LL, src, r0, r1, r2, &dead)
+                                 : wave_lcp_count_lean<COUNT, false, true>(P.grid, Kt, LL, src, r0, r1, r2, &dead);
+            if (bounded && dead) { alive = false; was_abandoned = true; }
+          }
+        }
+        if (valid) {
+          if (was_abandoned && lane == 0) atomicAdd(&S.pruned[bsel], 1u);
+          commit(bsel, li, r3, cnt);
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    } else
     while (true) {
       const uint32_t t = wave_ticket(&s_next);
       if (t >= hi) break;
@@ -447,25 +560,7 @@ __global__ __launch_bounds__(kVerifyMaxThreads, 6) void k_verify(VerifyParams P)
       if (LEAN) cnt = P.ablate == 1 ? wave_lcp_count_lean<COUNT, true, QLDS>(P.grid, K, LL, src, r0, r1, r2) : wave_lcp_count_lean<COUNT, false, QLDS>(P.grid, K, LL, src, r0, r1, r2);
       else cnt = P.ablate == 1 ? wave_lcp_count_auto<COUNT, true, QLDS>(P.grid, K, s_coarse, s_q, s_queue, src)
                                : wave_lcp_count_auto<COUNT, false, QLDS>(P.grid, K, s_coarse, s_q, s_queue, src);
-      { // (round 6: the record's last row stays in registers across the sweep -- re-reading it was a global round trip per candidate)
-        const float4 rr = r3;
-        const uint32_t i = P.use_surv ? uint32_t(__builtin_amdgcn_readfirstlane(int(__float_as_uint(rr.w)))) : li;      // the candidate's index in the gated list
-        const uint32_t kraw = uint32_t(__builtin_amdgcn_readfirstlane(int(__float_as_uint(rr.z)))), k = kraw & ~kBorderFlag;
-        const unsigned long long tag = (unsigned long long)uint32_t(__builtin_amdgcn_readfirstlane(int(__float_as_uint(rr.x)))) |
-                                       ((unsigned long long)uint32_t(__builtin_amdgcn_readfirstlane(int(__float_as_uint(rr.y)))) << 32);
-        B.counts[k] = cnt;                                   // (every lane, same address, same value)
-        if (kraw & kBorderFlag) {                            // (uniform) scored, but the host decides whether it is a candidate at all
-          uint32_t n = 0;
-          if (lane == 0) n = atomicAdd(&B.ctr->n_border, 1u);
-          n = uint32_t(__builtin_amdgcn_readfirstlane(int(n)));
-          if (n < kBorderCap) B.border[n] = i;
-        } else {
-          const uint32_t oc = uint32_t(__builtin_amdgcn_readfirstlane(int(S.wcnt[bsel][wave]))), oi = uint32_t(__builtin_amdgcn_readfirstlane(int(S.wcand[bsel][wave])));
-          const unsigned long long ot = S.wtag[bsel][wave];
-          const unsigned long long otu = (unsigned long long)uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(ot)))) | ((unsigned long long)uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(ot >> 32)))) << 32);
-          if (slot_better(cnt, tag, oc, otu, oi != kNil)) { S.wcnt[bsel][wave] = cnt; S.wtag[bsel][wave] = tag; S.wcand[bsel][wave] = i; }   // (uniform)
-        }
-      }
+      commit(bsel, li, r3, cnt);
       __builtin_amdgcn_wave_barrier();
 #if defined(S4P_PROF)
       { __builtin_amdgcn_s_waitcnt(0); const unsigned long long d_ = __builtin_amdgcn_s_memrealtime() - tc0_;

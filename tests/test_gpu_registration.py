@@ -741,7 +741,7 @@ def test_the_sweep_pass_changes_no_result(oracle_mod, s4p_lib_built, monkeypatch
     g_lcp, g_M, g_Q = gm.compute_transformation(P, Q)
     os_, gi = om.stats(), gm.info()
     if n_s > 2000:
-        assert gi.n_sampled_q > 2560 and "queries from global memory" in gm.verify_kernel_info()
+        assert gi.n_sampled_q > 2560 and "query tiles through LDS" in gm.verify_kernel_info()
     assert (gi.pairs_total, gi.quads_total, gi.candidates_verified) == (os_.n_pairs, os_.n_quads, os_.n_verified)
     assert g_lcp == o_lcp and np.array_equal(g_M, o_M) and np.max(np.abs(g_Q - o_Q)) <= 1e-4
     assert gm.profile_get().verify_pruned > 0.3 * gi.candidates_verified
