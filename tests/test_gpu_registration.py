@@ -709,8 +709,9 @@ def test_a_device_pass_that_stalls_is_an_error_not_a_hang(s4p_lib_built, monkeyp
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("force,n_s,max_angle,own_bitmap", [("1", 300, -1.0, True), ("1", 250, 30.0, True), (None, 2700, -1.0, True), (None, 2700, -1.0, False)])
-def test_the_sweep_pass_changes_no_result(oracle_mod, s4p_lib_built, monkeypatch, force, n_s, max_angle, own_bitmap):
+@pytest.mark.parametrize("force,n_s,max_angle,own_bitmap,tiled", [("1", 300, -1.0, True, True), ("1", 250, 30.0, True, True), (None, 2700, -1.0, True, True),
+                                                                   (None, 2700, -1.0, False, True), (None, 2700, -1.0, True, False)])
+def test_the_sweep_pass_changes_no_result(oracle_mod, s4p_lib_built, monkeypatch, force, n_s, max_angle, own_bitmap, tiled):
     """Round 6: with an early-exit bound in force k_sweep counts, for every gated candidate, the sampled-Q points whose coarse
     cube is marked under its transform -- an upper bound of its inlier count -- and only the candidates whose bound exceeds the
     registration's best go on to k_verify (samples that do not fit LDS by default; S4P_SWEEP_PASS=1 forces the pass for any
@@ -718,12 +719,16 @@ def test_the_sweep_pass_changes_no_result(oracle_mod, s4p_lib_built, monkeypatch
     whatever their count), and on a sample of several LDS tiles (2700 points: two tiles): the registration is the oracle's --
     LCP, 4x4, transformed cloud, totals -- and the pass really abandons candidates.  The pass indexes a bitmap of its own, as fine
     as a workgroup with a CU to itself can hold (k_sweep_bitmap; the block's four transforms by one MFMA per 16 queries);
-    S4P_SWEEP_COARSE=1 makes it use k_verify's coarse bitmap instead: the same registration either way."""
+    S4P_SWEEP_COARSE=1 makes it use k_verify's coarse bitmap instead: the same registration either way.  The survivors of a sample
+    beyond LDS are scored through LDS tiles in rounds (k_verify<., true, true, true>: L0 survivors per tile first, then the lean sweep
+    per tile against "confirmed + pending + the tiles to come"); S4P_VERIFY_TILED=0 keeps round 5's form: the same registration."""
     from super4pcs_amd import capi
     if force is not None:
         monkeypatch.setenv("S4P_SWEEP_PASS", force)
     if not own_bitmap:
         monkeypatch.setenv("S4P_SWEEP_COARSE", "1")
+    if not tiled:
+        monkeypatch.setenv("S4P_VERIFY_TILED", "0")             # the survivors scored with the queries from global memory (round 5's form)
     if max_angle >= 0:
         monkeypatch.setenv("S4P_ANGLE_TOL", "0.02")             # many candidates with an undecided gate
     delta, overlap = 0.01, 0.6
@@ -741,7 +746,7 @@ def test_the_sweep_pass_changes_no_result(oracle_mod, s4p_lib_built, monkeypatch
     g_lcp, g_M, g_Q = gm.compute_transformation(P, Q)
     os_, gi = om.stats(), gm.info()
     if n_s > 2000:
-        assert gi.n_sampled_q > 2560 and "query tiles through LDS" in gm.verify_kernel_info()
+        assert gi.n_sampled_q > 2560 and ("query tiles through LDS" if tiled else "queries from global memory") in gm.verify_kernel_info()
     assert (gi.pairs_total, gi.quads_total, gi.candidates_verified) == (os_.n_pairs, os_.n_quads, os_.n_verified)
     assert g_lcp == o_lcp and np.array_equal(g_M, o_M) and np.max(np.abs(g_Q - o_Q)) <= 1e-4
     assert gm.profile_get().verify_pruned > 0.3 * gi.candidates_verified
