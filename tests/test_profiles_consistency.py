@@ -63,10 +63,11 @@ def test_the_committed_bench_line_names_the_code_that_produced_it():
         assert (o["git_sha"], o["source_sha16"], o["k_verify"]) == (sha, prov["source_sha16"], prov["k_verify"])
     inst = re.search(r"k_verify<[a-z, ]+>", prov["k_verify"]).group(0)              # the instantiation of the timed loop
     names = [r["Name"] for r in csv.DictReader(open(os.path.join(P, R + "_kernel_stats_bench_final.csv")))]
-    assert any(inst.replace(" ", "") in n.replace(" ", "") for n in names), (inst, names[:6])
+    inst = inst.replace(" ", "").rstrip(">")                   # (round 6: k_verify has a fourth, defaulted template parameter -- TILED -- the line does not spell out)
+    assert any(inst in n.replace(" ", "") for n in names), (inst, names[:6])
     rows = [r for f in os.listdir(os.path.join(P, R + "_bench_final")) if f.startswith("pmc_")
             for r in csv.DictReader(open(os.path.join(P, R + "_bench_final", f)))]
-    assert rows and all(inst.replace(" ", "") in r["Kernel_Name"].replace(" ", "") for r in rows[-10:])
+    assert rows and all(inst in r["Kernel_Name"].replace(" ", "") for r in rows[-10:])
 
 
 def test_the_shipped_sources_are_the_measured_ones_and_the_hot_kernels_kept_their_instructions(s4p_lib_built):
