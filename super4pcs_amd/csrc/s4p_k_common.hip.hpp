@@ -216,6 +216,16 @@ __device__ __forceinline__ uint32_t dot2_u16_s(uint32_t a, uint32_t k_uniform, u
   asm("v_dot2_u32_u16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(k_uniform), "v"(c));
   return r;
 }
+// inclusive prefix sum over the wave on the DPP pipe: row_shr 1, 2, 4, 8 inside the rows of 16 lanes, then row_bcast 15 and 31
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
+  v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x111, 0xf, 0xf, false));
+  v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x112, 0xf, 0xf, false));
+  v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x114, 0xf, 0xf, false));
+  v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x118, 0xf, 0xf, false));
+  v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x142, 0xa, 0xf, false));
+  v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x143, 0xc, 0xf, false));
+  return v;
+}
 // floor(x) as an integer in one instruction (V_CVT_FLR_I32_F32; the compiler only emits v_floor + v_cvt)
 __device__ __forceinline__ int floor_to_int(float x) {
   int i;

@@ -34,9 +34,13 @@ __device__ __forceinline__ uint32_t hash_cell(uint32_t c) {
   return c;
 }
 
+// (round 6) A cell's set-1 pairs hang on kSubChains chains, not on one: an entry goes to chain (entry index mod kSubChains), and
+// k_quads walks the chains of a cell as separate work items.  The walk is one dependent round trip per hop and a workgroup of
+// k_quads waits for its longest walk: with one chain per cell that was ~50 hops (~35 us of the kernel's 52 alone).
+constexpr uint32_t kSubChains = 4;
 struct HashTable {
   unsigned long long* keys;    // (epoch << 32) | cell
-  unsigned long long* heads;   // (epoch << 32) | entry index
+  unsigned long long* heads;   // kSubChains per slot: (epoch << 32) | entry index
   uint32_t mask;               // allocated size - 1 (power of two; sized for the pair capacity: 128 MB + 128 MB at 8 M pairs)
   uint32_t epoch;
   const uint32_t* m1_dev;      // device count of the set-1 pairs of this base (final when k_prep / k_quads run)
@@ -97,7 +101,7 @@ __device__ __forceinline__ void prep1_item(const PrepParams& P, const uint32_t e
     }
     h = (h + 1u) & hmask;
   }
-  const unsigned long long prev = atomicExch(&P.ht.heads[h], ((unsigned long long)P.ht.epoch << 32) | e);
+  const unsigned long long prev = atomicExch(&P.ht.heads[size_t(h) * kSubChains + (e & (kSubChains - 1u))], ((unsigned long long)P.ht.epoch << 32) | e);
   P.next[e] = (uint32_t(prev >> 32) == P.ht.epoch) ? uint32_t(prev) : kNil;
 }
 

@@ -112,8 +112,12 @@ __global__ __launch_bounds__(kQuadThreads) void k_quads(QuadGroup QG) {
   __shared__ unsigned long long st_t[kQuadStage];
   __shared__ unsigned long long st_base, s_qsum, s_csum;
   __shared__ uint32_t st_n, s_wc[kQuadWaves], s_cbase, s_ic[kQuadWaves];
-  __shared__ uint32_t s_item_i[kQuadThreads], s_item_e[kQuadThreads];        // the tile's pairs whose cell holds a set-1 pair, compacted
-  __shared__ uint32_t s_mask[kQuadThreads * kMaskWords];   // each thread's direction mask (row stride 11: conflict-free)
+  __shared__ uint32_t s_pair_i[kQuadThreads];                // the tile's pairs whose cell holds set-1 pairs, compacted: pair slot -> index of the pair
+  __shared__ uint32_t s_item_p[kQuadThreads * kSubChains], s_item_e[kQuadThreads * kSubChains];      // work items: (pair slot, head of ONE of its cell's chains)
+  __shared__ float4 s_eq[kQuadThreads];                      // per pair slot: the world point of the pair's invariant point,
+  __shared__ int2 s_ab2[kQuadThreads];                       // ... its two point ids
+  __shared__ uint32_t s_ok2[kQuadThreads], s_pc[kQuadWaves]; // ... its order key; pairs with a chain per wave (s_ic: items per wave)
+  __shared__ uint32_t s_mask[kQuadThreads * kMaskWords];   // each pair slot's direction mask (row stride 11: conflict-free)
   const uint32_t m2 = min(*P.m2_dev, P.cap2);
   const uint32_t begin = P.r0, end = min(m2, P.r1);
   const uint32_t hmask = hash_mask(P.ht);
@@ -127,12 +131,16 @@ __global__ __launch_bounds__(kQuadThreads) void k_quads(QuadGroup QG) {
     unsigned long long pa_, pb_, pc_, pd_, pe_;
     PROF_NOW(pa_);
 #endif
-    // phase A, one thread per set-2 pair of the tile: invariant point -> cell -> head of the cell's set-1 chain (super4pcs.cc:141,
+    // phase A, one thread per set-2 pair of the tile: invariant point -> cell -> the heads of the cell's set-1 chains (super4pcs.cc:141,
     // normalset.hpp:162-171).  Typically well under half of the pairs fall into a cell that holds a set-1 pair; those are
-    // compacted (ballot + per-wave offsets) so that the expensive part below runs on DENSE waves.
+    // compacted (pair slots), and every non-empty chain of their cells becomes a WORK ITEM of its own (round 6: kSubChains chains
+    // per cell, so that a cell with fifty pairs is four walks of a dozen hops on four threads instead of one of fifty).
+    uint32_t n_pairs = 0, n_items = 0;
     {
       const uint32_t i = i0 + threadIdx.x;
-      uint32_t e = kNil;
+      uint32_t he[kSubChains], cnt = 0u;
+#pragma unroll
+      for (uint32_t sc = 0; sc < kSubChains; ++sc) he[sc] = kNil;
       // A share of the set (one GPU's part of a base) is defined on the pairs' ORDER KEYS, not on their positions: the
       // position of a pair in the list is whatever the appends of k_pairs made it on this device, its key is the same everywhere.
       if (i < end && (P.slice_den == 0u || P.okey2[i] % P.slice_den == P.slice_num)) {
@@ -145,45 +153,64 @@ __global__ __launch_bounds__(kQuadThreads) void k_quads(QuadGroup QG) {
         uint32_t h = hash_cell(cell) & hmask;
         while (true) {
           const unsigned long long k = P.ht.keys[h];
-          if (k == mykey) { const unsigned long long hd = P.ht.heads[h]; e = (uint32_t(hd >> 32) == P.ht.epoch) ? uint32_t(hd) : kNil; break; }
+          if (k == mykey) {
+            const ulonglong2* hp = reinterpret_cast<const ulonglong2*>(P.ht.heads + size_t(h) * kSubChains);      // (32 bytes: one segment)
+            const ulonglong2 h01 = hp[0], h23 = hp[1];
+            const unsigned long long hd[kSubChains] = {h01.x, h01.y, h23.x, h23.y};
+#pragma unroll
+            for (uint32_t sc = 0; sc < kSubChains; ++sc)
+              if (uint32_t(hd[sc] >> 32) == P.ht.epoch) { he[sc] = uint32_t(hd[sc]); ++cnt; }
+            break;
+          }
           if (uint32_t(k >> 32) != P.ht.epoch) break;
           h = (h + 1u) & hmask;
         }
       }
-      const unsigned long long m = __ballot(e != kNil);
-      if (lane == 0) s_ic[wave] = uint32_t(__popcll(m));
+      const unsigned long long m = __ballot(cnt != 0u);
+      const uint32_t incl = wave_incl_scan_u32(cnt);
+      if (lane == 63u) s_ic[wave] = incl;
+      if (lane == 0) s_pc[wave] = uint32_t(__popcll(m));
       __syncthreads();
-      uint32_t before = 0;
-      for (uint32_t w = 0; w < wave; ++w) before += s_ic[w];
-      if (e != kNil) {
-        const uint32_t at = before + __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u));
-        s_item_i[at] = i; s_item_e[at] = e;
+      uint32_t pbefore = 0, ibefore = 0;
+      for (uint32_t w = 0; w < wave; ++w) { pbefore += s_pc[w]; ibefore += s_ic[w]; }
+      if (cnt != 0u) {
+        const uint32_t slot = pbefore + __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u));
+        s_pair_i[slot] = i;
+        uint32_t at = ibefore + incl - cnt;
+#pragma unroll
+        for (uint32_t sc = 0; sc < kSubChains; ++sc)
+          if (he[sc] != kNil) { s_item_p[at] = slot; s_item_e[at] = he[sc]; ++at; }
       }
       __syncthreads();
-    }
-    uint32_t n_items = 0;
 #pragma unroll
-    for (int w = 0; w < kQuadWaves; ++w) n_items += s_ic[w];
+      for (int w = 0; w < kQuadWaves; ++w) { n_pairs += s_pc[w]; n_items += s_ic[w]; }
+    }
     PROF_NOW(pb_);
     uint32_t hops_ = 0; (void)hops_;
-    if (threadIdx.x < n_items) {
+    if (threadIdx.x < n_pairs) {
       // phase B, one thread per pair with a chain: world point (super4pcs.cc:142) and the cone mask of its direction
-      // (normalset.hpp:174-196) into the thread's LDS row -- what a separate preparation launch used to do for EVERY pair
-      const uint32_t i = s_item_i[threadIdx.x];
-      uint32_t e = s_item_e[threadIdx.x];
+      // (normalset.hpp:174-196) into the pair slot's LDS row -- what a separate preparation launch used to do for EVERY pair
+      const uint32_t i = s_pair_i[threadIdx.x];
       const int2 ab2 = P.ab2[i];
-      const uint32_t ok2 = P.okey2[i];
-      uint32_t* row = s_mask + threadIdx.x * kMaskWords;
-      float4 eq;
-      { const float p1x = P.ux[ab2.x], p1y = P.uy[ab2.x], p1z = P.uz[ab2.x];
-        const float p2x = P.ux[ab2.y], p2y = P.uy[ab2.y], p2z = P.uz[ab2.y];
-        const float w1x = P.qx[ab2.x], w1y = P.qy[ab2.x], w1z = P.qz[ab2.x];
-        const float w2x = P.qx[ab2.y], w2y = P.qy[ab2.y], w2z = P.qz[ab2.y];
-        eq = make_float4(w1x + P.invariant2 * (w2x - w1x), w1y + P.invariant2 * (w2y - w1y), w1z + P.invariant2 * (w2z - w1z), 0.f);
-        cone_mask_row(P.cone, P.qg.nepsilon, p2x - p1x, p2y - p1y, p2z - p1z, row); }
-      PROF_NOW(pc_);
-      // phase C: the walk is a chain of dependent gathers (one set-1 pair per hop), so each hop is ONE round trip: the hop's
-      // direction bucket, world point and successor are requested together; the bucket test reads the LDS row.
+      const float p1x = P.ux[ab2.x], p1y = P.uy[ab2.x], p1z = P.uz[ab2.x];
+      const float p2x = P.ux[ab2.y], p2y = P.uy[ab2.y], p2z = P.uz[ab2.y];
+      const float w1x = P.qx[ab2.x], w1y = P.qy[ab2.x], w1z = P.qz[ab2.x];
+      const float w2x = P.qx[ab2.y], w2y = P.qy[ab2.y], w2z = P.qz[ab2.y];
+      s_eq[threadIdx.x] = make_float4(w1x + P.invariant2 * (w2x - w1x), w1y + P.invariant2 * (w2y - w1y), w1z + P.invariant2 * (w2z - w1z), 0.f);
+      s_ab2[threadIdx.x] = ab2; s_ok2[threadIdx.x] = P.okey2[i];
+      cone_mask_row(P.cone, P.qg.nepsilon, p2x - p1x, p2y - p1y, p2z - p1z, s_mask + threadIdx.x * kMaskWords);
+    }
+    PROF_NOW(pc_);
+    __syncthreads();                                           // (the items of a pair are walked by other threads than the one that prepared it)
+    // phase C: the walk is a chain of dependent gathers (one set-1 pair per hop), so each hop is ONE round trip: the hop's
+    // direction bucket, world point and successor are requested together; the bucket test reads the pair slot's LDS row.
+    for (uint32_t it = threadIdx.x; it < n_items; it += blockDim.x) {
+      const uint32_t ps = s_item_p[it];
+      uint32_t e = s_item_e[it];
+      const uint32_t* row = s_mask + ps * kMaskWords;
+      const float4 eq = s_eq[ps];
+      const int2 ab2 = s_ab2[ps];
+      const uint32_t ok2 = s_ok2[ps];
       while (e != kNil) {
         const uint32_t b = P.bucket1[e];
         const float4 ep = P.ew1[e];
@@ -214,9 +241,6 @@ __global__ __launch_bounds__(kQuadThreads) void k_quads(QuadGroup QG) {
         e = nxt; ++hops_;
       }
     }
-#if defined(S4P_PROF)
-    else { pc_ = pb_; }
-#endif
     PROF_NOW(pd_);
     __syncthreads();
     const uint32_t n = min(st_n, uint32_t(kQuadStage));
