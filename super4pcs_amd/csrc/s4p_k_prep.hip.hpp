@@ -131,7 +131,7 @@ __device__ __forceinline__ void quat_from_z_to(float nx, float ny, float nz, flo
 
 // The 343-bit cone mask of one set-2 pair (getNeighbors, normalset.hpp:174-196): the direction buckets hit by the nb cone
 // samples rotated onto the pair's direction (nx, ny, nz: p2 - p1 in unit coordinates, not normalised), OR-ed into the
-// caller's private row of kMaskWords words (zeroed here).
+// caller's row of kMaskWords words (zeroed by the caller; bits are set by LDS atomics, so several threads may share a row).
 // Only the BUCKET of a rotated, normalised cone sample is needed: int((x / 2 + 0.5) / neps) per axis.  The exact
 // sequence -- the quaternion product as Eigen writes it, a square root and six correctly rounded divisions -- is ~150
 // instructions per sample.  The fast path rotates with the quaternion's 3x3 matrix (9 fma; equal to the exact product
@@ -139,7 +139,8 @@ __device__ __forceinline__ void quat_from_z_to(float nx, float ny, float nz, flo
 // | |d|^2 - 1 | < 1e-4 its bucket coordinates differ from the exact ones by < 2e-4 (measured < 2e-5,
 // tests/test_prep_bucket_fast_path.py), so if every coordinate lies further than 4e-4 from an integer the truncations
 // agree; otherwise (0.2 % of the samples) the exact sequence runs.
-__device__ __forceinline__ void cone_mask_row(const ConeTable& cone, const float nepsilon, float nx, float ny, float nz, uint32_t* row) {
+// (round 6) The caller zeroes the row; samples a0, a0 + astep, ... are this thread's share: k_quads gives a pair to 1, 2 or 4 threads.
+__device__ __forceinline__ void cone_mask_row(const ConeTable& cone, const float nepsilon, float nx, float ny, float nz, uint32_t* row, const int a0 = 0, const int astep = 1) {
   float q[4];
   normalize3(nx, ny, nz);                             // queryn = (p2-p1).normalized()            super4pcs.cc:144
   quat_from_z_to(nx, ny, nz, q);                      // setFromTwoVectors normalises it again    normalset.hpp:181
@@ -150,13 +151,11 @@ __device__ __forceinline__ void cone_mask_row(const ConeTable& cone, const float
     R[0] = 1.f - 2.f * (yy + zz); R[1] = 2.f * (xy - wz); R[2] = 2.f * (xz + wy);
     R[3] = 2.f * (xy + wz); R[4] = 1.f - 2.f * (xx + zz); R[5] = 2.f * (yz - wx);
     R[6] = 2.f * (xz - wy); R[7] = 2.f * (yz + wx); R[8] = 1.f - 2.f * (xx + yy); }
-#pragma unroll
-  for (int w = 0; w < kMaskWords; ++w) row[w] = 0u;
   // (round 6: four samples per trip, independent chains for a wave that is alone on its SIMD; the row's bits are set by LDS
   // atomics without a return value -- a read-modify-write per sample was a dependent LDS round trip per sample: phase B of
   // k_quads 11-15 us of a workgroup's ~45, profiles/r06_wave_profile.txt)
 #pragma unroll 4
-  for (int a = 0; a < cone.nb; ++a) {
+  for (int a = a0; a < cone.nb; a += astep) {
     const float vx = cone.v[a][0], vy = cone.v[a][1], vz = cone.v[a][2];
     const float fx = __builtin_fmaf(R[0], vx, __builtin_fmaf(R[1], vy, R[2] * vz)), fy = __builtin_fmaf(R[3], vx, __builtin_fmaf(R[4], vy, R[5] * vz)),
                 fz = __builtin_fmaf(R[6], vx, __builtin_fmaf(R[7], vy, R[8] * vz));

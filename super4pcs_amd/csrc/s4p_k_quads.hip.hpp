@@ -187,18 +187,28 @@ __global__ __launch_bounds__(kQuadThreads) void k_quads(QuadGroup QG) {
     }
     PROF_NOW(pb_);
     uint32_t hops_ = 0; (void)hops_;
-    if (threadIdx.x < n_pairs) {
-      // phase B, one thread per pair with a chain: world point (super4pcs.cc:142) and the cone mask of its direction
-      // (normalset.hpp:174-196) into the pair slot's LDS row -- what a separate preparation launch used to do for EVERY pair
-      const uint32_t i = s_pair_i[threadIdx.x];
-      const int2 ab2 = P.ab2[i];
-      const float p1x = P.ux[ab2.x], p1y = P.uy[ab2.x], p1z = P.uz[ab2.x];
-      const float p2x = P.ux[ab2.y], p2y = P.uy[ab2.y], p2z = P.uz[ab2.y];
-      const float w1x = P.qx[ab2.x], w1y = P.qy[ab2.x], w1z = P.qz[ab2.x];
-      const float w2x = P.qx[ab2.y], w2y = P.qy[ab2.y], w2z = P.qz[ab2.y];
-      s_eq[threadIdx.x] = make_float4(w1x + P.invariant2 * (w2x - w1x), w1y + P.invariant2 * (w2y - w1y), w1z + P.invariant2 * (w2z - w1z), 0.f);
-      s_ab2[threadIdx.x] = ab2; s_ok2[threadIdx.x] = P.okey2[i];
-      cone_mask_row(P.cone, P.qg.nepsilon, p2x - p1x, p2y - p1y, p2z - p1z, s_mask + threadIdx.x * kMaskWords);
+    // phase B, per pair with a chain: world point (super4pcs.cc:142) and the cone mask of its direction (normalset.hpp:174-196) into
+    // the pair slot's LDS row -- what a separate preparation launch used to do for EVERY pair.  The 56 cone samples of a pair are
+    // the phase's cost (~10 us for one thread) and the pairs with a chain rarely fill the workgroup: a pair gets 1, 2 or 4 threads
+    // (uniform per tile), each a share of the samples, all setting bits of the same row by LDS atomics.
+    for (uint32_t w = threadIdx.x; w < n_pairs * uint32_t(kMaskWords); w += blockDim.x) s_mask[w] = 0u;
+    __syncthreads();
+    {
+      const uint32_t tpp = n_pairs * 4u <= blockDim.x ? 4u : (n_pairs * 2u <= blockDim.x ? 2u : 1u);      // threads per pair
+      const uint32_t ps = threadIdx.x / tpp, part = threadIdx.x % tpp;
+      if (ps < n_pairs) {
+        const uint32_t i = s_pair_i[ps];
+        const int2 ab2 = P.ab2[i];
+        const float p1x = P.ux[ab2.x], p1y = P.uy[ab2.x], p1z = P.uz[ab2.x];
+        const float p2x = P.ux[ab2.y], p2y = P.uy[ab2.y], p2z = P.uz[ab2.y];
+        if (part == 0u) {
+          const float w1x = P.qx[ab2.x], w1y = P.qy[ab2.x], w1z = P.qz[ab2.x];
+          const float w2x = P.qx[ab2.y], w2y = P.qy[ab2.y], w2z = P.qz[ab2.y];
+          s_eq[ps] = make_float4(w1x + P.invariant2 * (w2x - w1x), w1y + P.invariant2 * (w2y - w1y), w1z + P.invariant2 * (w2z - w1z), 0.f);
+          s_ab2[ps] = ab2; s_ok2[ps] = P.okey2[i];
+        }
+        cone_mask_row(P.cone, P.qg.nepsilon, p2x - p1x, p2y - p1y, p2z - p1z, s_mask + ps * kMaskWords, int(part), int(tpp));
+      }
     }
     PROF_NOW(pc_);
     __syncthreads();                                           // (the items of a pair are walked by other threads than the one that prepared it)
