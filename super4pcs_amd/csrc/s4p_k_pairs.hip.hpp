@@ -164,12 +164,12 @@ __global__ __launch_bounds__(64 * kPair2Waves) void k_pairs2(PairGroup PG) {
   PROF_DECL;
   PROF_STAMP(0);
   auto wave_fence = [&]() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); };
-  auto write_out = [&](const uint32_t base) {            // entries -> ordered pairs at positions base, base + 1, ...
-    for (uint32_t pe = lane; pe < (ANGLE ? n_st : 2u * n_st); pe += 64u) {
-      const uint32_t e = ANGLE ? pe : pe >> 1, second = ANGLE ? uint32_t(st_f[wave][e]) : pe & 1u;
-      const uint32_t at = base + pe;
+  // pair pe of wave sw's staged entries -> the ordered pair at position `at` (and, for the first set of a fused pass, its preparation)
+  auto write_pair = [&](const uint32_t sw, const uint32_t pe, const uint32_t at) {
+    {
+      const uint32_t e = ANGLE ? pe : pe >> 1, second = ANGLE ? uint32_t(st_f[sw][e]) : pe & 1u;
       if ((ANGLE ? at : (at | 1u)) < P.cap) {              // both pairs of an entry fit, or neither is written
-        const uint32_t w = st_e[wave][e], pId = w & 0xFFFFu, sl = w >> 16;
+        const uint32_t w = st_e[sw][e], pId = w & 0xFFFFu, sl = w >> 16;
         const uint32_t j = P.seq_id[sl] & 0xFFFFu;
         // pairs->emplace_back(j, i) then pairs->emplace_back(i, j)   pairCreationFunctor.h:214-215
         const int2 ab = second ? make_int2(int(pId), int(j)) : make_int2(int(j), int(pId));
@@ -183,6 +183,9 @@ __global__ __launch_bounds__(64 * kPair2Waves) void k_pairs2(PairGroup PG) {
         atomicOr(P.overflow, P.overflow_bit);
       }
     }
+  };
+  auto write_out = [&](const uint32_t base) {            // this wave's entries -> ordered pairs at positions base, base + 1, ...
+    for (uint32_t pe = lane; pe < (ANGLE ? n_st : 2u * n_st); pe += 64u) write_pair(wave, pe, base + pe);
     wave_fence();
   };
   const uint32_t n_tiles = (P.n_q + 63u) >> 6, n_chunks = (P.n_seq + 63u) >> 6;
@@ -308,9 +311,22 @@ __global__ __launch_bounds__(64 * kPair2Waves) void k_pairs2(PairGroup PG) {
   }
   __syncthreads();
   PROF_STAMP(3);
-  uint32_t before = 0;
-  for (uint32_t w = 0; w < wave; ++w) before += s_cnt[w];
-  if (n_st) write_out(s_base + (ANGLE ? before : 2u * before));
+  // (round 6) The leftovers of ALL the workgroup's waves, flattened over all its threads: the waves' shares differ widely (0 .. 190
+  // entries) and a pair of the first set costs its thread a chain of dependent device-scope accesses (prep1_item: probe, CAS,
+  // exchange) -- with every wave writing its own the launch ended with a few waves doing ~6 pairs per lane one after the other
+  // (10-19 us, profiles/r06_wave_profile.txt).  Same positions as before: wave-major, entry order inside a wave.
+  {
+    const uint32_t per = ANGLE ? 1u : 2u;
+    uint32_t tot_pairs = 0;
+#pragma unroll
+    for (int w = 0; w < kPair2Waves; ++w) tot_pairs += per * s_cnt[w];
+    for (uint32_t p = threadIdx.x; p < tot_pairs; p += blockDim.x) {
+      uint32_t sw = 0, start = 0;
+#pragma unroll
+      for (int w = 0; w < kPair2Waves - 1; ++w) { const uint32_t c = per * s_cnt[w]; if (sw == uint32_t(w) && p >= start + c) { start += c; sw = uint32_t(w) + 1u; } }
+      write_pair(sw, p - start, s_base + p);
+    }
+  }
   PROF_STAMP(4);
 #if defined(S4P_PROF)
   tp_[5] = n_st;
