@@ -189,7 +189,10 @@ __global__ __launch_bounds__(64 * kPair2Waves) void k_pairs2(PairGroup PG) {
     wave_fence();
   };
   const uint32_t n_tiles = (P.n_q + 63u) >> 6, n_chunks = (P.n_seq + 63u) >> 6;
-  const uint32_t gw = blockIdx.x * kPair2Waves + wave, nw = gridDim.x * kPair2Waves;
+  // (round 6) consecutive items go to different WORKGROUPS: the heavy items -- a tile and a chunk at the base's distance from each other --
+  // are neighbours, and a workgroup that held eight of them ended the launch writing (and preparing) three pairs per thread while
+  // the others had none; the chunk's gathers a workgroup's waves used to share in cache are a few KB per wave out of L2
+  const uint32_t gw = wave * gridDim.x + blockIdx.x, nw = gridDim.x * kPair2Waves;
   const float r2 = P.nRadius * P.nRadius, e2 = P.eps_unit * P.eps_unit;
   // pre-test bounds on the squared distance: |sqrt(s2) - r| < eps can only hold inside [(r - E)^2, (r + E)^2], E = eps
   // widened by 1e-4 relative + 1e-6 absolute (the exact expression rounds three times at 6e-8 relative each)
